@@ -1,0 +1,81 @@
+"""Seeded synthetic descriptor / keypoint generators for the ComputeMatches hot path.
+
+Shapes follow SURVEY.md section 8(d); nothing here comes from reference code or data.
+
+* ``rootsift_images``  -- "clustered RootSIFT": a shared pool of unit-norm, non-negative
+  prototypes (what FeatureExtraction's L1-root normalisation produces,
+  /root/reference/src/Feature/FeatureExtraction.cpp:260-270) plus per-image jitter, so that
+  the Lowe ratio test, the cross-check and max_distance=0.7 all have something to keep.
+* ``u8_images``        -- integer-valued SIFT-like descriptors, i.i.d. round(clip(|N(0,48^2)|,0,255)),
+  with a planted near-duplicate subset so matches are non-empty (BASELINE configs 4-5).
+* ``keypoints``        -- n x 4 float32 (x, y, size, angle) rows like Database keypoint blobs
+  (/root/reference/src/Database/Database.cpp:114-126).
+"""
+import numpy as np
+
+F32 = np.float32
+
+
+def _l1_root(x):
+    """L1RootNormalized: divide by the L1 norm, then elementwise sqrt -> unit L2 norm."""
+    x = np.abs(x)
+    s = x.sum(axis=1, keepdims=True)
+    s[s == 0] = 1.0
+    return np.sqrt(x / s).astype(F32)
+
+
+def rootsift_images(n_images, n_desc, seed=1234, n_proto=20000, sigma=0.05, overlap=0.5):
+    """List of n_images float32 arrays [n_i, 128] with unit L2 norm, values in [0, 1].
+
+    ``n_desc`` may be an int or a per-image sequence.  Every image draws ``overlap`` of its
+    rows from the shared prototype pool (with jitter sigma on the pre-normalised histogram,
+    relative to its mean) and the rest from fresh random histograms.
+    """
+    rng = np.random.default_rng(seed)
+    if np.isscalar(n_desc):
+        n_desc = [int(n_desc)] * n_images
+    # SIFT-like gradient histograms: sparse-ish non-negative values
+    proto = rng.gamma(shape=0.6, scale=1.0, size=(n_proto, 128)).astype(F32)
+    out = []
+    for i in range(n_images):
+        n = int(n_desc[i])
+        n_shared = min(int(round(n * overlap)), n_proto)
+        pick = rng.choice(n_proto, size=n_shared, replace=False)
+        base = proto[pick]
+        jit = base * (1.0 + sigma * rng.standard_normal(base.shape).astype(F32))
+        fresh = rng.gamma(shape=0.6, scale=1.0, size=(n - n_shared, 128)).astype(F32)
+        d = np.concatenate([jit, fresh], axis=0)
+        d = d[rng.permutation(n)]
+        out.append(np.ascontiguousarray(_l1_root(d)))
+    return out
+
+
+def u8_images(n_images, n_desc, seed=1329, dup_frac=0.05, as_float=True):
+    """Integer-valued descriptors in 0..255 (uint8, or float32 holding the same integers)."""
+    rng = np.random.default_rng(seed)
+    if np.isscalar(n_desc):
+        n_desc = [int(n_desc)] * n_images
+    n_pool = max(int(max(n_desc) * dup_frac), 1)
+    pool = np.clip(np.rint(np.abs(rng.normal(0.0, 48.0, size=(n_pool, 128)))), 0, 255)
+    out = []
+    for i in range(n_images):
+        n = int(n_desc[i])
+        d = np.clip(np.rint(np.abs(rng.normal(0.0, 48.0, size=(n, 128)))), 0, 255)
+        k = min(n_pool, n)
+        rows = rng.choice(n, size=k, replace=False)
+        noise = np.rint(rng.normal(0.0, 2.0, size=(k, 128)))
+        d[rows] = np.clip(pool[:k] + noise, 0, 255)
+        d = d.astype(np.uint8)
+        out.append(np.ascontiguousarray(d.astype(F32) if as_float else d))
+    return out
+
+
+def keypoints(n, seed=0, width=3072, height=2304):
+    """n x 4 float32 keypoint rows (x, y, size, angle)."""
+    rng = np.random.default_rng(seed)
+    k = np.empty((n, 4), F32)
+    k[:, 0] = rng.uniform(0, width, n)
+    k[:, 1] = rng.uniform(0, height, n)
+    k[:, 2] = rng.gamma(2.0, 2.0, n) + 1.0
+    k[:, 3] = rng.uniform(0, 360, n)
+    return k

@@ -1,0 +1,418 @@
+/*
+ * msfm_oracle.c -- CPU oracle for the ComputeMatches hot path (see msfm_oracle.h).
+ * TEST INFRASTRUCTURE ONLY; PARITY UNPINNED (no OpenCV, no reference golden vectors).
+ *
+ * Build: gcc -O3 -ffp-contract=off -fPIC -shared -pthread (see oracle/Makefile).
+ * -ffp-contract=off is load-bearing: the SSE4X4 and SCALAR orders round the
+ * multiply and the add separately.
+ */
+#include "msfm_oracle.h"
+
+#include <float.h>
+#include <math.h>
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+
+#if defined(__SSE2__)
+#include <emmintrin.h>
+#endif
+
+/* ------------------------------------------------------------------------- */
+/* S(a,b): restatement of cv::hal::normL2Sqr_(const float*, const float*, n)  */
+/* for n = 128 (8 iterations of 16 floats, no scalar tail).                   */
+/* ------------------------------------------------------------------------- */
+
+/* Plain-C statement of the SSE baseline order; the reference form the others
+ * (intrinsics, numpy, HIP kernel) are checked against. */
+static float l2sqr_sse4x4_scalar(const float* a, const float* b)
+{
+    float p[16];
+    for (int L = 0; L < 16; ++L) {
+        float t = a[L] - b[L];
+        p[L] = t * t; /* 0 + t*t is exact */
+    }
+    for (int it = 1; it < 8; ++it)
+        for (int L = 0; L < 16; ++L) {
+            float t = a[16 * it + L] - b[16 * it + L];
+            float m = t * t;
+            p[L] = p[L] + m;
+        }
+    float s[4];
+    for (int l = 0; l < 4; ++l)
+        s[l] = ((p[l] + p[4 + l]) + p[8 + l]) + p[12 + l];
+    return (s[0] + s[2]) + (s[1] + s[3]);
+}
+
+#if defined(__SSE2__)
+static float l2sqr_sse4x4(const float* a, const float* b)
+{
+    __m128 d0 = _mm_setzero_ps(), d1 = _mm_setzero_ps(), d2 = _mm_setzero_ps(), d3 = _mm_setzero_ps();
+    for (int j = 0; j < 128; j += 16) {
+        __m128 t0 = _mm_sub_ps(_mm_loadu_ps(a + j), _mm_loadu_ps(b + j));
+        __m128 t1 = _mm_sub_ps(_mm_loadu_ps(a + j + 4), _mm_loadu_ps(b + j + 4));
+        __m128 t2 = _mm_sub_ps(_mm_loadu_ps(a + j + 8), _mm_loadu_ps(b + j + 8));
+        __m128 t3 = _mm_sub_ps(_mm_loadu_ps(a + j + 12), _mm_loadu_ps(b + j + 12));
+        d0 = _mm_add_ps(_mm_mul_ps(t0, t0), d0);
+        d1 = _mm_add_ps(_mm_mul_ps(t1, t1), d1);
+        d2 = _mm_add_ps(_mm_mul_ps(t2, t2), d2);
+        d3 = _mm_add_ps(_mm_mul_ps(t3, t3), d3);
+    }
+    __m128 v = _mm_add_ps(_mm_add_ps(_mm_add_ps(d0, d1), d2), d3);
+    /* v_reduce_sum(v_float32x4): (l0+l2)+(l1+l3) */
+    v = _mm_add_ps(v, _mm_movehl_ps(v, v));
+    v = _mm_add_ss(v, _mm_shuffle_ps(v, v, _MM_SHUFFLE(0, 0, 0, 1)));
+    return _mm_cvtss_f32(v);
+}
+#else
+#define l2sqr_sse4x4 l2sqr_sse4x4_scalar
+#endif
+
+static float l2sqr_avx2_fma(const float* a, const float* b)
+{
+    float p[32];
+    for (int L = 0; L < 32; ++L) p[L] = 0.0f;
+    for (int it = 0; it < 4; ++it)
+        for (int L = 0; L < 32; ++L) {
+            float t = a[32 * it + L] - b[32 * it + L];
+            p[L] = fmaf(t, t, p[L]);
+        }
+    float s[8];
+    for (int l = 0; l < 8; ++l)
+        s[l] = ((p[l] + p[8 + l]) + p[16 + l]) + p[24 + l];
+    return ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+}
+
+static float l2sqr_scalar(const float* a, const float* b)
+{
+    float d = 0.0f;
+    for (int c = 0; c < 128; ++c) {
+        float t = a[c] - b[c];
+        float m = t * t;
+        d = d + m;
+    }
+    return d;
+}
+
+float orc_l2sqr(const float* a, const float* b, int order)
+{
+    switch (order) {
+    case MSFM_ORC_ORDER_SSE4X4: return l2sqr_sse4x4(a, b);
+    case MSFM_ORC_ORDER_AVX2_FMA: return l2sqr_avx2_fma(a, b);
+    case MSFM_ORC_ORDER_SCALAR: return l2sqr_scalar(a, b);
+    case 100: return l2sqr_sse4x4_scalar(a, b); /* test hook: plain-C SSE order */
+    default: return NAN;
+    }
+}
+
+/* ------------------------------------------------------------------------- */
+/* knnMatch(k=2): restatement of cv::batchDistance(..., K=2, NORM_L2) as       */
+/* called by BFMatcher::knnMatchImpl (call site FeatureUtils.cpp:146-149).    */
+/* ------------------------------------------------------------------------- */
+
+static inline int32_t f2i(float f)
+{
+    int32_t i;
+    memcpy(&i, &f, 4);
+    return i;
+}
+static inline float i2f(int32_t i)
+{
+    float f;
+    memcpy(&f, &i, 4);
+    return f;
+}
+
+static void knn2_rows(const float* q, int q_begin, int q_end, const float* t, int nt, int order,
+                      int32_t* idx0, float* d0, int32_t* idx1, float* d1)
+{
+    const int K = nt < 2 ? nt : 2;
+    float* buf = (float*)malloc(sizeof(float) * (size_t)(nt > 0 ? nt : 1));
+    for (int i = q_begin; i < q_end; ++i) {
+        const float* qi = q + (size_t)i * 128;
+        /* batchDistL2_32f: dist[j] = std::sqrt(normL2Sqr(q, t_j)) */
+        switch (order) {
+        case MSFM_ORC_ORDER_SSE4X4:
+            for (int j = 0; j < nt; ++j) buf[j] = sqrtf(l2sqr_sse4x4(qi, t + (size_t)j * 128));
+            break;
+        case MSFM_ORC_ORDER_AVX2_FMA:
+            for (int j = 0; j < nt; ++j) buf[j] = sqrtf(l2sqr_avx2_fma(qi, t + (size_t)j * 128));
+            break;
+        default:
+            for (int j = 0; j < nt; ++j) buf[j] = sqrtf(orc_l2sqr(qi, t + (size_t)j * 128, order));
+        }
+        /* dist initialised to FLT_MAX, nidx to -1; positive floats compared as ints */
+        int32_t dist[2] = {f2i(FLT_MAX), f2i(FLT_MAX)};
+        int32_t nidx[2] = {-1, -1};
+        if (K > 0) {
+            for (int j = 0; j < nt; ++j) {
+                int32_t d = f2i(buf[j]);
+                if (d < dist[K - 1]) {
+                    int k;
+                    for (k = K - 2; k >= 0 && dist[k] > d; --k) {
+                        nidx[k + 1] = nidx[k];
+                        dist[k + 1] = dist[k];
+                    }
+                    nidx[k + 1] = j;
+                    dist[k + 1] = d;
+                }
+            }
+        }
+        idx0[i] = nidx[0];
+        d0[i] = i2f(dist[0]);
+        idx1[i] = nidx[1];
+        d1[i] = i2f(dist[1]);
+    }
+    free(buf);
+}
+
+void orc_knn2(const float* q, int nq, const float* t, int nt, int order,
+              int32_t* idx0, float* d0, int32_t* idx1, float* d1)
+{
+    knn2_rows(q, 0, nq, t, nt, order, idx0, d0, idx1, d1);
+}
+
+typedef struct {
+    const float *q, *t;
+    int q_begin, q_end, nt, order;
+    int32_t *idx0, *idx1;
+    float *d0, *d1;
+} knn_job;
+
+static void* knn_thread(void* arg)
+{
+    knn_job* j = (knn_job*)arg;
+    knn2_rows(j->q, j->q_begin, j->q_end, j->t, j->nt, j->order, j->idx0, j->d0, j->idx1, j->d1);
+    return NULL;
+}
+
+void orc_knn2_mt(const float* q, int nq, const float* t, int nt, int order, int nthreads,
+                 int32_t* idx0, float* d0, int32_t* idx1, float* d1)
+{
+    if (nthreads <= 1 || nq < 2 * nthreads) {
+        knn2_rows(q, 0, nq, t, nt, order, idx0, d0, idx1, d1);
+        return;
+    }
+    pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * (size_t)nthreads);
+    knn_job* jobs = (knn_job*)malloc(sizeof(knn_job) * (size_t)nthreads);
+    for (int k = 0; k < nthreads; ++k) {
+        knn_job jb = {q, t, (int)((long long)nq * k / nthreads), (int)((long long)nq * (k + 1) / nthreads),
+                      nt, order, idx0, idx1, d0, d1};
+        jobs[k] = jb;
+        pthread_create(&th[k], NULL, knn_thread, &jobs[k]);
+    }
+    for (int k = 0; k < nthreads; ++k) pthread_join(th[k], NULL);
+    free(th);
+    free(jobs);
+}
+
+/* ------------------------------------------------------------------------- */
+/* FeatureUtils operators                                                     */
+/* ------------------------------------------------------------------------- */
+
+int orc_compute_matches(const float* d1, int n1, const float* d2, int n2, float ratio,
+                        int order, int nthreads, int32_t* out_q, int32_t* out_t, float* out_d)
+{
+    /* FeatureUtils.cpp:152 indexes m[1] unconditionally: UB when the train set has
+     * < 2 rows.  Build-defined behaviour: no matches.  Empty query/train => none. */
+    if (n1 <= 0 || n2 < 2) return 0;
+    int32_t* i0 = (int32_t*)malloc(sizeof(int32_t) * (size_t)n1 * 2);
+    float* dd = (float*)malloc(sizeof(float) * (size_t)n1 * 2);
+    int32_t* i1 = i0 + n1;
+    float *dist0 = dd, *dist1 = dd + n1;
+    orc_knn2_mt(d1, n1, d2, n2, order, nthreads, i0, dist0, i1, dist1);
+    int m = 0;
+    for (int q = 0; q < n1; ++q) {
+        if (i0[q] < 0 || i1[q] < 0) continue; /* fewer than 2 finite neighbours */
+        float thr = ratio * dist1[q]; /* single-rounded fp32 product */
+        if (dist0[q] < thr) {
+            out_q[m] = q;
+            out_t[m] = i0[q];
+            out_d[m] = dist0[q];
+            ++m;
+        }
+    }
+    free(i0);
+    free(dd);
+    return m;
+}
+
+int orc_cross_check(const int32_t* q12, const int32_t* t12, const float* d12, int m12,
+                    const int32_t* q21, const int32_t* t21, int m21,
+                    int32_t* out_q, int32_t* out_t, float* out_d)
+{
+    /* vis[query_idx of reverse match] = its train_idx; unordered_map::operator[] on
+     * lookup default-inserts 0 for a missing key (FeatureUtils.cpp:302). */
+    int32_t maxkey = -1;
+    for (int i = 0; i < m21; ++i)
+        if (q21[i] > maxkey) maxkey = q21[i];
+    for (int i = 0; i < m12; ++i)
+        if (t12[i] > maxkey) maxkey = t12[i];
+    int32_t* vis = (int32_t*)calloc((size_t)(maxkey + 2), sizeof(int32_t)); /* missing -> 0 */
+    for (int i = 0; i < m21; ++i) vis[q21[i]] = t21[i];
+    int m = 0;
+    for (int i = 0; i < m12; ++i) {
+        if (vis[t12[i]] == q12[i]) {
+            out_q[m] = q12[i];
+            out_t[m] = t12[i];
+            out_d[m] = d12[i];
+            ++m;
+        }
+    }
+    free(vis);
+    return m;
+}
+
+int orc_filter_by_distance(const int32_t* q, const int32_t* t, const float* d, int m,
+                           double max_distance, int32_t* out_q, int32_t* out_t, float* out_d)
+{
+    int k = 0;
+    for (int i = 0; i < m; ++i) {
+        if ((double)d[i] > max_distance) continue;
+        out_q[k] = q[i];
+        out_t[k] = t[i];
+        out_d[k] = d[i];
+        ++k;
+    }
+    return k;
+}
+
+int orc_match_pair(const float* d1, int n1, const float* d2, int n2,
+                   float ratio, int cross_check, double max_distance, int order, int nthreads,
+                   int32_t* out_q, int32_t* out_t, float* out_d)
+{
+    if (n1 <= 0 || n2 <= 0) return 0;
+    int cap = n1 > n2 ? n1 : n2;
+    int32_t* ibuf = (int32_t*)malloc(sizeof(int32_t) * (size_t)cap * 6);
+    float* fbuf = (float*)malloc(sizeof(float) * (size_t)cap * 3);
+    int32_t *q12 = ibuf, *t12 = ibuf + cap, *q21 = ibuf + 2 * cap, *t21 = ibuf + 3 * cap;
+    int32_t *qc = ibuf + 4 * cap, *tc = ibuf + 5 * cap;
+    float *dd12 = fbuf, *dd21 = fbuf + cap, *dc = fbuf + 2 * cap;
+    int m12 = orc_compute_matches(d1, n1, d2, n2, ratio, order, nthreads, q12, t12, dd12);
+    int m;
+    if (cross_check) {
+        /* build-defined: a side with < 2 rows yields no matches in that direction (UB in the
+         * reference); the GPU library additionally returns 0 matches for the whole pair then. */
+        int m21 = orc_compute_matches(d2, n2, d1, n1, ratio, order, nthreads, q21, t21, dd21);
+        if (n1 < 2 || n2 < 2) m = 0;
+        else m = orc_cross_check(q12, t12, dd12, m12, q21, t21, m21, qc, tc, dc);
+    } else {
+        m = m12;
+        memcpy(qc, q12, sizeof(int32_t) * (size_t)m);
+        memcpy(tc, t12, sizeof(int32_t) * (size_t)m);
+        memcpy(dc, dd12, sizeof(float) * (size_t)m);
+    }
+    int k = orc_filter_by_distance(qc, tc, dc, m, max_distance, out_q, out_t, out_d);
+    free(ibuf);
+    free(fbuf);
+    return k;
+}
+
+/* ------------------------------------------------------------------------- */
+/* pre-emptive matching helper (FeatureUtils.cpp:68-96)                       */
+/* ------------------------------------------------------------------------- */
+
+typedef struct {
+    float size;
+    int32_t idx;
+} scale_ent;
+
+static int scale_cmp(const void* a, const void* b)
+{
+    const scale_ent* x = (const scale_ent*)a;
+    const scale_ent* y = (const scale_ent*)b;
+    if (x->size > y->size) return -1;
+    if (x->size < y->size) return 1;
+    return (x->idx > y->idx) - (x->idx < y->idx);
+}
+
+int orc_topscale_select(const float* kpts, int n, int k, int32_t* out_idx)
+{
+    if (k > n) { /* "if(num_features > kpts.size()) top = descriptors" */
+        for (int i = 0; i < n; ++i) out_idx[i] = i;
+        return n;
+    }
+    scale_ent* e = (scale_ent*)malloc(sizeof(scale_ent) * (size_t)(n > 0 ? n : 1));
+    for (int i = 0; i < n; ++i) {
+        e[i].size = kpts[(size_t)i * 4 + 2];
+        e[i].idx = i;
+    }
+    qsort(e, (size_t)n, sizeof(scale_ent), scale_cmp);
+    for (int i = 0; i < k; ++i) out_idx[i] = e[i].idx;
+    free(e);
+    return k;
+}
+
+/* ------------------------------------------------------------------------- */
+/* pair id codec (Database.cpp:6, 656-694)                                    */
+/* ------------------------------------------------------------------------- */
+
+#define K_MAX_NUM_IMAGES 10000
+
+int orc_swap_image_pair(int32_t id1, int32_t id2) { return id1 > id2; }
+
+int32_t orc_pair_id(int32_t id1, int32_t id2)
+{
+    if (orc_swap_image_pair(id1, id2)) return K_MAX_NUM_IMAGES * id2 + id1;
+    return K_MAX_NUM_IMAGES * id1 + id2;
+}
+
+void orc_pair_from_id(int32_t pair_id, int32_t* id1, int32_t* id2)
+{
+    *id2 = pair_id % K_MAX_NUM_IMAGES;
+    *id1 = (pair_id - *id2) / K_MAX_NUM_IMAGES;
+}
+
+/* ------------------------------------------------------------------------- */
+/* pair enumeration (FeatureMatching.cpp:75-145)                              */
+/* ------------------------------------------------------------------------- */
+
+int64_t orc_enumerate_brute(int n_images, int max_pairs, int32_t* pairs, int64_t* batch_end,
+                            int64_t* n_batches)
+{
+    int64_t np = 0, nb = 0;
+    for (int i = 0; i < n_images; ++i) {
+        int cur = 0;
+        for (int j = 0; j < i; ++j) {
+            if (pairs) {
+                pairs[2 * np] = i;
+                pairs[2 * np + 1] = j;
+            }
+            ++np;
+            ++cur;
+            if (cur == max_pairs) {
+                if (batch_end) batch_end[nb] = np;
+                ++nb;
+                cur = 0;
+            }
+        }
+        if (cur != 0) {
+            if (batch_end) batch_end[nb] = np;
+            ++nb;
+        }
+    }
+    if (n_batches) *n_batches = nb;
+    return np;
+}
+
+int64_t orc_enumerate_sequential(int n_images, int overlap, int32_t* pairs, int64_t* batch_end,
+                                 int64_t* n_batches)
+{
+    int64_t np = 0, nb = 0;
+    for (int i = 1; i < n_images; ++i) {
+        for (int k = 1; k <= overlap; ++k) {
+            int j = i - k;
+            if (j < 0) break;
+            if (pairs) {
+                pairs[2 * np] = i;
+                pairs[2 * np + 1] = j;
+            }
+            ++np;
+        }
+        /* MatchImagePairs is called once per i, even though the list is never empty for i>=1 */
+        if (batch_end) batch_end[nb] = np;
+        ++nb;
+    }
+    if (n_batches) *n_batches = nb;
+    return np;
+}
