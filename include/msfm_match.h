@@ -1,0 +1,132 @@
+/*
+ * msfm_match.h -- C ABI of the MI355X (gfx950) ComputeMatches hot path.
+ *
+ * Drop-in boundary for nebula-beta/MonocularSfM's descriptor matcher: every entry point
+ * replaces one C++ interface of the reference (cited per function, paths relative to the
+ * reference checkout).  The reference has no FFI layer of its own; its seams are the static
+ * FeatureUtils operators (include/Feature/FeatureUtils.h:94-108) called from
+ * src/Feature/FeatureMatching.cpp:36-49 and :163-170, and the Database blobs on either side.
+ *
+ * Conventions
+ *   - plain C types only; every call returns an int status (MSFM_OK == 0), never throws,
+ *     never exits.  msfm_last_error() gives the text of the last failure on a context.
+ *   - the caller owns all host buffers; the library owns all device memory.
+ *   - descriptors are row-major, contiguous, 128 columns (cv::Mat CV_32F n x 128 as read by
+ *     Database::ReadDescriptors, src/Database/Database.cpp:510-523), or uint8 with the same shape.
+ *   - a context is bound to one GPU and is not thread-safe; distinct contexts may be driven
+ *     from distinct threads (one per GPU).
+ *   - there is NO CPU fallback: without a usable gfx950 device msfm_create() fails.
+ */
+#ifndef MSFM_MATCH_H
+#define MSFM_MATCH_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MSFM_DIM 128
+#define MSFM_MAX_IMAGES 10000 /* kMaxNumImages, src/Database/Database.cpp:6 */
+
+enum {
+    MSFM_OK = 0,
+    MSFM_E_INVALID = 1,   /* bad argument */
+    MSFM_E_DEVICE = 2,    /* HIP error (text in msfm_last_error) */
+    MSFM_E_NOIMAGE = 3,   /* image id not uploaded */
+    MSFM_E_CAPACITY = 4,  /* caller buffer too small */
+    MSFM_E_STATE = 5      /* call sequence error (e.g. fetch without a prior match) */
+};
+
+enum { MSFM_DTYPE_F32 = 0, MSFM_DTYPE_U8 = 1 };
+
+/* fp32 accumulation order of S(q,t) = sum_c (a_c-b_c)^2, i.e. which build of
+ * cv::hal::normL2Sqr_ (called through BFMatcher::knnMatch at src/Feature/FeatureUtils.cpp:149)
+ * the bits are identical to.  Integer-valued descriptors give identical bits under all. */
+enum {
+    MSFM_ORDER_SSE4X4 = 0,   /* OpenCV 4.x SSE baseline: 16 lane partials, mul and add rounded apart */
+    MSFM_ORDER_AVX2_FMA = 1  /* OpenCV 4.x AVX2+FMA3 baseline: 32 lane partials, fused */
+};
+
+typedef struct msfm_ctx msfm_ctx;
+
+/* Matching parameters = the FeatureMatcher constructor arguments that reach the operators
+ * (include/Feature/FeatureMatching.h:28-32): distance_ratio (passed on as float),
+ * cross_check, max_distance (double). */
+typedef struct msfm_match_params {
+    float ratio;          /* default 0.8f */
+    int cross_check;      /* default 1    */
+    double max_distance;  /* default 0.7  */
+} msfm_match_params;
+
+/* Kernel-side timing of the last msfm_match_pairs / msfm_match_pair / msfm_knn2_pair call,
+ * measured with HIP events on the library's own stream. */
+typedef struct msfm_profile {
+    double dist_kernel_ms;     /* sum over launches of the distance/top-2 kernel */
+    int dist_kernel_launches;
+    double total_device_ms;    /* first launch -> last result copy of the call */
+    int64_t descriptor_pairs;  /* sum n1*n2 over the pairs of the call */
+    int64_t dist_algo_bytes;   /* compulsory HBM bytes of the distance kernel */
+} msfm_profile;
+
+/* ---- context ------------------------------------------------------------------------- */
+int msfm_create(int device_ordinal, msfm_ctx** out_ctx);
+void msfm_destroy(msfm_ctx* ctx);
+const char* msfm_last_error(const msfm_ctx* ctx);
+/* device name + CU count of the context's GPU (for bench reports); name_cap >= 64 */
+int msfm_device_info(const msfm_ctx* ctx, char* name, int name_cap, int* cu_count, int* clock_mhz);
+int msfm_set_accum_order(msfm_ctx* ctx, int order);
+int msfm_get_profile(const msfm_ctx* ctx, msfm_profile* out);
+
+/* ---- descriptor store -------------------------------------------------------------------
+ * Replaces the per-pair Database::ReadDescriptors calls of MatchImagePairs
+ * (src/Feature/FeatureMatching.cpp:32-33, "TODO: cache"): every image is uploaded once and
+ * stays resident in HBM.  ids are Database image ids, 0 <= id < MSFM_MAX_IMAGES. */
+int msfm_upload_image(msfm_ctx* ctx, int image_id, const void* desc, int n, int dim, int dtype);
+int msfm_image_rows(const msfm_ctx* ctx, int image_id, int* out_n);
+int msfm_clear_images(msfm_ctx* ctx);
+
+/* ---- one pair ---------------------------------------------------------------------------
+ * Twin of FeatureUtils::ComputeCrossMatches / ComputeMatches (src/Feature/FeatureUtils.cpp:
+ * 141-174) followed by FilterMatchesByDistance (:208-218), i.e. lines 36-49 of
+ * FeatureMatching.cpp.  query = id1, train = id2.  out_qt receives (queryIdx, trainIdx) int32
+ * pairs in ascending queryIdx (capacity: rows(id1) pairs); out_dist (nullable) the DMatch
+ * distances.  A side with < 2 rows yields no matches (the reference is undefined there). */
+int msfm_match_pair(msfm_ctx* ctx, int id1, int id2, float ratio, int cross_check,
+                    double max_distance, int32_t* out_qt, float* out_dist, int* out_count);
+
+/* ---- batch of pairs ---------------------------------------------------------------------
+ * Twin of the loop body of FeatureMatcher::MatchImagePairs (FeatureMatching.cpp:14-49) over
+ * independent pairs; results keep the input order.  pairs = P x 2 int32 (id1, id2).
+ * out_offsets (P+1 int64) receives the CSR offsets of each pair's match list; the lists
+ * themselves stay on the context until msfm_fetch_matches copies them out
+ * (out_qt: 2*out_offsets[P] int32, out_dist nullable: out_offsets[P] float). */
+int msfm_match_pairs(msfm_ctx* ctx, const int32_t* pairs, int n_pairs,
+                     const msfm_match_params* params, int64_t* out_offsets);
+int msfm_fetch_matches(msfm_ctx* ctx, int32_t* out_qt, float* out_dist);
+
+/* ---- knnMatch(k=2) twin (parity/debug) ----------------------------------------------------
+ * Both directions of cv::BFMatcher(NORM_L2).knnMatch(.., 2) for one pair
+ * (call site src/Feature/FeatureUtils.cpp:146-149), from ONE pass over the distance matrix.
+ * fwd_* have rows(id1) entries (train index into id2), rev_* rows(id2) entries.
+ * idx = -1 and d = FLT_MAX where fewer than 1 / 2 neighbours exist.  Any pointer may be NULL. */
+int msfm_knn2_pair(msfm_ctx* ctx, int id1, int id2,
+                   int32_t* fwd_idx0, float* fwd_d0, float* fwd_d1,
+                   int32_t* rev_idx0, float* rev_d0, float* rev_d1);
+
+/* ---- host-side helpers (no device work) ------------------------------------------------- */
+/* FeatureUtils::ExtractTopScaleDescriptors' row selection (FeatureUtils.cpp:68-96):
+ * kpts = n x 4 float (x, y, size, angle); writes min(k, n) indices, k > n => identity.
+ * Tie rule (reference: unspecified, std::partial_sort): size descending, index ascending. */
+int msfm_topscale_select(const float* kpts, int n, int k, int32_t* out_idx, int* out_count);
+/* Database::ImagePairToPairId / PairIdToImagePair / SwapImagePair (Database.cpp:656-694) */
+int msfm_pair_id(int id1, int id2, int32_t* out_pair_id);
+int msfm_pair_from_id(int32_t pair_id, int* out_id1, int* out_id2);
+int msfm_swap_image_pair(int id1, int id2);
+
+const char* msfm_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,237 @@
+"""ctypes binding of the C ABI in include/msfm_match.h (libmsfm_match.so, built in-tree).
+
+There is no fallback: if the shared library is missing or no gfx950 GPU is usable, loading /
+context creation raises.  Nothing here imports the CPU oracle.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libmsfm_match.so")
+
+OK, E_INVALID, E_DEVICE, E_NOIMAGE, E_CAPACITY, E_STATE = range(6)
+DTYPE_F32, DTYPE_U8 = 0, 1
+ORDER_SSE4X4, ORDER_AVX2_FMA = 0, 1
+MAX_IMAGES = 10000
+DIM = 128
+
+EXPORTS = [
+    "msfm_create", "msfm_destroy", "msfm_last_error", "msfm_device_info", "msfm_set_accum_order",
+    "msfm_get_profile", "msfm_upload_image", "msfm_image_rows", "msfm_clear_images",
+    "msfm_match_pair", "msfm_match_pairs", "msfm_fetch_matches", "msfm_knn2_pair",
+    "msfm_topscale_select", "msfm_pair_id", "msfm_pair_from_id", "msfm_swap_image_pair",
+    "msfm_version",
+]
+
+
+class MatchParams(C.Structure):
+    _fields_ = [("ratio", C.c_float), ("cross_check", C.c_int), ("max_distance", C.c_double)]
+
+
+class Profile(C.Structure):
+    _fields_ = [("dist_kernel_ms", C.c_double), ("dist_kernel_launches", C.c_int),
+                ("total_device_ms", C.c_double), ("descriptor_pairs", C.c_int64),
+                ("dist_algo_bytes", C.c_int64)]
+
+
+class MsfmError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("msfm error %d: %s" % (code, msg))
+        self.code = code
+
+
+_lib = None
+
+
+def load():
+    """Load libmsfm_match.so; raises (loudly) if the HIP extension has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "%s is missing: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; "
+            "g.build()'` (or `make -C monocularsfm_amd/csrc`). There is no CPU fallback." % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, ip, fp = C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_float)
+    L.msfm_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.msfm_destroy.argtypes = [vp]
+    L.msfm_destroy.restype = None
+    L.msfm_last_error.argtypes = [vp]
+    L.msfm_last_error.restype = C.c_char_p
+    L.msfm_device_info.argtypes = [vp, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.msfm_set_accum_order.argtypes = [vp, C.c_int]
+    L.msfm_get_profile.argtypes = [vp, C.POINTER(Profile)]
+    L.msfm_upload_image.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int]
+    L.msfm_image_rows.argtypes = [vp, C.c_int, C.POINTER(C.c_int)]
+    L.msfm_clear_images.argtypes = [vp]
+    L.msfm_match_pair.argtypes = [vp, C.c_int, C.c_int, C.c_float, C.c_int, C.c_double, ip, fp, C.POINTER(C.c_int)]
+    L.msfm_match_pairs.argtypes = [vp, ip, C.c_int, C.POINTER(MatchParams), C.POINTER(C.c_int64)]
+    L.msfm_fetch_matches.argtypes = [vp, ip, fp]
+    L.msfm_knn2_pair.argtypes = [vp, C.c_int, C.c_int, ip, fp, fp, ip, fp, fp]
+    L.msfm_topscale_select.argtypes = [fp, C.c_int, C.c_int, ip, C.POINTER(C.c_int)]
+    L.msfm_pair_id.argtypes = [C.c_int, C.c_int, ip]
+    L.msfm_pair_from_id.argtypes = [C.c_int32, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.msfm_swap_image_pair.argtypes = [C.c_int, C.c_int]
+    L.msfm_version.restype = C.c_char_p
+    for name in EXPORTS:
+        fn = getattr(L, name)
+        if fn.restype is C.c_int or fn.restype is None or fn.restype is C.c_char_p:
+            continue
+    _lib = L
+    return L
+
+
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+class Context:
+    """One matcher context bound to one GPU (msfm_ctx)."""
+
+    def __init__(self, device=0, order=ORDER_SSE4X4):
+        self._L = load()
+        h = C.c_void_p()
+        rc = self._L.msfm_create(int(device), C.byref(h))
+        if rc != OK:
+            raise MsfmError(rc, "msfm_create(device=%d) failed: no usable gfx950 GPU (there is no CPU fallback)" % device)
+        self._h = h
+        self.device = int(device)
+        if order != ORDER_SSE4X4:
+            self.set_accum_order(order)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.msfm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _chk(self, rc):
+        if rc != OK:
+            raise MsfmError(rc, self._L.msfm_last_error(self._h).decode())
+
+    def device_info(self):
+        name = C.create_string_buffer(256)
+        cu, mhz = C.c_int(), C.c_int()
+        self._chk(self._L.msfm_device_info(self._h, name, 256, C.byref(cu), C.byref(mhz)))
+        return {"name": name.value.decode(), "cu_count": cu.value, "clock_mhz": mhz.value}
+
+    def set_accum_order(self, order):
+        self._chk(self._L.msfm_set_accum_order(self._h, int(order)))
+
+    def profile(self):
+        p = Profile()
+        self._chk(self._L.msfm_get_profile(self._h, C.byref(p)))
+        return {k: getattr(p, k) for k, _ in Profile._fields_}
+
+    def upload_image(self, image_id, desc):
+        desc = np.asarray(desc)
+        if desc.dtype == np.uint8:
+            dtype = DTYPE_U8
+        else:
+            desc = desc.astype(np.float32, copy=False)
+            dtype = DTYPE_F32
+        desc = np.ascontiguousarray(desc)
+        if desc.ndim != 2:
+            raise ValueError("descriptors must be 2-D")
+        n, dim = desc.shape
+        if n == 0:
+            dim = DIM
+        self._chk(self._L.msfm_upload_image(self._h, int(image_id), desc.ctypes.data_as(C.c_void_p), n, dim, dtype))
+
+    def image_rows(self, image_id):
+        n = C.c_int()
+        self._chk(self._L.msfm_image_rows(self._h, int(image_id), C.byref(n)))
+        return n.value
+
+    def clear_images(self):
+        self._chk(self._L.msfm_clear_images(self._h))
+
+    def match_pair(self, id1, id2, ratio=0.8, cross_check=True, max_distance=0.7):
+        n1 = max(self.image_rows(id1), 1)
+        qt = np.empty((n1, 2), np.int32)
+        d = np.empty(n1, np.float32)
+        cnt = C.c_int()
+        self._chk(self._L.msfm_match_pair(self._h, int(id1), int(id2), C.c_float(ratio), int(bool(cross_check)),
+                                          float(max_distance), _ip(qt), _fp(d), C.byref(cnt)))
+        m = cnt.value
+        return qt[:m, 0].copy(), qt[:m, 1].copy(), d[:m].copy()
+
+    def match_pairs(self, pairs, ratio=0.8, cross_check=True, max_distance=0.7, fetch=True):
+        """pairs: P x 2 int array -> (offsets[P+1], qt[M,2], dist[M]); fetch=False skips the copy-out."""
+        pairs = np.ascontiguousarray(np.asarray(pairs, dtype=np.int32).reshape(-1, 2))
+        P = pairs.shape[0]
+        offs = np.zeros(P + 1, np.int64)
+        prm = MatchParams(ratio, int(bool(cross_check)), max_distance)
+        self._chk(self._L.msfm_match_pairs(self._h, _ip(pairs), P, C.byref(prm),
+                                           offs.ctypes.data_as(C.POINTER(C.c_int64))))
+        if not fetch:
+            return offs, None, None
+        M = int(offs[-1])
+        qt = np.empty((max(M, 1), 2), np.int32)
+        d = np.empty(max(M, 1), np.float32)
+        self._chk(self._L.msfm_fetch_matches(self._h, _ip(qt), _fp(d)))
+        return offs, qt[:M], d[:M]
+
+    def knn2_pair(self, id1, id2):
+        n1, n2 = self.image_rows(id1), self.image_rows(id2)
+        f_i = np.empty(max(n1, 1), np.int32)
+        f_d0 = np.empty(max(n1, 1), np.float32)
+        f_d1 = np.empty(max(n1, 1), np.float32)
+        r_i = np.empty(max(n2, 1), np.int32)
+        r_d0 = np.empty(max(n2, 1), np.float32)
+        r_d1 = np.empty(max(n2, 1), np.float32)
+        self._chk(self._L.msfm_knn2_pair(self._h, int(id1), int(id2), _ip(f_i), _fp(f_d0), _fp(f_d1),
+                                         _ip(r_i), _fp(r_d0), _fp(r_d1)))
+        return (f_i[:n1], f_d0[:n1], f_d1[:n1]), (r_i[:n2], r_d0[:n2], r_d1[:n2])
+
+
+def topscale_select(kpts, k):
+    L = load()
+    kpts = np.ascontiguousarray(kpts, dtype=np.float32).reshape(-1, 4)
+    n = kpts.shape[0]
+    out = np.empty(max(n, 1), np.int32)
+    cnt = C.c_int()
+    rc = L.msfm_topscale_select(_fp(kpts), n, int(k), _ip(out), C.byref(cnt))
+    if rc != OK:
+        raise MsfmError(rc, "msfm_topscale_select")
+    return out[:cnt.value].copy()
+
+
+def pair_id(id1, id2):
+    L = load()
+    out = C.c_int32()
+    rc = L.msfm_pair_id(int(id1), int(id2), C.byref(out))
+    if rc != OK:
+        raise MsfmError(rc, "msfm_pair_id: ids must be in [0, %d)" % MAX_IMAGES)
+    return out.value
+
+
+def pair_from_id(pid):
+    L = load()
+    a, b = C.c_int(), C.c_int()
+    rc = L.msfm_pair_from_id(int(pid), C.byref(a), C.byref(b))
+    if rc != OK:
+        raise MsfmError(rc, "msfm_pair_from_id")
+    return a.value, b.value
+
+
+def swap_image_pair(id1, id2):
+    return bool(load().msfm_swap_image_pair(int(id1), int(id2)))

@@ -1,0 +1,563 @@
+// msfm_kernels.hip.h -- gfx950 (CDNA4) device code of the ComputeMatches hot path.
+//
+// What the kernels replace (reference = nebula-beta/MonocularSfM):
+//   dist_top2_kernel   the two cv::BFMatcher::knnMatch(k=2) sweeps per image pair
+//                      (src/Feature/FeatureUtils.cpp:146-149 called twice from :168-169), i.e.
+//                      cv::batchDistance + hal::normL2Sqr_; BOTH directions come from one pass
+//                      over the distance tile because (a-b)^2 == (b-a)^2 bitwise.
+//   merge_knn_kernel   the K=2 insertion pass of batchDistance (lowest index wins ties) + sqrt.
+//   tie_fixup_kernel   restores knnMatch's sqrt-space tie rule where the d^2-space selection
+//                      above can pick a different index (distinct d^2, equal sqrtf).
+//   epilogue_kernel    Lowe ratio (FeatureUtils.cpp:150-156), CrossCheck incl. the operator[]
+//                      quirk (:281-310), FilterMatchesByDistance (:208-218), stream compaction.
+//
+// Numerics contract (bit-exact): S(q,t) is accumulated in fp32 in the order of
+// the named OpenCV build (MSFM_ORDER_*): no reassociation, and for the SSE order no FMA
+// contraction (this translation unit is compiled with -ffp-contract=off).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#pragma clang fp contract(off)
+
+namespace msfm {
+
+constexpr int kDim = 128;
+constexpr int kBM = 128;      // A rows (query descriptors) per workgroup
+constexpr int kBN = 128;      // B rows (train descriptors) per tile
+constexpr int kTM = 8;        // per-thread micro tile: 8 A rows x 4 B rows
+constexpr int kTN = 4;
+constexpr int kThreads = 512; // 16 (ty) x 32 (tx); wave w holds ty in {2w, 2w+1}
+constexpr int kChunkPos = 32; // storage positions per LDS chunk of a B tile
+constexpr int kChunks = kDim / kChunkPos;
+constexpr int kPanelFloats = kBM * kDim; // one 128-row block of an image, 64 KiB
+constexpr int kSlotFloats = kChunkPos * kBN; // one B chunk in LDS, 16 KiB
+// LDS carve-up (floats): A panel | 2 B chunk slots | column-merge scratch (8 waves x 128 x 3)
+constexpr int kLdsA = 0;
+constexpr int kLdsB = kPanelFloats;
+constexpr int kLdsC = kLdsB + 2 * kSlotFloats;
+constexpr int kLdsFloats = kLdsC + 8 * kBN * 3;
+constexpr int kLdsBytes = kLdsFloats * 4;
+
+template <int ORDER> struct OrderTraits;
+// OpenCV 4.x SSE baseline: lanes l=0..3 x accumulators v=0..3, 8 iterations, no FMA,
+// ((d0+d1)+d2)+d3 per lane then (l0+l2)+(l1+l3): groups are processed in lane order 0,2,1,3
+// so that the final tree is a balanced in-order reduction over the processing order.
+template <> struct OrderTraits<0> {
+    static constexpr int kGroups = 4, kIters = 8, kGroupPos = 32;
+    static constexpr bool kFused = false;
+    __host__ __device__ static int pos_to_k(int pos) {
+        const int g = pos >> 5, v = (pos >> 3) & 3, it = pos & 7;
+        const int lane = (g == 0) ? 0 : (g == 1) ? 2 : (g == 2) ? 1 : 3;
+        return 16 * it + 4 * v + lane;
+    }
+};
+// OpenCV 4.x AVX2+FMA3: lanes l=0..7 x accumulators v=0..3, 4 iterations, fused,
+// ((d0+d1)+d2)+d3 per lane then ((l0+l1)+(l2+l3))+((l4+l5)+(l6+l7)).
+template <> struct OrderTraits<1> {
+    static constexpr int kGroups = 8, kIters = 4, kGroupPos = 16;
+    static constexpr bool kFused = true;
+    __host__ __device__ static int pos_to_k(int pos) {
+        const int g = pos >> 4, v = (pos >> 2) & 3, it = pos & 3;
+        return 32 * it + 8 * v + g;
+    }
+};
+
+struct PairDesc {
+    const float* a_panel;  // image id1 (query), panel layout
+    const float* b_panel;  // image id2 (train)
+    const float* a_raw;    // row-major copies (tie fix-up only)
+    const float* b_raw;
+    int n1, n2;
+    int a_blocks, b_tiles;
+    int n1pad, n2pad;
+    int ranges;            // B-tile ranges the pair was split into
+    int valid;             // 0: a side has < 2 rows -> no matches, no device work
+    long long rp_off;      // row partials  [ranges][n1pad]
+    long long cp_off;      // column partials [a_blocks][n2pad]
+    long long kf_off;      // final forward knn arrays [n1pad]
+    long long kr_off;      // final reverse knn arrays [n2pad]
+    long long out_off;     // staged matches [n1]
+};
+
+struct WorkItem {
+    int pair;     // -1: padding item (XCD interleave), nothing to do
+    int a_blk;
+    int bt_begin, bt_end;
+    int range;
+    int pad[3];
+};
+
+struct Top2 {
+    float s0; int i0; float s1;
+};
+
+__device__ __forceinline__ float f_inf() { return __builtin_huge_valf(); }
+
+// candidate with a HIGHER index than everything folded so far (strict <: earlier wins ties)
+__device__ __forceinline__ void top2_push(float& s0, int& i0, float& s1, float s, int idx) {
+    const bool lt = s < s0;
+    s1 = __builtin_amdgcn_fmed3f(s0, s1, s);  // second smallest of {s0<=s1, s}
+    i0 = lt ? idx : i0;
+    s0 = fminf(s0, s);
+}
+// general merge: ties on s0 go to the lower index
+__device__ __forceinline__ void top2_merge(float& s0, int& i0, float& s1, float bs0, int bi0, float bs1) {
+    const bool take_b = (bs0 < s0) || (bs0 == s0 && (unsigned)bi0 < (unsigned)i0);
+    s1 = fminf(fmaxf(s0, bs0), fminf(s1, bs1));
+    i0 = take_b ? bi0 : i0;
+    s0 = fminf(s0, bs0);
+}
+
+// ---------------------------------------------------------------------------------------
+// layout kernel: row-major [n][128] f32 (or u8) -> panels [blk][pos][row], pos = storage
+// position in accumulation ("chain") order, rows >= n zero-filled.
+// ---------------------------------------------------------------------------------------
+template <int ORDER, typename T>
+__global__ void layout_kernel(const T* __restrict__ src, float* __restrict__ raw, float* __restrict__ panel,
+                              int n, int nblk) {
+    const long long total = (long long)nblk * kPanelFloats;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+         e += (long long)gridDim.x * blockDim.x) {
+        const int row = (int)(e & (kBM - 1));
+        const int pos = (int)((e >> 7) & (kDim - 1));
+        const int blk = (int)(e >> 14);
+        const int r = blk * kBM + row;
+        float v = 0.0f;
+        if (r < n) v = (float)src[(size_t)r * kDim + OrderTraits<ORDER>::pos_to_k(pos)];
+        panel[e] = v;
+    }
+    if (raw) {
+        const long long nraw = (long long)n * kDim;
+        for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < nraw;
+             e += (long long)gridDim.x * blockDim.x)
+            raw[e] = (float)src[e];
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// async global -> LDS copy of `bytes` (multiple of 8 KiB) by the whole 512-thread group:
+// each wave instruction moves 64 lanes x 16 B = 1 KiB, LDS image = global image (lane-linear).
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ void glds_copy(const float* __restrict__ g, float* lds, int floats, int tid) {
+    const int wave = tid >> 6, lane = tid & 63;
+#pragma unroll 1
+    for (int piece = wave; piece * 256 < floats; piece += kThreads / 64) {
+        const float* gp = g + piece * 256 + lane * 4;
+        float* lp = lds + piece * 256;  // wave-uniform base; hardware adds lane*16
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
+                                         (__attribute__((address_space(3))) void*)lp, 16, 0, 0);
+    }
+}
+
+// One group of 4 accumulator chains (one SIMD lane of the OpenCV loop) for the 8x4 micro tile:
+// s[i][j] = ((p0+p1)+p2)+p3, p_v = sum over `kIters` storage positions in order.
+template <int ORDER>
+__device__ __forceinline__ void group_chains(const float* __restrict__ sa, const float* __restrict__ sb,
+                                             float (&s)[kTM][kTN]) {
+    using OT = OrderTraits<ORDER>;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        float p[kTM][kTN];
+#pragma unroll
+        for (int it = 0; it < OT::kIters; ++it) {
+            const int pos = v * OT::kIters + it;
+            const float4 a0 = *reinterpret_cast<const float4*>(sa + pos * kBM);
+            const float4 a1 = *reinterpret_cast<const float4*>(sa + pos * kBM + 4);
+            const float4 b0 = *reinterpret_cast<const float4*>(sb + pos * kBN);
+            const float av[kTM] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+            const float bv[kTN] = {b0.x, b0.y, b0.z, b0.w};
+#pragma unroll
+            for (int i = 0; i < kTM; ++i)
+#pragma unroll
+                for (int j = 0; j < kTN; ++j) {
+                    const float t = av[i] - bv[j];
+                    if (it == 0) p[i][j] = t * t;  // 0 + t*t == t*t exactly
+                    else if (OT::kFused) p[i][j] = __builtin_fmaf(t, t, p[i][j]);
+                    else p[i][j] = p[i][j] + t * t;  // mul and add rounded separately
+                }
+        }
+#pragma unroll
+        for (int i = 0; i < kTM; ++i)
+#pragma unroll
+            for (int j = 0; j < kTN; ++j) s[i][j] = (v == 0) ? p[i][j] : s[i][j] + p[i][j];
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// dist_top2_kernel: one workgroup = one 128-row block of image A x a range of 128-row tiles
+// of image B.  Per B tile: S for the 128x128 tile in exact order (8x4 per thread), then
+//   rows:    running top-2 (S0, argmin, S1) per A row, kept in registers across tiles;
+//   columns: top-2 over this block's 128 A rows, written as a partial per (A block, B row).
+// ---------------------------------------------------------------------------------------
+template <int ORDER>
+__global__ __launch_bounds__(kThreads) void dist_top2_kernel(
+    const PairDesc* __restrict__ pairs, const WorkItem* __restrict__ items,
+    float* __restrict__ rp_s0, int* __restrict__ rp_i0, float* __restrict__ rp_s1,
+    float* __restrict__ cp_s0, int* __restrict__ cp_i0, float* __restrict__ cp_s1) {
+    using OT = OrderTraits<ORDER>;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sA = smem + kLdsA;
+    float* sB = smem + kLdsB;
+    float* sC = smem + kLdsC;
+
+    const WorkItem item = items[blockIdx.x];
+    if (item.pair < 0) return;
+    const PairDesc pd = pairs[item.pair];
+
+    const int tid = threadIdx.x;
+    const int tx = tid & 31;
+    const int ty = tid >> 5;
+    const int wave = tid >> 6;
+
+    const float* gA = pd.a_panel + (size_t)item.a_blk * kPanelFloats;
+    const int n_steps = (item.bt_end - item.bt_begin) * kChunks;
+
+    // prologue: A panel + first B chunk
+    glds_copy(gA, sA, kPanelFloats, tid);
+    glds_copy(pd.b_panel + (size_t)item.bt_begin * kPanelFloats, sB, kSlotFloats, tid);
+
+    const int row0 = item.a_blk * kBM + ty * kTM;  // first A row of this thread
+    float r_s0[kTM], r_s1[kTM];
+    int r_i0[kTM];
+#pragma unroll
+    for (int i = 0; i < kTM; ++i) { r_s0[i] = f_inf(); r_s1[i] = f_inf(); r_i0[i] = -1; }
+
+    float lvl0[kTM][kTN], lvl1[kTM][kTN], lvl2[kTM][kTN];
+    (void)lvl2;
+
+    int step = 0;
+#pragma unroll 1
+    for (int bt = item.bt_begin; bt < item.bt_end; ++bt) {
+        float fin[kTM][kTN];
+#pragma unroll 1
+        for (int c = 0; c < kChunks; ++c, ++step) {
+            // chunk `step` has landed (vmcnt(0) is part of the barrier release when an LDS-DMA
+            // is outstanding) and every wave is done with the slot we are about to refill
+            __syncthreads();
+            if (step + 1 < n_steps) {
+                const int nstep = step + 1;
+                const int nbt = item.bt_begin + nstep / kChunks, nc = nstep % kChunks;
+                glds_copy(pd.b_panel + (size_t)nbt * kPanelFloats + nc * kSlotFloats,
+                          sB + (nstep & 1) * kSlotFloats, kSlotFloats, tid);
+            }
+            const float* sa = sA + c * kChunkPos * kBM + ty * kTM;
+            const float* sb = sB + (step & 1) * kSlotFloats + tx * kTN;
+#pragma unroll
+            for (int gi = 0; gi < kChunkPos / OT::kGroupPos; ++gi) {
+                float s[kTM][kTN];
+                group_chains<ORDER>(sa + gi * OT::kGroupPos * kBM, sb + gi * OT::kGroupPos * kBN, s);
+                // balanced in-order tree over the groups (binary-counter stack)
+                const int g = c * (kChunkPos / OT::kGroupPos) + gi;
+                if ((g & 1) == 0) {
+#pragma unroll
+                    for (int i = 0; i < kTM; ++i)
+#pragma unroll
+                        for (int j = 0; j < kTN; ++j) lvl0[i][j] = s[i][j];
+                } else if ((g & 2) == 0) {
+#pragma unroll
+                    for (int i = 0; i < kTM; ++i)
+#pragma unroll
+                        for (int j = 0; j < kTN; ++j) lvl1[i][j] = lvl0[i][j] + s[i][j];
+                } else if (OT::kGroups == 4 || (g & 4) != 0) {
+#pragma unroll
+                    for (int i = 0; i < kTM; ++i)
+#pragma unroll
+                        for (int j = 0; j < kTN; ++j) {
+                            float r = lvl1[i][j] + (lvl0[i][j] + s[i][j]);
+                            if (OT::kGroups == 8) r = lvl2[i][j] + r;
+                            fin[i][j] = r;
+                        }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < kTM; ++i)
+#pragma unroll
+                        for (int j = 0; j < kTN; ++j) lvl2[i][j] = lvl1[i][j] + (lvl0[i][j] + s[i][j]);
+                }
+            }
+        }
+
+        // ---- tile epilogue -------------------------------------------------------------
+        const int col0 = bt * kBN + tx * kTN;  // first B row (train index) of this thread
+        if ((bt + 1) * kBN > pd.n2 || (item.a_blk + 1) * kBM > pd.n1) {
+#pragma unroll
+            for (int i = 0; i < kTM; ++i)
+#pragma unroll
+                for (int j = 0; j < kTN; ++j)
+                    if (row0 + i >= pd.n1 || col0 + j >= pd.n2) fin[i][j] = f_inf();
+        }
+        // rows: this thread's 4 train indices, ascending
+#pragma unroll
+        for (int i = 0; i < kTM; ++i)
+#pragma unroll
+            for (int j = 0; j < kTN; ++j) top2_push(r_s0[i], r_i0[i], r_s1[i], fin[i][j], col0 + j);
+        // columns: this thread's 8 query indices, ascending; then the partner half-wave
+        // (ty^1, higher rows for the upper half), then the 8 waves through LDS
+#pragma unroll
+        for (int j = 0; j < kTN; ++j) {
+            float c_s0 = f_inf(), c_s1 = f_inf();
+            int c_i0 = -1;
+#pragma unroll
+            for (int i = 0; i < kTM; ++i) top2_push(c_s0, c_i0, c_s1, fin[i][j], row0 + i);
+            const float o_s0 = __shfl_xor(c_s0, 32);
+            const int o_i0 = __shfl_xor(c_i0, 32);
+            const float o_s1 = __shfl_xor(c_s1, 32);
+            top2_merge(c_s0, c_i0, c_s1, o_s0, o_i0, o_s1);
+            if ((tid & 32) == 0) {
+                const int cc = tx * kTN + j;
+                sC[(wave * 3 + 0) * kBN + cc] = c_s0;
+                sC[(wave * 3 + 1) * kBN + cc] = __int_as_float(c_i0);
+                sC[(wave * 3 + 2) * kBN + cc] = c_s1;
+            }
+        }
+        __syncthreads();
+        if (tid < kBN) {
+            float c_s0 = sC[0 * kBN + tid];
+            int c_i0 = __float_as_int(sC[1 * kBN + tid]);
+            float c_s1 = sC[2 * kBN + tid];
+#pragma unroll
+            for (int w = 1; w < 8; ++w)
+                top2_merge(c_s0, c_i0, c_s1, sC[(w * 3 + 0) * kBN + tid],
+                           __float_as_int(sC[(w * 3 + 1) * kBN + tid]), sC[(w * 3 + 2) * kBN + tid]);
+            const long long o = pd.cp_off + (long long)item.a_blk * pd.n2pad + bt * kBN + tid;
+            cp_s0[o] = c_s0;
+            cp_i0[o] = c_i0;
+            cp_s1[o] = c_s1;
+        }
+        // sC is next written after kChunks more barriers: no extra barrier needed here
+    }
+
+    // ---- rows: merge the 32 tx lanes that share this thread's 8 A rows --------------------
+#pragma unroll
+    for (int i = 0; i < kTM; ++i) {
+#pragma unroll
+        for (int m = 1; m < 32; m <<= 1) {
+            const float o_s0 = __shfl_xor(r_s0[i], m);
+            const int o_i0 = __shfl_xor(r_i0[i], m);
+            const float o_s1 = __shfl_xor(r_s1[i], m);
+            top2_merge(r_s0[i], r_i0[i], r_s1[i], o_s0, o_i0, o_s1);
+        }
+    }
+    if (tx == 0) {
+        const long long o = pd.rp_off + (long long)item.range * pd.n1pad + row0;
+#pragma unroll
+        for (int i = 0; i < kTM; ++i) {
+            rp_s0[o + i] = r_s0[i];
+            rp_i0[o + i] = r_i0[i];
+            rp_s1[o + i] = r_s1[i];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// merge_knn_kernel: fold the partials of one pair into the final knnMatch(k=2) result per
+// query (forward) and per train row (reverse): idx0, d0 = sqrtf(S0), d1 = sqrtf(S1).
+// Rows whose two best distances collide in sqrt space are queued for tie_fixup_kernel.
+// grid = (ceil(max(n1pad,n2pad)/256), n_pairs)
+// ---------------------------------------------------------------------------------------
+__global__ void merge_knn_kernel(const PairDesc* __restrict__ pairs,
+                                 const float* __restrict__ rp_s0, const int* __restrict__ rp_i0,
+                                 const float* __restrict__ rp_s1, const float* __restrict__ cp_s0,
+                                 const int* __restrict__ cp_i0, const float* __restrict__ cp_s1,
+                                 int* __restrict__ k_i0, float* __restrict__ k_d0, float* __restrict__ k_d1,
+                                 int* __restrict__ fix_count, int4* __restrict__ fix_list, int fix_cap) {
+    const PairDesc pd = pairs[blockIdx.y];
+    if (!pd.valid) return;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    for (int dir = 0; dir < 2; ++dir) {
+        const int n = dir == 0 ? pd.n1 : pd.n2;
+        if (e >= n) continue;
+        const int npad = dir == 0 ? pd.n1pad : pd.n2pad;
+        const int parts = dir == 0 ? pd.ranges : pd.a_blocks;
+        const long long base = (dir == 0 ? pd.rp_off : pd.cp_off) + e;
+        const float* ps0 = dir == 0 ? rp_s0 : cp_s0;
+        const int* pi0 = dir == 0 ? rp_i0 : cp_i0;
+        const float* ps1 = dir == 0 ? rp_s1 : cp_s1;
+        float s0 = ps0[base], s1 = ps1[base];
+        int i0 = pi0[base];
+        for (int p = 1; p < parts; ++p) {
+            const long long o = base + (long long)p * npad;
+            top2_merge(s0, i0, s1, ps0[o], pi0[o], ps1[o]);
+        }
+        // FLT_MAX / -1 where batchDistance leaves its initial values (fewer than k neighbours)
+        const float d0 = (s0 < f_inf()) ? sqrtf(s0) : 3.402823466e+38f;
+        const float d1 = (s1 < f_inf()) ? sqrtf(s1) : 3.402823466e+38f;
+        if (!(s0 < f_inf())) i0 = -1;
+        const long long ko = (dir == 0 ? pd.kf_off : pd.kr_off) + e;
+        k_i0[ko] = i0;
+        k_d0[ko] = d0;
+        k_d1[ko] = d1;
+        // knnMatch orders by (sqrtf(S), index): if the two best collide after sqrt, a lower
+        // index with a slightly larger S but the same sqrtf may be the true first neighbour.
+        if (i0 >= 0 && d0 == d1) {
+            const int slot = atomicAdd(fix_count, 1);
+            if (slot < fix_cap) fix_list[slot] = make_int4((int)blockIdx.y, dir, e, 0);
+        }
+    }
+}
+
+// exact-order S for two row-major descriptors (used only on the rare tie path)
+template <int ORDER>
+__device__ float l2sqr_rowmajor(const float* __restrict__ a, const float* __restrict__ b) {
+    using OT = OrderTraits<ORDER>;
+    float lvl[3] = {0.f, 0.f, 0.f};
+    float fin = 0.f;
+    for (int g = 0; g < OT::kGroups; ++g) {
+        float s = 0.f;
+        for (int v = 0; v < 4; ++v) {
+            float p = 0.f;
+            for (int it = 0; it < OT::kIters; ++it) {
+                const int k = OT::pos_to_k(g * OT::kGroupPos + v * OT::kIters + it);
+                const float t = a[k] - b[k];
+                if (it == 0) p = t * t;
+                else if (OT::kFused) p = __builtin_fmaf(t, t, p);
+                else p = p + t * t;
+            }
+            s = (v == 0) ? p : s + p;
+        }
+        if ((g & 1) == 0) lvl[0] = s;
+        else if ((g & 2) == 0) lvl[1] = lvl[0] + s;
+        else if (OT::kGroups == 4 || (g & 4) != 0) {
+            float r = lvl[1] + (lvl[0] + s);
+            if (OT::kGroups == 8) r = lvl[2] + r;
+            fin = r;
+        } else lvl[2] = lvl[1] + (lvl[0] + s);
+    }
+    return fin;
+}
+
+// one 64-lane workgroup per queued row: lowest index whose sqrtf(S) equals d0
+template <int ORDER>
+__global__ void tie_fixup_kernel(const PairDesc* __restrict__ pairs, const int* __restrict__ fix_count,
+                                 const int4* __restrict__ fix_list, int fix_cap,
+                                 int* __restrict__ k_i0, const float* __restrict__ k_d0) {
+    const int nfix = min(*fix_count, fix_cap);
+    for (int f = blockIdx.x; f < nfix; f += gridDim.x) {
+        const int4 w = fix_list[f];
+        const PairDesc pd = pairs[w.x];
+        const bool fwd = (w.y == 0);
+        const float* me = (fwd ? pd.a_raw : pd.b_raw) + (size_t)w.z * kDim;
+        const float* other = fwd ? pd.b_raw : pd.a_raw;
+        const int n_other = fwd ? pd.n2 : pd.n1;
+        const long long ko = (fwd ? pd.kf_off : pd.kr_off) + w.z;
+        const float d0 = k_d0[ko];
+        int best = 0x7fffffff;
+        for (int t = threadIdx.x; t < n_other; t += 64) {
+            // forward: S(q=me, t); reverse: S(q=other row, t=me) -- same bits, (a-b)^2 == (b-a)^2
+            const float s = fwd ? l2sqr_rowmajor<ORDER>(me, other + (size_t)t * kDim)
+                                : l2sqr_rowmajor<ORDER>(other + (size_t)t * kDim, me);
+            if (sqrtf(s) == d0) { best = t; break; }  // ascending t per lane: first hit is the lane's lowest
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) best = min(best, __shfl_xor(best, m));
+        if (threadIdx.x == 0 && best != 0x7fffffff) k_i0[ko] = best;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// epilogue_kernel: one workgroup per pair.  Lowe ratio both directions, CrossCheck with the
+// reference's operator[] quirk (missing key reads 0), max-distance cut, ordered compaction.
+// ---------------------------------------------------------------------------------------
+struct EpiParams {
+    float ratio;
+    int cross_check;
+    double max_distance;
+};
+
+__global__ __launch_bounds__(256) void epilogue_kernel(const PairDesc* __restrict__ pairs, EpiParams prm,
+                                                       const int* __restrict__ k_i0,
+                                                       const float* __restrict__ k_d0,
+                                                       const float* __restrict__ k_d1,
+                                                       int2* __restrict__ st_qt, float* __restrict__ st_d,
+                                                       int* __restrict__ counts) {
+    const PairDesc pd = pairs[blockIdx.x];
+    __shared__ int wsum[4];
+    __shared__ int running;
+    if (threadIdx.x == 0) running = 0;
+    __syncthreads();
+    if (!pd.valid) {
+        if (threadIdx.x == 0) counts[blockIdx.x] = 0;
+        return;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int q0 = 0; q0 < pd.n1; q0 += 256) {
+        const int q = q0 + threadIdx.x;
+        bool keep = false;
+        int t = -1;
+        float d0 = 0.f;
+        if (q < pd.n1) {
+            t = k_i0[pd.kf_off + q];
+            d0 = k_d0[pd.kf_off + q];
+            const float d1 = k_d1[pd.kf_off + q];
+            // m[0].distance < distance_ratio * m[1].distance, fp32 product, strict
+            keep = (t >= 0) && (d1 < 3.402823466e+38f) && (d0 < prm.ratio * d1);
+            if (keep && prm.cross_check) {
+                const int rq = k_i0[pd.kr_off + t];
+                const float rd0 = k_d0[pd.kr_off + t];
+                const float rd1 = k_d1[pd.kr_off + t];
+                const bool rkeep = (rq >= 0) && (rd1 < 3.402823466e+38f) && (rd0 < prm.ratio * rd1);
+                const int vis = rkeep ? rq : 0;  // unordered_map::operator[] default-inserts 0
+                keep = (vis == q);
+            }
+            if (keep && ((double)d0 > prm.max_distance)) keep = false;
+        }
+        const unsigned long long bal = __ballot(keep);
+        const int before = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) wsum[wave] = __popcll(bal);
+        __syncthreads();
+        int off = running;
+        for (int w = 0; w < wave; ++w) off += wsum[w];
+        if (keep) {
+            st_qt[pd.out_off + off + before] = make_int2(q, t);
+            st_d[pd.out_off + off + before] = d0;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) running += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) counts[blockIdx.x] = running;
+}
+
+// exclusive scan of per-pair counts (single workgroup; P is at most a few thousand per batch)
+__global__ void scan_counts_kernel(const int* __restrict__ counts, long long* __restrict__ offsets, int n) {
+    __shared__ long long carry;
+    __shared__ long long wtot[4];
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int base = 0; base < n; base += 256) {
+        const int i = base + threadIdx.x;
+        long long v = (i < n) ? counts[i] : 0;
+        long long incl = v;
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) {
+            const long long o = __shfl_up(incl, m);
+            if (lane >= m) incl += o;
+        }
+        if (lane == 63) wtot[wave] = incl;
+        __syncthreads();
+        long long woff = carry;
+        for (int w = 0; w < wave; ++w) woff += wtot[w];
+        if (i < n) offsets[i] = woff + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 0) carry += wtot[0] + wtot[1] + wtot[2] + wtot[3];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) offsets[n] = carry;
+}
+
+// copy each pair's staged matches to its CSR position
+__global__ void gather_kernel(const PairDesc* __restrict__ pairs, const int* __restrict__ counts,
+                              const long long* __restrict__ offsets, const int2* __restrict__ st_qt,
+                              const float* __restrict__ st_d, int2* __restrict__ out_qt,
+                              float* __restrict__ out_d) {
+    const PairDesc pd = pairs[blockIdx.x];
+    const int c = counts[blockIdx.x];
+    const long long o = offsets[blockIdx.x];
+    for (int i = threadIdx.x; i < c; i += blockDim.x) {
+        out_qt[o + i] = st_qt[pd.out_off + i];
+        out_d[o + i] = st_d[pd.out_off + i];
+    }
+}
+
+}  // namespace msfm
