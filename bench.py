@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""bench.py -- ComputeMatches hot path on MI355X: descriptor-pairs/s (and image-pairs/s).
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+Workload (BASELINE.json configs[1]): South-Building-shaped job -- 128 images, ~5k 128-D float32
+RootSIFT-like descriptors each (seeded synthetic), brute-force all pairs
+(8128 image pairs, pre-emptive filter off), reference defaults ratio 0.8 / cross-check / 0.7.
+One "step" = the whole job: every pair through distance + kNN-2 both directions + ratio +
+cross-check + distance cut, match lists back on the host (and, for N > 1, all-gathered over RCCL).
+Descriptors are resident in HBM before the timed region.  The same total job is split over the
+ranks at N > 1 ("strong" scaling).
+
+Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel (dist_top2_kernel), timed
+with HIP events on the library's own stream inside the timed region; `cpu_baseline` is the CPU
+oracle ("port": a restatement of the OpenCV BFMatcher path, not OpenCV itself) on a bounded
+sample of the same pairs, on this box's host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FLOPS_PER_DESC_PAIR = 384.0   # 128 x (sub, mul, add), not fused (direct form)
+PEAK_FP32_VALU_TFLOPS = 157.3  # MI355X_MICROARCH.md: peak FP32 vector (FMA = 2 flop) = f32 MFMA rate
+PEAK_HBM_GBPS = 8000.0
+
+
+def build_workload(args):
+    from monocularsfm_amd import synth
+    rng = np.random.default_rng(args.seed)
+    if args.workload == "south-building":
+        n_images = args.images or 128
+        counts = rng.integers(4600, 5401, n_images) if args.desc is None else np.full(n_images, args.desc)
+        imgs = synth.rootsift_images(n_images, counts.tolist(), seed=args.seed, n_proto=20000, sigma=0.05)
+        name = "south-building-shaped synthetic: %d images x ~%d f32 RootSIFT-like desc, brute-force all pairs" % (
+            n_images, int(np.mean(counts)))
+    elif args.workload == "synthetic-u8":
+        n_images = args.images or 64
+        nd = args.desc or 8192
+        imgs = synth.u8_images(n_images, nd, seed=args.seed, as_float=True)
+        name = "synthetic u8-valued: %d images x %d desc (f32-holding-integers), brute-force all pairs" % (n_images, nd)
+    else:
+        raise SystemExit("unknown workload " + args.workload)
+    pairs = np.array([(i, j) for i in range(n_images) for j in range(i)], np.int32)
+    return imgs, pairs, name
+
+
+def cpu_baseline(imgs, pairs, budget_s=20.0, max_pairs=256, seed=0):
+    """CPU oracle on a seeded sample of the same pairs, all host hardware threads."""
+    from oracle import c_oracle as co
+    co.build()
+    threads = os.cpu_count() or 1
+    rng = np.random.default_rng(seed)
+    order = rng.permutation(len(pairs))
+    # calibrate on one pair, then size the sample to the budget
+    i, j = pairs[order[0]]
+    t0 = time.perf_counter()
+    co.match_pair(imgs[i], imgs[j], nthreads=threads)
+    t1 = time.perf_counter() - t0
+    n = int(max(4, min(max_pairs, budget_s / max(t1, 1e-4))))
+    sample = order[:n]
+    work = 0
+    t0 = time.perf_counter()
+    for p in sample:
+        i, j = pairs[p]
+        co.match_pair(imgs[i], imgs[j], nthreads=threads)
+        work += len(imgs[i]) * len(imgs[j])
+    dt = time.perf_counter() - t0
+    # single-thread figure on a few pairs (the reference's own code is single-threaded; OpenCV's
+    # batchDistance may fan out over its thread pool)
+    k = min(2, n)
+    t0 = time.perf_counter()
+    w1 = 0
+    for p in sample[:k]:
+        i, j = pairs[p]
+        co.match_pair(imgs[i], imgs[j], nthreads=1)
+        w1 += len(imgs[i]) * len(imgs[j])
+    dt1 = time.perf_counter() - t0
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {
+        "value": work / dt, "unit": "descriptor-pairs/s", "cores": threads, "kind": "port",
+        "sample": "%d of %d image pairs (seeded), both kNN-2 sweeps + ratio + cross-check + distance cut per pair, "
+                  "%.1f s wall; restated CPU BFMatcher (SSE order, pthreads over query rows), not OpenCV" % (n, len(pairs), dt),
+        "image_pairs_per_s": n / dt, "single_thread_value": w1 / dt1, "cpu_model": model,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="south-building")
+    ap.add_argument("--images", type=int, default=None)
+    ap.add_argument("--desc", type=int, default=None)
+    ap.add_argument("--seed", type=int, default=1234)
+    ap.add_argument("--order", type=int, default=0, help="0: OpenCV SSE order (default), 1: AVX2+FMA order")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=20.0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from monocularsfm_amd import _lib
+    from monocularsfm_amd.sharding import ShardedMatcher
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X; no GPU visible (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    imgs, pairs, wl_name = build_workload(args)
+    n_rows = np.array([len(x) for x in imgs], np.int64)
+    total_desc_pairs = int((n_rows[pairs[:, 0]] * n_rows[pairs[:, 1]]).sum())
+
+    ctx = _lib.Context(local_rank, order=args.order)
+    for i, im in enumerate(imgs):
+        ctx.upload_image(i, im)   # resident in HBM before the timed region
+    sm = ShardedMatcher(ctx=ctx, device=dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    kern_ms, kern_launches, local_pairs_work = 0.0, 0, 0
+    result = None
+    for _ in range(args.warmup):
+        result = sm.match_all(pairs, n_rows)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        result = sm.match_all(pairs, n_rows)
+        p = ctx.profile()
+        kern_ms += p["dist_kernel_ms"]
+        kern_launches += p["dist_kernel_launches"]
+        local_pairs_work += p["descriptor_pairs"]
+        algo_bytes_step = p["dist_algo_bytes"]
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    offs, qt, dd = result
+    n_matches = int(offs[-1])
+
+    value = total_desc_pairs * args.steps / dt
+    out = {
+        "metric": "descriptor-pairs/sec (and image-pairs/sec); match-index bit-parity vs CPU",
+        "value": value, "unit": "descriptor-pairs/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "image_pairs_per_s": len(pairs) * args.steps / dt,
+        "config": {"workload": wl_name, "image_pairs": int(len(pairs)), "descriptor_pairs_per_step": total_desc_pairs,
+                   "matches_per_step": n_matches, "accum_order": "opencv-sse4x4-nofma" if args.order == 0 else "opencv-avx2-fma",
+                   "ratio": 0.8, "cross_check": True, "max_distance": 0.7, "preemptive_filter": False,
+                   "parallelism": "pairs sharded over %d GPU(s), RCCL all-gather of match lists" % world},
+    }
+    if kern_launches > 0:
+        avg_ms = kern_ms / kern_launches
+        flops_per_launch = FLOPS_PER_DESC_PAIR * local_pairs_work / kern_launches
+        achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
+        out["roofline"] = {
+            "kernel": "dist_top2_kernel", "bound": "valu", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS,
+            "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_VALU_TFLOPS, "traffic": None,
+            "avg_launch_ms": avg_ms, "launches": kern_launches,
+            "flops_per_desc_pair": FLOPS_PER_DESC_PAIR,
+            "note": "exact-order path is VALU-bound (arithmetic intensity ~1e3 flop/B); its 384 ops per descriptor pair "
+                    "are unfusable sub/mul/add, so 78.6 TFLOP/s (half the FMA peak) is the attainable ceiling; "
+                    "frac_of_nofma_ceiling reports against that",
+            "frac_of_nofma_ceiling": achieved / (PEAK_FP32_VALU_TFLOPS / 2),
+            "hbm": {"algorithmic_bytes_per_launch": algo_bytes_step / max(1, kern_launches // args.steps) if args.steps else None,
+                    "achieved_GBps": (algo_bytes_step * args.steps / (kern_ms * 1e-3)) / 1e9, "peak_GBps": PEAK_HBM_GBPS,
+                    "frac": (algo_bytes_step * args.steps / (kern_ms * 1e-3)) / 1e9 / PEAK_HBM_GBPS},
+        }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(imgs, pairs, budget_s=args.cpu_budget)
+        out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -91,7 +91,9 @@ int msfm_clear_images(msfm_ctx* ctx);
  * 141-174) followed by FilterMatchesByDistance (:208-218), i.e. lines 36-49 of
  * FeatureMatching.cpp.  query = id1, train = id2.  out_qt receives (queryIdx, trainIdx) int32
  * pairs in ascending queryIdx (capacity: rows(id1) pairs); out_dist (nullable) the DMatch
- * distances.  A side with < 2 rows yields no matches (the reference is undefined there). */
+ * distances.  The reference indexes the 2nd neighbour unconditionally (FeatureUtils.cpp:152), so a
+ * direction whose train set has < 2 rows is undefined there; here it yields no matches, and a
+ * cross-checked pair with such a direction yields none at all.  Empty sides => no matches. */
 int msfm_match_pair(msfm_ctx* ctx, int id1, int id2, float ratio, int cross_check,
                     double max_distance, int32_t* out_qt, float* out_dist, int* out_count);
 

@@ -72,7 +72,7 @@ struct PairDesc {
     int a_blocks, b_tiles;
     int n1pad, n2pad;
     int ranges;            // B-tile ranges the pair was split into
-    int valid;             // 0: a side has < 2 rows -> no matches, no device work
+    int valid;             // 0: a side is empty -> no neighbours, no device work
     long long rp_off;      // row partials  [ranges][n1pad]
     long long cp_off;      // column partials [a_blocks][n2pad]
     long long kf_off;      // final forward knn arrays [n1pad]
@@ -475,7 +475,10 @@ __global__ __launch_bounds__(256) void epilogue_kernel(const PairDesc* __restric
     __shared__ int running;
     if (threadIdx.x == 0) running = 0;
     __syncthreads();
-    if (!pd.valid) {
+    // The reference indexes m[1] unconditionally (FeatureUtils.cpp:152): a direction whose train
+    // set has < 2 rows is undefined there.  Build-defined: that direction yields no matches, and a
+    // cross-checked pair with such a direction yields none at all.
+    if (!pd.valid || pd.n2 < 2 || (prm.cross_check && pd.n1 < 2)) {
         if (threadIdx.x == 0) counts[blockIdx.x] = 0;
         return;
     }

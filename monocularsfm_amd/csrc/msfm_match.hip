@@ -154,9 +154,8 @@ int fill_pair(msfm_ctx* ctx, int id1, int id2, PairDesc& pd) {
     pd.n1pad = a.nblk * kBM;
     pd.n2pad = b.nblk * kBN;
     pd.ranges = 1;
-    // the reference indexes m[1] unconditionally (FeatureUtils.cpp:152): undefined for < 2 train
-    // rows.  Build-defined: such a pair has no matches and no neighbours.
-    pd.valid = (a.n >= 2 && b.n >= 2) ? 1 : 0;
+    // empty query or train set: knnMatch returns nothing, no device work
+    pd.valid = (a.n >= 1 && b.n >= 1) ? 1 : 0;
     return MSFM_OK;
 }
 
@@ -575,7 +574,7 @@ int msfm_knn2_pair(msfm_ctx* ctx, int id1, int id2, int32_t* fwd_idx0, float* fw
     const PairDesc& q = b.pairs[0];
     const int n1 = ctx->images[id1].n, n2 = ctx->images[id2].n;
     if (!q.valid) {
-        // a side with < 2 rows: no neighbours reported (build-defined, see header)
+        // an empty side: no neighbours
         for (int i = 0; i < n1; ++i) {
             if (fwd_idx0) fwd_idx0[i] = -1;
             if (fwd_d0) fwd_d0[i] = 3.402823466e+38f;

@@ -1,0 +1,154 @@
+"""Multi-GPU sharding of the all-pairs job: one process per GPU, torch.distributed (RCCL) gather.
+
+The reference is single-process; image pairs are independent
+(/root/reference/src/Feature/FeatureMatching.cpp:14), so the pair list is partitioned and the
+only exchange step is an all-gather of the per-pair match lists at the end:
+
+  1. every rank holds the full descriptor store (<= 34 GB even for the largest config, vs 288 GB HBM);
+  2. the lower-triangular pair matrix is cut into square image tiles (32 x 32 images), tile costs
+     sum n_i * n_j, tiles are dealt to ranks by a deterministic longest-processing-time rule;
+  3. each rank runs its pairs through the C ABI;
+  4. counts: one all_reduce(sum) of a per-pair count vector; payload: one all_gather of the
+     rank-padded (queryIdx, trainIdx, distance-bits) int32 triples.  The payload is KBs-MBs, i.e.
+     latency-bound on xGMI -- no bucketing needed.
+
+`torch` is used for the process group and the device tensors of the collectives only.
+"""
+import numpy as np
+
+TILE = 32
+
+
+def partition_pairs(pairs, n_rows, world_size, tile=TILE):
+    """-> list (per rank) of int64 index arrays into `pairs`, each ascending.
+
+    pairs: P x 2 image ids; n_rows: mapping/array image id -> descriptor count."""
+    pairs = np.asarray(pairs, dtype=np.int64).reshape(-1, 2)
+    P = pairs.shape[0]
+    if world_size <= 1 or P == 0:
+        return [np.arange(P, dtype=np.int64)] + [np.zeros(0, np.int64) for _ in range(max(world_size - 1, 0))]
+    n_rows = np.asarray(n_rows, dtype=np.int64)
+    cost = n_rows[pairs[:, 0]] * n_rows[pairs[:, 1]]
+    # tile key of a pair (order of ids does not matter)
+    hi = np.maximum(pairs[:, 0], pairs[:, 1]) // tile
+    lo = np.minimum(pairs[:, 0], pairs[:, 1]) // tile
+    key = hi * (1 << 20) + lo
+    uniq, inv = np.unique(key, return_inverse=True)
+    tile_cost = np.bincount(inv, weights=cost.astype(np.float64), minlength=len(uniq))
+    # split tiles whose cost exceeds a fair share so that small jobs still use every rank
+    fair = tile_cost.sum() / world_size
+    order = np.lexsort((uniq, -tile_cost))  # cost descending, key ascending: deterministic
+    load = np.zeros(world_size)
+    owner_of_pair = np.empty(P, np.int64)
+    by_tile = np.argsort(inv, kind="stable")
+    starts = np.searchsorted(inv[by_tile], np.arange(len(uniq) + 1))
+    for t in order:
+        members = by_tile[starts[t]:starts[t + 1]]
+        if tile_cost[t] > 0.5 * fair and len(members) > 1:
+            # deal the pairs of a heavy tile one by one
+            for m in members[np.argsort(-cost[members], kind="stable")]:
+                r = int(np.argmin(load))
+                owner_of_pair[m] = r
+                load[r] += cost[m]
+        else:
+            r = int(np.argmin(load))
+            owner_of_pair[members] = r
+            load[r] += tile_cost[t]
+    return [np.nonzero(owner_of_pair == r)[0].astype(np.int64) for r in range(world_size)]
+
+
+def gather_matches(local_idx, local_offs, local_qt, local_dist, n_pairs, group=None, device=None):
+    """All-gather the per-pair match lists.  Every rank returns the full CSR
+    (offsets int64[P+1], qt int32[M,2], dist float32[M]) in global pair order."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    local_idx = np.asarray(local_idx, np.int64)
+    local_counts = np.diff(np.asarray(local_offs, np.int64))
+    if world == 1:
+        offs = np.zeros(n_pairs + 1, np.int64)
+        cnt = np.zeros(n_pairs, np.int64)
+        cnt[local_idx] = local_counts
+        np.cumsum(cnt, out=offs[1:])
+        # local results are in local_idx order; local_idx ascending => already global order
+        return offs, np.asarray(local_qt, np.int32).reshape(-1, 2), np.asarray(local_dist, np.float32)
+    dev = device if device is not None else torch.device("cpu")
+    rank = dist.get_rank(group)
+
+    # (1) counts + owner of every pair
+    counts = torch.zeros(n_pairs, dtype=torch.int32)
+    owner = torch.zeros(n_pairs, dtype=torch.int32)
+    counts[torch.from_numpy(local_idx)] = torch.from_numpy(local_counts.astype(np.int32))
+    owner[torch.from_numpy(local_idx)] = rank
+    co = torch.stack([counts, owner]).to(dev)
+    dist.all_reduce(co, op=dist.ReduceOp.SUM, group=group)
+    co = co.cpu().numpy()
+    counts_all, owner_all = co[0].astype(np.int64), co[1].astype(np.int64)
+
+    # (2) payload, padded to the largest rank
+    per_rank_total = np.bincount(owner_all, weights=counts_all, minlength=world).astype(np.int64)
+    max_m = int(per_rank_total.max()) if world > 0 else 0
+    send = torch.zeros((max(max_m, 1), 3), dtype=torch.int32)
+    m_local = int(local_counts.sum())
+    if m_local:
+        send[:m_local, 0:2] = torch.from_numpy(np.ascontiguousarray(local_qt, dtype=np.int32).reshape(-1, 2))
+        send[:m_local, 2] = torch.from_numpy(np.ascontiguousarray(local_dist, dtype=np.float32).view(np.int32))
+    send = send.to(dev)
+    recv = torch.empty((world,) + tuple(send.shape), dtype=torch.int32, device=dev)
+    # list form: supported by both RCCL ("nccl") and gloo (the CPU tests)
+    dist.all_gather([recv[r] for r in range(world)], send, group=group)
+    recv = recv.cpu().numpy()
+
+    # (3) reassemble in global pair order
+    offs = np.zeros(n_pairs + 1, np.int64)
+    np.cumsum(counts_all, out=offs[1:])
+    M = int(offs[-1])
+    qt = np.empty((M, 2), np.int32)
+    dd = np.empty(M, np.int32)
+    for r in range(world):
+        idx = np.nonzero(owner_all == r)[0]  # ascending == that rank's local order
+        if len(idx) == 0:
+            continue
+        c = counts_all[idx]
+        src_off = np.concatenate([[0], np.cumsum(c)])
+        # vectorised scatter of rank r's rows to their global positions
+        dst = np.repeat(offs[idx] - src_off[:-1], c) + np.arange(int(src_off[-1]))
+        qt[dst] = recv[r, :int(src_off[-1]), 0:2]
+        dd[dst] = recv[r, :int(src_off[-1]), 2]
+    return offs, qt, dd.view(np.float32)
+
+
+class ShardedMatcher:
+    """All-pairs matching over the ranks of a torch.distributed process group.
+
+    match_fn(pairs_subset) -> (offsets, qt, dist) defaults to the GPU context's match_pairs;
+    the CPU (gloo) tests inject a stand-in to exercise partition + gather without a GPU."""
+
+    def __init__(self, ctx=None, match_fn=None, group=None, device=None, **match_kw):
+        if ctx is None and match_fn is None:
+            raise ValueError("need a GPU context or a match_fn")
+        self.ctx = ctx
+        self.group = group
+        self.device = device
+        self.match_kw = match_kw
+        self.match_fn = match_fn if match_fn is not None else (lambda p: ctx.match_pairs(p, **match_kw))
+
+    def _rank_world(self):
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_rank(self.group), dist.get_world_size(self.group)
+        return 0, 1
+
+    def match_local(self, pairs, n_rows):
+        rank, world = self._rank_world()
+        pairs = np.asarray(pairs, np.int32).reshape(-1, 2)
+        mine = partition_pairs(pairs, n_rows, world)[rank]
+        offs, qt, d = self.match_fn(pairs[mine])
+        return mine, offs, qt, d
+
+    def match_all(self, pairs, n_rows):
+        """Every rank returns the complete result for `pairs` (global order)."""
+        pairs = np.asarray(pairs, np.int32).reshape(-1, 2)
+        mine, offs, qt, d = self.match_local(pairs, n_rows)
+        return gather_matches(mine, offs, qt, d, len(pairs), group=self.group, device=self.device)

@@ -1,0 +1,39 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (gfx950); run with -m gpu on the GPU box")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    """The CPU oracle (test infrastructure): builds oracle/libmsfm_oracle.so on first use."""
+    from oracle import c_oracle
+    c_oracle.build()
+    return c_oracle
+
+
+@pytest.fixture(scope="session")
+def built_lib():
+    """The in-tree HIP library; built (cross-compiled) on demand so CPU-only runs can check the ABI."""
+    import subprocess
+    from monocularsfm_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "monocularsfm_amd", "csrc"), "-s"])
+    return _lib.load()
+
+
+@pytest.fixture(scope="session")
+def gpu_ctx(built_lib):
+    """One GPU context for the whole session; fails loudly (no skip, no fallback) without a GPU."""
+    from monocularsfm_amd import _lib
+    ctx = _lib.Context(0)
+    yield ctx
+    ctx.close()

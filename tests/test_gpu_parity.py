@@ -1,0 +1,239 @@
+"""Parity tests proper: the HIP path (through the C ABI) against the CPU oracle, the committed golden
+fixtures, and size-independent properties at BASELINE's full sizes.  Bar: bit-exact -- indices equal,
+distances equal as int32 bit patterns.  All tests need a real MI355X (-m gpu)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from monocularsfm_amd import _lib, synth
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+F32 = np.float32
+FLT_MAX = np.finfo(F32).max
+
+
+def b(a):
+    a = np.asarray(a)
+    return a.view(np.int32) if a.dtype == np.float32 else a
+
+
+def assert_knn_equal(got, exp_idx0, exp_d0, exp_d1):
+    assert np.array_equal(got[0], exp_idx0)
+    assert np.array_equal(b(got[1]), b(exp_d0))
+    assert np.array_equal(b(got[2]), b(exp_d1))
+
+
+def upload_pair(ctx, A, B, ids=(0, 1)):
+    ctx.upload_image(ids[0], A)
+    ctx.upload_image(ids[1], B)
+
+
+# ---- golden fixtures -----------------------------------------------------------------------------
+
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p) for p in GOLDEN])
+@pytest.mark.parametrize("order", [0, 1])
+def test_hip_reproduces_golden(gpu_ctx, path, order):
+    g = np.load(path)
+    gpu_ctx.set_accum_order(order)
+    try:
+        upload_pair(gpu_ctx, g["desc1"], g["desc2"])
+        fwd, rev = gpu_ctx.knn2_pair(0, 1)
+        assert_knn_equal(fwd, g["o%d_fwd_idx0" % order], g["o%d_fwd_d0" % order], g["o%d_fwd_d1" % order])
+        assert_knn_equal(rev, g["o%d_rev_idx0" % order], g["o%d_rev_d0" % order], g["o%d_rev_d1" % order])
+        for cc in (1, 0):
+            q, t, d = gpu_ctx.match_pair(0, 1, 0.8, bool(cc), float(g["max_distance"]))
+            assert np.array_equal(q, g["o%d_cc%d_q" % (order, cc)])
+            assert np.array_equal(t, g["o%d_cc%d_t" % (order, cc)])
+            assert np.array_equal(b(d), b(g["o%d_cc%d_d" % (order, cc)]))
+    finally:
+        gpu_ctx.set_accum_order(0)
+
+
+def test_u8_upload_equals_float_upload(gpu_ctx):
+    g = np.load([p for p in GOLDEN if "u8_ties" in p][0])
+    A, B = g["desc1"], g["desc2"]
+    assert (A == np.rint(A)).all()
+    upload_pair(gpu_ctx, A.astype(np.uint8), B.astype(np.uint8))
+    fwd, rev = gpu_ctx.knn2_pair(0, 1)
+    assert_knn_equal(fwd, g["o0_fwd_idx0"], g["o0_fwd_d0"], g["o0_fwd_d1"])
+    assert_knn_equal(rev, g["o0_rev_idx0"], g["o0_rev_d0"], g["o0_rev_d1"])
+
+
+# ---- seeded inputs vs the oracle -------------------------------------------------------------------
+
+SHAPES = [(600, 500), (129, 257), (128, 128), (127, 1), (1, 127), (2, 2), (1000, 77), (384, 2049), (3000, 2900)]
+
+
+@pytest.mark.parametrize("order", [0, 1])
+@pytest.mark.parametrize("shape", SHAPES, ids=["%dx%d" % s for s in SHAPES])
+def test_knn2_and_matches_vs_oracle(gpu_ctx, oracle, shape, order):
+    n1, n2 = shape
+    imgs = synth.rootsift_images(2, [n1, n2], seed=n1 * 7 + n2, n_proto=max(n1, n2) * 2)
+    gpu_ctx.set_accum_order(order)
+    try:
+        upload_pair(gpu_ctx, imgs[0], imgs[1])
+        fwd, rev = gpu_ctx.knn2_pair(0, 1)
+        # K = min(2, rows): a 1-row train set reports one neighbour (idx1 = -1, d1 = FLT_MAX)
+        oi0, od0, _, od1 = oracle.knn2(imgs[0], imgs[1], order, 8)
+        pi0, pd0, _, pd1 = oracle.knn2(imgs[1], imgs[0], order, 8)
+        assert_knn_equal(fwd, oi0, od0, od1)
+        assert_knn_equal(rev, pi0, pd0, pd1)
+        for cc in (True, False):
+            q, t, d = gpu_ctx.match_pair(0, 1, 0.8, cc, 0.7)
+            oq, ot, od = oracle.match_pair(imgs[0], imgs[1], 0.8, cc, 0.7, order, 8)
+            assert np.array_equal(q, oq) and np.array_equal(t, ot) and np.array_equal(b(d), b(od))
+    finally:
+        gpu_ctx.set_accum_order(0)
+
+
+def test_params_ratio_and_max_distance(gpu_ctx, oracle):
+    imgs = synth.rootsift_images(2, [700, 640], seed=77, n_proto=1400)
+    upload_pair(gpu_ctx, imgs[0], imgs[1])
+    for ratio, md in [(0.5, 0.7), (0.95, 0.3), (1.0, 0.05), (0.8, 0.0), (0.8, float("inf"))]:
+        q, t, d = gpu_ctx.match_pair(0, 1, ratio, True, md)
+        oq, ot, od = oracle.match_pair(imgs[0], imgs[1], ratio, True, md, 0, 8)
+        assert np.array_equal(q, oq) and np.array_equal(t, ot) and np.array_equal(b(d), b(od))
+
+
+def test_empty_images(gpu_ctx):
+    A = synth.rootsift_images(1, [50], seed=1)[0]
+    gpu_ctx.upload_image(0, A)
+    gpu_ctx.upload_image(1, np.zeros((0, 128), F32))
+    assert len(gpu_ctx.match_pair(0, 1)[0]) == 0
+    assert len(gpu_ctx.match_pair(1, 0)[0]) == 0
+    assert len(gpu_ctx.match_pair(1, 1)[0]) == 0
+    with pytest.raises(_lib.MsfmError):
+        gpu_ctx.match_pair(0, 4321)  # never uploaded
+
+
+def test_exact_duplicates_and_sqrt_space_ties(gpu_ctx, oracle):
+    rng = np.random.default_rng(5)
+    A = synth.rootsift_images(1, [300], seed=9)[0]
+    B = A[rng.permutation(300)][:260].copy()
+    B[17] = B[3]; B[200] = B[3]; B[201] = B[3]          # 4 identical train rows
+    A[5] = B[3]                                         # query with four zero-distance neighbours
+    # near-tie cluster: rows whose S differ in the last bits (sqrtf may merge them)
+    base = A[40].copy()
+    for k, row in enumerate((30, 31, 32, 33)):
+        v = base.copy()
+        v[k] = np.nextafter(v[k], F32(2.0))
+        B[row] = v
+    upload_pair(gpu_ctx, A, B)
+    fwd, rev = gpu_ctx.knn2_pair(0, 1)
+    oi0, od0, _, od1 = oracle.knn2(A, B, 0, 8)
+    pi0, pd0, _, pd1 = oracle.knn2(B, A, 0, 8)
+    assert_knn_equal(fwd, oi0, od0, od1)
+    assert_knn_equal(rev, pi0, pd0, pd1)
+    assert fwd[0][5] == 3 and fwd[1][5] == 0.0 and fwd[2][5] == 0.0
+
+
+def test_integer_descriptors_identical_under_both_orders(gpu_ctx, oracle):
+    u = synth.u8_images(2, [900, 850], seed=31)
+    res = {}
+    for order in (0, 1):
+        gpu_ctx.set_accum_order(order)
+        upload_pair(gpu_ctx, u[0].astype(np.uint8), u[1].astype(np.uint8))
+        res[order] = gpu_ctx.knn2_pair(0, 1)
+    gpu_ctx.set_accum_order(0)
+    for d in (0, 1):
+        for k in range(3):
+            assert np.array_equal(b(res[0][d][k]), b(res[1][d][k]))
+    oi0, od0, _, od1 = oracle.knn2(u[0], u[1], 2, 8)   # plain scalar order: same bits for integers
+    assert_knn_equal(res[0][0], oi0, od0, od1)
+    q, t, d = gpu_ctx.match_pair(0, 1, 0.8, True, 1e9)
+    oq, ot, od = oracle.match_pair(u[0], u[1], 0.8, True, 1e9, 0, 8)
+    assert len(oq) > 20 and np.array_equal(q, oq) and np.array_equal(t, ot) and np.array_equal(b(d), b(od))
+
+
+def test_large_integer_distances_sqrt_collisions(gpu_ctx, oracle):
+    # S >= 2^22: consecutive integers share a sqrtf -> the sqrt-space tie rule decides the index
+    rng = np.random.default_rng(8)
+    A = rng.integers(0, 30, (200, 128)).astype(F32)
+    B = rng.integers(225, 256, (210, 128)).astype(F32)
+    upload_pair(gpu_ctx, A, B)
+    fwd, rev = gpu_ctx.knn2_pair(0, 1)
+    oi0, od0, _, od1 = oracle.knn2(A, B, 0, 8)
+    pi0, pd0, _, pd1 = oracle.knn2(B, A, 0, 8)
+    assert (od0 > 2048).all()
+    assert_knn_equal(fwd, oi0, od0, od1)
+    assert_knn_equal(rev, pi0, pd0, pd1)
+    assert (od0 == od1).sum() > 0, "test construction: expected sqrt collisions"
+
+
+# ---- batches -----------------------------------------------------------------------------------------
+
+def test_batch_equals_single_pairs_and_oracle(gpu_ctx, oracle):
+    sizes = [300, 257, 128, 1, 640, 0, 90, 513]
+    imgs = synth.rootsift_images(len(sizes), sizes, seed=55, n_proto=900)
+    for i, im in enumerate(imgs):
+        gpu_ctx.upload_image(i, im)
+    pairs = np.array([(i, j) for i in range(len(sizes)) for j in range(i)] + [(2, 5), (0, 0), (3, 3)], np.int32)
+    offs, qt, d = gpu_ctx.match_pairs(pairs)
+    assert offs[0] == 0 and len(offs) == len(pairs) + 1 and offs[-1] == len(qt) == len(d)
+    for p, (i, j) in enumerate(pairs):
+        oq, ot, od = oracle.match_pair(imgs[i], imgs[j], nthreads=4)
+        s, e = offs[p], offs[p + 1]
+        assert np.array_equal(qt[s:e, 0], oq) and np.array_equal(qt[s:e, 1], ot) and np.array_equal(b(d[s:e]), b(od)), (i, j)
+        q1, t1, d1 = gpu_ctx.match_pair(int(i), int(j))
+        assert np.array_equal(q1, oq) and np.array_equal(t1, ot)
+    # idempotent
+    offs2, qt2, d2 = gpu_ctx.match_pairs(pairs)
+    assert np.array_equal(offs, offs2) and np.array_equal(qt, qt2) and np.array_equal(b(d), b(d2))
+    # empty batch
+    offs0, qt0, _ = gpu_ctx.match_pairs(np.zeros((0, 2), np.int32))
+    assert list(offs0) == [0] and len(qt0) == 0
+
+
+def test_preemptive_subsets_vs_oracle(gpu_ctx, oracle):
+    """PreemptivelyFilterImagePairs' arithmetic: 100 x 100 cross-matched subsets (FeatureMatching.cpp:148-179)."""
+    imgs = synth.rootsift_images(6, [800, 750, 99, 820, 780, 400], seed=66, n_proto=1300)
+    kp = [synth.keypoints(len(x), seed=600 + i) for i, x in enumerate(imgs)]
+    tops = [x[_lib.topscale_select(k, 100)] for x, k in zip(imgs, kp)]
+    assert tops[2].shape[0] == 99  # 100 > n: whole matrix
+    for i, t_ in enumerate(tops):
+        gpu_ctx.upload_image(_lib.MAX_IMAGES + i, t_)
+    pairs = np.array([(i, j) for i in range(6) for j in range(i)], np.int32)
+    offs, qt, d = gpu_ctx.match_pairs(pairs + _lib.MAX_IMAGES, 0.8, True, float("inf"))
+    for p, (i, j) in enumerate(pairs):
+        oq, ot, od = oracle.match_pair(tops[i], tops[j], 0.8, True, np.inf)
+        assert np.array_equal(qt[offs[p]:offs[p + 1], 0], oq) and np.array_equal(qt[offs[p]:offs[p + 1], 1], ot)
+
+
+# ---- full-size properties (BASELINE config 2 shape: ~5000 descriptors per image) -------------------------
+
+def test_full_size_properties(gpu_ctx, oracle):
+    n1, n2 = 5000, 4873
+    imgs = synth.rootsift_images(2, [n1, n2], seed=1234, n_proto=20000)
+    A, B = imgs
+    upload_pair(gpu_ctx, A, B)
+    fwd, rev = gpu_ctx.knn2_pair(0, 1)
+    # (1) symmetry: forward of (B, A) is bitwise the reverse of (A, B)
+    fwd2, rev2 = gpu_ctx.knn2_pair(1, 0)
+    for k in range(3):
+        assert np.array_equal(b(fwd2[k]), b(rev[k])) and np.array_equal(b(rev2[k]), b(fwd[k]))
+    # (2) sampled rows against the oracle (full train set)
+    rows = np.random.default_rng(0).choice(n1, 96, replace=False)
+    oi0, od0, _, od1 = oracle.knn2(A[rows], B, 0, 8)
+    assert np.array_equal(fwd[0][rows], oi0) and np.array_equal(b(fwd[1][rows]), b(od0)) and np.array_equal(b(fwd[2][rows]), b(od1))
+    cols = np.random.default_rng(1).choice(n2, 96, replace=False)
+    pi0, pd0, _, pd1 = oracle.knn2(B[cols], A, 0, 8)
+    assert np.array_equal(rev[0][cols], pi0) and np.array_equal(b(rev[1][cols]), b(pd0)) and np.array_equal(b(rev[2][cols]), b(pd1))
+    # (3) d0 <= d1, indices in range, every distance is the sqrt of a recomputable S
+    assert (fwd[1] <= fwd[2]).all() and (fwd[0] >= 0).all() and (fwd[0] < n2).all()
+    # (4) permuting the train rows permutes the train indices (no exact ties in this data)
+    perm = np.random.default_rng(2).permutation(n2)
+    gpu_ctx.upload_image(2, B[perm])
+    fwdp, _ = gpu_ctx.knn2_pair(0, 2)
+    assert np.array_equal(perm[fwdp[0]], fwd[0]) and np.array_equal(b(fwdp[1]), b(fwd[1])) and np.array_equal(b(fwdp[2]), b(fwd[2]))
+    # (5) cross-checked matches are mutual nearest neighbours (q != 0, where the operator[] quirk cannot act)
+    q, t, d = gpu_ctx.match_pair(0, 1)
+    assert len(q) > 300 and (np.diff(q) > 0).all()
+    nz = q != 0
+    assert np.array_equal(rev[0][t[nz]], q[nz]) and np.array_equal(fwd[0][q], t) and (d <= F32(0.7)).all()
+    # (6) self-match: every descriptor's nearest neighbour in its own image is itself at distance 0
+    fs, _ = gpu_ctx.knn2_pair(0, 0)
+    assert np.array_equal(fs[0], np.arange(n1)) and (fs[1] == 0).all()

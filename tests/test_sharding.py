@@ -1,0 +1,97 @@
+"""Partition + gather of the multi-GPU path on CPU: world_size 2 over gloo.  The per-rank matcher is
+a stand-in (the oracle) injected by the test; the product default is the GPU context."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_partition_is_a_balanced_disjoint_cover():
+    from monocularsfm_amd.sharding import partition_pairs
+    N = 200
+    rng = np.random.default_rng(0)
+    n_rows = rng.integers(3000, 8000, N)
+    pairs = np.array([(i, j) for i in range(N) for j in range(i)], np.int32)
+    for world in (1, 2, 4, 8):
+        parts = partition_pairs(pairs, n_rows, world)
+        allidx = np.concatenate(parts)
+        assert len(allidx) == len(pairs) and len(np.unique(allidx)) == len(pairs)
+        cost = n_rows[pairs[:, 0]].astype(np.int64) * n_rows[pairs[:, 1]]
+        loads = np.array([cost[p].sum() for p in parts], float)
+        assert loads.max() / loads.mean() < 1.05
+        for p in parts:
+            assert (np.diff(p) > 0).all()
+    # deterministic
+    a = partition_pairs(pairs, n_rows, 8)
+    b = partition_pairs(pairs, n_rows, 8)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    # fewer pairs than ranks
+    parts = partition_pairs(pairs[:3], n_rows, 8)
+    assert sum(len(p) for p in parts) == 3
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from monocularsfm_amd import synth
+    from monocularsfm_amd.sharding import ShardedMatcher
+    from oracle import c_oracle as co
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    imgs = synth.rootsift_images(7, [90, 120, 60, 100, 2, 75, 110], seed=21, n_proto=260)
+    n_rows = np.array([len(x) for x in imgs])
+    pairs = np.array([(i, j) for i in range(7) for j in range(i)], np.int32)
+
+    def match_fn(sub):
+        offs = [0]
+        qs, ds = [], []
+        for i, j in sub:
+            q, t, d = co.match_pair(imgs[i], imgs[j])
+            qs.append(np.stack([q, t], 1).reshape(-1, 2))
+            ds.append(d)
+            offs.append(offs[-1] + len(q))
+        qt = np.concatenate(qs) if qs else np.zeros((0, 2), np.int32)
+        dd = np.concatenate(ds) if ds else np.zeros(0, np.float32)
+        return np.asarray(offs, np.int64), qt, dd
+
+    sm = ShardedMatcher(match_fn=match_fn)
+    offs, qt, d = sm.match_all(pairs, n_rows)
+    np.savez(os.path.join(out_dir, "r%d.npz" % rank), offs=offs, qt=qt, d=d)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gather_equals_single_process(tmp_path, oracle):
+    from monocularsfm_amd import synth
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    imgs = synth.rootsift_images(7, [90, 120, 60, 100, 2, 75, 110], seed=21, n_proto=260)
+    pairs = [(i, j) for i in range(7) for j in range(i)]
+    exp_q, exp_d, exp_off = [], [], [0]
+    for i, j in pairs:
+        q, t, d = oracle.match_pair(imgs[i], imgs[j])
+        exp_q.append(np.stack([q, t], 1).reshape(-1, 2))
+        exp_d.append(d)
+        exp_off.append(exp_off[-1] + len(q))
+    exp_q = np.concatenate(exp_q)
+    exp_d = np.concatenate(exp_d)
+    assert exp_off[-1] > 30
+    for r in range(world):
+        g = np.load(os.path.join(str(tmp_path), "r%d.npz" % r))
+        assert np.array_equal(g["offs"], np.asarray(exp_off))
+        assert np.array_equal(g["qt"], exp_q)
+        assert np.array_equal(g["d"].view(np.int32), exp_d.view(np.int32))
