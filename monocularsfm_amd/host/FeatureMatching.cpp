@@ -1,0 +1,220 @@
+// FeatureMatching.cpp -- see FeatureMatching.h.  Control flow follows the reference's
+// src/Feature/FeatureMatching.cpp (pair order, batch boundaries, transactions, resume-by-row,
+// stdout lines); the per-pair arithmetic runs on the GPU through include/msfm_match.h.
+#include "FeatureMatching.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <iostream>
+
+#include "GeometricVerification.h"
+#include "Timer.h"
+
+namespace MonocularSfM {
+
+namespace {
+[[noreturn]] void Die(msfm_ctx* ctx, const char* what, int rc) {
+    std::fprintf(stderr, "ComputeMatches: %s failed (status %d): %s\n", what, rc, ctx ? msfm_last_error(ctx) : "");
+    std::exit(EXIT_FAILURE);
+}
+#define MSFM_CALL(ctx, expr)                       \
+    do {                                           \
+        const int rc__ = (expr);                   \
+        if (rc__ != MSFM_OK) Die(ctx, #expr, rc__); \
+    } while (0)
+}  // namespace
+
+FeatureMatcher::FeatureMatcher(const std::string& database_path, const int& max_num_matches,
+                               const double& max_distance, const double& distance_ratio, const bool& cross_check)
+    : database_path_(database_path),
+      max_num_matches_(max_num_matches),
+      max_distance_(max_distance),
+      distance_ratio_(distance_ratio),
+      cross_check_(cross_check) {
+    const char* gv = std::getenv("MSFM_GEOMETRIC_VERIFICATION");
+    if (gv && gv[0] == '0') geometric_verification_ = false;
+}
+
+FeatureMatcher::~FeatureMatcher() { CloseDatabaseAndDevice(); }
+
+void FeatureMatcher::OpenDatabaseAndDevice() {
+    database_ = new Database();
+    database_->Open(database_path_);
+    if (!ctx_) {
+        int dev = 0;
+        if (const char* d = std::getenv("MSFM_DEVICE")) dev = std::atoi(d);
+        const int rc = msfm_create(dev, &ctx_);
+        if (rc != MSFM_OK) {
+            std::fprintf(stderr, "ComputeMatches: no usable gfx950 GPU (msfm_create status %d); there is no CPU fallback\n", rc);
+            std::exit(EXIT_FAILURE);
+        }
+        if (const char* o = std::getenv("MSFM_ACCUM_ORDER")) MSFM_CALL(ctx_, msfm_set_accum_order(ctx_, std::atoi(o)));
+    }
+}
+
+void FeatureMatcher::CloseDatabaseAndDevice() {
+    if (database_) {
+        database_->Close();
+        delete database_;
+        database_ = nullptr;
+    }
+    if (ctx_) {
+        msfm_destroy(ctx_);
+        ctx_ = nullptr;
+    }
+    resident_.clear();
+}
+
+void FeatureMatcher::EnsureResident(image_t image_id) {
+    if (resident_.count(image_id)) return;
+    const Descriptors d = database_->ReadDescriptors(image_id);
+    MSFM_CALL(ctx_, msfm_upload_image(ctx_, image_id, d.data.data(), d.rows, d.rows ? d.cols : MSFM_DIM, MSFM_DTYPE_F32));
+    resident_.insert(image_id);
+}
+
+void FeatureMatcher::MatchImagePairs(const std::vector<std::pair<image_t, image_t>>& image_pairs) {
+    database_->BeginTransaction();
+    std::vector<int32_t> todo;
+    for (const auto& image_pair : image_pairs) {
+        const image_t image_id1 = image_pair.first, image_id2 = image_pair.second;
+        if (database_->ExistMatches(image_id1, image_id2)) {
+            std::cout << "Compute Matches " << image_id1 << " - " << image_id2 << " Existing, Continue!" << std::endl;
+            continue;
+        }
+        todo.push_back(image_id1);
+        todo.push_back(image_id2);
+    }
+    const int P = (int)(todo.size() / 2);
+    if (P > 0) {
+        Timer timer;
+        timer.Start();
+        for (int32_t id : todo) EnsureResident(id);
+        msfm_match_params prm;
+        prm.ratio = (float)distance_ratio_;  // ComputeCrossMatches takes `const float distance_ratio`
+        prm.cross_check = cross_check_ ? 1 : 0;
+        prm.max_distance = max_distance_;
+        std::vector<int64_t> offs((size_t)P + 1);
+        MSFM_CALL(ctx_, msfm_match_pairs(ctx_, todo.data(), P, &prm, offs.data()));
+        std::vector<int32_t> qt((size_t)offs[(size_t)P] * 2 + 2);
+        std::vector<float> dist((size_t)offs[(size_t)P] + 1);
+        MSFM_CALL(ctx_, msfm_fetch_matches(ctx_, qt.data(), dist.data()));
+        const double gpu_seconds_per_pair = timer.ElapsedSeconds() / P;
+
+        for (int p = 0; p < P; ++p) {
+            Timer pair_timer;
+            pair_timer.Start();
+            const image_t image_id1 = todo[2 * (size_t)p], image_id2 = todo[2 * (size_t)p + 1];
+            std::cout << "Compute Matches " << image_id1 << " - " << image_id2 << " ... " << std::endl;
+            std::vector<DMatch> prune_matches((size_t)(offs[(size_t)p + 1] - offs[(size_t)p]));
+            for (size_t i = 0; i < prune_matches.size(); ++i) {
+                const size_t k = (size_t)offs[(size_t)p] + i;
+                prune_matches[i].queryIdx = qt[2 * k];
+                prune_matches[i].trainIdx = qt[2 * k + 1];
+                prune_matches[i].distance = dist[k];
+            }
+            std::vector<DMatch> geometric_verif_matches;
+            if (geometric_verification_) {
+                const std::vector<KeyPoint> kpts1 = database_->ReadKeyPoints(image_id1);
+                const std::vector<KeyPoint> kpts2 = database_->ReadKeyPoints(image_id2);
+                FilterMatches(kpts1, kpts2, prune_matches, &geometric_verif_matches);
+            } else {
+                geometric_verif_matches.swap(prune_matches);
+            }
+            std::cout << "\t matches num : " << geometric_verif_matches.size() << std::endl;
+            std::cout << "\t ";
+            Timer::Print(gpu_seconds_per_pair + pair_timer.ElapsedSeconds(), "seconds");
+            std::cout << std::endl;
+            database_->WriteMatches(image_id1, image_id2, geometric_verif_matches);
+        }
+    }
+    database_->EndTransaction();
+}
+
+void SequentialFeatureMatcher::RunMatching() {
+    OpenDatabaseAndDevice();
+    const std::vector<Database::Image> images = database_->ReadAllImages();
+    for (size_t i = 1; i < images.size(); ++i) {
+        std::vector<std::pair<image_t, image_t>> image_pairs;
+        for (int k = 1; k <= overlap_; ++k) {
+            const int j = (int)i - k;
+            if (j < 0) break;
+            image_pairs.emplace_back((image_t)i, (image_t)j);
+        }
+        MatchImagePairs(image_pairs);
+    }
+    CloseDatabaseAndDevice();
+}
+
+void BruteFeatureMatcher::RunMatching() {
+    OpenDatabaseAndDevice();
+    const std::vector<Database::Image> images = database_->ReadAllImages();
+    for (size_t i = 0; i < images.size(); ++i) {
+        std::vector<std::pair<image_t, image_t>> image_pairs;
+        int cur_pairs_size = 0;
+        for (size_t j = 0; j < i; ++j) {
+            image_pairs.emplace_back((image_t)i, (image_t)j);
+            cur_pairs_size += 1;
+            if (cur_pairs_size == max_pairs_size_) {
+                if (is_preemtive_) image_pairs = PreemptivelyFilterImagePairs(image_pairs);
+                MatchImagePairs(image_pairs);
+                image_pairs.clear();
+                cur_pairs_size = 0;
+            }
+        }
+        if (cur_pairs_size != 0) {
+            if (is_preemtive_) image_pairs = PreemptivelyFilterImagePairs(image_pairs);
+            MatchImagePairs(image_pairs);
+            image_pairs.clear();
+        }
+    }
+    CloseDatabaseAndDevice();
+}
+
+std::vector<std::pair<image_t, image_t>> BruteFeatureMatcher::PreemptivelyFilterImagePairs(
+    std::vector<std::pair<image_t, image_t>> image_pairs) {
+    std::vector<std::pair<image_t, image_t>> filtered_image_pairs;
+    if (image_pairs.empty()) return filtered_image_pairs;
+    std::vector<int32_t> slots;
+    for (const auto& image_pair : image_pairs) {
+        slots.push_back(GetTopScaleDescriptors(image_pair.first));
+        slots.push_back(GetTopScaleDescriptors(image_pair.second));
+    }
+    // ComputeCrossMatches / ComputeMatches on the two 100-row subsets, no distance filter here
+    // (src/Feature/FeatureMatching.cpp:163-172)
+    msfm_match_params prm;
+    prm.ratio = (float)distance_ratio_;
+    prm.cross_check = cross_check_ ? 1 : 0;
+    prm.max_distance = __builtin_huge_val();
+    const int P = (int)image_pairs.size();
+    std::vector<int64_t> offs((size_t)P + 1);
+    MSFM_CALL(ctx_, msfm_match_pairs(ctx_, slots.data(), P, &prm, offs.data()));
+    for (int p = 0; p < P; ++p)
+        if (offs[(size_t)p + 1] - offs[(size_t)p] >= preemtive_min_num_matches_) filtered_image_pairs.push_back(image_pairs[(size_t)p]);
+    return filtered_image_pairs;
+}
+
+int BruteFeatureMatcher::GetTopScaleDescriptors(const image_t& image_id) {
+    const int slot = MSFM_MAX_IMAGES + image_id;  // auxiliary store slot of this image's subset
+    if (HasTopScaleDescriptorsCache(image_id)) return slot;
+    const std::vector<KeyPoint> kpts = database_->ReadKeyPoints(image_id);
+    const Descriptors descriptors = database_->ReadDescriptors(image_id);
+    static_assert(sizeof(KeyPoint) == 16, "KeyPoint must be 4 packed floats");
+    std::vector<int32_t> idx(kpts.size() + 1);
+    int count = 0;
+    const int rc = msfm_topscale_select(reinterpret_cast<const float*>(kpts.data()), (int)kpts.size(),
+                                        preemtive_num_features_, idx.data(), &count);
+    if (rc != MSFM_OK) Die(ctx_, "msfm_topscale_select", rc);
+    std::vector<float> top((size_t)count * MSFM_DIM);
+    for (int i = 0; i < count; ++i)
+        for (int c = 0; c < MSFM_DIM; ++c)
+            top[(size_t)i * MSFM_DIM + c] = descriptors.data[(size_t)idx[(size_t)i] * MSFM_DIM + c];
+    MSFM_CALL(ctx_, msfm_upload_image(ctx_, slot, top.data(), count, MSFM_DIM, MSFM_DTYPE_F32));
+    top_scale_descriptors_cache_.insert(image_id);
+    return slot;
+}
+
+bool BruteFeatureMatcher::HasTopScaleDescriptorsCache(const image_t& image_id) {
+    return top_scale_descriptors_cache_.count(image_id) > 0;
+}
+
+}  // namespace MonocularSfM

@@ -1,0 +1,92 @@
+// FeatureMatching.h -- the reference's matcher classes (include/Feature/FeatureMatching.h:18-130)
+// with the same constructor arguments and defaults, running on the gfx950 C ABI
+// (include/msfm_match.h).  Differences from the reference, all behind the same interface:
+//   * descriptors are uploaded to the GPU once per image instead of being re-read from SQLite
+//     for every pair (the "TODO: cache" at src/Feature/FeatureMatching.cpp:31);
+//   * the pairs of one MatchImagePairs call are matched as one batched launch sequence.
+#pragma once
+#include <set>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "Database.h"
+#include "Types.h"
+#include "msfm_match.h"
+
+namespace MonocularSfM {
+
+class FeatureMatcher {
+public:
+    FeatureMatcher(const std::string& database_path, const int& max_num_matches = 10240,
+                   const double& max_distance = 0.7, const double& distance_ratio = 0.8,
+                   const bool& cross_check = true);
+    virtual ~FeatureMatcher();
+
+    // FeatureMatching.cpp:10-73: skip pairs that already have a row, match, distance filter,
+    // geometric verification, one matches row per pair (rows may be 0), all in one transaction.
+    void MatchImagePairs(const std::vector<std::pair<image_t, image_t>>& image_pairs);
+    virtual void RunMatching() = 0;
+
+    // FeatureUtils::FilterMatches (F-matrix RANSAC) is applied unless disabled
+    // (MSFM_GEOMETRIC_VERIFICATION=0); see GeometricVerification.h.
+    void SetGeometricVerification(bool on) { geometric_verification_ = on; }
+
+protected:
+    void OpenDatabaseAndDevice();
+    void CloseDatabaseAndDevice();
+    void EnsureResident(image_t image_id);
+
+    std::string database_path_;
+    int max_num_matches_;  // stored, never read -- as in the reference
+    double max_distance_;
+    double distance_ratio_;
+    bool cross_check_;
+    bool geometric_verification_ = true;
+    Database* database_ = nullptr;
+    msfm_ctx* ctx_ = nullptr;
+    std::set<image_t> resident_;
+};
+
+class SequentialFeatureMatcher : public FeatureMatcher {
+public:
+    SequentialFeatureMatcher(const std::string& database_path, const int& overlap = 3,
+                             const int& max_num_matches = 10240, const double& max_distance = 0.7,
+                             const double& distance_ratio = 0.8, const bool& cross_check = true)
+        : FeatureMatcher(database_path, max_num_matches, max_distance, distance_ratio, cross_check),
+          overlap_(overlap) {}
+    void RunMatching() override;
+
+private:
+    int overlap_;
+};
+
+class BruteFeatureMatcher : public FeatureMatcher {
+public:
+    BruteFeatureMatcher(const std::string& database_path, const int& max_pairs_size = 100,
+                        const bool& is_preemtive = true, const int& preemtive_num_features = 100,
+                        const int& preemtive_min_num_matches = 4, const int& max_num_matches = 10240,
+                        const double& max_distance = 0.7, const double& distance_ratio = 0.8,
+                        const bool& cross_check = true)
+        : FeatureMatcher(database_path, max_num_matches, max_distance, distance_ratio, cross_check),
+          max_pairs_size_(max_pairs_size),
+          is_preemtive_(is_preemtive),
+          preemtive_num_features_(preemtive_num_features),
+          preemtive_min_num_matches_(preemtive_min_num_matches) {}
+    void RunMatching() override;
+
+private:
+    // Wu, "Towards Linear-Time Incremental Structure from Motion", 3DV 2013 (pre-emptive matching)
+    std::vector<std::pair<image_t, image_t>> PreemptivelyFilterImagePairs(
+        std::vector<std::pair<image_t, image_t>> image_pairs);
+    int GetTopScaleDescriptors(const image_t& image_id);  // returns the auxiliary store slot
+    bool HasTopScaleDescriptorsCache(const image_t& image_id);
+
+    int max_pairs_size_;
+    bool is_preemtive_;
+    int preemtive_num_features_;
+    int preemtive_min_num_matches_;
+    std::set<image_t> top_scale_descriptors_cache_;
+};
+
+}  // namespace MonocularSfM

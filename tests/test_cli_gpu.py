@@ -1,0 +1,167 @@
+"""End-to-end drop-in test on the GPU box: the C++ `ComputeMatches <yaml>` executable against a
+synthetic SQLite database, compared row by row with what the reference's control flow
+(src/Feature/FeatureMatching.cpp) would write when its per-pair arithmetic is the CPU oracle."""
+import os
+import re
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+from monocularsfm_amd import database, synth
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = os.path.join(ROOT, "monocularsfm_amd", "host")
+EXE = os.path.join(HOST, "ComputeMatches")
+
+YAML = """%YAML:1.0
+database_path : "{db}"
+SIFTmatch.match_type : {mt}
+# the next three are parsed and ignored, exactly as the reference does
+SIFTmatch.max_distance : 0.1
+SIFTmatch.distance_ratio : 0.5
+SIFTmatch.cross_check : 0
+"""
+
+SIZES = [700, 650, 300, 90, 512, 640, 128]
+
+
+@pytest.fixture(scope="module")
+def exe(built_lib):
+    subprocess.check_call(["make", "-C", HOST, "-s"])
+    return EXE
+
+
+@pytest.fixture(scope="module")
+def dataset():
+    descs = synth.rootsift_images(len(SIZES), SIZES, seed=2024, n_proto=1400)
+    # image 6 shares nothing with the others: the pre-emptive test must drop its pairs
+    descs[6] = synth.rootsift_images(1, [SIZES[6]], seed=999, n_proto=300, overlap=0.0)[0]
+    kps = [synth.keypoints(len(d), seed=50 + i) for i, d in enumerate(descs)]
+    return descs, kps
+
+
+def run_cli(exe, cfg, env_extra=None):
+    env = dict(os.environ)
+    env.update(env_extra or {})
+    r = subprocess.run([exe, str(cfg)], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return r.stdout
+
+
+def expected_brute(oracle, descs, kps):
+    """pair -> (m x 2 matches as (query=i, train=j)) for pairs that get a row; pairs dropped by the
+    pre-emptive filter are absent."""
+    from monocularsfm_amd import _lib
+    tops = [d[_lib.topscale_select(k, 100)] for d, k in zip(descs, kps)]
+    rows = {}
+    for i in range(len(descs)):
+        for j in range(i):
+            pq, _, _ = oracle.match_pair(tops[i], tops[j], 0.8, True, np.inf)
+            if len(pq) < 4:
+                continue
+            q, t, _ = oracle.match_pair(descs[i], descs[j], 0.8, True, 0.7, nthreads=4)
+            rows[(i, j)] = np.stack([q, t], 1).reshape(-1, 2)
+    return rows
+
+
+def test_brute_mode_matches_table(exe, dataset, oracle, tmp_path):
+    descs, kps = dataset
+    db_path = str(tmp_path / "brute.db")
+    database.write_synthetic_database(db_path, descs, kps)
+    cfg = tmp_path / "brute.yaml"
+    cfg.write_text(YAML.format(db=db_path, mt=1))
+    out = run_cli(exe, cfg, {"MSFM_GEOMETRIC_VERIFICATION": "0"})
+    exp = expected_brute(oracle, descs, kps)
+    assert 5 <= len(exp) < len(SIZES) * (len(SIZES) - 1) // 2, "test data: the pre-emptive filter should drop some pairs"
+    db = database.Database(db_path)
+    n_rows = db.db.execute("SELECT COUNT(*) FROM matches").fetchone()[0]
+    assert n_rows == len(exp)
+    for (i, j), m in exp.items():
+        assert db.ExistMatches(i, j)
+        assert np.array_equal(db.ReadMatches(i, j), m), (i, j)
+        # stored canonical form: column 0 indexes the smaller image id
+        raw = db.db.execute("SELECT rows, cols, data FROM matches WHERE pair_id = ?", (database.ImagePairToPairId(i, j),)).fetchone()
+        assert raw[0] == len(m) and raw[1] == 2
+        assert np.array_equal(np.frombuffer(raw[2], np.int32).reshape(-1, 2), m[:, ::-1])
+    db.Close()
+    # stdout contract (FeatureMatching.cpp:29,63-66; sfm/ComputeMatches.cpp:65)
+    for (i, j), m in exp.items():
+        assert "Compute Matches %d - %d ... " % (i, j) in out
+    assert re.search(r"\t matches num : \d+\n\t Elapsed time: \d+\.\d{5} \[seconds\]\n", out)
+    assert re.search(r"Elapsed time: \d+\.\d{5} \[minutes\]\n$", out)
+
+    # resume: a second run recomputes nothing that has a row, retries only pre-emptively dropped pairs
+    out2 = run_cli(exe, cfg, {"MSFM_GEOMETRIC_VERIFICATION": "0"})
+    assert out2.count("Existing, Continue!") == len(exp)
+    assert " ... " not in out2
+    db = database.Database(db_path)
+    assert db.db.execute("SELECT COUNT(*) FROM matches").fetchone()[0] == len(exp)
+    db.Close()
+
+
+def test_sequential_mode_and_yaml_params_are_ignored(exe, dataset, oracle, tmp_path):
+    descs, kps = dataset
+    db_path = str(tmp_path / "seq.db")
+    database.write_synthetic_database(db_path, descs, kps)
+    cfg = tmp_path / "seq.yaml"
+    cfg.write_text(YAML.format(db=db_path, mt=0))
+    run_cli(exe, cfg, {"MSFM_GEOMETRIC_VERIFICATION": "0"})
+    pairs, _ = oracle.enumerate_sequential(len(descs), 3)
+    db = database.Database(db_path)
+    assert db.db.execute("SELECT COUNT(*) FROM matches").fetchone()[0] == len(pairs)
+    for i, j in pairs:
+        # defaults 0.8 / cross-check / 0.7, NOT the 0.5 / 0 / 0.1 written in the YAML
+        q, t, _ = oracle.match_pair(descs[i], descs[j], 0.8, True, 0.7, nthreads=4)
+        assert np.array_equal(db.ReadMatches(int(i), int(j)), np.stack([q, t], 1).reshape(-1, 2)), (i, j)
+    db.Close()
+    # opt-in: honour the YAML values
+    db2 = str(tmp_path / "seq2.db")
+    database.write_synthetic_database(db2, descs, kps)
+    cfg2 = tmp_path / "seq2.yaml"
+    cfg2.write_text(YAML.format(db=db2, mt=0))
+    run_cli(exe, cfg2, {"MSFM_GEOMETRIC_VERIFICATION": "0", "MSFM_HONOUR_YAML_MATCH_PARAMS": "1"})
+    db = database.Database(db2)
+    for i, j in pairs[:6]:
+        q, t, _ = oracle.match_pair(descs[i], descs[j], 0.5, False, 0.1, nthreads=4)
+        assert np.array_equal(db.ReadMatches(int(i), int(j)), np.stack([q, t], 1).reshape(-1, 2)), (i, j)
+    db.Close()
+
+
+def test_geometric_verification_default_on(exe, dataset, tmp_path):
+    """Default run applies the F-matrix RANSAC hand-off (a "next" row, outside bit parity): it may only
+    remove matches.  Synthetic keypoints carry no epipolar geometry, so most matches are rejected."""
+    descs, kps = dataset
+    a, b = str(tmp_path / "gv.db"), str(tmp_path / "nogv.db")
+    database.write_synthetic_database(a, descs, kps)
+    shutil.copy(a, b)
+    for path, env in ((a, {}), (b, {"MSFM_GEOMETRIC_VERIFICATION": "0"})):
+        cfg = tmp_path / (os.path.basename(path) + ".yaml")
+        cfg.write_text(YAML.format(db=path, mt=0))
+        run_cli(exe, cfg, env)
+    da, dbb = database.Database(a), database.Database(b)
+    for i in range(1, len(descs)):
+        ma, mb = da.ReadMatches(i, i - 1), dbb.ReadMatches(i, i - 1)
+        sa = set(map(tuple, ma.tolist()))
+        assert sa <= set(map(tuple, mb.tolist())) and len(ma) <= len(mb)
+    da.Close()
+    dbb.Close()
+
+
+def test_python_matcher_mirror_equals_cli(exe, dataset, gpu_ctx, tmp_path):
+    from monocularsfm_amd.matcher import BruteFeatureMatcher
+    descs, kps = dataset
+    a, b = str(tmp_path / "cli.db"), str(tmp_path / "py.db")
+    database.write_synthetic_database(a, descs, kps)
+    shutil.copy(a, b)
+    cfg = tmp_path / "cli.yaml"
+    cfg.write_text(YAML.format(db=a, mt=1))
+    run_cli(exe, cfg, {"MSFM_GEOMETRIC_VERIFICATION": "0"})
+    gpu_ctx.clear_images()
+    BruteFeatureMatcher(b, ctx=gpu_ctx, verbose=False).RunMatching()
+    ra = database.Database(a).db.execute("SELECT pair_id, rows, cols, data FROM matches ORDER BY pair_id").fetchall()
+    rb = database.Database(b).db.execute("SELECT pair_id, rows, cols, data FROM matches ORDER BY pair_id").fetchall()
+    assert ra == rb and len(ra) > 4

@@ -154,14 +154,22 @@ def test_large_integer_distances_sqrt_collisions(gpu_ctx, oracle):
     rng = np.random.default_rng(8)
     A = rng.integers(0, 30, (200, 128)).astype(F32)
     B = rng.integers(225, 256, (210, 128)).astype(F32)
+    # planted collision: query 0 = zeros; train rows 0/1 have S = X+1 / X with sqrtf(X) == sqrtf(X+1),
+    # X = 100*255^2 + j.  The d^2-space argmin is row 1, knnMatch's answer is row 0 (lower index).
+    base = 100 * 255 * 255
+    j = next(j for j in range(27) if np.sqrt(F32(base + j)) == np.sqrt(F32(base + j + 1)))
+    A[0] = 0
+    B[:, :] = np.maximum(B, 226)          # keep every other train row farther away than the planted two
+    B[0] = 0; B[0, :100] = 255; B[0, 100:100 + j + 1] = 1
+    B[1] = 0; B[1, :100] = 255; B[1, 100:100 + j] = 1
     upload_pair(gpu_ctx, A, B)
     fwd, rev = gpu_ctx.knn2_pair(0, 1)
     oi0, od0, _, od1 = oracle.knn2(A, B, 0, 8)
     pi0, pd0, _, pd1 = oracle.knn2(B, A, 0, 8)
     assert (od0 > 2048).all()
+    assert oi0[0] == 0 and od0[0] == od1[0], "test construction: expected a sqrt collision on query 0"
     assert_knn_equal(fwd, oi0, od0, od1)
     assert_knn_equal(rev, pi0, pd0, pd1)
-    assert (od0 == od1).sum() > 0, "test construction: expected sqrt collisions"
 
 
 # ---- batches -----------------------------------------------------------------------------------------

@@ -1,0 +1,170 @@
+"""Host-side pieces of the drop-in that need no GPU: YAML subset reader, C++ Database against the
+Python twin (same file format both ways), F-matrix RANSAC, and the CLI's argv/exit contract
+(sfm/ComputeMatches.cpp:15-30)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = os.path.join(ROOT, "monocularsfm_amd", "host")
+
+
+@pytest.fixture(scope="module")
+def host(built_lib):
+    subprocess.check_call(["make", "-C", HOST, "-s"])
+    L = C.CDLL(os.path.join(HOST, "libmsfm_host.so"))
+    L.host_yaml_get_double.restype = C.c_double
+    L.host_yaml_get_double.argtypes = [C.c_char_p, C.c_char_p, C.c_double]
+    return L
+
+
+YAML = """%YAML:1.0
+
+images_path : "/data/south-building/images"
+database_path : "{db}"
+
+# 0 for sequential match, 1 for brute match
+SIFTmatch.match_type :  {mt}
+SIFTmatch.max_distance : 0.6   # trailing comment
+SIFTmatch.distance_ratio : 0.75
+SIFTmatch.cross_check : 0
+Reconstruction.Camera.fx: 2559.68
+"""
+
+
+def test_yaml_subset(host, tmp_path):
+    p = tmp_path / "cfg.yaml"
+    p.write_text(YAML.format(db="/tmp/x y#z.db", mt=0))
+    path = str(p).encode()
+    assert host.host_yaml_is_opened(path) == 1
+    buf = C.create_string_buffer(512)
+    assert host.host_yaml_get_string(path, b"database_path", buf, 512) == 1
+    assert buf.value == b"/tmp/x y#z.db"            # '#' inside quotes is not a comment
+    assert host.host_yaml_get_int(path, b"SIFTmatch.match_type", 1) == 0
+    assert host.host_yaml_get_double(path, b"SIFTmatch.max_distance", 0.7) == 0.6
+    assert host.host_yaml_get_double(path, b"SIFTmatch.distance_ratio", 0.8) == 0.75
+    assert host.host_yaml_get_bool(path, b"SIFTmatch.cross_check", 1) == 0
+    assert host.host_yaml_get_double(path, b"Reconstruction.Camera.fx", 0) == 2559.68   # "key: value" without space
+    assert host.host_yaml_get_int(path, b"missing.key", 7) == 7                          # missing keeps the default
+    assert host.host_yaml_get_string(path, b"missing.key", buf, 512) == 0 and buf.value == b""
+    bad = tmp_path / "bad.yaml"
+    bad.write_text("database_path : x\n")            # no %YAML directive: FileStorage refuses it
+    assert host.host_yaml_is_opened(str(bad).encode()) == 0
+    assert host.host_yaml_is_opened(b"/nonexistent/file.yaml") == 0
+
+
+def test_reference_configs_parse(host):
+    ref = "/root/reference/config/south-building.yaml"
+    if not os.path.exists(ref):
+        pytest.skip("reference checkout not present (GPU box)")
+    assert host.host_yaml_is_opened(ref.encode()) == 1
+    assert host.host_yaml_get_int(ref.encode(), b"SIFTmatch.match_type", 1) == 0
+    buf = C.create_string_buffer(512)
+    host.host_yaml_get_string(ref.encode(), b"database_path", buf, 512)
+    assert buf.value.endswith(b"south-building.db")
+
+
+def test_database_cpp_and_python_agree(host, tmp_path):
+    from monocularsfm_amd import database, synth
+    db_path = str(tmp_path / "t.db")
+    descs = synth.rootsift_images(3, [40, 0, 17], seed=5, n_proto=100)
+    kps = [synth.keypoints(len(d), seed=i) for i, d in enumerate(descs)]
+    database.write_synthetic_database(db_path, descs, kps)
+    p = db_path.encode()
+    assert host.host_db_num_images(p) == 3
+    for i, d in enumerate(descs):
+        out = np.zeros(max(d.size, 1), np.float32)
+        cols = C.c_int()
+        rows = host.host_db_read_descriptors(p, i, out.ctypes.data_as(C.POINTER(C.c_float)), out.size, C.byref(cols))
+        assert rows == len(d) and cols.value == 128
+        assert np.array_equal(out[:d.size].reshape(-1, 128), d)
+        ko = np.zeros(max(len(d) * 4, 1), np.float32)
+        assert host.host_db_read_keypoints(p, i, ko.ctypes.data_as(C.POINTER(C.c_float)), ko.size) == len(d)
+        assert np.array_equal(ko[:len(d) * 4].reshape(-1, 4), kps[i])
+    # C++ writes matches for (2, 0) [id1 > id2 -> columns swapped on disk]; Python reads them both ways
+    qt = np.array([[3, 9], [5, 1], [16, 39]], np.int32)
+    assert host.host_db_exist_matches(p, 2, 0) == 0
+    host.host_db_write_matches(p, 2, 0, qt.ctypes.data_as(C.POINTER(C.c_int)), len(qt))
+    assert host.host_db_exist_matches(p, 2, 0) == 1 and host.host_db_exist_matches(p, 0, 2) == 1
+    db = database.Database(db_path)
+    assert np.array_equal(db.ReadMatches(2, 0), qt)
+    assert np.array_equal(db.ReadMatches(0, 2), qt[:, ::-1])
+    (pid, stored), = db.ReadAllMatches()
+    assert pid == 2 == host.host_pair_id(2, 0) and np.array_equal(stored, qt[:, ::-1])  # col 0 = smaller image id
+    # a rows=0 result still gets a row (resume marker) but is invisible to ReadAllMatches
+    db.WriteMatches(1, 0, np.zeros((0, 2), np.int32))
+    assert db.ExistMatches(0, 1) and len(db.ReadAllMatches()) == 1
+    db.Close()
+    back = np.zeros((8, 2), np.int32)
+    assert host.host_db_read_matches(p, 0, 2, back.ctypes.data_as(C.POINTER(C.c_int)), 8) == 3
+    assert np.array_equal(back[:3], qt[:, ::-1])
+    assert host.host_db_read_matches(p, 1, 0, back.ctypes.data_as(C.POINTER(C.c_int)), 8) == 0
+
+
+def _two_views(n_in, n_out, seed):
+    rng = np.random.default_rng(seed)
+    X = np.c_[rng.uniform(-2, 2, n_in), rng.uniform(-1.5, 1.5, n_in), rng.uniform(4, 9, n_in)]
+    K = np.array([[2559.68, 0, 1536], [0, 2559.68, 1152], [0, 0, 1]])
+    a = 0.12
+    R = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]])
+    t = np.array([0.8, 0.05, 0.1])
+    x1 = (K @ X.T).T
+    x1 = x1[:, :2] / x1[:, 2:]
+    x2 = (K @ (R @ X.T + t[:, None])).T
+    x2 = x2[:, :2] / x2[:, 2:]
+    x1 += rng.normal(0, 0.4, x1.shape)
+    x2 += rng.normal(0, 0.4, x2.shape)
+    o1 = np.c_[rng.uniform(0, 3072, n_out), rng.uniform(0, 2304, n_out)]
+    o2 = np.c_[rng.uniform(0, 3072, n_out), rng.uniform(0, 2304, n_out)]
+    p1 = np.r_[x1, o1].astype(np.float32)
+    p2 = np.r_[x2, o2].astype(np.float32)
+    perm = rng.permutation(len(p1))
+    truth = np.r_[np.ones(n_in, bool), np.zeros(n_out, bool)][perm]
+    return np.ascontiguousarray(p1[perm]), np.ascontiguousarray(p2[perm]), truth
+
+
+def test_fundamental_ransac_recovers_the_epipolar_inliers(host):
+    p1, p2, truth = _two_views(300, 120, seed=3)
+    mask = np.zeros(len(p1), np.uint8)
+    fp = C.POINTER(C.c_float)
+    n = host.host_fundamental_ransac(p1.ctypes.data_as(fp), p2.ctypes.data_as(fp), len(p1), mask.ctypes.data_as(C.POINTER(C.c_ubyte)))
+    assert n == len(p1)
+    got = mask.astype(bool)
+    assert (got & truth).sum() >= 0.95 * truth.sum()          # keeps the true correspondences
+    assert (got & ~truth).sum() <= 0.1 * (~truth).sum()       # random outliers rarely sit on an epipolar line
+    # deterministic
+    mask2 = np.zeros_like(mask)
+    host.host_fundamental_ransac(p1.ctypes.data_as(fp), p2.ctypes.data_as(fp), len(p1), mask2.ctypes.data_as(C.POINTER(C.c_ubyte)))
+    assert np.array_equal(mask, mask2)
+    # findFundamentalMat's small-count cases: < 7 -> no model (nothing kept), == 7 -> all ones
+    assert host.host_fundamental_ransac(p1.ctypes.data_as(fp), p2.ctypes.data_as(fp), 6, mask.ctypes.data_as(C.POINTER(C.c_ubyte))) == 0
+    mask[:] = 0
+    assert host.host_fundamental_ransac(p1.ctypes.data_as(fp), p2.ctypes.data_as(fp), 7, mask.ctypes.data_as(C.POINTER(C.c_ubyte))) == 7
+    assert mask[:7].all()
+
+
+def test_cli_argv_contract(host, tmp_path):
+    exe = os.path.join(HOST, "ComputeMatches")
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 255 and "You need specify the YAML file path!" in r.stdout      # exit(-1)
+    r = subprocess.run([exe, "/nonexistent.yaml"], capture_output=True, text=True)
+    assert r.returncode == 255 and "YAML file : /nonexistent.yaml can't not open!" in r.stdout
+
+
+def test_cli_fails_loudly_without_gpu(host, tmp_path):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from monocularsfm_amd import database, synth
+    db_path = str(tmp_path / "t.db")
+    database.write_synthetic_database(db_path, synth.rootsift_images(2, [30, 30], seed=1, n_proto=50))
+    cfg = tmp_path / "c.yaml"
+    cfg.write_text(YAML.format(db=db_path, mt=1))
+    r = subprocess.run([os.path.join(HOST, "ComputeMatches"), str(cfg)], capture_output=True, text=True)
+    assert r.returncode != 0 and "no CPU fallback" in r.stderr
+    db = database.Database(db_path)
+    assert len(db.ReadAllMatches()) == 0 and not db.ExistMatches(1, 0)   # nothing was written
+    db.Close()
