@@ -37,10 +37,23 @@ def exe(built_lib):
 
 @pytest.fixture(scope="module")
 def dataset():
+    rng = np.random.default_rng(7)
     descs = synth.rootsift_images(len(SIZES), SIZES, seed=2024, n_proto=1400)
-    # image 6 shares nothing with the others: the pre-emptive test must drop its pairs
-    descs[6] = synth.rootsift_images(1, [SIZES[6]], seed=999, n_proto=300, overlap=0.0)[0]
     kps = [synth.keypoints(len(d), seed=50 + i) for i, d in enumerate(descs)]
+    # "landmarks": 60 of 80 shared descriptors per image, carried by the LARGEST keypoints, so the
+    # top-scale subsets of two images overlap and the pre-emptive test passes ...
+    pool = descs[0][:80].copy()
+    for i in range(len(descs)):
+        if i == 6:
+            continue
+        pick = rng.choice(80, 60, replace=False)
+        rows = rng.choice(len(descs[i]), 60, replace=False)
+        v = np.abs(pool[pick] * (1 + 0.03 * rng.standard_normal((60, 128)).astype(np.float32)))
+        descs[i][rows] = v / np.linalg.norm(v, axis=1, keepdims=True)
+        kps[i][rows, 2] = 100 + rng.uniform(0, 50, 60).astype(np.float32)
+    # ... except for image 6, which shares nothing: its pairs must be dropped pre-emptively
+    descs[6] = synth.rootsift_images(1, [SIZES[6]], seed=999, n_proto=300, overlap=0.0)[0]
+    descs = [np.ascontiguousarray(d, dtype=np.float32) for d in descs]
     return descs, kps
 
 

@@ -239,7 +239,7 @@ def test_full_size_properties(gpu_ctx, oracle):
     assert np.array_equal(perm[fwdp[0]], fwd[0]) and np.array_equal(b(fwdp[1]), b(fwd[1])) and np.array_equal(b(fwdp[2]), b(fwd[2]))
     # (5) cross-checked matches are mutual nearest neighbours (q != 0, where the operator[] quirk cannot act)
     q, t, d = gpu_ctx.match_pair(0, 1)
-    assert len(q) > 300 and (np.diff(q) > 0).all()
+    assert len(q) > 150 and (np.diff(q) > 0).all()
     nz = q != 0
     assert np.array_equal(rev[0][t[nz]], q[nz]) and np.array_equal(fwd[0][q], t) and (d <= F32(0.7)).all()
     # (6) self-match: every descriptor's nearest neighbour in its own image is itself at distance 0
