@@ -150,35 +150,70 @@ __device__ __forceinline__ void glds_copy(const float* __restrict__ g, float* ld
     }
 }
 
-// One group of 4 accumulator chains (one SIMD lane of the OpenCV loop) for the 8x4 micro tile:
-// s[i][j] = ((p0+p1)+p2)+p3, p_v = sum over `kIters` storage positions in order.
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+// One group of 4 accumulator chains (one SIMD lane of the OpenCV loop) for the 8x4 micro tile,
+// in packed fp32 (v_pk_add/mul_f32: two A rows per instruction, the B value broadcast):
+// s[i][j] = ((p0+p1)+p2)+p3 for rows (2i, 2i+1) x column j, p_v = sum over `kIters` storage
+// positions in order.  Per position the three stages (sub, mul, accumulate) are issued as three
+// blocks of 16 independent packed ops so no instruction waits on its predecessor, and the LDS
+// reads of the next position are issued before the current one is consumed.
 template <int ORDER>
 __device__ __forceinline__ void group_chains(const float* __restrict__ sa, const float* __restrict__ sb,
-                                             float (&s)[kTM][kTN]) {
+                                             v2f (&s)[4][kTN]) {
     using OT = OrderTraits<ORDER>;
+    constexpr int kPos = 4 * OT::kIters;
+    v4f a_lo = *reinterpret_cast<const v4f*>(sa);
+    v4f a_hi = *reinterpret_cast<const v4f*>(sa + 4);
+    v4f bb = *reinterpret_cast<const v4f*>(sb);
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
-        float p[kTM][kTN];
+        v2f p[4][kTN];
 #pragma unroll
         for (int it = 0; it < OT::kIters; ++it) {
             const int pos = v * OT::kIters + it;
-            const float4 a0 = *reinterpret_cast<const float4*>(sa + pos * kBM);
-            const float4 a1 = *reinterpret_cast<const float4*>(sa + pos * kBM + 4);
-            const float4 b0 = *reinterpret_cast<const float4*>(sb + pos * kBN);
-            const float av[kTM] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-            const float bv[kTN] = {b0.x, b0.y, b0.z, b0.w};
+            const v2f ap[4] = {a_lo.xy, a_lo.zw, a_hi.xy, a_hi.zw};
+            const float bj[kTN] = {bb.x, bb.y, bb.z, bb.w};
+            if (pos + 1 < kPos) {
+                a_lo = *reinterpret_cast<const v4f*>(sa + (pos + 1) * kBM);
+                a_hi = *reinterpret_cast<const v4f*>(sa + (pos + 1) * kBM + 4);
+                bb = *reinterpret_cast<const v4f*>(sb + (pos + 1) * kBN);
+            }
+            // two half blocks (row pairs 0-1, then 2-3): 8 independent packed ops per stage keep
+            // dependent instructions >= 8 issue slots apart with only 8 temporaries live
 #pragma unroll
-            for (int i = 0; i < kTM; ++i)
+            for (int h = 0; h < 2; ++h) {
+                v2f t[2][kTN];
 #pragma unroll
-                for (int j = 0; j < kTN; ++j) {
-                    const float t = av[i] - bv[j];
-                    if (it == 0) p[i][j] = t * t;  // 0 + t*t == t*t exactly
-                    else if (OT::kFused) p[i][j] = __builtin_fmaf(t, t, p[i][j]);
-                    else p[i][j] = p[i][j] + t * t;  // mul and add rounded separately
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < kTN; ++j) t[i][j] = ap[2 * h + i] - (v2f)(bj[j]);
+                if (OT::kFused) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < kTN; ++j)
+                            p[2 * h + i][j] = (it == 0) ? t[i][j] * t[i][j]
+                                                        : __builtin_elementwise_fma(t[i][j], t[i][j], p[2 * h + i][j]);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < kTN; ++j) t[i][j] = t[i][j] * t[i][j];  // rounded product
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < kTN; ++j)
+                            p[2 * h + i][j] = (it == 0) ? t[i][j] : p[2 * h + i][j] + t[i][j];  // 0 + x == x
                 }
+            }
+            // keep the scheduler from hoisting later positions' LDS reads over this block (it
+            // otherwise runs out of VGPRs and spills)
+            __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
-        for (int i = 0; i < kTM; ++i)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < kTN; ++j) s[i][j] = (v == 0) ? p[i][j] : s[i][j] + p[i][j];
     }
@@ -223,59 +258,61 @@ __global__ __launch_bounds__(kThreads) void dist_top2_kernel(
 #pragma unroll
     for (int i = 0; i < kTM; ++i) { r_s0[i] = f_inf(); r_s1[i] = f_inf(); r_i0[i] = -1; }
 
-    float lvl0[kTM][kTN], lvl1[kTM][kTN], lvl2[kTM][kTN];
+    v2f lvl0[4][kTN], lvl1[4][kTN], lvl2[4][kTN];  // [row pair][column]
     (void)lvl2;
 
     int step = 0;
+    // start of a chunk step: chunk `step` has landed (vmcnt(0) is part of the barrier release when
+    // an LDS-DMA is outstanding) and every wave is done with the slot refilled next
+    auto begin_chunk = [&](int c, const float*& sa, const float*& sb) {
+        __syncthreads();
+        if (step + 1 < n_steps) {
+            const int nstep = step + 1;
+            const int nbt = item.bt_begin + nstep / kChunks, nc = nstep % kChunks;
+            glds_copy(pd.b_panel + (size_t)nbt * kPanelFloats + nc * kSlotFloats,
+                      sB + (nstep & 1) * kSlotFloats, kSlotFloats, tid);
+        }
+        sa = sA + c * kChunkPos * kBM + ty * kTM;
+        sb = sB + (step & 1) * kSlotFloats + tx * kTN;
+        ++step;
+    };
+#define MSFM_FOREACH(expr)                       \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) \
+        _Pragma("unroll") for (int j = 0; j < kTN; ++j) { expr; }
+
 #pragma unroll 1
     for (int bt = item.bt_begin; bt < item.bt_end; ++bt) {
-        float fin[kTM][kTN];
+        // Balanced in-order tree over the lane groups (a binary-counter stack).  Even groups
+        // accumulate straight into lvl0, odd groups into `s`; only adds, never copies.
+        const float *sa, *sb;
+        if (OT::kGroups == 4) {  // one group per chunk: ((g0+g1)+(g2+g3)) -> lvl1
 #pragma unroll 1
-        for (int c = 0; c < kChunks; ++c, ++step) {
-            // chunk `step` has landed (vmcnt(0) is part of the barrier release when an LDS-DMA
-            // is outstanding) and every wave is done with the slot we are about to refill
-            __syncthreads();
-            if (step + 1 < n_steps) {
-                const int nstep = step + 1;
-                const int nbt = item.bt_begin + nstep / kChunks, nc = nstep % kChunks;
-                glds_copy(pd.b_panel + (size_t)nbt * kPanelFloats + nc * kSlotFloats,
-                          sB + (nstep & 1) * kSlotFloats, kSlotFloats, tid);
+            for (int c = 0; c < kChunks; ++c) {
+                begin_chunk(c, sa, sb);
+                v2f s[4][kTN];
+                group_chains<ORDER>(sa, sb, s);
+                if ((c & 1) == 0) { MSFM_FOREACH(lvl0[i][j] = s[i][j]) }
+                else if (c == 1) { MSFM_FOREACH(lvl1[i][j] = lvl0[i][j] + s[i][j]) }
+                else { MSFM_FOREACH(lvl1[i][j] = lvl1[i][j] + (lvl0[i][j] + s[i][j])) }
             }
-            const float* sa = sA + c * kChunkPos * kBM + ty * kTM;
-            const float* sb = sB + (step & 1) * kSlotFloats + tx * kTN;
-#pragma unroll
-            for (int gi = 0; gi < kChunkPos / OT::kGroupPos; ++gi) {
-                float s[kTM][kTN];
-                group_chains<ORDER>(sa + gi * OT::kGroupPos * kBM, sb + gi * OT::kGroupPos * kBN, s);
-                // balanced in-order tree over the groups (binary-counter stack)
-                const int g = c * (kChunkPos / OT::kGroupPos) + gi;
-                if ((g & 1) == 0) {
-#pragma unroll
-                    for (int i = 0; i < kTM; ++i)
-#pragma unroll
-                        for (int j = 0; j < kTN; ++j) lvl0[i][j] = s[i][j];
-                } else if ((g & 2) == 0) {
-#pragma unroll
-                    for (int i = 0; i < kTM; ++i)
-#pragma unroll
-                        for (int j = 0; j < kTN; ++j) lvl1[i][j] = lvl0[i][j] + s[i][j];
-                } else if (OT::kGroups == 4 || (g & 4) != 0) {
-#pragma unroll
-                    for (int i = 0; i < kTM; ++i)
-#pragma unroll
-                        for (int j = 0; j < kTN; ++j) {
-                            float r = lvl1[i][j] + (lvl0[i][j] + s[i][j]);
-                            if (OT::kGroups == 8) r = lvl2[i][j] + r;
-                            fin[i][j] = r;
-                        }
-                } else {
-#pragma unroll
-                    for (int i = 0; i < kTM; ++i)
-#pragma unroll
-                        for (int j = 0; j < kTN; ++j) lvl2[i][j] = lvl1[i][j] + (lvl0[i][j] + s[i][j]);
-                }
+        } else {  // two groups per chunk: (((g0+g1)+(g2+g3)) + ((g4+g5)+(g6+g7))) -> lvl2
+#pragma unroll 1
+            for (int c = 0; c < kChunks; ++c) {
+                begin_chunk(c, sa, sb);
+                group_chains<ORDER>(sa, sb, lvl0);
+                v2f s[4][kTN];
+                group_chains<ORDER>(sa + OT::kGroupPos * kBM, sb + OT::kGroupPos * kBN, s);
+                if (c == 0 || c == 2) { MSFM_FOREACH(lvl1[i][j] = lvl0[i][j] + s[i][j]) }
+                else if (c == 1) { MSFM_FOREACH(lvl2[i][j] = lvl1[i][j] + (lvl0[i][j] + s[i][j])) }
+                else { MSFM_FOREACH(lvl2[i][j] = lvl2[i][j] + (lvl1[i][j] + (lvl0[i][j] + s[i][j]))) }
             }
         }
+        float fin[kTM][kTN];
+#pragma unroll
+        for (int i = 0; i < kTM; ++i)
+#pragma unroll
+            for (int j = 0; j < kTN; ++j)
+                fin[i][j] = (OT::kGroups == 4) ? lvl1[i >> 1][j][i & 1] : lvl2[i >> 1][j][i & 1];
 
         // ---- tile epilogue -------------------------------------------------------------
         const int col0 = bt * kBN + tx * kTN;  // first B row (train index) of this thread
