@@ -27,16 +27,18 @@ constexpr int kBM = 128;      // A rows (query descriptors) per workgroup
 constexpr int kBN = 128;      // B rows (train descriptors) per tile
 constexpr int kTM = 8;        // per-thread micro tile: 8 A rows x 4 B rows
 constexpr int kTN = 4;
-constexpr int kThreads = 512; // 16 (ty) x 32 (tx); wave w holds ty in {2w, 2w+1}
+constexpr int kThreads = 512; // 8 waves; lane = tx*16 + ty (tx 0..3, ty 0..15)
 constexpr int kChunkPos = 32; // storage positions per LDS chunk of a B tile
 constexpr int kChunks = kDim / kChunkPos;
 constexpr int kPanelFloats = kBM * kDim; // one 128-row block of an image, 64 KiB
-constexpr int kSlotFloats = kChunkPos * kBN; // one B chunk in LDS, 16 KiB
-// LDS carve-up (floats): A panel | 2 B chunk slots | column-merge scratch (8 waves x 128 x 3)
+constexpr int kSlotFloats = kChunkPos * kBN; // one B chunk of a tile in HBM, 16 KiB
+constexpr int kWaveCols = kBN / 8;            // B rows per wave per tile
+constexpr int kWaveSlotFloats = kChunkPos * kWaveCols;  // one wave-private chunk slot, 2 KiB
+// LDS carve-up (floats): A panel 64 KiB | 8 waves x 2 chunk slots (32 KiB; reused for the final
+// row merge: 8 waves x 3 x 128 floats = 12 KiB)
 constexpr int kLdsA = 0;
 constexpr int kLdsB = kPanelFloats;
-constexpr int kLdsC = kLdsB + 2 * kSlotFloats;
-constexpr int kLdsFloats = kLdsC + 8 * kBN * 3;
+constexpr int kLdsFloats = kLdsB + 8 * 2 * kWaveSlotFloats;
 constexpr int kLdsBytes = kLdsFloats * 4;
 
 template <int ORDER> struct OrderTraits;
@@ -155,17 +157,19 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 
 // One group of 4 accumulator chains (one SIMD lane of the OpenCV loop) for the 8x4 micro tile,
 // in packed fp32 (v_pk_add/mul_f32: two A rows per instruction, the B value broadcast):
-// s[i][j] = ((p0+p1)+p2)+p3 for rows (2i, 2i+1) x column j, p_v = sum over `kIters` storage
-// positions in order.  Per position the three stages (sub, mul, accumulate) are issued as three
-// blocks of 16 independent packed ops so no instruction waits on its predecessor, and the LDS
-// reads of the next position are issued before the current one is consumed.
+// s[i][j] = ((p0+p1)+p2)+p3 for row pair i x column j, p_v = sum over `kIters` storage positions
+// in order.  Per position the stages (sub, mul, accumulate) are issued as blocks of 8 independent
+// packed ops so no instruction waits on its predecessor, and the LDS reads of the next position
+// are issued before the current one is consumed.
+//   sa: this lane's A rows at position 0 (rows 4ty..4ty+3; +64 floats: rows 64+4ty..), stride kBM
+//   sb: this lane's 4 B rows at position 0 of the wave-private chunk, stride kWaveCols
 template <int ORDER>
 __device__ __forceinline__ void group_chains(const float* __restrict__ sa, const float* __restrict__ sb,
                                              v2f (&s)[4][kTN]) {
     using OT = OrderTraits<ORDER>;
     constexpr int kPos = 4 * OT::kIters;
     v4f a_lo = *reinterpret_cast<const v4f*>(sa);
-    v4f a_hi = *reinterpret_cast<const v4f*>(sa + 4);
+    v4f a_hi = *reinterpret_cast<const v4f*>(sa + 64);
     v4f bb = *reinterpret_cast<const v4f*>(sb);
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
@@ -175,15 +179,16 @@ __device__ __forceinline__ void group_chains(const float* __restrict__ sa, const
             const int pos = v * OT::kIters + it;
             const v2f ap[4] = {a_lo.xy, a_lo.zw, a_hi.xy, a_hi.zw};
             const float bj[kTN] = {bb.x, bb.y, bb.z, bb.w};
-            if (pos + 1 < kPos) {
-                a_lo = *reinterpret_cast<const v4f*>(sa + (pos + 1) * kBM);
-                a_hi = *reinterpret_cast<const v4f*>(sa + (pos + 1) * kBM + 4);
-                bb = *reinterpret_cast<const v4f*>(sb + (pos + 1) * kBN);
-            }
-            // two half blocks (row pairs 0-1, then 2-3): 8 independent packed ops per stage keep
-            // dependent instructions >= 8 issue slots apart with only 8 temporaries live
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
+                if (h == 1 && pos + 1 < kPos) {
+                    // next position's LDS reads go out between the two half blocks: the wait for THIS
+                    // position's operands (hipcc emits lgkmcnt(0)) then never covers a just-issued read
+                    __builtin_amdgcn_sched_barrier(0);
+                    a_lo = *reinterpret_cast<const v4f*>(sa + (pos + 1) * kBM);
+                    a_hi = *reinterpret_cast<const v4f*>(sa + (pos + 1) * kBM + 64);
+                    bb = *reinterpret_cast<const v4f*>(sb + (pos + 1) * kWaveCols);
+                }
                 v2f t[2][kTN];
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
@@ -220,10 +225,16 @@ __device__ __forceinline__ void group_chains(const float* __restrict__ sa, const
 }
 
 // ---------------------------------------------------------------------------------------
-// dist_top2_kernel: one workgroup = one 128-row block of image A x a range of 128-row tiles
-// of image B.  Per B tile: S for the 128x128 tile in exact order (8x4 per thread), then
-//   rows:    running top-2 (S0, argmin, S1) per A row, kept in registers across tiles;
-//   columns: top-2 over this block's 128 A rows, written as a partial per (A block, B row).
+// dist_top2_kernel: one workgroup (8 waves) = one 128-row block of image A x a range of 128-row
+// tiles of image B.  The A panel is shared in LDS (loaded once).  Each WAVE owns 16 of a tile's
+// 128 B rows and streams them through its own double-buffered LDS slots with LDS-DMA, so the
+// main loop has no workgroup barrier: waves drift freely and hide each other's LDS latency and
+// epilogues.  Lane (tx = lane>>4, ty = lane&15) computes an 8x4 micro tile: A rows
+// {4ty..4ty+3} U {64+4ty..64+4ty+3} x B rows tile*128 + wave*16 + 4tx..+3, S in exact order.
+//   rows:    running top-2 (S0, argmin, S1) per A row in registers across all tiles, merged over
+//            tx (shuffles) and the 8 waves (LDS) once at the end;
+//   columns: top-2 over the block's 128 A rows = the wave's 16 ty lanes (shuffles), written as a
+//            partial per (A block, B row).
 // ---------------------------------------------------------------------------------------
 template <int ORDER>
 __global__ __launch_bounds__(kThreads) void dist_top2_kernel(
@@ -233,26 +244,37 @@ __global__ __launch_bounds__(kThreads) void dist_top2_kernel(
     using OT = OrderTraits<ORDER>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* sA = smem + kLdsA;
-    float* sB = smem + kLdsB;
-    float* sC = smem + kLdsC;
 
     const WorkItem item = items[blockIdx.x];
     if (item.pair < 0) return;
     const PairDesc pd = pairs[item.pair];
 
     const int tid = threadIdx.x;
-    const int tx = tid & 31;
-    const int ty = tid >> 5;
-    const int wave = tid >> 6;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ty = lane & 15;
+    const int tx = lane >> 4;
+    float* sBw = smem + kLdsB + wave * (2 * kWaveSlotFloats);  // this wave's two chunk slots
 
-    const float* gA = pd.a_panel + (size_t)item.a_blk * kPanelFloats;
     const int n_steps = (item.bt_end - item.bt_begin) * kChunks;
+    // wave-private LDS-DMA of chunk `st` of the item: 32 positions x 16 B rows = 2 KiB = two
+    // 1-KiB wave instructions; lane l fetches 16 B: position l/4 (+16), B rows 4*(l%4)..+3
+    const float* gB = pd.b_panel + (size_t)item.bt_begin * kPanelFloats + wave * kWaveCols + (lane >> 2) * kBN + (lane & 3) * 4;
+    auto dma_chunk = [&](int st) {
+        const float* g = gB + (size_t)st * kSlotFloats;  // chunks of consecutive tiles are contiguous
+        float* l = sBw + (st & 1) * kWaveSlotFloats;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                         (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + 16 * kBN),
+                                         (__attribute__((address_space(3))) void*)(l + 256), 16, 0, 0);
+    };
 
-    // prologue: A panel + first B chunk
-    glds_copy(gA, sA, kPanelFloats, tid);
-    glds_copy(pd.b_panel + (size_t)item.bt_begin * kPanelFloats, sB, kSlotFloats, tid);
+    // prologue: A panel (all waves) + this wave's first B chunk, one barrier
+    glds_copy(pd.a_panel + (size_t)item.a_blk * kPanelFloats, sA, kPanelFloats, tid);
+    dma_chunk(0);
+    __syncthreads();  // includes vmcnt(0): the A panel and chunk 0 have landed
 
-    const int row0 = item.a_blk * kBM + ty * kTM;  // first A row of this thread
+    const int arow0 = item.a_blk * kBM + 4 * ty;  // rows arow0..+3 and arow0+64..+3
     float r_s0[kTM], r_s1[kTM];
     int r_i0[kTM];
 #pragma unroll
@@ -262,18 +284,13 @@ __global__ __launch_bounds__(kThreads) void dist_top2_kernel(
     (void)lvl2;
 
     int step = 0;
-    // start of a chunk step: chunk `step` has landed (vmcnt(0) is part of the barrier release when
-    // an LDS-DMA is outstanding) and every wave is done with the slot refilled next
+    // start of a chunk step: this wave's DMA for the step has landed; refill the other slot (its
+    // reads, issued during the previous step by this same wave, have all been consumed)
     auto begin_chunk = [&](int c, const float*& sa, const float*& sb) {
-        __syncthreads();
-        if (step + 1 < n_steps) {
-            const int nstep = step + 1;
-            const int nbt = item.bt_begin + nstep / kChunks, nc = nstep % kChunks;
-            glds_copy(pd.b_panel + (size_t)nbt * kPanelFloats + nc * kSlotFloats,
-                      sB + (nstep & 1) * kSlotFloats, kSlotFloats, tid);
-        }
-        sa = sA + c * kChunkPos * kBM + ty * kTM;
-        sb = sB + (step & 1) * kSlotFloats + tx * kTN;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (step + 1 < n_steps) dma_chunk(step + 1);
+        sa = sA + c * kChunkPos * kBM + 4 * ty;
+        sb = sBw + (step & 1) * kWaveSlotFloats + 4 * tx;
         ++step;
     };
 #define MSFM_FOREACH(expr)                       \
@@ -282,8 +299,7 @@ __global__ __launch_bounds__(kThreads) void dist_top2_kernel(
 
 #pragma unroll 1
     for (int bt = item.bt_begin; bt < item.bt_end; ++bt) {
-        // Balanced in-order tree over the lane groups (a binary-counter stack).  Even groups
-        // accumulate straight into lvl0, odd groups into `s`; only adds, never copies.
+        // Balanced in-order tree over the lane groups (a binary-counter stack).
         const float *sa, *sb;
         if (OT::kGroups == 4) {  // one group per chunk: ((g0+g1)+(g2+g3)) -> lvl1
 #pragma unroll 1
@@ -301,12 +317,13 @@ __global__ __launch_bounds__(kThreads) void dist_top2_kernel(
                 begin_chunk(c, sa, sb);
                 group_chains<ORDER>(sa, sb, lvl0);
                 v2f s[4][kTN];
-                group_chains<ORDER>(sa + OT::kGroupPos * kBM, sb + OT::kGroupPos * kBN, s);
+                group_chains<ORDER>(sa + OT::kGroupPos * kBM, sb + OT::kGroupPos * kWaveCols, s);
                 if (c == 0 || c == 2) { MSFM_FOREACH(lvl1[i][j] = lvl0[i][j] + s[i][j]) }
                 else if (c == 1) { MSFM_FOREACH(lvl2[i][j] = lvl1[i][j] + (lvl0[i][j] + s[i][j])) }
                 else { MSFM_FOREACH(lvl2[i][j] = lvl2[i][j] + (lvl1[i][j] + (lvl0[i][j] + s[i][j]))) }
             }
         }
+        // micro-tile row i: i < 4 -> A row arow0 + i (pair i/2), i >= 4 -> A row arow0 + 64 + (i-4)
         float fin[kTM][kTN];
 #pragma unroll
         for (int i = 0; i < kTM; ++i)
@@ -315,75 +332,80 @@ __global__ __launch_bounds__(kThreads) void dist_top2_kernel(
                 fin[i][j] = (OT::kGroups == 4) ? lvl1[i >> 1][j][i & 1] : lvl2[i >> 1][j][i & 1];
 
         // ---- tile epilogue -------------------------------------------------------------
-        const int col0 = bt * kBN + tx * kTN;  // first B row (train index) of this thread
+        const int col0 = bt * kBN + wave * kWaveCols + tx * kTN;  // first B row (train index) of this lane
         if ((bt + 1) * kBN > pd.n2 || (item.a_blk + 1) * kBM > pd.n1) {
 #pragma unroll
             for (int i = 0; i < kTM; ++i)
 #pragma unroll
                 for (int j = 0; j < kTN; ++j)
-                    if (row0 + i >= pd.n1 || col0 + j >= pd.n2) fin[i][j] = f_inf();
+                    if (arow0 + (i & 3) + (i >> 2) * 64 >= pd.n1 || col0 + j >= pd.n2) fin[i][j] = f_inf();
         }
-        // rows: this thread's 4 train indices, ascending
+        // rows: this lane's 4 train indices, ascending
 #pragma unroll
         for (int i = 0; i < kTM; ++i)
 #pragma unroll
             for (int j = 0; j < kTN; ++j) top2_push(r_s0[i], r_i0[i], r_s1[i], fin[i][j], col0 + j);
-        // columns: this thread's 8 query indices, ascending; then the partner half-wave
-        // (ty^1, higher rows for the upper half), then the 8 waves through LDS
+        // columns: this lane's 8 query indices (ascending), then the 16 ty lanes of the wave
 #pragma unroll
         for (int j = 0; j < kTN; ++j) {
             float c_s0 = f_inf(), c_s1 = f_inf();
             int c_i0 = -1;
 #pragma unroll
-            for (int i = 0; i < kTM; ++i) top2_push(c_s0, c_i0, c_s1, fin[i][j], row0 + i);
-            const float o_s0 = __shfl_xor(c_s0, 32);
-            const int o_i0 = __shfl_xor(c_i0, 32);
-            const float o_s1 = __shfl_xor(c_s1, 32);
-            top2_merge(c_s0, c_i0, c_s1, o_s0, o_i0, o_s1);
-            if ((tid & 32) == 0) {
-                const int cc = tx * kTN + j;
-                sC[(wave * 3 + 0) * kBN + cc] = c_s0;
-                sC[(wave * 3 + 1) * kBN + cc] = __int_as_float(c_i0);
-                sC[(wave * 3 + 2) * kBN + cc] = c_s1;
+            for (int i = 0; i < kTM; ++i)
+                top2_push(c_s0, c_i0, c_s1, fin[i][j], arow0 + (i & 3) + (i >> 2) * 64);
+#pragma unroll
+            for (int m = 1; m < 16; m <<= 1) {
+                const float o_s0 = __shfl_xor(c_s0, m);
+                const int o_i0 = __shfl_xor(c_i0, m);
+                const float o_s1 = __shfl_xor(c_s1, m);
+                top2_merge(c_s0, c_i0, c_s1, o_s0, o_i0, o_s1);
+            }
+            if (ty == 0) {
+                const long long o = pd.cp_off + (long long)item.a_blk * pd.n2pad + col0 + j;
+                cp_s0[o] = c_s0;
+                cp_i0[o] = c_i0;
+                cp_s1[o] = c_s1;
             }
         }
-        __syncthreads();
-        if (tid < kBN) {
-            float c_s0 = sC[0 * kBN + tid];
-            int c_i0 = __float_as_int(sC[1 * kBN + tid]);
-            float c_s1 = sC[2 * kBN + tid];
-#pragma unroll
-            for (int w = 1; w < 8; ++w)
-                top2_merge(c_s0, c_i0, c_s1, sC[(w * 3 + 0) * kBN + tid],
-                           __float_as_int(sC[(w * 3 + 1) * kBN + tid]), sC[(w * 3 + 2) * kBN + tid]);
-            const long long o = pd.cp_off + (long long)item.a_blk * pd.n2pad + bt * kBN + tid;
-            cp_s0[o] = c_s0;
-            cp_i0[o] = c_i0;
-            cp_s1[o] = c_s1;
-        }
-        // sC is next written after kChunks more barriers: no extra barrier needed here
     }
 
-    // ---- rows: merge the 32 tx lanes that share this thread's 8 A rows --------------------
+    // ---- rows: merge the 4 tx lane groups of the wave, then the 8 waves through LDS ----------
 #pragma unroll
     for (int i = 0; i < kTM; ++i) {
 #pragma unroll
-        for (int m = 1; m < 32; m <<= 1) {
+        for (int m = 16; m < 64; m <<= 1) {
             const float o_s0 = __shfl_xor(r_s0[i], m);
             const int o_i0 = __shfl_xor(r_i0[i], m);
             const float o_s1 = __shfl_xor(r_s1[i], m);
             top2_merge(r_s0[i], r_i0[i], r_s1[i], o_s0, o_i0, o_s1);
         }
     }
+    __syncthreads();  // every wave is done with its B slots: reuse the region as merge scratch
+    float* sR = smem + kLdsB;  // [wave][3][128 rows]
     if (tx == 0) {
-        const long long o = pd.rp_off + (long long)item.range * pd.n1pad + row0;
 #pragma unroll
         for (int i = 0; i < kTM; ++i) {
-            rp_s0[o + i] = r_s0[i];
-            rp_i0[o + i] = r_i0[i];
-            rp_s1[o + i] = r_s1[i];
+            const int r = 4 * ty + (i & 3) + (i >> 2) * 64;
+            sR[(wave * 3 + 0) * kBM + r] = r_s0[i];
+            sR[(wave * 3 + 1) * kBM + r] = __int_as_float(r_i0[i]);
+            sR[(wave * 3 + 2) * kBM + r] = r_s1[i];
         }
     }
+    __syncthreads();
+    if (tid < kBM) {
+        float s0 = sR[0 * kBM + tid];
+        int i0 = __float_as_int(sR[1 * kBM + tid]);
+        float s1 = sR[2 * kBM + tid];
+#pragma unroll
+        for (int w = 1; w < 8; ++w)
+            top2_merge(s0, i0, s1, sR[(w * 3 + 0) * kBM + tid], __float_as_int(sR[(w * 3 + 1) * kBM + tid]),
+                       sR[(w * 3 + 2) * kBM + tid]);
+        const long long o = pd.rp_off + (long long)item.range * pd.n1pad + item.a_blk * kBM + tid;
+        rp_s0[o] = s0;
+        rp_i0[o] = i0;
+        rp_s1[o] = s1;
+    }
+#undef MSFM_FOREACH
 }
 
 // ---------------------------------------------------------------------------------------
