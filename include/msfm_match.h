@@ -67,6 +67,14 @@ typedef struct msfm_profile {
     double total_device_ms;    /* first launch -> last result copy of the call */
     int64_t descriptor_pairs;  /* sum n1*n2 over the pairs of the call */
     int64_t dist_algo_bytes;   /* compulsory HBM bytes of the distance kernel */
+    /* MFMA prefilter path (two approx_kernel sweeps per batch + exact re-check of the candidates) */
+    double approx_kernel_ms;   /* sum over batches of pass 1 + thresholds + pass 2 */
+    int approx_kernel_launches;
+    int prefilter_pairs;       /* pairs answered through the prefilter path */
+    int fallback_pairs;        /* pairs whose candidate list overflowed -> brute-force exact kernel */
+    int64_t candidates;        /* exact distances evaluated for prefiltered pairs */
+    int64_t prefilter_descriptor_pairs;
+    int64_t exact_descriptor_pairs; /* descriptor pairs that went through the brute-force kernel */
 } msfm_profile;
 
 /* ---- context ------------------------------------------------------------------------- */
@@ -76,6 +84,9 @@ const char* msfm_last_error(const msfm_ctx* ctx);
 /* device name + CU count of the context's GPU (for bench reports); name_cap >= 64 */
 int msfm_device_info(const msfm_ctx* ctx, char* name, int name_cap, int* cu_count, int* clock_mhz);
 int msfm_set_accum_order(msfm_ctx* ctx, int order);
+/* 1 (default): MFMA prefilter + exact re-check where safe; 0: always the brute-force exact kernel.
+ * Results are bit-identical either way. */
+int msfm_set_prefilter(msfm_ctx* ctx, int enable);
 int msfm_get_profile(const msfm_ctx* ctx, msfm_profile* out);
 
 /* ---- descriptor store -------------------------------------------------------------------

@@ -18,7 +18,7 @@ MAX_IMAGES = 10000
 DIM = 128
 
 EXPORTS = [
-    "msfm_create", "msfm_destroy", "msfm_last_error", "msfm_device_info", "msfm_set_accum_order",
+    "msfm_create", "msfm_destroy", "msfm_last_error", "msfm_device_info", "msfm_set_accum_order", "msfm_set_prefilter",
     "msfm_get_profile", "msfm_upload_image", "msfm_image_rows", "msfm_clear_images",
     "msfm_match_pair", "msfm_match_pairs", "msfm_fetch_matches", "msfm_knn2_pair",
     "msfm_topscale_select", "msfm_pair_id", "msfm_pair_from_id", "msfm_swap_image_pair",
@@ -33,7 +33,10 @@ class MatchParams(C.Structure):
 class Profile(C.Structure):
     _fields_ = [("dist_kernel_ms", C.c_double), ("dist_kernel_launches", C.c_int),
                 ("total_device_ms", C.c_double), ("descriptor_pairs", C.c_int64),
-                ("dist_algo_bytes", C.c_int64)]
+                ("dist_algo_bytes", C.c_int64), ("approx_kernel_ms", C.c_double),
+                ("approx_kernel_launches", C.c_int), ("prefilter_pairs", C.c_int), ("fallback_pairs", C.c_int),
+                ("candidates", C.c_int64), ("prefilter_descriptor_pairs", C.c_int64),
+                ("exact_descriptor_pairs", C.c_int64)]
 
 
 class MsfmError(RuntimeError):
@@ -63,6 +66,7 @@ def load():
     L.msfm_last_error.restype = C.c_char_p
     L.msfm_device_info.argtypes = [vp, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.msfm_set_accum_order.argtypes = [vp, C.c_int]
+    L.msfm_set_prefilter.argtypes = [vp, C.c_int]
     L.msfm_get_profile.argtypes = [vp, C.POINTER(Profile)]
     L.msfm_upload_image.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int]
     L.msfm_image_rows.argtypes = [vp, C.c_int, C.POINTER(C.c_int)]
@@ -77,9 +81,7 @@ def load():
     L.msfm_swap_image_pair.argtypes = [C.c_int, C.c_int]
     L.msfm_version.restype = C.c_char_p
     for name in EXPORTS:
-        fn = getattr(L, name)
-        if fn.restype is C.c_int or fn.restype is None or fn.restype is C.c_char_p:
-            continue
+        getattr(L, name)  # raises AttributeError if the library lacks a declared symbol
     _lib = L
     return L
 
@@ -135,6 +137,10 @@ class Context:
 
     def set_accum_order(self, order):
         self._chk(self._L.msfm_set_accum_order(self._h, int(order)))
+
+    def set_prefilter(self, enable):
+        """True (default): MFMA prefilter + exact re-check; False: brute-force exact kernel only."""
+        self._chk(self._L.msfm_set_prefilter(self._h, int(bool(enable))))
 
     def profile(self):
         p = Profile()

@@ -75,6 +75,8 @@ struct PairDesc {
     int n1pad, n2pad;
     int ranges;            // B-tile ranges the pair was split into
     int valid;             // 0: a side is empty -> no neighbours, no device work
+    int path;              // 0: brute-force exact kernel, 1: MFMA prefilter + exact re-check
+    int pad0;
     long long rp_off;      // row partials  [ranges][n1pad]
     long long cp_off;      // column partials [a_blocks][n2pad]
     long long kf_off;      // final forward knn arrays [n1pad]
@@ -421,7 +423,7 @@ __global__ void merge_knn_kernel(const PairDesc* __restrict__ pairs,
                                  int* __restrict__ k_i0, float* __restrict__ k_d0, float* __restrict__ k_d1,
                                  int* __restrict__ fix_count, int4* __restrict__ fix_list, int fix_cap) {
     const PairDesc pd = pairs[blockIdx.y];
-    if (!pd.valid) return;
+    if (!pd.valid || pd.path != 0) return;
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     for (int dir = 0; dir < 2; ++dir) {
         const int n = dir == 0 ? pd.n1 : pd.n2;

@@ -8,9 +8,11 @@
 // when there is none.
 #include "msfm_match.h"
 #include "msfm_kernels.hip.h"
+#include "msfm_prefilter.hip.h"
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -45,7 +47,20 @@ struct Image {
     int nblk = 0;
     float* panel = nullptr;
     float* raw = nullptr;
+    // prefilter operands: fp16 swizzled blocks, row norms (+inf padded), maxima
+    _Float16* h16 = nullptr;
+    float* nrm = nullptr;
+    float nrm_max = 0.f, abs_max = 0.f;
+    bool pf_safe = false;
 };
+
+void free_image(Image& im) {
+    if (im.panel) (void)hipFree(im.panel);
+    if (im.raw) (void)hipFree(im.raw);
+    if (im.h16) (void)hipFree(im.h16);
+    if (im.nrm) (void)hipFree(im.nrm);
+    im = Image{};
+}
 
 constexpr int kSlots = 2 * MSFM_MAX_IMAGES;  // ids >= MSFM_MAX_IMAGES: auxiliary (top-scale subsets)
 
@@ -65,6 +80,9 @@ struct msfm_ctx {
     DevBuf d_k_i0, d_k_d0, d_k_d1;
     DevBuf d_st_qt, d_st_d, d_counts, d_offsets, d_out_qt, d_out_d;
     DevBuf d_fix_count, d_fix_list;
+    // prefilter path
+    int prefilter = 1;
+    DevBuf d_pf, d_tu, d_tv, d_cand, d_cand_s, d_cand_count, d_best, d_second, d_maxima;
 
     // results of the last msfm_match_pairs call
     bool have_results = false;
@@ -95,24 +113,22 @@ constexpr int kFixCap = 1 << 16;
 
 struct Batch {
     std::vector<PairDesc> pairs;
+    std::vector<PfPair> pf;
     std::vector<WorkItem> items;
-    long long rp_elems = 0, cp_elems = 0, kf_elems = 0, kr_elems = 0, out_elems = 0;
+    long long rp_elems = 0, cp_elems = 0, kf_elems = 0, kr_elems = 0, out_elems = 0, cand_elems = 0;
     int max_npad = 0;
     int64_t desc_pairs = 0;
     int64_t algo_bytes = 0;
 };
 
-// Split the pair list [begin, end) into work items.  Items of one pair are contiguous; the list
-// is then interleaved over the 8 XCDs (workgroup b runs on XCD b % 8) so that the workgroups
-// streaming the same B panels share one L2.
-void build_items(Batch& b) {
-    long long total_ablocks = 0;
-    for (auto& pd : b.pairs)
-        if (pd.valid) total_ablocks += pd.a_blocks;
+// Work items of the pairs whose `path` matches.  Items of one pair are contiguous; the list is then
+// interleaved over the 8 XCDs (workgroup b runs on XCD b % 8) so that the workgroups streaming the
+// same B panels share one L2.
+void build_items(Batch& b, int path) {
     std::vector<WorkItem> lin;
     for (size_t p = 0; p < b.pairs.size(); ++p) {
         PairDesc& pd = b.pairs[p];
-        if (!pd.valid) continue;
+        if (!pd.valid || pd.path != path) continue;
         for (int r = 0; r < pd.ranges; ++r) {
             const int t0 = (int)((long long)pd.b_tiles * r / pd.ranges);
             const int t1 = (int)((long long)pd.b_tiles * (r + 1) / pd.ranges);
@@ -136,7 +152,7 @@ void build_items(Batch& b) {
     }
 }
 
-int fill_pair(msfm_ctx* ctx, int id1, int id2, PairDesc& pd) {
+int fill_pair(msfm_ctx* ctx, int id1, int id2, PairDesc& pd, PfPair& pp) {
     if (id1 < 0 || id1 >= kSlots || id2 < 0 || id2 >= kSlots)
         return fail(ctx, MSFM_E_INVALID, "image id out of range");
     const Image& a = ctx->images[id1];
@@ -156,34 +172,57 @@ int fill_pair(msfm_ctx* ctx, int id1, int id2, PairDesc& pd) {
     pd.ranges = 1;
     // empty query or train set: knnMatch returns nothing, no device work
     pd.valid = (a.n >= 1 && b.n >= 1) ? 1 : 0;
+    pp = PfPair{};
+    pp.a_h = a.h16;
+    pp.b_h = b.h16;
+    pp.a_nrm = a.nrm;
+    pp.b_nrm = b.nrm;
+    pp.a_nrm_max = a.nrm_max;
+    pp.b_nrm_max = b.nrm_max;
+    // the MFMA prefilter needs fp16-representable magnitudes on both sides; tiny pairs are not worth it
+    pp.use = (ctx->prefilter && pd.valid && a.pf_safe && b.pf_safe) ? 1 : 0;
+    pd.path = pp.use;
     return MSFM_OK;
 }
 
-void assign_offsets(Batch& b, int target_items) {
+// offsets every path shares: final kNN arrays and staged match lists
+void assign_common(Batch& b) {
+    for (auto& pd : b.pairs) {
+        pd.kf_off = b.kf_elems;
+        pd.kr_off = b.kr_elems;
+        pd.out_off = b.out_elems;
+        if (!pd.valid) continue;
+        b.kf_elems += pd.n1pad;
+        b.kr_elems += pd.n2pad;
+        b.out_elems += pd.n1;
+        b.desc_pairs += (int64_t)pd.n1 * pd.n2;
+        // compulsory traffic, no cross-pair reuse: both descriptor sets once + both knn lists
+        b.algo_bytes += ((int64_t)pd.n1 + pd.n2) * kDim * 4 + ((int64_t)pd.n1 + pd.n2) * 12;
+        b.max_npad = std::max(b.max_npad, std::max(pd.n1pad, pd.n2pad));
+    }
+    // reverse arrays live behind the forward ones in the same buffers
+    for (auto& pd : b.pairs) pd.kr_off += b.kf_elems;
+}
+
+// partial-result offsets + B-range split of the pairs on `path` (1: prefilter doubles the partial
+// slots: two column halves per range, two row halves per A block)
+void assign_partials(Batch& b, int path, int target_items) {
+    b.rp_elems = b.cp_elems = 0;
     long long total_ablocks = 0;
     for (auto& pd : b.pairs)
-        if (pd.valid) total_ablocks += pd.a_blocks;
+        if (pd.valid && pd.path == path) total_ablocks += pd.a_blocks;
+    const int mult = path == 1 ? 2 : 1;
     for (auto& pd : b.pairs) {
-        if (pd.valid && total_ablocks > 0 && total_ablocks < target_items) {
+        if (!pd.valid || pd.path != path) continue;
+        pd.ranges = 1;
+        if (total_ablocks > 0 && total_ablocks < target_items) {
             long long r = (target_items + total_ablocks - 1) / total_ablocks;
             pd.ranges = (int)std::max<long long>(1, std::min<long long>(r, pd.b_tiles));
         }
         pd.rp_off = b.rp_elems;
         pd.cp_off = b.cp_elems;
-        pd.kf_off = b.kf_elems;
-        pd.kr_off = b.kr_elems;
-        pd.out_off = b.out_elems;
-        if (pd.valid) {
-            b.rp_elems += (long long)pd.ranges * pd.n1pad;
-            b.cp_elems += (long long)pd.a_blocks * pd.n2pad;
-            b.kf_elems += pd.n1pad;
-            b.kr_elems += pd.n2pad;
-            b.out_elems += pd.n1;
-            b.desc_pairs += (int64_t)pd.n1 * pd.n2;
-            // compulsory traffic, no cross-pair reuse: both descriptor sets once + both knn lists
-            b.algo_bytes += ((int64_t)pd.n1 + pd.n2) * kDim * 4 + ((int64_t)pd.n1 + pd.n2) * 12;
-            b.max_npad = std::max(b.max_npad, std::max(pd.n1pad, pd.n2pad));
-        }
+        b.rp_elems += (long long)pd.ranges * mult * pd.n1pad;
+        b.cp_elems += (long long)pd.a_blocks * mult * pd.n2pad;
     }
 }
 
@@ -196,63 +235,205 @@ hipEvent_t get_event(msfm_ctx* ctx, size_t i) {
     return ctx->ev_pool[i];
 }
 
-// distance + merge + tie fix-up for one batch (device arrays left in ctx buffers)
-int run_knn(msfm_ctx* ctx, Batch& b, size_t ev_base) {
+int upload_pairs(msfm_ctx* ctx, Batch& b) {
     const size_t P = b.pairs.size();
     HIPCHK(ctx, ctx->d_pairs.ensure(P * sizeof(PairDesc)));
+    HIPCHK(ctx, ctx->d_pf.ensure(P * sizeof(PfPair)));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_pairs.p, b.pairs.data(), P * sizeof(PairDesc), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_pf.p, b.pf.data(), P * sizeof(PfPair), hipMemcpyHostToDevice, ctx->stream));
+    return MSFM_OK;
+}
+
+int upload_items(msfm_ctx* ctx, Batch& b) {
     HIPCHK(ctx, ctx->d_items.ensure(std::max<size_t>(1, b.items.size()) * sizeof(WorkItem)));
+    if (!b.items.empty())
+        HIPCHK(ctx, hipMemcpyAsync(ctx->d_items.p, b.items.data(), b.items.size() * sizeof(WorkItem), hipMemcpyHostToDevice, ctx->stream));
+    return MSFM_OK;
+}
+
+// MFMA prefilter + exact re-check for the pairs on path 1.  On return pairs whose candidate list
+// overflowed have been moved to path 0.
+int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base) {
+    const size_t P = b.pairs.size();
+    assign_partials(b, 1, 8 * ctx->cu_count);
+    b.cand_elems = 0;
+    for (size_t p = 0; p < P; ++p) {
+        PairDesc& pd = b.pairs[p];
+        PfPair& pp = b.pf[p];
+        pp.tu_off = pd.kf_off;
+        pp.tv_off = pd.kr_off;  // same combined index space as the kNN arrays
+        pp.cand_off = b.cand_elems;
+        pp.cand_cap = 0;
+        if (pd.valid && pp.use) {
+            pp.cand_cap = 8 * (pd.n1 + pd.n2) + 1024;
+            b.cand_elems += pp.cand_cap;
+        }
+    }
+    build_items(b, 1);
+    if (b.items.empty()) return MSFM_OK;
+    const long long kn = std::max<long long>(1, b.kf_elems + b.kr_elems);
+    HIPCHK(ctx, ctx->d_rp_s0.ensure(std::max<long long>(1, b.rp_elems) * 4));
+    HIPCHK(ctx, ctx->d_rp_s1.ensure(std::max<long long>(1, b.rp_elems) * 4));
+    HIPCHK(ctx, ctx->d_cp_s0.ensure(std::max<long long>(1, b.cp_elems) * 4));
+    HIPCHK(ctx, ctx->d_cp_s1.ensure(std::max<long long>(1, b.cp_elems) * 4));
+    HIPCHK(ctx, ctx->d_tu.ensure(kn * 4));
+    HIPCHK(ctx, ctx->d_cand.ensure(std::max<long long>(1, b.cand_elems) * sizeof(int2)));
+    HIPCHK(ctx, ctx->d_cand_s.ensure(std::max<long long>(1, b.cand_elems) * 4));
+    HIPCHK(ctx, ctx->d_cand_count.ensure(P * 4));
+    HIPCHK(ctx, ctx->d_best.ensure(kn * 8));
+    HIPCHK(ctx, ctx->d_second.ensure(kn * 8));
+    int rc = upload_pairs(ctx, b);
+    if (rc != MSFM_OK) return rc;
+    rc = upload_items(ctx, b);
+    if (rc != MSFM_OK) return rc;
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_cand_count.p, 0, P * 4, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_best.p, 0xff, kn * 8, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_second.p, 0xff, kn * 8, ctx->stream));
+
+    hipEvent_t e0 = get_event(ctx, ev_base), e1 = get_event(ctx, ev_base + 1);
+    if (!e0 || !e1) return fail(ctx, MSFM_E_DEVICE, "hipEventCreate failed");
+    const dim3 grid((unsigned)b.items.size()), block(kPfThreads);
+    const PairDesc* dp = ctx->d_pairs.as<PairDesc>();
+    const PfPair* dpf = ctx->d_pf.as<PfPair>();
+    float* tuv = ctx->d_tu.as<float>();  // rows at kf offsets, columns at kr offsets (one buffer)
+    HIPCHK(ctx, hipEventRecord(e0, ctx->stream));
+    hipLaunchKernelGGL(approx_kernel<1>, grid, block, kPfLdsBytes, ctx->stream, dp, dpf, ctx->d_items.as<WorkItem>(),
+                       ctx->d_rp_s0.as<float>(), ctx->d_rp_s1.as<float>(), ctx->d_cp_s0.as<float>(), ctx->d_cp_s1.as<float>(),
+                       (const float*)nullptr, (const float*)nullptr, (int2*)nullptr, (int*)nullptr);
+    HIPCHK(ctx, hipGetLastError());
+    const dim3 mgrid((unsigned)((b.max_npad + 255) / 256), (unsigned)P);
+    hipLaunchKernelGGL(pf_thresholds_kernel, mgrid, dim3(256), 0, ctx->stream, dp, dpf, ctx->d_rp_s0.as<float>(),
+                       ctx->d_rp_s1.as<float>(), ctx->d_cp_s0.as<float>(), ctx->d_cp_s1.as<float>(), tuv, tuv);
+    HIPCHK(ctx, hipGetLastError());
+    hipLaunchKernelGGL(approx_kernel<2>, grid, block, kPfLdsBytes, ctx->stream, dp, dpf, ctx->d_items.as<WorkItem>(),
+                       (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (const float*)tuv, (const float*)tuv,
+                       ctx->d_cand.as<int2>(), ctx->d_cand_count.as<int>());
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipEventRecord(e1, ctx->stream));
+    ctx->prof.approx_kernel_launches += 2;
+    const dim3 cgrid(64, (unsigned)P);
+    if (ctx->order == MSFM_ORDER_SSE4X4)
+        hipLaunchKernelGGL(pf_exact_candidates_kernel<0>, cgrid, dim3(256), 0, ctx->stream, dp, dpf, ctx->d_cand_count.as<int>(),
+                           ctx->d_cand.as<int2>(), ctx->d_cand_s.as<float>());
+    else
+        hipLaunchKernelGGL(pf_exact_candidates_kernel<1>, cgrid, dim3(256), 0, ctx->stream, dp, dpf, ctx->d_cand_count.as<int>(),
+                           ctx->d_cand.as<int2>(), ctx->d_cand_s.as<float>());
+    HIPCHK(ctx, hipGetLastError());
+    const dim3 rgrid(16, (unsigned)P);
+    hipLaunchKernelGGL(pf_reduce_best_kernel, rgrid, dim3(256), 0, ctx->stream, dpf, dp, ctx->d_cand_count.as<int>(),
+                       ctx->d_cand.as<int2>(), ctx->d_cand_s.as<float>(), ctx->d_best.as<unsigned long long>());
+    HIPCHK(ctx, hipGetLastError());
+    hipLaunchKernelGGL(pf_reduce_second_kernel, rgrid, dim3(256), 0, ctx->stream, dpf, dp, ctx->d_cand_count.as<int>(),
+                       ctx->d_cand.as<int2>(), ctx->d_cand_s.as<float>(), ctx->d_best.as<unsigned long long>(),
+                       ctx->d_second.as<unsigned long long>());
+    HIPCHK(ctx, hipGetLastError());
+    hipLaunchKernelGGL(pf_finalize_kernel, mgrid, dim3(256), 0, ctx->stream, dp, dpf, ctx->d_best.as<unsigned long long>(),
+                       ctx->d_second.as<unsigned long long>(), ctx->d_k_i0.as<int>(), ctx->d_k_d0.as<float>(),
+                       ctx->d_k_d1.as<float>(), ctx->d_fix_count.as<int>(), ctx->d_fix_list.as<int4>(), kFixCap);
+    HIPCHK(ctx, hipGetLastError());
+
+    // candidate-list overflow -> brute-force exact path for that pair
+    std::vector<int> counts(P);
+    HIPCHK(ctx, hipMemcpyAsync(counts.data(), ctx->d_cand_count.p, P * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    float ms = 0.f;
+    HIPCHK(ctx, hipEventElapsedTime(&ms, e0, e1));
+    ctx->prof.approx_kernel_ms += ms;
+    for (size_t p = 0; p < P; ++p) {
+        if (!b.pairs[p].valid || !b.pf[p].use) continue;
+        if (counts[p] > b.pf[p].cand_cap) {
+            b.pf[p].use = 0;
+            b.pairs[p].path = 0;
+            ctx->prof.fallback_pairs += 1;
+        } else {
+            ctx->prof.prefilter_pairs += 1;
+            ctx->prof.candidates += counts[p];
+            ctx->prof.prefilter_descriptor_pairs += (int64_t)b.pairs[p].n1 * b.pairs[p].n2;
+        }
+    }
+    return MSFM_OK;
+}
+
+// brute-force exact distance kernel + merge for the pairs on path 0
+int run_exact(msfm_ctx* ctx, Batch& b, size_t ev_base) {
+    const size_t P = b.pairs.size();
+    assign_partials(b, 0, 4 * ctx->cu_count);
+    build_items(b, 0);
+    if (b.items.empty()) return MSFM_OK;
     HIPCHK(ctx, ctx->d_rp_s0.ensure(std::max<long long>(1, b.rp_elems) * 4));
     HIPCHK(ctx, ctx->d_rp_i0.ensure(std::max<long long>(1, b.rp_elems) * 4));
     HIPCHK(ctx, ctx->d_rp_s1.ensure(std::max<long long>(1, b.rp_elems) * 4));
     HIPCHK(ctx, ctx->d_cp_s0.ensure(std::max<long long>(1, b.cp_elems) * 4));
     HIPCHK(ctx, ctx->d_cp_i0.ensure(std::max<long long>(1, b.cp_elems) * 4));
     HIPCHK(ctx, ctx->d_cp_s1.ensure(std::max<long long>(1, b.cp_elems) * 4));
+    int rc = upload_pairs(ctx, b);
+    if (rc != MSFM_OK) return rc;
+    rc = upload_items(ctx, b);
+    if (rc != MSFM_OK) return rc;
+    hipEvent_t e0 = get_event(ctx, ev_base), e1 = get_event(ctx, ev_base + 1);
+    if (!e0 || !e1) return fail(ctx, MSFM_E_DEVICE, "hipEventCreate failed");
+    HIPCHK(ctx, hipEventRecord(e0, ctx->stream));
+    const dim3 grid((unsigned)b.items.size()), block(kThreads);
+    if (ctx->order == MSFM_ORDER_SSE4X4)
+        hipLaunchKernelGGL(dist_top2_kernel<0>, grid, block, kLdsBytes, ctx->stream,
+                           ctx->d_pairs.as<PairDesc>(), ctx->d_items.as<WorkItem>(),
+                           ctx->d_rp_s0.as<float>(), ctx->d_rp_i0.as<int>(), ctx->d_rp_s1.as<float>(),
+                           ctx->d_cp_s0.as<float>(), ctx->d_cp_i0.as<int>(), ctx->d_cp_s1.as<float>());
+    else
+        hipLaunchKernelGGL(dist_top2_kernel<1>, grid, block, kLdsBytes, ctx->stream,
+                           ctx->d_pairs.as<PairDesc>(), ctx->d_items.as<WorkItem>(),
+                           ctx->d_rp_s0.as<float>(), ctx->d_rp_i0.as<int>(), ctx->d_rp_s1.as<float>(),
+                           ctx->d_cp_s0.as<float>(), ctx->d_cp_i0.as<int>(), ctx->d_cp_s1.as<float>());
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipEventRecord(e1, ctx->stream));
+    ctx->prof.dist_kernel_launches += 1;
+    for (auto& pd : b.pairs)
+        if (pd.valid && pd.path == 0) ctx->prof.exact_descriptor_pairs += (int64_t)pd.n1 * pd.n2;
+    const dim3 mgrid((unsigned)((b.max_npad + 255) / 256), (unsigned)P);
+    hipLaunchKernelGGL(merge_knn_kernel, mgrid, dim3(256), 0, ctx->stream, ctx->d_pairs.as<PairDesc>(),
+                       ctx->d_rp_s0.as<float>(), ctx->d_rp_i0.as<int>(), ctx->d_rp_s1.as<float>(),
+                       ctx->d_cp_s0.as<float>(), ctx->d_cp_i0.as<int>(), ctx->d_cp_s1.as<float>(),
+                       ctx->d_k_i0.as<int>(), ctx->d_k_d0.as<float>(), ctx->d_k_d1.as<float>(),
+                       ctx->d_fix_count.as<int>(), ctx->d_fix_list.as<int4>(), kFixCap);
+    HIPCHK(ctx, hipGetLastError());
+    return MSFM_OK;
+}
+
+// kNN-2 of both directions for every pair of the batch (device arrays left in the ctx buffers):
+// prefilter path where eligible, brute-force exact path for the rest, then the sqrt-space tie fix-up
+int run_knn(msfm_ctx* ctx, Batch& b, size_t ev_base, bool* exact_launched) {
+    assign_common(b);
     const long long kn = std::max<long long>(1, b.kf_elems + b.kr_elems);
-    // reverse arrays live behind the forward ones in the same buffers
-    for (auto& pd : b.pairs) pd.kr_off += b.kf_elems;
     HIPCHK(ctx, ctx->d_k_i0.ensure(kn * 4));
     HIPCHK(ctx, ctx->d_k_d0.ensure(kn * 4));
     HIPCHK(ctx, ctx->d_k_d1.ensure(kn * 4));
     HIPCHK(ctx, ctx->d_fix_count.ensure(4));
     HIPCHK(ctx, ctx->d_fix_list.ensure((size_t)kFixCap * sizeof(int4)));
-
-    HIPCHK(ctx, hipMemcpyAsync(ctx->d_pairs.p, b.pairs.data(), P * sizeof(PairDesc), hipMemcpyHostToDevice, ctx->stream));
-    if (!b.items.empty())
-        HIPCHK(ctx, hipMemcpyAsync(ctx->d_items.p, b.items.data(), b.items.size() * sizeof(WorkItem), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemsetAsync(ctx->d_fix_count.p, 0, 4, ctx->stream));
-
-    hipEvent_t e0 = get_event(ctx, ev_base), e1 = get_event(ctx, ev_base + 1);
-    if (!e0 || !e1) return fail(ctx, MSFM_E_DEVICE, "hipEventCreate failed");
-    if (!b.items.empty()) {
-        HIPCHK(ctx, hipEventRecord(e0, ctx->stream));
-        const dim3 grid((unsigned)b.items.size()), block(kThreads);
+    bool any_pf = false, any_exact = false;
+    for (auto& pd : b.pairs) any_pf |= (pd.valid && pd.path == 1);
+    int rc;
+    if (any_pf) {
+        rc = run_prefilter(ctx, b, ev_base + 2);
+        if (rc != MSFM_OK) return rc;
+    }
+    for (auto& pd : b.pairs) any_exact |= (pd.valid && pd.path == 0);
+    *exact_launched = false;
+    if (any_exact) {
+        rc = run_exact(ctx, b, ev_base);
+        if (rc != MSFM_OK) return rc;
+        *exact_launched = !b.items.empty();
+    } else if (!any_pf) {
+        rc = upload_pairs(ctx, b);  // later kernels still read the (all-invalid) pair table
+        if (rc != MSFM_OK) return rc;
+    }
+    if (any_pf || any_exact) {
         if (ctx->order == MSFM_ORDER_SSE4X4)
-            hipLaunchKernelGGL(dist_top2_kernel<0>, grid, block, kLdsBytes, ctx->stream,
-                               ctx->d_pairs.as<PairDesc>(), ctx->d_items.as<WorkItem>(),
-                               ctx->d_rp_s0.as<float>(), ctx->d_rp_i0.as<int>(), ctx->d_rp_s1.as<float>(),
-                               ctx->d_cp_s0.as<float>(), ctx->d_cp_i0.as<int>(), ctx->d_cp_s1.as<float>());
-        else
-            hipLaunchKernelGGL(dist_top2_kernel<1>, grid, block, kLdsBytes, ctx->stream,
-                               ctx->d_pairs.as<PairDesc>(), ctx->d_items.as<WorkItem>(),
-                               ctx->d_rp_s0.as<float>(), ctx->d_rp_i0.as<int>(), ctx->d_rp_s1.as<float>(),
-                               ctx->d_cp_s0.as<float>(), ctx->d_cp_i0.as<int>(), ctx->d_cp_s1.as<float>());
-        HIPCHK(ctx, hipGetLastError());
-        HIPCHK(ctx, hipEventRecord(e1, ctx->stream));
-        ctx->prof.dist_kernel_launches += 1;
-
-        const dim3 mgrid((unsigned)((b.max_npad + 255) / 256), (unsigned)P);
-        hipLaunchKernelGGL(merge_knn_kernel, mgrid, dim3(256), 0, ctx->stream, ctx->d_pairs.as<PairDesc>(),
-                           ctx->d_rp_s0.as<float>(), ctx->d_rp_i0.as<int>(), ctx->d_rp_s1.as<float>(),
-                           ctx->d_cp_s0.as<float>(), ctx->d_cp_i0.as<int>(), ctx->d_cp_s1.as<float>(),
-                           ctx->d_k_i0.as<int>(), ctx->d_k_d0.as<float>(), ctx->d_k_d1.as<float>(),
-                           ctx->d_fix_count.as<int>(), ctx->d_fix_list.as<int4>(), kFixCap);
-        HIPCHK(ctx, hipGetLastError());
-        if (ctx->order == MSFM_ORDER_SSE4X4)
-            hipLaunchKernelGGL(tie_fixup_kernel<0>, dim3(1024), dim3(64), 0, ctx->stream, ctx->d_pairs.as<PairDesc>(),
+            hipLaunchKernelGGL(tie_fixup_kernel<0>, dim3(256), dim3(64), 0, ctx->stream, ctx->d_pairs.as<PairDesc>(),
                                ctx->d_fix_count.as<int>(), ctx->d_fix_list.as<int4>(), kFixCap,
                                ctx->d_k_i0.as<int>(), ctx->d_k_d0.as<float>());
         else
-            hipLaunchKernelGGL(tie_fixup_kernel<1>, dim3(1024), dim3(64), 0, ctx->stream, ctx->d_pairs.as<PairDesc>(),
+            hipLaunchKernelGGL(tie_fixup_kernel<1>, dim3(256), dim3(64), 0, ctx->stream, ctx->d_pairs.as<PairDesc>(),
                                ctx->d_fix_count.as<int>(), ctx->d_fix_list.as<int4>(), kFixCap,
                                ctx->d_k_i0.as<int>(), ctx->d_k_d0.as<float>());
         HIPCHK(ctx, hipGetLastError());
@@ -325,6 +506,17 @@ int msfm_create(int device_ordinal, msfm_ctx** out_ctx) {
         delete ctx;
         return MSFM_E_DEVICE;
     }
+    hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(approx_kernel<1>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, kPfLdsBytes);
+    hipError_t e3 = hipFuncSetAttribute(reinterpret_cast<const void*>(approx_kernel<2>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, kPfLdsBytes);
+    if (e2 != hipSuccess || e3 != hipSuccess) {
+        std::fprintf(stderr, "msfm_create: cannot reserve %d bytes of LDS for the prefilter kernels\n", kPfLdsBytes);
+        (void)hipStreamDestroy(ctx->stream);
+        delete ctx;
+        return MSFM_E_DEVICE;
+    }
+    if (const char* e = std::getenv("MSFM_PREFILTER")) ctx->prefilter = (e[0] != '0');
     *out_ctx = ctx;
     return MSFM_OK;
 }
@@ -333,14 +525,12 @@ void msfm_destroy(msfm_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    for (auto& im : ctx->images) {
-        if (im.panel) (void)hipFree(im.panel);
-        if (im.raw) (void)hipFree(im.raw);
-    }
+    for (auto& im : ctx->images) free_image(im);
     DevBuf* bufs[] = {&ctx->d_pairs, &ctx->d_items, &ctx->d_stage, &ctx->d_rp_s0, &ctx->d_rp_i0, &ctx->d_rp_s1,
                       &ctx->d_cp_s0, &ctx->d_cp_i0, &ctx->d_cp_s1, &ctx->d_k_i0, &ctx->d_k_d0, &ctx->d_k_d1,
                       &ctx->d_st_qt, &ctx->d_st_d, &ctx->d_counts, &ctx->d_offsets, &ctx->d_out_qt,
-                      &ctx->d_out_d, &ctx->d_fix_count, &ctx->d_fix_list};
+                      &ctx->d_out_d, &ctx->d_fix_count, &ctx->d_fix_list, &ctx->d_pf, &ctx->d_tu, &ctx->d_tv,
+                      &ctx->d_cand, &ctx->d_cand_s, &ctx->d_cand_count, &ctx->d_best, &ctx->d_second, &ctx->d_maxima};
     for (DevBuf* b : bufs) b->release();
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(ctx->stream);
@@ -377,6 +567,12 @@ int msfm_set_accum_order(msfm_ctx* ctx, int order) {
     return MSFM_OK;
 }
 
+int msfm_set_prefilter(msfm_ctx* ctx, int enable) {
+    if (!ctx) return MSFM_E_INVALID;
+    ctx->prefilter = enable ? 1 : 0;
+    return MSFM_OK;
+}
+
 int msfm_get_profile(const msfm_ctx* ctx, msfm_profile* out) {
     if (!ctx || !out) return MSFM_E_INVALID;
     *out = ctx->prof;
@@ -392,9 +588,7 @@ int msfm_upload_image(msfm_ctx* ctx, int image_id, const void* desc, int n, int 
     if (n > 0 && !desc) return fail(ctx, MSFM_E_INVALID, "null descriptor pointer");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     Image& im = ctx->images[image_id];
-    if (im.panel) (void)hipFree(im.panel);
-    if (im.raw) (void)hipFree(im.raw);
-    im = Image{};
+    free_image(im);
     im.n = n;
     im.nblk = (n + kBM - 1) / kBM;
     if (n == 0) return MSFM_OK;
@@ -416,8 +610,22 @@ int msfm_upload_image(msfm_ctx* ctx, int image_id, const void* desc, int n, int 
             hipLaunchKernelGGL((layout_kernel<1, unsigned char>), dim3(blocks), dim3(256), 0, ctx->stream, ctx->d_stage.as<unsigned char>(), im.raw, im.panel, n, im.nblk);
     }
     HIPCHK(ctx, hipGetLastError());
+    // prefilter operands (order-independent): fp16 swizzled blocks, norms, maxima
+    const int npad = im.nblk * kBM;
+    HIPCHK(ctx, hipMalloc((void**)&im.h16, (size_t)npad * kDim * 2));
+    HIPCHK(ctx, hipMalloc((void**)&im.nrm, (size_t)npad * 4));
+    HIPCHK(ctx, ctx->d_maxima.ensure(8));
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_maxima.p, 0, 8, ctx->stream));
+    hipLaunchKernelGGL(pf_prepare_kernel, dim3(std::min(2048, (npad * 16 + 255) / 256)), dim3(256), 0, ctx->stream,
+                       im.raw, im.h16, im.nrm, ctx->d_maxima.as<unsigned>(), n, npad);
+    HIPCHK(ctx, hipGetLastError());
+    unsigned mx[2] = {0, 0};
+    HIPCHK(ctx, hipMemcpyAsync(mx, ctx->d_maxima.p, 8, hipMemcpyDeviceToHost, ctx->stream));
     // the caller may free/reuse `desc` (and we reuse d_stage) as soon as we return
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    std::memcpy(&im.nrm_max, &mx[0], 4);
+    std::memcpy(&im.abs_max, &mx[1], 4);
+    im.pf_safe = (im.abs_max <= kF16Safe) && (im.nrm_max < 3.0e38f);  // NaN/inf compare false
     return MSFM_OK;
 }
 
@@ -433,11 +641,7 @@ int msfm_clear_images(msfm_ctx* ctx) {
     if (!ctx) return MSFM_E_INVALID;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    for (auto& im : ctx->images) {
-        if (im.panel) (void)hipFree(im.panel);
-        if (im.raw) (void)hipFree(im.raw);
-        im = Image{};
-    }
+    for (auto& im : ctx->images) free_image(im);
     return MSFM_OK;
 }
 
@@ -470,20 +674,23 @@ int msfm_match_pairs(msfm_ctx* ctx, const int32_t* pairs, int n_pairs, const msf
         int end = begin;
         while (end < n_pairs && (end - begin) < kMaxPairsPerBatch) {
             PairDesc pd;
-            int rc = fill_pair(ctx, pairs[2 * end], pairs[2 * end + 1], pd);
+            PfPair pp;
+            int rc = fill_pair(ctx, pairs[2 * end], pairs[2 * end + 1], pd, pp);
             if (rc != MSFM_OK) return rc;
-            const long long need = pd.valid ? ((long long)pd.n1pad + (long long)pd.a_blocks * pd.n2pad) : 0;
+            // partial-result scratch of the larger of the two paths (prefilter: 2x slots + candidates)
+            const long long need = pd.valid ? (2 * (long long)pd.n1pad + 2 * (long long)pd.a_blocks * pd.n2pad +
+                                               3 * (8LL * (pd.n1 + pd.n2) + 1024)) : 0;
             if (end > begin && est + need > kScratchElems) break;
             est += need;
             b.pairs.push_back(pd);
+            b.pf.push_back(pp);
             ++end;
         }
-        assign_offsets(b, 2 * ctx->cu_count * 2);
-        build_items(b);
         const size_t P = b.pairs.size();
         const size_t ev_base = ev_next;
-        ev_next += 2;
-        int rc = run_knn(ctx, b, ev_base);
+        ev_next += 4;
+        bool exact_launched = false;
+        int rc = run_knn(ctx, b, ev_base, &exact_launched);
         if (rc != MSFM_OK) return rc;
 
         HIPCHK(ctx, ctx->d_st_qt.ensure(std::max<long long>(1, b.out_elems) * sizeof(int2)));
@@ -519,7 +726,7 @@ int msfm_match_pairs(msfm_ctx* ctx, const int32_t* pairs, int n_pairs, const msf
             HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         }
         for (size_t p = 0; p < P; ++p) ctx->res_offsets[(size_t)begin + p + 1] = (int64_t)base + offs[p + 1];
-        rc = accumulate_kernel_time(ctx, ev_base, !b.items.empty());
+        rc = accumulate_kernel_time(ctx, ev_base, exact_launched);
         if (rc != MSFM_OK) return rc;
         begin = end;
     }
@@ -560,16 +767,17 @@ int msfm_knn2_pair(msfm_ctx* ctx, int id1, int id2, int32_t* fwd_idx0, float* fw
     ctx->prof = msfm_profile{};
     Batch b;
     PairDesc pd;
-    int rc = fill_pair(ctx, id1, id2, pd);
+    PfPair pp;
+    int rc = fill_pair(ctx, id1, id2, pd, pp);
     if (rc != MSFM_OK) return rc;
     b.pairs.push_back(pd);
-    assign_offsets(b, 2 * ctx->cu_count * 2);
-    build_items(b);
-    rc = run_knn(ctx, b, 2);
+    b.pf.push_back(pp);
+    bool exact_launched = false;
+    rc = run_knn(ctx, b, 2, &exact_launched);
     if (rc != MSFM_OK) return rc;
     rc = check_fix_overflow(ctx);
     if (rc != MSFM_OK) return rc;
-    rc = accumulate_kernel_time(ctx, 2, !b.items.empty());
+    rc = accumulate_kernel_time(ctx, 2, exact_launched);
     if (rc != MSFM_OK) return rc;
     const PairDesc& q = b.pairs[0];
     const int n1 = ctx->images[id1].n, n2 = ctx->images[id2].n;

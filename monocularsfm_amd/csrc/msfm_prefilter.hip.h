@@ -1,0 +1,416 @@
+// msfm_prefilter.hip.h -- MFMA prefilter + exact re-check: the fast way to the SAME bits.
+//
+// The exact-order kernel (dist_top2_kernel) spends 384 un-fusable VALU ops on every one of the
+// n1*n2 descriptor pairs although only the two nearest neighbours per row/column matter.  This path
+// finds a small, PROVABLY sufficient candidate set with the matrix cores and evaluates the pinned
+// fp32 order only on it:
+//
+//   pass 1  approx_kernel<1>   S~ = |a|^2 + |b|^2 - 2 a~.b~ with fp16 operands on
+//                              v_mfma_f32_32x32x16_f16; per row / column the two smallest S~ values.
+//   thresholds_kernel          T = S~(2) + 2*eps, eps = rigorous bound on |S~ - S_exact| (below).
+//   pass 2  approx_kernel<2>   same MFMA sweep; every (q,t) with S~ <= T_row[q] or S~ <= T_col[t]
+//                              is appended to the pair's candidate list (a few per row).
+//   exact_candidates_kernel    S_exact in the pinned accumulation order for the candidates only.
+//   reduce (3 tiny kernels)    per row / column the best and second best (S_exact, index) among
+//                              the candidates -> the same kNN arrays merge_knn_kernel produces.
+//
+// Why the candidates suffice.  Let |S~ - S_exact| <= eps for every element of a row.  The two
+// elements with the smallest S~ have S_exact <= S~(2) + eps, so the true second-smallest S_exact is
+// <= S~(2) + eps.  A non-candidate has S~ > S~(2) + 2 eps, hence S_exact > S~(2) + eps: strictly
+// worse than the true second neighbour, so it can neither enter the top-2 nor tie with it.
+//
+// eps.  a~ = fl16(a) (round to nearest): |a~_c - a_c| <= max(2^-11 |a_c|, 2^-25).  MFMA products of
+// two fp16 values are exact in fp32; the fp32 accumulation of 128 terms errs by at most
+// c_acc * sum|a~ b~| (we allow c_acc = 2^-13, an order of magnitude above 128 roundings).  With
+// Cauchy-Schwarz:  |a~.b~ - a.b| <= (2^-10 + 2^-13 + ...) sqrt(na nb) + 2^-25 sqrt(128) (sqrt(na)+sqrt(nb)).
+// Norms (fp32 sums of 128 squares), the three fp32 ops forming S~, and the distance of the pinned
+// fp32 order from the real-number value add < 1e-4 (na + nb).  Using sqrt(na nb) <= (na+nb)/2:
+//     eps(q,t) <= kEpsRel (na + nb) + kEpsAbs (sqrt(na) + sqrt(nb)),  kEpsRel = 1.5e-3, kEpsAbs = 1e-6
+// (the derivation gives 1.2e-3 / 8e-7).  Per row we use nb -> max_t nb.  Images with |value| > 6e4
+// (fp16 overflow) or non-finite norms are not prefiltered; a pair whose candidate list overflows
+// falls back to the brute-force exact kernel.  tests/test_gpu_prefilter.py checks the bound
+// empirically and the end results bit-for-bit.
+#pragma once
+#include "msfm_kernels.hip.h"
+
+namespace msfm {
+
+constexpr float kEpsRel = 1.5e-3f;
+constexpr float kEpsAbs = 1.0e-6f;
+constexpr float kF16Safe = 6.0e4f;
+
+constexpr int kPfThreads = 256;           // 4 waves: 2 (A row halves of 64) x 2 (B column halves of 32)
+constexpr int kPfBT = 64;                 // B rows per tile
+constexpr int kHalfRowBytes = kDim * 2;   // one fp16 descriptor = 256 B = 16 granules of 16 B
+constexpr int kPfLdsA = kBM * kHalfRowBytes;    // 32 KiB
+constexpr int kPfLdsB = kPfBT * kHalfRowBytes;  // 16 KiB per slot
+constexpr int kPfLdsBytes = kPfLdsA + 2 * kPfLdsB;  // 64 KiB -> two workgroups per CU
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+
+struct PfPair {            // per-pair extras of the prefilter path (parallel to PairDesc)
+    const _Float16* a_h;   // fp16 swizzled blocks
+    const _Float16* b_h;
+    const float* a_nrm;    // |row|^2, +inf on padding rows
+    const float* b_nrm;
+    float a_nrm_max, b_nrm_max;
+    long long tu_off;      // row thresholds (u-space) [n1pad]
+    long long tv_off;      // column thresholds (v-space) [n2pad]
+    long long cand_off;    // candidate list base
+    int cand_cap;
+    int use;               // 1: prefiltered; 0: not safe -> exact brute force
+};
+
+// ---------------------------------------------------------------------------------------------
+// upload-time preparation: fp16 swizzled blocks, row norms, maxima
+//   block layout: [64 rows][16 granules]; granule g of row r sits at position g ^ (r & 15), so a
+//   linear LDS-DMA of the block lands bank-conflict-free for the MFMA operand reads
+// ---------------------------------------------------------------------------------------------
+__global__ void pf_prepare_kernel(const float* __restrict__ raw, _Float16* __restrict__ h, float* __restrict__ nrm,
+                                  unsigned* __restrict__ maxima /* [0]=nrm_max bits, [1]=abs_max bits */,
+                                  int n, int npad) {
+    const long long total = (long long)npad * 16;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+         e += (long long)gridDim.x * blockDim.x) {
+        const int row = (int)(e >> 4), g = (int)(e & 15);
+        h8 v;
+        float amax = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float x = row < n ? raw[(size_t)row * kDim + g * 8 + k] : 0.f;
+            v[k] = (_Float16)x;
+            amax = fmaxf(amax, fabsf(x));
+            if (!(fabsf(x) <= 3.0e38f)) amax = f_inf();  // NaN / inf
+        }
+        *reinterpret_cast<h8*>(h + ((size_t)row * 16 + (g ^ (row & 15))) * 8) = v;
+        if (amax > 0.f) atomicMax(&maxima[1], __float_as_uint(amax));
+    }
+    for (int row = blockIdx.x * blockDim.x + threadIdx.x; row < npad; row += gridDim.x * blockDim.x) {
+        float s = f_inf();
+        if (row < n) {
+            s = 0.f;
+            for (int k = 0; k < kDim; ++k) {
+                const float x = raw[(size_t)row * kDim + k];
+                s = fmaf(x, x, s);
+            }
+            atomicMax(&maxima[0], __float_as_uint(s));  // s >= 0: uint order == float order; NaN bits sort high
+        }
+        nrm[row] = s;
+    }
+}
+
+__device__ __forceinline__ void glds_copy_bytes(const void* g, void* lds, int bytes, int tid, int nthreads) {
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const char* gp = reinterpret_cast<const char*>(g);
+    char* lp = reinterpret_cast<char*>(lds);
+#pragma unroll 1
+    for (int piece = wave; piece * 1024 < bytes; piece += nthreads / 64)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gp + piece * 1024 + lane * 16),
+                                         (__attribute__((address_space(3))) void*)(lp + piece * 1024), 16, 0, 0);
+}
+
+__device__ __forceinline__ void v2_merge(float& s0, float& s1, float b0, float b1) {
+    s1 = fminf(fmaxf(s0, b0), fminf(s1, b1));
+    s0 = fminf(s0, b0);
+}
+
+// ---------------------------------------------------------------------------------------------
+// approx_kernel<PASS>: one workgroup = one 128-row A block x a range of 64-row B tiles.
+//   wave (wr, wc): A rows wr*64..+63 (two 32-row MFMA blocks), B rows wc*32..+31 of the tile.
+//   MFMA 32x32x16 f16: lane l feeds A[row l&31][k (l>>5)*8..+7] and B[col l&31][same k]; it
+//   receives for column l&31 the 16 rows (r&3) + 8 (r>>2) + 4 (l>>5), r = 0..15.
+//   u = nb_t - 2 dot (row direction, na_q added later), v = na_q - 2 dot (column direction).
+// PASS 1: two smallest u per row (lane-private over its columns, merged at the end) and two
+//         smallest v per column (merged over the lane pair, written per (A block, row half)).
+// PASS 2: append (q, t) where u <= tu[q] or v <= tv[t].
+// ---------------------------------------------------------------------------------------------
+template <int PASS>
+__global__ __launch_bounds__(kPfThreads, 2) void approx_kernel(
+    const PairDesc* __restrict__ pairs, const PfPair* __restrict__ pf, const WorkItem* __restrict__ items,
+    float* __restrict__ rp_s0, float* __restrict__ rp_s1, float* __restrict__ cp_s0, float* __restrict__ cp_s1,
+    const float* __restrict__ tu, const float* __restrict__ tv, int2* __restrict__ cand, int* __restrict__ cand_count) {
+    extern __shared__ __attribute__((aligned(16))) char pf_smem[];
+    char* sA = pf_smem;
+    char* sB = pf_smem + kPfLdsA;
+
+    const WorkItem item = items[blockIdx.x];
+    if (item.pair < 0) return;
+    const PfPair pp = pf[item.pair];
+    if (!pp.use) return;
+    const PairDesc pd = pairs[item.pair];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int lcol = lane & 31, lhalf = lane >> 5;
+
+    const int t_begin = item.bt_begin * 2, t_end = item.bt_end * 2;  // 64-row tiles
+    const char* gA = reinterpret_cast<const char*>(pp.a_h) + (size_t)item.a_blk * kPfLdsA;
+    const char* gB = reinterpret_cast<const char*>(pp.b_h);
+
+    glds_copy_bytes(gA, sA, kPfLdsA, tid, kPfThreads);
+    glds_copy_bytes(gB + (size_t)t_begin * kPfLdsB, sB, kPfLdsB, tid, kPfThreads);
+
+    // this lane's 32 A rows: block i (0,1), reg r: row = wr*64 + i*32 + (r&3) + 8*(r>>2) + 4*lhalf
+    const int arow_base = item.a_blk * kBM + wr * 64 + 4 * lhalf;
+    float na[2][16];
+    float rs0[2][16], rs1[2][16];  // PASS 1: two smallest u per row; PASS 2: rs0 = tu threshold
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = arow_base + i * 32 + (r & 3) + 8 * (r >> 2);
+            na[i][r] = pp.a_nrm[row];
+            if (PASS == 1) { rs0[i][r] = f_inf(); rs1[i][r] = f_inf(); }
+            else { rs0[i][r] = tu[pp.tu_off + row]; rs1[i][r] = 0.f; }
+        }
+
+    // LDS byte offsets of this lane's operand rows (granule XOR applied per k-step)
+    const int a_row0 = wr * 64 + lcol, a_row1 = a_row0 + 32;
+    const int b_row = wc * 32 + lcol;
+
+    int slot = 0;
+#pragma unroll 1
+    for (int t = t_begin; t < t_end; ++t, slot ^= 1) {
+        __syncthreads();  // tile t landed (vmcnt(0) with the barrier), other slot free
+        if (t + 1 < t_end) glds_copy_bytes(gB + (size_t)(t + 1) * kPfLdsB, sB + (slot ^ 1) * kPfLdsB, kPfLdsB, tid, kPfThreads);
+        const char* sb = sB + slot * kPfLdsB;
+        f16v acc0, acc1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const int g = 2 * ks + lhalf;
+            const h8 a0 = *reinterpret_cast<const h8*>(sA + a_row0 * kHalfRowBytes + ((g ^ (a_row0 & 15)) << 4));
+            const h8 a1 = *reinterpret_cast<const h8*>(sA + a_row1 * kHalfRowBytes + ((g ^ (a_row1 & 15)) << 4));
+            const h8 bq = *reinterpret_cast<const h8*>(sb + b_row * kHalfRowBytes + ((g ^ (b_row & 15)) << 4));
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, bq, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, bq, acc1, 0, 0, 0);
+        }
+        const int col = t * kPfBT + wc * 32 + lcol;  // this lane's B row (train index)
+        const float nb = pp.b_nrm[col];
+        if (PASS == 1) {
+            float c0 = f_inf(), c1 = f_inf();
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float d = (i == 0) ? acc0[r] : acc1[r];
+                    const float u = fmaf(d, -2.f, nb);
+                    rs1[i][r] = __builtin_amdgcn_fmed3f(rs0[i][r], rs1[i][r], u);
+                    rs0[i][r] = fminf(rs0[i][r], u);
+                    const float v = fmaf(d, -2.f, na[i][r]);
+                    c1 = __builtin_amdgcn_fmed3f(c0, c1, v);
+                    c0 = fminf(c0, v);
+                }
+            v2_merge(c0, c1, __shfl_xor(c0, 32), __shfl_xor(c1, 32));
+            if (lhalf == 0) {
+                const long long o = pd.cp_off + (long long)(item.a_blk * 2 + wr) * pd.n2pad + col;
+                cp_s0[o] = c0;
+                cp_s1[o] = c1;
+            }
+        } else {
+            const float tvc = tv[pp.tv_off + col];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float d = (i == 0) ? acc0[r] : acc1[r];
+                    const float u = fmaf(d, -2.f, nb);
+                    const float v = fmaf(d, -2.f, na[i][r]);
+                    if (u <= rs0[i][r] || v <= tvc) {
+                        const int k = atomicAdd(&cand_count[item.pair], 1);
+                        if (k < pp.cand_cap)
+                            cand[pp.cand_off + k] = make_int2(arow_base + i * 32 + (r & 3) + 8 * (r >> 2), col);
+                    }
+                }
+        }
+    }
+
+    if (PASS == 1) {
+        // rows: merge the 32 column lanes, then the two column halves (waves wc = 0, 1) via partial slots
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+#pragma unroll
+                for (int m = 1; m < 32; m <<= 1) v2_merge(rs0[i][r], rs1[i][r], __shfl_xor(rs0[i][r], m), __shfl_xor(rs1[i][r], m));
+            }
+        if (lcol == 0) {
+            // row partial slot: (range * 2 + wc)
+            const long long o = pd.rp_off + (long long)(item.range * 2 + wc) * pd.n1pad + arow_base;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int off = i * 32 + (r & 3) + 8 * (r >> 2);
+                    rp_s0[o + off] = rs0[i][r];
+                    rp_s1[o + off] = rs1[i][r];
+                }
+        }
+    }
+}
+
+// thresholds: fold the pass-1 partials; T = S~(2) + 2 eps, stored in u- / v-space.
+// grid = (ceil(max_npad/256), n_pairs)
+__global__ void pf_thresholds_kernel(const PairDesc* __restrict__ pairs, const PfPair* __restrict__ pf,
+                                     const float* __restrict__ rp_s0, const float* __restrict__ rp_s1,
+                                     const float* __restrict__ cp_s0, const float* __restrict__ cp_s1,
+                                     float* __restrict__ tu, float* __restrict__ tv) {
+    const PairDesc pd = pairs[blockIdx.y];
+    const PfPair pp = pf[blockIdx.y];
+    if (!pd.valid || !pp.use) return;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < pd.n1pad) {
+        float s0 = f_inf(), s1 = f_inf();
+        for (int p = 0; p < pd.ranges * 2; ++p) {
+            const long long o = pd.rp_off + (long long)p * pd.n1pad + e;
+            v2_merge(s0, s1, rp_s0[o], rp_s1[o]);
+        }
+        // S~(2) = s1 + na; eps_row = rel*(na + nb_max) + abs*(sqrt(na)+sqrt(nb_max)); threshold in u-space
+        const float na = pp.a_nrm[e];
+        const float eps = kEpsRel * (na + pp.b_nrm_max) + kEpsAbs * (sqrtf(na) + sqrtf(pp.b_nrm_max));
+        const float slack = 2.f * eps + 1e-6f * (fabsf(s1) + na);  // + the roundings of this very formula
+        tu[pp.tu_off + e] = (e < pd.n1) ? s1 + slack : -f_inf();
+    }
+    if (e < pd.n2pad) {
+        float s0 = f_inf(), s1 = f_inf();
+        for (int p = 0; p < pd.a_blocks * 2; ++p) {
+            const long long o = pd.cp_off + (long long)p * pd.n2pad + e;
+            v2_merge(s0, s1, cp_s0[o], cp_s1[o]);
+        }
+        const float nb = pp.b_nrm[e];
+        const float eps = kEpsRel * (nb + pp.a_nrm_max) + kEpsAbs * (sqrtf(nb) + sqrtf(pp.a_nrm_max));
+        const float slack = 2.f * eps + 1e-6f * (fabsf(s1) + nb);
+        tv[pp.tv_off + e] = (e < pd.n2) ? s1 + slack : -f_inf();
+    }
+}
+
+// exact pinned-order S for every candidate: 16 lanes per candidate (SSE order: lane L owns the
+// lane partial k = L mod 16; AVX2 order: 32 partials -> 2 per lane), coalesced 64-B row reads.
+template <int ORDER>
+__global__ void pf_exact_candidates_kernel(const PairDesc* __restrict__ pairs, const PfPair* __restrict__ pf,
+                                           const int* __restrict__ cand_count, const int2* __restrict__ cand,
+                                           float* __restrict__ cand_s) {
+    const int pair = blockIdx.y;
+    const PfPair pp = pf[pair];
+    if (!pp.use) return;
+    const PairDesc pd = pairs[pair];
+    const int n = min(cand_count[pair], pp.cand_cap);
+    const int sub = threadIdx.x & 15;
+    for (int c = (blockIdx.x * blockDim.x + threadIdx.x) >> 4; c < ((n + 3) & ~3); c += (gridDim.x * blockDim.x) >> 4) {
+        const bool live = c < n;
+        const int2 qt = live ? cand[pp.cand_off + c] : make_int2(0, 0);
+        const float* a = pd.a_raw + (size_t)qt.x * kDim;
+        const float* b = pd.b_raw + (size_t)qt.y * kDim;
+        float res;
+        if (ORDER == 0) {
+            float p = 0.f;
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const float t = a[16 * it + sub] - b[16 * it + sub];
+                p = (it == 0) ? t * t : p + t * t;
+            }
+            // s[l] = ((p[l] + p[4+l]) + p[8+l]) + p[12+l]; result = (s0+s2)+(s1+s3)
+            const float p4 = __shfl(p, (threadIdx.x & ~15) | ((sub & 3) + 4), 64);
+            const float p8 = __shfl(p, (threadIdx.x & ~15) | ((sub & 3) + 8), 64);
+            const float p12 = __shfl(p, (threadIdx.x & ~15) | ((sub & 3) + 12), 64);
+            const float p0 = __shfl(p, (threadIdx.x & ~15) | (sub & 3), 64);
+            const float s = ((p0 + p4) + p8) + p12;  // valid in every lane for l = sub & 3
+            const float s0 = __shfl(s, (threadIdx.x & ~15) | 0, 64), s1 = __shfl(s, (threadIdx.x & ~15) | 1, 64);
+            const float s2 = __shfl(s, (threadIdx.x & ~15) | 2, 64), s3 = __shfl(s, (threadIdx.x & ~15) | 3, 64);
+            res = (s0 + s2) + (s1 + s3);
+        } else {
+            // 32 partials: lane `sub` owns L = sub and L = sub + 16
+            float pa = 0.f, pb = 0.f;
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const float ta = a[32 * it + sub] - b[32 * it + sub];
+                const float tb = a[32 * it + sub + 16] - b[32 * it + sub + 16];
+                pa = (it == 0) ? ta * ta : __builtin_fmaf(ta, ta, pa);
+                pb = (it == 0) ? tb * tb : __builtin_fmaf(tb, tb, pb);
+            }
+            // s[l] = ((p[l]+p[8+l])+p[16+l])+p[24+l], l = 0..7: p[l]=pa(l), p[8+l]=pa(8+l), p[16+l]=pb(l), p[24+l]=pb(8+l)
+            const int l = sub & 7, base = threadIdx.x & ~15;
+            const float q0 = __shfl(pa, base | l, 64), q1 = __shfl(pa, base | (8 + l), 64);
+            const float q2 = __shfl(pb, base | l, 64), q3 = __shfl(pb, base | (8 + l), 64);
+            const float s = ((q0 + q1) + q2) + q3;
+            float sv[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) sv[k] = __shfl(s, base | k, 64);
+            res = ((sv[0] + sv[1]) + (sv[2] + sv[3])) + ((sv[4] + sv[5]) + (sv[6] + sv[7]));
+        }
+        if (live && sub == 0) cand_s[pp.cand_off + c] = res;
+    }
+}
+
+__device__ __forceinline__ unsigned long long pf_key(float s, int idx) {
+    return ((unsigned long long)__float_as_uint(s) << 32) | (unsigned)idx;  // s >= 0: uint order == float order
+}
+
+// reduce phase A: best (S, idx) per row and per column among the candidates (64-bit atomicMin)
+__global__ void pf_reduce_best_kernel(const PfPair* __restrict__ pf, const PairDesc* __restrict__ pairs,
+                                      const int* __restrict__ cand_count, const int2* __restrict__ cand,
+                                      const float* __restrict__ cand_s, unsigned long long* __restrict__ best) {
+    const int pair = blockIdx.y;
+    const PfPair pp = pf[pair];
+    if (!pp.use) return;
+    const PairDesc pd = pairs[pair];
+    const int n = min(cand_count[pair], pp.cand_cap);
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < n; c += gridDim.x * blockDim.x) {
+        const int2 qt = cand[pp.cand_off + c];
+        const float s = cand_s[pp.cand_off + c];
+        if (!(s < f_inf())) continue;  // batchDistance never inserts a distance >= FLT_MAX
+        atomicMin(&best[pd.kf_off + qt.x], pf_key(s, qt.y));
+        atomicMin(&best[pd.kr_off + qt.y], pf_key(s, qt.x));
+    }
+}
+// reduce phase B: second best = min over the candidates that are not the best one
+__global__ void pf_reduce_second_kernel(const PfPair* __restrict__ pf, const PairDesc* __restrict__ pairs,
+                                        const int* __restrict__ cand_count, const int2* __restrict__ cand,
+                                        const float* __restrict__ cand_s, const unsigned long long* __restrict__ best,
+                                        unsigned long long* __restrict__ second) {
+    const int pair = blockIdx.y;
+    const PfPair pp = pf[pair];
+    if (!pp.use) return;
+    const PairDesc pd = pairs[pair];
+    const int n = min(cand_count[pair], pp.cand_cap);
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < n; c += gridDim.x * blockDim.x) {
+        const int2 qt = cand[pp.cand_off + c];
+        const float s = cand_s[pp.cand_off + c];
+        if (!(s < f_inf())) continue;
+        const unsigned long long kf = pf_key(s, qt.y), kr = pf_key(s, qt.x);
+        if (kf != best[pd.kf_off + qt.x]) atomicMin(&second[pd.kf_off + qt.x], kf);
+        if (kr != best[pd.kr_off + qt.y]) atomicMin(&second[pd.kr_off + qt.y], kr);
+    }
+}
+// finalize: the same outputs as merge_knn_kernel (idx0, d0, d1, tie queue)
+__global__ void pf_finalize_kernel(const PairDesc* __restrict__ pairs, const PfPair* __restrict__ pf,
+                                   const unsigned long long* __restrict__ best, const unsigned long long* __restrict__ second,
+                                   int* __restrict__ k_i0, float* __restrict__ k_d0, float* __restrict__ k_d1,
+                                   int* __restrict__ fix_count, int4* __restrict__ fix_list, int fix_cap) {
+    const PairDesc pd = pairs[blockIdx.y];
+    const PfPair pp = pf[blockIdx.y];
+    if (!pd.valid || !pp.use) return;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    for (int dir = 0; dir < 2; ++dir) {
+        const int n = dir == 0 ? pd.n1 : pd.n2;
+        if (e >= n) continue;
+        const long long ko = (dir == 0 ? pd.kf_off : pd.kr_off) + e;
+        const unsigned long long b = best[ko], s = second[ko];
+        int i0 = -1;
+        float d0 = 3.402823466e+38f, d1 = 3.402823466e+38f;
+        if (b != ~0ull) { i0 = (int)(unsigned)(b & 0xffffffffu); d0 = sqrtf(__uint_as_float((unsigned)(b >> 32))); }
+        if (s != ~0ull) d1 = sqrtf(__uint_as_float((unsigned)(s >> 32)));
+        k_i0[ko] = i0;
+        k_d0[ko] = d0;
+        k_d1[ko] = d1;
+        if (i0 >= 0 && d0 == d1) {
+            const int slot = atomicAdd(fix_count, 1);
+            if (slot < fix_cap) fix_list[slot] = make_int4((int)blockIdx.y, dir, e, 0);
+        }
+    }
+}
+
+}  // namespace msfm

@@ -1,0 +1,151 @@
+"""The MFMA prefilter + exact re-check path must return the SAME bits as the brute-force exact kernel
+(and the oracle), on friendly and on adversarial inputs: near-duplicate swarms, candidate-list overflow
+(fallback), magnitudes outside fp16 range (not prefiltered), tiny magnitudes (absolute error term),
+integer descriptors, both accumulation orders."""
+import numpy as np
+import pytest
+
+from monocularsfm_amd import _lib, synth
+
+pytestmark = pytest.mark.gpu
+F32 = np.float32
+
+
+def b(a):
+    a = np.asarray(a)
+    return a.view(np.int32) if a.dtype == np.float32 else a
+
+
+def knn_both_modes(ctx, A, B):
+    ctx.upload_image(0, A)
+    ctx.upload_image(1, B)
+    out = {}
+    for mode in (True, False):
+        ctx.set_prefilter(mode)
+        out[mode] = (ctx.knn2_pair(0, 1), ctx.profile(), ctx.match_pair(0, 1, 0.8, True, float("inf")))
+    ctx.set_prefilter(True)
+    return out
+
+
+def assert_same(out):
+    (kp, pp, mp), (ke, pe, me) = out[True], out[False]
+    for d in (0, 1):
+        for k in range(3):
+            assert np.array_equal(b(kp[d][k]), b(ke[d][k])), (d, k)
+    for x, y in zip(mp, me):
+        assert np.array_equal(b(x), b(y))
+    return pp, pe
+
+
+@pytest.mark.parametrize("order", [0, 1])
+@pytest.mark.parametrize("shape", [(5000, 4800), (1300, 700), (130, 4000), (64, 64), (2, 300)])
+def test_prefilter_equals_bruteforce_and_oracle(gpu_ctx, oracle, shape, order):
+    n1, n2 = shape
+    imgs = synth.rootsift_images(2, [n1, n2], seed=n1 + 3 * n2 + order, n_proto=max(n1, n2) * 2)
+    gpu_ctx.set_accum_order(order)
+    try:
+        out = knn_both_modes(gpu_ctx, imgs[0], imgs[1])
+        pp, pe = assert_same(out)
+        assert pp["prefilter_pairs"] == 1 and pp["fallback_pairs"] == 0 and pp["dist_kernel_launches"] == 0
+        assert pe["prefilter_pairs"] == 0 and pe["dist_kernel_launches"] == 1
+        # a handful of candidates per row/column, not thousands
+        assert pp["candidates"] <= 8 * (n1 + n2)
+        if n1 * n2 <= 3_000_000:
+            oi0, od0, _, od1 = oracle.knn2(imgs[0], imgs[1], order, 8)
+            fwd = out[True][0][0]
+            assert np.array_equal(fwd[0], oi0) and np.array_equal(b(fwd[1]), b(od0)) and np.array_equal(b(fwd[2]), b(od1))
+    finally:
+        gpu_ctx.set_accum_order(0)
+
+
+def test_near_duplicate_swarm(gpu_ctx, oracle):
+    """Many train rows within a few ulps of each other: the candidate margin must keep them all."""
+    rng = np.random.default_rng(3)
+    A = synth.rootsift_images(1, [400], seed=5)[0]
+    B = synth.rootsift_images(1, [600], seed=6)[0]
+    base = A[7].copy()
+    for k in range(40):  # 40 copies of A[7] differing in single ulps
+        v = base.copy()
+        v[rng.integers(0, 128)] = np.nextafter(v[rng.integers(0, 128)], F32(2.0))
+        B[100 + 3 * k] = v
+    B[50] = base
+    out = knn_both_modes(gpu_ctx, A, B)
+    assert_same(out)
+    oi0, od0, _, od1 = oracle.knn2(A, B, 0, 8)
+    fwd = out[True][0][0]
+    assert np.array_equal(fwd[0], oi0) and np.array_equal(b(fwd[1]), b(od0)) and np.array_equal(b(fwd[2]), b(od1))
+
+
+def test_candidate_overflow_falls_back(gpu_ctx, oracle):
+    """All train rows identical: every element is a candidate -> overflow -> brute-force path, same answer."""
+    A = synth.rootsift_images(1, [300], seed=8)[0]
+    B = np.repeat(A[:1], 2500, axis=0).copy()
+    out = knn_both_modes(gpu_ctx, A, B)
+    pp, _ = assert_same(out)
+    assert pp["fallback_pairs"] == 1 and pp["prefilter_pairs"] == 0 and pp["dist_kernel_launches"] == 1
+    oi0, od0, _, od1 = oracle.knn2(A, B, 0, 8)
+    fwd = out[True][0][0]
+    assert np.array_equal(fwd[0], oi0) and (oi0 == 0).all() and np.array_equal(b(fwd[1]), b(od0))
+
+
+def test_magnitudes_outside_fp16_are_not_prefiltered(gpu_ctx, oracle):
+    A = (synth.rootsift_images(1, [200], seed=9)[0] * F32(1e6)).astype(F32)
+    B = (synth.rootsift_images(1, [260], seed=10)[0] * F32(1e6)).astype(F32)
+    out = knn_both_modes(gpu_ctx, A, B)
+    pp, _ = assert_same(out)
+    assert pp["prefilter_pairs"] == 0 and pp["dist_kernel_launches"] == 1
+    oi0, od0, _, od1 = oracle.knn2(A, B, 0, 8)
+    fwd = out[True][0][0]
+    assert np.array_equal(fwd[0], oi0) and np.array_equal(b(fwd[1]), b(od0)) and np.array_equal(b(fwd[2]), b(od1))
+
+
+@pytest.mark.parametrize("scale", [1e-3, 1e-6, 3.0, 200.0])
+def test_scaled_magnitudes(gpu_ctx, oracle, scale):
+    """fp16 subnormal / underflow range (absolute error term) and large-but-safe magnitudes."""
+    imgs = synth.rootsift_images(2, [500, 450], seed=11, n_proto=900)
+    A = (imgs[0] * F32(scale)).astype(F32)
+    B = (imgs[1] * F32(scale)).astype(F32)
+    out = knn_both_modes(gpu_ctx, A, B)
+    assert_same(out)
+    oi0, od0, _, od1 = oracle.knn2(A, B, 0, 8)
+    fwd = out[True][0][0]
+    assert np.array_equal(fwd[0], oi0) and np.array_equal(b(fwd[1]), b(od0)) and np.array_equal(b(fwd[2]), b(od1))
+
+
+def test_integer_descriptors(gpu_ctx, oracle):
+    u = synth.u8_images(2, [1200, 1100], seed=12)
+    out = knn_both_modes(gpu_ctx, u[0].astype(np.uint8), u[1].astype(np.uint8))
+    pp, _ = assert_same(out)
+    assert pp["prefilter_pairs"] == 1
+    oi0, od0, _, od1 = oracle.knn2(u[0], u[1], 0, 8)
+    fwd = out[True][0][0]
+    assert np.array_equal(fwd[0], oi0) and np.array_equal(b(fwd[1]), b(od0)) and np.array_equal(b(fwd[2]), b(od1))
+
+
+def test_random_gaussian_descriptors_signed(gpu_ctx, oracle):
+    """Not SIFT-like at all: signed, distances concentrated (many near-equal neighbours)."""
+    rng = np.random.default_rng(13)
+    A = rng.normal(size=(700, 128)).astype(F32)
+    B = rng.normal(size=(900, 128)).astype(F32)
+    out = knn_both_modes(gpu_ctx, A, B)
+    assert_same(out)
+    oi0, od0, _, od1 = oracle.knn2(A, B, 0, 8)
+    fwd = out[True][0][0]
+    assert np.array_equal(fwd[0], oi0) and np.array_equal(b(fwd[1]), b(od0)) and np.array_equal(b(fwd[2]), b(od1))
+
+
+def test_batch_mixes_paths(gpu_ctx, oracle):
+    sizes = [700, 650, 300, 5, 900]
+    imgs = synth.rootsift_images(len(sizes), sizes, seed=14, n_proto=1500)
+    imgs[2] = (imgs[2] * F32(1e6)).astype(F32)            # unsafe for fp16 -> exact path
+    imgs.append(np.repeat(imgs[0][:1], 1800, axis=0))      # overflow -> fallback
+    for i, im in enumerate(imgs):
+        gpu_ctx.upload_image(i, im)
+    pairs = np.array([(i, j) for i in range(len(imgs)) for j in range(i)], np.int32)
+    offs, qt, d = gpu_ctx.match_pairs(pairs, 0.8, True, float("inf"))
+    prof = gpu_ctx.profile()
+    assert prof["prefilter_pairs"] > 0 and prof["fallback_pairs"] > 0 and prof["dist_kernel_launches"] >= 1
+    for p, (i, j) in enumerate(pairs):
+        oq, ot, od = oracle.match_pair(imgs[i], imgs[j], 0.8, True, np.inf, nthreads=4)
+        s, e = offs[p], offs[p + 1]
+        assert np.array_equal(qt[s:e, 0], oq) and np.array_equal(qt[s:e, 1], ot) and np.array_equal(b(d[s:e]), b(od)), (i, j)

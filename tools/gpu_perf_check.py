@@ -27,11 +27,22 @@ for order in orders:
     imgs = synth.rootsift_images(N, n, seed=11)
     for i, im in enumerate(imgs): ctx.upload_image(i, im)
     pairs = np.array([(i, j) for i in range(N) for j in range(i)], np.int32)
-    best = 0
-    for rep in range(3):
-        t0 = time.time(); offs, qt, d = ctx.match_pairs(pairs); dt = time.time() - t0
-        prof = ctx.profile()
-        best = max(best, prof["descriptor_pairs"] / prof["dist_kernel_ms"] * 1e3)
-    print("order %d: kernel %.1f ms  desc-pairs/s (kernel) %.4e  = %.1f T lane-ops/s  wall %.3f s" % (
-        order, prof["dist_kernel_ms"], best, best * (384 if order == 0 else 256) / 1e12, dt))
+    ref = None
+    for pf in (False, True):
+        ctx.set_prefilter(pf)
+        for rep in range(3):
+            t0 = time.time(); offs, qt, d = ctx.match_pairs(pairs); dt = time.time() - t0
+            prof = ctx.profile()
+        if not pf:
+            ref = (offs.copy(), qt.copy(), d.copy())
+            best = prof["descriptor_pairs"] / prof["dist_kernel_ms"] * 1e3
+            print("order %d brute : kernel %.1f ms  desc-pairs/s (kernel) %.4e  = %.1f T lane-ops/s  wall %.3f s" % (
+                order, prof["dist_kernel_ms"], best, best * (384 if order == 0 else 256) / 1e12, dt))
+        else:
+            same = eq(offs, ref[0]) and eq(qt, ref[1]) and eq(d, ref[2])
+            ok_all &= same
+            print("order %d prefilter: approx kernels %.2f ms (%.3e desc-pairs/s per 2 passes, %.0f TFLOP/s f16)  wall %.3f s  (%.3e desc-pairs/s)  cand/row %.2f  fallback %d  identical %s" % (
+                order, prof["approx_kernel_ms"], prof["prefilter_descriptor_pairs"] / max(prof["approx_kernel_ms"], 1e-9) * 1e3,
+                2 * 256 * prof["prefilter_descriptor_pairs"] / max(prof["approx_kernel_ms"], 1e-9) * 1e3 / 1e12, dt,
+                prof["descriptor_pairs"] / dt, prof["candidates"] / (2 * N * (N - 1) / 2 * n), prof["fallback_pairs"], same))
 print("ALL OK" if ok_all else "FAILURES")
