@@ -205,13 +205,13 @@ void assign_common(Batch& b) {
 }
 
 // partial-result offsets + B-range split of the pairs on `path` (1: prefilter doubles the partial
-// slots: two column halves per range, two row halves per A block)
+// slots: one column partial per wave of an A block)
 void assign_partials(Batch& b, int path, int target_items) {
     b.rp_elems = b.cp_elems = 0;
     long long total_ablocks = 0;
     for (auto& pd : b.pairs)
         if (pd.valid && pd.path == path) total_ablocks += pd.a_blocks;
-    const int mult = path == 1 ? 2 : 1;
+    const int rmult = 1, cmult = path == 1 ? 4 : 1;  // prefilter: one column partial per wave of an A block
     for (auto& pd : b.pairs) {
         if (!pd.valid || pd.path != path) continue;
         pd.ranges = 1;
@@ -221,8 +221,8 @@ void assign_partials(Batch& b, int path, int target_items) {
         }
         pd.rp_off = b.rp_elems;
         pd.cp_off = b.cp_elems;
-        b.rp_elems += (long long)pd.ranges * mult * pd.n1pad;
-        b.cp_elems += (long long)pd.a_blocks * mult * pd.n2pad;
+        b.rp_elems += (long long)pd.ranges * rmult * pd.n1pad;
+        b.cp_elems += (long long)pd.a_blocks * cmult * pd.n2pad;
     }
 }
 
@@ -678,7 +678,7 @@ int msfm_match_pairs(msfm_ctx* ctx, const int32_t* pairs, int n_pairs, const msf
             int rc = fill_pair(ctx, pairs[2 * end], pairs[2 * end + 1], pd, pp);
             if (rc != MSFM_OK) return rc;
             // partial-result scratch of the larger of the two paths (prefilter: 2x slots + candidates)
-            const long long need = pd.valid ? (2 * (long long)pd.n1pad + 2 * (long long)pd.a_blocks * pd.n2pad +
+            const long long need = pd.valid ? ((long long)pd.n1pad + 4 * (long long)pd.a_blocks * pd.n2pad +
                                                3 * (8LL * (pd.n1 + pd.n2) + 1024)) : 0;
             if (end > begin && est + need > kScratchElems) break;
             est += need;

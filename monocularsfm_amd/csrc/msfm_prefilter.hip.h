@@ -39,12 +39,12 @@ constexpr float kEpsRel = 1.5e-3f;
 constexpr float kEpsAbs = 1.0e-6f;
 constexpr float kF16Safe = 6.0e4f;
 
-constexpr int kPfThreads = 256;           // 4 waves: 2 (A row halves of 64) x 2 (B column halves of 32)
+constexpr int kPfThreads = 256;           // 4 waves, 32 A rows each
 constexpr int kPfBT = 64;                 // B rows per tile
 constexpr int kHalfRowBytes = kDim * 2;   // one fp16 descriptor = 256 B = 16 granules of 16 B
-constexpr int kPfLdsA = kBM * kHalfRowBytes;    // 32 KiB
 constexpr int kPfLdsB = kPfBT * kHalfRowBytes;  // 16 KiB per slot
-constexpr int kPfLdsBytes = kPfLdsA + 2 * kPfLdsB;  // 64 KiB -> two workgroups per CU
+constexpr int kPfCandBuf = 256;                  // per-wave LDS candidate buffer (pass 2), int2 entries
+constexpr int kPfLdsBytes = 2 * kPfLdsB + 4 * kPfCandBuf * 8;  // 40 KiB
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef float f16v __attribute__((ext_vector_type(16)));
@@ -116,23 +116,26 @@ __device__ __forceinline__ void v2_merge(float& s0, float& s1, float b0, float b
 }
 
 // ---------------------------------------------------------------------------------------------
-// approx_kernel<PASS>: one workgroup = one 128-row A block x a range of 64-row B tiles.
-//   wave (wr, wc): A rows wr*64..+63 (two 32-row MFMA blocks), B rows wc*32..+31 of the tile.
+// approx_kernel<PASS>: one workgroup (4 waves) = one 128-row A block x a range of 64-row B tiles.
+//   Wave w owns A rows w*32..w*32+31 for the whole item: its 8 fp16 A fragments live in registers
+//   (loaded once, straight from HBM), only B tiles stream through LDS (2 x 16 KiB, LDS-DMA).
+//   Per tile the wave computes 32 x 64 dots: two 32x32x16 MFMA column blocks x 8 k-steps.
 //   MFMA 32x32x16 f16: lane l feeds A[row l&31][k (l>>5)*8..+7] and B[col l&31][same k]; it
 //   receives for column l&31 the 16 rows (r&3) + 8 (r>>2) + 4 (l>>5), r = 0..15.
 //   u = nb_t - 2 dot (row direction, na_q added later), v = na_q - 2 dot (column direction).
-// PASS 1: two smallest u per row (lane-private over its columns, merged at the end) and two
-//         smallest v per column (merged over the lane pair, written per (A block, row half)).
-// PASS 2: append (q, t) where u <= tu[q] or v <= tv[t].
+// PASS 1: two smallest u per row (lane-private over its columns, merged over the 32 lanes at the
+//         end) and two smallest v per column (lane pair merged, written per (A block, wave)).
+// PASS 2: append (q, t) where u <= tu[q] or v <= tv[t], tested in dot space.
 // ---------------------------------------------------------------------------------------------
 template <int PASS>
 __global__ __launch_bounds__(kPfThreads, 2) void approx_kernel(
     const PairDesc* __restrict__ pairs, const PfPair* __restrict__ pf, const WorkItem* __restrict__ items,
     float* __restrict__ rp_s0, float* __restrict__ rp_s1, float* __restrict__ cp_s0, float* __restrict__ cp_s1,
     const float* __restrict__ tu, const float* __restrict__ tv, int2* __restrict__ cand, int* __restrict__ cand_count) {
+    typedef const __attribute__((address_space(1))) float* gfloat_p;  // keep these loads off the FLAT path
+    typedef const __attribute__((address_space(1))) h8* gh8_p;
     extern __shared__ __attribute__((aligned(16))) char pf_smem[];
-    char* sA = pf_smem;
-    char* sB = pf_smem + kPfLdsA;
+    char* sB = pf_smem;
 
     const WorkItem item = items[blockIdx.x];
     if (item.pair < 0) return;
@@ -142,112 +145,169 @@ __global__ __launch_bounds__(kPfThreads, 2) void approx_kernel(
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 1, wc = wave & 1;
     const int lcol = lane & 31, lhalf = lane >> 5;
 
     const int t_begin = item.bt_begin * 2, t_end = item.bt_end * 2;  // 64-row tiles
-    const char* gA = reinterpret_cast<const char*>(pp.a_h) + (size_t)item.a_blk * kPfLdsA;
     const char* gB = reinterpret_cast<const char*>(pp.b_h);
+    const gfloat_p g_bnrm = (gfloat_p)pp.b_nrm;
+    const gfloat_p g_anrm = (gfloat_p)pp.a_nrm;
+    const gfloat_p g_tu = (gfloat_p)tu;
+    const gfloat_p g_tv = (gfloat_p)tv;
 
-    glds_copy_bytes(gA, sA, kPfLdsA, tid, kPfThreads);
     glds_copy_bytes(gB + (size_t)t_begin * kPfLdsB, sB, kPfLdsB, tid, kPfThreads);
 
-    // this lane's 32 A rows: block i (0,1), reg r: row = wr*64 + i*32 + (r&3) + 8*(r>>2) + 4*lhalf
-    const int arow_base = item.a_blk * kBM + wr * 64 + 4 * lhalf;
-    float na[2][16];
-    float rs0[2][16], rs1[2][16];  // PASS 1: two smallest u per row; PASS 2: rs0 = tu threshold
+    // A fragments: row (a_blk*128 + wave*32 + lcol), granule 2*ks + lhalf (stored at granule ^ (row & 15))
+    const int a_frag_row = item.a_blk * kBM + wave * 32 + lcol;
+    h8 af[8];
+    {
+        const gh8_p ga = (gh8_p)(pp.a_h) + (size_t)a_frag_row * 16;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+        for (int ks = 0; ks < 8; ++ks) af[ks] = ga[(2 * ks + lhalf) ^ (a_frag_row & 15)];
+    }
+
+    // this lane's 16 result rows: reg r -> row = a_blk*128 + wave*32 + (r&3) + 8*(r>>2) + 4*lhalf
+    const int arow_base = item.a_blk * kBM + wave * 32 + 4 * lhalf;
+    // PASS 1: na = |a|^2, rs0/rs1 = two smallest u per row.
+    // PASS 2: na = 0.5 |a|^2, rs0 = 0.5 * row threshold (u-space); a hit is dot >= min(hb - rs0, na - hv).
+    float na[16], rs0[16], rs1[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = arow_base + i * 32 + (r & 3) + 8 * (r >> 2);
-            na[i][r] = pp.a_nrm[row];
-            if (PASS == 1) { rs0[i][r] = f_inf(); rs1[i][r] = f_inf(); }
-            else { rs0[i][r] = tu[pp.tu_off + row]; rs1[i][r] = 0.f; }
-        }
+    for (int r = 0; r < 16; ++r) {
+        const int row = arow_base + (r & 3) + 8 * (r >> 2);
+        if (PASS == 1) { na[r] = g_anrm[row]; rs0[r] = f_inf(); rs1[r] = f_inf(); }
+        else { na[r] = 0.5f * g_anrm[row]; rs0[r] = 0.5f * g_tu[pp.tu_off + row]; rs1[r] = 0.f; }
+    }
 
-    // LDS byte offsets of this lane's operand rows (granule XOR applied per k-step)
-    const int a_row0 = wr * 64 + lcol, a_row1 = a_row0 + 32;
-    const int b_row = wc * 32 + lcol;
+    // pass 2: wave-private candidate buffer in LDS
+    int2* cbuf = reinterpret_cast<int2*>(pf_smem + 2 * kPfLdsB) + wave * kPfCandBuf;
+    const unsigned cbuf_lds = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)cbuf;
+    int n_buf = 0;  // wave-uniform
+    auto flush_candidates = [&]() {
+        if (n_buf == 0) return;
+        int base = 0;
+        if (lane == 0) base = atomicAdd(&cand_count[item.pair], n_buf);
+        base = __builtin_amdgcn_readfirstlane(base);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the asm ds_writes below are not tracked by hipcc
+        for (int k = lane; k < n_buf; k += 64)
+            if (base + k < pp.cand_cap) cand[pp.cand_off + base + k] = cbuf[k];
+        n_buf = 0;
+    };
 
+    // per-column scalars of the tile (|b|^2, pass-2 threshold) are fetched one tile ahead
+    float nb_next[2], tv_next[2];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+        nb_next[cb] = g_bnrm[t_begin * kPfBT + cb * 32 + lcol];
+        tv_next[cb] = (PASS == 2) ? g_tv[pp.tv_off + t_begin * kPfBT + cb * 32 + lcol] : 0.f;
+    }
+    const int xb = lcol & 15;  // both column blocks: row & 15 == lcol & 15
     int slot = 0;
 #pragma unroll 1
     for (int t = t_begin; t < t_end; ++t, slot ^= 1) {
         __syncthreads();  // tile t landed (vmcnt(0) with the barrier), other slot free
         if (t + 1 < t_end) glds_copy_bytes(gB + (size_t)(t + 1) * kPfLdsB, sB + (slot ^ 1) * kPfLdsB, kPfLdsB, tid, kPfThreads);
-        const char* sb = sB + slot * kPfLdsB;
-        f16v acc0, acc1;
+        const float nb[2] = {nb_next[0], nb_next[1]}, tvc[2] = {tv_next[0], tv_next[1]};
+        if (t + 1 < t_end) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+            for (int cb = 0; cb < 2; ++cb) {
+                nb_next[cb] = g_bnrm[(t + 1) * kPfBT + cb * 32 + lcol];
+                if (PASS == 2) tv_next[cb] = g_tv[pp.tv_off + (t + 1) * kPfBT + cb * 32 + lcol];
+            }
+        }
+        const char* pb = sB + slot * kPfLdsB + lcol * kHalfRowBytes;
+        // all 16 B fragments of the tile up front, then 16 MFMAs back to back
+        h8 bf[2][8];
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+                bf[cb][ks] = *reinterpret_cast<const h8*>(pb + cb * 32 * kHalfRowBytes + (((2 * ks + lhalf) ^ xb) << 4));
+        f16v acc[2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
-            const int g = 2 * ks + lhalf;
-            const h8 a0 = *reinterpret_cast<const h8*>(sA + a_row0 * kHalfRowBytes + ((g ^ (a_row0 & 15)) << 4));
-            const h8 a1 = *reinterpret_cast<const h8*>(sA + a_row1 * kHalfRowBytes + ((g ^ (a_row1 & 15)) << 4));
-            const h8 bq = *reinterpret_cast<const h8*>(sb + b_row * kHalfRowBytes + ((g ^ (b_row & 15)) << 4));
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, bq, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, bq, acc1, 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks], bf[0][ks], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks], bf[1][ks], acc[1], 0, 0, 0);
         }
-        const int col = t * kPfBT + wc * 32 + lcol;  // this lane's B row (train index)
-        const float nb = pp.b_nrm[col];
+        const int col0 = t * kPfBT + lcol;  // this lane's B rows (train indices): col0 and col0 + 32
         if (PASS == 1) {
-            float c0 = f_inf(), c1 = f_inf();
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int cb = 0; cb < 2; ++cb) {
+                // two independent column chains (even / odd r) keep the VALU fed
+                float c0[2] = {f_inf(), f_inf()}, c1[2] = {f_inf(), f_inf()};
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float d = (i == 0) ? acc0[r] : acc1[r];
-                    const float u = fmaf(d, -2.f, nb);
-                    rs1[i][r] = __builtin_amdgcn_fmed3f(rs0[i][r], rs1[i][r], u);
-                    rs0[i][r] = fminf(rs0[i][r], u);
-                    const float v = fmaf(d, -2.f, na[i][r]);
-                    c1 = __builtin_amdgcn_fmed3f(c0, c1, v);
-                    c0 = fminf(c0, v);
-                }
-            v2_merge(c0, c1, __shfl_xor(c0, 32), __shfl_xor(c1, 32));
-            if (lhalf == 0) {
-                const long long o = pd.cp_off + (long long)(item.a_blk * 2 + wr) * pd.n2pad + col;
-                cp_s0[o] = c0;
-                cp_s1[o] = c1;
-            }
-        } else {
-            const float tvc = tv[pp.tv_off + col];
+                for (int rb = 0; rb < 4; ++rb) {
+                    float u[4], v[4];
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+                    for (int j = 0; j < 4; ++j) {
+                        const float d = acc[cb][4 * rb + j];
+                        u[j] = fmaf(d, -2.f, nb[cb]);
+                        v[j] = fmaf(d, -2.f, na[4 * rb + j]);
+                    }
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float d = (i == 0) ? acc0[r] : acc1[r];
-                    const float u = fmaf(d, -2.f, nb);
-                    const float v = fmaf(d, -2.f, na[i][r]);
-                    if (u <= rs0[i][r] || v <= tvc) {
-                        const int k = atomicAdd(&cand_count[item.pair], 1);
-                        if (k < pp.cand_cap)
-                            cand[pp.cand_off + k] = make_int2(arow_base + i * 32 + (r & 3) + 8 * (r >> 2), col);
+                    for (int j = 0; j < 4; ++j) {
+                        rs1[4 * rb + j] = __builtin_amdgcn_fmed3f(rs0[4 * rb + j], rs1[4 * rb + j], u[j]);
+                        rs0[4 * rb + j] = fminf(rs0[4 * rb + j], u[j]);
+                        c1[j & 1] = __builtin_amdgcn_fmed3f(c0[j & 1], c1[j & 1], v[j]);
+                        c0[j & 1] = fminf(c0[j & 1], v[j]);
                     }
                 }
-        }
-    }
-
-    if (PASS == 1) {
-        // rows: merge the 32 column lanes, then the two column halves (waves wc = 0, 1) via partial slots
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-#pragma unroll
-                for (int m = 1; m < 32; m <<= 1) v2_merge(rs0[i][r], rs1[i][r], __shfl_xor(rs0[i][r], m), __shfl_xor(rs1[i][r], m));
+                v2_merge(c0[0], c1[0], c0[1], c1[1]);
+                v2_merge(c0[0], c1[0], __shfl_xor(c0[0], 32), __shfl_xor(c1[0], 32));
+                if (lhalf == 0) {
+                    const long long o = pd.cp_off + (long long)(item.a_blk * 4 + wave) * pd.n2pad + col0 + cb * 32;
+                    cp_s0[o] = c0[0];
+                    cp_s1[o] = c1[0];
+                }
             }
-        if (lcol == 0) {
-            // row partial slot: (range * 2 + wc)
-            const long long o = pd.rp_off + (long long)(item.range * 2 + wc) * pd.n1pad + arow_base;
+        } else {
+            // branch-free hit mask: element k = cb*16 + r ends up at bit 31 - k
+            unsigned mask = 0;
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int cb = 0; cb < 2; ++cb) {
+                const float hb = 0.5f * nb[cb], hv = 0.5f * tvc[cb];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int off = i * 32 + (r & 3) + 8 * (r >> 2);
-                    rp_s0[o + off] = rs0[i][r];
-                    rp_s1[o + off] = rs1[i][r];
+                    const float th = fminf(hb - rs0[r], na[r] - hv);
+                    mask = mask + mask + ((acc[cb][r] >= th) ? 1u : 0u);
                 }
+            }
+            // Candidates are rare (a few per row): slot them with ballot/popcount into this wave's LDS
+            // buffer -- no atomics in the loop -- and flush to the pair's global list when it fills up.
+            while (__ballot(mask != 0u) != 0ull) {
+                const bool hit = mask != 0u;
+                const int k = __clz((int)mask);  // first remaining element of this lane (32 if none)
+                const unsigned long long m = __ballot(hit);
+                if (n_buf + 64 > kPfCandBuf) flush_candidates();
+                if (hit) {
+                    mask &= ~(0x80000000u >> k);
+                    const int sl = n_buf + __popcll(m & ((1ull << lane) - 1ull));
+                    // inline asm on purpose: for a compiler-visible LDS store hipcc first drains vmcnt(0),
+                    // i.e. waits for the next tile's LDS-DMA (which cannot alias cbuf)
+                    const int2 e = make_int2(arow_base + (k & 3) + 8 * ((k & 15) >> 2), col0 + (k >> 4) * 32);
+                    asm volatile("ds_write_b64 %0, %1" ::"v"(cbuf_lds + sl * 8), "v"(e) : "memory");
+                }
+                n_buf += __popcll(m);
+            }
+        }
+    }
+    if (PASS == 2) flush_candidates();
+
+    if (PASS == 1) {
+        // rows: merge the 32 column lanes; one partial slot per B range
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+#pragma unroll
+            for (int m = 1; m < 32; m <<= 1) v2_merge(rs0[r], rs1[r], __shfl_xor(rs0[r], m), __shfl_xor(rs1[r], m));
+        }
+        if (lcol == 0) {
+            const long long o = pd.rp_off + (long long)item.range * pd.n1pad + arow_base;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int off = (r & 3) + 8 * (r >> 2);
+                rp_s0[o + off] = rs0[r];
+                rp_s1[o + off] = rs1[r];
+            }
         }
     }
 }
@@ -264,25 +324,25 @@ __global__ void pf_thresholds_kernel(const PairDesc* __restrict__ pairs, const P
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e < pd.n1pad) {
         float s0 = f_inf(), s1 = f_inf();
-        for (int p = 0; p < pd.ranges * 2; ++p) {
+        for (int p = 0; p < pd.ranges; ++p) {
             const long long o = pd.rp_off + (long long)p * pd.n1pad + e;
             v2_merge(s0, s1, rp_s0[o], rp_s1[o]);
         }
         // S~(2) = s1 + na; eps_row = rel*(na + nb_max) + abs*(sqrt(na)+sqrt(nb_max)); threshold in u-space
         const float na = pp.a_nrm[e];
         const float eps = kEpsRel * (na + pp.b_nrm_max) + kEpsAbs * (sqrtf(na) + sqrtf(pp.b_nrm_max));
-        const float slack = 2.f * eps + 1e-6f * (fabsf(s1) + na);  // + the roundings of this very formula
+        const float slack = 2.f * eps + 1e-5f * (fabsf(s1) + na + pp.b_nrm_max);  // + roundings here and in pass 2's dot-space test
         tu[pp.tu_off + e] = (e < pd.n1) ? s1 + slack : -f_inf();
     }
     if (e < pd.n2pad) {
         float s0 = f_inf(), s1 = f_inf();
-        for (int p = 0; p < pd.a_blocks * 2; ++p) {
+        for (int p = 0; p < pd.a_blocks * 4; ++p) {
             const long long o = pd.cp_off + (long long)p * pd.n2pad + e;
             v2_merge(s0, s1, cp_s0[o], cp_s1[o]);
         }
         const float nb = pp.b_nrm[e];
         const float eps = kEpsRel * (nb + pp.a_nrm_max) + kEpsAbs * (sqrtf(nb) + sqrtf(pp.a_nrm_max));
-        const float slack = 2.f * eps + 1e-6f * (fabsf(s1) + nb);
+        const float slack = 2.f * eps + 1e-5f * (fabsf(s1) + nb + pp.a_nrm_max);
         tv[pp.tv_off + e] = (e < pd.n2) ? s1 + slack : -f_inf();
     }
 }
