@@ -76,7 +76,7 @@ struct PairDesc {
     int ranges;            // B-tile ranges the pair was split into
     int valid;             // 0: a side is empty -> no neighbours, no device work
     int path;              // 0: brute-force exact kernel, 1: MFMA prefilter + exact re-check
-    int pad0;
+    int a_blocks256;       // 256-row A blocks (prefilter work items)
     long long rp_off;      // row partials  [ranges][n1pad]
     long long cp_off;      // column partials [a_blocks][n2pad]
     long long kf_off;      // final forward knn arrays [n1pad]

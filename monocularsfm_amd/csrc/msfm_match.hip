@@ -44,7 +44,8 @@ struct DevBuf {
 
 struct Image {
     int n = -1;  // -1: not uploaded
-    int nblk = 0;
+    int nblk = 0;    // 128-row blocks holding data
+    int nalloc = 0;  // allocated blocks (even: the prefilter walks 256-row A blocks); padding is zero-filled
     float* panel = nullptr;
     float* raw = nullptr;
     // prefilter operands: fp16 swizzled blocks, row norms (+inf padded), maxima
@@ -132,7 +133,8 @@ void build_items(Batch& b, int path) {
         for (int r = 0; r < pd.ranges; ++r) {
             const int t0 = (int)((long long)pd.b_tiles * r / pd.ranges);
             const int t1 = (int)((long long)pd.b_tiles * (r + 1) / pd.ranges);
-            for (int ab = 0; ab < pd.a_blocks; ++ab) {
+            const int nab = path == 1 ? pd.a_blocks256 : pd.a_blocks;
+            for (int ab = 0; ab < nab; ++ab) {
                 WorkItem w = {};
                 w.pair = (int)p;
                 w.a_blk = ab;
@@ -167,8 +169,9 @@ int fill_pair(msfm_ctx* ctx, int id1, int id2, PairDesc& pd, PfPair& pp) {
     pd.n2 = b.n;
     pd.a_blocks = a.nblk;
     pd.b_tiles = b.nblk;
-    pd.n1pad = a.nblk * kBM;
-    pd.n2pad = b.nblk * kBN;
+    pd.n1pad = a.nalloc * kBM;
+    pd.n2pad = b.nalloc * kBN;
+    pd.a_blocks256 = a.nalloc / 2;
     pd.ranges = 1;
     // empty query or train set: knnMatch returns nothing, no device work
     pd.valid = (a.n >= 1 && b.n >= 1) ? 1 : 0;
@@ -210,8 +213,8 @@ void assign_partials(Batch& b, int path, int target_items) {
     b.rp_elems = b.cp_elems = 0;
     long long total_ablocks = 0;
     for (auto& pd : b.pairs)
-        if (pd.valid && pd.path == path) total_ablocks += pd.a_blocks;
-    const int rmult = 1, cmult = path == 1 ? 4 : 1;  // prefilter: one column partial per wave of an A block
+        if (pd.valid && pd.path == path) total_ablocks += (path == 1 ? pd.a_blocks256 : pd.a_blocks);
+    const int rmult = 1;
     for (auto& pd : b.pairs) {
         if (!pd.valid || pd.path != path) continue;
         pd.ranges = 1;
@@ -222,7 +225,8 @@ void assign_partials(Batch& b, int path, int target_items) {
         pd.rp_off = b.rp_elems;
         pd.cp_off = b.cp_elems;
         b.rp_elems += (long long)pd.ranges * rmult * pd.n1pad;
-        b.cp_elems += (long long)pd.a_blocks * cmult * pd.n2pad;
+        // prefilter: one column partial per wave of a 256-row A block
+        b.cp_elems += (long long)(path == 1 ? pd.a_blocks256 * 4 : pd.a_blocks) * pd.n2pad;
     }
 }
 
@@ -556,11 +560,11 @@ int msfm_set_accum_order(msfm_ctx* ctx, int order) {
     ctx->order = order;
     for (auto& im : ctx->images) {
         if (im.n <= 0) continue;
-        const int blocks = std::min(4096, im.nblk * 16);
+        const int blocks = std::min(4096, im.nalloc * 16);
         if (order == MSFM_ORDER_SSE4X4)
-            hipLaunchKernelGGL((layout_kernel<0, float>), dim3(blocks), dim3(256), 0, ctx->stream, im.raw, (float*)nullptr, im.panel, im.n, im.nblk);
+            hipLaunchKernelGGL((layout_kernel<0, float>), dim3(blocks), dim3(256), 0, ctx->stream, im.raw, (float*)nullptr, im.panel, im.n, im.nalloc);
         else
-            hipLaunchKernelGGL((layout_kernel<1, float>), dim3(blocks), dim3(256), 0, ctx->stream, im.raw, (float*)nullptr, im.panel, im.n, im.nblk);
+            hipLaunchKernelGGL((layout_kernel<1, float>), dim3(blocks), dim3(256), 0, ctx->stream, im.raw, (float*)nullptr, im.panel, im.n, im.nalloc);
         HIPCHK(ctx, hipGetLastError());
     }
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -591,27 +595,28 @@ int msfm_upload_image(msfm_ctx* ctx, int image_id, const void* desc, int n, int 
     free_image(im);
     im.n = n;
     im.nblk = (n + kBM - 1) / kBM;
+    im.nalloc = (im.nblk + 1) & ~1;
     if (n == 0) return MSFM_OK;
-    HIPCHK(ctx, hipMalloc((void**)&im.panel, (size_t)im.nblk * kPanelFloats * 4));
+    HIPCHK(ctx, hipMalloc((void**)&im.panel, (size_t)im.nalloc * kPanelFloats * 4));
     HIPCHK(ctx, hipMalloc((void**)&im.raw, (size_t)n * kDim * 4));
-    const int blocks = std::min(4096, im.nblk * 16);
+    const int blocks = std::min(4096, im.nalloc * 16);
     if (dtype == MSFM_DTYPE_F32) {
         HIPCHK(ctx, hipMemcpyAsync(im.raw, desc, (size_t)n * kDim * 4, hipMemcpyHostToDevice, ctx->stream));
         if (ctx->order == MSFM_ORDER_SSE4X4)
-            hipLaunchKernelGGL((layout_kernel<0, float>), dim3(blocks), dim3(256), 0, ctx->stream, im.raw, (float*)nullptr, im.panel, n, im.nblk);
+            hipLaunchKernelGGL((layout_kernel<0, float>), dim3(blocks), dim3(256), 0, ctx->stream, im.raw, (float*)nullptr, im.panel, n, im.nalloc);
         else
-            hipLaunchKernelGGL((layout_kernel<1, float>), dim3(blocks), dim3(256), 0, ctx->stream, im.raw, (float*)nullptr, im.panel, n, im.nblk);
+            hipLaunchKernelGGL((layout_kernel<1, float>), dim3(blocks), dim3(256), 0, ctx->stream, im.raw, (float*)nullptr, im.panel, n, im.nalloc);
     } else {
         HIPCHK(ctx, ctx->d_stage.ensure((size_t)n * kDim));
         HIPCHK(ctx, hipMemcpyAsync(ctx->d_stage.p, desc, (size_t)n * kDim, hipMemcpyHostToDevice, ctx->stream));
         if (ctx->order == MSFM_ORDER_SSE4X4)
-            hipLaunchKernelGGL((layout_kernel<0, unsigned char>), dim3(blocks), dim3(256), 0, ctx->stream, ctx->d_stage.as<unsigned char>(), im.raw, im.panel, n, im.nblk);
+            hipLaunchKernelGGL((layout_kernel<0, unsigned char>), dim3(blocks), dim3(256), 0, ctx->stream, ctx->d_stage.as<unsigned char>(), im.raw, im.panel, n, im.nalloc);
         else
-            hipLaunchKernelGGL((layout_kernel<1, unsigned char>), dim3(blocks), dim3(256), 0, ctx->stream, ctx->d_stage.as<unsigned char>(), im.raw, im.panel, n, im.nblk);
+            hipLaunchKernelGGL((layout_kernel<1, unsigned char>), dim3(blocks), dim3(256), 0, ctx->stream, ctx->d_stage.as<unsigned char>(), im.raw, im.panel, n, im.nalloc);
     }
     HIPCHK(ctx, hipGetLastError());
     // prefilter operands (order-independent): fp16 swizzled blocks, norms, maxima
-    const int npad = im.nblk * kBM;
+    const int npad = im.nalloc * kBM;
     HIPCHK(ctx, hipMalloc((void**)&im.h16, (size_t)npad * kDim * 2));
     HIPCHK(ctx, hipMalloc((void**)&im.nrm, (size_t)npad * 4));
     HIPCHK(ctx, ctx->d_maxima.ensure(8));
@@ -678,7 +683,7 @@ int msfm_match_pairs(msfm_ctx* ctx, const int32_t* pairs, int n_pairs, const msf
             int rc = fill_pair(ctx, pairs[2 * end], pairs[2 * end + 1], pd, pp);
             if (rc != MSFM_OK) return rc;
             // partial-result scratch of the larger of the two paths (prefilter: 2x slots + candidates)
-            const long long need = pd.valid ? ((long long)pd.n1pad + 4 * (long long)pd.a_blocks * pd.n2pad +
+            const long long need = pd.valid ? ((long long)pd.n1pad + 2 * (long long)pd.a_blocks * pd.n2pad +
                                                3 * (8LL * (pd.n1 + pd.n2) + 1024)) : 0;
             if (end > begin && est + need > kScratchElems) break;
             est += need;

@@ -39,12 +39,12 @@ constexpr float kEpsRel = 1.5e-3f;
 constexpr float kEpsAbs = 1.0e-6f;
 constexpr float kF16Safe = 6.0e4f;
 
-constexpr int kPfThreads = 256;           // 4 waves, 32 A rows each
+constexpr int kPfThreads = 256;           // 4 waves, 64 A rows each
 constexpr int kPfBT = 64;                 // B rows per tile
 constexpr int kHalfRowBytes = kDim * 2;   // one fp16 descriptor = 256 B = 16 granules of 16 B
 constexpr int kPfLdsB = kPfBT * kHalfRowBytes;  // 16 KiB per slot
 constexpr int kPfCandBuf = 256;                  // per-wave LDS candidate buffer (pass 2), int2 entries
-constexpr int kPfLdsBytes = 2 * kPfLdsB + 4 * kPfCandBuf * 8;  // 40 KiB
+constexpr int kPfLdsBytes = 3 * kPfLdsB + 4 * 3 * 2 * 64 * 4 + 4 * 64 * 4 + 4 * kPfCandBuf * 8;  // 48 + 6 + 1 + 8 = 63 KiB
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef float f16v __attribute__((ext_vector_type(16)));
@@ -116,17 +116,31 @@ __device__ __forceinline__ void v2_merge(float& s0, float& s1, float b0, float b
 }
 
 // ---------------------------------------------------------------------------------------------
-// approx_kernel<PASS>: one workgroup (4 waves) = one 128-row A block x a range of 64-row B tiles.
-//   Wave w owns A rows w*32..w*32+31 for the whole item: its 8 fp16 A fragments live in registers
-//   (loaded once, straight from HBM), only B tiles stream through LDS (2 x 16 KiB, LDS-DMA).
-//   Per tile the wave computes 32 x 64 dots: two 32x32x16 MFMA column blocks x 8 k-steps.
-//   MFMA 32x32x16 f16: lane l feeds A[row l&31][k (l>>5)*8..+7] and B[col l&31][same k]; it
-//   receives for column l&31 the 16 rows (r&3) + 8 (r>>2) + 4 (l>>5), r = 0..15.
+// approx_kernel<PASS>: one workgroup (4 waves) = one 256-row A block x a range of 64-row B tiles.
+//   Wave w owns A rows w*64..w*64+63 for the whole item: its 16 fp16 A fragments (two 32-row MFMA
+//   blocks x 8 k-steps) live in registers, loaded once straight from HBM.  Only B tiles stream
+//   through LDS: a ring of three 16 KiB slots filled by LDS-DMA two tiles ahead, synchronised with
+//   raw s_barrier + COUNTED s_waitcnt vmcnt(N) so the two younger tiles stay in flight across the
+//   barrier.  The tile's |b|^2 (and pass-2 thresholds) ride along as 256-byte dword DMAs, so the
+//   loop contains no ordinary global load that would make hipcc drain vmcnt(0).
+//   Per tile and column block: 2 x 8 MFMA 32x32x16 f16, then the epilogue on the 2 x 16 results.
+//   MFMA layout: lane l feeds A[row l&31][k (l>>5)*8..+7] and B[col l&31][same k]; it receives for
+//   column l&31 the 16 rows (r&3) + 8 (r>>2) + 4 (l>>5), r = 0..15.
 //   u = nb_t - 2 dot (row direction, na_q added later), v = na_q - 2 dot (column direction).
 // PASS 1: two smallest u per row (lane-private over its columns, merged over the 32 lanes at the
 //         end) and two smallest v per column (lane pair merged, written per (A block, wave)).
 // PASS 2: append (q, t) where u <= tu[q] or v <= tv[t], tested in dot space.
+// VMEM ops per wave per tile (the counted waits depend on it): PASS 1: 5 DMA + 4 stores,
+// PASS 2: 6 DMA (+ rare flushes, which only add ops and are therefore safe).
 // ---------------------------------------------------------------------------------------------
+constexpr int kPfRing = 3;
+constexpr int kPfAuxFloats = 64;  // per slot: |b|^2 of the tile's 64 rows (and 64 thresholds in pass 2)
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
 template <int PASS>
 __global__ __launch_bounds__(kPfThreads, 2) void approx_kernel(
     const PairDesc* __restrict__ pairs, const PfPair* __restrict__ pf, const WorkItem* __restrict__ items,
@@ -135,7 +149,9 @@ __global__ __launch_bounds__(kPfThreads, 2) void approx_kernel(
     typedef const __attribute__((address_space(1))) float* gfloat_p;  // keep these loads off the FLAT path
     typedef const __attribute__((address_space(1))) h8* gh8_p;
     extern __shared__ __attribute__((aligned(16))) char pf_smem[];
+    // LDS: ring of B tiles | per-wave aux rings (|b|^2, thresholds) | per-wave candidate buffers
     char* sB = pf_smem;
+    float* sAux = reinterpret_cast<float*>(pf_smem + kPfRing * kPfLdsB);
 
     const WorkItem item = items[blockIdx.x];
     if (item.pair < 0) return;
@@ -149,36 +165,74 @@ __global__ __launch_bounds__(kPfThreads, 2) void approx_kernel(
 
     const int t_begin = item.bt_begin * 2, t_end = item.bt_end * 2;  // 64-row tiles
     const char* gB = reinterpret_cast<const char*>(pp.b_h);
-    const gfloat_p g_bnrm = (gfloat_p)pp.b_nrm;
     const gfloat_p g_anrm = (gfloat_p)pp.a_nrm;
     const gfloat_p g_tu = (gfloat_p)tu;
-    const gfloat_p g_tv = (gfloat_p)tv;
+    float* aux_w = sAux + wave * (kPfRing * 2 * kPfAuxFloats);  // this wave's private copies
 
-    glds_copy_bytes(gB + (size_t)t_begin * kPfLdsB, sB, kPfLdsB, tid, kPfThreads);
-
-    // A fragments: row (a_blk*128 + wave*32 + lcol), granule 2*ks + lhalf (stored at granule ^ (row & 15))
-    const int a_frag_row = item.a_blk * kBM + wave * 32 + lcol;
-    h8 af[8];
-    {
-        const gh8_p ga = (gh8_p)(pp.a_h) + (size_t)a_frag_row * 16;
+    // DMA group of tile tt (clamped: the tail re-fetches the last tile so every iteration issues the
+    // same number of VMEM ops): this wave's quarter of the 16 KiB tile + its private |b|^2 / threshold rows
+    auto dma_tile = [&](int tt) {
+        const int tc = tt < t_end ? tt : t_end - 1;
+        const int sl = (tt - t_begin) % kPfRing;
+        const char* g = gB + (size_t)tc * kPfLdsB + wave * 4096 + lane * 16;
+        char* l = sB + sl * kPfLdsB + wave * 4096;
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) af[ks] = ga[(2 * ks + lhalf) ^ (a_frag_row & 15)];
+        for (int k = 0; k < 4; ++k)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + k * 1024),
+                                             (__attribute__((address_space(3))) void*)(l + k * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pp.b_nrm + tc * kPfBT + lane),
+                                         (__attribute__((address_space(3))) void*)(aux_w + sl * 2 * kPfAuxFloats), 4, 0, 0);
+        if (PASS == 2)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(tv + pp.tv_off + tc * kPfBT + lane),
+                                             (__attribute__((address_space(3))) void*)(aux_w + sl * 2 * kPfAuxFloats + kPfAuxFloats), 4, 0, 0);
+    };
+    constexpr int kDmaOps = (PASS == 1) ? 5 : 6;
+    constexpr int kStoreOps = (PASS == 1) ? 4 : 0;  // 2 column blocks x (cp_s0, cp_s1); see the stores below
+
+    dma_tile(t_begin);
+    dma_tile(t_begin + 1);
+
+    // A fragments: rows a_blk*256 + wave*64 + rb*32 + lcol, granule 2*ks + lhalf (stored at ^ (row & 15))
+    h8 af[2][8];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+        const int frow = item.a_blk * 256 + wave * 64 + rb * 32 + lcol;
+        const gh8_p ga = (gh8_p)(pp.a_h) + (size_t)frow * 16;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) af[rb][ks] = ga[(2 * ks + lhalf) ^ (frow & 15)];
     }
 
-    // this lane's 16 result rows: reg r -> row = a_blk*128 + wave*32 + (r&3) + 8*(r>>2) + 4*lhalf
-    const int arow_base = item.a_blk * kBM + wave * 32 + 4 * lhalf;
+    // this lane's 32 result rows: (rb, r) -> row = a_blk*256 + wave*64 + rb*32 + (r&3) + 8*(r>>2) + 4*lhalf
+    const int arow_base = item.a_blk * 256 + wave * 64 + 4 * lhalf;
     // PASS 1: na = |a|^2, rs0/rs1 = two smallest u per row.
     // PASS 2: na = 0.5 |a|^2, rs0 = 0.5 * row threshold (u-space); a hit is dot >= min(hb - rs0, na - hv).
-    float na[16], rs0[16], rs1[16];
+    // In pass 1 the row norms sit in LDS (wave-private, 64 floats) to keep the VGPR budget spill-free:
+    // a spill reload is a scratch (VMEM) load and would drain the DMA ring at every use.
+    float* na_w = sAux + 4 * kPfRing * 2 * kPfAuxFloats + wave * 64;
+    float na[2][16], rs0[2][16], rs1[2][16];
+    if (PASS == 1) {
+        const int row = item.a_blk * 256 + wave * 64 + lane;
+        na_w[lane] = row < pd.n1 ? g_anrm[row] : f_inf();  // padding rows: +inf norm, never selected
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int row = arow_base + (r & 3) + 8 * (r >> 2);
-        if (PASS == 1) { na[r] = g_anrm[row]; rs0[r] = f_inf(); rs1[r] = f_inf(); }
-        else { na[r] = 0.5f * g_anrm[row]; rs0[r] = 0.5f * g_tu[pp.tu_off + row]; rs1[r] = 0.f; }
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { rs0[rb][r] = f_inf(); rs1[rb][r] = f_inf(); na[rb][r] = 0.f; }
+    } else {
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = arow_base + rb * 32 + (r & 3) + 8 * (r >> 2);
+                const bool live = row < pd.n1;  // padding rows: +inf norm / -inf threshold, never selected
+                na[rb][r] = live ? 0.5f * g_anrm[row] : f_inf();
+                rs0[rb][r] = live ? 0.5f * g_tu[pp.tu_off + row] : -f_inf();
+                rs1[rb][r] = 0.f;
+            }
     }
+    wait_vmcnt<0>();  // prologue loads (and the first two DMA groups) are done: counted waits start clean
 
     // pass 2: wave-private candidate buffer in LDS
-    int2* cbuf = reinterpret_cast<int2*>(pf_smem + 2 * kPfLdsB) + wave * kPfCandBuf;
+    int2* cbuf = reinterpret_cast<int2*>(sAux + 4 * kPfRing * 2 * kPfAuxFloats + 4 * 64) + wave * kPfCandBuf;
     const unsigned cbuf_lds = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)cbuf;
     int n_buf = 0;  // wave-uniform
     auto flush_candidates = [&]() {
@@ -192,122 +246,120 @@ __global__ __launch_bounds__(kPfThreads, 2) void approx_kernel(
         n_buf = 0;
     };
 
-    // per-column scalars of the tile (|b|^2, pass-2 threshold) are fetched one tile ahead
-    float nb_next[2], tv_next[2];
-#pragma unroll
-    for (int cb = 0; cb < 2; ++cb) {
-        nb_next[cb] = g_bnrm[t_begin * kPfBT + cb * 32 + lcol];
-        tv_next[cb] = (PASS == 2) ? g_tv[pp.tv_off + t_begin * kPfBT + cb * 32 + lcol] : 0.f;
-    }
     const int xb = lcol & 15;  // both column blocks: row & 15 == lcol & 15
-    int slot = 0;
 #pragma unroll 1
-    for (int t = t_begin; t < t_end; ++t, slot ^= 1) {
-        __syncthreads();  // tile t landed (vmcnt(0) with the barrier), other slot free
-        if (t + 1 < t_end) glds_copy_bytes(gB + (size_t)(t + 1) * kPfLdsB, sB + (slot ^ 1) * kPfLdsB, kPfLdsB, tid, kPfThreads);
-        const float nb[2] = {nb_next[0], nb_next[1]}, tvc[2] = {tv_next[0], tv_next[1]};
-        if (t + 1 < t_end) {
+    for (int t = t_begin; t < t_end; ++t) {
+        // Tile t must have landed.  VMEM ops younger than its DMA group: first iteration none (drained
+        // above), second iteration none, afterwards the stores of iteration t-2, and all of iteration
+        // t-1 (DMA group of tile t+1 + stores).
+        if (t - t_begin >= 2) wait_vmcnt<kStoreOps + kDmaOps + kStoreOps>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // every wave's part of tile t is in LDS; slot of tile t-1 is free
+        asm volatile("" ::: "memory");
+        dma_tile(t + 2);
+        const int sl = (t - t_begin) % kPfRing;
+        const char* pb = sB + sl * kPfLdsB + lcol * kHalfRowBytes;
+        const float* aux = aux_w + sl * 2 * kPfAuxFloats;
 #pragma unroll
-            for (int cb = 0; cb < 2; ++cb) {
-                nb_next[cb] = g_bnrm[(t + 1) * kPfBT + cb * 32 + lcol];
-                if (PASS == 2) tv_next[cb] = g_tv[pp.tv_off + (t + 1) * kPfBT + cb * 32 + lcol];
+        for (int cb = 0; cb < 2; ++cb) {
+            h8 bf[8];
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks)
+                bf[ks] = *reinterpret_cast<const h8*>(pb + cb * 32 * kHalfRowBytes + (((2 * ks + lhalf) ^ xb) << 4));
+            const float nb = aux[cb * 32 + lcol];
+            const float tvc = (PASS == 2) ? aux[kPfAuxFloats + cb * 32 + lcol] : 0.f;
+            f16v acc[2];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][ks], bf[ks], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[1][ks], bf[ks], acc[1], 0, 0, 0);
             }
-        }
-        const char* pb = sB + slot * kPfLdsB + lcol * kHalfRowBytes;
-        // all 16 B fragments of the tile up front, then 16 MFMAs back to back
-        h8 bf[2][8];
+            const int col = t * kPfBT + cb * 32 + lcol;  // this lane's B row (train index)
+            if (PASS == 1) {
+                // Only MINIMA are tracked (1 op per element instead of 2): the second smallest of minima
+                // over disjoint subsets is an upper bound of the true second-smallest S~, which is all
+                // the threshold needs (it is exact unless both neighbours fall into one subset).
+                float c[4];
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks)
+                for (int j = 0; j < 4; ++j) c[j] = f_inf();
 #pragma unroll
-            for (int cb = 0; cb < 2; ++cb)
-                bf[cb][ks] = *reinterpret_cast<const h8*>(pb + cb * 32 * kHalfRowBytes + (((2 * ks + lhalf) ^ xb) << 4));
-        f16v acc[2];
+                for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
+                    for (int q4 = 0; q4 < 4; ++q4) {
+                        // rows (r&3) = 0..3 of this quad are consecutive: one 16-byte LDS read
+                        const v4f nav = *reinterpret_cast<const v4f*>(na_w + rb * 32 + 8 * q4 + 4 * lhalf);
+                        float v[4];
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks], bf[0][ks], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks], bf[1][ks], acc[1], 0, 0, 0);
-        }
-        const int col0 = t * kPfBT + lcol;  // this lane's B rows (train indices): col0 and col0 + 32
-        if (PASS == 1) {
-#pragma unroll
-            for (int cb = 0; cb < 2; ++cb) {
-                // two independent column chains (even / odd r) keep the VALU fed
-                float c0[2] = {f_inf(), f_inf()}, c1[2] = {f_inf(), f_inf()};
-#pragma unroll
-                for (int rb = 0; rb < 4; ++rb) {
-                    float u[4], v[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const float d = acc[cb][4 * rb + j];
-                        u[j] = fmaf(d, -2.f, nb[cb]);
-                        v[j] = fmaf(d, -2.f, na[4 * rb + j]);
+                        for (int j = 0; j < 4; ++j) {
+                            const float d = acc[rb][4 * q4 + j];
+                            rs0[rb][4 * q4 + j] = fminf(rs0[rb][4 * q4 + j], fmaf(d, -2.f, nb));
+                            v[j] = fmaf(d, -2.f, nav[j]);
+                        }
+                        c[q4] = fminf(c[q4], fminf(fminf(v[0], v[1]), fminf(v[2], v[3])));  // folds to v_min3
                     }
+                // this lane: min over its 32 rows; partner lane (l ^ 32): the other 32 rows of the wave
+                const float mine = fminf(fminf(c[0], c[1]), fminf(c[2], c[3]));
+                const float other = __shfl_xor(mine, 32);
+                // always two store instructions per column block (the counted waits rely on it)
+                const long long o = pd.cp_off + (long long)(item.a_blk * 4 + wave) * pd.n2pad + col;
+                if (lhalf == 0) cp_s0[o] = fminf(mine, other);
+                if (lhalf == 0) cp_s1[o] = fmaxf(mine, other);
+                asm volatile("" ::: "memory");
+            } else {
+                // branch-free hit mask: element k = rb*16 + r ends up at bit 31 - k
+                const float hb = 0.5f * nb, hv = 0.5f * tvc;
+                unsigned mask = 0;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        rs1[4 * rb + j] = __builtin_amdgcn_fmed3f(rs0[4 * rb + j], rs1[4 * rb + j], u[j]);
-                        rs0[4 * rb + j] = fminf(rs0[4 * rb + j], u[j]);
-                        c1[j & 1] = __builtin_amdgcn_fmed3f(c0[j & 1], c1[j & 1], v[j]);
-                        c0[j & 1] = fminf(c0[j & 1], v[j]);
+                for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float th = fminf(hb - rs0[rb][r], na[rb][r] - hv);
+                        mask = mask + mask + ((acc[rb][r] >= th) ? 1u : 0u);
                     }
+                // Candidates are rare (a few per row): slot them with ballot/popcount into this wave's
+                // LDS buffer -- no atomics in the loop -- and flush to the pair's global list when full.
+                while (__ballot(mask != 0u) != 0ull) {
+                    const bool hit = mask != 0u;
+                    const int k = __clz((int)mask);  // first remaining element of this lane (32 if none)
+                    const unsigned long long m = __ballot(hit);
+                    if (n_buf + 64 > kPfCandBuf) flush_candidates();
+                    if (hit) {
+                        mask &= ~(0x80000000u >> k);
+                        const int slt = n_buf + __popcll(m & ((1ull << lane) - 1ull));
+                        // inline asm on purpose: hipcc would first drain vmcnt(0) for a visible LDS store
+                        const int2 e = make_int2(arow_base + (k >> 4) * 32 + (k & 3) + 8 * ((k & 15) >> 2), col);
+                        asm volatile("ds_write_b64 %0, %1" ::"v"(cbuf_lds + slt * 8), "v"(e) : "memory");
+                    }
+                    n_buf += __popcll(m);
                 }
-                v2_merge(c0[0], c1[0], c0[1], c1[1]);
-                v2_merge(c0[0], c1[0], __shfl_xor(c0[0], 32), __shfl_xor(c1[0], 32));
-                if (lhalf == 0) {
-                    const long long o = pd.cp_off + (long long)(item.a_blk * 4 + wave) * pd.n2pad + col0 + cb * 32;
-                    cp_s0[o] = c0[0];
-                    cp_s1[o] = c1[0];
-                }
-            }
-        } else {
-            // branch-free hit mask: element k = cb*16 + r ends up at bit 31 - k
-            unsigned mask = 0;
-#pragma unroll
-            for (int cb = 0; cb < 2; ++cb) {
-                const float hb = 0.5f * nb[cb], hv = 0.5f * tvc[cb];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float th = fminf(hb - rs0[r], na[r] - hv);
-                    mask = mask + mask + ((acc[cb][r] >= th) ? 1u : 0u);
-                }
-            }
-            // Candidates are rare (a few per row): slot them with ballot/popcount into this wave's LDS
-            // buffer -- no atomics in the loop -- and flush to the pair's global list when it fills up.
-            while (__ballot(mask != 0u) != 0ull) {
-                const bool hit = mask != 0u;
-                const int k = __clz((int)mask);  // first remaining element of this lane (32 if none)
-                const unsigned long long m = __ballot(hit);
-                if (n_buf + 64 > kPfCandBuf) flush_candidates();
-                if (hit) {
-                    mask &= ~(0x80000000u >> k);
-                    const int sl = n_buf + __popcll(m & ((1ull << lane) - 1ull));
-                    // inline asm on purpose: for a compiler-visible LDS store hipcc first drains vmcnt(0),
-                    // i.e. waits for the next tile's LDS-DMA (which cannot alias cbuf)
-                    const int2 e = make_int2(arow_base + (k & 3) + 8 * ((k & 15) >> 2), col0 + (k >> 4) * 32);
-                    asm volatile("ds_write_b64 %0, %1" ::"v"(cbuf_lds + sl * 8), "v"(e) : "memory");
-                }
-                n_buf += __popcll(m);
             }
         }
     }
     if (PASS == 2) flush_candidates();
 
     if (PASS == 1) {
-        // rows: merge the 32 column lanes; one partial slot per B range
+        // rows: the two smallest of the 32 lanes' minima; one partial slot per B range
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
+        for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-            for (int m = 1; m < 32; m <<= 1) v2_merge(rs0[r], rs1[r], __shfl_xor(rs0[r], m), __shfl_xor(rs1[r], m));
-        }
+            for (int r = 0; r < 16; ++r) {
+                rs1[rb][r] = f_inf();
+#pragma unroll
+                for (int m = 1; m < 32; m <<= 1)
+                    v2_merge(rs0[rb][r], rs1[rb][r], __shfl_xor(rs0[rb][r], m), __shfl_xor(rs1[rb][r], m));
+            }
         if (lcol == 0) {
             const long long o = pd.rp_off + (long long)item.range * pd.n1pad + arow_base;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int off = (r & 3) + 8 * (r >> 2);
-                rp_s0[o + off] = rs0[r];
-                rp_s1[o + off] = rs1[r];
-            }
+            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int off = rb * 32 + (r & 3) + 8 * (r >> 2);
+                    rp_s0[o + off] = rs0[rb][r];
+                    rp_s1[o + off] = rs1[rb][r];
+                }
         }
     }
 }
@@ -336,7 +388,7 @@ __global__ void pf_thresholds_kernel(const PairDesc* __restrict__ pairs, const P
     }
     if (e < pd.n2pad) {
         float s0 = f_inf(), s1 = f_inf();
-        for (int p = 0; p < pd.a_blocks * 4; ++p) {
+        for (int p = 0; p < pd.a_blocks256 * 4; ++p) {
             const long long o = pd.cp_off + (long long)p * pd.n2pad + e;
             v2_merge(s0, s1, cp_s0[o], cp_s1[o]);
         }
