@@ -31,6 +31,7 @@ sys.path.insert(0, ROOT)
 FLOPS_PER_DESC_PAIR = 384.0   # 128 x (sub, mul, add), not fused (direct form)
 PEAK_FP32_VALU_TFLOPS = 157.3  # MI355X_MICROARCH.md: peak FP32 vector (FMA = 2 flop) = f32 MFMA rate
 PEAK_HBM_GBPS = 8000.0
+PEAK_F16_MFMA_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16/f16 MFMA peak
 
 
 def build_workload(args):
@@ -111,6 +112,8 @@ def main():
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--order", type=int, default=0, help="0: OpenCV SSE order (default), 1: AVX2+FMA order")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-prefilter", action="store_true",
+                    help="brute-force exact-order kernel for every pair (same results, ~6x slower)")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     args = ap.parse_args()
 
@@ -139,6 +142,8 @@ def main():
     total_desc_pairs = int((n_rows[pairs[:, 0]] * n_rows[pairs[:, 1]]).sum())
 
     ctx = _lib.Context(local_rank, order=args.order)
+    if args.no_prefilter:
+        ctx.set_prefilter(False)
     for i, im in enumerate(imgs):
         ctx.upload_image(i, im)   # resident in HBM before the timed region
     sm = ShardedMatcher(ctx=ctx, device=dev)
@@ -149,6 +154,8 @@ def main():
         torch.cuda.synchronize()
 
     kern_ms, kern_launches, local_pairs_work = 0.0, 0, 0
+    pf_ms, pf_launches, pf_pairs_work, exact_pairs_work, cand, rows_work, fallback = 0.0, 0, 0, 0, 0, 0, 0
+    algo_bytes_step = 0
     result = None
     for _ in range(args.warmup):
         result = sm.match_all(pairs, n_rows)
@@ -161,6 +168,12 @@ def main():
         kern_launches += p["dist_kernel_launches"]
         local_pairs_work += p["descriptor_pairs"]
         algo_bytes_step = p["dist_algo_bytes"]
+        pf_ms += p["approx_kernel_ms"]
+        pf_launches += p["approx_kernel_launches"]
+        pf_pairs_work += p["prefilter_descriptor_pairs"]
+        exact_pairs_work += p["exact_descriptor_pairs"]
+        cand += p["candidates"]
+        fallback += p["fallback_pairs"]
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -169,6 +182,7 @@ def main():
         dt = float(tmax.item())
     offs, qt, dd = result
     n_matches = int(offs[-1])
+    rows_work = float((n_rows[pairs[:, 0]] + n_rows[pairs[:, 1]]).sum()) * args.steps / max(world, 1)
 
     value = total_desc_pairs * args.steps / dt
     out = {
@@ -177,29 +191,46 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "path": "brute-force exact fp32" if args.no_prefilter else "fp16 MFMA prefilter + exact fp32 re-check (bit-identical results)",
         "image_pairs_per_s": len(pairs) * args.steps / dt,
         "config": {"workload": wl_name, "image_pairs": int(len(pairs)), "descriptor_pairs_per_step": total_desc_pairs,
                    "matches_per_step": n_matches, "accum_order": "opencv-sse4x4-nofma" if args.order == 0 else "opencv-avx2-fma",
                    "ratio": 0.8, "cross_check": True, "max_distance": 0.7, "preemptive_filter": False,
                    "parallelism": "pairs sharded over %d GPU(s), RCCL all-gather of match lists" % world},
     }
+    if pf_launches > 0:
+        # dominant kernel of the default path: approx_kernel (MFMA fp16 32x32x16), two sweeps per batch
+        avg_ms = pf_ms / pf_launches
+        flops = 256.0 * 2.0 * pf_pairs_work   # GEMM form, 128 x (mul, add) per descriptor pair, two sweeps
+        achieved = flops / (pf_ms * 1e-3) / 1e12
+        out["roofline"] = {
+            "kernel": "approx_kernel<1|2> (MFMA prefilter sweeps; exact fp32 re-check only on the candidates)",
+            "bound": "mfma", "achieved": achieved, "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": achieved / PEAK_F16_MFMA_TFLOPS, "traffic": None,
+            "avg_launch_ms": avg_ms, "launches": pf_launches, "flops_per_desc_pair_per_sweep": 256.0,
+            "descriptor_pairs_per_launch": pf_pairs_work / pf_launches,
+            "candidates_per_row": cand / max(1.0, rows_work),
+            "fallback_pairs": fallback,
+            "hbm": {"algorithmic_bytes_per_step": algo_bytes_step,
+                    "achieved_GBps": (algo_bytes_step * args.steps / (pf_ms * 1e-3)) / 1e9, "peak_GBps": PEAK_HBM_GBPS,
+                    "frac": (algo_bytes_step * args.steps / (pf_ms * 1e-3)) / 1e9 / PEAK_HBM_GBPS},
+        }
     if kern_launches > 0:
         avg_ms = kern_ms / kern_launches
-        flops_per_launch = FLOPS_PER_DESC_PAIR * local_pairs_work / kern_launches
+        flops_per_launch = FLOPS_PER_DESC_PAIR * exact_pairs_work / kern_launches
         achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
-        out["roofline"] = {
-            "kernel": "dist_top2_kernel", "bound": "valu", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS,
-            "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_VALU_TFLOPS, "traffic": None,
-            "avg_launch_ms": avg_ms, "launches": kern_launches,
-            "flops_per_desc_pair": FLOPS_PER_DESC_PAIR,
-            "note": "exact-order path is VALU-bound (arithmetic intensity ~1e3 flop/B); its 384 ops per descriptor pair "
-                    "are unfusable sub/mul/add, so 78.6 TFLOP/s (half the FMA peak) is the attainable ceiling; "
-                    "frac_of_nofma_ceiling reports against that",
+        exact = {
+            "kernel": "dist_top2_kernel (brute-force exact-order path)", "bound": "valu", "achieved": achieved,
+            "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_VALU_TFLOPS, "traffic": None,
+            "avg_launch_ms": avg_ms, "launches": kern_launches, "flops_per_desc_pair": FLOPS_PER_DESC_PAIR,
+            "note": "384 unfusable sub/mul/add per descriptor pair: 78.6 TFLOP/s (half the FMA peak) is the "
+                    "attainable ceiling; frac_of_nofma_ceiling reports against that",
             "frac_of_nofma_ceiling": achieved / (PEAK_FP32_VALU_TFLOPS / 2),
-            "hbm": {"algorithmic_bytes_per_launch": algo_bytes_step / max(1, kern_launches // args.steps) if args.steps else None,
-                    "achieved_GBps": (algo_bytes_step * args.steps / (kern_ms * 1e-3)) / 1e9, "peak_GBps": PEAK_HBM_GBPS,
-                    "frac": (algo_bytes_step * args.steps / (kern_ms * 1e-3)) / 1e9 / PEAK_HBM_GBPS},
         }
+        if "roofline" in out:
+            out["roofline_exact_path"] = exact
+        else:
+            out["roofline"] = exact
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(imgs, pairs, budget_s=args.cpu_budget)
         out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]

@@ -75,6 +75,7 @@ typedef struct msfm_profile {
     int64_t candidates;        /* exact distances evaluated for prefiltered pairs */
     int64_t prefilter_descriptor_pairs;
     int64_t exact_descriptor_pairs; /* descriptor pairs that went through the brute-force kernel */
+    int64_t tie_rows;          /* rows re-scanned by the sqrt-space tie fix-up */
 } msfm_profile;
 
 /* ---- context ------------------------------------------------------------------------- */

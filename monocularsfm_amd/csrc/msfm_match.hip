@@ -451,6 +451,7 @@ int check_fix_overflow(msfm_ctx* ctx) {
     int nfix = 0;
     HIPCHK(ctx, hipMemcpyAsync(&nfix, ctx->d_fix_count.p, 4, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->prof.tie_rows += nfix;
     if (nfix > kFixCap)
         return fail(ctx, MSFM_E_CAPACITY, "tie fix-up list overflow (" + std::to_string(nfix) + " tied rows in one batch)");
     return MSFM_OK;
@@ -668,7 +669,7 @@ int msfm_match_pairs(msfm_ctx* ctx, const int32_t* pairs, int n_pairs, const msf
     HIPCHK(ctx, hipEventRecord(ev_begin, ctx->stream));
 
     // sub-batches bounded by the partial-result scratch (12 B per partial entry)
-    const long long kScratchElems = (long long)1 << 28;  // 3 GiB of partials at most
+    const long long kScratchElems = (long long)5 << 30;  // ~20 GiB of scratch (4-byte units) at most, of 288 GB HBM
     const int kMaxPairsPerBatch = 4096;
     size_t ev_next = 2;
     std::vector<size_t> ev_of_batch;

@@ -204,29 +204,22 @@ __global__ __launch_bounds__(kPfThreads, 2) void approx_kernel(
 
     // this lane's 32 result rows: (rb, r) -> row = a_blk*256 + wave*64 + rb*32 + (r&3) + 8*(r>>2) + 4*lhalf
     const int arow_base = item.a_blk * 256 + wave * 64 + 4 * lhalf;
-    // PASS 1: na = |a|^2, rs0/rs1 = two smallest u per row.
-    // PASS 2: na = 0.5 |a|^2, rs0 = 0.5 * row threshold (u-space); a hit is dot >= min(hb - rs0, na - hv).
-    // In pass 1 the row norms sit in LDS (wave-private, 64 floats) to keep the VGPR budget spill-free:
-    // a spill reload is a scratch (VMEM) load and would drain the DMA ring at every use.
+    // Row scalars in LDS (wave-private, 64 floats): PASS 1 |a|^2, PASS 2 0.5 |a|^2.  They are read back
+    // four rows at a time; keeping them out of the VGPR budget keeps the kernel spill-free (a spill
+    // reload is a scratch = VMEM load and would drain the DMA ring at every use).
+    // rs0: PASS 1 running row minimum of u; PASS 2 0.5 * row threshold (a hit is dot >= min(hb - rs0, ha - hv)).
     float* na_w = sAux + 4 * kPfRing * 2 * kPfAuxFloats + wave * 64;
-    float na[2][16], rs0[2][16], rs1[2][16];
-    if (PASS == 1) {
+    float rs0[2][16];
+    {
         const int row = item.a_blk * 256 + wave * 64 + lane;
-        na_w[lane] = row < pd.n1 ? g_anrm[row] : f_inf();  // padding rows: +inf norm, never selected
-#pragma unroll
-        for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { rs0[rb][r] = f_inf(); rs1[rb][r] = f_inf(); na[rb][r] = 0.f; }
-    } else {
+        const float nrm = row < pd.n1 ? g_anrm[row] : f_inf();  // padding rows: +inf norm, never selected
+        na_w[lane] = (PASS == 1) ? nrm : 0.5f * nrm;
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = arow_base + rb * 32 + (r & 3) + 8 * (r >> 2);
-                const bool live = row < pd.n1;  // padding rows: +inf norm / -inf threshold, never selected
-                na[rb][r] = live ? 0.5f * g_anrm[row] : f_inf();
-                rs0[rb][r] = live ? 0.5f * g_tu[pp.tu_off + row] : -f_inf();
-                rs1[rb][r] = 0.f;
+                const int rr = arow_base + rb * 32 + (r & 3) + 8 * (r >> 2);
+                rs0[rb][r] = (PASS == 1) ? f_inf() : (rr < pd.n1 ? 0.5f * g_tu[pp.tu_off + rr] : -f_inf());
             }
     }
     wait_vmcnt<0>();  // prologue loads (and the first two DMA groups) are done: counted waits start clean
@@ -247,11 +240,114 @@ __global__ __launch_bounds__(kPfThreads, 2) void approx_kernel(
     };
 
     const int xb = lcol & 15;  // both column blocks: row & 15 == lcol & 15
+
+    // ---- the two halves of the software pipeline -------------------------------------------------
+    // A "block" is (tile, column block): 32 x 64... per wave 2 x 16 MFMA results per lane.
+    // stage(): issue the 16 MFMAs of block k+1 into `nxt` while the VALU epilogue of block k (in `cur`)
+    // runs -- in ONE basic block, so the scheduler can interleave them: co-resident waves run in
+    // lockstep (same barriers), only the overlap inside a wave keeps both pipes busy.
+    struct BlockMeta { float nb, tvc; int col; };
+    auto load_bf = [&](const char* pb, int cb, h8 (&bf)[8]) {
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks)
+            bf[ks] = *reinterpret_cast<const h8*>(pb + cb * 32 * kHalfRowBytes + (((2 * ks + lhalf) ^ xb) << 4));
+    };
+    auto mfma_block = [&](const h8 (&bf)[8], f16v (&acc)[2]) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][ks], bf[ks], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[1][ks], bf[ks], acc[1], 0, 0, 0);
+        }
+    };
+    // branch-free part of the epilogue; returns the pass-2 hit mask (element k = rb*16 + r at bit 31-k)
+    auto epilogue_valu = [&](const f16v (&acc)[2], const BlockMeta& bm) -> unsigned {
+        unsigned mask = 0;
+        if (PASS == 1) {
+            // Only MINIMA are tracked (1 op per element instead of 2): the second smallest of minima
+            // over disjoint subsets is an upper bound of the true second-smallest S~, which is all
+            // the threshold needs (it is exact unless both neighbours fall into one subset).
+            float c[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) c[j] = f_inf();
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    // rows (r&3) = 0..3 of this quad are consecutive: one 16-byte LDS read
+                    const v4f nav = *reinterpret_cast<const v4f*>(na_w + rb * 32 + 8 * q4 + 4 * lhalf);
+                    float v[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float d = acc[rb][4 * q4 + j];
+                        rs0[rb][4 * q4 + j] = fminf(rs0[rb][4 * q4 + j], fmaf(d, -2.f, bm.nb));
+                        v[j] = fmaf(d, -2.f, nav[j]);
+                    }
+                    c[q4] = fminf(c[q4], fminf(fminf(v[0], v[1]), fminf(v[2], v[3])));  // folds to v_min3
+                }
+            // this lane: min over its 32 rows; partner lane (l ^ 32): the other 32 rows of the wave
+            const float mine = fminf(fminf(c[0], c[1]), fminf(c[2], c[3]));
+            const float other = __shfl_xor(mine, 32);
+            // always two store instructions per block (the counted waits rely on it)
+            const long long o = pd.cp_off + (long long)(item.a_blk * 4 + wave) * pd.n2pad + bm.col;
+            if (lhalf == 0) cp_s0[o] = fminf(mine, other);
+            if (lhalf == 0) cp_s1[o] = fmaxf(mine, other);
+        } else {
+            const float hb = 0.5f * bm.nb, hv = 0.5f * bm.tvc;
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const v4f hav = *reinterpret_cast<const v4f*>(na_w + rb * 32 + 8 * q4 + 4 * lhalf);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float th = fminf(hb - rs0[rb][4 * q4 + j], hav[j] - hv);
+                        mask = mask + mask + ((acc[rb][4 * q4 + j] >= th) ? 1u : 0u);
+                    }
+                }
+        }
+        return mask;
+    };
+    // pass 2: slot the (rare) hits with ballot/popcount into this wave's LDS buffer -- no atomics in the
+    // loop -- and flush to the pair's global list when the buffer fills up
+    auto append_hits = [&](unsigned mask, int col) {
+        while (__ballot(mask != 0u) != 0ull) {
+            const bool hit = mask != 0u;
+            const int k = __clz((int)mask);  // first remaining element of this lane (32 if none)
+            const unsigned long long m = __ballot(hit);
+            if (n_buf + 64 > kPfCandBuf) flush_candidates();
+            if (hit) {
+                mask &= ~(0x80000000u >> k);
+                const int slt = n_buf + __popcll(m & ((1ull << lane) - 1ull));
+                // inline asm on purpose: hipcc would first drain vmcnt(0) for a compiler-visible LDS store
+                const int2 e = make_int2(arow_base + (k >> 4) * 32 + (k & 3) + 8 * ((k & 15) >> 2), col);
+                asm volatile("ds_write_b64 %0, %1" ::"v"(cbuf_lds + slt * 8), "v"(e) : "memory");
+            }
+            n_buf += __popcll(m);
+        }
+    };
+    // interleave hint: one MFMA, then a slice of the epilogue's VALU / LDS work, 16 times
+    auto interleave_hint = [&]() {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                     // 1 MFMA
+            __builtin_amdgcn_sched_group_barrier(0x002, PASS == 1 ? 8 : 11, 0);    // VALU
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                     // 1 DS read
+        }
+    };
+
+    // accB / metaB start as a harmless dummy block (|b|^2 = +inf, threshold = -inf: no minimum moves,
+    // no hit; its column-partial store is overwritten by the real block (t_begin, cb 1) later), so
+    // that every iteration runs the same instruction sequence -- the counted waits rely on it
+    f16v accA[2], accB[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { accB[0][r] = 0.f; accB[1][r] = 0.f; }
+    BlockMeta metaA = {0.f, 0.f, 0}, metaB = {f_inf(), -f_inf(), t_begin * kPfBT + 32 + lcol};
 #pragma unroll 1
     for (int t = t_begin; t < t_end; ++t) {
-        // Tile t must have landed.  VMEM ops younger than its DMA group: first iteration none (drained
-        // above), second iteration none, afterwards the stores of iteration t-2, and all of iteration
-        // t-1 (DMA group of tile t+1 + stores).
+        // Tile t must have landed.  Younger VMEM ops than its DMA group: the stores of iteration t-2
+        // issued after it, and all of iteration t-1 (DMA group of tile t+1 + stores).
         if (t - t_begin >= 2) wait_vmcnt<kStoreOps + kDmaOps + kStoreOps>();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();  // every wave's part of tile t is in LDS; slot of tile t-1 is free
@@ -260,87 +356,36 @@ __global__ __launch_bounds__(kPfThreads, 2) void approx_kernel(
         const int sl = (t - t_begin) % kPfRing;
         const char* pb = sB + sl * kPfLdsB + lcol * kHalfRowBytes;
         const float* aux = aux_w + sl * 2 * kPfAuxFloats;
-#pragma unroll
-        for (int cb = 0; cb < 2; ++cb) {
-            h8 bf[8];
-#pragma unroll
-            for (int ks = 0; ks < 8; ++ks)
-                bf[ks] = *reinterpret_cast<const h8*>(pb + cb * 32 * kHalfRowBytes + (((2 * ks + lhalf) ^ xb) << 4));
-            const float nb = aux[cb * 32 + lcol];
-            const float tvc = (PASS == 2) ? aux[kPfAuxFloats + cb * 32 + lcol] : 0.f;
-            f16v acc[2];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
-#pragma unroll
-            for (int ks = 0; ks < 8; ++ks) {
-                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][ks], bf[ks], acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[1][ks], bf[ks], acc[1], 0, 0, 0);
-            }
-            const int col = t * kPfBT + cb * 32 + lcol;  // this lane's B row (train index)
-            if (PASS == 1) {
-                // Only MINIMA are tracked (1 op per element instead of 2): the second smallest of minima
-                // over disjoint subsets is an upper bound of the true second-smallest S~, which is all
-                // the threshold needs (it is exact unless both neighbours fall into one subset).
-                float c[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) c[j] = f_inf();
-#pragma unroll
-                for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-                    for (int q4 = 0; q4 < 4; ++q4) {
-                        // rows (r&3) = 0..3 of this quad are consecutive: one 16-byte LDS read
-                        const v4f nav = *reinterpret_cast<const v4f*>(na_w + rb * 32 + 8 * q4 + 4 * lhalf);
-                        float v[4];
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const float d = acc[rb][4 * q4 + j];
-                            rs0[rb][4 * q4 + j] = fminf(rs0[rb][4 * q4 + j], fmaf(d, -2.f, nb));
-                            v[j] = fmaf(d, -2.f, nav[j]);
-                        }
-                        c[q4] = fminf(c[q4], fminf(fminf(v[0], v[1]), fminf(v[2], v[3])));  // folds to v_min3
-                    }
-                // this lane: min over its 32 rows; partner lane (l ^ 32): the other 32 rows of the wave
-                const float mine = fminf(fminf(c[0], c[1]), fminf(c[2], c[3]));
-                const float other = __shfl_xor(mine, 32);
-                // always two store instructions per column block (the counted waits rely on it)
-                const long long o = pd.cp_off + (long long)(item.a_blk * 4 + wave) * pd.n2pad + col;
-                if (lhalf == 0) cp_s0[o] = fminf(mine, other);
-                if (lhalf == 0) cp_s1[o] = fmaxf(mine, other);
-                asm volatile("" ::: "memory");
-            } else {
-                // branch-free hit mask: element k = rb*16 + r ends up at bit 31 - k
-                const float hb = 0.5f * nb, hv = 0.5f * tvc;
-                unsigned mask = 0;
-#pragma unroll
-                for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float th = fminf(hb - rs0[rb][r], na[rb][r] - hv);
-                        mask = mask + mask + ((acc[rb][r] >= th) ? 1u : 0u);
-                    }
-                // Candidates are rare (a few per row): slot them with ballot/popcount into this wave's
-                // LDS buffer -- no atomics in the loop -- and flush to the pair's global list when full.
-                while (__ballot(mask != 0u) != 0ull) {
-                    const bool hit = mask != 0u;
-                    const int k = __clz((int)mask);  // first remaining element of this lane (32 if none)
-                    const unsigned long long m = __ballot(hit);
-                    if (n_buf + 64 > kPfCandBuf) flush_candidates();
-                    if (hit) {
-                        mask &= ~(0x80000000u >> k);
-                        const int slt = n_buf + __popcll(m & ((1ull << lane) - 1ull));
-                        // inline asm on purpose: hipcc would first drain vmcnt(0) for a visible LDS store
-                        const int2 e = make_int2(arow_base + (k >> 4) * 32 + (k & 3) + 8 * ((k & 15) >> 2), col);
-                        asm volatile("ds_write_b64 %0, %1" ::"v"(cbuf_lds + slt * 8), "v"(e) : "memory");
-                    }
-                    n_buf += __popcll(m);
-                }
-            }
-        }
+        h8 bf[8];
+        // stage 1: MFMA (t, cb 0) -> accA   ||   epilogue of (t-1, cb 1) in accB
+        load_bf(pb, 0, bf);
+        metaA.nb = aux[lcol];
+        metaA.tvc = (PASS == 2) ? aux[kPfAuxFloats + lcol] : 0.f;
+        metaA.col = t * kPfBT + lcol;
+        unsigned mask = 0;
+        mfma_block(bf, accA);
+        mask = epilogue_valu(accB, metaB);
+        interleave_hint();
+        if (PASS == 2) append_hits(mask, metaB.col);
+        // stage 2: MFMA (t, cb 1) -> accB   ||   epilogue of (t, cb 0) in accA
+        load_bf(pb, 1, bf);
+        metaB.nb = aux[32 + lcol];
+        metaB.tvc = (PASS == 2) ? aux[kPfAuxFloats + 32 + lcol] : 0.f;
+        metaB.col = t * kPfBT + 32 + lcol;
+        mfma_block(bf, accB);
+        mask = epilogue_valu(accA, metaA);
+        interleave_hint();
+        if (PASS == 2) append_hits(mask, metaA.col);
+    }
+    {   // drain: epilogue of the last block
+        const unsigned mask = epilogue_valu(accB, metaB);
+        if (PASS == 2) append_hits(mask, metaB.col);
     }
     if (PASS == 2) flush_candidates();
 
     if (PASS == 1) {
         // rows: the two smallest of the 32 lanes' minima; one partial slot per B range
+        float rs1[2][16];
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
