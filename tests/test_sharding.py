@@ -24,6 +24,8 @@ def test_partition_is_a_balanced_disjoint_cover():
         cost = n_rows[pairs[:, 0]].astype(np.int64) * n_rows[pairs[:, 1]]
         loads = np.array([cost[p].sum() for p in parts], float)
         assert loads.max() / loads.mean() < 1.05
+        assert all((np.diff(p) == 1).all() for p in parts if len(p) > 1)      # contiguous ranges
+        assert (np.concatenate(parts) == np.arange(len(pairs))).all()          # in global order
         for p in parts:
             assert (np.diff(p) > 0).all()
     # deterministic
