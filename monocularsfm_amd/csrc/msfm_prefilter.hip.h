@@ -130,8 +130,8 @@ __device__ __forceinline__ void v2_merge(float& s0, float& s1, float b0, float b
 // PASS 1: two smallest u per row (lane-private over its columns, merged over the 32 lanes at the
 //         end) and two smallest v per column (lane pair merged, written per (A block, wave)).
 // PASS 2: append (q, t) where u <= tu[q] or v <= tv[t], tested in dot space.
-// VMEM ops per wave per tile (the counted waits depend on it): PASS 1: 5 DMA + 4 stores,
-// PASS 2: 6 DMA (+ rare flushes, which only add ops and are therefore safe).
+// VMEM LOADS per wave per tile (the counted wait depends on it): PASS 1: 5 DMA, PASS 2: 6 DMA.
+// Stores and the rare candidate flushes only add ops, which makes the wait more conservative.
 // ---------------------------------------------------------------------------------------------
 constexpr int kPfRing = 3;
 constexpr int kPfAuxFloats = 64;  // per slot: |b|^2 of the tile's 64 rows (and 64 thresholds in pass 2)
@@ -187,7 +187,6 @@ __global__ __launch_bounds__(kPfThreads, 2) void approx_kernel(
                                              (__attribute__((address_space(3))) void*)(aux_w + sl * 2 * kPfAuxFloats + kPfAuxFloats), 4, 0, 0);
     };
     constexpr int kDmaOps = (PASS == 1) ? 5 : 6;
-    constexpr int kStoreOps = (PASS == 1) ? 4 : 0;  // 2 column blocks x (cp_s0, cp_s1); see the stores below
 
     dma_tile(t_begin);
     dma_tile(t_begin + 1);
@@ -289,7 +288,6 @@ __global__ __launch_bounds__(kPfThreads, 2) void approx_kernel(
             // this lane: min over its 32 rows; partner lane (l ^ 32): the other 32 rows of the wave
             const float mine = fminf(fminf(c[0], c[1]), fminf(c[2], c[3]));
             const float other = __shfl_xor(mine, 32);
-            // always two store instructions per block (the counted waits rely on it)
             const long long o = pd.cp_off + (long long)(item.a_blk * 4 + wave) * pd.n2pad + bm.col;
             if (lhalf == 0) cp_s0[o] = fminf(mine, other);
             if (lhalf == 0) cp_s1[o] = fmaxf(mine, other);
@@ -346,9 +344,12 @@ __global__ __launch_bounds__(kPfThreads, 2) void approx_kernel(
     BlockMeta metaA = {0.f, 0.f, 0}, metaB = {f_inf(), -f_inf(), t_begin * kPfBT + 32 + lcol};
 #pragma unroll 1
     for (int t = t_begin; t < t_end; ++t) {
-        // Tile t must have landed.  Younger VMEM ops than its DMA group: the stores of iteration t-2
-        // issued after it, and all of iteration t-1 (DMA group of tile t+1 + stores).
-        if (t - t_begin >= 2) wait_vmcnt<kStoreOps + kDmaOps + kStoreOps>();
+        // Tile t must have landed.  Its DMA group is followed by exactly one younger group of LOADS
+        // (tile t+1, kDmaOps of them).  Loads retire in order among themselves, but on gfx9-class
+        // vmcnt stores may retire out of order with respect to loads, so the count must not rely on
+        // the (pass-1) stores: "at most kDmaOps outstanding" implies every load of tile t is done,
+        // because a pending load of tile t would keep all kDmaOps loads of tile t+1 pending as well.
+        if (t - t_begin >= 2) wait_vmcnt<kDmaOps>();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();  // every wave's part of tile t is in LDS; slot of tile t-1 is free
         asm volatile("" ::: "memory");
