@@ -3,9 +3,12 @@
 // stdout lines); the per-pair arithmetic runs on the GPU through include/msfm_match.h.
 #include "FeatureMatching.h"
 
+#include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <iostream>
+#include <thread>
 
 #include "GeometricVerification.h"
 #include "Timer.h"
@@ -63,6 +66,7 @@ void FeatureMatcher::CloseDatabaseAndDevice() {
         ctx_ = nullptr;
     }
     resident_.clear();
+    keypoints_cache_.clear();
 }
 
 void FeatureMatcher::EnsureResident(image_t image_id) {
@@ -100,11 +104,18 @@ void FeatureMatcher::MatchImagePairs(const std::vector<std::pair<image_t, image_
         MSFM_CALL(ctx_, msfm_fetch_matches(ctx_, qt.data(), dist.data()));
         const double gpu_seconds_per_pair = timer.ElapsedSeconds() / P;
 
-        for (int p = 0; p < P; ++p) {
+        // Geometric verification (FeatureUtils::FilterMatches) is host work, ~1 ms per pair: keypoints are
+        // read once per image (SQLite handle: this thread only) and the pairs of the batch are verified
+        // on all host cores; rows are then written in pair order by this thread.
+        std::vector<std::vector<DMatch>> verified((size_t)P);
+        std::vector<double> verify_seconds((size_t)P, 0.0);
+        if (geometric_verification_)
+            for (int32_t id : todo)
+                if (!keypoints_cache_.count(id)) keypoints_cache_[id] = database_->ReadKeyPoints(id);
+        auto verify_pair = [&](int p) {
             Timer pair_timer;
             pair_timer.Start();
             const image_t image_id1 = todo[2 * (size_t)p], image_id2 = todo[2 * (size_t)p + 1];
-            std::cout << "Compute Matches " << image_id1 << " - " << image_id2 << " ... " << std::endl;
             std::vector<DMatch> prune_matches((size_t)(offs[(size_t)p + 1] - offs[(size_t)p]));
             for (size_t i = 0; i < prune_matches.size(); ++i) {
                 const size_t k = (size_t)offs[(size_t)p] + i;
@@ -112,19 +123,29 @@ void FeatureMatcher::MatchImagePairs(const std::vector<std::pair<image_t, image_
                 prune_matches[i].trainIdx = qt[2 * k + 1];
                 prune_matches[i].distance = dist[k];
             }
-            std::vector<DMatch> geometric_verif_matches;
-            if (geometric_verification_) {
-                const std::vector<KeyPoint> kpts1 = database_->ReadKeyPoints(image_id1);
-                const std::vector<KeyPoint> kpts2 = database_->ReadKeyPoints(image_id2);
-                FilterMatches(kpts1, kpts2, prune_matches, &geometric_verif_matches);
-            } else {
-                geometric_verif_matches.swap(prune_matches);
-            }
-            std::cout << "\t matches num : " << geometric_verif_matches.size() << std::endl;
+            if (geometric_verification_)
+                FilterMatches(keypoints_cache_.at(image_id1), keypoints_cache_.at(image_id2), prune_matches, &verified[(size_t)p]);
+            else
+                verified[(size_t)p].swap(prune_matches);
+            verify_seconds[(size_t)p] = pair_timer.ElapsedSeconds();
+        };
+        {
+            const int nthreads = std::max(1, std::min<int>(P, (int)std::thread::hardware_concurrency()));
+            std::atomic<int> next(0);
+            std::vector<std::thread> pool;
+            for (int t = 1; t < nthreads; ++t)
+                pool.emplace_back([&] { for (int p; (p = next.fetch_add(1)) < P;) verify_pair(p); });
+            for (int p; (p = next.fetch_add(1)) < P;) verify_pair(p);
+            for (auto& th : pool) th.join();
+        }
+        for (int p = 0; p < P; ++p) {
+            const image_t image_id1 = todo[2 * (size_t)p], image_id2 = todo[2 * (size_t)p + 1];
+            std::cout << "Compute Matches " << image_id1 << " - " << image_id2 << " ... " << std::endl;
+            std::cout << "\t matches num : " << verified[(size_t)p].size() << std::endl;
             std::cout << "\t ";
-            Timer::Print(gpu_seconds_per_pair + pair_timer.ElapsedSeconds(), "seconds");
+            Timer::Print(gpu_seconds_per_pair + verify_seconds[(size_t)p], "seconds");
             std::cout << std::endl;
-            database_->WriteMatches(image_id1, image_id2, geometric_verif_matches);
+            database_->WriteMatches(image_id1, image_id2, verified[(size_t)p]);
         }
     }
     database_->EndTransaction();

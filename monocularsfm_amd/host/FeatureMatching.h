@@ -5,6 +5,7 @@
 //     for every pair (the "TODO: cache" at src/Feature/FeatureMatching.cpp:31);
 //   * the pairs of one MatchImagePairs call are matched as one batched launch sequence.
 #pragma once
+#include <map>
 #include <set>
 #include <string>
 #include <utility>
@@ -46,6 +47,7 @@ protected:
     Database* database_ = nullptr;
     msfm_ctx* ctx_ = nullptr;
     std::set<image_t> resident_;
+    std::map<image_t, std::vector<KeyPoint>> keypoints_cache_;  // read once per image (verification)
 };
 
 class SequentialFeatureMatcher : public FeatureMatcher {
