@@ -34,6 +34,21 @@ PEAK_HBM_GBPS = 8000.0
 PEAK_F16_MFMA_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16/f16 MFMA peak
 
 
+def pmc_traffic():
+    """HBM bytes per approx_kernel launch from the committed rocprofv3 PMC passes of this same command
+    (separate --pmc FETCH_SIZE / WRITE_SIZE runs, profiles/r01_pmc_traffic_approx.json): KB -> bytes, and
+    FETCH_SIZE doubled (gfx950 counts 128-byte requests as 64 B, MI355X_MICROARCH.md).  None if absent."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic_approx.json")
+    try:
+        d = json.load(open(path))
+        per = [2.0 * k["FETCH_SIZE"]["per_launch_KB_mean"] * 1024 + k["WRITE_SIZE"]["per_launch_KB_mean"] * 1024
+               for k in d.values()]
+        return {"bytes_per_launch_mean": sum(per) / len(per), "source": "profiles/r01_pmc_traffic_approx.json",
+                "per_kernel_bytes": dict(zip(d.keys(), per))}
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def build_workload(args):
     from monocularsfm_amd import synth
     rng = np.random.default_rng(args.seed)
@@ -206,7 +221,7 @@ def main():
         out["roofline"] = {
             "kernel": "approx_kernel<1|2> (MFMA prefilter sweeps; exact fp32 re-check only on the candidates)",
             "bound": "mfma", "achieved": achieved, "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": achieved / PEAK_F16_MFMA_TFLOPS, "traffic": None,
+            "frac": achieved / PEAK_F16_MFMA_TFLOPS, "traffic": pmc_traffic(),
             "avg_launch_ms": avg_ms, "launches": pf_launches, "flops_per_desc_pair_per_sweep": 256.0,
             "descriptor_pairs_per_launch": pf_pairs_work / pf_launches,
             "candidates_per_row": cand / max(1.0, rows_work),

@@ -225,8 +225,8 @@ void assign_partials(Batch& b, int path, int target_items) {
         pd.rp_off = b.rp_elems;
         pd.cp_off = b.cp_elems;
         b.rp_elems += (long long)pd.ranges * rmult * pd.n1pad;
-        // prefilter: one column partial per wave of a 256-row A block
-        b.cp_elems += (long long)(path == 1 ? pd.a_blocks256 * 4 : pd.a_blocks) * pd.n2pad;
+        // prefilter: one column partial per 256-row A block (the four waves are merged in LDS)
+        b.cp_elems += (long long)(path == 1 ? pd.a_blocks256 : pd.a_blocks) * pd.n2pad;
     }
 }
 

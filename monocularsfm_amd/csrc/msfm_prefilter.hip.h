@@ -44,7 +44,7 @@ constexpr int kPfBT = 64;                 // B rows per tile
 constexpr int kHalfRowBytes = kDim * 2;   // one fp16 descriptor = 256 B = 16 granules of 16 B
 constexpr int kPfLdsB = kPfBT * kHalfRowBytes;  // 16 KiB per slot
 constexpr int kPfCandBuf = 256;                  // per-wave LDS candidate buffer (pass 2), int2 entries
-constexpr int kPfLdsBytes = 3 * kPfLdsB + 4 * 3 * 2 * 64 * 4 + 4 * 64 * 4 + 4 * kPfCandBuf * 8;  // 48 + 6 + 1 + 8 = 63 KiB
+constexpr int kPfLdsBytes = 3 * kPfLdsB + 4 * 3 * 2 * 64 * 4 + 4 * 64 * 4 + 4 * kPfCandBuf * 8 + 3 * 4 * 64 * 8;  // 48 + 6 + 1 + 8 + 6 = 69 KiB
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef float f16v __attribute__((ext_vector_type(16)));
@@ -226,6 +226,10 @@ __global__ __launch_bounds__(kPfThreads, 2) void approx_kernel(
     // pass 2: wave-private candidate buffer in LDS
     int2* cbuf = reinterpret_cast<int2*>(sAux + 4 * kPfRing * 2 * kPfAuxFloats + 4 * 64) + wave * kPfCandBuf;
     const unsigned cbuf_lds = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)cbuf;
+    // pass 1: column partials of the four waves meet in LDS ([ring slot][wave][64 columns] x (s0, s1)) and
+    // are merged by one wave two tiles later: 4x less partial traffic to HBM than one slot per wave
+    const unsigned colbuf_lds = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)(
+        reinterpret_cast<char*>(sAux + 4 * kPfRing * 2 * kPfAuxFloats + 4 * 64) + 4 * kPfCandBuf * 8);
     int n_buf = 0;  // wave-uniform
     auto flush_candidates = [&]() {
         if (n_buf == 0) return;
@@ -245,7 +249,7 @@ __global__ __launch_bounds__(kPfThreads, 2) void approx_kernel(
     // stage(): issue the 16 MFMAs of block k+1 into `nxt` while the VALU epilogue of block k (in `cur`)
     // runs -- in ONE basic block, so the scheduler can interleave them: co-resident waves run in
     // lockstep (same barriers), only the overlap inside a wave keeps both pipes busy.
-    struct BlockMeta { float nb, tvc; int col; };
+    struct BlockMeta { float nb, tvc; int col; int cslot; };  // cslot: LDS slot of the block's 32 column partials
     auto load_bf = [&](const char* pb, int cb, h8 (&bf)[8]) {
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks)
@@ -288,9 +292,11 @@ __global__ __launch_bounds__(kPfThreads, 2) void approx_kernel(
             // this lane: min over its 32 rows; partner lane (l ^ 32): the other 32 rows of the wave
             const float mine = fminf(fminf(c[0], c[1]), fminf(c[2], c[3]));
             const float other = __shfl_xor(mine, 32);
-            const long long o = pd.cp_off + (long long)(item.a_blk * 4 + wave) * pd.n2pad + bm.col;
-            if (lhalf == 0) cp_s0[o] = fminf(mine, other);
-            if (lhalf == 0) cp_s1[o] = fmaxf(mine, other);
+            // (s0, s1) of this wave's 64 rows for column bm.col -> LDS (inline asm: see append_hits)
+            if (lhalf == 0) {
+                const float2 pr = make_float2(fminf(mine, other), fmaxf(mine, other));
+                asm volatile("ds_write_b64 %0, %1" ::"v"(colbuf_lds + (unsigned)(bm.cslot + lcol) * 8u), "v"(pr) : "memory");
+            }
         } else {
             const float hb = 0.5f * bm.nb, hv = 0.5f * bm.tvc;
 #pragma unroll
@@ -335,13 +341,28 @@ __global__ __launch_bounds__(kPfThreads, 2) void approx_kernel(
         }
     };
 
+    // pass 1: lane = column of tile tt; fold the four waves' (s0, s1) and store one partial per A block
+    auto merge_columns = [&](int tt) {
+        const unsigned base = colbuf_lds + (unsigned)((((tt - t_begin) % kPfRing) * 4) * 64 + lane) * 8u;
+        float2 w0, w1, w2, w3;
+        asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %4 offset:512\n\tds_read_b64 %2, %4 offset:1024\n\t"
+                     "ds_read_b64 %3, %4 offset:1536\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(w0), "=&v"(w1), "=&v"(w2), "=&v"(w3) : "v"(base) : "memory");
+        v2_merge(w0.x, w0.y, w1.x, w1.y);
+        v2_merge(w2.x, w2.y, w3.x, w3.y);
+        v2_merge(w0.x, w0.y, w2.x, w2.y);
+        const long long o = pd.cp_off + (long long)item.a_blk * pd.n2pad + tt * kPfBT + lane;
+        cp_s0[o] = w0.x;
+        cp_s1[o] = w0.y;
+    };
+
     // accB / metaB start as a harmless dummy block (|b|^2 = +inf, threshold = -inf: no minimum moves,
-    // no hit; its column-partial store is overwritten by the real block (t_begin, cb 1) later), so
+    // no hit; its column partial lands in an LDS slot that a real block rewrites before it is merged), so
     // that every iteration runs the same instruction sequence -- the counted waits rely on it
     f16v accA[2], accB[2];
 #pragma unroll
     for (int r = 0; r < 16; ++r) { accB[0][r] = 0.f; accB[1][r] = 0.f; }
-    BlockMeta metaA = {0.f, 0.f, 0}, metaB = {f_inf(), -f_inf(), t_begin * kPfBT + 32 + lcol};
+    BlockMeta metaA = {0.f, 0.f, 0, 0}, metaB = {f_inf(), -f_inf(), t_begin * kPfBT + 32 + lcol, (2 * 4 + wave) * 64 + 32};
 #pragma unroll 1
     for (int t = t_begin; t < t_end; ++t) {
         // Tile t must have landed.  Its DMA group is followed by exactly one younger group of LOADS
@@ -354,6 +375,8 @@ __global__ __launch_bounds__(kPfThreads, 2) void approx_kernel(
         __builtin_amdgcn_s_barrier();  // every wave's part of tile t is in LDS; slot of tile t-1 is free
         asm volatile("" ::: "memory");
         dma_tile(t + 2);
+        // tile t-2's column partials are complete in LDS (its last epilogue ran before this barrier)
+        if (PASS == 1 && t - t_begin >= 2 && wave == (t & 3)) merge_columns(t - 2);
         const int sl = (t - t_begin) % kPfRing;
         const char* pb = sB + sl * kPfLdsB + lcol * kHalfRowBytes;
         const float* aux = aux_w + sl * 2 * kPfAuxFloats;
@@ -363,6 +386,7 @@ __global__ __launch_bounds__(kPfThreads, 2) void approx_kernel(
         metaA.nb = aux[lcol];
         metaA.tvc = (PASS == 2) ? aux[kPfAuxFloats + lcol] : 0.f;
         metaA.col = t * kPfBT + lcol;
+        metaA.cslot = (sl * 4 + wave) * 64;
         unsigned mask = 0;
         mfma_block(bf, accA);
         mask = epilogue_valu(accB, metaB);
@@ -373,6 +397,7 @@ __global__ __launch_bounds__(kPfThreads, 2) void approx_kernel(
         metaB.nb = aux[32 + lcol];
         metaB.tvc = (PASS == 2) ? aux[kPfAuxFloats + 32 + lcol] : 0.f;
         metaB.col = t * kPfBT + 32 + lcol;
+        metaB.cslot = (sl * 4 + wave) * 64 + 32;
         mfma_block(bf, accB);
         mask = epilogue_valu(accA, metaA);
         interleave_hint();
@@ -383,6 +408,13 @@ __global__ __launch_bounds__(kPfThreads, 2) void approx_kernel(
         if (PASS == 2) append_hits(mask, metaB.col);
     }
     if (PASS == 2) flush_candidates();
+    if (PASS == 1) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // every wave's last column partials are in LDS
+        asm volatile("" ::: "memory");
+        if (wave == 0) merge_columns(t_end - 2);
+        if (wave == 1) merge_columns(t_end - 1);
+    }
 
     if (PASS == 1) {
         // rows: the two smallest of the 32 lanes' minima; one partial slot per B range
@@ -434,7 +466,7 @@ __global__ void pf_thresholds_kernel(const PairDesc* __restrict__ pairs, const P
     }
     if (e < pd.n2pad) {
         float s0 = f_inf(), s1 = f_inf();
-        for (int p = 0; p < pd.a_blocks256 * 4; ++p) {
+        for (int p = 0; p < pd.a_blocks256; ++p) {
             const long long o = pd.cp_off + (long long)p * pd.n2pad + e;
             v2_merge(s0, s1, cp_s0[o], cp_s1[o]);
         }
