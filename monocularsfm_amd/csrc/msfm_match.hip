@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <cmath>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -257,7 +258,7 @@ int upload_items(msfm_ctx* ctx, Batch& b) {
 
 // MFMA prefilter + exact re-check for the pairs on path 1.  On return pairs whose candidate list
 // overflowed have been moved to path 0.
-int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base) {
+int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
     const size_t P = b.pairs.size();
     assign_partials(b, 1, 8 * ctx->cu_count);
     b.cand_elems = 0;
@@ -307,7 +308,7 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base) {
     HIPCHK(ctx, hipGetLastError());
     const dim3 mgrid((unsigned)((b.max_npad + 255) / 256), (unsigned)P);
     hipLaunchKernelGGL(pf_thresholds_kernel, mgrid, dim3(256), 0, ctx->stream, dp, dpf, ctx->d_rp_s0.as<float>(),
-                       ctx->d_rp_s1.as<float>(), ctx->d_cp_s0.as<float>(), ctx->d_cp_s1.as<float>(), tuv, tuv);
+                       ctx->d_rp_s1.as<float>(), ctx->d_cp_s0.as<float>(), ctx->d_cp_s1.as<float>(), tuv, tuv, prune);
     HIPCHK(ctx, hipGetLastError());
     hipLaunchKernelGGL(approx_kernel<2>, grid, block, kPfLdsBytes, ctx->stream, dp, dpf, ctx->d_items.as<WorkItem>(),
                        (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (const float*)tuv, (const float*)tuv,
@@ -331,7 +332,7 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base) {
                        ctx->d_cand.as<int2>(), ctx->d_cand_s.as<float>(), ctx->d_best.as<unsigned long long>(),
                        ctx->d_second.as<unsigned long long>());
     HIPCHK(ctx, hipGetLastError());
-    hipLaunchKernelGGL(pf_finalize_kernel, mgrid, dim3(256), 0, ctx->stream, dp, dpf, ctx->d_best.as<unsigned long long>(),
+    hipLaunchKernelGGL(pf_finalize_kernel, mgrid, dim3(256), 0, ctx->stream, dp, dpf, (const float*)tuv, ctx->d_best.as<unsigned long long>(),
                        ctx->d_second.as<unsigned long long>(), ctx->d_k_i0.as<int>(), ctx->d_k_d0.as<float>(),
                        ctx->d_k_d1.as<float>(), ctx->d_fix_count.as<int>(), ctx->d_fix_list.as<int4>(), kFixCap);
     HIPCHK(ctx, hipGetLastError());
@@ -405,7 +406,7 @@ int run_exact(msfm_ctx* ctx, Batch& b, size_t ev_base) {
 
 // kNN-2 of both directions for every pair of the batch (device arrays left in the ctx buffers):
 // prefilter path where eligible, brute-force exact path for the rest, then the sqrt-space tie fix-up
-int run_knn(msfm_ctx* ctx, Batch& b, size_t ev_base, bool* exact_launched) {
+int run_knn(msfm_ctx* ctx, Batch& b, size_t ev_base, bool* exact_launched, PruneParams prune) {
     assign_common(b);
     const long long kn = std::max<long long>(1, b.kf_elems + b.kr_elems);
     HIPCHK(ctx, ctx->d_k_i0.ensure(kn * 4));
@@ -418,7 +419,7 @@ int run_knn(msfm_ctx* ctx, Batch& b, size_t ev_base, bool* exact_launched) {
     for (auto& pd : b.pairs) any_pf |= (pd.valid && pd.path == 1);
     int rc;
     if (any_pf) {
-        rc = run_prefilter(ctx, b, ev_base + 2);
+        rc = run_prefilter(ctx, b, ev_base + 2, prune);
         if (rc != MSFM_OK) return rc;
     }
     for (auto& pd : b.pairs) any_exact |= (pd.valid && pd.path == 0);
@@ -657,6 +658,11 @@ int msfm_match_pairs(msfm_ctx* ctx, const int32_t* pairs, int n_pairs, const msf
     if (n_pairs < 0 || (n_pairs > 0 && !pairs) || !out_offsets) return fail(ctx, MSFM_E_INVALID, "bad pair list");
     msfm_match_params prm = {0.8f, 1, 0.7};
     if (params) prm = *params;
+    // rows / columns that provably fail the ratio test or the distance cut need no exact neighbours
+    PruneParams prune = {1, prm.ratio, (float)prm.max_distance};
+    if ((double)prune.max_distance < prm.max_distance) prune.max_distance = nextafterf(prune.max_distance, __builtin_huge_valf());
+    if (!(prm.ratio > 0.f) || !(prm.ratio <= 1.f)) prune.ratio = 0.f;  // outside (0, 1]: no ratio-based pruning
+    if (!(prm.max_distance >= 0.0)) prune.max_distance = __builtin_huge_valf();  // NaN / negative: no distance-based pruning
     HIPCHK(ctx, hipSetDevice(ctx->device));
     ctx->have_results = false;
     ctx->res_offsets.assign((size_t)n_pairs + 1, 0);
@@ -696,7 +702,7 @@ int msfm_match_pairs(msfm_ctx* ctx, const int32_t* pairs, int n_pairs, const msf
         const size_t ev_base = ev_next;
         ev_next += 4;
         bool exact_launched = false;
-        int rc = run_knn(ctx, b, ev_base, &exact_launched);
+        int rc = run_knn(ctx, b, ev_base, &exact_launched, prune);
         if (rc != MSFM_OK) return rc;
 
         HIPCHK(ctx, ctx->d_st_qt.ensure(std::max<long long>(1, b.out_elems) * sizeof(int2)));
@@ -779,7 +785,7 @@ int msfm_knn2_pair(msfm_ctx* ctx, int id1, int id2, int32_t* fwd_idx0, float* fw
     b.pairs.push_back(pd);
     b.pf.push_back(pp);
     bool exact_launched = false;
-    rc = run_knn(ctx, b, 2, &exact_launched);
+    rc = run_knn(ctx, b, 2, &exact_launched, PruneParams{0, 0.f, 0.f});  // knnMatch twin: every row keeps its neighbours
     if (rc != MSFM_OK) return rc;
     rc = check_fix_overflow(ctx);
     if (rc != MSFM_OK) return rc;

@@ -443,11 +443,33 @@ __global__ __launch_bounds__(kPfThreads, 2) void approx_kernel(
 }
 
 // thresholds: fold the pass-1 partials; T = S~(2) + 2 eps, stored in u- / v-space.
+// With `prune` (match lists, not the knnMatch-level API) a row / column that PROVABLY cannot yield a match
+// gets T = -inf: pass 1 knows the exact minimum S~min of the row and an upper bound S~2ub of its second
+// smallest, so S0_exact >= S~min - eps and S1_exact <= S~2ub + eps; if sqrt(S0lb) >= ratio * sqrt(S1ub) the
+// Lowe test d0 < ratio * d1 fails whatever the exact values are, and if sqrt(S0lb) > max_distance the
+// distance cut removes it.  pf_finalize_kernel reports such rows as "no neighbour".
 // grid = (ceil(max_npad/256), n_pairs)
+struct PruneParams {
+    int prune;
+    float ratio;
+    float max_distance;  // rounded up to float
+};
+
+__device__ __forceinline__ bool pf_dead(float s0, float s1, float nrm, float eps, float other_max, PruneParams pr) {
+    if (!pr.prune) return false;
+    const float tiny = 1e-5f * (fabsf(s0) + fabsf(s1) + nrm + other_max);
+    const float s0lb = fmaxf((s0 + nrm) - eps - tiny, 0.f);
+    const float s1ub = (s1 + nrm) + eps + tiny;
+    const float d0lb = sqrtf(s0lb) * (1.f - 1e-6f);
+    const bool ratio_fails = pr.ratio > 0.f && d0lb >= pr.ratio * sqrtf(s1ub) * (1.f + 1e-5f);
+    const bool too_far = d0lb > pr.max_distance * (1.f + 1e-5f);
+    return ratio_fails || too_far;
+}
+
 __global__ void pf_thresholds_kernel(const PairDesc* __restrict__ pairs, const PfPair* __restrict__ pf,
                                      const float* __restrict__ rp_s0, const float* __restrict__ rp_s1,
                                      const float* __restrict__ cp_s0, const float* __restrict__ cp_s1,
-                                     float* __restrict__ tu, float* __restrict__ tv) {
+                                     float* __restrict__ tu, float* __restrict__ tv, PruneParams pr) {
     const PairDesc pd = pairs[blockIdx.y];
     const PfPair pp = pf[blockIdx.y];
     if (!pd.valid || !pp.use) return;
@@ -462,7 +484,8 @@ __global__ void pf_thresholds_kernel(const PairDesc* __restrict__ pairs, const P
         const float na = pp.a_nrm[e];
         const float eps = kEpsRel * (na + pp.b_nrm_max) + kEpsAbs * (sqrtf(na) + sqrtf(pp.b_nrm_max));
         const float slack = 2.f * eps + 1e-5f * (fabsf(s1) + na + pp.b_nrm_max);  // + roundings here and in pass 2's dot-space test
-        tu[pp.tu_off + e] = (e < pd.n1) ? s1 + slack : -f_inf();
+        const bool live = (e < pd.n1) && !pf_dead(s0, s1, na, eps, pp.b_nrm_max, pr);
+        tu[pp.tu_off + e] = live ? s1 + slack : -f_inf();
     }
     if (e < pd.n2pad) {
         float s0 = f_inf(), s1 = f_inf();
@@ -473,7 +496,8 @@ __global__ void pf_thresholds_kernel(const PairDesc* __restrict__ pairs, const P
         const float nb = pp.b_nrm[e];
         const float eps = kEpsRel * (nb + pp.a_nrm_max) + kEpsAbs * (sqrtf(nb) + sqrtf(pp.a_nrm_max));
         const float slack = 2.f * eps + 1e-5f * (fabsf(s1) + nb + pp.a_nrm_max);
-        tv[pp.tv_off + e] = (e < pd.n2) ? s1 + slack : -f_inf();
+        const bool live = (e < pd.n2) && !pf_dead(s0, s1, nb, eps, pp.a_nrm_max, pr);
+        tv[pp.tv_off + e] = live ? s1 + slack : -f_inf();
     }
 }
 
@@ -577,6 +601,7 @@ __global__ void pf_reduce_second_kernel(const PfPair* __restrict__ pf, const Pai
 }
 // finalize: the same outputs as merge_knn_kernel (idx0, d0, d1, tie queue)
 __global__ void pf_finalize_kernel(const PairDesc* __restrict__ pairs, const PfPair* __restrict__ pf,
+                                   const float* __restrict__ tuv,
                                    const unsigned long long* __restrict__ best, const unsigned long long* __restrict__ second,
                                    int* __restrict__ k_i0, float* __restrict__ k_d0, float* __restrict__ k_d1,
                                    int* __restrict__ fix_count, int4* __restrict__ fix_list, int fix_cap) {
@@ -588,7 +613,10 @@ __global__ void pf_finalize_kernel(const PairDesc* __restrict__ pairs, const PfP
         const int n = dir == 0 ? pd.n1 : pd.n2;
         if (e >= n) continue;
         const long long ko = (dir == 0 ? pd.kf_off : pd.kr_off) + e;
-        const unsigned long long b = best[ko], s = second[ko];
+        // a pruned row / column (threshold -inf) may still own stray candidates of the other direction:
+        // they are not its neighbour set, report "no neighbour"
+        const bool dead = tuv[ko] == -f_inf();
+        const unsigned long long b = dead ? ~0ull : best[ko], s = dead ? ~0ull : second[ko];
         int i0 = -1;
         float d0 = 3.402823466e+38f, d1 = 3.402823466e+38f;
         if (b != ~0ull) { i0 = (int)(unsigned)(b & 0xffffffffu); d0 = sqrtf(__uint_as_float((unsigned)(b >> 32))); }

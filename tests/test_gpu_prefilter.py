@@ -134,17 +134,39 @@ def test_random_gaussian_descriptors_signed(gpu_ctx, oracle):
     assert np.array_equal(fwd[0], oi0) and np.array_equal(b(fwd[1]), b(od0)) and np.array_equal(b(fwd[2]), b(od1))
 
 
+def test_pruning_keeps_match_lists_identical(gpu_ctx, oracle):
+    """match_pairs discards rows/columns that provably fail the ratio test or the distance cut before pass 2;
+    the match lists must not change, for any ratio / max_distance, and far fewer candidates are evaluated."""
+    imgs = synth.rootsift_images(3, [2500, 2300, 2100], seed=21, n_proto=5000)
+    for i, im in enumerate(imgs):
+        gpu_ctx.upload_image(i, im)
+    pairs = np.array([(1, 0), (2, 0), (2, 1), (0, 2)], np.int32)
+    for ratio, cc, md in [(0.8, True, 0.7), (0.6, True, 0.7), (0.95, False, 0.2), (1.0, True, float("inf")), (0.8, True, 0.05)]:
+        offs, qt, d = gpu_ctx.match_pairs(pairs, ratio, cc, md)
+        prof = gpu_ctx.profile()
+        gpu_ctx.set_prefilter(False)
+        try:
+            offs_b, qt_b, d_b = gpu_ctx.match_pairs(pairs, ratio, cc, md)
+        finally:
+            gpu_ctx.set_prefilter(True)
+        assert np.array_equal(offs, offs_b) and np.array_equal(qt, qt_b) and np.array_equal(b(d), b(d_b)), (ratio, cc, md)
+        oq, ot, od = oracle.match_pair(imgs[1], imgs[0], ratio, cc, md, nthreads=8)
+        assert np.array_equal(qt[offs[0]:offs[1], 0], oq) and np.array_equal(qt[offs[0]:offs[1], 1], ot)
+        if ratio <= 0.8:
+            assert prof["candidates"] < 1.0 * sum(len(imgs[i]) + len(imgs[j]) for i, j in pairs)
+
+
 def test_batch_mixes_paths(gpu_ctx, oracle):
     sizes = [700, 650, 300, 5, 900]
     imgs = synth.rootsift_images(len(sizes), sizes, seed=14, n_proto=1500)
     imgs[2] = (imgs[2] * F32(1e6)).astype(F32)            # unsafe for fp16 -> exact path
-    imgs.append(np.repeat(imgs[0][:1], 1800, axis=0))      # overflow -> fallback
+    imgs.append(np.repeat(imgs[0][:1], 1800, axis=0))      # all rows identical: every ratio test fails (rows are pruned)
     for i, im in enumerate(imgs):
         gpu_ctx.upload_image(i, im)
     pairs = np.array([(i, j) for i in range(len(imgs)) for j in range(i)], np.int32)
     offs, qt, d = gpu_ctx.match_pairs(pairs, 0.8, True, float("inf"))
     prof = gpu_ctx.profile()
-    assert prof["prefilter_pairs"] > 0 and prof["fallback_pairs"] > 0 and prof["dist_kernel_launches"] >= 1
+    assert prof["prefilter_pairs"] > 0 and prof["dist_kernel_launches"] >= 1   # image 2 forces the exact path
     for p, (i, j) in enumerate(pairs):
         oq, ot, od = oracle.match_pair(imgs[i], imgs[j], 0.8, True, np.inf, nthreads=4)
         s, e = offs[p], offs[p + 1]
