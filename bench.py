@@ -41,10 +41,10 @@ def pmc_traffic():
     path = os.path.join(ROOT, "profiles", "r01_pmc_traffic_approx.json")
     try:
         d = json.load(open(path))
-        per = [2.0 * k["FETCH_SIZE"]["per_launch_KB_mean"] * 1024 + k["WRITE_SIZE"]["per_launch_KB_mean"] * 1024
-               for k in d.values()]
-        return {"bytes_per_launch_mean": sum(per) / len(per), "source": "profiles/r01_pmc_traffic_approx.json",
-                "per_kernel_bytes": dict(zip(d.keys(), per))}
+        per = {n: 2.0 * k["FETCH_SIZE"]["per_launch_KB_mean"] * 1024 + k["WRITE_SIZE"]["per_launch_KB_mean"] * 1024
+               for n, k in d.items()}
+        return {"bytes_per_launch": per["approx_kernel<1>"], "source": "profiles/r01_pmc_traffic_approx.json",
+                "per_kernel_bytes": per}
     except (OSError, KeyError, ValueError):
         return None
 
@@ -170,6 +170,7 @@ def main():
 
     kern_ms, kern_launches, local_pairs_work = 0.0, 0, 0
     pf_ms, pf_launches, pf_pairs_work, exact_pairs_work, cand, rows_work, fallback = 0.0, 0, 0, 0, 0, 0, 0
+    s2_ms, s2_launches, s2_pairs_work, compacted = 0.0, 0, 0, 0
     algo_bytes_step = 0
     result = None
     for _ in range(args.warmup):
@@ -189,6 +190,10 @@ def main():
         exact_pairs_work += p["exact_descriptor_pairs"]
         cand += p["candidates"]
         fallback += p["fallback_pairs"]
+        s2_ms += p["sweep2_ms"]
+        s2_launches += p["sweep2_launches"]
+        s2_pairs_work += p["sweep2_descriptor_pairs"]
+        compacted += p["compacted_pairs"]
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -214,16 +219,23 @@ def main():
                    "parallelism": "pairs sharded over %d GPU(s), RCCL all-gather of match lists" % world},
     }
     if pf_launches > 0:
-        # dominant kernel of the default path: approx_kernel (MFMA fp16 32x32x16), two sweeps per batch
+        # dominant kernel of the default path: approx_kernel<1> (MFMA fp16 32x32x16), sweep 1: every descriptor
+        # pair of the batch once.  Sweep 2 only revisits the rows / columns the ratio and distance tests left alive.
         avg_ms = pf_ms / pf_launches
-        flops = 256.0 * 2.0 * pf_pairs_work   # GEMM form, 128 x (mul, add) per descriptor pair, two sweeps
+        flops = 256.0 * pf_pairs_work   # GEMM form: 128 x (mul, add) per descriptor pair
         achieved = flops / (pf_ms * 1e-3) / 1e12
+        tr = pmc_traffic()
         out["roofline"] = {
-            "kernel": "approx_kernel<1|2> (MFMA prefilter sweeps; exact fp32 re-check only on the candidates)",
+            "kernel": "approx_kernel<1> (MFMA prefilter sweep 1; sweep 2 and the exact fp32 re-check only touch survivors)",
             "bound": "mfma", "achieved": achieved, "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": achieved / PEAK_F16_MFMA_TFLOPS, "traffic": pmc_traffic(),
-            "avg_launch_ms": avg_ms, "launches": pf_launches, "flops_per_desc_pair_per_sweep": 256.0,
+            "frac": achieved / PEAK_F16_MFMA_TFLOPS,
+            "traffic": tr["bytes_per_launch"] if tr else None, "traffic_unit": "HBM bytes/launch (PMC)", "traffic_detail": tr,
+            "avg_launch_ms": avg_ms, "launches": pf_launches, "flops_per_desc_pair": 256.0,
             "descriptor_pairs_per_launch": pf_pairs_work / pf_launches,
+            "algorithmic_bytes_per_launch": algo_bytes_step * args.steps / pf_launches,
+            "sweep2": {"ms_per_step": s2_ms / args.steps, "launches": s2_launches, "compacted_image_pairs": compacted // max(1, args.steps),
+                       "work_fraction_of_sweep1": s2_pairs_work / max(1, pf_pairs_work)},
+            "sweep1_ms_per_step": pf_ms / args.steps,
             "candidates_per_row": cand / max(1.0, rows_work),
             "fallback_pairs": fallback,
             "hbm": {"algorithmic_bytes_per_step": algo_bytes_step,

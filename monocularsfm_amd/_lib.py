@@ -36,7 +36,9 @@ class Profile(C.Structure):
                 ("dist_algo_bytes", C.c_int64), ("approx_kernel_ms", C.c_double),
                 ("approx_kernel_launches", C.c_int), ("prefilter_pairs", C.c_int), ("fallback_pairs", C.c_int),
                 ("candidates", C.c_int64), ("prefilter_descriptor_pairs", C.c_int64),
-                ("exact_descriptor_pairs", C.c_int64), ("tie_rows", C.c_int64)]
+                ("exact_descriptor_pairs", C.c_int64), ("tie_rows", C.c_int64),
+                ("sweep2_ms", C.c_double), ("sweep2_launches", C.c_int), ("compacted_pairs", C.c_int),
+                ("sweep2_descriptor_pairs", C.c_int64)]
 
 
 class MsfmError(RuntimeError):

@@ -85,6 +85,7 @@ struct msfm_ctx {
     // prefilter path
     int prefilter = 1;
     DevBuf d_pf, d_tu, d_tv, d_cand, d_cand_s, d_cand_count, d_best, d_second, d_maxima;
+    DevBuf d_live_cnt, d_cmp_h, d_cmp_tu, d_live_idx, d_vpairs, d_vpf, d_vitems, d_jobs, d_lists;
 
     // results of the last msfm_match_pairs call
     bool have_results = false;
@@ -256,23 +257,29 @@ int upload_items(msfm_ctx* ctx, Batch& b) {
     return MSFM_OK;
 }
 
+// XCD interleave of a linear item list (see build_items)
+std::vector<WorkItem> interleave_items(const std::vector<WorkItem>& lin) {
+    const size_t n = lin.size();
+    const size_t per = (n + 7) / 8;
+    std::vector<WorkItem> out(per * 8, WorkItem{-1, 0, 0, 0, 0, {0, 0, 0}});
+    for (size_t k = 0; k < n; ++k) out[(k % per) * 8 + k / per] = lin[k];
+    return out;
+}
+
 // MFMA prefilter + exact re-check for the pairs on path 1.  On return pairs whose candidate list
 // overflowed have been moved to path 0.
+//   sweep 1 (approx_kernel<1>): S~ minima per row / column -> thresholds (with pruning for match lists)
+//   sweep 2: dense pairs re-sweep everything (approx_kernel<2>); pairs where pruning left few live rows
+//            and columns sweep only those, compacted per direction (approx_kernel<3>)
+//   exact pinned-order S of the candidates, 64-bit atomicMin reduce, finalize
 int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
     const size_t P = b.pairs.size();
     assign_partials(b, 1, 8 * ctx->cu_count);
-    b.cand_elems = 0;
     for (size_t p = 0; p < P; ++p) {
-        PairDesc& pd = b.pairs[p];
-        PfPair& pp = b.pf[p];
-        pp.tu_off = pd.kf_off;
-        pp.tv_off = pd.kr_off;  // same combined index space as the kNN arrays
-        pp.cand_off = b.cand_elems;
-        pp.cand_cap = 0;
-        if (pd.valid && pp.use) {
-            pp.cand_cap = 8 * (pd.n1 + pd.n2) + 1024;
-            b.cand_elems += pp.cand_cap;
-        }
+        b.pf[p].tu_off = b.pairs[p].kf_off;
+        b.pf[p].tv_off = b.pairs[p].kr_off;  // same combined index space as the kNN arrays
+        b.pf[p].cand_off = 0;
+        b.pf[p].cand_cap = 0;
     }
     build_items(b, 1);
     if (b.items.empty()) return MSFM_OK;
@@ -282,53 +289,193 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
     HIPCHK(ctx, ctx->d_cp_s0.ensure(std::max<long long>(1, b.cp_elems) * 4));
     HIPCHK(ctx, ctx->d_cp_s1.ensure(std::max<long long>(1, b.cp_elems) * 4));
     HIPCHK(ctx, ctx->d_tu.ensure(kn * 4));
-    HIPCHK(ctx, ctx->d_cand.ensure(std::max<long long>(1, b.cand_elems) * sizeof(int2)));
-    HIPCHK(ctx, ctx->d_cand_s.ensure(std::max<long long>(1, b.cand_elems) * 4));
-    HIPCHK(ctx, ctx->d_cand_count.ensure(P * 4));
     HIPCHK(ctx, ctx->d_best.ensure(kn * 8));
     HIPCHK(ctx, ctx->d_second.ensure(kn * 8));
+    HIPCHK(ctx, ctx->d_live_cnt.ensure(2 * P * 4));
     int rc = upload_pairs(ctx, b);
     if (rc != MSFM_OK) return rc;
     rc = upload_items(ctx, b);
     if (rc != MSFM_OK) return rc;
-    HIPCHK(ctx, hipMemsetAsync(ctx->d_cand_count.p, 0, P * 4, ctx->stream));
     HIPCHK(ctx, hipMemsetAsync(ctx->d_best.p, 0xff, kn * 8, ctx->stream));
     HIPCHK(ctx, hipMemsetAsync(ctx->d_second.p, 0xff, kn * 8, ctx->stream));
 
     hipEvent_t e0 = get_event(ctx, ev_base), e1 = get_event(ctx, ev_base + 1);
-    if (!e0 || !e1) return fail(ctx, MSFM_E_DEVICE, "hipEventCreate failed");
-    const dim3 grid((unsigned)b.items.size()), block(kPfThreads);
+    hipEvent_t e2 = get_event(ctx, ev_base + 2), e3 = get_event(ctx, ev_base + 3);
+    if (!e0 || !e1 || !e2 || !e3) return fail(ctx, MSFM_E_DEVICE, "hipEventCreate failed");
+    const dim3 block(kPfThreads);
     const PairDesc* dp = ctx->d_pairs.as<PairDesc>();
     const PfPair* dpf = ctx->d_pf.as<PfPair>();
     float* tuv = ctx->d_tu.as<float>();  // rows at kf offsets, columns at kr offsets (one buffer)
     HIPCHK(ctx, hipEventRecord(e0, ctx->stream));
-    hipLaunchKernelGGL(approx_kernel<1>, grid, block, kPfLdsBytes, ctx->stream, dp, dpf, ctx->d_items.as<WorkItem>(),
-                       ctx->d_rp_s0.as<float>(), ctx->d_rp_s1.as<float>(), ctx->d_cp_s0.as<float>(), ctx->d_cp_s1.as<float>(),
-                       (const float*)nullptr, (const float*)nullptr, (int2*)nullptr, (int*)nullptr);
+    hipLaunchKernelGGL(approx_kernel<1>, dim3((unsigned)b.items.size()), block, kPfLdsBytes, ctx->stream, dp, dpf,
+                       ctx->d_items.as<WorkItem>(), ctx->d_rp_s0.as<float>(), ctx->d_rp_s1.as<float>(),
+                       ctx->d_cp_s0.as<float>(), ctx->d_cp_s1.as<float>(), (const float*)nullptr, (const float*)nullptr,
+                       (int2*)nullptr, (int*)nullptr);
     HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipEventRecord(e1, ctx->stream));
+    ctx->prof.approx_kernel_launches += 1;
     const dim3 mgrid((unsigned)((b.max_npad + 255) / 256), (unsigned)P);
     hipLaunchKernelGGL(pf_thresholds_kernel, mgrid, dim3(256), 0, ctx->stream, dp, dpf, ctx->d_rp_s0.as<float>(),
                        ctx->d_rp_s1.as<float>(), ctx->d_cp_s0.as<float>(), ctx->d_cp_s1.as<float>(), tuv, tuv, prune);
     HIPCHK(ctx, hipGetLastError());
-    hipLaunchKernelGGL(approx_kernel<2>, grid, block, kPfLdsBytes, ctx->stream, dp, dpf, ctx->d_items.as<WorkItem>(),
-                       (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (const float*)tuv, (const float*)tuv,
-                       ctx->d_cand.as<int2>(), ctx->d_cand_count.as<int>());
-    HIPCHK(ctx, hipGetLastError());
-    HIPCHK(ctx, hipEventRecord(e1, ctx->stream));
-    ctx->prof.approx_kernel_launches += 2;
-    const dim3 cgrid(64, (unsigned)P);
+
+    // ---- which pairs are worth compacting: needs the live counts on the host -------------------
+    std::vector<int> live(2 * P, 0);
+    std::vector<char> compact(P, 0);
+    if (prune.prune) {
+        hipLaunchKernelGGL(pf_count_live_kernel, dim3((unsigned)(2 * P)), dim3(256), 0, ctx->stream, dp, dpf,
+                           (const float*)tuv, ctx->d_live_cnt.as<int>());
+        HIPCHK(ctx, hipGetLastError());
+        HIPCHK(ctx, hipMemcpyAsync(live.data(), ctx->d_live_cnt.p, 2 * P * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        for (size_t p = 0; p < P; ++p) {
+            const PairDesc& pd = b.pairs[p];
+            if (!pd.valid || !b.pf[p].use) continue;
+            // both compact sweeps together must be clearly cheaper than the one dense sweep
+            const long long dense_cost = (long long)pd.a_blocks256 * pd.b_tiles;
+            const long long cmp_cost = (long long)((live[2 * p] + 255) / 256) * pd.b_tiles +
+                                       (long long)((live[2 * p + 1] + 255) / 256) * pd.a_blocks;
+            compact[p] = (2 * cmp_cost <= dense_cost) ? 1 : 0;
+        }
+    }
+
+    // ---- sweep-2 descriptors -------------------------------------------------------------------
+    struct VSweep { int pair, dir, cnt; long long row; };
+    std::vector<VSweep> vs;
+    long long cmp_rows = 0, cand_elems = 0;
+    for (size_t p = 0; p < P; ++p) {
+        PairDesc& pd = b.pairs[p];
+        PfPair& pp = b.pf[p];
+        if (!pd.valid || !pp.use) continue;
+        if (!compact[p]) {
+            pp.cand_off = cand_elems;
+            pp.cand_cap = 8 * (pd.n1 + pd.n2) + 1024;
+            cand_elems += pp.cand_cap;
+            continue;
+        }
+        for (int dir = 0; dir < 2; ++dir) {
+            const int cnt = live[2 * p + dir];
+            if (cnt == 0) continue;
+            vs.push_back(VSweep{(int)p, dir, cnt, cmp_rows});
+            cmp_rows += (cnt + 255) / 256 * 256;
+        }
+    }
+    const size_t V = vs.size();
+    HIPCHK(ctx, ctx->d_cmp_h.ensure(std::max<long long>(1, cmp_rows) * kDim * 2));
+    HIPCHK(ctx, ctx->d_cmp_tu.ensure(std::max<long long>(1, cmp_rows) * 4));
+    HIPCHK(ctx, ctx->d_live_idx.ensure(std::max<long long>(1, cmp_rows) * 4));
+    std::vector<PairDesc> vpairs(V);
+    std::vector<PfPair> vpf(V);
+    std::vector<GatherJob> jobs(V);
+    std::vector<CandList> lists(P + V);
+    long long v_ablocks = 0;
+    for (size_t v = 0; v < V; ++v) v_ablocks += (vs[v].cnt + 255) / 256;
+    for (size_t p = 0; p < P; ++p) {
+        const PfPair& pp = b.pf[p];
+        lists[p] = CandList{(int)p, 0, pp.cand_off, (b.pairs[p].valid && pp.use && !compact[p]) ? pp.cand_cap : 0, 0, nullptr};
+    }
+    std::vector<WorkItem> vlin;
+    for (size_t v = 0; v < V; ++v) {
+        const VSweep& s = vs[v];
+        const PairDesc& pd = b.pairs[s.pair];
+        const PfPair& pp = b.pf[s.pair];
+        PairDesc& vd = vpairs[v];
+        PfPair& vp = vpf[v];
+        vd = PairDesc{};
+        vd.a_raw = s.dir ? pd.b_raw : pd.a_raw;
+        vd.b_raw = s.dir ? pd.a_raw : pd.b_raw;
+        vd.n1 = s.cnt;
+        vd.n2 = s.dir ? pd.n1 : pd.n2;
+        vd.a_blocks256 = (s.cnt + 255) / 256;
+        vd.b_tiles = s.dir ? pd.a_blocks : pd.b_tiles;
+        vd.n1pad = vd.a_blocks256 * 256;
+        vd.n2pad = s.dir ? pd.n1pad : pd.n2pad;
+        vd.valid = 1;
+        vd.path = 1;
+        vd.ranges = 1;
+        if (v_ablocks < 8LL * ctx->cu_count)
+            vd.ranges = (int)std::max<long long>(1, std::min<long long>((8LL * ctx->cu_count + v_ablocks - 1) / v_ablocks, vd.b_tiles));
+        vp = PfPair{};
+        vp.a_h = ctx->d_cmp_h.as<_Float16>() + (size_t)s.row * kDim;
+        vp.b_h = s.dir ? pp.a_h : pp.b_h;
+        vp.b_nrm = s.dir ? pp.a_nrm : pp.b_nrm;
+        vp.tu_off = s.row;
+        vp.cand_off = cand_elems;
+        vp.cand_cap = 8 * s.cnt + 1024;
+        vp.use = 1;
+        cand_elems += vp.cand_cap;
+        jobs[v] = GatherJob{s.dir ? pp.b_h : pp.a_h, s.dir ? pp.tv_off : pp.tu_off, s.row, s.dir ? pd.n2 : pd.n1, 0};
+        lists[P + v] = CandList{s.pair, 1 + s.dir, vp.cand_off, vp.cand_cap, 0, ctx->d_live_idx.as<int>() + s.row};
+        for (int r = 0; r < vd.ranges; ++r) {
+            const int t0 = (int)((long long)vd.b_tiles * r / vd.ranges), t1 = (int)((long long)vd.b_tiles * (r + 1) / vd.ranges);
+            for (int ab = 0; ab < vd.a_blocks256; ++ab) vlin.push_back(WorkItem{(int)v, ab, t0, t1, r, {0, 0, 0}});
+        }
+        ctx->prof.sweep2_descriptor_pairs += (int64_t)vd.n1pad * vd.n2;
+    }
+    // dense items: the sweep-1 list minus the compacted pairs
+    std::vector<WorkItem> dlin;
+    for (const WorkItem& w : b.items)
+        if (w.pair >= 0 && !compact[w.pair]) dlin.push_back(w);
+    for (size_t p = 0; p < P; ++p)
+        if (b.pairs[p].valid && b.pf[p].use && !compact[p]) ctx->prof.sweep2_descriptor_pairs += (int64_t)b.pairs[p].n1pad * b.pairs[p].n2;
+    const std::vector<WorkItem> ditems = dlin.empty() ? dlin : interleave_items(dlin);
+    const std::vector<WorkItem> vitems = vlin.empty() ? vlin : interleave_items(vlin);
+
+    HIPCHK(ctx, ctx->d_cand.ensure(std::max<long long>(1, cand_elems) * sizeof(int2)));
+    HIPCHK(ctx, ctx->d_cand_s.ensure(std::max<long long>(1, cand_elems) * 4));
+    HIPCHK(ctx, ctx->d_cand_count.ensure((P + V) * 4));
+    HIPCHK(ctx, ctx->d_lists.ensure((P + V) * sizeof(CandList)));
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_cand_count.p, 0, (P + V) * 4, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_lists.p, lists.data(), (P + V) * sizeof(CandList), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_pf.p, b.pf.data(), P * sizeof(PfPair), hipMemcpyHostToDevice, ctx->stream));  // cand_off / cap
+    if (!ditems.empty()) {
+        HIPCHK(ctx, hipMemcpyAsync(ctx->d_items.p, ditems.data(), ditems.size() * sizeof(WorkItem), hipMemcpyHostToDevice, ctx->stream));
+    }
+    if (V > 0) {
+        HIPCHK(ctx, ctx->d_vpairs.ensure(V * sizeof(PairDesc)));
+        HIPCHK(ctx, ctx->d_vpf.ensure(V * sizeof(PfPair)));
+        HIPCHK(ctx, ctx->d_jobs.ensure(V * sizeof(GatherJob)));
+        HIPCHK(ctx, ctx->d_vitems.ensure(vitems.size() * sizeof(WorkItem)));
+        HIPCHK(ctx, hipMemcpyAsync(ctx->d_vpairs.p, vpairs.data(), V * sizeof(PairDesc), hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(ctx->d_vpf.p, vpf.data(), V * sizeof(PfPair), hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(ctx->d_jobs.p, jobs.data(), V * sizeof(GatherJob), hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(ctx->d_vitems.p, vitems.data(), vitems.size() * sizeof(WorkItem), hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(pf_gather_live_kernel, dim3((unsigned)V), dim3(256), 0, ctx->stream, ctx->d_jobs.as<GatherJob>(),
+                           (const float*)tuv, ctx->d_live_idx.as<int>(), ctx->d_cmp_tu.as<float>(), ctx->d_cmp_h.as<_Float16>());
+        HIPCHK(ctx, hipGetLastError());
+    }
+    HIPCHK(ctx, hipEventRecord(e2, ctx->stream));
+    if (!ditems.empty()) {
+        hipLaunchKernelGGL(approx_kernel<2>, dim3((unsigned)ditems.size()), block, kPfLdsBytes, ctx->stream, dp, dpf,
+                           ctx->d_items.as<WorkItem>(), (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr,
+                           (const float*)tuv, (const float*)tuv, ctx->d_cand.as<int2>(), ctx->d_cand_count.as<int>());
+        HIPCHK(ctx, hipGetLastError());
+        ctx->prof.sweep2_launches += 1;
+    }
+    if (V > 0) {
+        hipLaunchKernelGGL(approx_kernel<3>, dim3((unsigned)vitems.size()), block, kPfLdsBytes, ctx->stream,
+                           ctx->d_vpairs.as<PairDesc>(), ctx->d_vpf.as<PfPair>(), ctx->d_vitems.as<WorkItem>(), (float*)nullptr,
+                           (float*)nullptr, (float*)nullptr, (float*)nullptr, ctx->d_cmp_tu.as<float>(), (const float*)nullptr,
+                           ctx->d_cand.as<int2>(), ctx->d_cand_count.as<int>() + P);
+        HIPCHK(ctx, hipGetLastError());
+        ctx->prof.sweep2_launches += 1;
+    }
+    HIPCHK(ctx, hipEventRecord(e3, ctx->stream));
+
+    const CandList* dl = ctx->d_lists.as<CandList>();
+    const dim3 cgrid(V > 0 ? 16 : 64, (unsigned)(P + V));
     if (ctx->order == MSFM_ORDER_SSE4X4)
-        hipLaunchKernelGGL(pf_exact_candidates_kernel<0>, cgrid, dim3(256), 0, ctx->stream, dp, dpf, ctx->d_cand_count.as<int>(),
+        hipLaunchKernelGGL(pf_exact_candidates_kernel<0>, cgrid, dim3(256), 0, ctx->stream, dp, dl, ctx->d_cand_count.as<int>(),
                            ctx->d_cand.as<int2>(), ctx->d_cand_s.as<float>());
     else
-        hipLaunchKernelGGL(pf_exact_candidates_kernel<1>, cgrid, dim3(256), 0, ctx->stream, dp, dpf, ctx->d_cand_count.as<int>(),
+        hipLaunchKernelGGL(pf_exact_candidates_kernel<1>, cgrid, dim3(256), 0, ctx->stream, dp, dl, ctx->d_cand_count.as<int>(),
                            ctx->d_cand.as<int2>(), ctx->d_cand_s.as<float>());
     HIPCHK(ctx, hipGetLastError());
-    const dim3 rgrid(16, (unsigned)P);
-    hipLaunchKernelGGL(pf_reduce_best_kernel, rgrid, dim3(256), 0, ctx->stream, dpf, dp, ctx->d_cand_count.as<int>(),
+    const dim3 rgrid(V > 0 ? 4 : 16, (unsigned)(P + V));
+    hipLaunchKernelGGL(pf_reduce_best_kernel, rgrid, dim3(256), 0, ctx->stream, dp, dl, ctx->d_cand_count.as<int>(),
                        ctx->d_cand.as<int2>(), ctx->d_cand_s.as<float>(), ctx->d_best.as<unsigned long long>());
     HIPCHK(ctx, hipGetLastError());
-    hipLaunchKernelGGL(pf_reduce_second_kernel, rgrid, dim3(256), 0, ctx->stream, dpf, dp, ctx->d_cand_count.as<int>(),
+    hipLaunchKernelGGL(pf_reduce_second_kernel, rgrid, dim3(256), 0, ctx->stream, dp, dl, ctx->d_cand_count.as<int>(),
                        ctx->d_cand.as<int2>(), ctx->d_cand_s.as<float>(), ctx->d_best.as<unsigned long long>(),
                        ctx->d_second.as<unsigned long long>());
     HIPCHK(ctx, hipGetLastError());
@@ -338,22 +485,32 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
     HIPCHK(ctx, hipGetLastError());
 
     // candidate-list overflow -> brute-force exact path for that pair
-    std::vector<int> counts(P);
-    HIPCHK(ctx, hipMemcpyAsync(counts.data(), ctx->d_cand_count.p, P * 4, hipMemcpyDeviceToHost, ctx->stream));
+    std::vector<int> counts(P + V);
+    HIPCHK(ctx, hipMemcpyAsync(counts.data(), ctx->d_cand_count.p, (P + V) * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     float ms = 0.f;
     HIPCHK(ctx, hipEventElapsedTime(&ms, e0, e1));
     ctx->prof.approx_kernel_ms += ms;
+    HIPCHK(ctx, hipEventElapsedTime(&ms, e2, e3));
+    ctx->prof.sweep2_ms += ms;
+    std::vector<char> overflow(P, 0);
+    std::vector<long long> ncand(P, 0);
+    for (size_t l = 0; l < P + V; ++l) {
+        if (lists[l].cap == 0) continue;
+        ncand[lists[l].pair] += counts[l];
+        if (counts[l] > lists[l].cap) overflow[lists[l].pair] = 1;
+    }
     for (size_t p = 0; p < P; ++p) {
         if (!b.pairs[p].valid || !b.pf[p].use) continue;
-        if (counts[p] > b.pf[p].cand_cap) {
+        if (overflow[p]) {
             b.pf[p].use = 0;
             b.pairs[p].path = 0;
             ctx->prof.fallback_pairs += 1;
         } else {
             ctx->prof.prefilter_pairs += 1;
-            ctx->prof.candidates += counts[p];
+            ctx->prof.candidates += ncand[p];
             ctx->prof.prefilter_descriptor_pairs += (int64_t)b.pairs[p].n1 * b.pairs[p].n2;
+            if (compact[p]) ctx->prof.compacted_pairs += 1;
         }
     }
     return MSFM_OK;
@@ -419,7 +576,7 @@ int run_knn(msfm_ctx* ctx, Batch& b, size_t ev_base, bool* exact_launched, Prune
     for (auto& pd : b.pairs) any_pf |= (pd.valid && pd.path == 1);
     int rc;
     if (any_pf) {
-        rc = run_prefilter(ctx, b, ev_base + 2, prune);
+        rc = run_prefilter(ctx, b, ev_base + 2, prune);  // events ev_base+2 .. ev_base+5
         if (rc != MSFM_OK) return rc;
     }
     for (auto& pd : b.pairs) any_exact |= (pd.valid && pd.path == 0);
@@ -516,7 +673,9 @@ int msfm_create(int device_ordinal, msfm_ctx** out_ctx) {
                                         hipFuncAttributeMaxDynamicSharedMemorySize, kPfLdsBytes);
     hipError_t e3 = hipFuncSetAttribute(reinterpret_cast<const void*>(approx_kernel<2>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, kPfLdsBytes);
-    if (e2 != hipSuccess || e3 != hipSuccess) {
+    hipError_t e4 = hipFuncSetAttribute(reinterpret_cast<const void*>(approx_kernel<3>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, kPfLdsBytes);
+    if (e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess) {
         std::fprintf(stderr, "msfm_create: cannot reserve %d bytes of LDS for the prefilter kernels\n", kPfLdsBytes);
         (void)hipStreamDestroy(ctx->stream);
         delete ctx;
@@ -536,7 +695,9 @@ void msfm_destroy(msfm_ctx* ctx) {
                       &ctx->d_cp_s0, &ctx->d_cp_i0, &ctx->d_cp_s1, &ctx->d_k_i0, &ctx->d_k_d0, &ctx->d_k_d1,
                       &ctx->d_st_qt, &ctx->d_st_d, &ctx->d_counts, &ctx->d_offsets, &ctx->d_out_qt,
                       &ctx->d_out_d, &ctx->d_fix_count, &ctx->d_fix_list, &ctx->d_pf, &ctx->d_tu, &ctx->d_tv,
-                      &ctx->d_cand, &ctx->d_cand_s, &ctx->d_cand_count, &ctx->d_best, &ctx->d_second, &ctx->d_maxima};
+                      &ctx->d_cand, &ctx->d_cand_s, &ctx->d_cand_count, &ctx->d_best, &ctx->d_second, &ctx->d_maxima,
+                      &ctx->d_live_cnt, &ctx->d_cmp_h, &ctx->d_cmp_tu, &ctx->d_live_idx, &ctx->d_vpairs, &ctx->d_vpf,
+                      &ctx->d_vitems, &ctx->d_jobs, &ctx->d_lists};
     for (DevBuf* b : bufs) b->release();
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(ctx->stream);
@@ -700,7 +861,7 @@ int msfm_match_pairs(msfm_ctx* ctx, const int32_t* pairs, int n_pairs, const msf
         }
         const size_t P = b.pairs.size();
         const size_t ev_base = ev_next;
-        ev_next += 4;
+        ev_next += 6;
         bool exact_launched = false;
         int rc = run_knn(ctx, b, ev_base, &exact_launched, prune);
         if (rc != MSFM_OK) return rc;

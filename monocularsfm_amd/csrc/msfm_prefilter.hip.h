@@ -182,11 +182,11 @@ __global__ __launch_bounds__(kPfThreads, 2) void approx_kernel(
                                              (__attribute__((address_space(3))) void*)(l + k * 1024), 16, 0, 0);
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pp.b_nrm + tc * kPfBT + lane),
                                          (__attribute__((address_space(3))) void*)(aux_w + sl * 2 * kPfAuxFloats), 4, 0, 0);
-        if (PASS == 2)
+        if (PASS == 2)  // PASS 3 (compacted live rows) has no column criterion
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(tv + pp.tv_off + tc * kPfBT + lane),
                                              (__attribute__((address_space(3))) void*)(aux_w + sl * 2 * kPfAuxFloats + kPfAuxFloats), 4, 0, 0);
     };
-    constexpr int kDmaOps = (PASS == 1) ? 5 : 6;
+    constexpr int kDmaOps = (PASS == 2) ? 6 : 5;
 
     dma_tile(t_begin);
     dma_tile(t_begin + 1);
@@ -211,8 +211,10 @@ __global__ __launch_bounds__(kPfThreads, 2) void approx_kernel(
     float rs0[2][16];
     {
         const int row = item.a_blk * 256 + wave * 64 + lane;
-        const float nrm = row < pd.n1 ? g_anrm[row] : f_inf();  // padding rows: +inf norm, never selected
-        na_w[lane] = (PASS == 1) ? nrm : 0.5f * nrm;
+        if (PASS != 3) {
+            const float nrm = row < pd.n1 ? g_anrm[row] : f_inf();  // padding rows: +inf norm, never selected
+            na_w[lane] = (PASS == 1) ? nrm : 0.5f * nrm;
+        }
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
@@ -303,11 +305,19 @@ __global__ __launch_bounds__(kPfThreads, 2) void approx_kernel(
             for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
                 for (int q4 = 0; q4 < 4; ++q4) {
-                    const v4f hav = *reinterpret_cast<const v4f*>(na_w + rb * 32 + 8 * q4 + 4 * lhalf);
+                    if (PASS == 2) {
+                        const v4f hav = *reinterpret_cast<const v4f*>(na_w + rb * 32 + 8 * q4 + 4 * lhalf);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const float th = fminf(hb - rs0[rb][4 * q4 + j], hav[j] - hv);
-                        mask = mask + mask + ((acc[rb][4 * q4 + j] >= th) ? 1u : 0u);
+                        for (int j = 0; j < 4; ++j) {
+                            const float th = fminf(hb - rs0[rb][4 * q4 + j], hav[j] - hv);
+                            mask = mask + mask + ((acc[rb][4 * q4 + j] >= th) ? 1u : 0u);
+                        }
+                    } else {  // PASS 3: row criterion only (same arithmetic as the row half of PASS 2)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float th = hb - rs0[rb][4 * q4 + j];
+                            mask = mask + mask + ((acc[rb][4 * q4 + j] >= th) ? 1u : 0u);
+                        }
                     }
                 }
         }
@@ -336,7 +346,7 @@ __global__ __launch_bounds__(kPfThreads, 2) void approx_kernel(
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                     // 1 MFMA
-            __builtin_amdgcn_sched_group_barrier(0x002, PASS == 1 ? 8 : 11, 0);    // VALU
+            __builtin_amdgcn_sched_group_barrier(0x002, PASS == 1 ? 8 : (PASS == 2 ? 11 : 6), 0);    // VALU
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                     // 1 DS read
         }
     };
@@ -391,7 +401,7 @@ __global__ __launch_bounds__(kPfThreads, 2) void approx_kernel(
         mfma_block(bf, accA);
         mask = epilogue_valu(accB, metaB);
         interleave_hint();
-        if (PASS == 2) append_hits(mask, metaB.col);
+        if (PASS >= 2) append_hits(mask, metaB.col);
         // stage 2: MFMA (t, cb 1) -> accB   ||   epilogue of (t, cb 0) in accA
         load_bf(pb, 1, bf);
         metaB.nb = aux[32 + lcol];
@@ -401,13 +411,13 @@ __global__ __launch_bounds__(kPfThreads, 2) void approx_kernel(
         mfma_block(bf, accB);
         mask = epilogue_valu(accA, metaA);
         interleave_hint();
-        if (PASS == 2) append_hits(mask, metaA.col);
+        if (PASS >= 2) append_hits(mask, metaA.col);
     }
     {   // drain: epilogue of the last block
         const unsigned mask = epilogue_valu(accB, metaB);
-        if (PASS == 2) append_hits(mask, metaB.col);
+        if (PASS >= 2) append_hits(mask, metaB.col);
     }
-    if (PASS == 2) flush_candidates();
+    if (PASS >= 2) flush_candidates();
     if (PASS == 1) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();  // every wave's last column partials are in LDS
@@ -501,21 +511,35 @@ __global__ void pf_thresholds_kernel(const PairDesc* __restrict__ pairs, const P
     }
 }
 
+// A candidate list: the (q, t) records one sweep produced for one pair.  mode 0: records are real
+// (q, t); mode 1: (k, t) with q = live_idx[k] (compacted live rows of image 1 against image 2);
+// mode 2: (k, q) with t = live_idx[k] (compacted live rows of image 2 against image 1).
+struct CandList {
+    int pair;
+    int mode;
+    long long off;
+    int cap;  // 0: unused list
+    int pad;
+    const int* live_idx;
+};
+
 // exact pinned-order S for every candidate: 16 lanes per candidate (SSE order: lane L owns the
 // lane partial k = L mod 16; AVX2 order: 32 partials -> 2 per lane), coalesced 64-B row reads.
+// Records are rewritten in place as real (q, t).   grid = (x, n_lists)
 template <int ORDER>
-__global__ void pf_exact_candidates_kernel(const PairDesc* __restrict__ pairs, const PfPair* __restrict__ pf,
-                                           const int* __restrict__ cand_count, const int2* __restrict__ cand,
+__global__ void pf_exact_candidates_kernel(const PairDesc* __restrict__ pairs, const CandList* __restrict__ lists,
+                                           const int* __restrict__ cand_count, int2* __restrict__ cand,
                                            float* __restrict__ cand_s) {
-    const int pair = blockIdx.y;
-    const PfPair pp = pf[pair];
-    if (!pp.use) return;
-    const PairDesc pd = pairs[pair];
-    const int n = min(cand_count[pair], pp.cand_cap);
+    const CandList L = lists[blockIdx.y];
+    if (L.cap == 0) return;
+    const PairDesc pd = pairs[L.pair];
+    const int n = min(cand_count[blockIdx.y], L.cap);
     const int sub = threadIdx.x & 15;
     for (int c = (blockIdx.x * blockDim.x + threadIdx.x) >> 4; c < ((n + 3) & ~3); c += (gridDim.x * blockDim.x) >> 4) {
         const bool live = c < n;
-        const int2 qt = live ? cand[pp.cand_off + c] : make_int2(0, 0);
+        int2 qt = live ? cand[L.off + c] : make_int2(0, 0);
+        if (live && L.mode == 1) qt.x = L.live_idx[qt.x];
+        if (live && L.mode == 2) qt = make_int2(qt.y, L.live_idx[qt.x]);
         const float* a = pd.a_raw + (size_t)qt.x * kDim;
         const float* b = pd.b_raw + (size_t)qt.y * kDim;
         float res;
@@ -555,7 +579,10 @@ __global__ void pf_exact_candidates_kernel(const PairDesc* __restrict__ pairs, c
             for (int k = 0; k < 8; ++k) sv[k] = __shfl(s, base | k, 64);
             res = ((sv[0] + sv[1]) + (sv[2] + sv[3])) + ((sv[4] + sv[5]) + (sv[6] + sv[7]));
         }
-        if (live && sub == 0) cand_s[pp.cand_off + c] = res;
+        if (live && sub == 0) {
+            cand[L.off + c] = qt;
+            cand_s[L.off + c] = res;
+        }
     }
 }
 
@@ -563,42 +590,115 @@ __device__ __forceinline__ unsigned long long pf_key(float s, int idx) {
     return ((unsigned long long)__float_as_uint(s) << 32) | (unsigned)idx;  // s >= 0: uint order == float order
 }
 
-// reduce phase A: best (S, idx) per row and per column among the candidates (64-bit atomicMin)
-__global__ void pf_reduce_best_kernel(const PfPair* __restrict__ pf, const PairDesc* __restrict__ pairs,
+// reduce phase A: best (S, idx) per row and per column among the candidates (64-bit atomicMin).
+// A mode-1 list only serves the row direction, a mode-2 list only the column direction: the live
+// rows of the OTHER direction get their complete candidate sets from their own list.
+__global__ void pf_reduce_best_kernel(const PairDesc* __restrict__ pairs, const CandList* __restrict__ lists,
                                       const int* __restrict__ cand_count, const int2* __restrict__ cand,
                                       const float* __restrict__ cand_s, unsigned long long* __restrict__ best) {
-    const int pair = blockIdx.y;
-    const PfPair pp = pf[pair];
-    if (!pp.use) return;
-    const PairDesc pd = pairs[pair];
-    const int n = min(cand_count[pair], pp.cand_cap);
+    const CandList L = lists[blockIdx.y];
+    if (L.cap == 0) return;
+    const PairDesc pd = pairs[L.pair];
+    const int n = min(cand_count[blockIdx.y], L.cap);
     for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < n; c += gridDim.x * blockDim.x) {
-        const int2 qt = cand[pp.cand_off + c];
-        const float s = cand_s[pp.cand_off + c];
+        const int2 qt = cand[L.off + c];
+        const float s = cand_s[L.off + c];
         if (!(s < f_inf())) continue;  // batchDistance never inserts a distance >= FLT_MAX
-        atomicMin(&best[pd.kf_off + qt.x], pf_key(s, qt.y));
-        atomicMin(&best[pd.kr_off + qt.y], pf_key(s, qt.x));
+        if (L.mode != 2) atomicMin(&best[pd.kf_off + qt.x], pf_key(s, qt.y));
+        if (L.mode != 1) atomicMin(&best[pd.kr_off + qt.y], pf_key(s, qt.x));
     }
 }
 // reduce phase B: second best = min over the candidates that are not the best one
-__global__ void pf_reduce_second_kernel(const PfPair* __restrict__ pf, const PairDesc* __restrict__ pairs,
+__global__ void pf_reduce_second_kernel(const PairDesc* __restrict__ pairs, const CandList* __restrict__ lists,
                                         const int* __restrict__ cand_count, const int2* __restrict__ cand,
                                         const float* __restrict__ cand_s, const unsigned long long* __restrict__ best,
                                         unsigned long long* __restrict__ second) {
-    const int pair = blockIdx.y;
-    const PfPair pp = pf[pair];
-    if (!pp.use) return;
-    const PairDesc pd = pairs[pair];
-    const int n = min(cand_count[pair], pp.cand_cap);
+    const CandList L = lists[blockIdx.y];
+    if (L.cap == 0) return;
+    const PairDesc pd = pairs[L.pair];
+    const int n = min(cand_count[blockIdx.y], L.cap);
     for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < n; c += gridDim.x * blockDim.x) {
-        const int2 qt = cand[pp.cand_off + c];
-        const float s = cand_s[pp.cand_off + c];
+        const int2 qt = cand[L.off + c];
+        const float s = cand_s[L.off + c];
         if (!(s < f_inf())) continue;
         const unsigned long long kf = pf_key(s, qt.y), kr = pf_key(s, qt.x);
-        if (kf != best[pd.kf_off + qt.x]) atomicMin(&second[pd.kf_off + qt.x], kf);
-        if (kr != best[pd.kr_off + qt.y]) atomicMin(&second[pd.kr_off + qt.y], kr);
+        if (L.mode != 2 && kf != best[pd.kf_off + qt.x]) atomicMin(&second[pd.kf_off + qt.x], kf);
+        if (L.mode != 1 && kr != best[pd.kr_off + qt.y]) atomicMin(&second[pd.kr_off + qt.y], kr);
     }
 }
+
+// live rows (threshold > -inf) per (pair, direction); grid = 2 * n_pairs blocks of 256
+__global__ void pf_count_live_kernel(const PairDesc* __restrict__ pairs, const PfPair* __restrict__ pf,
+                                     const float* __restrict__ tuv, int* __restrict__ live_cnt) {
+    const int p = blockIdx.x >> 1, dir = blockIdx.x & 1;
+    const PairDesc pd = pairs[p];
+    const PfPair pp = pf[p];
+    __shared__ int total;
+    if (threadIdx.x == 0) total = 0;
+    __syncthreads();
+    if (pd.valid && pp.use) {
+        const int n = dir ? pd.n2 : pd.n1;
+        const long long off = dir ? pp.tv_off : pp.tu_off;
+        int c = 0;
+        for (int e = threadIdx.x; e < n; e += blockDim.x) c += (tuv[off + e] != -f_inf()) ? 1 : 0;
+        for (int m = 32; m >= 1; m >>= 1) c += __shfl_xor(c, m);
+        if ((threadIdx.x & 63) == 0) atomicAdd(&total, c);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) live_cnt[blockIdx.x] = total;
+}
+
+// compaction of the live rows of one (pair, direction): indices, thresholds and the fp16 rows
+// (re-swizzled for their new row number).   grid = n_jobs blocks of 256
+struct GatherJob {
+    const _Float16* src_h;   // image's fp16 blocks
+    long long src_thr_off;   // into tuv
+    long long dst_row;       // first row of this job in the compact arrays (multiple of 256)
+    int n;                   // rows of the image
+    int pad;
+};
+__global__ void pf_gather_live_kernel(const GatherJob* __restrict__ jobs, const float* __restrict__ tuv,
+                                      int* __restrict__ live_idx, float* __restrict__ cmp_tu, _Float16* __restrict__ cmp_h) {
+    const GatherJob J = jobs[blockIdx.x];
+    __shared__ int wsum[4];
+    __shared__ int running;
+    if (threadIdx.x == 0) running = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int e0 = 0; e0 < J.n; e0 += 256) {
+        const int e = e0 + threadIdx.x;
+        const float t = e < J.n ? tuv[J.src_thr_off + e] : -f_inf();
+        const bool live = t != -f_inf();
+        const unsigned long long bal = __ballot(live);
+        if (lane == 0) wsum[wave] = __popcll(bal);
+        __syncthreads();
+        int k = running + __popcll(bal & ((1ull << lane) - 1ull));
+        for (int w = 0; w < wave; ++w) k += wsum[w];
+        if (live) {
+            live_idx[J.dst_row + k] = e;
+            cmp_tu[J.dst_row + k] = t;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) running += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        __syncthreads();
+    }
+    const int cnt = running;
+    // fp16 rows: 16 threads per row, one 16-byte granule each; granule g of row r lives at g ^ (r & 15)
+    for (int k = threadIdx.x >> 4; k < cnt; k += 16) {
+        const int r = live_idx[J.dst_row + k];
+        const int g = threadIdx.x & 15;
+        const h8 v = *reinterpret_cast<const h8*>(J.src_h + ((size_t)r * 16 + (g ^ (r & 15))) * 8);
+        *reinterpret_cast<h8*>(cmp_h + ((size_t)(J.dst_row + k) * 16 + (g ^ (k & 15))) * 8) = v;
+    }
+    // rows up to the next multiple of 256 are swept too: zero them (their threshold is -inf, but an
+    // fp16 inf from stale memory would still compare >= +inf)
+    h8 z;
+    for (int j = 0; j < 8; ++j) z[j] = (_Float16)0.f;
+    const int cpad = (cnt + 255) & ~255;
+    for (int k = cnt + (threadIdx.x >> 4); k < cpad; k += 16)
+        *reinterpret_cast<h8*>(cmp_h + ((size_t)(J.dst_row + k) * 16 + (threadIdx.x & 15)) * 8) = z;
+}
+
 // finalize: the same outputs as merge_knn_kernel (idx0, d0, d1, tie queue)
 __global__ void pf_finalize_kernel(const PairDesc* __restrict__ pairs, const PfPair* __restrict__ pf,
                                    const float* __restrict__ tuv,

@@ -154,6 +154,35 @@ def test_pruning_keeps_match_lists_identical(gpu_ctx, oracle):
         assert np.array_equal(qt[offs[0]:offs[1], 0], oq) and np.array_equal(qt[offs[0]:offs[1], 1], ot)
         if ratio <= 0.8:
             assert prof["candidates"] < 1.0 * sum(len(imgs[i]) + len(imgs[j]) for i, j in pairs)
+            assert prof["compacted_pairs"] == len(pairs)   # sweep 2 ran on the compacted live rows only
+            assert prof["sweep2_descriptor_pairs"] < 0.5 * prof["prefilter_descriptor_pairs"]
+        if ratio >= 1.0:
+            assert prof["compacted_pairs"] == 0             # nothing to prune: dense sweep 2
+
+
+def test_compacted_and_dense_pairs_in_one_batch(gpu_ctx, oracle):
+    """One batch with a pair of near-duplicate images (almost every row stays alive -> dense sweep 2), pairs of
+    unrelated images (few live rows -> compacted sweep 2, both directions), a pair with no live row at all and
+    tiny images; every list must equal the oracle's."""
+    base = synth.rootsift_images(4, [1800, 1700, 1500, 40], seed=33, n_proto=4000)
+    rng = np.random.default_rng(5)
+    twin = base[0] + rng.normal(0, 2e-3, base[0].shape).astype(F32)    # same scene, small noise: ~all rows match
+    far = np.abs(rng.normal(0, 1, (900, 128))).astype(F32)
+    far /= np.linalg.norm(far, axis=1, keepdims=True).astype(F32)       # unrelated to everything: nothing within 0.7?
+    imgs = base + [twin.astype(F32), far.astype(F32)]
+    for i, im in enumerate(imgs):
+        gpu_ctx.upload_image(i, im)
+    pairs = np.array([(4, 0), (1, 0), (2, 1), (5, 0), (3, 0), (0, 3), (5, 4), (2, 0)], np.int32)
+    for ratio, cc, md in [(0.8, True, 0.7), (0.9, False, 0.3)]:
+        offs, qt, d = gpu_ctx.match_pairs(pairs, ratio, cc, md)
+        prof = gpu_ctx.profile()
+        assert 0 < prof["compacted_pairs"] < len(pairs), prof
+        assert prof["fallback_pairs"] == 0
+        for p, (i, j) in enumerate(pairs):
+            oq, ot, od = oracle.match_pair(imgs[i], imgs[j], ratio, cc, md, nthreads=8)
+            s, e = offs[p], offs[p + 1]
+            assert np.array_equal(qt[s:e, 0], oq) and np.array_equal(qt[s:e, 1], ot) and np.array_equal(b(d[s:e]), b(od)), (i, j, ratio)
+        assert offs[1] - offs[0] > 1000   # the twin pair really matches almost everywhere
 
 
 def test_batch_mixes_paths(gpu_ctx, oracle):

@@ -41,8 +41,9 @@ for order in orders:
         else:
             same = eq(offs, ref[0]) and eq(qt, ref[1]) and eq(d, ref[2])
             ok_all &= same
-            print("order %d prefilter: approx kernels %.2f ms (%.3e desc-pairs/s per 2 passes, %.0f TFLOP/s f16)  wall %.3f s  (%.3e desc-pairs/s)  cand/row %.2f  fallback %d  identical %s" % (
-                order, prof["approx_kernel_ms"], prof["prefilter_descriptor_pairs"] / max(prof["approx_kernel_ms"], 1e-9) * 1e3,
-                2 * 256 * prof["prefilter_descriptor_pairs"] / max(prof["approx_kernel_ms"], 1e-9) * 1e3 / 1e12, dt,
+            print("order %d prefilter: sweep1 %.2f ms (%.0f TFLOP/s f16)  sweep2 %.2f ms (%d compacted pairs, %.3f of the dense work)  wall %.3f s  (%.3e desc-pairs/s)  cand/row %.2f  fallback %d  identical %s" % (
+                order, prof["approx_kernel_ms"],
+                256 * prof["prefilter_descriptor_pairs"] / max(prof["approx_kernel_ms"], 1e-9) * 1e3 / 1e12,
+                prof["sweep2_ms"], prof["compacted_pairs"], prof["sweep2_descriptor_pairs"] / max(1, prof["prefilter_descriptor_pairs"]), dt,
                 prof["descriptor_pairs"] / dt, prof["candidates"] / (2 * N * (N - 1) / 2 * n), prof["fallback_pairs"], same))
 print("ALL OK" if ok_all else "FAILURES")
