@@ -52,6 +52,8 @@ struct Image {
     // prefilter operands: fp16 swizzled blocks, row norms (+inf padded), maxima
     _Float16* h16 = nullptr;
     float* nrm = nullptr;
+    _Float16* ext = nullptr;  // norm quadruples for the ninth MFMA k-step
+    float c = 1.f;            // their scale (power of two)
     float nrm_max = 0.f, abs_max = 0.f;
     bool pf_safe = false;
 };
@@ -61,6 +63,7 @@ void free_image(Image& im) {
     if (im.raw) (void)hipFree(im.raw);
     if (im.h16) (void)hipFree(im.h16);
     if (im.nrm) (void)hipFree(im.nrm);
+    if (im.ext) (void)hipFree(im.ext);
     im = Image{};
 }
 
@@ -113,6 +116,18 @@ int fail(msfm_ctx* ctx, int code, const std::string& msg) {
     } while (0)
 
 constexpr int kFixCap = 1 << 16;
+
+// MSFM_DEBUG_SYNC=1: synchronise after every launch of the prefilter path and name it on stderr
+// (a faulting kernel is then the one named last)
+#define DBGSYNC(ctx, name)                                                        \
+    do {                                                                          \
+        static const bool on__ = std::getenv("MSFM_DEBUG_SYNC") != nullptr;       \
+        if (on__) {                                                               \
+            std::fprintf(stderr, "[msfm] %s ...", name);                          \
+            hipError_t e__ = hipStreamSynchronize((ctx)->stream);                 \
+            std::fprintf(stderr, " %s\n", hipGetErrorString(e__));                \
+        }                                                                         \
+    } while (0)
 
 struct Batch {
     std::vector<PairDesc> pairs;
@@ -184,8 +199,14 @@ int fill_pair(msfm_ctx* ctx, int id1, int id2, PairDesc& pd, PfPair& pp) {
     pp.b_nrm = b.nrm;
     pp.a_nrm_max = a.nrm_max;
     pp.b_nrm_max = b.nrm_max;
-    // the MFMA prefilter needs fp16-representable magnitudes on both sides; tiny pairs are not worth it
-    pp.use = (ctx->prefilter && pd.valid && a.pf_safe && b.pf_safe) ? 1 : 0;
+    pp.a_ext = a.ext;
+    pp.b_ext = b.ext;
+    pp.a_c = a.c;
+    pp.b_c = b.c;
+    // the MFMA prefilter needs fp16-representable magnitudes on both sides, and norms of comparable scale
+    // (one image's norms are expressed in units of the other's c)
+    const bool scales_ok = a.nrm_max <= 8.f * b.nrm_max && b.nrm_max <= 8.f * a.nrm_max;
+    pp.use = (ctx->prefilter && pd.valid && a.pf_safe && b.pf_safe && scales_ok) ? 1 : 0;
     pd.path = pp.use;
     return MSFM_OK;
 }
@@ -312,12 +333,14 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
                        ctx->d_cp_s0.as<float>(), ctx->d_cp_s1.as<float>(), (const float*)nullptr, (const float*)nullptr,
                        (int2*)nullptr, (int*)nullptr);
     HIPCHK(ctx, hipGetLastError());
+    DBGSYNC(ctx, "approx_kernel<1>");
     HIPCHK(ctx, hipEventRecord(e1, ctx->stream));
     ctx->prof.approx_kernel_launches += 1;
     const dim3 mgrid((unsigned)((b.max_npad + 255) / 256), (unsigned)P);
     hipLaunchKernelGGL(pf_thresholds_kernel, mgrid, dim3(256), 0, ctx->stream, dp, dpf, ctx->d_rp_s0.as<float>(),
                        ctx->d_rp_s1.as<float>(), ctx->d_cp_s0.as<float>(), ctx->d_cp_s1.as<float>(), tuv, tuv, prune);
     HIPCHK(ctx, hipGetLastError());
+    DBGSYNC(ctx, "pf_thresholds_kernel");
 
     // ---- which pairs are worth compacting: needs the live counts on the host -------------------
     std::vector<int> live(2 * P, 0);
@@ -326,6 +349,7 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
         hipLaunchKernelGGL(pf_count_live_kernel, dim3((unsigned)(2 * P)), dim3(256), 0, ctx->stream, dp, dpf,
                            (const float*)tuv, ctx->d_live_cnt.as<int>());
         HIPCHK(ctx, hipGetLastError());
+    DBGSYNC(ctx, "pf_count_live_kernel");
         HIPCHK(ctx, hipMemcpyAsync(live.data(), ctx->d_live_cnt.p, 2 * P * 4, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         for (size_t p = 0; p < P; ++p) {
@@ -399,12 +423,16 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
         vp.a_h = ctx->d_cmp_h.as<_Float16>() + (size_t)s.row * kDim;
         vp.b_h = s.dir ? pp.a_h : pp.b_h;
         vp.b_nrm = s.dir ? pp.a_nrm : pp.b_nrm;
+        vp.b_ext = s.dir ? pp.a_ext : pp.b_ext;
+        vp.b_c = s.dir ? pp.a_c : pp.b_c;
+        vp.a_c = s.dir ? pp.b_c : pp.a_c;
         vp.tu_off = s.row;
         vp.cand_off = cand_elems;
         vp.cand_cap = 8 * s.cnt + 1024;
         vp.use = 1;
         cand_elems += vp.cand_cap;
-        jobs[v] = GatherJob{s.dir ? pp.b_h : pp.a_h, s.dir ? pp.tv_off : pp.tu_off, s.row, s.dir ? pd.n2 : pd.n1, 0};
+        jobs[v] = GatherJob{s.dir ? pp.b_h : pp.a_h, s.dir ? pp.b_nrm : pp.a_nrm, s.dir ? pp.tv_off : pp.tu_off, s.row,
+                            s.dir ? pd.n2 : pd.n1, 0};
         lists[P + v] = CandList{s.pair, 1 + s.dir, vp.cand_off, vp.cand_cap, 0, ctx->d_live_idx.as<int>() + s.row};
         for (int r = 0; r < vd.ranges; ++r) {
             const int t0 = (int)((long long)vd.b_tiles * r / vd.ranges), t1 = (int)((long long)vd.b_tiles * (r + 1) / vd.ranges);
@@ -443,6 +471,7 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
         hipLaunchKernelGGL(pf_gather_live_kernel, dim3((unsigned)V), dim3(256), 0, ctx->stream, ctx->d_jobs.as<GatherJob>(),
                            (const float*)tuv, ctx->d_live_idx.as<int>(), ctx->d_cmp_tu.as<float>(), ctx->d_cmp_h.as<_Float16>());
         HIPCHK(ctx, hipGetLastError());
+    DBGSYNC(ctx, "pf_gather_live_kernel");
     }
     HIPCHK(ctx, hipEventRecord(e2, ctx->stream));
     if (!ditems.empty()) {
@@ -450,6 +479,7 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
                            ctx->d_items.as<WorkItem>(), (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr,
                            (const float*)tuv, (const float*)tuv, ctx->d_cand.as<int2>(), ctx->d_cand_count.as<int>());
         HIPCHK(ctx, hipGetLastError());
+    DBGSYNC(ctx, "approx_kernel<2>");
         ctx->prof.sweep2_launches += 1;
     }
     if (V > 0) {
@@ -458,6 +488,7 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
                            (float*)nullptr, (float*)nullptr, (float*)nullptr, ctx->d_cmp_tu.as<float>(), (const float*)nullptr,
                            ctx->d_cand.as<int2>(), ctx->d_cand_count.as<int>() + P);
         HIPCHK(ctx, hipGetLastError());
+    DBGSYNC(ctx, "approx_kernel<3>");
         ctx->prof.sweep2_launches += 1;
     }
     HIPCHK(ctx, hipEventRecord(e3, ctx->stream));
@@ -471,18 +502,22 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
         hipLaunchKernelGGL(pf_exact_candidates_kernel<1>, cgrid, dim3(256), 0, ctx->stream, dp, dl, ctx->d_cand_count.as<int>(),
                            ctx->d_cand.as<int2>(), ctx->d_cand_s.as<float>());
     HIPCHK(ctx, hipGetLastError());
+    DBGSYNC(ctx, "pf_exact_candidates_kernel<1>");
     const dim3 rgrid(V > 0 ? 4 : 16, (unsigned)(P + V));
     hipLaunchKernelGGL(pf_reduce_best_kernel, rgrid, dim3(256), 0, ctx->stream, dp, dl, ctx->d_cand_count.as<int>(),
                        ctx->d_cand.as<int2>(), ctx->d_cand_s.as<float>(), ctx->d_best.as<unsigned long long>());
     HIPCHK(ctx, hipGetLastError());
+    DBGSYNC(ctx, "pf_reduce_best_kernel");
     hipLaunchKernelGGL(pf_reduce_second_kernel, rgrid, dim3(256), 0, ctx->stream, dp, dl, ctx->d_cand_count.as<int>(),
                        ctx->d_cand.as<int2>(), ctx->d_cand_s.as<float>(), ctx->d_best.as<unsigned long long>(),
                        ctx->d_second.as<unsigned long long>());
     HIPCHK(ctx, hipGetLastError());
+    DBGSYNC(ctx, "pf_reduce_second_kernel");
     hipLaunchKernelGGL(pf_finalize_kernel, mgrid, dim3(256), 0, ctx->stream, dp, dpf, (const float*)tuv, ctx->d_best.as<unsigned long long>(),
                        ctx->d_second.as<unsigned long long>(), ctx->d_k_i0.as<int>(), ctx->d_k_d0.as<float>(),
                        ctx->d_k_d1.as<float>(), ctx->d_fix_count.as<int>(), ctx->d_fix_list.as<int4>(), kFixCap);
     HIPCHK(ctx, hipGetLastError());
+    DBGSYNC(ctx, "pf_finalize_kernel");
 
     // candidate-list overflow -> brute-force exact path for that pair
     std::vector<int> counts(P + V);
@@ -794,6 +829,21 @@ int msfm_upload_image(msfm_ctx* ctx, int image_id, const void* desc, int n, int 
     std::memcpy(&im.nrm_max, &mx[0], 4);
     std::memcpy(&im.abs_max, &mx[1], 4);
     im.pf_safe = (im.abs_max <= kF16Safe) && (im.nrm_max < 3.0e38f);  // NaN/inf compare false
+    if (im.pf_safe) {
+        // c = 2^k with max|row|^2 / 2 / c in (2^11, 2^12]; k must keep c an exact fp16 value
+        int e = 0;
+        (void)std::frexp(0.5f * im.nrm_max, &e);  // 0.5 nrm_max = m * 2^e, m in [0.5, 1)
+        int k = (im.nrm_max > 0.f ? e : -24) - 12;
+        if (k < -24) k = -24;
+        if (k > 15) im.pf_safe = false;
+        else {
+            im.c = std::ldexp(1.f, k);
+            HIPCHK(ctx, hipMalloc((void**)&im.ext, (size_t)npad * 16));
+            hipLaunchKernelGGL(pf_ext_kernel, dim3((npad + 255) / 256), dim3(256), 0, ctx->stream, im.nrm, im.ext, npad, im.c);
+            HIPCHK(ctx, hipGetLastError());
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        }
+    }
     return MSFM_OK;
 }
 

@@ -5,11 +5,15 @@
 // finds a small, PROVABLY sufficient candidate set with the matrix cores and evaluates the pinned
 // fp32 order only on it:
 //
-//   pass 1  approx_kernel<1>   S~ = |a|^2 + |b|^2 - 2 a~.b~ with fp16 operands on
-//                              v_mfma_f32_32x32x16_f16; per row / column the two smallest S~ values.
-//   thresholds_kernel          T = S~(2) + 2*eps, eps = rigorous bound on |S~ - S_exact| (below).
-//   pass 2  approx_kernel<2>   same MFMA sweep; every (q,t) with S~ <= T_row[q] or S~ <= T_col[t]
-//                              is appended to the pair's candidate list (a few per row).
+//   sweep 1  approx_kernel<1>  S~ = |a|^2 + |b|^2 - 2 a~.b~ with fp16 operands on
+//                              v_mfma_f32_32x32x16_f16 -- the norms ride in a ninth k-step (below), so the
+//                              accumulator IS -S~/2; per row / column the two smallest S~ values.
+//   thresholds_kernel          T = S~(2) + 2*eps, eps = rigorous bound on |S~ - S_exact| (below); rows /
+//                              columns that provably cannot match get T = -inf (match lists only).
+//   sweep 2  approx_kernel<3>  live rows of one image (compacted) against the other image, per direction:
+//                              the row threshold rides in the ninth k-step too, a hit is accumulator >= 0;
+//            approx_kernel<2>  dense variant (nothing pruned): S~ <= T_row[q] or S~ <= T_col[t];
+//                              hits are appended to the pair's candidate list (a few per row).
 //   exact_candidates_kernel    S_exact in the pinned accumulation order for the candidates only.
 //   reduce (3 tiny kernels)    per row / column the best and second best (S_exact, index) among
 //                              the candidates -> the same kNN arrays merge_knn_kernel produces.
@@ -30,6 +34,15 @@
 // (fp16 overflow) or non-finite norms are not prefiltered; a pair whose candidate list overflows
 // falls back to the brute-force exact kernel.  tests/test_gpu_prefilter.py checks the bound
 // empirically and the end results bit-for-bit.
+//
+// Norms in the MFMA.  Per image c = 2^k with max|row|^2 / 2 / c in (2^11, 2^12]; each row stores the fp16
+// quadruple e = [h_hi, h_lo, c, c] with h = |row|^2 / 2 / c split into two fp16 (hi + lo: 2^-21 relative).
+// The A side (built in registers per work item) is [-c, -c, x_hi, x_lo] with x = X / c, X = -|a|^2/2 (sweep
+// 1, dense sweep 2) or X = (T_row - |a|^2)/2 (compacted sweep 2), so the ninth k-step adds -|b|^2/2 + X and
+// the accumulator is -S~/2 resp. -(S~ - T_row)/2.  Extra error: 2^-21 relative on the norms (inside the
+// 1e-4 budget above) plus, should the MFMA flush fp16 subnormals, <= 4 * 2^-14 c absolute on the
+// accumulator -> eps_norm = 2^-11 c is added to eps.  Pairs whose |a|^2 maximum exceeds 8x the |b|^2
+// maximum (x would leave the fp16 range) take the brute-force path.
 #pragma once
 #include "msfm_kernels.hip.h"
 
@@ -44,7 +57,10 @@ constexpr int kPfBT = 64;                 // B rows per tile
 constexpr int kHalfRowBytes = kDim * 2;   // one fp16 descriptor = 256 B = 16 granules of 16 B
 constexpr int kPfLdsB = kPfBT * kHalfRowBytes;  // 16 KiB per slot
 constexpr int kPfCandBuf = 256;                  // per-wave LDS candidate buffer (pass 2), int2 entries
-constexpr int kPfLdsBytes = 3 * kPfLdsB + 4 * 3 * 2 * 64 * 4 + 4 * 64 * 4 + 4 * kPfCandBuf * 8 + 3 * 4 * 64 * 8;  // 48 + 6 + 1 + 8 + 6 = 69 KiB
+constexpr int kPfExtB = kPfBT * 16;              // the tile's norm quadruples: 16 B per row
+// B ring 48 KiB | per-wave quadruple rings 12 KiB | per-wave column-threshold rings 3 KiB | zero granule |
+// per-wave candidate buffers 8 KiB | column partials 6 KiB
+constexpr int kPfLdsBytes = 3 * kPfLdsB + 4 * 3 * kPfExtB + 4 * 3 * 64 * 4 + 64 + 4 * kPfCandBuf * 8 + 3 * 4 * 64 * 8;
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef float f16v __attribute__((ext_vector_type(16)));
@@ -54,9 +70,12 @@ struct PfPair {            // per-pair extras of the prefilter path (parallel to
     const _Float16* b_h;
     const float* a_nrm;    // |row|^2, +inf on padding rows
     const float* b_nrm;
+    const _Float16* a_ext; // norm quadruples [rows][8 halfs] (the A image's are used when it plays B in a compacted sweep)
+    const _Float16* b_ext;
+    float a_c, b_c;        // the images' scales c (powers of two)
     float a_nrm_max, b_nrm_max;
-    long long tu_off;      // row thresholds (u-space) [n1pad]
-    long long tv_off;      // column thresholds (v-space) [n2pad]
+    long long tu_off;      // row thresholds T (S-space) [n1pad]; compacted sweep: T - |a|^2 per live row
+    long long tv_off;      // column thresholds T (S-space) [n2pad]
     long long cand_off;    // candidate list base
     int cand_cap;
     int use;               // 1: prefiltered; 0: not safe -> exact brute force
@@ -100,6 +119,21 @@ __global__ void pf_prepare_kernel(const float* __restrict__ raw, _Float16* __res
     }
 }
 
+// norm quadruples [h_hi, h_lo, c, c, 0, 0, 0, 0], h = |row|^2 / 2 / c (padding rows: +inf -> never selected)
+__global__ void pf_ext_kernel(const float* __restrict__ nrm, _Float16* __restrict__ ext, int npad, float c) {
+    const float inv_c = 1.f / c;  // power of two: exact
+    for (int row = blockIdx.x * blockDim.x + threadIdx.x; row < npad; row += gridDim.x * blockDim.x) {
+        const float h = 0.5f * nrm[row] * inv_c;
+        const _Float16 hi = (_Float16)h;
+        const float rest = h - (float)hi;
+        const _Float16 lo = (rest == rest && fabsf(rest) < 3.0e38f) ? (_Float16)rest : (_Float16)0.f;
+        h8 v;
+        v[0] = hi; v[1] = lo; v[2] = (_Float16)c; v[3] = (_Float16)c;
+        v[4] = v[5] = v[6] = v[7] = (_Float16)0.f;
+        *reinterpret_cast<h8*>(ext + (size_t)row * 8) = v;
+    }
+}
+
 __device__ __forceinline__ void glds_copy_bytes(const void* g, void* lds, int bytes, int tid, int nthreads) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const char* gp = reinterpret_cast<const char*>(g);
@@ -117,29 +151,33 @@ __device__ __forceinline__ void v2_merge(float& s0, float& s1, float b0, float b
 
 // ---------------------------------------------------------------------------------------------
 // approx_kernel<PASS>: one workgroup (4 waves) = one 256-row A block x a range of 64-row B tiles.
-//   Wave w owns A rows w*64..w*64+63 for the whole item: its 16 fp16 A fragments (two 32-row MFMA
-//   blocks x 8 k-steps) live in registers, loaded once straight from HBM.  Only B tiles stream
-//   through LDS: a ring of three 16 KiB slots filled by LDS-DMA two tiles ahead, synchronised with
-//   raw s_barrier + COUNTED s_waitcnt vmcnt(N) so the two younger tiles stay in flight across the
-//   barrier.  The tile's |b|^2 (and pass-2 thresholds) ride along as 256-byte dword DMAs, so the
-//   loop contains no ordinary global load that would make hipcc drain vmcnt(0).
-//   Per tile and column block: 2 x 8 MFMA 32x32x16 f16, then the epilogue on the 2 x 16 results.
+//   Wave w owns A rows w*64..w*64+63 for the whole item: its fp16 A fragments (two 32-row MFMA
+//   blocks x 9 k-steps, the ninth holding the norm / threshold quadruple) live in registers, loaded
+//   once straight from HBM.  Only B tiles stream through LDS: a ring of three 16 KiB slots filled by
+//   LDS-DMA two tiles ahead, synchronised with raw s_barrier + COUNTED s_waitcnt vmcnt(N) so the two
+//   younger tiles stay in flight across the barrier.  The tile's norm quadruples (and the dense sweep's
+//   column thresholds) ride along as per-wave DMAs, so the loop contains no ordinary global load that
+//   would make hipcc drain vmcnt(0).
+//   Per tile and column block: 2 x 9 MFMA 32x32x16 f16, then the epilogue on the 2 x 16 results.
 //   MFMA layout: lane l feeds A[row l&31][k (l>>5)*8..+7] and B[col l&31][same k]; it receives for
 //   column l&31 the 16 rows (r&3) + 8 (r>>2) + 4 (l>>5), r = 0..15.
-//   u = nb_t - 2 dot (row direction, na_q added later), v = na_q - 2 dot (column direction).
-// PASS 1: two smallest u per row (lane-private over its columns, merged over the 32 lanes at the
-//         end) and two smallest v per column (lane pair merged, written per (A block, wave)).
-// PASS 2: append (q, t) where u <= tu[q] or v <= tv[t], tested in dot space.
-// VMEM LOADS per wave per tile (the counted wait depends on it): PASS 1: 5 DMA, PASS 2: 6 DMA.
+// PASS 1: accumulator = -S~/2.  Row maxima (1 op / element), column maxima (v_max3: 0.5 op / element);
+//         the two smallest S~ per row (merged over the 32 lanes at the end) and per column (lane pair
+//         merged, the four waves folded in LDS) are written as partials.
+// PASS 2: accumulator = -S~/2; append (q, t) where S~ <= T_row[q] or S~ <= T_col[t].
+// PASS 3: A = compacted live rows, accumulator = -(S~ - T_row)/2; append (k, t) where it is >= 0.
+//         PASS 2 / 3 first reduce the block to "any hit?" with v_max3 and only then build the bit mask.
+// VMEM LOADS per wave per tile (the counted wait depends on it): PASS 1 / 3: 5 DMA, PASS 2: 6 DMA.
 // Stores and the rare candidate flushes only add ops, which makes the wait more conservative.
 // ---------------------------------------------------------------------------------------------
 constexpr int kPfRing = 3;
-constexpr int kPfAuxFloats = 64;  // per slot: |b|^2 of the tile's 64 rows (and 64 thresholds in pass 2)
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
+
+__device__ __forceinline__ float max3f(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }  // folds to v_max3_f32
 
 template <int PASS>
 __global__ __launch_bounds__(kPfThreads, 2) void approx_kernel(
@@ -149,9 +187,11 @@ __global__ __launch_bounds__(kPfThreads, 2) void approx_kernel(
     typedef const __attribute__((address_space(1))) float* gfloat_p;  // keep these loads off the FLAT path
     typedef const __attribute__((address_space(1))) h8* gh8_p;
     extern __shared__ __attribute__((aligned(16))) char pf_smem[];
-    // LDS: ring of B tiles | per-wave aux rings (|b|^2, thresholds) | per-wave candidate buffers
     char* sB = pf_smem;
-    float* sAux = reinterpret_cast<float*>(pf_smem + kPfRing * kPfLdsB);
+    char* sExt = pf_smem + kPfRing * kPfLdsB;                                    // [wave][slot][64 rows x 16 B]
+    float* sThr = reinterpret_cast<float*>(sExt + 4 * kPfRing * kPfExtB);        // [wave][slot][64]
+    char* sZero = reinterpret_cast<char*>(sThr + 4 * kPfRing * 64);              // 64 B, first 16 used
+    char* sCand = sZero + 64;
 
     const WorkItem item = items[blockIdx.x];
     if (item.pair < 0) return;
@@ -165,12 +205,14 @@ __global__ __launch_bounds__(kPfThreads, 2) void approx_kernel(
 
     const int t_begin = item.bt_begin * 2, t_end = item.bt_end * 2;  // 64-row tiles
     const char* gB = reinterpret_cast<const char*>(pp.b_h);
+    const char* gE = reinterpret_cast<const char*>(pp.b_ext);
     const gfloat_p g_anrm = (gfloat_p)pp.a_nrm;
     const gfloat_p g_tu = (gfloat_p)tu;
-    float* aux_w = sAux + wave * (kPfRing * 2 * kPfAuxFloats);  // this wave's private copies
+    char* ext_w = sExt + wave * (kPfRing * kPfExtB);   // this wave's private copies
+    float* thr_w = sThr + wave * (kPfRing * 64);
 
     // DMA group of tile tt (clamped: the tail re-fetches the last tile so every iteration issues the
-    // same number of VMEM ops): this wave's quarter of the 16 KiB tile + its private |b|^2 / threshold rows
+    // same number of VMEM ops): this wave's quarter of the 16 KiB tile + its private quadruples / thresholds
     auto dma_tile = [&](int tt) {
         const int tc = tt < t_end ? tt : t_end - 1;
         const int sl = (tt - t_begin) % kPfRing;
@@ -180,58 +222,74 @@ __global__ __launch_bounds__(kPfThreads, 2) void approx_kernel(
         for (int k = 0; k < 4; ++k)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + k * 1024),
                                              (__attribute__((address_space(3))) void*)(l + k * 1024), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pp.b_nrm + tc * kPfBT + lane),
-                                         (__attribute__((address_space(3))) void*)(aux_w + sl * 2 * kPfAuxFloats), 4, 0, 0);
-        if (PASS == 2)  // PASS 3 (compacted live rows) has no column criterion
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gE + (size_t)tc * kPfExtB + lane * 16),
+                                         (__attribute__((address_space(3))) void*)(ext_w + sl * kPfExtB), 16, 0, 0);
+        if (PASS == 2)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(tv + pp.tv_off + tc * kPfBT + lane),
-                                             (__attribute__((address_space(3))) void*)(aux_w + sl * 2 * kPfAuxFloats + kPfAuxFloats), 4, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(thr_w + sl * 64), 4, 0, 0);
     };
     constexpr int kDmaOps = (PASS == 2) ? 6 : 5;
 
     dma_tile(t_begin);
     dma_tile(t_begin + 1);
+    if (tid < 4) reinterpret_cast<float*>(sZero)[tid] = 0.f;
 
-    // A fragments: rows a_blk*256 + wave*64 + rb*32 + lcol, granule 2*ks + lhalf (stored at ^ (row & 15))
-    h8 af[2][8];
+    // A fragments: rows a_blk*256 + wave*64 + rb*32 + lcol, granule 2*ks + lhalf (stored at ^ (row & 15));
+    // ninth k-step: [-c, -c, x_hi, x_lo, 0...] in the lhalf == 0 lanes (k = 128..135), zeros in the others
+    h8 af[2][9];
+    const float inv_c = 1.f / pp.b_c;
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb) {
         const int frow = item.a_blk * 256 + wave * 64 + rb * 32 + lcol;
         const gh8_p ga = (gh8_p)(pp.a_h) + (size_t)frow * 16;
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) af[rb][ks] = ga[(2 * ks + lhalf) ^ (frow & 15)];
+        // padding rows: X = -inf -> accumulator -inf, never a maximum, never a hit
+        float X;
+        if (PASS == 3) X = frow < pd.n1 ? 0.5f * g_tu[pp.tu_off + frow] : -f_inf();
+        else X = frow < pd.n1 ? -0.5f * g_anrm[frow] : -f_inf();
+        const float xs = X * inv_c;
+        const _Float16 hi = (_Float16)xs;
+        const float rest = xs - (float)hi;
+        const _Float16 lo = (rest == rest && fabsf(rest) < 3.0e38f) ? (_Float16)rest : (_Float16)0.f;
+        h8 e;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) e[j] = (_Float16)0.f;
+        if (lhalf == 0) {
+            e[0] = (_Float16)(-pp.b_c);
+            e[1] = (_Float16)(-pp.b_c);
+            e[2] = hi;
+            e[3] = lo;
+        }
+        af[rb][8] = e;
     }
 
     // this lane's 32 result rows: (rb, r) -> row = a_blk*256 + wave*64 + rb*32 + (r&3) + 8*(r>>2) + 4*lhalf
     const int arow_base = item.a_blk * 256 + wave * 64 + 4 * lhalf;
-    // Row scalars in LDS (wave-private, 64 floats): PASS 1 |a|^2, PASS 2 0.5 |a|^2.  They are read back
-    // four rows at a time; keeping them out of the VGPR budget keeps the kernel spill-free (a spill
-    // reload is a scratch = VMEM load and would drain the DMA ring at every use).
-    // rs0: PASS 1 running row minimum of u; PASS 2 0.5 * row threshold (a hit is dot >= min(hb - rs0, ha - hv)).
-    float* na_w = sAux + 4 * kPfRing * 2 * kPfAuxFloats + wave * 64;
+    // rs0: PASS 1 running row maximum of the accumulator (-S~min/2); PASS 2 the row's hit level -T_row/2
     float rs0[2][16];
-    {
-        const int row = item.a_blk * 256 + wave * 64 + lane;
-        if (PASS != 3) {
-            const float nrm = row < pd.n1 ? g_anrm[row] : f_inf();  // padding rows: +inf norm, never selected
-            na_w[lane] = (PASS == 1) ? nrm : 0.5f * nrm;
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int rr = arow_base + rb * 32 + (r & 3) + 8 * (r >> 2);
+            rs0[rb][r] = (PASS == 2) ? (rr < pd.n1 ? -0.5f * g_tu[pp.tu_off + rr] : f_inf()) : -f_inf();
         }
+    // Make hipcc itself wait for the fragment loads here (a register use it can see): otherwise its
+    // scoreboard still holds them as pending at the first MFMA and it drains vmcnt(0) INSIDE the loop,
+    // which would serialise the DMA ring.
 #pragma unroll
-        for (int rb = 0; rb < 2; ++rb)
+    for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int rr = arow_base + rb * 32 + (r & 3) + 8 * (r >> 2);
-                rs0[rb][r] = (PASS == 1) ? f_inf() : (rr < pd.n1 ? 0.5f * g_tu[pp.tu_off + rr] : -f_inf());
-            }
-    }
+        for (int ks = 0; ks < 9; ++ks) asm volatile("" ::"v"(af[rb][ks]));
     wait_vmcnt<0>();  // prologue loads (and the first two DMA groups) are done: counted waits start clean
 
-    // pass 2: wave-private candidate buffer in LDS
-    int2* cbuf = reinterpret_cast<int2*>(sAux + 4 * kPfRing * 2 * kPfAuxFloats + 4 * 64) + wave * kPfCandBuf;
+    // sweep 2: wave-private candidate buffer in LDS
+    int2* cbuf = reinterpret_cast<int2*>(sCand) + wave * kPfCandBuf;
     const unsigned cbuf_lds = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)cbuf;
-    // pass 1: column partials of the four waves meet in LDS ([ring slot][wave][64 columns] x (s0, s1)) and
+    // sweep 1: column partials of the four waves meet in LDS ([ring slot][wave][64 columns] x (s0, s1)) and
     // are merged by one wave two tiles later: 4x less partial traffic to HBM than one slot per wave
-    const unsigned colbuf_lds = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)(
-        reinterpret_cast<char*>(sAux + 4 * kPfRing * 2 * kPfAuxFloats + 4 * 64) + 4 * kPfCandBuf * 8);
+    const unsigned colbuf_lds = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)(sCand + 4 * kPfCandBuf * 8);
     int n_buf = 0;  // wave-uniform
     auto flush_candidates = [&]() {
         if (n_buf == 0) return;
@@ -247,111 +305,111 @@ __global__ __launch_bounds__(kPfThreads, 2) void approx_kernel(
     const int xb = lcol & 15;  // both column blocks: row & 15 == lcol & 15
 
     // ---- the two halves of the software pipeline -------------------------------------------------
-    // A "block" is (tile, column block): 32 x 64... per wave 2 x 16 MFMA results per lane.
-    // stage(): issue the 16 MFMAs of block k+1 into `nxt` while the VALU epilogue of block k (in `cur`)
+    // A "block" is (tile, column block): per wave 2 x 16 MFMA results per lane.
+    // stage(): issue the 18 MFMAs of block k+1 into `nxt` while the VALU epilogue of block k (in `cur`)
     // runs -- in ONE basic block, so the scheduler can interleave them: co-resident waves run in
     // lockstep (same barriers), only the overlap inside a wave keeps both pipes busy.
-    struct BlockMeta { float nb, tvc; int col; int cslot; };  // cslot: LDS slot of the block's 32 column partials
-    auto load_bf = [&](const char* pb, int cb, h8 (&bf)[8]) {
+    struct BlockMeta { float hc; int col; int cslot; };  // hc: PASS 2 column hit level -T_col/2; cslot: LDS slot of the column partials
+    const int zero_off = (int)(sZero - pf_smem);
+    auto load_bf = [&](const char* pb, int pe_off, int cb, h8 (&bf)[9]) {
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks)
             bf[ks] = *reinterpret_cast<const h8*>(pb + cb * 32 * kHalfRowBytes + (((2 * ks + lhalf) ^ xb) << 4));
+        // ninth k-step: the quadruple of column cb*32 + lcol for k = 128..135, the zero granule for k = 136..143
+        // (one base pointer + selected offset: a select between two pointers makes hipcc drain vmcnt(0))
+        bf[8] = *reinterpret_cast<const h8*>(pf_smem + (lhalf == 0 ? pe_off + (cb * 32 + lcol) * 16 : zero_off));
     };
-    auto mfma_block = [&](const h8 (&bf)[8], f16v (&acc)[2]) {
+    auto mfma_block = [&](const h8 (&bf)[9], f16v (&acc)[2]) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
+        for (int ks = 0; ks < 9; ++ks) {
             acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][ks], bf[ks], acc[0], 0, 0, 0);
             acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[1][ks], bf[ks], acc[1], 0, 0, 0);
         }
     };
-    // branch-free part of the epilogue; returns the pass-2 hit mask (element k = rb*16 + r at bit 31-k)
-    auto epilogue_valu = [&](const f16v (&acc)[2], const BlockMeta& bm) -> unsigned {
-        unsigned mask = 0;
-        if (PASS == 1) {
-            // Only MINIMA are tracked (1 op per element instead of 2): the second smallest of minima
-            // over disjoint subsets is an upper bound of the true second-smallest S~, which is all
-            // the threshold needs (it is exact unless both neighbours fall into one subset).
-            float c[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) c[j] = f_inf();
+    // branch-free part of the epilogue; returns "this lane saw a hit" for the sweep-2 variants
+    auto epilogue_valu = [&](const f16v (&acc)[2], const BlockMeta& bm) -> bool {
+        // column maximum of the accumulator over this lane's 32 rows: 16 v_max3
+        float m = -f_inf();
+        if (PASS != 2) {
 #pragma unroll
             for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-                for (int q4 = 0; q4 < 4; ++q4) {
-                    // rows (r&3) = 0..3 of this quad are consecutive: one 16-byte LDS read
-                    const v4f nav = *reinterpret_cast<const v4f*>(na_w + rb * 32 + 8 * q4 + 4 * lhalf);
-                    float v[4];
+                for (int r = 0; r < 16; r += 2) m = max3f(m, acc[rb][r], acc[rb][r + 1]);
+        }
+        if (PASS == 1) {
+            // Only MAXIMA are tracked: the second smallest of the minima of S~ over disjoint subsets is an
+            // upper bound of the true second-smallest S~, which is all the threshold needs (it is exact
+            // unless both neighbours fall into one subset).
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const float d = acc[rb][4 * q4 + j];
-                        rs0[rb][4 * q4 + j] = fminf(rs0[rb][4 * q4 + j], fmaf(d, -2.f, bm.nb));
-                        v[j] = fmaf(d, -2.f, nav[j]);
-                    }
-                    c[q4] = fminf(c[q4], fminf(fminf(v[0], v[1]), fminf(v[2], v[3])));  // folds to v_min3
-                }
-            // this lane: min over its 32 rows; partner lane (l ^ 32): the other 32 rows of the wave
-            const float mine = fminf(fminf(c[0], c[1]), fminf(c[2], c[3]));
-            const float other = __shfl_xor(mine, 32);
+            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) rs0[rb][r] = fmaxf(rs0[rb][r], acc[rb][r]);
+            // partner lane (l ^ 32): the other 32 rows of the wave
+            const float other = __shfl_xor(m, 32);
             // (s0, s1) of this wave's 64 rows for column bm.col -> LDS (inline asm: see append_hits)
             if (lhalf == 0) {
-                const float2 pr = make_float2(fminf(mine, other), fmaxf(mine, other));
+                const float2 pr = make_float2(-2.f * fmaxf(m, other), -2.f * fminf(m, other));
                 asm volatile("ds_write_b64 %0, %1" ::"v"(colbuf_lds + (unsigned)(bm.cslot + lcol) * 8u), "v"(pr) : "memory");
             }
+            return false;
+        } else if (PASS == 3) {
+            return m >= 0.f;
         } else {
-            const float hb = 0.5f * bm.nb, hv = 0.5f * bm.tvc;
+            // row criterion: max over (acc - level_row) >= 0; column criterion: max over acc >= level_col
+            float mr = -f_inf(), mc = -f_inf();
 #pragma unroll
             for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-                for (int q4 = 0; q4 < 4; ++q4) {
-                    if (PASS == 2) {
-                        const v4f hav = *reinterpret_cast<const v4f*>(na_w + rb * 32 + 8 * q4 + 4 * lhalf);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const float th = fminf(hb - rs0[rb][4 * q4 + j], hav[j] - hv);
-                            mask = mask + mask + ((acc[rb][4 * q4 + j] >= th) ? 1u : 0u);
-                        }
-                    } else {  // PASS 3: row criterion only (same arithmetic as the row half of PASS 2)
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const float th = hb - rs0[rb][4 * q4 + j];
-                            mask = mask + mask + ((acc[rb][4 * q4 + j] >= th) ? 1u : 0u);
-                        }
-                    }
+                for (int r = 0; r < 16; r += 2) {
+                    mr = max3f(mr, acc[rb][r] - rs0[rb][r], acc[rb][r + 1] - rs0[rb][r + 1]);
+                    mc = max3f(mc, acc[rb][r], acc[rb][r + 1]);
                 }
+            return mr >= 0.f || mc >= bm.hc;
         }
-        return mask;
     };
-    // pass 2: slot the (rare) hits with ballot/popcount into this wave's LDS buffer -- no atomics in the
-    // loop -- and flush to the pair's global list when the buffer fills up
-    auto append_hits = [&](unsigned mask, int col) {
+    // sweep 2, rare path: the block holds at least one hit -> bit mask per lane (element k = rb*16 + r at
+    // bit 31-k), slotted with ballot/popcount into this wave's LDS buffer -- no atomics in the loop --
+    // and flushed to the pair's global list when the buffer fills up
+    auto append_hits = [&](bool any, const f16v (&acc)[2], const BlockMeta& bm) {
+        if (__ballot(any) == 0ull) return;
+        unsigned mask = 0;
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                // padding rows / columns hold -inf: with an infinite threshold (fewer than two real elements in
+                // a subset) the hit level is -inf as well, and -inf >= -inf must not count
+                const bool hit = (PASS == 3) ? (acc[rb][r] >= 0.f)
+                                             : (acc[rb][r] > -f_inf() && (acc[rb][r] >= rs0[rb][r] || acc[rb][r] >= bm.hc));
+                mask = mask + mask + (hit ? 1u : 0u);
+            }
         while (__ballot(mask != 0u) != 0ull) {
             const bool hit = mask != 0u;
             const int k = __clz((int)mask);  // first remaining element of this lane (32 if none)
-            const unsigned long long m = __ballot(hit);
+            const unsigned long long mm = __ballot(hit);
             if (n_buf + 64 > kPfCandBuf) flush_candidates();
             if (hit) {
                 mask &= ~(0x80000000u >> k);
-                const int slt = n_buf + __popcll(m & ((1ull << lane) - 1ull));
+                const int slt = n_buf + __popcll(mm & ((1ull << lane) - 1ull));
                 // inline asm on purpose: hipcc would first drain vmcnt(0) for a compiler-visible LDS store
-                const int2 e = make_int2(arow_base + (k >> 4) * 32 + (k & 3) + 8 * ((k & 15) >> 2), col);
+                const int2 e = make_int2(arow_base + (k >> 4) * 32 + (k & 3) + 8 * ((k & 15) >> 2), bm.col);
                 asm volatile("ds_write_b64 %0, %1" ::"v"(cbuf_lds + slt * 8), "v"(e) : "memory");
             }
-            n_buf += __popcll(m);
+            n_buf += __popcll(mm);
         }
     };
-    // interleave hint: one MFMA, then a slice of the epilogue's VALU / LDS work, 16 times
+    // interleave hint: one MFMA, then a slice of the epilogue's VALU work, 18 times
     auto interleave_hint = [&]() {
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                     // 1 MFMA
-            __builtin_amdgcn_sched_group_barrier(0x002, PASS == 1 ? 8 : (PASS == 2 ? 11 : 6), 0);    // VALU
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                     // 1 DS read
+        for (int k = 0; k < 18; ++k) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                          // 1 MFMA
+            __builtin_amdgcn_sched_group_barrier(0x002, PASS == 1 ? 3 : (PASS == 2 ? 4 : 1), 0);      // VALU
         }
     };
 
-    // pass 1: lane = column of tile tt; fold the four waves' (s0, s1) and store one partial per A block
+    // sweep 1: lane = column of tile tt; fold the four waves' (s0, s1) and store one partial per A block
     auto merge_columns = [&](int tt) {
         const unsigned base = colbuf_lds + (unsigned)((((tt - t_begin) % kPfRing) * 4) * 64 + lane) * 8u;
         float2 w0, w1, w2, w3;
@@ -366,19 +424,19 @@ __global__ __launch_bounds__(kPfThreads, 2) void approx_kernel(
         cp_s1[o] = w0.y;
     };
 
-    // accB / metaB start as a harmless dummy block (|b|^2 = +inf, threshold = -inf: no minimum moves,
-    // no hit; its column partial lands in an LDS slot that a real block rewrites before it is merged), so
-    // that every iteration runs the same instruction sequence -- the counted waits rely on it
+    // accB / metaB start as a harmless dummy block (accumulator -inf: no maximum moves, no hit; its
+    // column partial lands in an LDS slot that a real block rewrites before it is merged), so that every
+    // iteration runs the same instruction sequence -- the counted waits rely on it
     f16v accA[2], accB[2];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { accB[0][r] = 0.f; accB[1][r] = 0.f; }
-    BlockMeta metaA = {0.f, 0.f, 0, 0}, metaB = {f_inf(), -f_inf(), t_begin * kPfBT + 32 + lcol, (2 * 4 + wave) * 64 + 32};
+    for (int r = 0; r < 16; ++r) { accB[0][r] = -f_inf(); accB[1][r] = -f_inf(); }
+    BlockMeta metaA = {0.f, 0, 0}, metaB = {f_inf(), t_begin * kPfBT + 32 + lcol, (2 * 4 + wave) * 64 + 32};
 #pragma unroll 1
     for (int t = t_begin; t < t_end; ++t) {
         // Tile t must have landed.  Its DMA group is followed by exactly one younger group of LOADS
         // (tile t+1, kDmaOps of them).  Loads retire in order among themselves, but on gfx9-class
         // vmcnt stores may retire out of order with respect to loads, so the count must not rely on
-        // the (pass-1) stores: "at most kDmaOps outstanding" implies every load of tile t is done,
+        // the (sweep-1) stores: "at most kDmaOps outstanding" implies every load of tile t is done,
         // because a pending load of tile t would keep all kDmaOps loads of tile t+1 pending as well.
         if (t - t_begin >= 2) wait_vmcnt<kDmaOps>();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -389,33 +447,31 @@ __global__ __launch_bounds__(kPfThreads, 2) void approx_kernel(
         if (PASS == 1 && t - t_begin >= 2 && wave == (t & 3)) merge_columns(t - 2);
         const int sl = (t - t_begin) % kPfRing;
         const char* pb = sB + sl * kPfLdsB + lcol * kHalfRowBytes;
-        const float* aux = aux_w + sl * 2 * kPfAuxFloats;
-        h8 bf[8];
+        const int pe_off = (int)(ext_w - pf_smem) + sl * kPfExtB;
+        const float* thr = thr_w + sl * 64;
+        h8 bf[9];
         // stage 1: MFMA (t, cb 0) -> accA   ||   epilogue of (t-1, cb 1) in accB
-        load_bf(pb, 0, bf);
-        metaA.nb = aux[lcol];
-        metaA.tvc = (PASS == 2) ? aux[kPfAuxFloats + lcol] : 0.f;
+        load_bf(pb, pe_off, 0, bf);
+        metaA.hc = (PASS == 2) ? -0.5f * thr[lcol] : 0.f;
         metaA.col = t * kPfBT + lcol;
         metaA.cslot = (sl * 4 + wave) * 64;
-        unsigned mask = 0;
         mfma_block(bf, accA);
-        mask = epilogue_valu(accB, metaB);
+        bool any = epilogue_valu(accB, metaB);
         interleave_hint();
-        if (PASS >= 2) append_hits(mask, metaB.col);
+        if (PASS >= 2) append_hits(any, accB, metaB);
         // stage 2: MFMA (t, cb 1) -> accB   ||   epilogue of (t, cb 0) in accA
-        load_bf(pb, 1, bf);
-        metaB.nb = aux[32 + lcol];
-        metaB.tvc = (PASS == 2) ? aux[kPfAuxFloats + 32 + lcol] : 0.f;
+        load_bf(pb, pe_off, 1, bf);
+        metaB.hc = (PASS == 2) ? -0.5f * thr[32 + lcol] : 0.f;
         metaB.col = t * kPfBT + 32 + lcol;
         metaB.cslot = (sl * 4 + wave) * 64 + 32;
         mfma_block(bf, accB);
-        mask = epilogue_valu(accA, metaA);
+        any = epilogue_valu(accA, metaA);
         interleave_hint();
-        if (PASS >= 2) append_hits(mask, metaA.col);
+        if (PASS >= 2) append_hits(any, accA, metaA);
     }
     {   // drain: epilogue of the last block
-        const unsigned mask = epilogue_valu(accB, metaB);
-        if (PASS >= 2) append_hits(mask, metaB.col);
+        const bool any = epilogue_valu(accB, metaB);
+        if (PASS >= 2) append_hits(any, accB, metaB);
     }
     if (PASS >= 2) flush_candidates();
     if (PASS == 1) {
@@ -427,12 +483,13 @@ __global__ __launch_bounds__(kPfThreads, 2) void approx_kernel(
     }
 
     if (PASS == 1) {
-        // rows: the two smallest of the 32 lanes' minima; one partial slot per B range
+        // rows: S~ = -2 * accumulator; the two smallest of the 32 lanes' minima; one partial slot per B range
         float rs1[2][16];
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
+                rs0[rb][r] = -2.f * rs0[rb][r];
                 rs1[rb][r] = f_inf();
 #pragma unroll
                 for (int m = 1; m < 32; m <<= 1)
@@ -468,8 +525,8 @@ struct PruneParams {
 __device__ __forceinline__ bool pf_dead(float s0, float s1, float nrm, float eps, float other_max, PruneParams pr) {
     if (!pr.prune) return false;
     const float tiny = 1e-5f * (fabsf(s0) + fabsf(s1) + nrm + other_max);
-    const float s0lb = fmaxf((s0 + nrm) - eps - tiny, 0.f);
-    const float s1ub = (s1 + nrm) + eps + tiny;
+    const float s0lb = fmaxf(s0 - eps - tiny, 0.f);
+    const float s1ub = s1 + eps + tiny;
     const float d0lb = sqrtf(s0lb) * (1.f - 1e-6f);
     const bool ratio_fails = pr.ratio > 0.f && d0lb >= pr.ratio * sqrtf(s1ub) * (1.f + 1e-5f);
     const bool too_far = d0lb > pr.max_distance * (1.f + 1e-5f);
@@ -484,16 +541,17 @@ __global__ void pf_thresholds_kernel(const PairDesc* __restrict__ pairs, const P
     const PfPair pp = pf[blockIdx.y];
     if (!pd.valid || !pp.use) return;
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    const float eps_norm = 4.8828125e-4f * fmaxf(pp.a_c, pp.b_c);  // 2^-11 c: fp16 subnormal flush of the norm quadruples
     if (e < pd.n1pad) {
         float s0 = f_inf(), s1 = f_inf();
         for (int p = 0; p < pd.ranges; ++p) {
             const long long o = pd.rp_off + (long long)p * pd.n1pad + e;
             v2_merge(s0, s1, rp_s0[o], rp_s1[o]);
         }
-        // S~(2) = s1 + na; eps_row = rel*(na + nb_max) + abs*(sqrt(na)+sqrt(nb_max)); threshold in u-space
+        // s1 = S~(2); eps_row = rel*(na + nb_max) + abs*(sqrt(na)+sqrt(nb_max)) + eps_norm; threshold in S-space
         const float na = pp.a_nrm[e];
-        const float eps = kEpsRel * (na + pp.b_nrm_max) + kEpsAbs * (sqrtf(na) + sqrtf(pp.b_nrm_max));
-        const float slack = 2.f * eps + 1e-5f * (fabsf(s1) + na + pp.b_nrm_max);  // + roundings here and in pass 2's dot-space test
+        const float eps = kEpsRel * (na + pp.b_nrm_max) + kEpsAbs * (sqrtf(na) + sqrtf(pp.b_nrm_max)) + eps_norm;
+        const float slack = 2.f * eps + 1e-5f * (fabsf(s1) + na + pp.b_nrm_max);  // + roundings here and in sweep 2's test
         const bool live = (e < pd.n1) && !pf_dead(s0, s1, na, eps, pp.b_nrm_max, pr);
         tu[pp.tu_off + e] = live ? s1 + slack : -f_inf();
     }
@@ -504,7 +562,7 @@ __global__ void pf_thresholds_kernel(const PairDesc* __restrict__ pairs, const P
             v2_merge(s0, s1, cp_s0[o], cp_s1[o]);
         }
         const float nb = pp.b_nrm[e];
-        const float eps = kEpsRel * (nb + pp.a_nrm_max) + kEpsAbs * (sqrtf(nb) + sqrtf(pp.a_nrm_max));
+        const float eps = kEpsRel * (nb + pp.a_nrm_max) + kEpsAbs * (sqrtf(nb) + sqrtf(pp.a_nrm_max)) + eps_norm;
         const float slack = 2.f * eps + 1e-5f * (fabsf(s1) + nb + pp.a_nrm_max);
         const bool live = (e < pd.n2) && !pf_dead(s0, s1, nb, eps, pp.a_nrm_max, pr);
         tv[pp.tv_off + e] = live ? s1 + slack : -f_inf();
@@ -652,6 +710,7 @@ __global__ void pf_count_live_kernel(const PairDesc* __restrict__ pairs, const P
 // (re-swizzled for their new row number).   grid = n_jobs blocks of 256
 struct GatherJob {
     const _Float16* src_h;   // image's fp16 blocks
+    const float* src_nrm;    // its |row|^2
     long long src_thr_off;   // into tuv
     long long dst_row;       // first row of this job in the compact arrays (multiple of 256)
     int n;                   // rows of the image
@@ -676,7 +735,7 @@ __global__ void pf_gather_live_kernel(const GatherJob* __restrict__ jobs, const 
         for (int w = 0; w < wave; ++w) k += wsum[w];
         if (live) {
             live_idx[J.dst_row + k] = e;
-            cmp_tu[J.dst_row + k] = t;
+            cmp_tu[J.dst_row + k] = t - J.src_nrm[e];  // sweep 2 folds (T - |a|^2)/2 into the MFMA
         }
         __syncthreads();
         if (threadIdx.x == 0) running += wsum[0] + wsum[1] + wsum[2] + wsum[3];

@@ -134,6 +134,51 @@ def test_random_gaussian_descriptors_signed(gpu_ctx, oracle):
     assert np.array_equal(fwd[0], oi0) and np.array_equal(b(fwd[1]), b(od0)) and np.array_equal(b(fwd[2]), b(od1))
 
 
+@pytest.mark.parametrize("shape", [(2, 2), (127, 1), (1, 127), (3, 200), (70, 5), (65, 3)])
+def test_padding_rows_never_become_candidates(gpu_ctx, oracle, shape):
+    """Tiny images leave most of a 256-row block as zero padding and make thresholds infinite (fewer than two
+    real elements per subset).  Signed unit vectors are ~1.41 apart, FARTHER than the all-zero padding row
+    (distance 1): a padding row that slipped into the candidate list would win."""
+    n1, n2 = shape
+    rng = np.random.default_rng(n1 * 131 + n2)
+    A = rng.normal(size=(n1, 128)).astype(F32)
+    B = rng.normal(size=(n2, 128)).astype(F32)
+    A /= np.linalg.norm(A, axis=1, keepdims=True).astype(F32)
+    B /= np.linalg.norm(B, axis=1, keepdims=True).astype(F32)
+    gpu_ctx.upload_image(0, A)
+    gpu_ctx.upload_image(1, B)
+    fwd, rev = gpu_ctx.knn2_pair(0, 1)
+    prof = gpu_ctx.profile()
+    assert prof["prefilter_pairs"] == 1 and prof["candidates"] <= n1 * n2
+    oi0, od0, _, od1 = oracle.knn2(A, B, 0, 4)
+    pi0, pd0, _, pd1 = oracle.knn2(B, A, 0, 4)
+    assert np.array_equal(fwd[0], oi0) and np.array_equal(b(fwd[1]), b(od0)) and np.array_equal(b(fwd[2]), b(od1))
+    assert np.array_equal(rev[0], pi0) and np.array_equal(b(rev[1]), b(pd0)) and np.array_equal(b(rev[2]), b(pd1))
+    q, t, d = gpu_ctx.match_pair(0, 1, 0.99, True, float("inf"))
+    oq, ot, od = oracle.match_pair(A, B, 0.99, True, np.inf, nthreads=4)
+    assert np.array_equal(q, oq) and np.array_equal(t, ot) and np.array_equal(b(d), b(od))
+
+
+def test_norm_scales_far_apart_take_the_exact_path(gpu_ctx, oracle):
+    """The norms ride in the MFMA in units of the other image's scale: a pair whose norm maxima differ by more
+    than 8x is not prefiltered (same answer from the brute-force kernel)."""
+    imgs = synth.rootsift_images(2, [400, 380], seed=19, n_proto=800)
+    A, B = imgs[0], (imgs[1] * F32(5.0)).astype(F32)
+    out = knn_both_modes(gpu_ctx, A, B)
+    pp, _ = assert_same(out)
+    assert pp["prefilter_pairs"] == 0 and pp["dist_kernel_launches"] == 1
+    oi0, od0, _, od1 = oracle.knn2(A, B, 0, 8)
+    fwd = out[True][0][0]
+    assert np.array_equal(fwd[0], oi0) and np.array_equal(b(fwd[1]), b(od0)) and np.array_equal(b(fwd[2]), b(od1))
+    B2 = (imgs[1] * F32(2.5)).astype(F32)   # 6.25x in norm: still prefiltered
+    out = knn_both_modes(gpu_ctx, A, B2)
+    pp, _ = assert_same(out)
+    assert pp["prefilter_pairs"] == 1
+    oi0, od0, _, od1 = oracle.knn2(A, B2, 0, 8)
+    fwd = out[True][0][0]
+    assert np.array_equal(fwd[0], oi0) and np.array_equal(b(fwd[1]), b(od0)) and np.array_equal(b(fwd[2]), b(od1))
+
+
 def test_pruning_keeps_match_lists_identical(gpu_ctx, oracle):
     """match_pairs discards rows/columns that provably fail the ratio test or the distance cut before pass 2;
     the match lists must not change, for any ratio / max_distance, and far fewer candidates are evaluated."""
