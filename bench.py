@@ -119,8 +119,8 @@ def cpu_baseline(imgs, pairs, budget_s=20.0, max_pairs=256, seed=0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="south-building")
     ap.add_argument("--images", type=int, default=None)
     ap.add_argument("--desc", type=int, default=None)

@@ -172,6 +172,16 @@ __device__ __forceinline__ void v2_merge(float& s0, float& s1, float b0, float b
 // ---------------------------------------------------------------------------------------------
 constexpr int kPfRing = 3;
 
+// Timing experiments only (results are WRONG unless 0): 1 no epilogue VALU, 2 no MFMA, 3 B fragments read
+// from LDS once per item instead of per block, 4 no barrier / DMA in the loop, 5 = 1 + 3, 6 = 1 + 3 + 4
+#ifndef MSFM_ABL
+#define MSFM_ABL 0
+#endif
+constexpr bool kAblNoEpi = MSFM_ABL == 1 || MSFM_ABL == 5 || MSFM_ABL == 6;
+constexpr bool kAblNoMfma = MSFM_ABL == 2;
+constexpr bool kAblNoLds = MSFM_ABL == 3 || MSFM_ABL == 5 || MSFM_ABL == 6;
+constexpr bool kAblNoSync = MSFM_ABL == 4 || MSFM_ABL == 6;
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -303,6 +313,14 @@ __global__ __launch_bounds__(kPfThreads, 2) void approx_kernel(
     };
 
     const int xb = lcol & 15;  // both column blocks: row & 15 == lcol & 15
+    const bool wave_active = item.a_blk * 256 + wave * 64 < pd.n1;  // wave-uniform
+    if (PASS == 1 && !wave_active) {
+        // its column partials are never written: park (+inf, +inf) in all three ring slots once
+        const float2 pr = make_float2(f_inf(), f_inf());
+#pragma unroll
+        for (int sl = 0; sl < kPfRing; ++sl)
+            asm volatile("ds_write_b64 %0, %1" ::"v"(colbuf_lds + (unsigned)((sl * 4 + wave) * 64 + lane) * 8u), "v"(pr) : "memory");
+    }
 
     // ---- the two halves of the software pipeline -------------------------------------------------
     // A "block" is (tile, column block): per wave 2 x 16 MFMA results per lane.
@@ -311,7 +329,9 @@ __global__ __launch_bounds__(kPfThreads, 2) void approx_kernel(
     // lockstep (same barriers), only the overlap inside a wave keeps both pipes busy.
     struct BlockMeta { float hc; int col; int cslot; };  // hc: PASS 2 column hit level -T_col/2; cslot: LDS slot of the column partials
     const int zero_off = (int)(sZero - pf_smem);
+    int abl_t = t_begin;
     auto load_bf = [&](const char* pb, int pe_off, int cb, h8 (&bf)[9]) {
+        if (kAblNoLds && abl_t != t_begin) return;
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks)
             bf[ks] = *reinterpret_cast<const h8*>(pb + cb * 32 * kHalfRowBytes + (((2 * ks + lhalf) ^ xb) << 4));
@@ -320,6 +340,11 @@ __global__ __launch_bounds__(kPfThreads, 2) void approx_kernel(
         bf[8] = *reinterpret_cast<const h8*>(pf_smem + (lhalf == 0 ? pe_off + (cb * 32 + lcol) * 16 : zero_off));
     };
     auto mfma_block = [&](const h8 (&bf)[9], f16v (&acc)[2]) {
+        if (kAblNoMfma) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[0][r] += (float)bf[r & 7][0]; acc[1][r] += (float)bf[8][r & 7]; }
+            return;
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
 #pragma unroll
@@ -330,6 +355,10 @@ __global__ __launch_bounds__(kPfThreads, 2) void approx_kernel(
     };
     // branch-free part of the epilogue; returns "this lane saw a hit" for the sweep-2 variants
     auto epilogue_valu = [&](const f16v (&acc)[2], const BlockMeta& bm) -> bool {
+        if (kAblNoEpi) {
+            rs0[0][0] = fmaxf(rs0[0][0], acc[0][0] + acc[1][15]);
+            return false;
+        }
         // column maximum of the accumulator over this lane's 32 rows: 16 v_max3
         float m = -f_inf();
         if (PASS != 2) {
@@ -431,6 +460,9 @@ __global__ __launch_bounds__(kPfThreads, 2) void approx_kernel(
 #pragma unroll
     for (int r = 0; r < 16; ++r) { accB[0][r] = -f_inf(); accB[1][r] = -f_inf(); }
     BlockMeta metaA = {0.f, 0, 0}, metaB = {f_inf(), t_begin * kPfBT + 32 + lcol, (2 * 4 + wave) * 64 + 32};
+#if MSFM_ABL
+    h8 bf[9];  // must survive the iteration when the reads are ablated
+#endif
 #pragma unroll 1
     for (int t = t_begin; t < t_end; ++t) {
         // Tile t must have landed.  Its DMA group is followed by exactly one younger group of LOADS
@@ -438,38 +470,47 @@ __global__ __launch_bounds__(kPfThreads, 2) void approx_kernel(
         // vmcnt stores may retire out of order with respect to loads, so the count must not rely on
         // the (sweep-1) stores: "at most kDmaOps outstanding" implies every load of tile t is done,
         // because a pending load of tile t would keep all kDmaOps loads of tile t+1 pending as well.
-        if (t - t_begin >= 2) wait_vmcnt<kDmaOps>();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();  // every wave's part of tile t is in LDS; slot of tile t-1 is free
-        asm volatile("" ::: "memory");
-        dma_tile(t + 2);
+        if (!kAblNoSync) {
+            if (t - t_begin >= 2) wait_vmcnt<kDmaOps>();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();  // every wave's part of tile t is in LDS; slot of tile t-1 is free
+            asm volatile("" ::: "memory");
+            dma_tile(t + 2);
+        }
         // tile t-2's column partials are complete in LDS (its last epilogue ran before this barrier)
         if (PASS == 1 && t - t_begin >= 2 && wave == (t & 3)) merge_columns(t - 2);
         const int sl = (t - t_begin) % kPfRing;
         const char* pb = sB + sl * kPfLdsB + lcol * kHalfRowBytes;
         const int pe_off = (int)(ext_w - pf_smem) + sl * kPfExtB;
         const float* thr = thr_w + sl * 64;
-        h8 bf[9];
-        // stage 1: MFMA (t, cb 0) -> accA   ||   epilogue of (t-1, cb 1) in accB
-        load_bf(pb, pe_off, 0, bf);
-        metaA.hc = (PASS == 2) ? -0.5f * thr[lcol] : 0.f;
-        metaA.col = t * kPfBT + lcol;
-        metaA.cslot = (sl * 4 + wave) * 64;
-        mfma_block(bf, accA);
-        bool any = epilogue_valu(accB, metaB);
-        interleave_hint();
-        if (PASS >= 2) append_hits(any, accB, metaB);
-        // stage 2: MFMA (t, cb 1) -> accB   ||   epilogue of (t, cb 0) in accA
-        load_bf(pb, pe_off, 1, bf);
-        metaB.hc = (PASS == 2) ? -0.5f * thr[32 + lcol] : 0.f;
-        metaB.col = t * kPfBT + 32 + lcol;
-        metaB.cslot = (sl * 4 + wave) * 64 + 32;
-        mfma_block(bf, accB);
-        any = epilogue_valu(accA, metaA);
-        interleave_hint();
-        if (PASS >= 2) append_hits(any, accA, metaA);
+        abl_t = t;
+        // A wave whose 64 rows are all padding (tail of an image, tail of a compacted row set) still takes
+        // part in the DMA and the barriers, but leaves the matrix pipe to the co-resident workgroup
+        if (wave_active) {
+#if !MSFM_ABL
+            h8 bf[9];
+#endif
+            // stage 1: MFMA (t, cb 0) -> accA   ||   epilogue of (t-1, cb 1) in accB
+            load_bf(pb, pe_off, 0, bf);
+            metaA.hc = (PASS == 2) ? -0.5f * thr[lcol] : 0.f;
+            metaA.col = t * kPfBT + lcol;
+            metaA.cslot = (sl * 4 + wave) * 64;
+            mfma_block(bf, accA);
+            bool any = epilogue_valu(accB, metaB);
+            interleave_hint();
+            if (PASS >= 2) append_hits(any, accB, metaB);
+            // stage 2: MFMA (t, cb 1) -> accB   ||   epilogue of (t, cb 0) in accA
+            load_bf(pb, pe_off, 1, bf);
+            metaB.hc = (PASS == 2) ? -0.5f * thr[32 + lcol] : 0.f;
+            metaB.col = t * kPfBT + 32 + lcol;
+            metaB.cslot = (sl * 4 + wave) * 64 + 32;
+            mfma_block(bf, accB);
+            any = epilogue_valu(accA, metaA);
+            interleave_hint();
+            if (PASS >= 2) append_hits(any, accA, metaA);
+        }
     }
-    {   // drain: epilogue of the last block
+    if (wave_active) {   // drain: epilogue of the last block
         const bool any = epilogue_valu(accB, metaB);
         if (PASS >= 2) append_hits(any, accB, metaB);
     }

@@ -8,7 +8,7 @@ mkdir -p $OUT
 timeout 900 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -3 $OUT/pytest_gpu.log
 timeout 300 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"; tail -c 600 $OUT/bench.json
 export TMPDIR=/tmp
-BENCH="python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline"
+BENCH="python $ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline"
 cd /tmp
 rm -rf $OUT/prof_stats $OUT/pmc_fetch $OUT/pmc_write
 timeout 400 rocprofv3 --kernel-trace --stats -d $OUT/prof_stats -- $BENCH > $OUT/prof_stats.log 2>&1; echo "stats rc=$?"
