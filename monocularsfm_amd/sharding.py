@@ -7,8 +7,9 @@ only exchange step is an all-gather of the per-pair match lists at the end (SURV
   1. every rank holds the full descriptor store (<= 34 GB even for the largest config, vs 288 GB HBM);
   2. the pair list is cut into world_size contiguous ranges of equal total cost sum n_i * n_j;
   3. each rank runs its pairs through the C ABI;
-  4. counts: one all_reduce(sum) of a per-pair count vector; payload: one all_gather of the
-     rank-padded (queryIdx, trainIdx, distance-bits) int32 triples.  The payload is KBs-MBs, i.e.
+  4. counts: one all_reduce(sum) of a per-pair count vector; payload: rank-padded (queryIdx, trainIdx
+     [, distance-bits]) int32 rows, either gathered to the writer rank (gather_to_writer: the CLI flow, only
+     the owner of the SQLite handle needs them) or all-gathered (gather_matches).  The payload is MBs, i.e.
      latency-bound on xGMI -- no bucketing needed.
 
 `torch` is used for the process group and the device tensors of the collectives only.
@@ -104,19 +105,94 @@ def gather_matches(local_idx, local_offs, local_qt, local_dist, n_pairs, group=N
     return offs, qt, dd.view(np.float32)
 
 
+def gather_to_writer(local_idx, local_offs, local_qt, local_dist, n_pairs, dst=0, group=None, device=None,
+                     with_dist=True, force_collectives=False):
+    """The exchange step of the CLI flow: only the rank that owns the SQLite handle needs the match lists.
+
+    Every rank returns the global CSR offsets (one all_reduce of the per-pair counts); rank `dst` also returns
+    qt int32[M,2] (and dist float32[M] if with_dist) in global pair order, the other ranks return None for
+    them.  The `matches` table stores index pairs only (Database.cpp:631-654), so with_dist=False is what the
+    writer needs; the payload then is 8 bytes per match.  Per-rank pair ranges must be contiguous and in rank
+    order (partition_pairs), so the payload is reassembled by concatenation."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    local_idx = np.asarray(local_idx, np.int64)
+    local_counts = np.diff(np.asarray(local_offs, np.int64))
+    qt_local = np.ascontiguousarray(local_qt, dtype=np.int32).reshape(-1, 2)
+    if world == 1 and not (force_collectives and dist.is_initialized()):  # force: single-rank check of the RCCL path
+        offs = np.zeros(n_pairs + 1, np.int64)
+        cnt = np.zeros(n_pairs, np.int64)
+        cnt[local_idx] = local_counts
+        np.cumsum(cnt, out=offs[1:])
+        return offs, qt_local, (np.asarray(local_dist, np.float32) if with_dist else None)
+    dev = device if device is not None else torch.device("cpu")
+    rank = dist.get_rank(group)
+    if len(local_idx) > 1 and not (np.diff(local_idx) == 1).all():
+        raise ValueError("gather_to_writer needs contiguous per-rank pair ranges (partition_pairs)")
+
+    counts = torch.zeros(n_pairs, dtype=torch.int32)
+    counts[torch.from_numpy(local_idx)] = torch.from_numpy(local_counts.astype(np.int32))
+    starts = torch.full((world,), n_pairs, dtype=torch.int32)
+    starts[rank] = int(local_idx[0]) if len(local_idx) else n_pairs
+    cs = torch.cat([counts, starts]).to(dev)
+    # counts: disjoint supports -> SUM is a concatenation; starts: every rank contributes its own slot on top
+    # of the n_pairs fill of the others -> subtract (world - 1) * n_pairs afterwards
+    dist.all_reduce(cs, op=dist.ReduceOp.SUM, group=group)
+    cs = cs.cpu().numpy().astype(np.int64)
+    counts_all, starts_all = cs[:n_pairs], cs[n_pairs:] - (world - 1) * n_pairs
+    if not (np.diff(starts_all) >= 0).all():
+        raise ValueError("gather_to_writer: rank ranges are not in rank order")
+    offs = np.zeros(n_pairs + 1, np.int64)
+    np.cumsum(counts_all, out=offs[1:])
+    bounds = np.concatenate([starts_all, [n_pairs]])
+    per_rank_total = np.array([offs[bounds[r + 1]] - offs[bounds[r]] for r in range(world)], np.int64)
+
+    cols = 3 if with_dist else 2
+    max_m = max(int(per_rank_total.max()), 1)
+    m_local = int(local_counts.sum())
+    send = torch.zeros((max_m, cols), dtype=torch.int32)
+    if m_local:
+        send[:m_local, 0:2] = torch.from_numpy(qt_local)
+        if with_dist:
+            send[:m_local, 2] = torch.from_numpy(np.ascontiguousarray(local_dist, dtype=np.float32).view(np.int32))
+    send = send.to(dev)
+    if rank == dst:
+        recv = [torch.empty_like(send) for _ in range(world)]
+        dist.gather(send, recv, dst=dst, group=group)
+        M = int(offs[-1])
+        pin = dev.type == "cuda"
+        out = torch.empty((M, cols), dtype=torch.int32, pin_memory=pin)
+        at = 0
+        for r in range(world):
+            k = int(per_rank_total[r])
+            out[at:at + k].copy_(recv[r][:k], non_blocking=pin)
+            at += k
+        if pin:
+            torch.cuda.synchronize(dev)
+        allm = out.numpy()
+        qt = np.ascontiguousarray(allm[:, 0:2])
+        dd = np.ascontiguousarray(allm[:, 2]).view(np.float32) if with_dist else None
+        return offs, qt, dd
+    dist.gather(send, None, dst=dst, group=group)
+    return offs, None, None
+
+
 class ShardedMatcher:
     """All-pairs matching over the ranks of a torch.distributed process group.
 
     match_fn(pairs_subset) -> (offsets, qt, dist) defaults to the GPU context's match_pairs;
     the CPU (gloo) tests inject a stand-in to exercise partition + gather without a GPU."""
 
-    def __init__(self, ctx=None, match_fn=None, group=None, device=None, **match_kw):
+    def __init__(self, ctx=None, match_fn=None, group=None, device=None, force_collectives=False, **match_kw):
         if ctx is None and match_fn is None:
             raise ValueError("need a GPU context or a match_fn")
         self.ctx = ctx
         self.group = group
         self.device = device
         self.match_kw = match_kw
+        self.force_collectives = force_collectives
         self.match_fn = match_fn if match_fn is not None else (lambda p: ctx.match_pairs(p, **match_kw))
 
     def _rank_world(self):
@@ -137,3 +213,10 @@ class ShardedMatcher:
         pairs = np.asarray(pairs, np.int32).reshape(-1, 2)
         mine, offs, qt, d = self.match_local(pairs, n_rows)
         return gather_matches(mine, offs, qt, d, len(pairs), group=self.group, device=self.device)
+
+    def match_to_writer(self, pairs, n_rows, dst=0, with_dist=False):
+        """The CLI flow: global offsets everywhere, the match lists only on rank `dst` (the SQLite writer)."""
+        pairs = np.asarray(pairs, np.int32).reshape(-1, 2)
+        mine, offs, qt, d = self.match_local(pairs, n_rows)
+        return gather_to_writer(mine, offs, qt, d, len(pairs), dst=dst, group=self.group, device=self.device,
+                                with_dist=with_dist, force_collectives=self.force_collectives)

@@ -73,13 +73,23 @@ def _worker(rank, world, port, out_dir):
     sm = ShardedMatcher(match_fn=match_fn)
     offs, qt, d = sm.match_all(pairs, n_rows)
     np.savez(os.path.join(out_dir, "r%d.npz" % rank), offs=offs, qt=qt, d=d)
+    # the CLI flow: lists only on the writer rank (with and without the distance column)
+    dst = world - 1
+    for with_dist in (True, False):
+        woffs, wqt, wd = sm.match_to_writer(pairs, n_rows, dst=dst, with_dist=with_dist)
+        assert np.array_equal(woffs, offs)
+        if rank == dst:
+            assert np.array_equal(wqt, qt)
+            assert (wd is None) if not with_dist else np.array_equal(wd.view(np.int32), d.view(np.int32))
+        else:
+            assert wqt is None and wd is None
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_rank_gather_equals_single_process(tmp_path, oracle):
+@pytest.mark.parametrize("world", [2, 3])
+def test_multi_rank_gather_equals_single_process(tmp_path, oracle, world):
     from monocularsfm_amd import synth
-    world = 2
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     imgs = synth.rootsift_images(7, [90, 120, 60, 100, 2, 75, 110], seed=21, n_proto=260)
     pairs = [(i, j) for i in range(7) for j in range(i)]
