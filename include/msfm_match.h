@@ -80,6 +80,7 @@ typedef struct msfm_profile {
     int sweep2_launches;
     int compacted_pairs;       /* pairs whose sweep 2 ran on the compacted live rows only */
     int64_t sweep2_descriptor_pairs; /* descriptor pairs sweep 2 actually multiplied (padded rows included) */
+    double verify_ms;          /* geometric verification kernels (msfm_match_pairs_verified) */
 } msfm_profile;
 
 /* ---- context ------------------------------------------------------------------------- */
@@ -122,6 +123,29 @@ int msfm_match_pair(msfm_ctx* ctx, int id1, int id2, float ratio, int cross_chec
 int msfm_match_pairs(msfm_ctx* ctx, const int32_t* pairs, int n_pairs,
                      const msfm_match_params* params, int64_t* out_offsets);
 int msfm_fetch_matches(msfm_ctx* ctx, int32_t* out_qt, float* out_dist);
+
+/* ---- batch of pairs with the geometric verification hand-off -------------------------------
+ * Lines 36-60 of FeatureMatching.cpp in one call: matching as above, then FeatureUtils::FilterMatches
+ * (src/Feature/FeatureUtils.cpp:176-206: GetAlignedPointsFromMatches + cv::findFundamentalMat(FM_RANSAC,
+ * 3.0, 0.99) + keep the inliers) for every pair, on the device, before the lists are copied out.
+ * Needs the keypoint coordinates of every image of the batch: msfm_upload_keypoints after msfm_upload_image
+ * (kpts: n rows of `stride_floats` floats, x and y first -- the Database's keypoint blob has stride 4:
+ * x, y, size, angle; n >= descriptor rows).  NULL `verify` = the reference's constants (3.0 px, 0.99, OpenCV's
+ * 1000-iteration cap).  OpenCV's RANSAC (RNG, 7-point solver) cannot be reproduced without OpenCV: this entry
+ * point is OUTSIDE the bit-parity claim; it is bit-identical to the host twin
+ * monocularsfm_amd/host/GeometricVerification.cpp (shared arithmetic, csrc/msfm_fmat.h).
+ * Cases as in findFundamentalMat: no matches -> none; < 7 -> none; exactly 7 -> all; otherwise RANSAC with
+ * the adaptive iteration bound, and a consensus set below 8 keeps none. */
+typedef struct msfm_verify_params {
+    double threshold;            /* pixels (reference: 3.0) */
+    double confidence;           /* (reference: 0.99) */
+    int max_iters;               /* hypotheses per pair at most (OpenCV default: 1000) */
+    unsigned long long seed;     /* sampling stream, the same for every pair */
+} msfm_verify_params;
+int msfm_upload_keypoints(msfm_ctx* ctx, int image_id, const float* kpts, int n, int stride_floats);
+int msfm_match_pairs_verified(msfm_ctx* ctx, const int32_t* pairs, int n_pairs,
+                              const msfm_match_params* params, const msfm_verify_params* verify,
+                              int64_t* out_offsets);
 
 /* ---- knnMatch(k=2) twin (parity/debug) ----------------------------------------------------
  * Both directions of cv::BFMatcher(NORM_L2).knnMatch(.., 2) for one pair

@@ -22,12 +22,16 @@ EXPORTS = [
     "msfm_get_profile", "msfm_upload_image", "msfm_image_rows", "msfm_clear_images",
     "msfm_match_pair", "msfm_match_pairs", "msfm_fetch_matches", "msfm_knn2_pair",
     "msfm_topscale_select", "msfm_pair_id", "msfm_pair_from_id", "msfm_swap_image_pair",
-    "msfm_version",
+    "msfm_version", "msfm_upload_keypoints", "msfm_match_pairs_verified",
 ]
 
 
 class MatchParams(C.Structure):
     _fields_ = [("ratio", C.c_float), ("cross_check", C.c_int), ("max_distance", C.c_double)]
+
+
+class VerifyParams(C.Structure):
+    _fields_ = [("threshold", C.c_double), ("confidence", C.c_double), ("max_iters", C.c_int), ("seed", C.c_ulonglong)]
 
 
 class Profile(C.Structure):
@@ -38,7 +42,7 @@ class Profile(C.Structure):
                 ("candidates", C.c_int64), ("prefilter_descriptor_pairs", C.c_int64),
                 ("exact_descriptor_pairs", C.c_int64), ("tie_rows", C.c_int64),
                 ("sweep2_ms", C.c_double), ("sweep2_launches", C.c_int), ("compacted_pairs", C.c_int),
-                ("sweep2_descriptor_pairs", C.c_int64)]
+                ("sweep2_descriptor_pairs", C.c_int64), ("verify_ms", C.c_double)]
 
 
 class MsfmError(RuntimeError):
@@ -76,6 +80,9 @@ def load():
     L.msfm_match_pair.argtypes = [vp, C.c_int, C.c_int, C.c_float, C.c_int, C.c_double, ip, fp, C.POINTER(C.c_int)]
     L.msfm_match_pairs.argtypes = [vp, ip, C.c_int, C.POINTER(MatchParams), C.POINTER(C.c_int64)]
     L.msfm_fetch_matches.argtypes = [vp, ip, fp]
+    L.msfm_upload_keypoints.argtypes = [vp, C.c_int, fp, C.c_int, C.c_int]
+    L.msfm_match_pairs_verified.argtypes = [vp, ip, C.c_int, C.POINTER(MatchParams), C.POINTER(VerifyParams),
+                                            C.POINTER(C.c_int64)]
     L.msfm_knn2_pair.argtypes = [vp, C.c_int, C.c_int, ip, fp, fp, ip, fp, fp]
     L.msfm_topscale_select.argtypes = [fp, C.c_int, C.c_int, ip, C.POINTER(C.c_int)]
     L.msfm_pair_id.argtypes = [C.c_int, C.c_int, ip]
@@ -190,6 +197,31 @@ class Context:
         prm = MatchParams(ratio, int(bool(cross_check)), max_distance)
         self._chk(self._L.msfm_match_pairs(self._h, _ip(pairs), P, C.byref(prm),
                                            offs.ctypes.data_as(C.POINTER(C.c_int64))))
+        if not fetch:
+            return offs, None, None
+        M = int(offs[-1])
+        qt = np.empty((max(M, 1), 2), np.int32)
+        d = np.empty(max(M, 1), np.float32)
+        self._chk(self._L.msfm_fetch_matches(self._h, _ip(qt), _fp(d)))
+        return offs, qt[:M], d[:M]
+
+    def upload_keypoints(self, image_id, kpts):
+        """kpts: n x k float32 (k >= 2), x and y in the first two columns."""
+        kpts = np.ascontiguousarray(kpts, dtype=np.float32)
+        if kpts.ndim != 2 or kpts.shape[1] < 2:
+            raise ValueError("keypoints must be n x (>=2)")
+        self._chk(self._L.msfm_upload_keypoints(self._h, int(image_id), _fp(kpts), kpts.shape[0], kpts.shape[1]))
+
+    def match_pairs_verified(self, pairs, ratio=0.8, cross_check=True, max_distance=0.7, threshold=3.0,
+                             confidence=0.99, max_iters=1000, seed=0x5eed5eed, fetch=True):
+        """match_pairs + FeatureUtils::FilterMatches (F-matrix RANSAC) on the device."""
+        pairs = np.ascontiguousarray(np.asarray(pairs, dtype=np.int32).reshape(-1, 2))
+        P = pairs.shape[0]
+        offs = np.zeros(P + 1, np.int64)
+        prm = MatchParams(ratio, int(bool(cross_check)), max_distance)
+        vprm = VerifyParams(threshold, confidence, int(max_iters), int(seed))
+        self._chk(self._L.msfm_match_pairs_verified(self._h, _ip(pairs), P, C.byref(prm), C.byref(vprm),
+                                                    offs.ctypes.data_as(C.POINTER(C.c_int64))))
         if not fetch:
             return offs, None, None
         M = int(offs[-1])

@@ -9,6 +9,7 @@
 #include "msfm_match.h"
 #include "msfm_kernels.hip.h"
 #include "msfm_prefilter.hip.h"
+#include "msfm_verify.hip.h"
 
 #include <algorithm>
 #include <cstdio>
@@ -56,6 +57,9 @@ struct Image {
     float c = 1.f;            // their scale (power of two)
     float nrm_max = 0.f, abs_max = 0.f;
     bool pf_safe = false;
+    // keypoint coordinates (x, y) for the geometric verification; nk = -1: not uploaded
+    float2* kxy = nullptr;
+    int nk = -1;
 };
 
 void free_image(Image& im) {
@@ -64,6 +68,7 @@ void free_image(Image& im) {
     if (im.h16) (void)hipFree(im.h16);
     if (im.nrm) (void)hipFree(im.nrm);
     if (im.ext) (void)hipFree(im.ext);
+    if (im.kxy) (void)hipFree(im.kxy);
     im = Image{};
 }
 
@@ -89,6 +94,9 @@ struct msfm_ctx {
     int prefilter = 1;
     DevBuf d_pf, d_tu, d_tv, d_cand, d_cand_s, d_cand_count, d_best, d_second, d_maxima;
     DevBuf d_live_cnt, d_cmp_h, d_cmp_tu, d_live_idx, d_vpairs, d_vpf, d_vitems, d_jobs, d_lists;
+    // geometric verification
+    DevBuf d_vf_pairs, d_vf_x1, d_vf_y1, d_vf_x2, d_vf_y2, d_vf_hyp, d_vf_best_it, d_vf_best_count, d_vf_flags,
+        d_st2_qt, d_st2_d, d_counts2;
 
     // results of the last msfm_match_pairs call
     bool have_results = false;
@@ -732,7 +740,9 @@ void msfm_destroy(msfm_ctx* ctx) {
                       &ctx->d_out_d, &ctx->d_fix_count, &ctx->d_fix_list, &ctx->d_pf, &ctx->d_tu, &ctx->d_tv,
                       &ctx->d_cand, &ctx->d_cand_s, &ctx->d_cand_count, &ctx->d_best, &ctx->d_second, &ctx->d_maxima,
                       &ctx->d_live_cnt, &ctx->d_cmp_h, &ctx->d_cmp_tu, &ctx->d_live_idx, &ctx->d_vpairs, &ctx->d_vpf,
-                      &ctx->d_vitems, &ctx->d_jobs, &ctx->d_lists};
+                      &ctx->d_vitems, &ctx->d_jobs, &ctx->d_lists, &ctx->d_vf_pairs, &ctx->d_vf_x1, &ctx->d_vf_y1,
+                      &ctx->d_vf_x2, &ctx->d_vf_y2, &ctx->d_vf_hyp, &ctx->d_vf_best_it, &ctx->d_vf_best_count,
+                      &ctx->d_vf_flags, &ctx->d_st2_qt, &ctx->d_st2_d, &ctx->d_counts2};
     for (DevBuf* b : bufs) b->release();
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(ctx->stream);
@@ -863,8 +873,8 @@ int msfm_clear_images(msfm_ctx* ctx) {
     return MSFM_OK;
 }
 
-int msfm_match_pairs(msfm_ctx* ctx, const int32_t* pairs, int n_pairs, const msfm_match_params* params,
-                     int64_t* out_offsets) {
+static int match_pairs_impl(msfm_ctx* ctx, const int32_t* pairs, int n_pairs, const msfm_match_params* params,
+                            const msfm_verify_params* verify, int64_t* out_offsets) {
     if (!ctx) return MSFM_E_INVALID;
     if (n_pairs < 0 || (n_pairs > 0 && !pairs) || !out_offsets) return fail(ctx, MSFM_E_INVALID, "bad pair list");
     msfm_match_params prm = {0.8f, 1, 0.7};
@@ -900,6 +910,13 @@ int msfm_match_pairs(msfm_ctx* ctx, const int32_t* pairs, int n_pairs, const msf
             PfPair pp;
             int rc = fill_pair(ctx, pairs[2 * end], pairs[2 * end + 1], pd, pp);
             if (rc != MSFM_OK) return rc;
+            if (verify) {
+                const Image& ia = ctx->images[pairs[2 * end]];
+                const Image& ib = ctx->images[pairs[2 * end + 1]];
+                if (ia.nk < ia.n || ib.nk < ib.n)
+                    return fail(ctx, MSFM_E_STATE, "geometric verification needs msfm_upload_keypoints for image " +
+                                                       std::to_string(ia.nk < ia.n ? pairs[2 * end] : pairs[2 * end + 1]));
+            }
             // partial-result scratch of the larger of the two paths (prefilter: 2x slots + candidates)
             const long long need = pd.valid ? ((long long)pd.n1pad + 2 * (long long)pd.a_blocks * pd.n2pad +
                                                3 * (8LL * (pd.n1 + pd.n2) + 1024)) : 0;
@@ -911,7 +928,7 @@ int msfm_match_pairs(msfm_ctx* ctx, const int32_t* pairs, int n_pairs, const msf
         }
         const size_t P = b.pairs.size();
         const size_t ev_base = ev_next;
-        ev_next += 6;
+        ev_next += 8;
         bool exact_launched = false;
         int rc = run_knn(ctx, b, ev_base, &exact_launched, prune);
         if (rc != MSFM_OK) return rc;
@@ -927,12 +944,61 @@ int msfm_match_pairs(msfm_ctx* ctx, const int32_t* pairs, int n_pairs, const msf
                            ctx->d_k_i0.as<int>(), ctx->d_k_d0.as<float>(), ctx->d_k_d1.as<float>(),
                            ctx->d_st_qt.as<int2>(), ctx->d_st_d.as<float>(), ctx->d_counts.as<int>());
         HIPCHK(ctx, hipGetLastError());
-        hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(256), 0, ctx->stream, ctx->d_counts.as<int>(),
+        const int* d_counts = ctx->d_counts.as<int>();
+        const int2* d_st_qt = ctx->d_st_qt.as<int2>();
+        const float* d_st_d = ctx->d_st_d.as<float>();
+        if (verify) {
+            // FeatureUtils::FilterMatches on the staged lists: all hypotheses of all pairs at once
+            VerifyParams vprm = {verify->threshold * verify->threshold, verify->confidence, verify->max_iters, 0, verify->seed};
+            const long long oe = std::max<long long>(1, b.out_elems);
+            std::vector<VerifyPair> vpairs(P);
+            for (size_t p = 0; p < P; ++p)
+                vpairs[p] = VerifyPair{ctx->images[pairs[2 * (begin + (int)p)]].kxy, ctx->images[pairs[2 * (begin + (int)p) + 1]].kxy};
+            HIPCHK(ctx, ctx->d_vf_pairs.ensure(P * sizeof(VerifyPair)));
+            HIPCHK(ctx, ctx->d_vf_x1.ensure(oe * 4));
+            HIPCHK(ctx, ctx->d_vf_y1.ensure(oe * 4));
+            HIPCHK(ctx, ctx->d_vf_x2.ensure(oe * 4));
+            HIPCHK(ctx, ctx->d_vf_y2.ensure(oe * 4));
+            HIPCHK(ctx, ctx->d_vf_flags.ensure(oe));
+            HIPCHK(ctx, ctx->d_vf_hyp.ensure(P * (size_t)vprm.max_iters * 4));
+            HIPCHK(ctx, ctx->d_vf_best_it.ensure(P * 4));
+            HIPCHK(ctx, ctx->d_vf_best_count.ensure(P * 4));
+            HIPCHK(ctx, ctx->d_st2_qt.ensure(oe * sizeof(int2)));
+            HIPCHK(ctx, ctx->d_st2_d.ensure(oe * 4));
+            HIPCHK(ctx, ctx->d_counts2.ensure(P * 4));
+            HIPCHK(ctx, hipMemcpyAsync(ctx->d_vf_pairs.p, vpairs.data(), P * sizeof(VerifyPair), hipMemcpyHostToDevice, ctx->stream));
+            hipEvent_t v0 = get_event(ctx, ev_base + 6), v1 = get_event(ctx, ev_base + 7);
+            if (!v0 || !v1) return fail(ctx, MSFM_E_DEVICE, "hipEventCreate failed");
+            HIPCHK(ctx, hipEventRecord(v0, ctx->stream));
+            const PairDesc* dp = ctx->d_pairs.as<PairDesc>();
+            float *x1 = ctx->d_vf_x1.as<float>(), *y1 = ctx->d_vf_y1.as<float>(), *x2 = ctx->d_vf_x2.as<float>(), *y2 = ctx->d_vf_y2.as<float>();
+            hipLaunchKernelGGL(vf_points_kernel, dim3((unsigned)P), dim3(256), 0, ctx->stream, dp, ctx->d_vf_pairs.as<VerifyPair>(),
+                               d_counts, d_st_qt, x1, y1, x2, y2);
+            HIPCHK(ctx, hipGetLastError());
+            hipLaunchKernelGGL(vf_hypotheses_kernel, dim3((unsigned)((vprm.max_iters + 255) / 256), (unsigned)P), dim3(256), 0, ctx->stream,
+                               dp, d_counts, (const float*)x1, (const float*)y1, (const float*)x2, (const float*)y2,
+                               ctx->d_vf_hyp.as<int>(), vprm);
+            HIPCHK(ctx, hipGetLastError());
+            hipLaunchKernelGGL(vf_select_kernel, dim3((unsigned)((P + 63) / 64)), dim3(64), 0, ctx->stream, d_counts,
+                               (const int*)ctx->d_vf_hyp.as<int>(), (int)P, vprm, ctx->d_vf_best_it.as<int>(), ctx->d_vf_best_count.as<int>());
+            HIPCHK(ctx, hipGetLastError());
+            hipLaunchKernelGGL(vf_mask_compact_kernel, dim3((unsigned)P), dim3(256), 0, ctx->stream, dp, d_counts, d_st_qt, d_st_d,
+                               (const float*)x1, (const float*)y1, (const float*)x2, (const float*)y2,
+                               (const int*)ctx->d_vf_best_it.as<int>(), (const int*)ctx->d_vf_best_count.as<int>(),
+                               ctx->d_vf_flags.as<unsigned char>(), vprm, ctx->d_st2_qt.as<int2>(), ctx->d_st2_d.as<float>(),
+                               ctx->d_counts2.as<int>());
+            HIPCHK(ctx, hipGetLastError());
+            HIPCHK(ctx, hipEventRecord(v1, ctx->stream));
+            d_counts = ctx->d_counts2.as<int>();
+            d_st_qt = ctx->d_st2_qt.as<int2>();
+            d_st_d = ctx->d_st2_d.as<float>();
+        }
+        hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(256), 0, ctx->stream, d_counts,
                            ctx->d_offsets.as<long long>(), (int)P);
         HIPCHK(ctx, hipGetLastError());
         hipLaunchKernelGGL(gather_kernel, dim3((unsigned)P), dim3(256), 0, ctx->stream, ctx->d_pairs.as<PairDesc>(),
-                           ctx->d_counts.as<int>(), ctx->d_offsets.as<long long>(), ctx->d_st_qt.as<int2>(),
-                           ctx->d_st_d.as<float>(), ctx->d_out_qt.as<int2>(), ctx->d_out_d.as<float>());
+                           d_counts, ctx->d_offsets.as<long long>(), d_st_qt,
+                           d_st_d, ctx->d_out_qt.as<int2>(), ctx->d_out_d.as<float>());
         HIPCHK(ctx, hipGetLastError());
 
         std::vector<long long> offs(P + 1);
@@ -951,6 +1017,11 @@ int msfm_match_pairs(msfm_ctx* ctx, const int32_t* pairs, int n_pairs, const msf
         for (size_t p = 0; p < P; ++p) ctx->res_offsets[(size_t)begin + p + 1] = (int64_t)base + offs[p + 1];
         rc = accumulate_kernel_time(ctx, ev_base, exact_launched);
         if (rc != MSFM_OK) return rc;
+        if (verify) {
+            float vms = 0.f;
+            HIPCHK(ctx, hipEventElapsedTime(&vms, ctx->ev_pool[ev_base + 6], ctx->ev_pool[ev_base + 7]));
+            ctx->prof.verify_ms += vms;
+        }
         begin = end;
     }
     HIPCHK(ctx, hipEventRecord(ev_end, ctx->stream));
@@ -960,6 +1031,40 @@ int msfm_match_pairs(msfm_ctx* ctx, const int32_t* pairs, int n_pairs, const msf
     ctx->prof.total_device_ms = ms;
     std::memcpy(out_offsets, ctx->res_offsets.data(), ((size_t)n_pairs + 1) * sizeof(int64_t));
     ctx->have_results = true;
+    return MSFM_OK;
+}
+
+int msfm_match_pairs(msfm_ctx* ctx, const int32_t* pairs, int n_pairs, const msfm_match_params* params,
+                     int64_t* out_offsets) {
+    return match_pairs_impl(ctx, pairs, n_pairs, params, nullptr, out_offsets);
+}
+
+int msfm_match_pairs_verified(msfm_ctx* ctx, const int32_t* pairs, int n_pairs, const msfm_match_params* params,
+                              const msfm_verify_params* verify, int64_t* out_offsets) {
+    msfm_verify_params v = {3.0, 0.99, 1000, 0x5eed5eedULL};  // FeatureUtils.cpp:196: FM_RANSAC, 3.0, 0.99; OpenCV's maxIters
+    if (verify) v = *verify;
+    if (!(v.threshold >= 0.0) || !(v.confidence > 0.0) || !(v.confidence < 1.0) || v.max_iters < 1 || v.max_iters > (1 << 16))
+        return fail(ctx, MSFM_E_INVALID, "bad verification parameters");
+    return match_pairs_impl(ctx, pairs, n_pairs, params, &v, out_offsets);
+}
+
+int msfm_upload_keypoints(msfm_ctx* ctx, int image_id, const float* kpts, int n, int stride_floats) {
+    if (!ctx) return MSFM_E_INVALID;
+    if (image_id < 0 || image_id >= kSlots) return fail(ctx, MSFM_E_INVALID, "image id out of range");
+    if (n < 0 || (n > 0 && !kpts) || stride_floats < 2) return fail(ctx, MSFM_E_INVALID, "bad keypoint array");
+    Image& im = ctx->images[image_id];
+    if (im.n < 0) return fail(ctx, MSFM_E_NOIMAGE, "msfm_upload_keypoints before msfm_upload_image for image " + std::to_string(image_id));
+    if (n < im.n) return fail(ctx, MSFM_E_INVALID, "fewer keypoints than descriptor rows");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (im.kxy) (void)hipFree(im.kxy);
+    im.kxy = nullptr;
+    im.nk = -1;
+    std::vector<float2> xy((size_t)std::max(n, 1));
+    for (int i = 0; i < n; ++i) xy[(size_t)i] = make_float2(kpts[(size_t)i * stride_floats], kpts[(size_t)i * stride_floats + 1]);
+    HIPCHK(ctx, hipMalloc((void**)&im.kxy, xy.size() * sizeof(float2)));
+    HIPCHK(ctx, hipMemcpyAsync(im.kxy, xy.data(), xy.size() * sizeof(float2), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    im.nk = n;
     return MSFM_OK;
 }
 

@@ -177,6 +177,9 @@ constexpr int kPfRing = 3;
 #ifndef MSFM_ABL
 #define MSFM_ABL 0
 #endif
+#ifndef MSFM_HINT_VALU
+#define MSFM_HINT_VALU 3
+#endif
 constexpr bool kAblNoEpi = MSFM_ABL == 1 || MSFM_ABL == 5 || MSFM_ABL == 6;
 constexpr bool kAblNoMfma = MSFM_ABL == 2;
 constexpr bool kAblNoLds = MSFM_ABL == 3 || MSFM_ABL == 5 || MSFM_ABL == 6;
@@ -431,10 +434,13 @@ __global__ __launch_bounds__(kPfThreads, 2) void approx_kernel(
     };
     // interleave hint: one MFMA, then a slice of the epilogue's VALU work, 18 times
     auto interleave_hint = [&]() {
+#ifdef MSFM_NO_HINT
+        return;
+#endif
 #pragma unroll
         for (int k = 0; k < 18; ++k) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                          // 1 MFMA
-            __builtin_amdgcn_sched_group_barrier(0x002, PASS == 1 ? 3 : (PASS == 2 ? 4 : 1), 0);      // VALU
+            __builtin_amdgcn_sched_group_barrier(0x002, PASS == 1 ? MSFM_HINT_VALU : (PASS == 2 ? 4 : 1), 0);      // VALU
         }
     };
 

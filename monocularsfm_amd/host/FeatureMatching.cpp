@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <iostream>
+#include <string>
 #include <thread>
 
 #include "GeometricVerification.h"
@@ -16,6 +17,23 @@
 namespace MonocularSfM {
 
 namespace {
+// MSFM_CLI_TIMING=1: wall-clock per phase on stderr when the matcher closes
+struct PhaseClock {
+    double exist = 0, read_desc = 0, device = 0, read_kp = 0, verify = 0, emit = 0, preemptive = 0;
+    bool on = std::getenv("MSFM_CLI_TIMING") != nullptr;
+    void Report() const {
+        if (!on || exist + read_desc + device + emit == 0) return;
+        std::fprintf(stderr, "[msfm timing] exist-check %.3f s | read descriptors + upload %.3f s | device match + fetch %.3f s | "
+                             "pre-emptive filter %.3f s | read keypoints %.3f s | verification %.3f s | stdout + WriteMatches %.3f s\n",
+                     exist, read_desc, device, preemptive, read_kp, verify, emit);
+    }
+} g_clock;
+struct Lap {
+    double* acc;
+    Timer t;
+    explicit Lap(double* a) : acc(a) { t.Start(); }
+    ~Lap() { *acc += t.ElapsedSeconds(); }
+};
 [[noreturn]] void Die(msfm_ctx* ctx, const char* what, int rc) {
     std::fprintf(stderr, "ComputeMatches: %s failed (status %d): %s\n", what, rc, ctx ? msfm_last_error(ctx) : "");
     std::exit(EXIT_FAILURE);
@@ -67,6 +85,8 @@ void FeatureMatcher::CloseDatabaseAndDevice() {
     }
     resident_.clear();
     keypoints_cache_.clear();
+    g_clock.Report();
+    g_clock = PhaseClock();
 }
 
 void FeatureMatcher::EnsureResident(image_t image_id) {
@@ -77,41 +97,72 @@ void FeatureMatcher::EnsureResident(image_t image_id) {
 }
 
 void FeatureMatcher::MatchImagePairs(const std::vector<std::pair<image_t, image_t>>& image_pairs) {
-    database_->BeginTransaction();
+    MatchImagePairGroups({image_pairs});
+}
+
+// The reference calls MatchImagePairs once per group of <= 100 pairs: one transaction, and per pair either
+// the "Existing, Continue!" line or match -> filter -> verify -> stdout -> WriteMatches
+// (src/Feature/FeatureMatching.cpp:10-73).  Here several groups are computed together -- one batched GPU
+// call, one parallel verification pass -- and then EMITTED group by group, pair by pair, in the reference's
+// order, so stdout, the rows and the transaction boundaries are the same while the device sees thousands
+// of pairs per launch instead of 100.
+void FeatureMatcher::MatchImagePairGroups(const std::vector<std::vector<std::pair<image_t, image_t>>>& groups) {
+    struct Slot { int todo_index; };  // -1: a row exists (or an earlier group of this call writes it)
+    std::vector<std::vector<Slot>> slots(groups.size());
     std::vector<int32_t> todo;
-    for (const auto& image_pair : image_pairs) {
-        const image_t image_id1 = image_pair.first, image_id2 = image_pair.second;
-        if (database_->ExistMatches(image_id1, image_id2)) {
-            std::cout << "Compute Matches " << image_id1 << " - " << image_id2 << " Existing, Continue!" << std::endl;
-            continue;
+    std::set<std::pair<image_t, image_t>> scheduled;
+    Lap* lap = new Lap(&g_clock.exist);
+    for (size_t g = 0; g < groups.size(); ++g) {
+        slots[g].resize(groups[g].size());
+        for (size_t k = 0; k < groups[g].size(); ++k) {
+            const image_t image_id1 = groups[g][k].first, image_id2 = groups[g][k].second;
+            const std::pair<image_t, image_t> key(std::min(image_id1, image_id2), std::max(image_id1, image_id2));
+            if (scheduled.count(key) || database_->ExistMatches(image_id1, image_id2)) {
+                slots[g][k].todo_index = -1;
+                continue;
+            }
+            scheduled.insert(key);
+            slots[g][k].todo_index = (int)(todo.size() / 2);
+            todo.push_back(image_id1);
+            todo.push_back(image_id2);
         }
-        todo.push_back(image_id1);
-        todo.push_back(image_id2);
     }
+    delete lap;
     const int P = (int)(todo.size() / 2);
+    std::vector<std::vector<DMatch>> verified((size_t)P);
+    std::vector<double> verify_seconds((size_t)P, 0.0);
+    double gpu_seconds_per_pair = 0.0;
     if (P > 0) {
         Timer timer;
         timer.Start();
-        for (int32_t id : todo) EnsureResident(id);
+        {
+            Lap l(&g_clock.read_desc);
+            for (int32_t id : todo) EnsureResident(id);
+        }
         msfm_match_params prm;
         prm.ratio = (float)distance_ratio_;  // ComputeCrossMatches takes `const float distance_ratio`
         prm.cross_check = cross_check_ ? 1 : 0;
         prm.max_distance = max_distance_;
         std::vector<int64_t> offs((size_t)P + 1);
-        MSFM_CALL(ctx_, msfm_match_pairs(ctx_, todo.data(), P, &prm, offs.data()));
-        std::vector<int32_t> qt((size_t)offs[(size_t)P] * 2 + 2);
-        std::vector<float> dist((size_t)offs[(size_t)P] + 1);
-        MSFM_CALL(ctx_, msfm_fetch_matches(ctx_, qt.data(), dist.data()));
-        const double gpu_seconds_per_pair = timer.ElapsedSeconds() / P;
+        std::vector<int32_t> qt;
+        std::vector<float> dist;
+        {
+            Lap l(&g_clock.device);
+            MSFM_CALL(ctx_, msfm_match_pairs(ctx_, todo.data(), P, &prm, offs.data()));
+            qt.resize((size_t)offs[(size_t)P] * 2 + 2);
+            dist.resize((size_t)offs[(size_t)P] + 1);
+            MSFM_CALL(ctx_, msfm_fetch_matches(ctx_, qt.data(), dist.data()));
+        }
+        gpu_seconds_per_pair = timer.ElapsedSeconds() / P;
 
-        // Geometric verification (FeatureUtils::FilterMatches) is host work, ~1 ms per pair: keypoints are
-        // read once per image (SQLite handle: this thread only) and the pairs of the batch are verified
-        // on all host cores; rows are then written in pair order by this thread.
-        std::vector<std::vector<DMatch>> verified((size_t)P);
-        std::vector<double> verify_seconds((size_t)P, 0.0);
-        if (geometric_verification_)
+        // Geometric verification (FeatureUtils::FilterMatches) is host work: keypoints are read once per
+        // image (SQLite handle: this thread only) and the pairs are verified on all host cores.
+        if (geometric_verification_) {
+            Lap l(&g_clock.read_kp);
             for (int32_t id : todo)
                 if (!keypoints_cache_.count(id)) keypoints_cache_[id] = database_->ReadKeyPoints(id);
+        }
+        Lap lv(&g_clock.verify);
         auto verify_pair = [&](int p) {
             Timer pair_timer;
             pair_timer.Start();
@@ -129,31 +180,50 @@ void FeatureMatcher::MatchImagePairs(const std::vector<std::pair<image_t, image_
                 verified[(size_t)p].swap(prune_matches);
             verify_seconds[(size_t)p] = pair_timer.ElapsedSeconds();
         };
-        {
-            const int nthreads = std::max(1, std::min<int>(P, (int)std::thread::hardware_concurrency()));
-            std::atomic<int> next(0);
-            std::vector<std::thread> pool;
-            for (int t = 1; t < nthreads; ++t)
-                pool.emplace_back([&] { for (int p; (p = next.fetch_add(1)) < P;) verify_pair(p); });
-            for (int p; (p = next.fetch_add(1)) < P;) verify_pair(p);
-            for (auto& th : pool) th.join();
-        }
-        for (int p = 0; p < P; ++p) {
-            const image_t image_id1 = todo[2 * (size_t)p], image_id2 = todo[2 * (size_t)p + 1];
-            std::cout << "Compute Matches " << image_id1 << " - " << image_id2 << " ... " << std::endl;
-            std::cout << "\t matches num : " << verified[(size_t)p].size() << std::endl;
-            std::cout << "\t ";
-            Timer::Print(gpu_seconds_per_pair + verify_seconds[(size_t)p], "seconds");
-            std::cout << std::endl;
+        const int nthreads = std::max(1, std::min<int>(P / 4 + 1, (int)std::thread::hardware_concurrency()));
+        std::atomic<int> next(0);
+        std::vector<std::thread> pool;
+        for (int t = 1; t < nthreads; ++t)
+            pool.emplace_back([&] { for (int p; (p = next.fetch_add(1)) < P;) verify_pair(p); });
+        for (int p; (p = next.fetch_add(1)) < P;) verify_pair(p);
+        for (auto& th : pool) th.join();
+    }
+    // emission: the reference's order, one transaction per group
+    Lap le(&g_clock.emit);
+    std::string out;
+    char buf[160];
+    for (size_t g = 0; g < groups.size(); ++g) {
+        database_->BeginTransaction();
+        out.clear();
+        for (size_t k = 0; k < groups[g].size(); ++k) {
+            const image_t image_id1 = groups[g][k].first, image_id2 = groups[g][k].second;
+            const int p = slots[g][k].todo_index;
+            if (p < 0) {
+                std::snprintf(buf, sizeof(buf), "Compute Matches %d - %d Existing, Continue!\n", image_id1, image_id2);
+                out += buf;
+                continue;
+            }
+            std::snprintf(buf, sizeof(buf), "Compute Matches %d - %d ... \n\t matches num : %zu\n\t ", image_id1, image_id2,
+                          verified[(size_t)p].size());
+            out += buf;
+            out += Timer::Format(gpu_seconds_per_pair + verify_seconds[(size_t)p], "seconds");
+            out += "\n";
             database_->WriteMatches(image_id1, image_id2, verified[(size_t)p]);
         }
+        std::cout << out << std::flush;
+        database_->EndTransaction();
     }
-    database_->EndTransaction();
+}
+
+namespace {
+constexpr size_t kSuperBatchPairs = 4096;  // pairs computed per device call (the reference's groups are <= 100)
 }
 
 void SequentialFeatureMatcher::RunMatching() {
     OpenDatabaseAndDevice();
     const std::vector<Database::Image> images = database_->ReadAllImages();
+    std::vector<std::vector<std::pair<image_t, image_t>>> groups;
+    size_t pending = 0;
     for (size_t i = 1; i < images.size(); ++i) {
         std::vector<std::pair<image_t, image_t>> image_pairs;
         for (int k = 1; k <= overlap_; ++k) {
@@ -161,14 +231,31 @@ void SequentialFeatureMatcher::RunMatching() {
             if (j < 0) break;
             image_pairs.emplace_back((image_t)i, (image_t)j);
         }
-        MatchImagePairs(image_pairs);
+        pending += image_pairs.size();
+        groups.push_back(std::move(image_pairs));
+        if (pending >= kSuperBatchPairs) {
+            MatchImagePairGroups(groups);
+            groups.clear();
+            pending = 0;
+        }
     }
+    if (!groups.empty()) MatchImagePairGroups(groups);
     CloseDatabaseAndDevice();
 }
 
 void BruteFeatureMatcher::RunMatching() {
     OpenDatabaseAndDevice();
     const std::vector<Database::Image> images = database_->ReadAllImages();
+    // the reference's groups: a flush every max_pairs_size_ pairs and at the end of every row i
+    std::vector<std::vector<std::pair<image_t, image_t>>> groups;
+    size_t pending = 0;
+    auto flush = [&]() {
+        if (groups.empty()) return;
+        if (is_preemtive_) PreemptivelyFilterGroups(&groups);
+        MatchImagePairGroups(groups);
+        groups.clear();
+        pending = 0;
+    };
     for (size_t i = 0; i < images.size(); ++i) {
         std::vector<std::pair<image_t, image_t>> image_pairs;
         int cur_pairs_size = 0;
@@ -176,25 +263,44 @@ void BruteFeatureMatcher::RunMatching() {
             image_pairs.emplace_back((image_t)i, (image_t)j);
             cur_pairs_size += 1;
             if (cur_pairs_size == max_pairs_size_) {
-                if (is_preemtive_) image_pairs = PreemptivelyFilterImagePairs(image_pairs);
-                MatchImagePairs(image_pairs);
+                pending += image_pairs.size();
+                groups.push_back(image_pairs);
                 image_pairs.clear();
                 cur_pairs_size = 0;
             }
         }
         if (cur_pairs_size != 0) {
-            if (is_preemtive_) image_pairs = PreemptivelyFilterImagePairs(image_pairs);
-            MatchImagePairs(image_pairs);
-            image_pairs.clear();
+            pending += image_pairs.size();
+            groups.push_back(image_pairs);
         }
+        if (pending >= kSuperBatchPairs) flush();
     }
+    flush();
     CloseDatabaseAndDevice();
 }
 
-std::vector<std::pair<image_t, image_t>> BruteFeatureMatcher::PreemptivelyFilterImagePairs(
-    std::vector<std::pair<image_t, image_t>> image_pairs) {
-    std::vector<std::pair<image_t, image_t>> filtered_image_pairs;
-    if (image_pairs.empty()) return filtered_image_pairs;
+// PreemptivelyFilterImagePairs (src/Feature/FeatureMatching.cpp:148-179) for every group of a super-batch in
+// one device call
+void BruteFeatureMatcher::PreemptivelyFilterGroups(std::vector<std::vector<std::pair<image_t, image_t>>>* groups) {
+    std::vector<std::pair<image_t, image_t>> all;
+    for (const auto& g : *groups) all.insert(all.end(), g.begin(), g.end());
+    std::vector<char> keep;
+    {
+        Lap l(&g_clock.preemptive);
+        keep = PreemptiveKeepFlags(all);
+    }
+    size_t at = 0;
+    for (auto& g : *groups) {
+        std::vector<std::pair<image_t, image_t>> filtered;
+        for (const auto& image_pair : g)
+            if (keep[at++]) filtered.push_back(image_pair);
+        g.swap(filtered);
+    }
+}
+
+std::vector<char> BruteFeatureMatcher::PreemptiveKeepFlags(const std::vector<std::pair<image_t, image_t>>& image_pairs) {
+    std::vector<char> keep(image_pairs.size(), 0);
+    if (image_pairs.empty()) return keep;
     std::vector<int32_t> slots;
     for (const auto& image_pair : image_pairs) {
         slots.push_back(GetTopScaleDescriptors(image_pair.first));
@@ -209,8 +315,16 @@ std::vector<std::pair<image_t, image_t>> BruteFeatureMatcher::PreemptivelyFilter
     const int P = (int)image_pairs.size();
     std::vector<int64_t> offs((size_t)P + 1);
     MSFM_CALL(ctx_, msfm_match_pairs(ctx_, slots.data(), P, &prm, offs.data()));
-    for (int p = 0; p < P; ++p)
-        if (offs[(size_t)p + 1] - offs[(size_t)p] >= preemtive_min_num_matches_) filtered_image_pairs.push_back(image_pairs[(size_t)p]);
+    for (int p = 0; p < P; ++p) keep[(size_t)p] = (offs[(size_t)p + 1] - offs[(size_t)p] >= preemtive_min_num_matches_) ? 1 : 0;
+    return keep;
+}
+
+std::vector<std::pair<image_t, image_t>> BruteFeatureMatcher::PreemptivelyFilterImagePairs(
+    std::vector<std::pair<image_t, image_t>> image_pairs) {
+    std::vector<std::pair<image_t, image_t>> filtered_image_pairs;
+    const std::vector<char> keep = PreemptiveKeepFlags(image_pairs);
+    for (size_t p = 0; p < image_pairs.size(); ++p)
+        if (keep[p]) filtered_image_pairs.push_back(image_pairs[p]);
     return filtered_image_pairs;
 }
 

@@ -27,6 +27,9 @@ public:
     // FeatureMatching.cpp:10-73: skip pairs that already have a row, match, distance filter,
     // geometric verification, one matches row per pair (rows may be 0), all in one transaction.
     void MatchImagePairs(const std::vector<std::pair<image_t, image_t>>& image_pairs);
+    // Several such calls at once: computed together (one device batch, one parallel verification pass),
+    // emitted group by group exactly as consecutive MatchImagePairs calls would.
+    void MatchImagePairGroups(const std::vector<std::vector<std::pair<image_t, image_t>>>& groups);
     virtual void RunMatching() = 0;
 
     // FeatureUtils::FilterMatches (F-matrix RANSAC) is applied unless disabled
@@ -81,6 +84,8 @@ private:
     // Wu, "Towards Linear-Time Incremental Structure from Motion", 3DV 2013 (pre-emptive matching)
     std::vector<std::pair<image_t, image_t>> PreemptivelyFilterImagePairs(
         std::vector<std::pair<image_t, image_t>> image_pairs);
+    void PreemptivelyFilterGroups(std::vector<std::vector<std::pair<image_t, image_t>>>* groups);
+    std::vector<char> PreemptiveKeepFlags(const std::vector<std::pair<image_t, image_t>>& image_pairs);
     int GetTopScaleDescriptors(const image_t& image_id);  // returns the auxiliary store slot
     bool HasTopScaleDescriptorsCache(const image_t& image_id);
 

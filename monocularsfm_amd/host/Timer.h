@@ -3,7 +3,9 @@
 #pragma once
 #include <chrono>
 #include <iomanip>
+#include <cstdio>
 #include <iostream>
+#include <string>
 
 namespace MonocularSfM {
 
@@ -34,9 +36,12 @@ public:
     void PrintSeconds() const { Print(ElapsedSeconds(), "seconds"); }
     void PrintMinutes() const { Print(ElapsedMinutes(), "minutes"); }
     void PrintHours() const { Print(ElapsedHours(), "hours"); }
-    static void Print(double v, const char* unit) {
-        std::cout << "Elapsed time: " << std::setiosflags(std::ios::fixed) << std::setprecision(5) << v << " ["
-                  << unit << "]" << std::endl;
+    static void Print(double v, const char* unit) { std::cout << Format(v, unit) << std::flush; }
+    // the line Print writes, newline included
+    static std::string Format(double v, const char* unit) {
+        char buf[96];
+        std::snprintf(buf, sizeof(buf), "Elapsed time: %.5f [%s]\n", v, unit);
+        return buf;
     }
 
 private:

@@ -37,9 +37,11 @@ for label, env in (("geometric verification on (reference default)", {}), ("geom
     open(c2, "w").write('%%YAML:1.0\ndatabase_path : "%s"\nSIFTmatch.match_type : 1\n' % db2)
     e = dict(os.environ); e.update(env)
     t0 = time.time()
+    e["MSFM_CLI_TIMING"] = "1"
     r = subprocess.run([exe, c2], capture_output=True, text=True, env=e)
     dt = time.time() - t0
     assert r.returncode == 0, r.stderr[-500:]
+    print("   ", r.stderr.strip().splitlines()[-1] if r.stderr.strip() else "")
     db = database.Database(db2)
     rows = db.db.execute("SELECT COUNT(*), SUM(rows) FROM matches").fetchone()
     db.Close()

@@ -1,0 +1,32 @@
+#!/bin/bash
+# usage: tools/variant_bench.sh "<name>=<extra hipcc flags>" ...   -> sweep times of each build on the 32 x 5000 job
+set -u
+ROOT=$(pwd)
+names=()
+for spec in "$@"; do
+  name="${spec%%=*}"; flags="${spec#*=}"
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -I$ROOT/include $flags -shared \
+      -o /tmp/libmsfm_var_$name.so $ROOT/monocularsfm_amd/csrc/msfm_match.hip 2>&1 | grep -E "error"
+  names+=("$name")
+done
+python - "${names[@]}" <<'PY'
+import sys, numpy as np
+sys.path.insert(0, '.')
+from monocularsfm_amd import _lib, synth
+imgs = synth.rootsift_images(32, 5000, seed=11)
+pairs = np.array([(i, j) for i in range(32) for j in range(i)], np.int32)
+ref = None
+for name in sys.argv[1:]:
+    _lib._lib = None
+    _lib.LIB_PATH = "/tmp/libmsfm_var_%s.so" % name
+    ctx = _lib.Context(0)
+    for i, im in enumerate(imgs): ctx.upload_image(i, im)
+    s1, s2 = [], []
+    for rep in range(40):
+        offs, qt, d = ctx.match_pairs(pairs)
+        p = ctx.profile(); s1.append(p["approx_kernel_ms"]); s2.append(p["sweep2_ms"])
+    if ref is None: ref = (offs.copy(), qt.copy(), d.copy())
+    same = np.array_equal(offs, ref[0]) and np.array_equal(qt, ref[1]) and np.array_equal(d.view(np.int32), ref[2].view(np.int32))
+    print("%-14s sweep1 min %.3f med %.3f ms | sweep2 min %.3f ms | same as first: %s" % (name, min(s1), sorted(s1)[len(s1) // 2], min(s2), same), flush=True)
+    ctx.close()
+PY
