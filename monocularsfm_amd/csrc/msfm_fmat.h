@@ -274,7 +274,7 @@ MSFM_HD int replay_adaptive(int n, int max_iters, double confidence, CountFn cou
             double q = 1.0 - w8;
             if (q < 1e-300) q = 1e-300;
             const double need = logfn(1.0 - confidence) / logfn(q);
-            if (need == need && need < (double)iters) {
+            if (need > 0.0 && need < (double)iters) {  // q == 1 (tiny consensus) gives -inf / NaN: no bound
                 int ni = (int)need;
                 if ((double)ni < need) ni += 1;  // ceil
                 iters = ni > it + 1 ? ni : it + 1;

@@ -52,8 +52,10 @@ FeatureMatcher::FeatureMatcher(const std::string& database_path, const int& max_
       max_distance_(max_distance),
       distance_ratio_(distance_ratio),
       cross_check_(cross_check) {
+    // MSFM_GEOMETRIC_VERIFICATION: unset / "1" = on the device (default), "host" = host twin, "0" = off
     const char* gv = std::getenv("MSFM_GEOMETRIC_VERIFICATION");
     if (gv && gv[0] == '0') geometric_verification_ = false;
+    if (gv && std::string(gv) == "host") verification_on_host_ = true;
 }
 
 FeatureMatcher::~FeatureMatcher() { CloseDatabaseAndDevice(); }
@@ -93,6 +95,12 @@ void FeatureMatcher::EnsureResident(image_t image_id) {
     if (resident_.count(image_id)) return;
     const Descriptors d = database_->ReadDescriptors(image_id);
     MSFM_CALL(ctx_, msfm_upload_image(ctx_, image_id, d.data.data(), d.rows, d.rows ? d.cols : MSFM_DIM, MSFM_DTYPE_F32));
+    if (geometric_verification_ && !verification_on_host_) {
+        // the device verifies: it needs the keypoint coordinates next to the descriptors
+        const std::vector<KeyPoint> kpts = database_->ReadKeyPoints(image_id);
+        static_assert(sizeof(KeyPoint) == 16, "KeyPoint must be 4 packed floats");
+        MSFM_CALL(ctx_, msfm_upload_keypoints(ctx_, image_id, reinterpret_cast<const float*>(kpts.data()), (int)kpts.size(), 4));
+    }
     resident_.insert(image_id);
 }
 
@@ -148,16 +156,21 @@ void FeatureMatcher::MatchImagePairGroups(const std::vector<std::vector<std::pai
         std::vector<float> dist;
         {
             Lap l(&g_clock.device);
-            MSFM_CALL(ctx_, msfm_match_pairs(ctx_, todo.data(), P, &prm, offs.data()));
+            if (geometric_verification_ && !verification_on_host_)
+                MSFM_CALL(ctx_, msfm_match_pairs_verified(ctx_, todo.data(), P, &prm, nullptr, offs.data()));  // FilterMatches' constants
+            else
+                MSFM_CALL(ctx_, msfm_match_pairs(ctx_, todo.data(), P, &prm, offs.data()));
             qt.resize((size_t)offs[(size_t)P] * 2 + 2);
             dist.resize((size_t)offs[(size_t)P] + 1);
             MSFM_CALL(ctx_, msfm_fetch_matches(ctx_, qt.data(), dist.data()));
         }
         gpu_seconds_per_pair = timer.ElapsedSeconds() / P;
 
-        // Geometric verification (FeatureUtils::FilterMatches) is host work: keypoints are read once per
-        // image (SQLite handle: this thread only) and the pairs are verified on all host cores.
-        if (geometric_verification_) {
+        // Geometric verification (FeatureUtils::FilterMatches) already happened on the device, unless the host
+        // twin was asked for: then keypoints are read once per image (SQLite handle: this thread only) and
+        // the pairs are verified on all host cores.
+        const bool host_verify = geometric_verification_ && verification_on_host_;
+        if (host_verify) {
             Lap l(&g_clock.read_kp);
             for (int32_t id : todo)
                 if (!keypoints_cache_.count(id)) keypoints_cache_[id] = database_->ReadKeyPoints(id);
@@ -174,7 +187,7 @@ void FeatureMatcher::MatchImagePairGroups(const std::vector<std::vector<std::pai
                 prune_matches[i].trainIdx = qt[2 * k + 1];
                 prune_matches[i].distance = dist[k];
             }
-            if (geometric_verification_)
+            if (host_verify)
                 FilterMatches(keypoints_cache_.at(image_id1), keypoints_cache_.at(image_id2), prune_matches, &verified[(size_t)p]);
             else
                 verified[(size_t)p].swap(prune_matches);

@@ -32,8 +32,9 @@ public:
     void MatchImagePairGroups(const std::vector<std::vector<std::pair<image_t, image_t>>>& groups);
     virtual void RunMatching() = 0;
 
-    // FeatureUtils::FilterMatches (F-matrix RANSAC) is applied unless disabled
-    // (MSFM_GEOMETRIC_VERIFICATION=0); see GeometricVerification.h.
+    // FeatureUtils::FilterMatches (F-matrix RANSAC) is applied unless disabled (MSFM_GEOMETRIC_VERIFICATION=0):
+    // on the device by default (msfm_match_pairs_verified), by the host twin with MSFM_GEOMETRIC_VERIFICATION=host
+    // (GeometricVerification.h; the two give identical lists).
     void SetGeometricVerification(bool on) { geometric_verification_ = on; }
 
 protected:
@@ -47,6 +48,7 @@ protected:
     double distance_ratio_;
     bool cross_check_;
     bool geometric_verification_ = true;
+    bool verification_on_host_ = false;  // MSFM_GEOMETRIC_VERIFICATION=host
     Database* database_ = nullptr;
     msfm_ctx* ctx_ = nullptr;
     std::set<image_t> resident_;

@@ -148,20 +148,23 @@ def test_geometric_verification_default_on(exe, dataset, tmp_path):
     """Default run applies the F-matrix RANSAC hand-off (a "next" row, outside bit parity): it may only
     remove matches.  Synthetic keypoints carry no epipolar geometry, so most matches are rejected."""
     descs, kps = dataset
-    a, b = str(tmp_path / "gv.db"), str(tmp_path / "nogv.db")
+    a, b, c = str(tmp_path / "gv.db"), str(tmp_path / "nogv.db"), str(tmp_path / "gvhost.db")
     database.write_synthetic_database(a, descs, kps)
     shutil.copy(a, b)
-    for path, env in ((a, {}), (b, {"MSFM_GEOMETRIC_VERIFICATION": "0"})):
+    shutil.copy(a, c)
+    for path, env in ((a, {}), (b, {"MSFM_GEOMETRIC_VERIFICATION": "0"}), (c, {"MSFM_GEOMETRIC_VERIFICATION": "host"})):
         cfg = tmp_path / (os.path.basename(path) + ".yaml")
         cfg.write_text(YAML.format(db=path, mt=0))
         run_cli(exe, cfg, env)
-    da, dbb = database.Database(a), database.Database(b)
+    da, dbb, dc = database.Database(a), database.Database(b), database.Database(c)
     for i in range(1, len(descs)):
-        ma, mb = da.ReadMatches(i, i - 1), dbb.ReadMatches(i, i - 1)
+        ma, mb, mc = da.ReadMatches(i, i - 1), dbb.ReadMatches(i, i - 1), dc.ReadMatches(i, i - 1)
         sa = set(map(tuple, ma.tolist()))
         assert sa <= set(map(tuple, mb.tolist())) and len(ma) <= len(mb)
+        assert np.array_equal(ma, mc)          # device RANSAC == host twin, row for row
     da.Close()
     dbb.Close()
+    dc.Close()
 
 
 def test_python_matcher_mirror_equals_cli(exe, dataset, gpu_ctx, tmp_path):

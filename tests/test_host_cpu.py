@@ -146,6 +146,20 @@ def test_fundamental_ransac_recovers_the_epipolar_inliers(host):
     assert mask[:7].all()
 
 
+def test_fundamental_ransac_runs_its_iterations_on_unrelated_points(host):
+    """A consensus of ~8 of 358 makes 1 - w^8 round to 1.0: the adaptive bound must then stay at the cap instead
+    of collapsing (log(1) = 0 in the denominator).  With all 1000 hypotheses tried, some 8-point model always
+    gathers >= 8 of 358 random correspondences within 3 px of its epipolar lines."""
+    rng = np.random.default_rng(0)
+    n = 358
+    p1 = np.c_[rng.uniform(0, 3072, n), rng.uniform(0, 2304, n)].astype(np.float32)
+    p2 = np.c_[rng.uniform(0, 3072, n), rng.uniform(0, 2304, n)].astype(np.float32)
+    mask = np.zeros(n, np.uint8)
+    fp = C.POINTER(C.c_float)
+    assert host.host_fundamental_ransac(p1.ctypes.data_as(fp), p2.ctypes.data_as(fp), n, mask.ctypes.data_as(C.POINTER(C.c_ubyte))) == n
+    assert 8 <= mask.sum() <= 40
+
+
 def test_cli_argv_contract(host, tmp_path):
     exe = os.path.join(HOST, "ComputeMatches")
     r = subprocess.run([exe], capture_output=True, text=True)

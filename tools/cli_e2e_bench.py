@@ -30,10 +30,12 @@ cfg = os.path.join(tmp, "cfg.yaml")
 open(cfg, "w").write('%%YAML:1.0\ndatabase_path : "%s"\nSIFTmatch.match_type : 1\n' % db_path)
 print("dataset: %d images, %d descriptors, db %.0f MB, built in %.1f s" % (N, int(counts.sum()), os.path.getsize(db_path) / 1e6, time.time() - t0))
 exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "monocularsfm_amd", "host", "ComputeMatches")
-for label, env in (("geometric verification on (reference default)", {}), ("geometric verification off", {"MSFM_GEOMETRIC_VERIFICATION": "0"})):
-    db2 = db_path + "." + ("gv" if not env else "nogv")
+for label, env in (("geometric verification on the device (reference default flow)", {}),
+                   ("geometric verification by the host twin", {"MSFM_GEOMETRIC_VERIFICATION": "host"}),
+                   ("geometric verification off", {"MSFM_GEOMETRIC_VERIFICATION": "0"})):
+    db2 = db_path + "." + ("gv" if not env else ("gvhost" if env["MSFM_GEOMETRIC_VERIFICATION"] == "host" else "nogv"))
     subprocess.check_call(["cp", db_path, db2])
-    c2 = cfg + ("gv" if not env else "nogv")
+    c2 = cfg + os.path.basename(db2).rsplit(".", 1)[1]
     open(c2, "w").write('%%YAML:1.0\ndatabase_path : "%s"\nSIFTmatch.match_type : 1\n' % db2)
     e = dict(os.environ); e.update(env)
     t0 = time.time()
