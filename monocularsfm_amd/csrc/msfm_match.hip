@@ -16,7 +16,9 @@
 #include <cstdlib>
 #include <cmath>
 #include <cstring>
+#include <map>
 #include <string>
+#include <utility>
 #include <vector>
 
 using namespace msfm;
@@ -93,7 +95,7 @@ struct msfm_ctx {
     // prefilter path
     int prefilter = 1;
     DevBuf d_pf, d_tu, d_tv, d_cand, d_cand_s, d_cand_count, d_best, d_second, d_maxima;
-    DevBuf d_live_cnt, d_cmp_h, d_cmp_tu, d_live_idx, d_vpairs, d_vpf, d_vitems, d_jobs, d_lists;
+    DevBuf d_live_cnt, d_cmp_h, d_cmp_tu, d_live_idx, d_row_pair, d_cand_pair, d_vpairs, d_vpf, d_vitems, d_jobs, d_lists;
     // geometric verification
     DevBuf d_vf_pairs, d_vf_x1, d_vf_y1, d_vf_x2, d_vf_y2, d_vf_hyp, d_vf_best_it, d_vf_best_count, d_vf_flags,
         d_st2_qt, d_st2_d, d_counts2;
@@ -372,76 +374,110 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
     }
 
     // ---- sweep-2 descriptors -------------------------------------------------------------------
-    struct VSweep { int pair, dir, cnt; long long row; };
-    std::vector<VSweep> vs;
+    // Compacted sweeps are GROUPED: the live rows of every pair that streams the same image in the same
+    // direction are concatenated into one dense matrix (blocks are then full except for one tail per group;
+    // a pair's own ~300 live rows would fill its last 256-row block to a fifth).
+    struct VMember { int pair, dir, cnt; long long row; };
+    struct VGroup { const _Float16* b_h; int dir; int first, count; long long row0, rows; };
+    std::vector<VMember> members;
+    std::vector<VGroup> groups;
     long long cmp_rows = 0, cand_elems = 0;
-    for (size_t p = 0; p < P; ++p) {
-        PairDesc& pd = b.pairs[p];
-        PfPair& pp = b.pf[p];
-        if (!pd.valid || !pp.use) continue;
-        if (!compact[p]) {
-            pp.cand_off = cand_elems;
-            pp.cand_cap = 8 * (pd.n1 + pd.n2) + 1024;
-            cand_elems += pp.cand_cap;
-            continue;
+    {
+        std::map<std::pair<const void*, int>, std::vector<VMember>> by_key;
+        std::vector<std::pair<const void*, int>> key_order;
+        for (size_t p = 0; p < P; ++p) {
+            PairDesc& pd = b.pairs[p];
+            PfPair& pp = b.pf[p];
+            if (!pd.valid || !pp.use) continue;
+            if (!compact[p]) {
+                pp.cand_off = cand_elems;
+                pp.cand_cap = 8 * (pd.n1 + pd.n2) + 1024;
+                cand_elems += pp.cand_cap;
+                continue;
+            }
+            for (int dir = 0; dir < 2; ++dir) {
+                const int cnt = live[2 * p + dir];
+                if (cnt == 0) continue;
+                const std::pair<const void*, int> key(dir ? (const void*)pp.a_h : (const void*)pp.b_h, dir);
+                auto it = by_key.find(key);
+                if (it == by_key.end()) {
+                    key_order.push_back(key);
+                    it = by_key.emplace(key, std::vector<VMember>()).first;
+                }
+                it->second.push_back(VMember{(int)p, dir, cnt, 0});
+            }
         }
-        for (int dir = 0; dir < 2; ++dir) {
-            const int cnt = live[2 * p + dir];
-            if (cnt == 0) continue;
-            vs.push_back(VSweep{(int)p, dir, cnt, cmp_rows});
-            cmp_rows += (cnt + 255) / 256 * 256;
+        for (const auto& key : key_order) {
+            std::vector<VMember>& ms = by_key[key];
+            VGroup g{(const _Float16*)key.first, key.second, (int)members.size(), (int)ms.size(), cmp_rows, 0};
+            for (VMember& m : ms) {
+                m.row = cmp_rows + g.rows;
+                g.rows += m.cnt;
+                members.push_back(m);
+            }
+            cmp_rows += (g.rows + 255) / 256 * 256;
+            groups.push_back(g);
         }
     }
-    const size_t V = vs.size();
+    const size_t V = groups.size();
     HIPCHK(ctx, ctx->d_cmp_h.ensure(std::max<long long>(1, cmp_rows) * kDim * 2));
     HIPCHK(ctx, ctx->d_cmp_tu.ensure(std::max<long long>(1, cmp_rows) * 4));
     HIPCHK(ctx, ctx->d_live_idx.ensure(std::max<long long>(1, cmp_rows) * 4));
+    HIPCHK(ctx, ctx->d_row_pair.ensure(std::max<long long>(1, cmp_rows) * 4));
     std::vector<PairDesc> vpairs(V);
     std::vector<PfPair> vpf(V);
-    std::vector<GatherJob> jobs(V);
+    std::vector<GatherJob> jobs(members.size());
     std::vector<CandList> lists(P + V);
     long long v_ablocks = 0;
-    for (size_t v = 0; v < V; ++v) v_ablocks += (vs[v].cnt + 255) / 256;
+    for (size_t v = 0; v < V; ++v) v_ablocks += (groups[v].rows + 255) / 256;
     for (size_t p = 0; p < P; ++p) {
         const PfPair& pp = b.pf[p];
-        lists[p] = CandList{(int)p, 0, pp.cand_off, (b.pairs[p].valid && pp.use && !compact[p]) ? pp.cand_cap : 0, 0, nullptr};
+        lists[p] = CandList{(int)p, 0, pp.cand_off, (b.pairs[p].valid && pp.use && !compact[p]) ? pp.cand_cap : 0, 0, nullptr, nullptr};
     }
     std::vector<WorkItem> vlin;
     for (size_t v = 0; v < V; ++v) {
-        const VSweep& s = vs[v];
-        const PairDesc& pd = b.pairs[s.pair];
-        const PfPair& pp = b.pf[s.pair];
+        const VGroup& g = groups[v];
+        const VMember& m0 = members[(size_t)g.first];
+        const PairDesc& pd = b.pairs[m0.pair];   // every member streams the same image: take its description from the first
+        const PfPair& pp = b.pf[m0.pair];
         PairDesc& vd = vpairs[v];
         PfPair& vp = vpf[v];
         vd = PairDesc{};
-        vd.a_raw = s.dir ? pd.b_raw : pd.a_raw;
-        vd.b_raw = s.dir ? pd.a_raw : pd.b_raw;
-        vd.n1 = s.cnt;
-        vd.n2 = s.dir ? pd.n1 : pd.n2;
-        vd.a_blocks256 = (s.cnt + 255) / 256;
-        vd.b_tiles = s.dir ? pd.a_blocks : pd.b_tiles;
+        vd.n1 = (int)g.rows;
+        vd.n2 = g.dir ? pd.n1 : pd.n2;
+        vd.a_blocks256 = (int)((g.rows + 255) / 256);
+        vd.b_tiles = g.dir ? pd.a_blocks : pd.b_tiles;
         vd.n1pad = vd.a_blocks256 * 256;
-        vd.n2pad = s.dir ? pd.n1pad : pd.n2pad;
+        vd.n2pad = g.dir ? pd.n1pad : pd.n2pad;
         vd.valid = 1;
         vd.path = 1;
         vd.ranges = 1;
         if (v_ablocks < 8LL * ctx->cu_count)
             vd.ranges = (int)std::max<long long>(1, std::min<long long>((8LL * ctx->cu_count + v_ablocks - 1) / v_ablocks, vd.b_tiles));
         vp = PfPair{};
-        vp.a_h = ctx->d_cmp_h.as<_Float16>() + (size_t)s.row * kDim;
-        vp.b_h = s.dir ? pp.a_h : pp.b_h;
-        vp.b_nrm = s.dir ? pp.a_nrm : pp.b_nrm;
-        vp.b_ext = s.dir ? pp.a_ext : pp.b_ext;
-        vp.b_c = s.dir ? pp.a_c : pp.b_c;
-        vp.a_c = s.dir ? pp.b_c : pp.a_c;
-        vp.tu_off = s.row;
+        vp.a_h = ctx->d_cmp_h.as<_Float16>() + (size_t)g.row0 * kDim;
+        vp.b_h = g.dir ? pp.a_h : pp.b_h;
+        vp.b_nrm = g.dir ? pp.a_nrm : pp.b_nrm;
+        vp.b_ext = g.dir ? pp.a_ext : pp.b_ext;
+        vp.b_c = g.dir ? pp.a_c : pp.b_c;
+        vp.a_c = g.dir ? pp.b_c : pp.a_c;
+        vp.tu_off = g.row0;
         vp.cand_off = cand_elems;
-        vp.cand_cap = 8 * s.cnt + 1024;
+        vp.cand_cap = (int)std::min<long long>(8 * g.rows + 1024, 1LL << 30);
         vp.use = 1;
         cand_elems += vp.cand_cap;
-        jobs[v] = GatherJob{s.dir ? pp.b_h : pp.a_h, s.dir ? pp.b_nrm : pp.a_nrm, s.dir ? pp.tv_off : pp.tu_off, s.row,
-                            s.dir ? pd.n2 : pd.n1, 0};
-        lists[P + v] = CandList{s.pair, 1 + s.dir, vp.cand_off, vp.cand_cap, 0, ctx->d_live_idx.as<int>() + s.row};
+        for (int k = 0; k < g.count; ++k) {
+            const VMember& m = members[(size_t)(g.first + k)];
+            const PairDesc& mpd = b.pairs[m.pair];
+            const PfPair& mpp = b.pf[m.pair];
+            const bool last = k + 1 == g.count;
+            jobs[(size_t)(g.first + k)] = GatherJob{m.dir ? mpp.b_h : mpp.a_h, m.dir ? mpp.b_nrm : mpp.a_nrm,
+                                                    m.dir ? mpp.tv_off : mpp.tu_off, m.row,
+                                                    last ? g.row0 + (long long)vd.n1pad : m.row + m.cnt,
+                                                    m.dir ? mpd.n2 : mpd.n1, m.pair};
+        }
+        lists[P + v] = CandList{-1, 1 + g.dir, vp.cand_off, vp.cand_cap, 0, ctx->d_live_idx.as<int>() + g.row0,
+                                ctx->d_row_pair.as<int>() + g.row0};
         for (int r = 0; r < vd.ranges; ++r) {
             const int t0 = (int)((long long)vd.b_tiles * r / vd.ranges), t1 = (int)((long long)vd.b_tiles * (r + 1) / vd.ranges);
             for (int ab = 0; ab < vd.a_blocks256; ++ab) vlin.push_back(WorkItem{(int)v, ab, t0, t1, r, {0, 0, 0}});
@@ -459,6 +495,7 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
 
     HIPCHK(ctx, ctx->d_cand.ensure(std::max<long long>(1, cand_elems) * sizeof(int2)));
     HIPCHK(ctx, ctx->d_cand_s.ensure(std::max<long long>(1, cand_elems) * 4));
+    HIPCHK(ctx, ctx->d_cand_pair.ensure(std::max<long long>(1, cand_elems) * 4));
     HIPCHK(ctx, ctx->d_cand_count.ensure((P + V) * 4));
     HIPCHK(ctx, ctx->d_lists.ensure((P + V) * sizeof(CandList)));
     HIPCHK(ctx, hipMemsetAsync(ctx->d_cand_count.p, 0, (P + V) * 4, ctx->stream));
@@ -470,14 +507,15 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
     if (V > 0) {
         HIPCHK(ctx, ctx->d_vpairs.ensure(V * sizeof(PairDesc)));
         HIPCHK(ctx, ctx->d_vpf.ensure(V * sizeof(PfPair)));
-        HIPCHK(ctx, ctx->d_jobs.ensure(V * sizeof(GatherJob)));
+        HIPCHK(ctx, ctx->d_jobs.ensure(jobs.size() * sizeof(GatherJob)));
         HIPCHK(ctx, ctx->d_vitems.ensure(vitems.size() * sizeof(WorkItem)));
         HIPCHK(ctx, hipMemcpyAsync(ctx->d_vpairs.p, vpairs.data(), V * sizeof(PairDesc), hipMemcpyHostToDevice, ctx->stream));
         HIPCHK(ctx, hipMemcpyAsync(ctx->d_vpf.p, vpf.data(), V * sizeof(PfPair), hipMemcpyHostToDevice, ctx->stream));
-        HIPCHK(ctx, hipMemcpyAsync(ctx->d_jobs.p, jobs.data(), V * sizeof(GatherJob), hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(ctx->d_jobs.p, jobs.data(), jobs.size() * sizeof(GatherJob), hipMemcpyHostToDevice, ctx->stream));
         HIPCHK(ctx, hipMemcpyAsync(ctx->d_vitems.p, vitems.data(), vitems.size() * sizeof(WorkItem), hipMemcpyHostToDevice, ctx->stream));
-        hipLaunchKernelGGL(pf_gather_live_kernel, dim3((unsigned)V), dim3(256), 0, ctx->stream, ctx->d_jobs.as<GatherJob>(),
-                           (const float*)tuv, ctx->d_live_idx.as<int>(), ctx->d_cmp_tu.as<float>(), ctx->d_cmp_h.as<_Float16>());
+        hipLaunchKernelGGL(pf_gather_live_kernel, dim3((unsigned)jobs.size()), dim3(256), 0, ctx->stream, ctx->d_jobs.as<GatherJob>(),
+                           (const float*)tuv, ctx->d_live_idx.as<int>(), ctx->d_row_pair.as<int>(), ctx->d_cmp_tu.as<float>(),
+                           ctx->d_cmp_h.as<_Float16>());
         HIPCHK(ctx, hipGetLastError());
     DBGSYNC(ctx, "pf_gather_live_kernel");
     }
@@ -502,23 +540,24 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
     HIPCHK(ctx, hipEventRecord(e3, ctx->stream));
 
     const CandList* dl = ctx->d_lists.as<CandList>();
-    const dim3 cgrid(V > 0 ? 16 : 64, (unsigned)(P + V));
+    const dim3 cgrid(64, (unsigned)(P + V));
     if (ctx->order == MSFM_ORDER_SSE4X4)
         hipLaunchKernelGGL(pf_exact_candidates_kernel<0>, cgrid, dim3(256), 0, ctx->stream, dp, dl, ctx->d_cand_count.as<int>(),
-                           ctx->d_cand.as<int2>(), ctx->d_cand_s.as<float>());
+                           ctx->d_cand.as<int2>(), ctx->d_cand_s.as<float>(), ctx->d_cand_pair.as<int>());
     else
         hipLaunchKernelGGL(pf_exact_candidates_kernel<1>, cgrid, dim3(256), 0, ctx->stream, dp, dl, ctx->d_cand_count.as<int>(),
-                           ctx->d_cand.as<int2>(), ctx->d_cand_s.as<float>());
+                           ctx->d_cand.as<int2>(), ctx->d_cand_s.as<float>(), ctx->d_cand_pair.as<int>());
     HIPCHK(ctx, hipGetLastError());
     DBGSYNC(ctx, "pf_exact_candidates_kernel<1>");
-    const dim3 rgrid(V > 0 ? 4 : 16, (unsigned)(P + V));
+    const dim3 rgrid(16, (unsigned)(P + V));
     hipLaunchKernelGGL(pf_reduce_best_kernel, rgrid, dim3(256), 0, ctx->stream, dp, dl, ctx->d_cand_count.as<int>(),
-                       ctx->d_cand.as<int2>(), ctx->d_cand_s.as<float>(), ctx->d_best.as<unsigned long long>());
+                       ctx->d_cand.as<int2>(), ctx->d_cand_s.as<float>(), (const int*)ctx->d_cand_pair.as<int>(),
+                       ctx->d_best.as<unsigned long long>());
     HIPCHK(ctx, hipGetLastError());
     DBGSYNC(ctx, "pf_reduce_best_kernel");
     hipLaunchKernelGGL(pf_reduce_second_kernel, rgrid, dim3(256), 0, ctx->stream, dp, dl, ctx->d_cand_count.as<int>(),
-                       ctx->d_cand.as<int2>(), ctx->d_cand_s.as<float>(), ctx->d_best.as<unsigned long long>(),
-                       ctx->d_second.as<unsigned long long>());
+                       ctx->d_cand.as<int2>(), ctx->d_cand_s.as<float>(), (const int*)ctx->d_cand_pair.as<int>(),
+                       ctx->d_best.as<unsigned long long>(), ctx->d_second.as<unsigned long long>());
     HIPCHK(ctx, hipGetLastError());
     DBGSYNC(ctx, "pf_reduce_second_kernel");
     hipLaunchKernelGGL(pf_finalize_kernel, mgrid, dim3(256), 0, ctx->stream, dp, dpf, (const float*)tuv, ctx->d_best.as<unsigned long long>(),
@@ -537,11 +576,15 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
     HIPCHK(ctx, hipEventElapsedTime(&ms, e2, e3));
     ctx->prof.sweep2_ms += ms;
     std::vector<char> overflow(P, 0);
-    std::vector<long long> ncand(P, 0);
     for (size_t l = 0; l < P + V; ++l) {
         if (lists[l].cap == 0) continue;
-        ncand[lists[l].pair] += counts[l];
-        if (counts[l] > lists[l].cap) overflow[lists[l].pair] = 1;
+        if (counts[l] <= lists[l].cap) {
+            ctx->prof.candidates += counts[l];
+            continue;
+        }
+        if (l < P) overflow[l] = 1;
+        else  // a group's list: every pair that has rows in it
+            for (int k = 0; k < groups[l - P].count; ++k) overflow[(size_t)members[(size_t)(groups[l - P].first + k)].pair] = 1;
     }
     for (size_t p = 0; p < P; ++p) {
         if (!b.pairs[p].valid || !b.pf[p].use) continue;
@@ -551,7 +594,6 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
             ctx->prof.fallback_pairs += 1;
         } else {
             ctx->prof.prefilter_pairs += 1;
-            ctx->prof.candidates += ncand[p];
             ctx->prof.prefilter_descriptor_pairs += (int64_t)b.pairs[p].n1 * b.pairs[p].n2;
             if (compact[p]) ctx->prof.compacted_pairs += 1;
         }
@@ -740,7 +782,7 @@ void msfm_destroy(msfm_ctx* ctx) {
                       &ctx->d_out_d, &ctx->d_fix_count, &ctx->d_fix_list, &ctx->d_pf, &ctx->d_tu, &ctx->d_tv,
                       &ctx->d_cand, &ctx->d_cand_s, &ctx->d_cand_count, &ctx->d_best, &ctx->d_second, &ctx->d_maxima,
                       &ctx->d_live_cnt, &ctx->d_cmp_h, &ctx->d_cmp_tu, &ctx->d_live_idx, &ctx->d_vpairs, &ctx->d_vpf,
-                      &ctx->d_vitems, &ctx->d_jobs, &ctx->d_lists, &ctx->d_vf_pairs, &ctx->d_vf_x1, &ctx->d_vf_y1,
+                      &ctx->d_vitems, &ctx->d_jobs, &ctx->d_lists, &ctx->d_row_pair, &ctx->d_cand_pair, &ctx->d_vf_pairs, &ctx->d_vf_x1, &ctx->d_vf_y1,
                       &ctx->d_vf_x2, &ctx->d_vf_y2, &ctx->d_vf_hyp, &ctx->d_vf_best_it, &ctx->d_vf_best_count,
                       &ctx->d_vf_flags, &ctx->d_st2_qt, &ctx->d_st2_d, &ctx->d_counts2};
     for (DevBuf* b : bufs) b->release();

@@ -616,16 +616,18 @@ __global__ void pf_thresholds_kernel(const PairDesc* __restrict__ pairs, const P
     }
 }
 
-// A candidate list: the (q, t) records one sweep produced for one pair.  mode 0: records are real
-// (q, t); mode 1: (k, t) with q = live_idx[k] (compacted live rows of image 1 against image 2);
-// mode 2: (k, q) with t = live_idx[k] (compacted live rows of image 2 against image 1).
+// A candidate list: the records one sweep produced.  mode 0: real (q, t) of pair `pair`; mode 1: (k, t) with
+// q = live_idx[k] (compacted live rows of image 1 against image 2); mode 2: (k, q) with t = live_idx[k]
+// (compacted live rows of image 2 against image 1).  A compacted list serves a GROUP of pairs that share the
+// streamed image: row k belongs to pair row_pair[k].
 struct CandList {
-    int pair;
+    int pair;   // mode 0 only
     int mode;
     long long off;
     int cap;  // 0: unused list
     int pad;
     const int* live_idx;
+    const int* row_pair;
 };
 
 // exact pinned-order S for every candidate: 16 lanes per candidate (SSE order: lane L owns the
@@ -634,19 +636,20 @@ struct CandList {
 template <int ORDER>
 __global__ void pf_exact_candidates_kernel(const PairDesc* __restrict__ pairs, const CandList* __restrict__ lists,
                                            const int* __restrict__ cand_count, int2* __restrict__ cand,
-                                           float* __restrict__ cand_s) {
+                                           float* __restrict__ cand_s, int* __restrict__ cand_pair) {
     const CandList L = lists[blockIdx.y];
     if (L.cap == 0) return;
-    const PairDesc pd = pairs[L.pair];
     const int n = min(cand_count[blockIdx.y], L.cap);
     const int sub = threadIdx.x & 15;
     for (int c = (blockIdx.x * blockDim.x + threadIdx.x) >> 4; c < ((n + 3) & ~3); c += (gridDim.x * blockDim.x) >> 4) {
         const bool live = c < n;
         int2 qt = live ? cand[L.off + c] : make_int2(0, 0);
+        int pair = L.mode == 0 ? L.pair : L.row_pair[live ? qt.x : 0];
+        if (!live && L.mode != 0) pair = L.row_pair[0], qt = make_int2(0, 0);
         if (live && L.mode == 1) qt.x = L.live_idx[qt.x];
         if (live && L.mode == 2) qt = make_int2(qt.y, L.live_idx[qt.x]);
-        const float* a = pd.a_raw + (size_t)qt.x * kDim;
-        const float* b = pd.b_raw + (size_t)qt.y * kDim;
+        const float* a = pairs[pair].a_raw + (size_t)qt.x * kDim;
+        const float* b = pairs[pair].b_raw + (size_t)qt.y * kDim;
         float res;
         if (ORDER == 0) {
             float p = 0.f;
@@ -687,6 +690,7 @@ __global__ void pf_exact_candidates_kernel(const PairDesc* __restrict__ pairs, c
         if (live && sub == 0) {
             cand[L.off + c] = qt;
             cand_s[L.off + c] = res;
+            cand_pair[L.off + c] = pair;
         }
     }
 }
@@ -700,35 +704,37 @@ __device__ __forceinline__ unsigned long long pf_key(float s, int idx) {
 // rows of the OTHER direction get their complete candidate sets from their own list.
 __global__ void pf_reduce_best_kernel(const PairDesc* __restrict__ pairs, const CandList* __restrict__ lists,
                                       const int* __restrict__ cand_count, const int2* __restrict__ cand,
-                                      const float* __restrict__ cand_s, unsigned long long* __restrict__ best) {
+                                      const float* __restrict__ cand_s, const int* __restrict__ cand_pair,
+                                      unsigned long long* __restrict__ best) {
     const CandList L = lists[blockIdx.y];
     if (L.cap == 0) return;
-    const PairDesc pd = pairs[L.pair];
     const int n = min(cand_count[blockIdx.y], L.cap);
     for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < n; c += gridDim.x * blockDim.x) {
         const int2 qt = cand[L.off + c];
         const float s = cand_s[L.off + c];
         if (!(s < f_inf())) continue;  // batchDistance never inserts a distance >= FLT_MAX
-        if (L.mode != 2) atomicMin(&best[pd.kf_off + qt.x], pf_key(s, qt.y));
-        if (L.mode != 1) atomicMin(&best[pd.kr_off + qt.y], pf_key(s, qt.x));
+        const int pair = cand_pair[L.off + c];
+        if (L.mode != 2) atomicMin(&best[pairs[pair].kf_off + qt.x], pf_key(s, qt.y));
+        if (L.mode != 1) atomicMin(&best[pairs[pair].kr_off + qt.y], pf_key(s, qt.x));
     }
 }
 // reduce phase B: second best = min over the candidates that are not the best one
 __global__ void pf_reduce_second_kernel(const PairDesc* __restrict__ pairs, const CandList* __restrict__ lists,
                                         const int* __restrict__ cand_count, const int2* __restrict__ cand,
-                                        const float* __restrict__ cand_s, const unsigned long long* __restrict__ best,
+                                        const float* __restrict__ cand_s, const int* __restrict__ cand_pair,
+                                        const unsigned long long* __restrict__ best,
                                         unsigned long long* __restrict__ second) {
     const CandList L = lists[blockIdx.y];
     if (L.cap == 0) return;
-    const PairDesc pd = pairs[L.pair];
     const int n = min(cand_count[blockIdx.y], L.cap);
     for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < n; c += gridDim.x * blockDim.x) {
         const int2 qt = cand[L.off + c];
         const float s = cand_s[L.off + c];
         if (!(s < f_inf())) continue;
+        const long long kfo = pairs[cand_pair[L.off + c]].kf_off, kro = pairs[cand_pair[L.off + c]].kr_off;
         const unsigned long long kf = pf_key(s, qt.y), kr = pf_key(s, qt.x);
-        if (L.mode != 2 && kf != best[pd.kf_off + qt.x]) atomicMin(&second[pd.kf_off + qt.x], kf);
-        if (L.mode != 1 && kr != best[pd.kr_off + qt.y]) atomicMin(&second[pd.kr_off + qt.y], kr);
+        if (L.mode != 2 && kf != best[kfo + qt.x]) atomicMin(&second[kfo + qt.x], kf);
+        if (L.mode != 1 && kr != best[kro + qt.y]) atomicMin(&second[kro + qt.y], kr);
     }
 }
 
@@ -759,12 +765,14 @@ struct GatherJob {
     const _Float16* src_h;   // image's fp16 blocks
     const float* src_nrm;    // its |row|^2
     long long src_thr_off;   // into tuv
-    long long dst_row;       // first row of this job in the compact arrays (multiple of 256)
+    long long dst_row;       // first row of this job in the compact arrays (its group starts at a multiple of 256)
+    long long zero_upto;     // rows [dst_row + live, zero_upto) are zero-filled (the group's tail; else == dst_row + live)
     int n;                   // rows of the image
-    int pad;
+    int pair;                // batch index of the pair the rows belong to
 };
 __global__ void pf_gather_live_kernel(const GatherJob* __restrict__ jobs, const float* __restrict__ tuv,
-                                      int* __restrict__ live_idx, float* __restrict__ cmp_tu, _Float16* __restrict__ cmp_h) {
+                                      int* __restrict__ live_idx, int* __restrict__ row_pair, float* __restrict__ cmp_tu,
+                                      _Float16* __restrict__ cmp_h) {
     const GatherJob J = jobs[blockIdx.x];
     __shared__ int wsum[4];
     __shared__ int running;
@@ -782,6 +790,7 @@ __global__ void pf_gather_live_kernel(const GatherJob* __restrict__ jobs, const 
         for (int w = 0; w < wave; ++w) k += wsum[w];
         if (live) {
             live_idx[J.dst_row + k] = e;
+            row_pair[J.dst_row + k] = J.pair;
             cmp_tu[J.dst_row + k] = t - J.src_nrm[e];  // sweep 2 folds (T - |a|^2)/2 into the MFMA
         }
         __syncthreads();
@@ -790,19 +799,20 @@ __global__ void pf_gather_live_kernel(const GatherJob* __restrict__ jobs, const 
     }
     const int cnt = running;
     // fp16 rows: 16 threads per row, one 16-byte granule each; granule g of row r lives at g ^ (r & 15)
+    // (r = the row number inside its 256-aligned group: dst_row + k has the same low bits)
     for (int k = threadIdx.x >> 4; k < cnt; k += 16) {
         const int r = live_idx[J.dst_row + k];
         const int g = threadIdx.x & 15;
+        const long long d = J.dst_row + k;
         const h8 v = *reinterpret_cast<const h8*>(J.src_h + ((size_t)r * 16 + (g ^ (r & 15))) * 8);
-        *reinterpret_cast<h8*>(cmp_h + ((size_t)(J.dst_row + k) * 16 + (g ^ (k & 15))) * 8) = v;
+        *reinterpret_cast<h8*>(cmp_h + ((size_t)d * 16 + (g ^ (int)(d & 15))) * 8) = v;
     }
-    // rows up to the next multiple of 256 are swept too: zero them (their threshold is -inf, but an
-    // fp16 inf from stale memory would still compare >= +inf)
+    // the group's tail up to the next multiple of 256 is swept too: zero it (its rows count as dead, but an
+    // fp16 inf / NaN from stale memory must not reach the matrix core)
     h8 z;
     for (int j = 0; j < 8; ++j) z[j] = (_Float16)0.f;
-    const int cpad = (cnt + 255) & ~255;
-    for (int k = cnt + (threadIdx.x >> 4); k < cpad; k += 16)
-        *reinterpret_cast<h8*>(cmp_h + ((size_t)(J.dst_row + k) * 16 + (threadIdx.x & 15)) * 8) = z;
+    for (long long d = J.dst_row + cnt + (threadIdx.x >> 4); d < J.zero_upto; d += 16)
+        *reinterpret_cast<h8*>(cmp_h + ((size_t)d * 16 + (threadIdx.x & 15)) * 8) = z;
 }
 
 // finalize: the same outputs as merge_knn_kernel (idx0, d0, d1, tie queue)

@@ -230,6 +230,34 @@ def test_compacted_and_dense_pairs_in_one_batch(gpu_ctx, oracle):
         assert offs[1] - offs[0] > 1000   # the twin pair really matches almost everywhere
 
 
+def test_compacted_group_overflow_falls_back(gpu_ctx, oracle):
+    """A live row whose second neighbour is shared by thousands of identical columns floods the (grouped)
+    candidate list of the compacted sweep: every pair of that group must fall back to the brute-force kernel
+    and still return the oracle's lists."""
+    imgs = synth.rootsift_images(3, [1500, 400, 1400], seed=41, n_proto=4000)
+    A, other, other2 = imgs
+    rng = np.random.default_rng(2)
+    lone = np.abs(rng.normal(0, 1, 128)).astype(F32)                 # a direction no prototype is close to
+    A[5] = (lone / np.linalg.norm(lone)).astype(F32)
+    twin = np.abs(A[5] + rng.normal(0, 0.002, 128).astype(F32))      # a second row next to A[5]: the flood columns then
+    A[8] = (twin / np.linalg.norm(twin)).astype(F32)                  # fail the reverse ratio test and stay dead (row 8: other lane half than row 5)
+    near = np.abs(A[5] + rng.normal(0, 0.01, 128).astype(F32))
+    near /= np.linalg.norm(near)
+    far = np.abs(A[5] + rng.normal(0, 0.06, 128).astype(F32))
+    far /= np.linalg.norm(far)
+    B = np.r_[other[:50], near[None].astype(F32), np.repeat(far[None].astype(F32), 3000, axis=0), other[50:]].astype(F32)
+    for i, im in enumerate([A, B, other2]):
+        gpu_ctx.upload_image(i, im)
+    pairs = np.array([(0, 1), (2, 1), (2, 0)], np.int32)     # (0,1) and (2,1) stream image 1 in the same group
+    offs, qt, d = gpu_ctx.match_pairs(pairs, 0.8, True, 0.7)
+    prof = gpu_ctx.profile()
+    assert prof["fallback_pairs"] >= 1 and prof["dist_kernel_launches"] >= 1
+    for p, (i, j) in enumerate(pairs):
+        oq, ot, od = oracle.match_pair([A, B, other2][i], [A, B, other2][j], 0.8, True, 0.7, nthreads=8)
+        s, e = offs[p], offs[p + 1]
+        assert np.array_equal(qt[s:e, 0], oq) and np.array_equal(qt[s:e, 1], ot) and np.array_equal(b(d[s:e]), b(od)), (i, j)
+
+
 def test_batch_mixes_paths(gpu_ctx, oracle):
     sizes = [700, 650, 300, 5, 900]
     imgs = synth.rootsift_images(len(sizes), sizes, seed=14, n_proto=1500)
