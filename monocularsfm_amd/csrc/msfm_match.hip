@@ -12,6 +12,7 @@
 #include "msfm_verify.hip.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cmath>
@@ -126,6 +127,18 @@ int fail(msfm_ctx* ctx, int code, const std::string& msg) {
     } while (0)
 
 constexpr int kFixCap = 1 << 16;
+
+// MSFM_DEBUG_TIMING=1: host-side wall clock of the orchestration phases of each batch on stderr
+struct HostClock {
+    bool on = std::getenv("MSFM_DEBUG_TIMING") != nullptr;
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    void lap(const char* what) {
+        if (!on) return;
+        const auto n = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[msfm host] %-28s %.3f ms\n", what, std::chrono::duration<double, std::milli>(n - t).count());
+        t = n;
+    }
+};
 
 // MSFM_DEBUG_SYNC=1: synchronise after every launch of the prefilter path and name it on stderr
 // (a faulting kernel is then the one named last)
@@ -305,6 +318,7 @@ std::vector<WorkItem> interleave_items(const std::vector<WorkItem>& lin) {
 //   exact pinned-order S of the candidates, 64-bit atomicMin reduce, finalize
 int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
     const size_t P = b.pairs.size();
+    HostClock hc;
     assign_partials(b, 1, 8 * ctx->cu_count);
     for (size_t p = 0; p < P; ++p) {
         b.pf[p].tu_off = b.pairs[p].kf_off;
@@ -337,6 +351,7 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
     const PairDesc* dp = ctx->d_pairs.as<PairDesc>();
     const PfPair* dpf = ctx->d_pf.as<PfPair>();
     float* tuv = ctx->d_tu.as<float>();  // rows at kf offsets, columns at kr offsets (one buffer)
+    hc.lap("sweep-1 setup + uploads");
     HIPCHK(ctx, hipEventRecord(e0, ctx->stream));
     hipLaunchKernelGGL(approx_kernel<1>, dim3((unsigned)b.items.size()), block, kPfLdsBytes, ctx->stream, dp, dpf,
                        ctx->d_items.as<WorkItem>(), ctx->d_rp_s0.as<float>(), ctx->d_rp_s1.as<float>(),
@@ -361,7 +376,9 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
         HIPCHK(ctx, hipGetLastError());
     DBGSYNC(ctx, "pf_count_live_kernel");
         HIPCHK(ctx, hipMemcpyAsync(live.data(), ctx->d_live_cnt.p, 2 * P * 4, hipMemcpyDeviceToHost, ctx->stream));
+        hc.lap("launch sweep 1 .. count");
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        hc.lap("wait for live counts (GPU)");
         for (size_t p = 0; p < P; ++p) {
             const PairDesc& pd = b.pairs[p];
             if (!pd.valid || !b.pf[p].use) continue;
@@ -519,6 +536,7 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
         HIPCHK(ctx, hipGetLastError());
     DBGSYNC(ctx, "pf_gather_live_kernel");
     }
+    hc.lap("sweep-2 descriptors + uploads");
     HIPCHK(ctx, hipEventRecord(e2, ctx->stream));
     if (!ditems.empty()) {
         hipLaunchKernelGGL(approx_kernel<2>, dim3((unsigned)ditems.size()), block, kPfLdsBytes, ctx->stream, dp, dpf,
@@ -569,7 +587,9 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
     // candidate-list overflow -> brute-force exact path for that pair
     std::vector<int> counts(P + V);
     HIPCHK(ctx, hipMemcpyAsync(counts.data(), ctx->d_cand_count.p, (P + V) * 4, hipMemcpyDeviceToHost, ctx->stream));
+    hc.lap("launch sweep 2 .. finalize");
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    hc.lap("wait for candidate counts (GPU)");
     float ms = 0.f;
     HIPCHK(ctx, hipEventElapsedTime(&ms, e0, e1));
     ctx->prof.approx_kernel_ms += ms;
