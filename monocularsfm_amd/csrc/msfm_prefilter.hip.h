@@ -479,6 +479,7 @@ __global__ __launch_bounds__(kPfThreads, 2) void approx_kernel(
         if (!kAblNoSync) {
             if (t - t_begin >= 2) wait_vmcnt<kDmaOps>();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (MSFM_ABL != 7 || ((t - t_begin) & 1) == 0)  // ablation 7: a barrier every other tile only (timing experiment)
             __builtin_amdgcn_s_barrier();  // every wave's part of tile t is in LDS; slot of tile t-1 is free
             asm volatile("" ::: "memory");
             dma_tile(t + 2);

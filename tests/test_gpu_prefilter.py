@@ -258,6 +258,22 @@ def test_compacted_group_overflow_falls_back(gpu_ctx, oracle):
         assert np.array_equal(qt[s:e, 0], oq) and np.array_equal(qt[s:e, 1], ot) and np.array_equal(b(d[s:e]), b(od)), (i, j)
 
 
+def test_self_pairs_and_repeated_pairs(gpu_ctx, oracle):
+    """An image matched against itself (every row's nearest neighbour is itself at distance 0) and the same pair
+    listed several times in one batch (their compacted rows land in the same group)."""
+    imgs = synth.rootsift_images(2, [1300, 1100], seed=51, n_proto=2600)
+    for i, im in enumerate(imgs):
+        gpu_ctx.upload_image(i, im)
+    pairs = np.array([(0, 0), (1, 0), (1, 0), (0, 1), (1, 1), (1, 0)], np.int32)
+    offs, qt, d = gpu_ctx.match_pairs(pairs, 0.8, True, 0.7)
+    for p, (i, j) in enumerate(pairs):
+        oq, ot, od = oracle.match_pair(imgs[i], imgs[j], 0.8, True, 0.7, nthreads=8)
+        s, e = offs[p], offs[p + 1]
+        assert np.array_equal(qt[s:e, 0], oq) and np.array_equal(qt[s:e, 1], ot) and np.array_equal(b(d[s:e]), b(od)), (i, j)
+    s, e = offs[0], offs[1]
+    assert e - s > 1000 and np.array_equal(qt[s:e, 0], qt[s:e, 1]) and (d[s:e] == 0).all()
+
+
 def test_batch_mixes_paths(gpu_ctx, oracle):
     sizes = [700, 650, 300, 5, 900]
     imgs = synth.rootsift_images(len(sizes), sizes, seed=14, n_proto=1500)
