@@ -100,6 +100,12 @@ int msfm_get_profile(const msfm_ctx* ctx, msfm_profile* out);
  * (src/Feature/FeatureMatching.cpp:32-33, "TODO: cache"): every image is uploaded once and
  * stays resident in HBM.  ids are Database image ids, 0 <= id < MSFM_MAX_IMAGES. */
 int msfm_upload_image(msfm_ctx* ctx, int image_id, const void* desc, int n, int dim, int dtype);
+/* A new store entry from rows of a resident one, entirely on the device: the sub-matrix
+ * FeatureUtils::ExtractTopScaleDescriptors builds (src/Feature/FeatureUtils.cpp:84-95, rows picked by
+ * msfm_topscale_select) without reading the descriptors from the database a second time
+ * (BruteFeatureMatcher::GetTopScaleDescriptors, FeatureMatching.cpp:181-196, does re-read them).
+ * rows: `count` indices into src, any order, repeats allowed; dst != src (usually MSFM_MAX_IMAGES + id). */
+int msfm_subset_image(msfm_ctx* ctx, int src_image_id, int dst_image_id, const int32_t* rows, int count);
 int msfm_image_rows(const msfm_ctx* ctx, int image_id, int* out_n);
 int msfm_clear_images(msfm_ctx* ctx);
 

@@ -22,7 +22,7 @@ EXPORTS = [
     "msfm_get_profile", "msfm_upload_image", "msfm_image_rows", "msfm_clear_images",
     "msfm_match_pair", "msfm_match_pairs", "msfm_fetch_matches", "msfm_knn2_pair",
     "msfm_topscale_select", "msfm_pair_id", "msfm_pair_from_id", "msfm_swap_image_pair",
-    "msfm_version", "msfm_upload_keypoints", "msfm_match_pairs_verified",
+    "msfm_version", "msfm_upload_keypoints", "msfm_match_pairs_verified", "msfm_subset_image",
 ]
 
 
@@ -76,6 +76,7 @@ def load():
     L.msfm_get_profile.argtypes = [vp, C.POINTER(Profile)]
     L.msfm_upload_image.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int]
     L.msfm_image_rows.argtypes = [vp, C.c_int, C.POINTER(C.c_int)]
+    L.msfm_subset_image.argtypes = [vp, C.c_int, C.c_int, ip, C.c_int]
     L.msfm_clear_images.argtypes = [vp]
     L.msfm_match_pair.argtypes = [vp, C.c_int, C.c_int, C.c_float, C.c_int, C.c_double, ip, fp, C.POINTER(C.c_int)]
     L.msfm_match_pairs.argtypes = [vp, ip, C.c_int, C.POINTER(MatchParams), C.POINTER(C.c_int64)]
@@ -170,6 +171,11 @@ class Context:
         if n == 0:
             dim = DIM
         self._chk(self._L.msfm_upload_image(self._h, int(image_id), desc.ctypes.data_as(C.c_void_p), n, dim, dtype))
+
+    def subset_image(self, src_id, dst_id, rows):
+        """dst = the given rows of the resident image src (device-side gather; no host descriptors needed)."""
+        rows = np.ascontiguousarray(rows, dtype=np.int32)
+        self._chk(self._L.msfm_subset_image(self._h, int(src_id), int(dst_id), _ip(rows), len(rows)))
 
     def image_rows(self, image_id):
         n = C.c_int()

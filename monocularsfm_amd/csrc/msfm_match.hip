@@ -853,15 +853,8 @@ int msfm_get_profile(const msfm_ctx* ctx, msfm_profile* out) {
     return MSFM_OK;
 }
 
-int msfm_upload_image(msfm_ctx* ctx, int image_id, const void* desc, int n, int dim, int dtype) {
-    if (!ctx) return MSFM_E_INVALID;
-    if (image_id < 0 || image_id >= kSlots) return fail(ctx, MSFM_E_INVALID, "image id out of range");
-    if (n < 0 || dim != MSFM_DIM) return fail(ctx, MSFM_E_INVALID, "descriptors must be n x 128");
-    if (n >= (1 << 18)) return fail(ctx, MSFM_E_INVALID, "more than 2^18 - 1 rows (BFMatcher packs the train index in 18 bits)");
-    if (dtype != MSFM_DTYPE_F32 && dtype != MSFM_DTYPE_U8) return fail(ctx, MSFM_E_INVALID, "dtype must be F32 or U8");
-    if (n > 0 && !desc) return fail(ctx, MSFM_E_INVALID, "null descriptor pointer");
-    HIPCHK(ctx, hipSetDevice(ctx->device));
-    Image& im = ctx->images[image_id];
+// allocate the store of an n-row image (panels + row-major copy); rows are filled by the caller
+static int alloc_image(msfm_ctx* ctx, Image& im, int n) {
     free_image(im);
     im.n = n;
     im.nblk = (n + kBM - 1) / kBM;
@@ -869,20 +862,24 @@ int msfm_upload_image(msfm_ctx* ctx, int image_id, const void* desc, int n, int 
     if (n == 0) return MSFM_OK;
     HIPCHK(ctx, hipMalloc((void**)&im.panel, (size_t)im.nalloc * kPanelFloats * 4));
     HIPCHK(ctx, hipMalloc((void**)&im.raw, (size_t)n * kDim * 4));
+    return MSFM_OK;
+}
+
+// everything derived from the row-major fp32 copy `im.raw` (src8 != nullptr: u8 rows still to be widened
+// into im.raw by the layout kernel): panels in accumulation order, prefilter operands
+static int build_image(msfm_ctx* ctx, Image& im, const unsigned char* src8) {
+    const int n = im.n;
     const int blocks = std::min(4096, im.nalloc * 16);
-    if (dtype == MSFM_DTYPE_F32) {
-        HIPCHK(ctx, hipMemcpyAsync(im.raw, desc, (size_t)n * kDim * 4, hipMemcpyHostToDevice, ctx->stream));
+    if (!src8) {
         if (ctx->order == MSFM_ORDER_SSE4X4)
             hipLaunchKernelGGL((layout_kernel<0, float>), dim3(blocks), dim3(256), 0, ctx->stream, im.raw, (float*)nullptr, im.panel, n, im.nalloc);
         else
             hipLaunchKernelGGL((layout_kernel<1, float>), dim3(blocks), dim3(256), 0, ctx->stream, im.raw, (float*)nullptr, im.panel, n, im.nalloc);
     } else {
-        HIPCHK(ctx, ctx->d_stage.ensure((size_t)n * kDim));
-        HIPCHK(ctx, hipMemcpyAsync(ctx->d_stage.p, desc, (size_t)n * kDim, hipMemcpyHostToDevice, ctx->stream));
         if (ctx->order == MSFM_ORDER_SSE4X4)
-            hipLaunchKernelGGL((layout_kernel<0, unsigned char>), dim3(blocks), dim3(256), 0, ctx->stream, ctx->d_stage.as<unsigned char>(), im.raw, im.panel, n, im.nalloc);
+            hipLaunchKernelGGL((layout_kernel<0, unsigned char>), dim3(blocks), dim3(256), 0, ctx->stream, src8, im.raw, im.panel, n, im.nalloc);
         else
-            hipLaunchKernelGGL((layout_kernel<1, unsigned char>), dim3(blocks), dim3(256), 0, ctx->stream, ctx->d_stage.as<unsigned char>(), im.raw, im.panel, n, im.nalloc);
+            hipLaunchKernelGGL((layout_kernel<1, unsigned char>), dim3(blocks), dim3(256), 0, ctx->stream, src8, im.raw, im.panel, n, im.nalloc);
     }
     HIPCHK(ctx, hipGetLastError());
     // prefilter operands (order-independent): fp16 swizzled blocks, norms, maxima
@@ -896,7 +893,7 @@ int msfm_upload_image(msfm_ctx* ctx, int image_id, const void* desc, int n, int 
     HIPCHK(ctx, hipGetLastError());
     unsigned mx[2] = {0, 0};
     HIPCHK(ctx, hipMemcpyAsync(mx, ctx->d_maxima.p, 8, hipMemcpyDeviceToHost, ctx->stream));
-    // the caller may free/reuse `desc` (and we reuse d_stage) as soon as we return
+    // the caller may free/reuse its buffer (and we reuse d_stage) as soon as we return
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     std::memcpy(&im.nrm_max, &mx[0], 4);
     std::memcpy(&im.abs_max, &mx[1], 4);
@@ -917,6 +914,54 @@ int msfm_upload_image(msfm_ctx* ctx, int image_id, const void* desc, int n, int 
         }
     }
     return MSFM_OK;
+}
+
+int msfm_upload_image(msfm_ctx* ctx, int image_id, const void* desc, int n, int dim, int dtype) {
+    if (!ctx) return MSFM_E_INVALID;
+    if (image_id < 0 || image_id >= kSlots) return fail(ctx, MSFM_E_INVALID, "image id out of range");
+    if (n < 0 || dim != MSFM_DIM) return fail(ctx, MSFM_E_INVALID, "descriptors must be n x 128");
+    if (n >= (1 << 18)) return fail(ctx, MSFM_E_INVALID, "more than 2^18 - 1 rows (BFMatcher packs the train index in 18 bits)");
+    if (dtype != MSFM_DTYPE_F32 && dtype != MSFM_DTYPE_U8) return fail(ctx, MSFM_E_INVALID, "dtype must be F32 or U8");
+    if (n > 0 && !desc) return fail(ctx, MSFM_E_INVALID, "null descriptor pointer");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    Image& im = ctx->images[image_id];
+    int rc = alloc_image(ctx, im, n);
+    if (rc != MSFM_OK || n == 0) return rc;
+    if (dtype == MSFM_DTYPE_F32) {
+        HIPCHK(ctx, hipMemcpyAsync(im.raw, desc, (size_t)n * kDim * 4, hipMemcpyHostToDevice, ctx->stream));
+        return build_image(ctx, im, nullptr);
+    }
+    HIPCHK(ctx, ctx->d_stage.ensure((size_t)n * kDim));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_stage.p, desc, (size_t)n * kDim, hipMemcpyHostToDevice, ctx->stream));
+    return build_image(ctx, im, ctx->d_stage.as<unsigned char>());
+}
+
+namespace {
+__global__ void subset_rows_kernel(const float* __restrict__ src, const int* __restrict__ idx, float* __restrict__ dst, int count) {
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < (long long)count * kDim; e += (long long)gridDim.x * blockDim.x)
+        dst[e] = src[(size_t)idx[e >> 7] * kDim + (e & (kDim - 1))];
+}
+}  // namespace
+
+int msfm_subset_image(msfm_ctx* ctx, int src_image_id, int dst_image_id, const int32_t* rows, int count) {
+    if (!ctx) return MSFM_E_INVALID;
+    if (src_image_id < 0 || src_image_id >= kSlots || dst_image_id < 0 || dst_image_id >= kSlots || src_image_id == dst_image_id)
+        return fail(ctx, MSFM_E_INVALID, "bad image ids for msfm_subset_image");
+    if (count < 0 || (count > 0 && !rows)) return fail(ctx, MSFM_E_INVALID, "bad row list");
+    const Image& src = ctx->images[src_image_id];
+    if (src.n < 0) return fail(ctx, MSFM_E_NOIMAGE, "image not uploaded: " + std::to_string(src_image_id));
+    for (int i = 0; i < count; ++i)
+        if (rows[i] < 0 || rows[i] >= src.n) return fail(ctx, MSFM_E_INVALID, "row index out of range in msfm_subset_image");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    Image& im = ctx->images[dst_image_id];
+    int rc = alloc_image(ctx, im, count);
+    if (rc != MSFM_OK || count == 0) return rc;
+    HIPCHK(ctx, ctx->d_stage.ensure((size_t)count * 4));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_stage.p, rows, (size_t)count * 4, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(subset_rows_kernel, dim3(std::min(1024, (count * kDim + 255) / 256)), dim3(256), 0, ctx->stream,
+                       (const float*)ctx->images[src_image_id].raw, (const int*)ctx->d_stage.as<int>(), im.raw, count);
+    HIPCHK(ctx, hipGetLastError());
+    return build_image(ctx, im, nullptr);
 }
 
 int msfm_image_rows(const msfm_ctx* ctx, int image_id, int* out_n) {

@@ -91,13 +91,19 @@ void FeatureMatcher::CloseDatabaseAndDevice() {
     g_clock = PhaseClock();
 }
 
+const std::vector<KeyPoint>& FeatureMatcher::KeyPointsOf(image_t image_id) {
+    auto it = keypoints_cache_.find(image_id);
+    if (it == keypoints_cache_.end()) it = keypoints_cache_.emplace(image_id, database_->ReadKeyPoints(image_id)).first;
+    return it->second;
+}
+
 void FeatureMatcher::EnsureResident(image_t image_id) {
     if (resident_.count(image_id)) return;
     const Descriptors d = database_->ReadDescriptors(image_id);
     MSFM_CALL(ctx_, msfm_upload_image(ctx_, image_id, d.data.data(), d.rows, d.rows ? d.cols : MSFM_DIM, MSFM_DTYPE_F32));
     if (geometric_verification_ && !verification_on_host_) {
         // the device verifies: it needs the keypoint coordinates next to the descriptors
-        const std::vector<KeyPoint> kpts = database_->ReadKeyPoints(image_id);
+        const std::vector<KeyPoint>& kpts = KeyPointsOf(image_id);
         static_assert(sizeof(KeyPoint) == 16, "KeyPoint must be 4 packed floats");
         MSFM_CALL(ctx_, msfm_upload_keypoints(ctx_, image_id, reinterpret_cast<const float*>(kpts.data()), (int)kpts.size(), 4));
     }
@@ -172,8 +178,7 @@ void FeatureMatcher::MatchImagePairGroups(const std::vector<std::vector<std::pai
         const bool host_verify = geometric_verification_ && verification_on_host_;
         if (host_verify) {
             Lap l(&g_clock.read_kp);
-            for (int32_t id : todo)
-                if (!keypoints_cache_.count(id)) keypoints_cache_[id] = database_->ReadKeyPoints(id);
+            for (int32_t id : todo) (void)KeyPointsOf(id);
         }
         Lap lv(&g_clock.verify);
         auto verify_pair = [&](int p) {
@@ -344,19 +349,17 @@ std::vector<std::pair<image_t, image_t>> BruteFeatureMatcher::PreemptivelyFilter
 int BruteFeatureMatcher::GetTopScaleDescriptors(const image_t& image_id) {
     const int slot = MSFM_MAX_IMAGES + image_id;  // auxiliary store slot of this image's subset
     if (HasTopScaleDescriptorsCache(image_id)) return slot;
-    const std::vector<KeyPoint> kpts = database_->ReadKeyPoints(image_id);
-    const Descriptors descriptors = database_->ReadDescriptors(image_id);
+    // the reference re-reads the descriptors here (FeatureMatching.cpp:181-196); they are resident on the
+    // device already (or become so now), so only the keypoint scales are needed on the host
+    EnsureResident(image_id);
+    const std::vector<KeyPoint>& kpts = KeyPointsOf(image_id);
     static_assert(sizeof(KeyPoint) == 16, "KeyPoint must be 4 packed floats");
     std::vector<int32_t> idx(kpts.size() + 1);
     int count = 0;
     const int rc = msfm_topscale_select(reinterpret_cast<const float*>(kpts.data()), (int)kpts.size(),
                                         preemtive_num_features_, idx.data(), &count);
     if (rc != MSFM_OK) Die(ctx_, "msfm_topscale_select", rc);
-    std::vector<float> top((size_t)count * MSFM_DIM);
-    for (int i = 0; i < count; ++i)
-        for (int c = 0; c < MSFM_DIM; ++c)
-            top[(size_t)i * MSFM_DIM + c] = descriptors.data[(size_t)idx[(size_t)i] * MSFM_DIM + c];
-    MSFM_CALL(ctx_, msfm_upload_image(ctx_, slot, top.data(), count, MSFM_DIM, MSFM_DTYPE_F32));
+    MSFM_CALL(ctx_, msfm_subset_image(ctx_, image_id, slot, idx.data(), count));
     top_scale_descriptors_cache_.insert(image_id);
     return slot;
 }

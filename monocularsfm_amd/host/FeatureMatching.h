@@ -41,6 +41,7 @@ protected:
     void OpenDatabaseAndDevice();
     void CloseDatabaseAndDevice();
     void EnsureResident(image_t image_id);
+    const std::vector<KeyPoint>& KeyPointsOf(image_t image_id);  // read once per image
 
     std::string database_path_;
     int max_num_matches_;  // stored, never read -- as in the reference

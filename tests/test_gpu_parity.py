@@ -245,3 +245,31 @@ def test_full_size_properties(gpu_ctx, oracle):
     # (6) self-match: every descriptor's nearest neighbour in its own image is itself at distance 0
     fs, _ = gpu_ctx.knn2_pair(0, 0)
     assert np.array_equal(fs[0], np.arange(n1)) and (fs[1] == 0).all()
+
+
+def test_subset_image_equals_uploading_the_rows(gpu_ctx, oracle):
+    """msfm_subset_image (device-side ExtractTopScaleDescriptors sub-matrix) == uploading those rows from the host."""
+    imgs = synth.rootsift_images(2, [900, 700], seed=61, n_proto=1500)
+    kp = synth.keypoints(900, seed=3)
+    sel = _lib.topscale_select(kp, 100)
+    gpu_ctx.upload_image(0, imgs[0])
+    gpu_ctx.upload_image(1, imgs[1])
+    gpu_ctx.subset_image(0, _lib.MAX_IMAGES + 0, sel)
+    gpu_ctx.upload_image(_lib.MAX_IMAGES + 5, imgs[0][sel])
+    assert gpu_ctx.image_rows(_lib.MAX_IMAGES + 0) == 100
+    a = gpu_ctx.match_pair(_lib.MAX_IMAGES + 0, 1, 0.8, True, float("inf"))
+    c = gpu_ctx.match_pair(_lib.MAX_IMAGES + 5, 1, 0.8, True, float("inf"))
+    oq, ot, od = oracle.match_pair(imgs[0][sel], imgs[1], 0.8, True, np.inf, nthreads=4)
+    for x, y, z in zip(a, c, (oq, ot, od)):
+        assert np.array_equal(b(x), b(y)) and np.array_equal(b(x), b(z))
+    fa, ra = gpu_ctx.knn2_pair(1, _lib.MAX_IMAGES + 0)
+    fc, rc = gpu_ctx.knn2_pair(1, _lib.MAX_IMAGES + 5)
+    for x, y in zip(fa + ra, fc + rc):
+        assert np.array_equal(b(x), b(y))
+    # k > n: identity; repeats and arbitrary order are allowed; errors are reported
+    gpu_ctx.subset_image(1, _lib.MAX_IMAGES + 1, np.array([5, 5, 699, 0], np.int32))
+    assert gpu_ctx.image_rows(_lib.MAX_IMAGES + 1) == 4
+    with pytest.raises(_lib.MsfmError):
+        gpu_ctx.subset_image(1, _lib.MAX_IMAGES + 1, np.array([700], np.int32))
+    with pytest.raises(_lib.MsfmError):
+        gpu_ctx.subset_image(1, 1, np.array([0], np.int32))
