@@ -177,9 +177,7 @@ constexpr int kPfRing = 3;
 #ifndef MSFM_ABL
 #define MSFM_ABL 0
 #endif
-#ifndef MSFM_HINT_VALU
-#define MSFM_HINT_VALU 3
-#endif
+
 constexpr bool kAblNoEpi = MSFM_ABL == 1 || MSFM_ABL == 5 || MSFM_ABL == 6;
 constexpr bool kAblNoMfma = MSFM_ABL == 2;
 constexpr bool kAblNoLds = MSFM_ABL == 3 || MSFM_ABL == 5 || MSFM_ABL == 6;
@@ -357,7 +355,7 @@ __global__ __launch_bounds__(kPfThreads, 2) void approx_kernel(
         }
     };
     // branch-free part of the epilogue; returns "this lane saw a hit" for the sweep-2 variants
-    auto epilogue_valu = [&](const f16v (&acc)[2], const BlockMeta& bm) -> bool {
+    auto epilogue_valu = [&](const f16v (&acc)[2], const BlockMeta& bm, bool do_rows = true) -> bool {
         if (kAblNoEpi) {
             rs0[0][0] = fmaxf(rs0[0][0], acc[0][0] + acc[1][15]);
             return false;
@@ -374,10 +372,12 @@ __global__ __launch_bounds__(kPfThreads, 2) void approx_kernel(
             // Only MAXIMA are tracked: the second smallest of the minima of S~ over disjoint subsets is an
             // upper bound of the true second-smallest S~, which is all the threshold needs (it is exact
             // unless both neighbours fall into one subset).
+            if (do_rows) {
 #pragma unroll
-            for (int rb = 0; rb < 2; ++rb)
+                for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) rs0[rb][r] = fmaxf(rs0[rb][r], acc[rb][r]);
+                    for (int r = 0; r < 16; ++r) rs0[rb][r] = fmaxf(rs0[rb][r], acc[rb][r]);
+            }
             // partner lane (l ^ 32): the other 32 rows of the wave
             const float other = __shfl_xor(m, 32);
             // (s0, s1) of this wave's 64 rows for column bm.col -> LDS (inline asm: see append_hits)
@@ -432,18 +432,6 @@ __global__ __launch_bounds__(kPfThreads, 2) void approx_kernel(
             n_buf += __popcll(mm);
         }
     };
-    // interleave hint: one MFMA, then a slice of the epilogue's VALU work, 18 times
-    auto interleave_hint = [&]() {
-#ifdef MSFM_NO_HINT
-        return;
-#endif
-#pragma unroll
-        for (int k = 0; k < 18; ++k) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                          // 1 MFMA
-            __builtin_amdgcn_sched_group_barrier(0x002, PASS == 1 ? MSFM_HINT_VALU : (PASS == 2 ? 4 : 1), 0);      // VALU
-        }
-    };
-
     // sweep 1: lane = column of tile tt; fold the four waves' (s0, s1) and store one partial per A block
     auto merge_columns = [&](int tt) {
         const unsigned base = colbuf_lds + (unsigned)((((tt - t_begin) % kPfRing) * 4) * 64 + lane) * 8u;
@@ -459,13 +447,13 @@ __global__ __launch_bounds__(kPfThreads, 2) void approx_kernel(
         cp_s1[o] = w0.y;
     };
 
-    // accB / metaB start as a harmless dummy block (accumulator -inf: no maximum moves, no hit; its
-    // column partial lands in an LDS slot that a real block rewrites before it is merged), so that every
-    // iteration runs the same instruction sequence -- the counted waits rely on it
+    // Both column blocks of a tile are multiplied first (four independent accumulator chains), then their
+    // epilogues run together: rows take ONE v_max3 per pair of elements (running maximum, block cb 0, block
+    // cb 1), and no accumulator lives across the loop back-edge -- carrying the second block's accumulator
+    // into the next iteration (to overlap its epilogue with the next MFMAs) cost 32 register copies per tile
+    // and bought nothing: MFMA and VALU issue of a SIMD do not overlap on this part (tools/ubench_mfma_valu).
     f16v accA[2], accB[2];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { accB[0][r] = -f_inf(); accB[1][r] = -f_inf(); }
-    BlockMeta metaA = {0.f, 0, 0}, metaB = {f_inf(), t_begin * kPfBT + 32 + lcol, (2 * 4 + wave) * 64 + 32};
+    BlockMeta metaA = {0.f, 0, 0}, metaB = {0.f, 0, 0};
 #if MSFM_ABL
     h8 bf[9];  // must survive the iteration when the reads are ablated
 #endif
@@ -477,14 +465,14 @@ __global__ __launch_bounds__(kPfThreads, 2) void approx_kernel(
         // the (sweep-1) stores: "at most kDmaOps outstanding" implies every load of tile t is done,
         // because a pending load of tile t would keep all kDmaOps loads of tile t+1 pending as well.
         if (!kAblNoSync) {
-            if (t - t_begin >= 2) wait_vmcnt<kDmaOps>();
+            if (MSFM_ABL != 8 && t - t_begin >= 2) wait_vmcnt<kDmaOps>();  // ablation 8: do not wait for the DMA (timing experiment)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if (MSFM_ABL != 7 || ((t - t_begin) & 1) == 0)  // ablation 7: a barrier every other tile only (timing experiment)
             __builtin_amdgcn_s_barrier();  // every wave's part of tile t is in LDS; slot of tile t-1 is free
             asm volatile("" ::: "memory");
             dma_tile(t + 2);
         }
-        // tile t-2's column partials are complete in LDS (its last epilogue ran before this barrier)
+        // tile t-2's column partials are complete in LDS (its epilogues ran before the previous barrier)
         if (PASS == 1 && t - t_begin >= 2 && wave == (t & 3)) merge_columns(t - 2);
         const int sl = (t - t_begin) % kPfRing;
         const char* pb = sB + sl * kPfLdsB + lcol * kHalfRowBytes;
@@ -497,29 +485,29 @@ __global__ __launch_bounds__(kPfThreads, 2) void approx_kernel(
 #if !MSFM_ABL
             h8 bf[9];
 #endif
-            // stage 1: MFMA (t, cb 0) -> accA   ||   epilogue of (t-1, cb 1) in accB
             load_bf(pb, pe_off, 0, bf);
             metaA.hc = (PASS == 2) ? -0.5f * thr[lcol] : 0.f;
             metaA.col = t * kPfBT + lcol;
             metaA.cslot = (sl * 4 + wave) * 64;
             mfma_block(bf, accA);
-            bool any = epilogue_valu(accB, metaB);
-            interleave_hint();
-            if (PASS >= 2) append_hits(any, accB, metaB);
-            // stage 2: MFMA (t, cb 1) -> accB   ||   epilogue of (t, cb 0) in accA
             load_bf(pb, pe_off, 1, bf);
             metaB.hc = (PASS == 2) ? -0.5f * thr[32 + lcol] : 0.f;
             metaB.col = t * kPfBT + 32 + lcol;
             metaB.cslot = (sl * 4 + wave) * 64 + 32;
             mfma_block(bf, accB);
-            any = epilogue_valu(accA, metaA);
-            interleave_hint();
-            if (PASS >= 2) append_hits(any, accA, metaA);
+            const bool anyA = epilogue_valu(accA, metaA, false);
+            const bool anyB = epilogue_valu(accB, metaB, false);
+            if (PASS == 1 && !kAblNoEpi) {
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) rs0[rb][r] = max3f(rs0[rb][r], accA[rb][r], accB[rb][r]);
+            }
+            if (PASS >= 2) {
+                append_hits(anyA, accA, metaA);
+                append_hits(anyB, accB, metaB);
+            }
         }
-    }
-    if (wave_active) {   // drain: epilogue of the last block
-        const bool any = epilogue_valu(accB, metaB);
-        if (PASS >= 2) append_hits(any, accB, metaB);
     }
     if (PASS >= 2) flush_candidates();
     if (PASS == 1) {

@@ -3,7 +3,7 @@
 # (results of the ablated builds are wrong by construction; only the kernel times matter).
 set -u
 ROOT=$(pwd)
-for v in 0 1 2 3 4 5 6; do
+for v in 0 1 2 3 4 5 6 7 8; do
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -I$ROOT/include -DMSFM_ABL=$v -shared \
       -o /tmp/libmsfm_abl$v.so $ROOT/monocularsfm_amd/csrc/msfm_match.hip 2>&1 | grep -E "error" 
 done
@@ -13,8 +13,8 @@ sys.path.insert(0, '.')
 from monocularsfm_amd import _lib, synth
 imgs = synth.rootsift_images(32, 5000, seed=11)
 pairs = np.array([(i, j) for i in range(32) for j in range(i)], np.int32)
-names = {0: "full", 1: "no epilogue", 2: "no MFMA", 3: "no LDS B reads", 4: "no barrier/DMA", 5: "no epi + no LDS", 6: "MFMA only"}
-for v in range(7):
+names = {0: "full", 1: "no epilogue", 2: "no MFMA", 3: "no LDS B reads", 4: "no barrier/DMA", 5: "no epi + no LDS", 6: "MFMA only", 7: "barrier every 2nd tile", 8: "no DMA wait"}
+for v in range(9):
     _lib._lib = None
     _lib.LIB_PATH = "/tmp/libmsfm_abl%d.so" % v
     ctx = _lib.Context(0)
