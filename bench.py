@@ -31,6 +31,7 @@ sys.path.insert(0, ROOT)
 FLOPS_PER_DESC_PAIR = 384.0   # 128 x (sub, mul, add), not fused (direct form)
 PEAK_FP32_VALU_TFLOPS = 157.3  # MI355X_MICROARCH.md: peak FP32 vector (FMA = 2 flop) = f32 MFMA rate
 PEAK_HBM_GBPS = 8000.0
+MEASURED_MFMA_TFLOPS = 4 * 256 * (2 * 32768) / 32.1e-9 / 1e12   # see roofline.measured_mfma_issue_ceiling
 PEAK_F16_MFMA_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16/f16 MFMA peak
 
 
@@ -241,6 +242,9 @@ def main():
             "kernel": "approx_kernel<1> (MFMA prefilter sweep 1; sweep 2 and the exact fp32 re-check only touch survivors)",
             "bound": "mfma", "achieved": achieved, "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": achieved / PEAK_F16_MFMA_TFLOPS,
+            # a loop of nothing but independent v_mfma_f32_32x32x16_f16 sustains 2 MFMA / 32.1 ns per SIMD on this part
+            # (profiles/r01_ubench_mfma_valu.txt): 2.09 PFLOP/s, not the 2.5 of the data sheet
+            "measured_mfma_issue_ceiling": MEASURED_MFMA_TFLOPS, "frac_of_measured_ceiling": achieved / MEASURED_MFMA_TFLOPS,
             "traffic": tr["bytes_per_launch"] if tr else None, "traffic_unit": "HBM bytes/launch (PMC)", "traffic_detail": tr,
             "avg_launch_ms": avg_ms, "launches": pf_launches, "flops_per_desc_pair": 256.0,
             "descriptor_pairs_per_launch": pf_pairs_work / pf_launches,
