@@ -105,13 +105,28 @@ def gather_matches(local_idx, local_offs, local_qt, local_dist, n_pairs, group=N
     return offs, qt, dd.view(np.float32)
 
 
+_staging = {}
+
+
+def _host_buffer(rows, cols, pinned, slot="recv"):
+    """Host staging buffers of the exchange step; pinned (page-locked) when they talk to a GPU.
+    Pinning 100+ MB costs tens of milliseconds, so the buffers are kept and only grown."""
+    import torch
+    key = (slot, cols, bool(pinned))
+    buf = _staging.get(key)
+    if buf is None or buf.shape[0] < rows:
+        buf = torch.empty((max(rows, 1) * 5 // 4 + 1024, cols), dtype=torch.int32, pin_memory=bool(pinned))
+        _staging[key] = buf
+    return buf[:rows]
+
+
 def gather_to_writer(local_idx, local_offs, local_qt, local_dist, n_pairs, dst=0, group=None, device=None,
                      with_dist=True, force_collectives=False):
     """The exchange step of the CLI flow: only the rank that owns the SQLite handle needs the match lists.
 
     Every rank returns the global CSR offsets (one all_reduce of the per-pair counts); rank `dst` also returns
     qt int32[M,2] (and dist float32[M] if with_dist) in global pair order, the other ranks return None for
-    them.  The `matches` table stores index pairs only (Database.cpp:631-654), so with_dist=False is what the
+    them.  With with_dist=False the returned qt is a view of a reused staging buffer: valid until the next call.  The `matches` table stores index pairs only (Database.cpp:631-654), so with_dist=False is what the
     writer needs; the payload then is 8 bytes per match.  Per-rank pair ranges must be contiguous and in rank
     order (partition_pairs), so the payload is reassembled by concatenation."""
     import torch
@@ -152,18 +167,20 @@ def gather_to_writer(local_idx, local_offs, local_qt, local_dist, n_pairs, dst=0
     cols = 3 if with_dist else 2
     max_m = max(int(per_rank_total.max()), 1)
     m_local = int(local_counts.sum())
-    send = torch.zeros((max_m, cols), dtype=torch.int32)
+    pin = dev.type == "cuda"
+    # rank-padded payload; the padding rows are never read (receivers slice by the counts), so no zero fill
+    stage = _host_buffer(max_m, cols, pin, slot="send")
     if m_local:
-        send[:m_local, 0:2] = torch.from_numpy(qt_local)
+        sv = stage.numpy()
+        sv[:m_local, 0:2] = qt_local
         if with_dist:
-            send[:m_local, 2] = torch.from_numpy(np.ascontiguousarray(local_dist, dtype=np.float32).view(np.int32))
-    send = send.to(dev)
+            sv[:m_local, 2] = np.ascontiguousarray(local_dist, dtype=np.float32).view(np.int32)
+    send = stage.to(dev, non_blocking=pin) if pin else stage.clone()
     if rank == dst:
         recv = [torch.empty_like(send) for _ in range(world)]
         dist.gather(send, recv, dst=dst, group=group)
         M = int(offs[-1])
-        pin = dev.type == "cuda"
-        out = torch.empty((M, cols), dtype=torch.int32, pin_memory=pin)
+        out = _host_buffer(M, cols, pin, slot="recv")
         at = 0
         for r in range(world):
             k = int(per_rank_total[r])
@@ -171,10 +188,11 @@ def gather_to_writer(local_idx, local_offs, local_qt, local_dist, n_pairs, dst=0
             at += k
         if pin:
             torch.cuda.synchronize(dev)
-        allm = out.numpy()
-        qt = np.ascontiguousarray(allm[:, 0:2])
-        dd = np.ascontiguousarray(allm[:, 2]).view(np.float32) if with_dist else None
-        return offs, qt, dd
+        allm = out.numpy()   # a view of the reused staging buffer
+        if with_dist:
+            return offs, np.array(allm[:, 0:2], dtype=np.int32, order="C"), np.array(allm[:, 2], dtype=np.int32).view(np.float32)
+        # (q, t) only: the staging buffer IS the result -- no copy of 100+ MB; valid until the next call
+        return offs, allm, None
     dist.gather(send, None, dst=dst, group=group)
     return offs, None, None
 
