@@ -158,7 +158,8 @@ __device__ __forceinline__ void v2_merge(float& s0, float& s1, float b0, float b
 //   younger tiles stay in flight across the barrier.  The tile's norm quadruples (and the dense sweep's
 //   column thresholds) ride along as per-wave DMAs, so the loop contains no ordinary global load that
 //   would make hipcc drain vmcnt(0).
-//   Per tile and column block: 2 x 9 MFMA 32x32x16 f16, then the epilogue on the 2 x 16 results.
+//   Per tile and column block: 2 x (8 MFMA 32x32x16 f16 + 1 MFMA 32x32x8 f16 for the norm quadruple), then the
+//   epilogue on the 2 x 16 results.
 //   MFMA layout: lane l feeds A[row l&31][k (l>>5)*8..+7] and B[col l&31][same k]; it receives for
 //   column l&31 the 16 rows (r&3) + 8 (r>>2) + 4 (l>>5), r = 0..15.
 // PASS 1: accumulator = -S~/2.  Row maxima (1 op / element), column maxima (v_max3: 0.5 op / element);
@@ -349,9 +350,15 @@ __global__ __launch_bounds__(kPfThreads, 2) void approx_kernel(
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
 #pragma unroll
-        for (int ks = 0; ks < 9; ++ks) {
+        for (int ks = 0; ks < 8; ++ks) {
             acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][ks], bf[ks], acc[0], 0, 0, 0);
             acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[1][ks], bf[ks], acc[1], 0, 0, 0);
+        }
+        {   // the quadruple only fills k = 0..3: the K = 8 instruction (lane l: k = 4 (l >> 5) .. +3) takes half the passes
+            typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+            const h4 b4 = __builtin_shufflevector(bf[8], bf[8], 0, 1, 2, 3);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x8f16(__builtin_shufflevector(af[0][8], af[0][8], 0, 1, 2, 3), b4, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x8f16(__builtin_shufflevector(af[1][8], af[1][8], 0, 1, 2, 3), b4, acc[1], 0, 0, 0);
         }
     };
     // branch-free part of the epilogue; returns "this lane saw a hit" for the sweep-2 variants
