@@ -96,7 +96,7 @@ struct msfm_ctx {
     // prefilter path
     int prefilter = 1;
     DevBuf d_pf, d_tu, d_tv, d_cand, d_cand_s, d_cand_count, d_best, d_second, d_maxima;
-    DevBuf d_live_cnt, d_cmp_h, d_cmp_tu, d_live_idx, d_row_pair, d_cand_pair, d_vpairs, d_vpf, d_vitems, d_jobs, d_lists;
+    DevBuf d_live_cnt, d_cmp_h, d_cmp_tu, d_live_idx, d_row_pair, d_cand_pair, d_active, d_vpairs, d_vpf, d_vitems, d_jobs, d_lists;
     // geometric verification
     DevBuf d_vf_pairs, d_vf_x1, d_vf_y1, d_vf_x2, d_vf_y2, d_vf_hyp, d_vf_best_it, d_vf_best_count, d_vf_flags,
         d_st2_qt, d_st2_d, d_counts2;
@@ -517,6 +517,12 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
     HIPCHK(ctx, ctx->d_lists.ensure((P + V) * sizeof(CandList)));
     HIPCHK(ctx, hipMemsetAsync(ctx->d_cand_count.p, 0, (P + V) * 4, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(ctx->d_lists.p, lists.data(), (P + V) * sizeof(CandList), hipMemcpyHostToDevice, ctx->stream));
+    std::vector<int> active;  // the exact / reduce kernels only visit lists that can hold candidates
+    for (size_t l = 0; l < P + V; ++l)
+        if (lists[l].cap > 0) active.push_back((int)l);
+    HIPCHK(ctx, ctx->d_active.ensure(std::max<size_t>(1, active.size()) * 4));
+    if (!active.empty())
+        HIPCHK(ctx, hipMemcpyAsync(ctx->d_active.p, active.data(), active.size() * 4, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(ctx->d_pf.p, b.pf.data(), P * sizeof(PfPair), hipMemcpyHostToDevice, ctx->stream));  // cand_off / cap
     if (!ditems.empty()) {
         HIPCHK(ctx, hipMemcpyAsync(ctx->d_items.p, ditems.data(), ditems.size() * sizeof(WorkItem), hipMemcpyHostToDevice, ctx->stream));
@@ -557,27 +563,30 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
     }
     HIPCHK(ctx, hipEventRecord(e3, ctx->stream));
 
-    const CandList* dl = ctx->d_lists.as<CandList>();
-    const dim3 cgrid(64, (unsigned)(P + V));
-    if (ctx->order == MSFM_ORDER_SSE4X4)
-        hipLaunchKernelGGL(pf_exact_candidates_kernel<0>, cgrid, dim3(256), 0, ctx->stream, dp, dl, ctx->d_cand_count.as<int>(),
-                           ctx->d_cand.as<int2>(), ctx->d_cand_s.as<float>(), ctx->d_cand_pair.as<int>());
-    else
-        hipLaunchKernelGGL(pf_exact_candidates_kernel<1>, cgrid, dim3(256), 0, ctx->stream, dp, dl, ctx->d_cand_count.as<int>(),
-                           ctx->d_cand.as<int2>(), ctx->d_cand_s.as<float>(), ctx->d_cand_pair.as<int>());
-    HIPCHK(ctx, hipGetLastError());
-    DBGSYNC(ctx, "pf_exact_candidates_kernel<1>");
-    const dim3 rgrid(16, (unsigned)(P + V));
-    hipLaunchKernelGGL(pf_reduce_best_kernel, rgrid, dim3(256), 0, ctx->stream, dp, dl, ctx->d_cand_count.as<int>(),
-                       ctx->d_cand.as<int2>(), ctx->d_cand_s.as<float>(), (const int*)ctx->d_cand_pair.as<int>(),
-                       ctx->d_best.as<unsigned long long>());
-    HIPCHK(ctx, hipGetLastError());
-    DBGSYNC(ctx, "pf_reduce_best_kernel");
-    hipLaunchKernelGGL(pf_reduce_second_kernel, rgrid, dim3(256), 0, ctx->stream, dp, dl, ctx->d_cand_count.as<int>(),
-                       ctx->d_cand.as<int2>(), ctx->d_cand_s.as<float>(), (const int*)ctx->d_cand_pair.as<int>(),
-                       ctx->d_best.as<unsigned long long>(), ctx->d_second.as<unsigned long long>());
-    HIPCHK(ctx, hipGetLastError());
-    DBGSYNC(ctx, "pf_reduce_second_kernel");
+    if (!active.empty()) {
+        const CandList* dl = ctx->d_lists.as<CandList>();
+        const dim3 cgrid(64, (unsigned)std::max<size_t>(1, active.size()));
+        const int* dact = ctx->d_active.as<int>();
+        if (ctx->order == MSFM_ORDER_SSE4X4)
+            hipLaunchKernelGGL(pf_exact_candidates_kernel<0>, cgrid, dim3(256), 0, ctx->stream, dp, dl, dact, ctx->d_cand_count.as<int>(),
+                               ctx->d_cand.as<int2>(), ctx->d_cand_s.as<float>(), ctx->d_cand_pair.as<int>());
+        else
+            hipLaunchKernelGGL(pf_exact_candidates_kernel<1>, cgrid, dim3(256), 0, ctx->stream, dp, dl, dact, ctx->d_cand_count.as<int>(),
+                               ctx->d_cand.as<int2>(), ctx->d_cand_s.as<float>(), ctx->d_cand_pair.as<int>());
+        HIPCHK(ctx, hipGetLastError());
+        DBGSYNC(ctx, "pf_exact_candidates_kernel<1>");
+        const dim3 rgrid(16, (unsigned)std::max<size_t>(1, active.size()));
+        hipLaunchKernelGGL(pf_reduce_best_kernel, rgrid, dim3(256), 0, ctx->stream, dp, dl, dact, ctx->d_cand_count.as<int>(),
+                           ctx->d_cand.as<int2>(), ctx->d_cand_s.as<float>(), (const int*)ctx->d_cand_pair.as<int>(),
+                           ctx->d_best.as<unsigned long long>());
+        HIPCHK(ctx, hipGetLastError());
+        DBGSYNC(ctx, "pf_reduce_best_kernel");
+        hipLaunchKernelGGL(pf_reduce_second_kernel, rgrid, dim3(256), 0, ctx->stream, dp, dl, dact, ctx->d_cand_count.as<int>(),
+                           ctx->d_cand.as<int2>(), ctx->d_cand_s.as<float>(), (const int*)ctx->d_cand_pair.as<int>(),
+                           ctx->d_best.as<unsigned long long>(), ctx->d_second.as<unsigned long long>());
+        HIPCHK(ctx, hipGetLastError());
+        DBGSYNC(ctx, "pf_reduce_second_kernel");
+    }
     hipLaunchKernelGGL(pf_finalize_kernel, mgrid, dim3(256), 0, ctx->stream, dp, dpf, (const float*)tuv, ctx->d_best.as<unsigned long long>(),
                        ctx->d_second.as<unsigned long long>(), ctx->d_k_i0.as<int>(), ctx->d_k_d0.as<float>(),
                        ctx->d_k_d1.as<float>(), ctx->d_fix_count.as<int>(), ctx->d_fix_list.as<int4>(), kFixCap);
@@ -802,7 +811,7 @@ void msfm_destroy(msfm_ctx* ctx) {
                       &ctx->d_out_d, &ctx->d_fix_count, &ctx->d_fix_list, &ctx->d_pf, &ctx->d_tu, &ctx->d_tv,
                       &ctx->d_cand, &ctx->d_cand_s, &ctx->d_cand_count, &ctx->d_best, &ctx->d_second, &ctx->d_maxima,
                       &ctx->d_live_cnt, &ctx->d_cmp_h, &ctx->d_cmp_tu, &ctx->d_live_idx, &ctx->d_vpairs, &ctx->d_vpf,
-                      &ctx->d_vitems, &ctx->d_jobs, &ctx->d_lists, &ctx->d_row_pair, &ctx->d_cand_pair, &ctx->d_vf_pairs, &ctx->d_vf_x1, &ctx->d_vf_y1,
+                      &ctx->d_vitems, &ctx->d_jobs, &ctx->d_lists, &ctx->d_row_pair, &ctx->d_cand_pair, &ctx->d_active, &ctx->d_vf_pairs, &ctx->d_vf_x1, &ctx->d_vf_y1,
                       &ctx->d_vf_x2, &ctx->d_vf_y2, &ctx->d_vf_hyp, &ctx->d_vf_best_it, &ctx->d_vf_best_count,
                       &ctx->d_vf_flags, &ctx->d_st2_qt, &ctx->d_st2_d, &ctx->d_counts2};
     for (DevBuf* b : bufs) b->release();

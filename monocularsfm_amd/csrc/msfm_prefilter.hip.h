@@ -631,11 +631,13 @@ struct CandList {
 // Records are rewritten in place as real (q, t).   grid = (x, n_lists)
 template <int ORDER>
 __global__ void pf_exact_candidates_kernel(const PairDesc* __restrict__ pairs, const CandList* __restrict__ lists,
+                                           const int* __restrict__ active /* ids of the non-empty lists */,
                                            const int* __restrict__ cand_count, int2* __restrict__ cand,
                                            float* __restrict__ cand_s, int* __restrict__ cand_pair) {
-    const CandList L = lists[blockIdx.y];
+    const int lid = active[blockIdx.y];
+    const CandList L = lists[lid];
     if (L.cap == 0) return;
-    const int n = min(cand_count[blockIdx.y], L.cap);
+    const int n = min(cand_count[lid], L.cap);
     const int sub = threadIdx.x & 15;
     for (int c = (blockIdx.x * blockDim.x + threadIdx.x) >> 4; c < ((n + 3) & ~3); c += (gridDim.x * blockDim.x) >> 4) {
         const bool live = c < n;
@@ -699,12 +701,13 @@ __device__ __forceinline__ unsigned long long pf_key(float s, int idx) {
 // A mode-1 list only serves the row direction, a mode-2 list only the column direction: the live
 // rows of the OTHER direction get their complete candidate sets from their own list.
 __global__ void pf_reduce_best_kernel(const PairDesc* __restrict__ pairs, const CandList* __restrict__ lists,
-                                      const int* __restrict__ cand_count, const int2* __restrict__ cand,
-                                      const float* __restrict__ cand_s, const int* __restrict__ cand_pair,
-                                      unsigned long long* __restrict__ best) {
-    const CandList L = lists[blockIdx.y];
+                                      const int* __restrict__ active, const int* __restrict__ cand_count,
+                                      const int2* __restrict__ cand, const float* __restrict__ cand_s,
+                                      const int* __restrict__ cand_pair, unsigned long long* __restrict__ best) {
+    const int lid = active[blockIdx.y];
+    const CandList L = lists[lid];
     if (L.cap == 0) return;
-    const int n = min(cand_count[blockIdx.y], L.cap);
+    const int n = min(cand_count[lid], L.cap);
     for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < n; c += gridDim.x * blockDim.x) {
         const int2 qt = cand[L.off + c];
         const float s = cand_s[L.off + c];
@@ -716,13 +719,14 @@ __global__ void pf_reduce_best_kernel(const PairDesc* __restrict__ pairs, const 
 }
 // reduce phase B: second best = min over the candidates that are not the best one
 __global__ void pf_reduce_second_kernel(const PairDesc* __restrict__ pairs, const CandList* __restrict__ lists,
-                                        const int* __restrict__ cand_count, const int2* __restrict__ cand,
-                                        const float* __restrict__ cand_s, const int* __restrict__ cand_pair,
-                                        const unsigned long long* __restrict__ best,
+                                        const int* __restrict__ active, const int* __restrict__ cand_count,
+                                        const int2* __restrict__ cand, const float* __restrict__ cand_s,
+                                        const int* __restrict__ cand_pair, const unsigned long long* __restrict__ best,
                                         unsigned long long* __restrict__ second) {
-    const CandList L = lists[blockIdx.y];
+    const int lid = active[blockIdx.y];
+    const CandList L = lists[lid];
     if (L.cap == 0) return;
-    const int n = min(cand_count[blockIdx.y], L.cap);
+    const int n = min(cand_count[lid], L.cap);
     for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < n; c += gridDim.x * blockDim.x) {
         const int2 qt = cand[L.off + c];
         const float s = cand_s[L.off + c];
