@@ -1013,7 +1013,7 @@ static int match_pairs_impl(msfm_ctx* ctx, const int32_t* pairs, int n_pairs, co
 
     // sub-batches bounded by the partial-result scratch (12 B per partial entry)
     const long long kScratchElems = (long long)5 << 30;  // ~20 GiB of scratch (4-byte units) at most, of 288 GB HBM
-    const int kMaxPairsPerBatch = 4096;
+    const int kMaxPairsPerBatch = 16384;
     size_t ev_next = 2;
     std::vector<size_t> ev_of_batch;
     int begin = 0;
