@@ -1012,7 +1012,7 @@ static int match_pairs_impl(msfm_ctx* ctx, const int32_t* pairs, int n_pairs, co
     HIPCHK(ctx, hipEventRecord(ev_begin, ctx->stream));
 
     // sub-batches bounded by the partial-result scratch (12 B per partial entry)
-    const long long kScratchElems = (long long)5 << 30;  // ~20 GiB of scratch (4-byte units) at most, of 288 GB HBM
+    const long long kScratchElems = (long long)12 << 30;  // ~48 GiB of scratch (4-byte units) at most, of 288 GB HBM
     const int kMaxPairsPerBatch = 16384;
     size_t ev_next = 2;
     std::vector<size_t> ev_of_batch;
