@@ -231,7 +231,7 @@ __global__ __launch_bounds__(kPfThreads, 2) void approx_kernel(
         const char* g = gB + (size_t)tc * kPfLdsB + wave * 4096 + lane * 16;
         char* l = sB + sl * kPfLdsB + wave * 4096;
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
+        for (int k = 0; k < (MSFM_ABL == 9 ? 2 : 4); ++k)  // ablation 9: half of the tile DMA (timing experiment)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + k * 1024),
                                              (__attribute__((address_space(3))) void*)(l + k * 1024), 16, 0, 0);
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gE + (size_t)tc * kPfExtB + lane * 16),
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(kPfThreads, 2) void approx_kernel(
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(tv + pp.tv_off + tc * kPfBT + lane),
                                              (__attribute__((address_space(3))) void*)(thr_w + sl * 64), 4, 0, 0);
     };
-    constexpr int kDmaOps = (PASS == 2) ? 6 : 5;
+    constexpr int kDmaOps = ((PASS == 2) ? 6 : 5) - (MSFM_ABL == 9 ? 2 : 0);
 
     dma_tile(t_begin);
     dma_tile(t_begin + 1);
