@@ -130,6 +130,9 @@ def main():
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--order", type=int, default=0, help="0: OpenCV SSE order (default), 1: AVX2+FMA order")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend; gloo (+ --share-gpu) runs the multi-rank flow on a box with fewer GPUs than ranks")
+    ap.add_argument("--share-gpu", action="store_true", help="every rank uses GPU 0 (flow check only: the value is meaningless)")
     ap.add_argument("--force-collectives", action="store_true",
                     help="run the RCCL exchange step even with one rank (sanity check of the multi-GPU path on a 1-GPU box)")
     ap.add_argument("--no-prefilter", action="store_true",
@@ -151,12 +154,18 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; no GPU visible (there is no CPU fallback)")
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    coll_dev = dev if args.backend == "nccl" else torch.device("cpu")   # where the collectives' tensors live
     if world > 1 or args.force_collectives:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     imgs, pairs, wl_name = build_workload(args, world)
     n_rows = np.array([len(x) for x in imgs], np.int64)
@@ -169,7 +178,7 @@ def main():
     for i, im in enumerate(imgs):
         ctx.upload_image(i, im)   # resident in HBM before the timed region
     upload_s = time.perf_counter() - t_up   # host buffers -> HBM (PCIe) + the on-device layout / fp16 / norm passes
-    sm = ShardedMatcher(ctx=ctx, device=dev, force_collectives=args.force_collectives)
+    sm = ShardedMatcher(ctx=ctx, device=coll_dev, force_collectives=args.force_collectives)
 
     def barrier():
         if world > 1:
@@ -205,7 +214,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     offs, qt, dd = result
