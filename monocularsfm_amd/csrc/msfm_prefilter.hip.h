@@ -178,6 +178,9 @@ constexpr int kPfRing = 3;
 #ifndef MSFM_ABL
 #define MSFM_ABL 0
 #endif
+#ifndef MSFM_SCHED
+#define MSFM_SCHED 0   // scheduling experiments (tools/variant_bench.sh); 0 = production
+#endif
 
 constexpr bool kAblNoEpi = MSFM_ABL == 1 || MSFM_ABL == 5 || MSFM_ABL == 6;
 constexpr bool kAblNoMfma = MSFM_ABL == 2;
@@ -496,12 +499,34 @@ __global__ __launch_bounds__(kPfThreads, 2) void approx_kernel(
             metaA.hc = (PASS == 2) ? -0.5f * thr[lcol] : 0.f;
             metaA.col = t * kPfBT + lcol;
             metaA.cslot = (sl * 4 + wave) * 64;
+#if MSFM_SCHED == 3
+            __builtin_amdgcn_s_setprio(2);
+#endif
             mfma_block(bf, accA);
+#if MSFM_SCHED == 1
+            __builtin_amdgcn_sched_group_barrier(0x100, 9, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 18, 0);
+#endif
+#if MSFM_SCHED == 2
+            h8 bf2[9];
+            load_bf(pb, pe_off, 1, bf2);
+            mfma_block(bf2, accB);
+            __builtin_amdgcn_sched_group_barrier(0x100, 18, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 36, 0);
+#else
             load_bf(pb, pe_off, 1, bf);
+            mfma_block(bf, accB);
+#endif
+#if MSFM_SCHED == 1
+            __builtin_amdgcn_sched_group_barrier(0x100, 9, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 18, 0);
+#endif
+#if MSFM_SCHED == 3
+            __builtin_amdgcn_s_setprio(0);
+#endif
             metaB.hc = (PASS == 2) ? -0.5f * thr[32 + lcol] : 0.f;
             metaB.col = t * kPfBT + 32 + lcol;
             metaB.cslot = (sl * 4 + wave) * 64 + 32;
-            mfma_block(bf, accB);
             const bool anyA = epilogue_valu(accA, metaA, false);
             const bool anyB = epilogue_valu(accB, metaB, false);
             if (PASS == 1 && !kAblNoEpi) {

@@ -10,23 +10,34 @@ for spec in "$@"; do
   names+=("$name")
 done
 python - "${names[@]}" <<'PY'
-import sys, numpy as np
+import sys, ctypes, numpy as np
 sys.path.insert(0, '.')
 from monocularsfm_amd import _lib, synth
 imgs = synth.rootsift_images(32, 5000, seed=11)
 pairs = np.array([(i, j) for i in range(32) for j in range(i)], np.int32)
-ref = None
-for name in sys.argv[1:]:
+names = sys.argv[1:]
+ctxs = {}
+for name in names:          # one context per variant, all resident at once: the variants are timed in alternation
     _lib._lib = None
     _lib.LIB_PATH = "/tmp/libmsfm_var_%s.so" % name
     ctx = _lib.Context(0)
     for i, im in enumerate(imgs): ctx.upload_image(i, im)
-    s1, s2 = [], []
-    for rep in range(40):
+    ctxs[name] = ctx
+res = {n: ([], []) for n in names}
+ref = None
+same = {}
+for rnd in range(30):
+    for name in names:
+        ctx = ctxs[name]
         offs, qt, d = ctx.match_pairs(pairs)
-        p = ctx.profile(); s1.append(p["approx_kernel_ms"]); s2.append(p["sweep2_ms"])
-    if ref is None: ref = (offs.copy(), qt.copy(), d.copy())
-    same = np.array_equal(offs, ref[0]) and np.array_equal(qt, ref[1]) and np.array_equal(d.view(np.int32), ref[2].view(np.int32))
-    print("%-14s sweep1 min %.3f med %.3f ms | sweep2 min %.3f ms | same as first: %s" % (name, min(s1), sorted(s1)[len(s1) // 2], min(s2), same), flush=True)
-    ctx.close()
+        p = ctx.profile()
+        if rnd >= 5:
+            res[name][0].append(p["approx_kernel_ms"]); res[name][1].append(p["sweep2_ms"])
+        if rnd == 0:
+            if ref is None: ref = (offs.copy(), qt.copy(), d.copy())
+            same[name] = np.array_equal(offs, ref[0]) and np.array_equal(qt, ref[1]) and np.array_equal(d.view(np.int32), ref[2].view(np.int32))
+for name in names:
+    s1, s2 = res[name]
+    print("%-14s sweep1 min %.3f med %.3f ms | sweep2 min %.3f med %.3f ms | same as first: %s" % (
+        name, min(s1), sorted(s1)[len(s1) // 2], min(s2), sorted(s2)[len(s2) // 2], same[name]), flush=True)
 PY
