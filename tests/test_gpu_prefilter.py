@@ -289,3 +289,50 @@ def test_batch_mixes_paths(gpu_ctx, oracle):
         oq, ot, od = oracle.match_pair(imgs[i], imgs[j], 0.8, True, np.inf, nthreads=4)
         s, e = offs[p], offs[p + 1]
         assert np.array_equal(qt[s:e, 0], oq) and np.array_equal(qt[s:e, 1], ot) and np.array_equal(b(d[s:e]), b(od)), (i, j)
+
+
+def test_fuzz_prefilter_equals_bruteforce(gpu_ctx, oracle):
+    """Seeded fuzz over sizes, parameters, accumulation orders, value types, duplicates and multi-pair batches: the
+    prefilter route (pruning, grouping, compaction, fallbacks) must return the brute-force route's lists bit for bit;
+    every fifth case is also checked against the oracle."""
+    rng = np.random.default_rng(20260927)
+    for case in range(200):
+        n_img = int(rng.integers(2, 6))
+        sizes = [int(rng.choice([1, 2, 3, 7, 60, 130, 257, 600, 1100, 1700])) for _ in range(n_img)]
+        kind = rng.choice(["rootsift", "u8", "gauss", "scaled"])
+        if kind == "rootsift":
+            imgs = synth.rootsift_images(n_img, sizes, seed=1000 + case, n_proto=max(sizes) + 50, sigma=float(rng.choice([0.02, 0.05, 0.1])))
+        elif kind == "u8":
+            imgs = [x.astype(F32) for x in synth.u8_images(n_img, sizes, seed=2000 + case, as_float=True)]
+        elif kind == "gauss":
+            imgs = [rng.normal(size=(n, 128)).astype(F32) for n in sizes]
+        else:
+            sc = F32(rng.choice([1e-3, 0.25, 7.0, 150.0]))
+            imgs = [(x * sc).astype(F32) for x in synth.rootsift_images(n_img, sizes, seed=3000 + case, n_proto=max(sizes) + 50)]
+        if rng.random() < 0.5 and sizes[0] >= 3:                       # exact duplicates inside and across images
+            imgs[0][1] = imgs[0][0]
+            imgs[-1][-1] = imgs[0][0]
+        order = int(rng.integers(0, 2))
+        ratio = float(rng.choice([0.3, 0.6, 0.8, 0.95, 1.0, 1.2]))
+        cc = bool(rng.integers(0, 2))
+        md = float(rng.choice([0.05, 0.3, 0.7, 2.0, 1e4, np.inf]))
+        gpu_ctx.set_accum_order(order)
+        try:
+            for i, im in enumerate(imgs):
+                gpu_ctx.upload_image(i, im)
+            pairs = np.array([(i, j) for i in range(n_img) for j in range(n_img) if i != j or rng.random() < 0.2], np.int32)
+            got = gpu_ctx.match_pairs(pairs, ratio, cc, md)
+            gpu_ctx.set_prefilter(False)
+            try:
+                ref = gpu_ctx.match_pairs(pairs, ratio, cc, md)
+            finally:
+                gpu_ctx.set_prefilter(True)
+            tag = (case, kind, sizes, order, ratio, cc, md)
+            assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1]) and np.array_equal(b(got[2]), b(ref[2])), tag
+            if case % 5 == 0:
+                for p, (i, j) in enumerate(pairs[:6]):
+                    oq, ot, od = oracle.match_pair(imgs[i], imgs[j], ratio, cc, md, order, 4)
+                    s, e = got[0][p], got[0][p + 1]
+                    assert np.array_equal(got[1][s:e, 0], oq) and np.array_equal(got[1][s:e, 1], ot) and np.array_equal(b(got[2][s:e]), b(od)), tag
+        finally:
+            gpu_ctx.set_accum_order(0)
