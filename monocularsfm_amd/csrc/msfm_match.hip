@@ -356,7 +356,7 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
     hipLaunchKernelGGL(approx_kernel<1>, dim3((unsigned)b.items.size()), block, kPfLdsBytes, ctx->stream, dp, dpf,
                        ctx->d_items.as<WorkItem>(), ctx->d_rp_s0.as<float>(), ctx->d_rp_s1.as<float>(),
                        ctx->d_cp_s0.as<float>(), ctx->d_cp_s1.as<float>(), (const float*)nullptr, (const float*)nullptr,
-                       (int2*)nullptr, (int*)nullptr);
+                       (int2*)nullptr, (unsigned long long*)nullptr);
     HIPCHK(ctx, hipGetLastError());
     DBGSYNC(ctx, "approx_kernel<1>");
     HIPCHK(ctx, hipEventRecord(e1, ctx->stream));
@@ -513,9 +513,9 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
     HIPCHK(ctx, ctx->d_cand.ensure(std::max<long long>(1, cand_elems) * sizeof(int2)));
     HIPCHK(ctx, ctx->d_cand_s.ensure(std::max<long long>(1, cand_elems) * 4));
     HIPCHK(ctx, ctx->d_cand_pair.ensure(std::max<long long>(1, cand_elems) * 4));
-    HIPCHK(ctx, ctx->d_cand_count.ensure((P + V) * 4));
+    HIPCHK(ctx, ctx->d_cand_count.ensure((P + V) * 8));
     HIPCHK(ctx, ctx->d_lists.ensure((P + V) * sizeof(CandList)));
-    HIPCHK(ctx, hipMemsetAsync(ctx->d_cand_count.p, 0, (P + V) * 4, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_cand_count.p, 0, (P + V) * 8, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(ctx->d_lists.p, lists.data(), (P + V) * sizeof(CandList), hipMemcpyHostToDevice, ctx->stream));
     std::vector<int> active;  // the exact / reduce kernels only visit lists that can hold candidates
     for (size_t l = 0; l < P + V; ++l)
@@ -547,7 +547,7 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
     if (!ditems.empty()) {
         hipLaunchKernelGGL(approx_kernel<2>, dim3((unsigned)ditems.size()), block, kPfLdsBytes, ctx->stream, dp, dpf,
                            ctx->d_items.as<WorkItem>(), (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr,
-                           (const float*)tuv, (const float*)tuv, ctx->d_cand.as<int2>(), ctx->d_cand_count.as<int>());
+                           (const float*)tuv, (const float*)tuv, ctx->d_cand.as<int2>(), ctx->d_cand_count.as<unsigned long long>());
         HIPCHK(ctx, hipGetLastError());
     DBGSYNC(ctx, "approx_kernel<2>");
         ctx->prof.sweep2_launches += 1;
@@ -556,7 +556,7 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
         hipLaunchKernelGGL(approx_kernel<3>, dim3((unsigned)vitems.size()), block, kPfLdsBytes, ctx->stream,
                            ctx->d_vpairs.as<PairDesc>(), ctx->d_vpf.as<PfPair>(), ctx->d_vitems.as<WorkItem>(), (float*)nullptr,
                            (float*)nullptr, (float*)nullptr, (float*)nullptr, ctx->d_cmp_tu.as<float>(), (const float*)nullptr,
-                           ctx->d_cand.as<int2>(), ctx->d_cand_count.as<int>() + P);
+                           ctx->d_cand.as<int2>(), ctx->d_cand_count.as<unsigned long long>() + P);
         HIPCHK(ctx, hipGetLastError());
     DBGSYNC(ctx, "approx_kernel<3>");
         ctx->prof.sweep2_launches += 1;
@@ -568,20 +568,20 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
         const dim3 cgrid(64, (unsigned)std::max<size_t>(1, active.size()));
         const int* dact = ctx->d_active.as<int>();
         if (ctx->order == MSFM_ORDER_SSE4X4)
-            hipLaunchKernelGGL(pf_exact_candidates_kernel<0>, cgrid, dim3(256), 0, ctx->stream, dp, dl, dact, ctx->d_cand_count.as<int>(),
+            hipLaunchKernelGGL(pf_exact_candidates_kernel<0>, cgrid, dim3(256), 0, ctx->stream, dp, dl, dact, (const unsigned long long*)ctx->d_cand_count.as<unsigned long long>(),
                                ctx->d_cand.as<int2>(), ctx->d_cand_s.as<float>(), ctx->d_cand_pair.as<int>());
         else
-            hipLaunchKernelGGL(pf_exact_candidates_kernel<1>, cgrid, dim3(256), 0, ctx->stream, dp, dl, dact, ctx->d_cand_count.as<int>(),
+            hipLaunchKernelGGL(pf_exact_candidates_kernel<1>, cgrid, dim3(256), 0, ctx->stream, dp, dl, dact, (const unsigned long long*)ctx->d_cand_count.as<unsigned long long>(),
                                ctx->d_cand.as<int2>(), ctx->d_cand_s.as<float>(), ctx->d_cand_pair.as<int>());
         HIPCHK(ctx, hipGetLastError());
         DBGSYNC(ctx, "pf_exact_candidates_kernel<1>");
         const dim3 rgrid(16, (unsigned)std::max<size_t>(1, active.size()));
-        hipLaunchKernelGGL(pf_reduce_best_kernel, rgrid, dim3(256), 0, ctx->stream, dp, dl, dact, ctx->d_cand_count.as<int>(),
+        hipLaunchKernelGGL(pf_reduce_best_kernel, rgrid, dim3(256), 0, ctx->stream, dp, dl, dact, (const unsigned long long*)ctx->d_cand_count.as<unsigned long long>(),
                            ctx->d_cand.as<int2>(), ctx->d_cand_s.as<float>(), (const int*)ctx->d_cand_pair.as<int>(),
                            ctx->d_best.as<unsigned long long>());
         HIPCHK(ctx, hipGetLastError());
         DBGSYNC(ctx, "pf_reduce_best_kernel");
-        hipLaunchKernelGGL(pf_reduce_second_kernel, rgrid, dim3(256), 0, ctx->stream, dp, dl, dact, ctx->d_cand_count.as<int>(),
+        hipLaunchKernelGGL(pf_reduce_second_kernel, rgrid, dim3(256), 0, ctx->stream, dp, dl, dact, (const unsigned long long*)ctx->d_cand_count.as<unsigned long long>(),
                            ctx->d_cand.as<int2>(), ctx->d_cand_s.as<float>(), (const int*)ctx->d_cand_pair.as<int>(),
                            ctx->d_best.as<unsigned long long>(), ctx->d_second.as<unsigned long long>());
         HIPCHK(ctx, hipGetLastError());
@@ -594,8 +594,8 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
     DBGSYNC(ctx, "pf_finalize_kernel");
 
     // candidate-list overflow -> brute-force exact path for that pair
-    std::vector<int> counts(P + V);
-    HIPCHK(ctx, hipMemcpyAsync(counts.data(), ctx->d_cand_count.p, (P + V) * 4, hipMemcpyDeviceToHost, ctx->stream));
+    std::vector<unsigned long long> counts(P + V);
+    HIPCHK(ctx, hipMemcpyAsync(counts.data(), ctx->d_cand_count.p, (P + V) * 8, hipMemcpyDeviceToHost, ctx->stream));
     hc.lap("launch sweep 2 .. finalize");
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     hc.lap("wait for candidate counts (GPU)");
@@ -607,7 +607,7 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
     std::vector<char> overflow(P, 0);
     for (size_t l = 0; l < P + V; ++l) {
         if (lists[l].cap == 0) continue;
-        if (counts[l] <= lists[l].cap) {
+        if (counts[l] <= (unsigned long long)lists[l].cap) {
             ctx->prof.candidates += counts[l];
             continue;
         }

@@ -198,7 +198,8 @@ template <int PASS>
 __global__ __launch_bounds__(kPfThreads, 2) void approx_kernel(
     const PairDesc* __restrict__ pairs, const PfPair* __restrict__ pf, const WorkItem* __restrict__ items,
     float* __restrict__ rp_s0, float* __restrict__ rp_s1, float* __restrict__ cp_s0, float* __restrict__ cp_s1,
-    const float* __restrict__ tu, const float* __restrict__ tv, int2* __restrict__ cand, int* __restrict__ cand_count) {
+    const float* __restrict__ tu, const float* __restrict__ tv, int2* __restrict__ cand,
+    unsigned long long* __restrict__ cand_count /* 64-bit: n1 * n2 hits of a flooded list do not fit 32 bits */) {
     typedef const __attribute__((address_space(1))) float* gfloat_p;  // keep these loads off the FLAT path
     typedef const __attribute__((address_space(1))) h8* gh8_p;
     extern __shared__ __attribute__((aligned(16))) char pf_smem[];
@@ -308,9 +309,10 @@ __global__ __launch_bounds__(kPfThreads, 2) void approx_kernel(
     int n_buf = 0;  // wave-uniform
     auto flush_candidates = [&]() {
         if (n_buf == 0) return;
-        int base = 0;
-        if (lane == 0) base = atomicAdd(&cand_count[item.pair], n_buf);
-        base = __builtin_amdgcn_readfirstlane(base);
+        unsigned long long base64 = 0;
+        if (lane == 0) base64 = atomicAdd(&cand_count[item.pair], (unsigned long long)n_buf);
+        // beyond the capacity nothing is stored: the clamped base keeps the test below false for every k
+        const int base = __builtin_amdgcn_readfirstlane((int)(base64 < (unsigned long long)pp.cand_cap ? base64 : (unsigned long long)pp.cand_cap));
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the asm ds_writes below are not tracked by hipcc
         for (int k = lane; k < n_buf; k += 64)
             if (base + k < pp.cand_cap) cand[pp.cand_off + base + k] = cbuf[k];
@@ -657,12 +659,12 @@ struct CandList {
 template <int ORDER>
 __global__ void pf_exact_candidates_kernel(const PairDesc* __restrict__ pairs, const CandList* __restrict__ lists,
                                            const int* __restrict__ active /* ids of the non-empty lists */,
-                                           const int* __restrict__ cand_count, int2* __restrict__ cand,
+                                           const unsigned long long* __restrict__ cand_count, int2* __restrict__ cand,
                                            float* __restrict__ cand_s, int* __restrict__ cand_pair) {
     const int lid = active[blockIdx.y];
     const CandList L = lists[lid];
     if (L.cap == 0) return;
-    const int n = min(cand_count[lid], L.cap);
+    const int n = (int)(cand_count[lid] < (unsigned long long)L.cap ? cand_count[lid] : (unsigned long long)L.cap);
     const int sub = threadIdx.x & 15;
     for (int c = (blockIdx.x * blockDim.x + threadIdx.x) >> 4; c < ((n + 3) & ~3); c += (gridDim.x * blockDim.x) >> 4) {
         const bool live = c < n;
@@ -726,13 +728,13 @@ __device__ __forceinline__ unsigned long long pf_key(float s, int idx) {
 // A mode-1 list only serves the row direction, a mode-2 list only the column direction: the live
 // rows of the OTHER direction get their complete candidate sets from their own list.
 __global__ void pf_reduce_best_kernel(const PairDesc* __restrict__ pairs, const CandList* __restrict__ lists,
-                                      const int* __restrict__ active, const int* __restrict__ cand_count,
+                                      const int* __restrict__ active, const unsigned long long* __restrict__ cand_count,
                                       const int2* __restrict__ cand, const float* __restrict__ cand_s,
                                       const int* __restrict__ cand_pair, unsigned long long* __restrict__ best) {
     const int lid = active[blockIdx.y];
     const CandList L = lists[lid];
     if (L.cap == 0) return;
-    const int n = min(cand_count[lid], L.cap);
+    const int n = (int)(cand_count[lid] < (unsigned long long)L.cap ? cand_count[lid] : (unsigned long long)L.cap);
     for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < n; c += gridDim.x * blockDim.x) {
         const int2 qt = cand[L.off + c];
         const float s = cand_s[L.off + c];
@@ -744,14 +746,14 @@ __global__ void pf_reduce_best_kernel(const PairDesc* __restrict__ pairs, const 
 }
 // reduce phase B: second best = min over the candidates that are not the best one
 __global__ void pf_reduce_second_kernel(const PairDesc* __restrict__ pairs, const CandList* __restrict__ lists,
-                                        const int* __restrict__ active, const int* __restrict__ cand_count,
+                                        const int* __restrict__ active, const unsigned long long* __restrict__ cand_count,
                                         const int2* __restrict__ cand, const float* __restrict__ cand_s,
                                         const int* __restrict__ cand_pair, const unsigned long long* __restrict__ best,
                                         unsigned long long* __restrict__ second) {
     const int lid = active[blockIdx.y];
     const CandList L = lists[lid];
     if (L.cap == 0) return;
-    const int n = min(cand_count[lid], L.cap);
+    const int n = (int)(cand_count[lid] < (unsigned long long)L.cap ? cand_count[lid] : (unsigned long long)L.cap);
     for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < n; c += gridDim.x * blockDim.x) {
         const int2 qt = cand[L.off + c];
         const float s = cand_s[L.off + c];
