@@ -178,7 +178,8 @@ def main():
     for i, im in enumerate(imgs):
         ctx.upload_image(i, im)   # resident in HBM before the timed region
     upload_s = time.perf_counter() - t_up   # host buffers -> HBM (PCIe) + the on-device layout / fp16 / norm passes
-    sm = ShardedMatcher(ctx=ctx, device=coll_dev, force_collectives=args.force_collectives)
+    # the step ends with the match lists in host memory (the library's page-locked result buffers; "view" = no second copy)
+    sm = ShardedMatcher(ctx=ctx, device=coll_dev, force_collectives=args.force_collectives, fetch="view")
 
     def barrier():
         if world > 1:

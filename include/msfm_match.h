@@ -129,6 +129,9 @@ int msfm_match_pair(msfm_ctx* ctx, int id1, int id2, float ratio, int cross_chec
 int msfm_match_pairs(msfm_ctx* ctx, const int32_t* pairs, int n_pairs,
                      const msfm_match_params* params, int64_t* out_offsets);
 int msfm_fetch_matches(msfm_ctx* ctx, int32_t* out_qt, float* out_dist);
+/* The same lists without the copy: pointers into the context's page-locked result buffers
+ * (2 * count int32, count float), valid until the next matching call on this context or msfm_destroy. */
+int msfm_view_matches(msfm_ctx* ctx, const int32_t** out_qt, const float** out_dist, int64_t* out_count);
 
 /* ---- batch of pairs with the geometric verification hand-off -------------------------------
  * Lines 36-60 of FeatureMatching.cpp in one call: matching as above, then FeatureUtils::FilterMatches

@@ -22,7 +22,7 @@ EXPORTS = [
     "msfm_get_profile", "msfm_upload_image", "msfm_image_rows", "msfm_clear_images",
     "msfm_match_pair", "msfm_match_pairs", "msfm_fetch_matches", "msfm_knn2_pair",
     "msfm_topscale_select", "msfm_pair_id", "msfm_pair_from_id", "msfm_swap_image_pair",
-    "msfm_version", "msfm_upload_keypoints", "msfm_match_pairs_verified", "msfm_subset_image",
+    "msfm_version", "msfm_upload_keypoints", "msfm_match_pairs_verified", "msfm_subset_image", "msfm_view_matches",
 ]
 
 
@@ -81,6 +81,7 @@ def load():
     L.msfm_match_pair.argtypes = [vp, C.c_int, C.c_int, C.c_float, C.c_int, C.c_double, ip, fp, C.POINTER(C.c_int)]
     L.msfm_match_pairs.argtypes = [vp, ip, C.c_int, C.POINTER(MatchParams), C.POINTER(C.c_int64)]
     L.msfm_fetch_matches.argtypes = [vp, ip, fp]
+    L.msfm_view_matches.argtypes = [vp, C.POINTER(ip), C.POINTER(fp), C.POINTER(C.c_int64)]
     L.msfm_upload_keypoints.argtypes = [vp, C.c_int, fp, C.c_int, C.c_int]
     L.msfm_match_pairs_verified.argtypes = [vp, ip, C.c_int, C.POINTER(MatchParams), C.POINTER(VerifyParams),
                                             C.POINTER(C.c_int64)]
@@ -195,8 +196,19 @@ class Context:
         m = cnt.value
         return qt[:m, 0].copy(), qt[:m, 1].copy(), d[:m].copy()
 
+    def _view(self):
+        """(qt[M,2], dist[M]) as NumPy views of the context's result buffers: no copy, valid until the next
+        matching call on this context."""
+        qp, dp, n = C.POINTER(C.c_int32)(), C.POINTER(C.c_float)(), C.c_int64()
+        self._chk(self._L.msfm_view_matches(self._h, C.byref(qp), C.byref(dp), C.byref(n)))
+        M = n.value
+        if M == 0:
+            return np.zeros((0, 2), np.int32), np.zeros(0, np.float32)
+        return np.ctypeslib.as_array(qp, shape=(M, 2)), np.ctypeslib.as_array(dp, shape=(M,))
+
     def match_pairs(self, pairs, ratio=0.8, cross_check=True, max_distance=0.7, fetch=True):
-        """pairs: P x 2 int array -> (offsets[P+1], qt[M,2], dist[M]); fetch=False skips the copy-out."""
+        """pairs: P x 2 int array -> (offsets[P+1], qt[M,2], dist[M]); fetch=False skips the copy-out,
+        fetch="view" returns views of the context's buffers (valid until the next matching call)."""
         pairs = np.ascontiguousarray(np.asarray(pairs, dtype=np.int32).reshape(-1, 2))
         P = pairs.shape[0]
         offs = np.zeros(P + 1, np.int64)
@@ -205,6 +217,8 @@ class Context:
                                            offs.ctypes.data_as(C.POINTER(C.c_int64))))
         if not fetch:
             return offs, None, None
+        if fetch == "view":
+            return (offs,) + self._view()
         M = int(offs[-1])
         qt = np.empty((max(M, 1), 2), np.int32)
         d = np.empty(max(M, 1), np.float32)
@@ -230,6 +244,8 @@ class Context:
                                                     offs.ctypes.data_as(C.POINTER(C.c_int64))))
         if not fetch:
             return offs, None, None
+        if fetch == "view":
+            return (offs,) + self._view()
         M = int(offs[-1])
         qt = np.empty((max(M, 1), 2), np.int32)
         d = np.empty(max(M, 1), np.float32)

@@ -47,6 +47,30 @@ struct DevBuf {
     template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
 };
 
+// page-locked host memory, grow-only and content-preserving (result lists of a call accumulate over its sub-batches)
+struct PinnedBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes, size_t keep) {
+        if (bytes <= cap) return hipSuccess;
+        size_t want = bytes + bytes / 2 + 4096;
+        void* q = nullptr;
+        hipError_t e = hipHostMalloc(&q, want, hipHostMallocDefault);
+        if (e != hipSuccess) return e;
+        if (p && keep) std::memcpy(q, p, keep);
+        if (p) (void)hipHostFree(p);
+        p = q;
+        cap = want;
+        return hipSuccess;
+    }
+    void release() {
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
 struct Image {
     int n = -1;  // -1: not uploaded
     int nblk = 0;    // 128-row blocks holding data
@@ -104,8 +128,8 @@ struct msfm_ctx {
     // results of the last msfm_match_pairs call
     bool have_results = false;
     std::vector<int64_t> res_offsets;
-    std::vector<int32_t> res_qt;
-    std::vector<float> res_dist;
+    PinnedBuf res_qt, res_dist;  // (q, t) int32 pairs and distances of res_count matches
+    size_t res_count = 0;
 
     msfm_profile prof = {};
     std::vector<hipEvent_t> ev_pool;
@@ -815,6 +839,8 @@ void msfm_destroy(msfm_ctx* ctx) {
                       &ctx->d_vf_x2, &ctx->d_vf_y2, &ctx->d_vf_hyp, &ctx->d_vf_best_it, &ctx->d_vf_best_count,
                       &ctx->d_vf_flags, &ctx->d_st2_qt, &ctx->d_st2_d, &ctx->d_counts2};
     for (DevBuf* b : bufs) b->release();
+    ctx->res_qt.release();
+    ctx->res_dist.release();
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -1003,8 +1029,7 @@ static int match_pairs_impl(msfm_ctx* ctx, const int32_t* pairs, int n_pairs, co
     HIPCHK(ctx, hipSetDevice(ctx->device));
     ctx->have_results = false;
     ctx->res_offsets.assign((size_t)n_pairs + 1, 0);
-    ctx->res_qt.clear();
-    ctx->res_dist.clear();
+    ctx->res_count = 0;
     ctx->prof = msfm_profile{};
 
     hipEvent_t ev_begin = get_event(ctx, 0), ev_end = get_event(ctx, 1);
@@ -1122,12 +1147,13 @@ static int match_pairs_impl(msfm_ctx* ctx, const int32_t* pairs, int n_pairs, co
         rc = check_fix_overflow(ctx);  // synchronises the stream
         if (rc != MSFM_OK) return rc;
         const long long total = offs[P];
-        const size_t base = ctx->res_dist.size();
-        ctx->res_qt.resize(2 * (base + (size_t)total));
-        ctx->res_dist.resize(base + (size_t)total);
+        const size_t base = ctx->res_count;
+        HIPCHK(ctx, ctx->res_qt.ensure((base + (size_t)total + 1) * 8, base * 8));
+        HIPCHK(ctx, ctx->res_dist.ensure((base + (size_t)total + 1) * 4, base * 4));
+        ctx->res_count = base + (size_t)total;
         if (total > 0) {
-            HIPCHK(ctx, hipMemcpyAsync(ctx->res_qt.data() + 2 * base, ctx->d_out_qt.p, (size_t)total * 8, hipMemcpyDeviceToHost, ctx->stream));
-            HIPCHK(ctx, hipMemcpyAsync(ctx->res_dist.data() + base, ctx->d_out_d.p, (size_t)total * 4, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(ctx, hipMemcpyAsync(ctx->res_qt.as<int32_t>() + 2 * base, ctx->d_out_qt.p, (size_t)total * 8, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(ctx, hipMemcpyAsync(ctx->res_dist.as<float>() + base, ctx->d_out_d.p, (size_t)total * 4, hipMemcpyDeviceToHost, ctx->stream));
             HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         }
         for (size_t p = 0; p < P; ++p) ctx->res_offsets[(size_t)begin + p + 1] = (int64_t)base + offs[p + 1];
@@ -1187,8 +1213,17 @@ int msfm_upload_keypoints(msfm_ctx* ctx, int image_id, const float* kpts, int n,
 int msfm_fetch_matches(msfm_ctx* ctx, int32_t* out_qt, float* out_dist) {
     if (!ctx) return MSFM_E_INVALID;
     if (!ctx->have_results) return fail(ctx, MSFM_E_STATE, "msfm_fetch_matches without a completed msfm_match_pairs");
-    if (out_qt && !ctx->res_qt.empty()) std::memcpy(out_qt, ctx->res_qt.data(), ctx->res_qt.size() * 4);
-    if (out_dist && !ctx->res_dist.empty()) std::memcpy(out_dist, ctx->res_dist.data(), ctx->res_dist.size() * 4);
+    if (out_qt && ctx->res_count) std::memcpy(out_qt, ctx->res_qt.p, ctx->res_count * 8);
+    if (out_dist && ctx->res_count) std::memcpy(out_dist, ctx->res_dist.p, ctx->res_count * 4);
+    return MSFM_OK;
+}
+
+int msfm_view_matches(msfm_ctx* ctx, const int32_t** out_qt, const float** out_dist, int64_t* out_count) {
+    if (!ctx) return MSFM_E_INVALID;
+    if (!ctx->have_results) return fail(ctx, MSFM_E_STATE, "msfm_view_matches without a completed msfm_match_pairs");
+    if (out_qt) *out_qt = ctx->res_qt.as<int32_t>();
+    if (out_dist) *out_dist = ctx->res_dist.as<float>();
+    if (out_count) *out_count = (int64_t)ctx->res_count;
     return MSFM_OK;
 }
 

@@ -273,3 +273,20 @@ def test_subset_image_equals_uploading_the_rows(gpu_ctx, oracle):
         gpu_ctx.subset_image(1, _lib.MAX_IMAGES + 1, np.array([700], np.int32))
     with pytest.raises(_lib.MsfmError):
         gpu_ctx.subset_image(1, 1, np.array([0], np.int32))
+
+
+def test_view_matches_equals_fetch(gpu_ctx):
+    imgs = synth.rootsift_images(3, [800, 700, 600], seed=71, n_proto=1500)
+    for i, im in enumerate(imgs):
+        gpu_ctx.upload_image(i, im)
+    pairs = np.array([(1, 0), (2, 0), (2, 1)], np.int32)
+    offs, qt, d = gpu_ctx.match_pairs(pairs)
+    voffs, vqt, vd = gpu_ctx.match_pairs(pairs, fetch="view")
+    assert np.array_equal(offs, voffs) and np.array_equal(qt, vqt) and np.array_equal(b(d), b(vd)) and len(qt) > 100
+    # the views belong to the context: the next call overwrites them
+    keep = vqt.copy()
+    gpu_ctx.match_pairs(pairs[:1], fetch=False)
+    o2, q2, d2 = gpu_ctx.match_pairs(pairs, fetch="view")
+    assert np.array_equal(q2, keep)
+    e = gpu_ctx.match_pairs(np.zeros((0, 2), np.int32), fetch="view")
+    assert e[1].shape == (0, 2) and e[2].shape == (0,)

@@ -19,6 +19,8 @@ for rep in range(4):
     t1 = time.perf_counter()
     offs, qt, d = ctx.match_pairs(pairs, fetch=True)
     t2 = time.perf_counter()
+    offs, qt, d = ctx.match_pairs(pairs, fetch="view")
+    t3 = time.perf_counter()
     p = ctx.profile()
-    print("rep %d: match_pairs(no fetch) %.1f ms | with fetch %.1f ms | device span %.1f ms | sweep1 %.1f ms sweep2 %.1f ms exact-path %.1f ms | matches %d" % (
-        rep, (t1 - t0) * 1e3, (t2 - t1) * 1e3, p["total_device_ms"], p["approx_kernel_ms"], p["sweep2_ms"], p["dist_kernel_ms"], offs[-1]))
+    print("rep %d: match_pairs(no fetch) %.1f ms | with fetch %.1f ms | view %.1f ms | device span %.1f ms | sweep1 %.1f ms sweep2 %.1f ms exact-path %.1f ms | matches %d" % (
+        rep, (t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, p["total_device_ms"], p["approx_kernel_ms"], p["sweep2_ms"], p["dist_kernel_ms"], offs[-1]))
