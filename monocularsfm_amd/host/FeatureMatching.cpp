@@ -158,17 +158,15 @@ void FeatureMatcher::MatchImagePairGroups(const std::vector<std::vector<std::pai
         prm.cross_check = cross_check_ ? 1 : 0;
         prm.max_distance = max_distance_;
         std::vector<int64_t> offs((size_t)P + 1);
-        std::vector<int32_t> qt;
-        std::vector<float> dist;
+        const int32_t* qt = nullptr;   // the library's page-locked result buffers: valid until the next matching call
+        const float* dist = nullptr;
         {
             Lap l(&g_clock.device);
             if (geometric_verification_ && !verification_on_host_)
                 MSFM_CALL(ctx_, msfm_match_pairs_verified(ctx_, todo.data(), P, &prm, nullptr, offs.data()));  // FilterMatches' constants
             else
                 MSFM_CALL(ctx_, msfm_match_pairs(ctx_, todo.data(), P, &prm, offs.data()));
-            qt.resize((size_t)offs[(size_t)P] * 2 + 2);
-            dist.resize((size_t)offs[(size_t)P] + 1);
-            MSFM_CALL(ctx_, msfm_fetch_matches(ctx_, qt.data(), dist.data()));
+            MSFM_CALL(ctx_, msfm_view_matches(ctx_, &qt, &dist, nullptr));
         }
         gpu_seconds_per_pair = timer.ElapsedSeconds() / P;
 
