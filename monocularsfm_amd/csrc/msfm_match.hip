@@ -235,7 +235,7 @@ int fill_pair(msfm_ctx* ctx, int id1, int id2, PairDesc& pd, PfPair& pp) {
     pd.b_tiles = b.nblk;
     pd.n1pad = a.nalloc * kBM;
     pd.n2pad = b.nalloc * kBN;
-    pd.a_blocks256 = a.nalloc / 2;
+    pd.a_blocks256 = a.nalloc * kBM / kPfWgRows;  // sweep work items: kPfWgRows A rows each (the name dates from 256)
     pd.ranges = 1;
     // empty query or train set: knnMatch returns nothing, no device work
     pd.valid = (a.n >= 1 && b.n >= 1) ? 1 : 0;
@@ -408,8 +408,8 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
             if (!pd.valid || !b.pf[p].use) continue;
             // both compact sweeps together must be clearly cheaper than the one dense sweep
             const long long dense_cost = (long long)pd.a_blocks256 * pd.b_tiles;
-            const long long cmp_cost = (long long)((live[2 * p] + 255) / 256) * pd.b_tiles +
-                                       (long long)((live[2 * p + 1] + 255) / 256) * pd.a_blocks;
+            const long long cmp_cost = (long long)((live[2 * p] + kPfWgRows - 1) / kPfWgRows) * pd.b_tiles +
+                                       (long long)((live[2 * p + 1] + kPfWgRows - 1) / kPfWgRows) * pd.a_blocks;
             compact[p] = (2 * cmp_cost <= dense_cost) ? 1 : 0;
         }
     }
@@ -456,7 +456,7 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
                 g.rows += m.cnt;
                 members.push_back(m);
             }
-            cmp_rows += (g.rows + 255) / 256 * 256;
+            cmp_rows += (g.rows + kPfWgRows - 1) / kPfWgRows * kPfWgRows;
             groups.push_back(g);
         }
     }
@@ -470,7 +470,7 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
     std::vector<GatherJob> jobs(members.size());
     std::vector<CandList> lists(P + V);
     long long v_ablocks = 0;
-    for (size_t v = 0; v < V; ++v) v_ablocks += (groups[v].rows + 255) / 256;
+    for (size_t v = 0; v < V; ++v) v_ablocks += (groups[v].rows + kPfWgRows - 1) / kPfWgRows;
     for (size_t p = 0; p < P; ++p) {
         const PfPair& pp = b.pf[p];
         lists[p] = CandList{(int)p, 0, pp.cand_off, (b.pairs[p].valid && pp.use && !compact[p]) ? pp.cand_cap : 0, 0, nullptr, nullptr};
@@ -486,9 +486,9 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
         vd = PairDesc{};
         vd.n1 = (int)g.rows;
         vd.n2 = g.dir ? pd.n1 : pd.n2;
-        vd.a_blocks256 = (int)((g.rows + 255) / 256);
+        vd.a_blocks256 = (int)((g.rows + kPfWgRows - 1) / kPfWgRows);
         vd.b_tiles = g.dir ? pd.a_blocks : pd.b_tiles;
-        vd.n1pad = vd.a_blocks256 * 256;
+        vd.n1pad = vd.a_blocks256 * kPfWgRows;
         vd.n2pad = g.dir ? pd.n1pad : pd.n2pad;
         vd.valid = 1;
         vd.path = 1;
@@ -893,7 +893,7 @@ static int alloc_image(msfm_ctx* ctx, Image& im, int n) {
     free_image(im);
     im.n = n;
     im.nblk = (n + kBM - 1) / kBM;
-    im.nalloc = (im.nblk + 1) & ~1;
+    im.nalloc = (im.nblk + kPfWgRows / kBM - 1) / (kPfWgRows / kBM) * (kPfWgRows / kBM);
     if (n == 0) return MSFM_OK;
     HIPCHK(ctx, hipMalloc((void**)&im.panel, (size_t)im.nalloc * kPanelFloats * 4));
     HIPCHK(ctx, hipMalloc((void**)&im.raw, (size_t)n * kDim * 4));

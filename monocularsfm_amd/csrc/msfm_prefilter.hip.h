@@ -52,7 +52,13 @@ constexpr float kEpsRel = 1.5e-3f;
 constexpr float kEpsAbs = 1.0e-6f;
 constexpr float kF16Safe = 6.0e4f;
 
-constexpr int kPfThreads = 256;           // 4 waves, 64 A rows each
+#ifndef MSFM_RB
+#define MSFM_RB 2
+#endif
+constexpr int kPfRB = MSFM_RB;            // 32-row MFMA blocks per wave (A fragments of 32 kPfRB rows stay in registers)
+constexpr int kPfWaveRows = 32 * kPfRB;
+constexpr int kPfWgRows = 4 * kPfWaveRows; // A rows per workgroup / work item
+constexpr int kPfThreads = 256;           // 4 waves
 constexpr int kPfBT = 64;                 // B rows per tile
 constexpr int kHalfRowBytes = kDim * 2;   // one fp16 descriptor = 256 B = 16 granules of 16 B
 constexpr int kPfLdsB = kPfBT * kHalfRowBytes;  // 16 KiB per slot
@@ -195,7 +201,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 __device__ __forceinline__ float max3f(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }  // folds to v_max3_f32
 
 template <int PASS>
-__global__ __launch_bounds__(kPfThreads, 2) void approx_kernel(
+__global__ __launch_bounds__(kPfThreads, kPfRB <= 2 ? 2 : 1) void approx_kernel(
     const PairDesc* __restrict__ pairs, const PfPair* __restrict__ pf, const WorkItem* __restrict__ items,
     float* __restrict__ rp_s0, float* __restrict__ rp_s1, float* __restrict__ cp_s0, float* __restrict__ cp_s1,
     const float* __restrict__ tu, const float* __restrict__ tv, int2* __restrict__ cand,
@@ -252,11 +258,11 @@ __global__ __launch_bounds__(kPfThreads, 2) void approx_kernel(
 
     // A fragments: rows a_blk*256 + wave*64 + rb*32 + lcol, granule 2*ks + lhalf (stored at ^ (row & 15));
     // ninth k-step: [-c, -c, x_hi, x_lo, 0...] in the lhalf == 0 lanes (k = 128..135), zeros in the others
-    h8 af[2][9];
+    h8 af[kPfRB][9];
     const float inv_c = 1.f / pp.b_c;
 #pragma unroll
-    for (int rb = 0; rb < 2; ++rb) {
-        const int frow = item.a_blk * 256 + wave * 64 + rb * 32 + lcol;
+    for (int rb = 0; rb < kPfRB; ++rb) {
+        const int frow = item.a_blk * kPfWgRows + wave * kPfWaveRows + rb * 32 + lcol;
         const gh8_p ga = (gh8_p)(pp.a_h) + (size_t)frow * 16;
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) af[rb][ks] = ga[(2 * ks + lhalf) ^ (frow & 15)];
@@ -281,11 +287,11 @@ __global__ __launch_bounds__(kPfThreads, 2) void approx_kernel(
     }
 
     // this lane's 32 result rows: (rb, r) -> row = a_blk*256 + wave*64 + rb*32 + (r&3) + 8*(r>>2) + 4*lhalf
-    const int arow_base = item.a_blk * 256 + wave * 64 + 4 * lhalf;
+    const int arow_base = item.a_blk * kPfWgRows + wave * kPfWaveRows + 4 * lhalf;
     // rs0: PASS 1 running row maximum of the accumulator (-S~min/2); PASS 2 the row's hit level -T_row/2
-    float rs0[2][16];
+    float rs0[kPfRB][16];
 #pragma unroll
-    for (int rb = 0; rb < 2; ++rb)
+    for (int rb = 0; rb < kPfRB; ++rb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int rr = arow_base + rb * 32 + (r & 3) + 8 * (r >> 2);
@@ -295,7 +301,7 @@ __global__ __launch_bounds__(kPfThreads, 2) void approx_kernel(
     // scoreboard still holds them as pending at the first MFMA and it drains vmcnt(0) INSIDE the loop,
     // which would serialise the DMA ring.
 #pragma unroll
-    for (int rb = 0; rb < 2; ++rb)
+    for (int rb = 0; rb < kPfRB; ++rb)
 #pragma unroll
         for (int ks = 0; ks < 9; ++ks) asm volatile("" ::"v"(af[rb][ks]));
     wait_vmcnt<0>();  // prologue loads (and the first two DMA groups) are done: counted waits start clean
@@ -320,7 +326,7 @@ __global__ __launch_bounds__(kPfThreads, 2) void approx_kernel(
     };
 
     const int xb = lcol & 15;  // both column blocks: row & 15 == lcol & 15
-    const bool wave_active = item.a_blk * 256 + wave * 64 < pd.n1;  // wave-uniform
+    const bool wave_active = item.a_blk * kPfWgRows + wave * kPfWaveRows < pd.n1;  // wave-uniform
     if (PASS == 1 && !wave_active) {
         // its column partials are never written: park (+inf, +inf) in all three ring slots once
         const float2 pr = make_float2(f_inf(), f_inf());
@@ -346,37 +352,41 @@ __global__ __launch_bounds__(kPfThreads, 2) void approx_kernel(
         // (one base pointer + selected offset: a select between two pointers makes hipcc drain vmcnt(0))
         bf[8] = *reinterpret_cast<const h8*>(pf_smem + (lhalf == 0 ? pe_off + (cb * 32 + lcol) * 16 : zero_off));
     };
-    auto mfma_block = [&](const h8 (&bf)[9], f16v (&acc)[2]) {
+    auto mfma_block = [&](const h8 (&bf)[9], f16v (&acc)[kPfRB]) {
         if (kAblNoMfma) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { acc[0][r] += (float)bf[r & 7][0]; acc[1][r] += (float)bf[8][r & 7]; }
+            for (int r = 0; r < 16; ++r)
+#pragma unroll
+                for (int rb = 0; rb < kPfRB; ++rb) acc[rb][r] += (float)bf[(r + rb) & 7][0] + (float)bf[8][r & 7];
             return;
         }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
+        for (int r = 0; r < 16; ++r)
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][ks], bf[ks], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[1][ks], bf[ks], acc[1], 0, 0, 0);
-        }
+            for (int rb = 0; rb < kPfRB; ++rb) acc[rb][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+            for (int rb = 0; rb < kPfRB; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[rb][ks], bf[ks], acc[rb], 0, 0, 0);
         {   // the quadruple only fills k = 0..3: the K = 8 instruction (lane l: k = 4 (l >> 5) .. +3) takes half the passes
             typedef _Float16 h4 __attribute__((ext_vector_type(4)));
             const h4 b4 = __builtin_shufflevector(bf[8], bf[8], 0, 1, 2, 3);
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x8f16(__builtin_shufflevector(af[0][8], af[0][8], 0, 1, 2, 3), b4, acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x8f16(__builtin_shufflevector(af[1][8], af[1][8], 0, 1, 2, 3), b4, acc[1], 0, 0, 0);
+#pragma unroll
+            for (int rb = 0; rb < kPfRB; ++rb)
+                acc[rb] = __builtin_amdgcn_mfma_f32_32x32x8f16(__builtin_shufflevector(af[rb][8], af[rb][8], 0, 1, 2, 3), b4, acc[rb], 0, 0, 0);
         }
     };
     // branch-free part of the epilogue; returns "this lane saw a hit" for the sweep-2 variants
-    auto epilogue_valu = [&](const f16v (&acc)[2], const BlockMeta& bm, bool do_rows = true) -> bool {
+    auto epilogue_valu = [&](const f16v (&acc)[kPfRB], const BlockMeta& bm, bool do_rows = true) -> bool {
         if (kAblNoEpi) {
-            rs0[0][0] = fmaxf(rs0[0][0], acc[0][0] + acc[1][15]);
+            rs0[0][0] = fmaxf(rs0[0][0], acc[0][0] + acc[kPfRB - 1][15]);
             return false;
         }
         // column maximum of the accumulator over this lane's 32 rows: 16 v_max3
         float m = -f_inf();
         if (PASS != 2) {
 #pragma unroll
-            for (int rb = 0; rb < 2; ++rb)
+            for (int rb = 0; rb < kPfRB; ++rb)
 #pragma unroll
                 for (int r = 0; r < 16; r += 2) m = max3f(m, acc[rb][r], acc[rb][r + 1]);
         }
@@ -386,7 +396,7 @@ __global__ __launch_bounds__(kPfThreads, 2) void approx_kernel(
             // unless both neighbours fall into one subset).
             if (do_rows) {
 #pragma unroll
-                for (int rb = 0; rb < 2; ++rb)
+                for (int rb = 0; rb < kPfRB; ++rb)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) rs0[rb][r] = fmaxf(rs0[rb][r], acc[rb][r]);
             }
@@ -404,7 +414,7 @@ __global__ __launch_bounds__(kPfThreads, 2) void approx_kernel(
             // row criterion: max over (acc - level_row) >= 0; column criterion: max over acc >= level_col
             float mr = -f_inf(), mc = -f_inf();
 #pragma unroll
-            for (int rb = 0; rb < 2; ++rb)
+            for (int rb = 0; rb < kPfRB; ++rb)
 #pragma unroll
                 for (int r = 0; r < 16; r += 2) {
                     mr = max3f(mr, acc[rb][r] - rs0[rb][r], acc[rb][r + 1] - rs0[rb][r + 1]);
@@ -416,26 +426,27 @@ __global__ __launch_bounds__(kPfThreads, 2) void approx_kernel(
     // sweep 2, rare path: the block holds at least one hit -> bit mask per lane (element k = rb*16 + r at
     // bit 31-k), slotted with ballot/popcount into this wave's LDS buffer -- no atomics in the loop --
     // and flushed to the pair's global list when the buffer fills up
-    auto append_hits = [&](bool any, const f16v (&acc)[2], const BlockMeta& bm) {
+    auto append_hits = [&](bool any, const f16v (&acc)[kPfRB], const BlockMeta& bm) {
         if (__ballot(any) == 0ull) return;
-        unsigned mask = 0;
+        unsigned long long mask = 0;   // element k = rb*16 + r at bit (16 kPfRB - 1 - k)
+        constexpr int kEl = 16 * kPfRB;
 #pragma unroll
-        for (int rb = 0; rb < 2; ++rb)
+        for (int rb = 0; rb < kPfRB; ++rb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 // padding rows / columns hold -inf: with an infinite threshold (fewer than two real elements in
                 // a subset) the hit level is -inf as well, and -inf >= -inf must not count
                 const bool hit = (PASS == 3) ? (acc[rb][r] >= 0.f)
                                              : (acc[rb][r] > -f_inf() && (acc[rb][r] >= rs0[rb][r] || acc[rb][r] >= bm.hc));
-                mask = mask + mask + (hit ? 1u : 0u);
+                mask = mask + mask + (hit ? 1ull : 0ull);
             }
-        while (__ballot(mask != 0u) != 0ull) {
-            const bool hit = mask != 0u;
-            const int k = __clz((int)mask);  // first remaining element of this lane (32 if none)
+        while (__ballot(mask != 0ull) != 0ull) {
+            const bool hit = mask != 0ull;
+            const int k = __clzll((long long)mask) - (64 - kEl);  // first remaining element of this lane
             const unsigned long long mm = __ballot(hit);
             if (n_buf + 64 > kPfCandBuf) flush_candidates();
             if (hit) {
-                mask &= ~(0x80000000u >> k);
+                mask &= ~(1ull << (kEl - 1 - k));
                 const int slt = n_buf + __popcll(mm & ((1ull << lane) - 1ull));
                 // inline asm on purpose: hipcc would first drain vmcnt(0) for a compiler-visible LDS store
                 const int2 e = make_int2(arow_base + (k >> 4) * 32 + (k & 3) + 8 * ((k & 15) >> 2), bm.col);
@@ -464,7 +475,7 @@ __global__ __launch_bounds__(kPfThreads, 2) void approx_kernel(
     // cb 1), and no accumulator lives across the loop back-edge -- carrying the second block's accumulator
     // into the next iteration (to overlap its epilogue with the next MFMAs) cost 32 register copies per tile
     // and bought nothing: MFMA and VALU issue of a SIMD do not overlap on this part (tools/ubench_mfma_valu).
-    f16v accA[2], accB[2];
+    f16v accA[kPfRB], accB[kPfRB];
     BlockMeta metaA = {0.f, 0, 0}, metaB = {0.f, 0, 0};
 #if MSFM_ABL
     h8 bf[9];  // must survive the iteration when the reads are ablated
@@ -533,7 +544,7 @@ __global__ __launch_bounds__(kPfThreads, 2) void approx_kernel(
             const bool anyB = epilogue_valu(accB, metaB, false);
             if (PASS == 1 && !kAblNoEpi) {
 #pragma unroll
-                for (int rb = 0; rb < 2; ++rb)
+                for (int rb = 0; rb < kPfRB; ++rb)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) rs0[rb][r] = max3f(rs0[rb][r], accA[rb][r], accB[rb][r]);
             }
@@ -554,9 +565,9 @@ __global__ __launch_bounds__(kPfThreads, 2) void approx_kernel(
 
     if (PASS == 1) {
         // rows: S~ = -2 * accumulator; the two smallest of the 32 lanes' minima; one partial slot per B range
-        float rs1[2][16];
+        float rs1[kPfRB][16];
 #pragma unroll
-        for (int rb = 0; rb < 2; ++rb)
+        for (int rb = 0; rb < kPfRB; ++rb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 rs0[rb][r] = -2.f * rs0[rb][r];
@@ -568,7 +579,7 @@ __global__ __launch_bounds__(kPfThreads, 2) void approx_kernel(
         if (lcol == 0) {
             const long long o = pd.rp_off + (long long)item.range * pd.n1pad + arow_base;
 #pragma unroll
-            for (int rb = 0; rb < 2; ++rb)
+            for (int rb = 0; rb < kPfRB; ++rb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int off = rb * 32 + (r & 3) + 8 * (r >> 2);
