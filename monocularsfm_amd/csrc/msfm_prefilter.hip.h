@@ -225,7 +225,8 @@ __global__ __launch_bounds__(kPfThreads, kPfRB <= 2 ? 2 : 1) void approx_kernel(
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lcol = lane & 31, lhalf = lane >> 5;
 
-    const int t_begin = item.bt_begin * 2, t_end = item.bt_end * 2;  // 64-row tiles
+    // 64-row tiles; the last 128-row block of the B image may hold an all-padding second tile: skip it
+    const int t_begin = item.bt_begin * 2, t_end = min(item.bt_end * 2, max(item.bt_begin * 2 + 1, (pd.n2 + kPfBT - 1) / kPfBT));
     const char* gB = reinterpret_cast<const char*>(pp.b_h);
     const char* gE = reinterpret_cast<const char*>(pp.b_ext);
     const gfloat_p g_anrm = (gfloat_p)pp.a_nrm;
@@ -559,7 +560,7 @@ __global__ __launch_bounds__(kPfThreads, kPfRB <= 2 ? 2 : 1) void approx_kernel(
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();  // every wave's last column partials are in LDS
         asm volatile("" ::: "memory");
-        if (wave == 0) merge_columns(t_end - 2);
+        if (wave == 0 && t_end - 2 >= t_begin) merge_columns(t_end - 2);  // (a range may consist of a single tile)
         if (wave == 1) merge_columns(t_end - 1);
     }
 
