@@ -7,6 +7,7 @@
 #include <atomic>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <iostream>
 #include <string>
 #include <thread>
@@ -64,14 +65,33 @@ void FeatureMatcher::OpenDatabaseAndDevice() {
     database_ = new Database();
     database_->Open(database_path_);
     if (!ctx_) {
-        int dev = 0;
-        if (const char* d = std::getenv("MSFM_DEVICE")) dev = std::atoi(d);
-        const int rc = msfm_create(dev, &ctx_);
-        if (rc != MSFM_OK) {
-            std::fprintf(stderr, "ComputeMatches: no usable gfx950 GPU (msfm_create status %d); there is no CPU fallback\n", rc);
-            std::exit(EXIT_FAILURE);
+        std::vector<int> devs;
+        if (const char* list = std::getenv("MSFM_DEVICES")) {
+            for (const char* c = list; *c;) {
+                char* end = nullptr;
+                const long v = std::strtol(c, &end, 10);
+                if (end == c) break;
+                devs.push_back((int)v);
+                c = (*end == ',') ? end + 1 : end;
+            }
         }
-        if (const char* o = std::getenv("MSFM_ACCUM_ORDER")) MSFM_CALL(ctx_, msfm_set_accum_order(ctx_, std::atoi(o)));
+        if (devs.empty()) {
+            int dev = 0;
+            if (const char* d = std::getenv("MSFM_DEVICE")) dev = std::atoi(d);
+            devs.push_back(dev);
+        }
+        for (size_t g = 0; g < devs.size(); ++g) {
+            msfm_ctx* c = nullptr;
+            const int rc = msfm_create(devs[g], &c);
+            if (rc != MSFM_OK) {
+                std::fprintf(stderr, "ComputeMatches: no usable gfx950 GPU at ordinal %d (msfm_create status %d); there is no CPU fallback\n", devs[g], rc);
+                std::exit(EXIT_FAILURE);
+            }
+            if (const char* o = std::getenv("MSFM_ACCUM_ORDER")) MSFM_CALL(c, msfm_set_accum_order(c, std::atoi(o)));
+            if (g == 0) ctx_ = c;
+            else extra_ctxs_.push_back(c);
+        }
+        extra_resident_.assign(extra_ctxs_.size(), std::set<image_t>());
     }
 }
 
@@ -85,6 +105,10 @@ void FeatureMatcher::CloseDatabaseAndDevice() {
         msfm_destroy(ctx_);
         ctx_ = nullptr;
     }
+    for (msfm_ctx* c : extra_ctxs_) msfm_destroy(c);
+    extra_ctxs_.clear();
+    extra_resident_.clear();
+    descriptor_cache_.clear();
     resident_.clear();
     keypoints_cache_.clear();
     g_clock.Report();
@@ -97,9 +121,24 @@ const std::vector<KeyPoint>& FeatureMatcher::KeyPointsOf(image_t image_id) {
     return it->second;
 }
 
+void FeatureMatcher::EnsureResidentOn(size_t extra_index, image_t image_id) {
+    std::set<image_t>& have = extra_resident_[extra_index];
+    if (have.count(image_id)) return;
+    EnsureResident(image_id);  // fills the host cache
+    msfm_ctx* c = extra_ctxs_[extra_index];
+    const Descriptors& d = descriptor_cache_.at(image_id);
+    MSFM_CALL(c, msfm_upload_image(c, image_id, d.data.data(), d.rows, d.rows ? d.cols : MSFM_DIM, MSFM_DTYPE_F32));
+    if (geometric_verification_ && !verification_on_host_) {
+        const std::vector<KeyPoint>& kpts = KeyPointsOf(image_id);
+        MSFM_CALL(c, msfm_upload_keypoints(c, image_id, reinterpret_cast<const float*>(kpts.data()), (int)kpts.size(), 4));
+    }
+    have.insert(image_id);
+}
+
 void FeatureMatcher::EnsureResident(image_t image_id) {
     if (resident_.count(image_id)) return;
-    const Descriptors d = database_->ReadDescriptors(image_id);
+    Descriptors read = database_->ReadDescriptors(image_id);
+    const Descriptors& d = extra_ctxs_.empty() ? read : (descriptor_cache_[image_id] = std::move(read));
     MSFM_CALL(ctx_, msfm_upload_image(ctx_, image_id, d.data.data(), d.rows, d.rows ? d.cols : MSFM_DIM, MSFM_DTYPE_F32));
     if (geometric_verification_ && !verification_on_host_) {
         // the device verifies: it needs the keypoint coordinates next to the descriptors
@@ -160,13 +199,70 @@ void FeatureMatcher::MatchImagePairGroups(const std::vector<std::vector<std::pai
         std::vector<int64_t> offs((size_t)P + 1);
         const int32_t* qt = nullptr;   // the library's page-locked result buffers: valid until the next matching call
         const float* dist = nullptr;
-        {
+        std::vector<int32_t> qt_merged;   // several devices: their lists concatenated in pair order
+        std::vector<float> dist_merged;
+        const bool verify_on_device = geometric_verification_ && !verification_on_host_;
+        auto run_on = [&](msfm_ctx* c, const int32_t* pairs, int n, int64_t* out_offs) {
+            if (verify_on_device) MSFM_CALL(c, msfm_match_pairs_verified(c, pairs, n, &prm, nullptr, out_offs));  // FilterMatches' constants
+            else MSFM_CALL(c, msfm_match_pairs(c, pairs, n, &prm, out_offs));
+        };
+        if (extra_ctxs_.empty()) {
             Lap l(&g_clock.device);
-            if (geometric_verification_ && !verification_on_host_)
-                MSFM_CALL(ctx_, msfm_match_pairs_verified(ctx_, todo.data(), P, &prm, nullptr, offs.data()));  // FilterMatches' constants
-            else
-                MSFM_CALL(ctx_, msfm_match_pairs(ctx_, todo.data(), P, &prm, offs.data()));
+            run_on(ctx_, todo.data(), P, offs.data());
             MSFM_CALL(ctx_, msfm_view_matches(ctx_, &qt, &dist, nullptr));
+        } else {
+            // contiguous ranges of equal cost sum n1 * n2, one per device; every device needs the images of its range
+            const size_t G = 1 + extra_ctxs_.size();
+            std::vector<double> cum((size_t)P + 1, 0.0);
+            for (int p = 0; p < P; ++p) {
+                int n1 = 0, n2 = 0;
+                (void)msfm_image_rows(ctx_, todo[2 * (size_t)p], &n1);
+                (void)msfm_image_rows(ctx_, todo[2 * (size_t)p + 1], &n2);
+                cum[(size_t)p + 1] = cum[(size_t)p] + (double)n1 * n2 + 1.0;
+            }
+            std::vector<int> cut(G + 1, P);
+            cut[0] = 0;
+            for (size_t g = 1; g < G; ++g)
+                cut[g] = (int)(std::lower_bound(cum.begin(), cum.end(), cum[(size_t)P] * (double)g / (double)G) - cum.begin());
+            for (size_t g = 1; g <= G; ++g) cut[g] = std::max(cut[g], cut[g - 1]);
+            {
+                Lap l(&g_clock.read_desc);
+                for (size_t g = 1; g < G; ++g)
+                    for (int p = cut[g]; p < cut[g + 1]; ++p) {
+                        EnsureResidentOn(g - 1, todo[2 * (size_t)p]);
+                        EnsureResidentOn(g - 1, todo[2 * (size_t)p + 1]);
+                    }
+            }
+            Lap l(&g_clock.device);
+            std::vector<std::vector<int64_t>> part_offs(G);
+            std::vector<std::thread> workers;
+            for (size_t g = 0; g < G; ++g) {
+                part_offs[g].assign((size_t)(cut[g + 1] - cut[g]) + 1, 0);
+                msfm_ctx* c = g == 0 ? ctx_ : extra_ctxs_[g - 1];
+                workers.emplace_back([&, g, c] { run_on(c, todo.data() + 2 * (size_t)cut[g], cut[g + 1] - cut[g], part_offs[g].data()); });
+            }
+            for (auto& w : workers) w.join();
+            int64_t total = 0;
+            for (size_t g = 0; g < G; ++g) {
+                for (int p = cut[g]; p < cut[g + 1]; ++p) offs[(size_t)p + 1] = total + part_offs[g][(size_t)(p - cut[g]) + 1];
+                total += part_offs[g].back();
+            }
+            qt_merged.resize((size_t)total * 2 + 2);
+            dist_merged.resize((size_t)total + 1);
+            for (size_t g = 0; g < G; ++g) {
+                msfm_ctx* c = g == 0 ? ctx_ : extra_ctxs_[g - 1];
+                const int32_t* q = nullptr;
+                const float* dd = nullptr;
+                int64_t cnt = 0;
+                MSFM_CALL(c, msfm_view_matches(c, &q, &dd, &cnt));
+                const size_t at = (size_t)offs[(size_t)cut[g]];
+                if (cnt > 0) {
+                    std::memcpy(qt_merged.data() + 2 * at, q, (size_t)cnt * 8);
+                    std::memcpy(dist_merged.data() + at, dd, (size_t)cnt * 4);
+                }
+            }
+            qt = qt_merged.data();
+            dist = dist_merged.data();
         }
         gpu_seconds_per_pair = timer.ElapsedSeconds() / P;
 

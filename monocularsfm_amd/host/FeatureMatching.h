@@ -51,8 +51,14 @@ protected:
     bool geometric_verification_ = true;
     bool verification_on_host_ = false;  // MSFM_GEOMETRIC_VERIFICATION=host
     Database* database_ = nullptr;
-    msfm_ctx* ctx_ = nullptr;
+    msfm_ctx* ctx_ = nullptr;             // primary device (MSFM_DEVICE, or the first entry of MSFM_DEVICES)
     std::set<image_t> resident_;
+    // MSFM_DEVICES="0,1,...": the pairs of a super-batch are split over these GPUs (one context and one host
+    // thread per device, the whole descriptor store replicated on each; SQLite stays on the calling thread)
+    std::vector<msfm_ctx*> extra_ctxs_;                 // devices 1..G-1
+    std::vector<std::set<image_t>> extra_resident_;
+    std::map<image_t, Descriptors> descriptor_cache_;   // host copies, kept only when there are extra devices
+    void EnsureResidentOn(size_t extra_index, image_t image_id);
     std::map<image_t, std::vector<KeyPoint>> keypoints_cache_;  // read once per image (verification)
 };
 

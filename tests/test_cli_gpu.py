@@ -181,3 +181,29 @@ def test_python_matcher_mirror_equals_cli(exe, dataset, gpu_ctx, tmp_path):
     ra = database.Database(a).db.execute("SELECT pair_id, rows, cols, data FROM matches ORDER BY pair_id").fetchall()
     rb = database.Database(b).db.execute("SELECT pair_id, rows, cols, data FROM matches ORDER BY pair_id").fetchall()
     assert ra == rb and len(ra) > 4
+
+
+@pytest.mark.parametrize("gv", ["", "0"])
+def test_multi_device_split_writes_the_same_rows(exe, dataset, tmp_path, gv):
+    """MSFM_DEVICES splits every super-batch over several contexts (one host thread each).  With one GPU in the box
+    the same ordinal is listed three times: three contexts, three threads, same rows and stdout as a single device."""
+    descs, kps = dataset
+    a, b = str(tmp_path / "one.db"), str(tmp_path / "three.db")
+    database.write_synthetic_database(a, descs, kps)
+    shutil.copy(a, b)
+    outs = []
+    for path, env in ((a, {}), (b, {"MSFM_DEVICES": "0,0,0"})):
+        cfg = tmp_path / (os.path.basename(path) + ".yaml")
+        cfg.write_text(YAML.format(db=path, mt=1))
+        e = dict(env)
+        if gv:
+            e["MSFM_GEOMETRIC_VERIFICATION"] = gv
+        outs.append(run_cli(exe, cfg, e))
+    da, dbb = database.Database(a), database.Database(b)
+    ra = da.db.execute("SELECT pair_id, rows, cols, data FROM matches ORDER BY pair_id").fetchall()
+    rb = dbb.db.execute("SELECT pair_id, rows, cols, data FROM matches ORDER BY pair_id").fetchall()
+    da.Close()
+    dbb.Close()
+    assert len(ra) > 5 and ra == rb
+    strip = lambda s: re.sub(r"Elapsed time: [0-9.]+", "Elapsed time: X", s)
+    assert strip(outs[0]) == strip(outs[1])
