@@ -53,7 +53,11 @@ template <typename T>
 void WriteBlob(sqlite3_stmt* stmt, const T* data, size_t rows, size_t cols, int col) {
     SQL_CALL(Sqlite().bind_int64(stmt, col + 0, (int64_t)rows));
     SQL_CALL(Sqlite().bind_int64(stmt, col + 1, (int64_t)cols));
-    SQL_CALL(Sqlite().bind_blob(stmt, col + 2, data, (int)(rows * cols * sizeof(T)), nullptr /* SQLITE_STATIC */));
+    // The reference binds malloc(rows * cols * sizeof(T)) (Database.cpp:57-61, 270-277): for an empty list that is
+    // a non-null pointer with length 0, i.e. a zero-length BLOB -- not NULL, which a null data pointer would give.
+    static const char kEmpty = 0;
+    const void* ptr = (rows * cols == 0 || data == nullptr) ? static_cast<const void*>(&kEmpty) : static_cast<const void*>(data);
+    SQL_CALL(Sqlite().bind_blob(stmt, col + 2, ptr, (int)(rows * cols * sizeof(T)), nullptr /* SQLITE_STATIC */));
 }
 
 }  // namespace

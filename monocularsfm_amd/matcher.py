@@ -59,9 +59,10 @@ class FeatureUtils:
 
 
 class FeatureMatcher:
-    """FeatureMatcher (FeatureMatching.h:18-57).  geometric_verification, if given, is called as
-    f(kpts1, kpts2, matches) -> matches in place of FeatureUtils::FilterMatches (F-RANSAC, a
-    "next" row of the scope table); None keeps the distance-filtered matches."""
+    """FeatureMatcher (FeatureMatching.h:18-57).  geometric_verification: "device" runs FeatureUtils::FilterMatches
+    (F-matrix RANSAC, a "next" row of the scope table) on the GPU inside the matching call
+    (msfm_match_pairs_verified, what the C++ CLI does by default); a callable is called as
+    f(kpts1, kpts2, matches) -> matches instead; None keeps the distance-filtered matches."""
 
     def __init__(self, database_path, max_num_matches=10240, max_distance=0.7, distance_ratio=0.8,
                  cross_check=True, ctx=None, device=0, geometric_verification=None, verbose=True):
@@ -84,6 +85,8 @@ class FeatureMatcher:
         # replaces the per-pair Database::ReadDescriptors re-read (FeatureMatching.cpp:31-33)
         if image_id not in self._resident:
             self.ctx.upload_image(image_id, self.database_.ReadDescriptors(image_id))
+            if self.geometric_verification == "device":
+                self.ctx.upload_keypoints(image_id, self.database_.ReadKeyPoints(image_id))
             self._resident.add(image_id)
 
     def MatchImagePairs(self, image_pairs):
@@ -101,13 +104,14 @@ class FeatureMatcher:
                 self._ensure_resident(id1)
                 self._ensure_resident(id2)
             t0 = time.perf_counter()
-            offs, qt, dist = self.ctx.match_pairs(np.asarray(todo, np.int32), ratio=self.distance_ratio_,
-                                                  cross_check=self.cross_check_, max_distance=self.max_distance_)
+            match = self.ctx.match_pairs_verified if self.geometric_verification == "device" else self.ctx.match_pairs
+            offs, qt, dist = match(np.asarray(todo, np.int32), ratio=self.distance_ratio_,
+                                   cross_check=self.cross_check_, max_distance=self.max_distance_)
             per_pair = (time.perf_counter() - t0) / len(todo)
             for p, (id1, id2) in enumerate(todo):
                 self._out("Compute Matches %d - %d ... \n" % (id1, id2))
                 m = qt[offs[p]:offs[p + 1]]
-                if self.geometric_verification is not None:
+                if callable(self.geometric_verification):
                     k1, k2 = db.ReadKeyPoints(id1), db.ReadKeyPoints(id2)
                     q, t, _ = self.geometric_verification(k1, k2, (m[:, 0], m[:, 1], dist[offs[p]:offs[p + 1]]))
                     m = np.stack([q, t], axis=1) if len(q) else np.zeros((0, 2), np.int32)

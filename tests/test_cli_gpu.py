@@ -181,6 +181,18 @@ def test_python_matcher_mirror_equals_cli(exe, dataset, gpu_ctx, tmp_path):
     ra = database.Database(a).db.execute("SELECT pair_id, rows, cols, data FROM matches ORDER BY pair_id").fetchall()
     rb = database.Database(b).db.execute("SELECT pair_id, rows, cols, data FROM matches ORDER BY pair_id").fetchall()
     assert ra == rb and len(ra) > 4
+    # and with the geometric verification on the device on both sides (the CLI's default)
+    c, d = str(tmp_path / "cli_gv.db"), str(tmp_path / "py_gv.db")
+    database.write_synthetic_database(c, descs, kps)
+    shutil.copy(c, d)
+    cfg2 = tmp_path / "cli_gv.yaml"
+    cfg2.write_text(YAML.format(db=c, mt=1))
+    run_cli(exe, cfg2, {})
+    gpu_ctx.clear_images()
+    BruteFeatureMatcher(d, ctx=gpu_ctx, verbose=False, geometric_verification="device").RunMatching()
+    rc = database.Database(c).db.execute("SELECT pair_id, rows, cols, data FROM matches ORDER BY pair_id").fetchall()
+    rd = database.Database(d).db.execute("SELECT pair_id, rows, cols, data FROM matches ORDER BY pair_id").fetchall()
+    assert rc == rd and len(rc) == len(ra)
 
 
 @pytest.mark.parametrize("gv", ["", "0"])

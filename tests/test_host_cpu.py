@@ -98,6 +98,12 @@ def test_database_cpp_and_python_agree(host, tmp_path):
     db.WriteMatches(1, 0, np.zeros((0, 2), np.int32))
     assert db.ExistMatches(0, 1) and len(db.ReadAllMatches()) == 1
     db.Close()
+    # ... and its data column is a zero-length BLOB, not NULL, from both writers (the reference binds malloc(0))
+    host.host_db_write_matches(p, 2, 1, qt.ctypes.data_as(C.POINTER(C.c_int)), 0)
+    db = database.Database(db_path)
+    kinds = db.db.execute("SELECT pair_id, rows, typeof(data), length(data) FROM matches WHERE rows = 0 ORDER BY pair_id").fetchall()
+    assert kinds == [(database.ImagePairToPairId(1, 0), 0, "blob", 0), (database.ImagePairToPairId(2, 1), 0, "blob", 0)]
+    db.Close()
     back = np.zeros((8, 2), np.int32)
     assert host.host_db_read_matches(p, 0, 2, back.ctypes.data_as(C.POINTER(C.c_int)), 8) == 3
     assert np.array_equal(back[:3], qt[:, ::-1])
