@@ -328,7 +328,7 @@ void FeatureMatcher::MatchImagePairGroups(const std::vector<std::vector<std::pai
 }
 
 namespace {
-constexpr size_t kSuperBatchPairs = 4096;  // pairs computed per device call (the reference's groups are <= 100)
+constexpr size_t kSuperBatchPairs = 16384;  // pairs computed per device call (the reference's groups are <= 100)
 }
 
 void SequentialFeatureMatcher::RunMatching() {
