@@ -331,7 +331,10 @@ __global__ __launch_bounds__(kThreads) void dist_top2_kernel(
         for (int i = 0; i < kTM; ++i)
 #pragma unroll
             for (int j = 0; j < kTN; ++j)
-                fin[i][j] = (OT::kGroups == 4) ? lvl1[i >> 1][j][i & 1] : lvl2[i >> 1][j][i & 1];
+                // v_min_f32 returns the non-NaN operand: a NaN distance becomes +inf, which is never inserted
+                // (batchDistance only replaces its FLT_MAX-initialised slots by strictly smaller values) -- and
+                // v_med3_f32 in top2_push is only well-defined without NaNs
+                fin[i][j] = fminf((OT::kGroups == 4) ? lvl1[i >> 1][j][i & 1] : lvl2[i >> 1][j][i & 1], f_inf());
 
         // ---- tile epilogue -------------------------------------------------------------
         const int col0 = bt * kBN + wave * kWaveCols + tx * kTN;  // first B row (train index) of this lane

@@ -290,3 +290,28 @@ def test_view_matches_equals_fetch(gpu_ctx):
     assert np.array_equal(q2, keep)
     e = gpu_ctx.match_pairs(np.zeros((0, 2), np.int32), fetch="view")
     assert e[1].shape == (0, 2) and e[2].shape == (0,)
+
+
+def test_non_finite_and_huge_values_follow_the_oracle(gpu_ctx, oracle):
+    """NaN / inf / overflowing components: such rows take the brute-force route (not fp16-safe); a non-finite or
+    >= FLT_MAX distance is never inserted as a neighbour (batchDistance compares against FLT_MAX-initialised slots)."""
+    imgs = synth.rootsift_images(2, [300, 280], seed=81, n_proto=600)
+    A, B = imgs[0].copy(), imgs[1].copy()
+    A[3, 7] = np.nan
+    A[10, :] = np.inf
+    A[20, 5] = -np.inf
+    A[30, :] = F32(3e19)          # squares overflow to inf
+    B[4, 100] = np.nan
+    B[40, :] = F32(-3e19)
+    B[50, 0] = F32(1e30)
+    upload_pair(gpu_ctx, A, B)
+    fwd, rev = gpu_ctx.knn2_pair(0, 1)
+    oi0, od0, _, od1 = oracle.knn2(A, B, 0, 4)
+    pi0, pd0, _, pd1 = oracle.knn2(B, A, 0, 4)
+    assert_knn_equal(fwd, oi0, od0, od1)
+    assert_knn_equal(rev, pi0, pd0, pd1)
+    for cc in (True, False):
+        q, t, d = gpu_ctx.match_pair(0, 1, 0.8, cc, float("inf"))
+        oq, ot, od = oracle.match_pair(A, B, 0.8, cc, np.inf, 0, 4)
+        assert np.array_equal(q, oq) and np.array_equal(t, ot) and np.array_equal(b(d), b(od))
+    assert gpu_ctx.profile()["prefilter_pairs"] == 0
