@@ -99,7 +99,7 @@ def test_magnitudes_outside_fp16_are_not_prefiltered(gpu_ctx, oracle):
     assert np.array_equal(fwd[0], oi0) and np.array_equal(b(fwd[1]), b(od0)) and np.array_equal(b(fwd[2]), b(od1))
 
 
-@pytest.mark.parametrize("scale", [1e-3, 1e-6, 3.0, 200.0])
+@pytest.mark.parametrize("scale", [1e-3, 1e-6, 3.0, 200.0, 3000.0, 30000.0, 1e-4, 1e-5])
 def test_scaled_magnitudes(gpu_ctx, oracle, scale):
     """fp16 subnormal / underflow range (absolute error term) and large-but-safe magnitudes."""
     imgs = synth.rootsift_images(2, [500, 450], seed=11, n_proto=900)
