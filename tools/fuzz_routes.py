@@ -1,0 +1,49 @@
+"""Long seeded fuzz: the prefilter route against the brute-force route (match lists and knnMatch-level arrays) over random
+sizes, value types, scales, duplicates, NaNs, parameters and orders.  Usage: python tools/fuzz_routes.py [seed] [cases]"""
+import sys, numpy as np
+sys.path.insert(0, '.')
+from monocularsfm_amd import _lib, synth
+F32 = np.float32
+b = lambda a: np.asarray(a).view(np.int32) if np.asarray(a).dtype == np.float32 else np.asarray(a)
+ctx = _lib.Context(0)
+rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 7)
+bad = 0
+for case in range(int(sys.argv[2]) if len(sys.argv) > 2 else 1500):
+    n_img = int(rng.integers(2, 6))
+    sizes = [int(rng.choice([1, 2, 3, 7, 31, 60, 64, 65, 130, 255, 256, 257, 600, 1100, 1700, 2600])) for _ in range(n_img)]
+    kind = rng.choice(["rootsift", "u8", "gauss", "scaled", "mixed"])
+    if kind == "rootsift":
+        imgs = synth.rootsift_images(n_img, sizes, seed=1000 + case, n_proto=max(sizes) + 50, sigma=float(rng.choice([0.02, 0.05, 0.1])))
+    elif kind == "u8":
+        imgs = [x.astype(F32) for x in synth.u8_images(n_img, sizes, seed=2000 + case, as_float=True)]
+    elif kind == "gauss":
+        imgs = [rng.normal(size=(n, 128)).astype(F32) for n in sizes]
+    elif kind == "scaled":
+        sc = F32(rng.choice([1e-5, 1e-3, 0.25, 7.0, 150.0, 4000.0]))
+        imgs = [(x * sc).astype(F32) for x in synth.rootsift_images(n_img, sizes, seed=3000 + case, n_proto=max(sizes) + 50)]
+    else:
+        imgs = [(x * F32(rng.choice([0.5, 1.0, 2.0, 4.0]))).astype(F32) for x in synth.rootsift_images(n_img, sizes, seed=4000 + case, n_proto=max(sizes) + 50)]
+    if rng.random() < 0.5 and sizes[0] >= 3:
+        imgs[0][1] = imgs[0][0]; imgs[-1][-1] = imgs[0][0]
+    if rng.random() < 0.1:
+        imgs[0][0, 3] = np.nan
+    order = int(rng.integers(0, 2)); ratio = float(rng.choice([0.3, 0.6, 0.8, 0.95, 1.0, 1.2])); cc = bool(rng.integers(0, 2))
+    md = float(rng.choice([0.05, 0.3, 0.7, 2.0, 1e4, np.inf]))
+    ctx.set_accum_order(order)
+    for i, im in enumerate(imgs): ctx.upload_image(i, im)
+    pairs = np.array([(i, j) for i in range(n_img) for j in range(n_img) if i != j or rng.random() < 0.2], np.int32)
+    got = ctx.match_pairs(pairs, ratio, cc, md)
+    kp = [ctx.knn2_pair(int(i), int(j)) for i, j in pairs[:3]]
+    ctx.set_prefilter(False)
+    ref = ctx.match_pairs(pairs, ratio, cc, md)
+    kb = [ctx.knn2_pair(int(i), int(j)) for i, j in pairs[:3]]
+    ctx.set_prefilter(True)
+    ok = np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1]) and np.array_equal(b(got[2]), b(ref[2]))
+    for x, y in zip(kp, kb):
+        for d in (0, 1):
+            for k in range(3):
+                ok &= np.array_equal(b(x[d][k]), b(y[d][k]))
+    if not ok:
+        bad += 1
+        print("MISMATCH", case, kind, sizes, order, ratio, cc, md, flush=True)
+print("cases done, mismatches:", bad)
