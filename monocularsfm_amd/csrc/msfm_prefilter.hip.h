@@ -184,6 +184,9 @@ constexpr int kPfRing = 3;
 #ifndef MSFM_ABL
 #define MSFM_ABL 0
 #endif
+#ifndef MSFM_PIPE
+#define MSFM_PIPE 0    // 1: block-level software pipeline (experiment, see the loop)
+#endif
 #ifndef MSFM_SCHED
 #define MSFM_SCHED 0   // scheduling experiments (tools/variant_bench.sh); 0 = production
 #endif
@@ -471,6 +474,68 @@ __global__ __launch_bounds__(kPfThreads, kPfRB <= 2 ? 2 : 1) void approx_kernel(
         cp_s1[o] = w0.y;
     };
 
+    if constexpr (MSFM_PIPE == 1) {
+    // EXPERIMENT (-DMSFM_PIPE=1, measured and not adopted): software pipeline at block granularity.  At two waves
+    // per SIMD the second fragment buffer spills in sweep 1 (+35 %); in the compacted sweep it gains 1.6 %; at one
+    // wave per SIMD (MSFM_RB=4) the accumulators land in AGPRs and the epilogue pays v_accvgpr_read copies (+35 %).  While block k multiplies, the B fragments
+    // of block k+1 are read from LDS (second fragment buffer) and the epilogue of block k-1 runs on the other
+    // accumulator set; one barrier per tile at the start of its second half, DMA one tile ahead (vmcnt(0) there:
+    // the loads are a full tile old).
+    f16v accA[kPfRB], accB[kPfRB];
+#pragma unroll
+    for (int rb = 0; rb < kPfRB; ++rb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accB[rb][r] = -f_inf();
+    BlockMeta metaA = {0.f, 0, 0}, metaB = {f_inf(), t_begin * kPfBT + 32 + lcol, (2 * 4 + wave) * 64 + 32};
+    h8 bfA[9], bfB[9];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // tile t_begin is in LDS (every wave waited for its own DMA part above)
+    asm volatile("" ::: "memory");
+    if (wave_active) load_bf(sB + lcol * kHalfRowBytes, (int)(ext_w - pf_smem), 0, bfA);
+#pragma unroll 1
+    for (int t = t_begin; t < t_end; ++t) {
+        const int sl = (t - t_begin) % kPfRing;
+        const char* pb = sB + sl * kPfLdsB + lcol * kHalfRowBytes;
+        const int pe_off = (int)(ext_w - pf_smem) + sl * kPfExtB;
+        const float* thr = thr_w + sl * 64;
+        abl_t = t;
+        // ---- first half: block (t, 0) multiplies; fragments of (t, 1) arrive; epilogue of (t-1, 1) ----
+        if (wave_active) {
+            load_bf(pb, pe_off, 1, bfB);
+            metaA.hc = (PASS == 2) ? -0.5f * thr[lcol] : 0.f;
+            metaA.col = t * kPfBT + lcol;
+            metaA.cslot = (sl * 4 + wave) * 64;
+            mfma_block(bfA, accA);
+            const bool anyB = epilogue_valu(accB, metaB, true);
+            if (PASS >= 2) append_hits(anyB, accB, metaB);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- tile t+1 must have landed; tile t-1's slot is free for tile t+2 ----
+        wait_vmcnt<0>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        dma_tile(t + 2);
+        if (PASS == 1 && t - t_begin >= 2 && wave == (t & 3)) merge_columns(t - 2);
+        // ---- second half: block (t, 1) multiplies; fragments of (t+1, 0) arrive; epilogue of (t, 0) ----
+        if (wave_active) {
+            const int tn = t + 1 < t_end ? t + 1 : t;   // the last prefetch re-reads the current tile (unused)
+            const int sn = (tn - t_begin) % kPfRing;
+            load_bf(sB + sn * kPfLdsB + lcol * kHalfRowBytes, (int)(ext_w - pf_smem) + sn * kPfExtB, 0, bfA);
+            metaB.hc = (PASS == 2) ? -0.5f * thr[32 + lcol] : 0.f;
+            metaB.col = t * kPfBT + 32 + lcol;
+            metaB.cslot = (sl * 4 + wave) * 64 + 32;
+            mfma_block(bfB, accB);
+            const bool anyA = epilogue_valu(accA, metaA, true);
+            if (PASS >= 2) append_hits(anyA, accA, metaA);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (wave_active) {   // drain: epilogue of the last block
+        const bool any = epilogue_valu(accB, metaB, true);
+        if (PASS >= 2) append_hits(any, accB, metaB);
+    }
+    } else {
     // Both column blocks of a tile are multiplied first (four independent accumulator chains), then their
     // epilogues run together: rows take ONE v_max3 per pair of elements (running maximum, block cb 0, block
     // cb 1), and no accumulator lives across the loop back-edge -- carrying the second block's accumulator
@@ -554,6 +619,7 @@ __global__ __launch_bounds__(kPfThreads, kPfRB <= 2 ? 2 : 1) void approx_kernel(
                 append_hits(anyB, accB, metaB);
             }
         }
+    }
     }
     if (PASS >= 2) flush_candidates();
     if (PASS == 1) {
