@@ -219,3 +219,31 @@ def test_multi_device_split_writes_the_same_rows(exe, dataset, tmp_path, gv):
     assert len(ra) > 5 and ra == rb
     strip = lambda s: re.sub(r"Elapsed time: [0-9.]+", "Elapsed time: X", s)
     assert strip(outs[0]) == strip(outs[1])
+
+
+@pytest.mark.parametrize("mt", [0, 1])
+def test_images_without_descriptors_and_tiny_images(exe, tmp_path, mt):
+    """Images with 0, 1 and 2 descriptors next to normal ones: the reference would hit knnMatch's undefined cases
+    (FeatureUtils.cpp:152); the drop-in must finish, give every non-skipped pair a row and never invent matches
+    for the degenerate sides."""
+    descs = synth.rootsift_images(5, [400, 0, 1, 2, 350], seed=404, n_proto=800)
+    descs = [np.ascontiguousarray(d, np.float32).reshape(-1, 128) for d in descs]
+    kps = [synth.keypoints(len(d), seed=70 + i) for i, d in enumerate(descs)]
+    db_path = str(tmp_path / "tiny.db")
+    database.write_synthetic_database(db_path, descs, kps)
+    cfg = tmp_path / "tiny.yaml"
+    cfg.write_text(YAML.format(db=db_path, mt=mt))
+    for env in ({"MSFM_GEOMETRIC_VERIFICATION": "0"}, {}):
+        p2 = db_path + (".gv" if not env else ".nogv")
+        shutil.copy(db_path, p2)
+        c2 = tmp_path / (os.path.basename(p2) + ".yaml")
+        c2.write_text(YAML.format(db=p2, mt=mt))
+        out = run_cli(exe, c2, env)
+        assert re.search(r"Elapsed time: \d+\.\d{5} \[minutes\]\n$", out)
+        db = database.Database(p2)
+        rows = db.db.execute("SELECT pair_id, rows FROM matches").fetchall()
+        db.Close()
+        for pid, r in rows:
+            i, j = pid % 10000, pid // 10000     # pair_id = 10000 * min + max
+            if min(len(descs[i]), len(descs[j])) < 2:
+                assert r == 0, (pid, r)
