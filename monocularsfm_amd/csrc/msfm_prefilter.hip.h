@@ -474,7 +474,63 @@ __global__ __launch_bounds__(kPfThreads, kPfRB <= 2 ? 2 : 1) void approx_kernel(
         cp_s1[o] = w0.y;
     };
 
-    if constexpr (MSFM_PIPE == 1) {
+    if constexpr (MSFM_PIPE == 2) {
+        // EXPERIMENT (-DMSFM_PIPE=2): epilogue of block k-1 placed in the MFMA gaps of block k (one fragment buffer,
+        // two accumulator sets alternating statically; sched_barrier between the halves keeps hipcc from sinking the
+        // row updates across them, which is what cost 32 register copies per tile in the first version of this loop)
+        f16v accA[kPfRB], accB[kPfRB];
+#pragma unroll
+        for (int rb = 0; rb < kPfRB; ++rb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accB[rb][r] = -f_inf();
+        BlockMeta metaA = {0.f, 0, 0}, metaB = {f_inf(), t_begin * kPfBT + 32 + lcol, (2 * 4 + wave) * 64 + 32};
+        auto hint = [&]() {
+#pragma unroll
+            for (int k = 0; k < 18; ++k) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+            }
+        };
+#pragma unroll 1
+        for (int t = t_begin; t < t_end; ++t) {
+            if (t - t_begin >= 2) wait_vmcnt<kDmaOps>();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            dma_tile(t + 2);
+            if (PASS == 1 && t - t_begin >= 2 && wave == (t & 3)) merge_columns(t - 2);
+            const int sl = (t - t_begin) % kPfRing;
+            const char* pb = sB + sl * kPfLdsB + lcol * kHalfRowBytes;
+            const int pe_off = (int)(ext_w - pf_smem) + sl * kPfExtB;
+            const float* thr = thr_w + sl * 64;
+            abl_t = t;
+            if (wave_active) {
+                h8 bf[9];
+                load_bf(pb, pe_off, 0, bf);
+                metaA.hc = (PASS == 2) ? -0.5f * thr[lcol] : 0.f;
+                metaA.col = t * kPfBT + lcol;
+                metaA.cslot = (sl * 4 + wave) * 64;
+                mfma_block(bf, accA);
+                const bool anyB = epilogue_valu(accB, metaB, true);
+                hint();
+                if (PASS >= 2) append_hits(anyB, accB, metaB);
+                __builtin_amdgcn_sched_barrier(0);
+                load_bf(pb, pe_off, 1, bf);
+                metaB.hc = (PASS == 2) ? -0.5f * thr[32 + lcol] : 0.f;
+                metaB.col = t * kPfBT + 32 + lcol;
+                metaB.cslot = (sl * 4 + wave) * 64 + 32;
+                mfma_block(bf, accB);
+                const bool anyA = epilogue_valu(accA, metaA, true);
+                hint();
+                if (PASS >= 2) append_hits(anyA, accA, metaA);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (wave_active) {
+            const bool any = epilogue_valu(accB, metaB, true);
+            if (PASS >= 2) append_hits(any, accB, metaB);
+        }
+    } else if constexpr (MSFM_PIPE == 1) {
     // EXPERIMENT (-DMSFM_PIPE=1, measured and not adopted): software pipeline at block granularity.  At two waves
     // per SIMD the second fragment buffer spills in sweep 1 (+35 %); in the compacted sweep it gains 1.6 %; at one
     // wave per SIMD (MSFM_RB=4) the accumulators land in AGPRs and the epilogue pays v_accvgpr_read copies (+35 %).  While block k multiplies, the B fragments
