@@ -247,3 +247,27 @@ def test_images_without_descriptors_and_tiny_images(exe, tmp_path, mt):
             i, j = pid % 10000, pid // 10000     # pair_id = 10000 * min + max
             if min(len(descs[i]), len(descs[j])) < 2:
                 assert r == 0, (pid, r)
+
+
+def test_partial_resume_recomputes_only_missing_rows(exe, dataset, tmp_path):
+    """Rows are the checkpoint (FeatureMatching.cpp:23-27): after deleting a few rows a rerun recomputes exactly
+    those, in place, with the same bytes, and reports every other pair as existing."""
+    descs, kps = dataset
+    db_path = str(tmp_path / "resume.db")
+    database.write_synthetic_database(db_path, descs, kps)
+    cfg = tmp_path / "resume.yaml"
+    cfg.write_text(YAML.format(db=db_path, mt=1))
+    run_cli(exe, cfg, {})
+    db = database.Database(db_path)
+    before = db.db.execute("SELECT pair_id, rows, cols, data FROM matches ORDER BY pair_id").fetchall()
+    victims = [before[1][0], before[len(before) // 2][0], before[-1][0]]
+    db.db.execute("DELETE FROM matches WHERE pair_id IN (%s)" % ",".join(str(v) for v in victims))
+    db.db.commit()
+    db.Close()
+    out = run_cli(exe, cfg, {})
+    db = database.Database(db_path)
+    after = db.db.execute("SELECT pair_id, rows, cols, data FROM matches ORDER BY pair_id").fetchall()
+    db.Close()
+    assert after == before
+    assert out.count("Existing, Continue!") == len(before) - len(victims)
+    assert out.count(" ... \n") == len(victims)
