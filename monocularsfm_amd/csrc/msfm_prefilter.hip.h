@@ -630,6 +630,11 @@ __global__ __launch_bounds__(kPfThreads, kPfRB <= 2 ? 2 : 1) void approx_kernel(
 #if !MSFM_ABL
             h8 bf[9];
 #endif
+#if MSFM_SCHED == 4
+            __builtin_amdgcn_iglp_opt(0);
+#elif MSFM_SCHED == 5
+            __builtin_amdgcn_iglp_opt(1);
+#endif
             load_bf(pb, pe_off, 0, bf);
             metaA.hc = (PASS == 2) ? -0.5f * thr[lcol] : 0.f;
             metaA.col = t * kPfBT + lcol;
