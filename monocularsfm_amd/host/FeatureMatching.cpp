@@ -164,7 +164,8 @@ void FeatureMatcher::MatchImagePairGroups(const std::vector<std::vector<std::pai
     std::vector<std::vector<Slot>> slots(groups.size());
     std::vector<int32_t> todo;
     std::set<std::pair<image_t, image_t>> scheduled;
-    Lap* lap = new Lap(&g_clock.exist);
+    {
+    Lap lap(&g_clock.exist);
     for (size_t g = 0; g < groups.size(); ++g) {
         slots[g].resize(groups[g].size());
         for (size_t k = 0; k < groups[g].size(); ++k) {
@@ -180,7 +181,7 @@ void FeatureMatcher::MatchImagePairGroups(const std::vector<std::vector<std::pai
             todo.push_back(image_id2);
         }
     }
-    delete lap;
+    }
     const int P = (int)(todo.size() / 2);
     std::vector<std::vector<DMatch>> verified((size_t)P);
     std::vector<double> verify_seconds((size_t)P, 0.0);
