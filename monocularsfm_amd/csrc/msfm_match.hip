@@ -334,6 +334,150 @@ std::vector<WorkItem> interleave_items(const std::vector<WorkItem>& lin) {
     return out;
 }
 
+// ---- host-side plan of sweep 2 ----------------------------------------------------------------
+struct VMember { int pair, dir, cnt; long long row; };                                   // one (pair, direction): a slice of a group's rows
+struct VGroup { const _Float16* b_h; int dir; int first, count; long long row0, rows; };  // the pairs streaming one image in one direction
+struct Sweep2Plan {
+    std::vector<VMember> members;
+    std::vector<VGroup> groups;
+    std::vector<PairDesc> vpairs;   // per group: the compacted "pair" (A = concatenated live rows, B = the streamed image)
+    std::vector<PfPair> vpf;
+    std::vector<GatherJob> jobs;    // per member
+    std::vector<CandList> lists;    // [0, P): dense lists of the pairs; [P, P+V): one per group
+    std::vector<WorkItem> ditems, vitems;
+    long long cand_elems = 0;
+};
+
+// Which candidate lists exist, where the compacted rows go, which work items sweep them.  `compact[p]`: pair p
+// is swept through its compacted live rows (live[2p], live[2p+1] of them); the others get the dense sweep.
+int plan_sweep2(msfm_ctx* ctx, Batch& b, const std::vector<char>& compact, const std::vector<int>& live, Sweep2Plan& plan) {
+    const size_t P = b.pairs.size();
+    // Compacted sweeps are GROUPED: the live rows of every pair that streams the same image in the same
+    // direction are concatenated into one dense matrix (blocks are then full except for one tail per group;
+    // a pair's own ~300 live rows would fill its last 256-row block to a fifth).
+    std::vector<VMember>& members = plan.members;
+    std::vector<VGroup>& groups = plan.groups;
+    long long cmp_rows = 0;
+    long long& cand_elems = plan.cand_elems;
+    cand_elems = 0;
+    {
+        std::map<std::pair<const void*, int>, std::vector<VMember>> by_key;
+        std::vector<std::pair<const void*, int>> key_order;
+        for (size_t p = 0; p < P; ++p) {
+            PairDesc& pd = b.pairs[p];
+            PfPair& pp = b.pf[p];
+            if (!pd.valid || !pp.use) continue;
+            if (!compact[p]) {
+                pp.cand_off = cand_elems;
+                pp.cand_cap = 8 * (pd.n1 + pd.n2) + 1024;
+                cand_elems += pp.cand_cap;
+                continue;
+            }
+            for (int dir = 0; dir < 2; ++dir) {
+                const int cnt = live[2 * p + dir];
+                if (cnt == 0) continue;
+                const std::pair<const void*, int> key(dir ? (const void*)pp.a_h : (const void*)pp.b_h, dir);
+                auto it = by_key.find(key);
+                if (it == by_key.end()) {
+                    key_order.push_back(key);
+                    it = by_key.emplace(key, std::vector<VMember>()).first;
+                }
+                it->second.push_back(VMember{(int)p, dir, cnt, 0});
+            }
+        }
+        for (const auto& key : key_order) {
+            std::vector<VMember>& ms = by_key[key];
+            VGroup g{(const _Float16*)key.first, key.second, (int)members.size(), (int)ms.size(), cmp_rows, 0};
+            for (VMember& m : ms) {
+                m.row = cmp_rows + g.rows;
+                g.rows += m.cnt;
+                members.push_back(m);
+            }
+            cmp_rows += (g.rows + kPfWgRows - 1) / kPfWgRows * kPfWgRows;
+            groups.push_back(g);
+        }
+    }
+    const size_t V = groups.size();
+    HIPCHK(ctx, ctx->d_cmp_h.ensure(std::max<long long>(1, cmp_rows) * kDim * 2));
+    HIPCHK(ctx, ctx->d_cmp_tu.ensure(std::max<long long>(1, cmp_rows) * 4));
+    HIPCHK(ctx, ctx->d_live_idx.ensure(std::max<long long>(1, cmp_rows) * 4));
+    HIPCHK(ctx, ctx->d_row_pair.ensure(std::max<long long>(1, cmp_rows) * 4));
+    std::vector<PairDesc>& vpairs = plan.vpairs;
+    std::vector<PfPair>& vpf = plan.vpf;
+    std::vector<GatherJob>& jobs = plan.jobs;
+    std::vector<CandList>& lists = plan.lists;
+    vpairs.assign(V, PairDesc{});
+    vpf.assign(V, PfPair{});
+    jobs.assign(members.size(), GatherJob{});
+    lists.assign(P + V, CandList{});
+    long long v_ablocks = 0;
+    for (size_t v = 0; v < V; ++v) v_ablocks += (groups[v].rows + kPfWgRows - 1) / kPfWgRows;
+    for (size_t p = 0; p < P; ++p) {
+        const PfPair& pp = b.pf[p];
+        lists[p] = CandList{(int)p, 0, pp.cand_off, (b.pairs[p].valid && pp.use && !compact[p]) ? pp.cand_cap : 0, 0, nullptr, nullptr};
+    }
+    std::vector<WorkItem> vlin;
+    for (size_t v = 0; v < V; ++v) {
+        const VGroup& g = groups[v];
+        const VMember& m0 = members[(size_t)g.first];
+        const PairDesc& pd = b.pairs[m0.pair];   // every member streams the same image: take its description from the first
+        const PfPair& pp = b.pf[m0.pair];
+        PairDesc& vd = vpairs[v];
+        PfPair& vp = vpf[v];
+        vd = PairDesc{};
+        vd.n1 = (int)g.rows;
+        vd.n2 = g.dir ? pd.n1 : pd.n2;
+        vd.a_blocks256 = (int)((g.rows + kPfWgRows - 1) / kPfWgRows);
+        vd.b_tiles = g.dir ? pd.a_blocks : pd.b_tiles;
+        vd.n1pad = vd.a_blocks256 * kPfWgRows;
+        vd.n2pad = g.dir ? pd.n1pad : pd.n2pad;
+        vd.valid = 1;
+        vd.path = 1;
+        vd.ranges = 1;
+        if (v_ablocks < 8LL * ctx->cu_count)
+            vd.ranges = (int)std::max<long long>(1, std::min<long long>((8LL * ctx->cu_count + v_ablocks - 1) / v_ablocks, vd.b_tiles));
+        vp = PfPair{};
+        vp.a_h = ctx->d_cmp_h.as<_Float16>() + (size_t)g.row0 * kDim;
+        vp.b_h = g.dir ? pp.a_h : pp.b_h;
+        vp.b_nrm = g.dir ? pp.a_nrm : pp.b_nrm;
+        vp.b_ext = g.dir ? pp.a_ext : pp.b_ext;
+        vp.b_c = g.dir ? pp.a_c : pp.b_c;
+        vp.a_c = g.dir ? pp.b_c : pp.a_c;
+        vp.tu_off = g.row0;
+        vp.cand_off = cand_elems;
+        vp.cand_cap = (int)std::min<long long>(8 * g.rows + 1024, 1LL << 30);
+        vp.use = 1;
+        cand_elems += vp.cand_cap;
+        for (int k = 0; k < g.count; ++k) {
+            const VMember& m = members[(size_t)(g.first + k)];
+            const PairDesc& mpd = b.pairs[m.pair];
+            const PfPair& mpp = b.pf[m.pair];
+            const bool last = k + 1 == g.count;
+            jobs[(size_t)(g.first + k)] = GatherJob{m.dir ? mpp.b_h : mpp.a_h, m.dir ? mpp.b_nrm : mpp.a_nrm,
+                                                    m.dir ? mpp.tv_off : mpp.tu_off, m.row,
+                                                    last ? g.row0 + (long long)vd.n1pad : m.row + m.cnt,
+                                                    m.dir ? mpd.n2 : mpd.n1, m.pair};
+        }
+        lists[P + v] = CandList{-1, 1 + g.dir, vp.cand_off, vp.cand_cap, 0, ctx->d_live_idx.as<int>() + g.row0,
+                                ctx->d_row_pair.as<int>() + g.row0};
+        for (int r = 0; r < vd.ranges; ++r) {
+            const int t0 = (int)((long long)vd.b_tiles * r / vd.ranges), t1 = (int)((long long)vd.b_tiles * (r + 1) / vd.ranges);
+            for (int ab = 0; ab < vd.a_blocks256; ++ab) vlin.push_back(WorkItem{(int)v, ab, t0, t1, r, {0, 0, 0}});
+        }
+        ctx->prof.sweep2_descriptor_pairs += (int64_t)vd.n1pad * vd.n2;
+    }
+    // dense items: the sweep-1 list minus the compacted pairs
+    std::vector<WorkItem> dlin;
+    for (const WorkItem& w : b.items)
+        if (w.pair >= 0 && !compact[w.pair]) dlin.push_back(w);
+    for (size_t p = 0; p < P; ++p)
+        if (b.pairs[p].valid && b.pf[p].use && !compact[p]) ctx->prof.sweep2_descriptor_pairs += (int64_t)b.pairs[p].n1pad * b.pairs[p].n2;
+    plan.ditems = dlin.empty() ? dlin : interleave_items(dlin);
+    plan.vitems = vlin.empty() ? vlin : interleave_items(vlin);
+    return MSFM_OK;
+}
+
+
 // MFMA prefilter + exact re-check for the pairs on path 1.  On return pairs whose candidate list
 // overflowed have been moved to path 0.
 //   sweep 1 (approx_kernel<1>): S~ minima per row / column -> thresholds (with pruning for match lists)
@@ -415,125 +559,18 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
     }
 
     // ---- sweep-2 descriptors -------------------------------------------------------------------
-    // Compacted sweeps are GROUPED: the live rows of every pair that streams the same image in the same
-    // direction are concatenated into one dense matrix (blocks are then full except for one tail per group;
-    // a pair's own ~300 live rows would fill its last 256-row block to a fifth).
-    struct VMember { int pair, dir, cnt; long long row; };
-    struct VGroup { const _Float16* b_h; int dir; int first, count; long long row0, rows; };
-    std::vector<VMember> members;
-    std::vector<VGroup> groups;
-    long long cmp_rows = 0, cand_elems = 0;
-    {
-        std::map<std::pair<const void*, int>, std::vector<VMember>> by_key;
-        std::vector<std::pair<const void*, int>> key_order;
-        for (size_t p = 0; p < P; ++p) {
-            PairDesc& pd = b.pairs[p];
-            PfPair& pp = b.pf[p];
-            if (!pd.valid || !pp.use) continue;
-            if (!compact[p]) {
-                pp.cand_off = cand_elems;
-                pp.cand_cap = 8 * (pd.n1 + pd.n2) + 1024;
-                cand_elems += pp.cand_cap;
-                continue;
-            }
-            for (int dir = 0; dir < 2; ++dir) {
-                const int cnt = live[2 * p + dir];
-                if (cnt == 0) continue;
-                const std::pair<const void*, int> key(dir ? (const void*)pp.a_h : (const void*)pp.b_h, dir);
-                auto it = by_key.find(key);
-                if (it == by_key.end()) {
-                    key_order.push_back(key);
-                    it = by_key.emplace(key, std::vector<VMember>()).first;
-                }
-                it->second.push_back(VMember{(int)p, dir, cnt, 0});
-            }
-        }
-        for (const auto& key : key_order) {
-            std::vector<VMember>& ms = by_key[key];
-            VGroup g{(const _Float16*)key.first, key.second, (int)members.size(), (int)ms.size(), cmp_rows, 0};
-            for (VMember& m : ms) {
-                m.row = cmp_rows + g.rows;
-                g.rows += m.cnt;
-                members.push_back(m);
-            }
-            cmp_rows += (g.rows + kPfWgRows - 1) / kPfWgRows * kPfWgRows;
-            groups.push_back(g);
-        }
-    }
-    const size_t V = groups.size();
-    HIPCHK(ctx, ctx->d_cmp_h.ensure(std::max<long long>(1, cmp_rows) * kDim * 2));
-    HIPCHK(ctx, ctx->d_cmp_tu.ensure(std::max<long long>(1, cmp_rows) * 4));
-    HIPCHK(ctx, ctx->d_live_idx.ensure(std::max<long long>(1, cmp_rows) * 4));
-    HIPCHK(ctx, ctx->d_row_pair.ensure(std::max<long long>(1, cmp_rows) * 4));
-    std::vector<PairDesc> vpairs(V);
-    std::vector<PfPair> vpf(V);
-    std::vector<GatherJob> jobs(members.size());
-    std::vector<CandList> lists(P + V);
-    long long v_ablocks = 0;
-    for (size_t v = 0; v < V; ++v) v_ablocks += (groups[v].rows + kPfWgRows - 1) / kPfWgRows;
-    for (size_t p = 0; p < P; ++p) {
-        const PfPair& pp = b.pf[p];
-        lists[p] = CandList{(int)p, 0, pp.cand_off, (b.pairs[p].valid && pp.use && !compact[p]) ? pp.cand_cap : 0, 0, nullptr, nullptr};
-    }
-    std::vector<WorkItem> vlin;
-    for (size_t v = 0; v < V; ++v) {
-        const VGroup& g = groups[v];
-        const VMember& m0 = members[(size_t)g.first];
-        const PairDesc& pd = b.pairs[m0.pair];   // every member streams the same image: take its description from the first
-        const PfPair& pp = b.pf[m0.pair];
-        PairDesc& vd = vpairs[v];
-        PfPair& vp = vpf[v];
-        vd = PairDesc{};
-        vd.n1 = (int)g.rows;
-        vd.n2 = g.dir ? pd.n1 : pd.n2;
-        vd.a_blocks256 = (int)((g.rows + kPfWgRows - 1) / kPfWgRows);
-        vd.b_tiles = g.dir ? pd.a_blocks : pd.b_tiles;
-        vd.n1pad = vd.a_blocks256 * kPfWgRows;
-        vd.n2pad = g.dir ? pd.n1pad : pd.n2pad;
-        vd.valid = 1;
-        vd.path = 1;
-        vd.ranges = 1;
-        if (v_ablocks < 8LL * ctx->cu_count)
-            vd.ranges = (int)std::max<long long>(1, std::min<long long>((8LL * ctx->cu_count + v_ablocks - 1) / v_ablocks, vd.b_tiles));
-        vp = PfPair{};
-        vp.a_h = ctx->d_cmp_h.as<_Float16>() + (size_t)g.row0 * kDim;
-        vp.b_h = g.dir ? pp.a_h : pp.b_h;
-        vp.b_nrm = g.dir ? pp.a_nrm : pp.b_nrm;
-        vp.b_ext = g.dir ? pp.a_ext : pp.b_ext;
-        vp.b_c = g.dir ? pp.a_c : pp.b_c;
-        vp.a_c = g.dir ? pp.b_c : pp.a_c;
-        vp.tu_off = g.row0;
-        vp.cand_off = cand_elems;
-        vp.cand_cap = (int)std::min<long long>(8 * g.rows + 1024, 1LL << 30);
-        vp.use = 1;
-        cand_elems += vp.cand_cap;
-        for (int k = 0; k < g.count; ++k) {
-            const VMember& m = members[(size_t)(g.first + k)];
-            const PairDesc& mpd = b.pairs[m.pair];
-            const PfPair& mpp = b.pf[m.pair];
-            const bool last = k + 1 == g.count;
-            jobs[(size_t)(g.first + k)] = GatherJob{m.dir ? mpp.b_h : mpp.a_h, m.dir ? mpp.b_nrm : mpp.a_nrm,
-                                                    m.dir ? mpp.tv_off : mpp.tu_off, m.row,
-                                                    last ? g.row0 + (long long)vd.n1pad : m.row + m.cnt,
-                                                    m.dir ? mpd.n2 : mpd.n1, m.pair};
-        }
-        lists[P + v] = CandList{-1, 1 + g.dir, vp.cand_off, vp.cand_cap, 0, ctx->d_live_idx.as<int>() + g.row0,
-                                ctx->d_row_pair.as<int>() + g.row0};
-        for (int r = 0; r < vd.ranges; ++r) {
-            const int t0 = (int)((long long)vd.b_tiles * r / vd.ranges), t1 = (int)((long long)vd.b_tiles * (r + 1) / vd.ranges);
-            for (int ab = 0; ab < vd.a_blocks256; ++ab) vlin.push_back(WorkItem{(int)v, ab, t0, t1, r, {0, 0, 0}});
-        }
-        ctx->prof.sweep2_descriptor_pairs += (int64_t)vd.n1pad * vd.n2;
-    }
-    // dense items: the sweep-1 list minus the compacted pairs
-    std::vector<WorkItem> dlin;
-    for (const WorkItem& w : b.items)
-        if (w.pair >= 0 && !compact[w.pair]) dlin.push_back(w);
-    for (size_t p = 0; p < P; ++p)
-        if (b.pairs[p].valid && b.pf[p].use && !compact[p]) ctx->prof.sweep2_descriptor_pairs += (int64_t)b.pairs[p].n1pad * b.pairs[p].n2;
-    const std::vector<WorkItem> ditems = dlin.empty() ? dlin : interleave_items(dlin);
-    const std::vector<WorkItem> vitems = vlin.empty() ? vlin : interleave_items(vlin);
-
+    Sweep2Plan plan;
+    rc = plan_sweep2(ctx, b, compact, live, plan);
+    if (rc != MSFM_OK) return rc;
+    const size_t V = plan.groups.size();
+    const std::vector<VMember>& members = plan.members;
+    const std::vector<VGroup>& groups = plan.groups;
+    const std::vector<PairDesc>& vpairs = plan.vpairs;
+    const std::vector<PfPair>& vpf = plan.vpf;
+    const std::vector<GatherJob>& jobs = plan.jobs;
+    const std::vector<CandList>& lists = plan.lists;
+    const std::vector<WorkItem>&ditems = plan.ditems, &vitems = plan.vitems;
+    const long long cand_elems = plan.cand_elems;
     HIPCHK(ctx, ctx->d_cand.ensure(std::max<long long>(1, cand_elems) * sizeof(int2)));
     HIPCHK(ctx, ctx->d_cand_s.ensure(std::max<long long>(1, cand_elems) * 4));
     HIPCHK(ctx, ctx->d_cand_pair.ensure(std::max<long long>(1, cand_elems) * 4));
