@@ -184,6 +184,9 @@ constexpr int kPfRing = 3;
 #ifndef MSFM_ABL
 #define MSFM_ABL 0
 #endif
+#ifndef MSFM_DMA_LATE
+#define MSFM_DMA_LATE 5
+#endif
 #ifndef MSFM_PIPE
 #define MSFM_PIPE 0    // 1: block-level software pipeline (experiment, see the loop)
 #endif
@@ -255,6 +258,11 @@ __global__ __launch_bounds__(kPfThreads, kPfRB <= 2 ? 2 : 1) void approx_kernel(
                                              (__attribute__((address_space(3))) void*)(thr_w + sl * 64), 4, 0, 0);
     };
     constexpr int kDmaOps = ((PASS == 2) ? 6 : 5) - (MSFM_ABL == 9 ? 2 : 0);
+    // where tile t+2's DMA pieces are issued in iteration t: 0 right after the barrier, 1 at the end of the iteration,
+    // 2 / 3 between / before the epilogues (MSFM_DMA_LATE: 4 = end of iteration in sweep 1 only; 5 = the default:
+    // before the epilogues in sweep 1 (-2.4 .. -4.7 %: among the epilogue's VALU work a 1-KiB piece costs the wave
+    // less than among the ds_reads and MFMAs right after the barrier), right after the barrier in sweep 2)
+    constexpr int kDmaLate = (MSFM_DMA_LATE == 4) ? (PASS == 1 ? 1 : 0) : (MSFM_DMA_LATE == 5) ? (PASS == 1 ? 3 : 0) : MSFM_DMA_LATE;
 
     dma_tile(t_begin);
     dma_tile(t_begin + 1);
@@ -615,7 +623,7 @@ __global__ __launch_bounds__(kPfThreads, kPfRB <= 2 ? 2 : 1) void approx_kernel(
             if (MSFM_ABL != 7 || ((t - t_begin) & 1) == 0)  // ablation 7: a barrier every other tile only (timing experiment)
             __builtin_amdgcn_s_barrier();  // every wave's part of tile t is in LDS; slot of tile t-1 is free
             asm volatile("" ::: "memory");
-            dma_tile(t + 2);
+            if (!kDmaLate) dma_tile(t + 2);
         }
         // tile t-2's column partials are complete in LDS (its epilogues ran before the previous barrier)
         if (PASS == 1 && t - t_begin >= 2 && wave == (t & 3)) merge_columns(t - 2);
@@ -667,7 +675,9 @@ __global__ __launch_bounds__(kPfThreads, kPfRB <= 2 ? 2 : 1) void approx_kernel(
             metaB.hc = (PASS == 2) ? -0.5f * thr[32 + lcol] : 0.f;
             metaB.col = t * kPfBT + 32 + lcol;
             metaB.cslot = (sl * 4 + wave) * 64 + 32;
+            if (kDmaLate == 3 && !kAblNoSync) dma_tile(t + 2);
             const bool anyA = epilogue_valu(accA, metaA, false);
+            if (kDmaLate == 2 && !kAblNoSync) dma_tile(t + 2);
             const bool anyB = epilogue_valu(accB, metaB, false);
             if (PASS == 1 && !kAblNoEpi) {
 #pragma unroll
@@ -680,6 +690,9 @@ __global__ __launch_bounds__(kPfThreads, kPfRB <= 2 ? 2 : 1) void approx_kernel(
                 append_hits(anyB, accB, metaB);
             }
         }
+        // the slot of tile t-1 has been free since this iteration's barrier; issuing the pieces here, after the
+        // epilogue's VALU work, is cheaper than among the ds_reads and MFMAs right after the barrier
+        if ((kDmaLate == 1 || (kDmaLate >= 2 && !wave_active)) && !kAblNoSync) dma_tile(t + 2);
     }
     }
     if (PASS >= 2) flush_candidates();
