@@ -184,6 +184,9 @@ constexpr int kPfRing = 3;
 #ifndef MSFM_ABL
 #define MSFM_ABL 0
 #endif
+#ifndef MSFM_MERGE_LATE
+#define MSFM_MERGE_LATE 0
+#endif
 #ifndef MSFM_DMA_LATE
 #define MSFM_DMA_LATE 5
 #endif
@@ -626,7 +629,7 @@ __global__ __launch_bounds__(kPfThreads, kPfRB <= 2 ? 2 : 1) void approx_kernel(
             if (!kDmaLate) dma_tile(t + 2);
         }
         // tile t-2's column partials are complete in LDS (its epilogues ran before the previous barrier)
-        if (PASS == 1 && t - t_begin >= 2 && wave == (t & 3)) merge_columns(t - 2);
+        if (!MSFM_MERGE_LATE && PASS == 1 && t - t_begin >= 2 && wave == (t & 3)) merge_columns(t - 2);
         const int sl = (t - t_begin) % kPfRing;
         const char* pb = sB + sl * kPfLdsB + lcol * kHalfRowBytes;
         const int pe_off = (int)(ext_w - pf_smem) + sl * kPfExtB;
@@ -693,6 +696,9 @@ __global__ __launch_bounds__(kPfThreads, kPfRB <= 2 ? 2 : 1) void approx_kernel(
         // the slot of tile t-1 has been free since this iteration's barrier; issuing the pieces here, after the
         // epilogue's VALU work, is cheaper than among the ds_reads and MFMAs right after the barrier
         if ((kDmaLate == 1 || (kDmaLate >= 2 && !wave_active)) && !kAblNoSync) dma_tile(t + 2);
+        // (the merge of tile t-2's column partials may run anywhere in iteration t; at the end it keeps the head of
+        // the iteration -- the first cycles after the barrier release -- free of VALU work)
+        if (MSFM_MERGE_LATE && PASS == 1 && t - t_begin >= 2 && wave == (t & 3)) merge_columns(t - 2);
     }
     }
     if (PASS >= 2) flush_candidates();
