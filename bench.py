@@ -4,20 +4,26 @@
   python bench.py --gpus N --steps K --warmup W
   (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-Workload (BASELINE.json configs[1]): South-Building-shaped job -- 128 images, ~5k 128-D float32
-RootSIFT-like descriptors each (seeded synthetic), brute-force all pairs
-(8128 image pairs, pre-emptive filter off), reference defaults ratio 0.8 / cross-check / 0.7.
-One "step" = the whole job: every pair through distance + kNN-2 both directions + ratio +
-cross-check + distance cut, match lists back on the host (and, for N > 1, all-gathered over RCCL).
-Descriptors are resident in HBM before the timed region.  The same total job is split over the
-ranks at N > 1 ("strong" scaling).
+Workload (BASELINE.json configs[1]): South-Building-shaped job -- 128 images, ~5k 128-D float32 RootSIFT-like
+descriptors each (seeded synthetic), brute-force all pairs (8128 image pairs, pre-emptive filter
+off), reference defaults ratio 0.8 / cross-check / 0.7.  One "step" = the whole job: every pair through distance +
+kNN-2 in both directions + ratio + cross-check + distance cut, with the match lists in host memory on the writer
+rank at the end (N > 1: per-pair counts all-reduced, the lists sent over RCCL from HBM to the writer).
+Descriptors are resident in HBM before the timed region.
 
-Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel (dist_top2_kernel), timed
-with HIP events on the library's own stream inside the timed region; `cpu_baseline` is the CPU
-oracle ("port": a restatement of the OpenCV BFMatcher path, not OpenCV itself) on a bounded
-sample of the same pairs, on this box's host cores.
+STRONG scaling: the SAME job at every N (the N = 1 line is the BENCH line); the pair list is cut into N contiguous
+cost-balanced ranges, the store is replicated.  `strong_u8` in the same JSON line is a second strong-scaling
+measurement on a seeded subset of BASELINE configs[3] (the 1329 x 8192 u8 job north_star names): `--u8-images`
+images (default 192) of the 1329, full per-image size -- large enough that per-rank work at N = 8 is tens of ms.
+`--workload synthetic-u8 --images 1329 --desc 8192` runs that job in full as the main workload.
+
+Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel (sweep 1 of the MFMA prefilter), timed with
+HIP events on the library's own stream inside the timed region; `cpu_baseline` is the CPU oracle ("port": a
+restatement of the OpenCV BFMatcher path, not OpenCV itself) on a bounded sample of the same pairs, on this box's
+host cores, parallel over image pairs.
 """
 import argparse
+import glob
 import json
 import os
 import sys
@@ -31,78 +37,69 @@ sys.path.insert(0, ROOT)
 FLOPS_PER_DESC_PAIR = 384.0   # 128 x (sub, mul, add), not fused (direct form)
 PEAK_FP32_VALU_TFLOPS = 157.3  # MI355X_MICROARCH.md: peak FP32 vector (FMA = 2 flop) = f32 MFMA rate
 PEAK_HBM_GBPS = 8000.0
-MEASURED_MFMA_TFLOPS = 4 * 256 * (2 * 32768) / 32.1e-9 / 1e12   # see roofline.measured_mfma_issue_ceiling
 PEAK_F16_MFMA_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16/f16 MFMA peak
+PEAK_I8_MFMA_TOPS = 5000.0      # dense int8 MFMA (2 x K of fp16)
 
 
 def pmc_traffic():
-    """HBM bytes per approx_kernel launch from the committed rocprofv3 PMC passes of this same command
-    (separate --pmc FETCH_SIZE / WRITE_SIZE runs, profiles/r01_pmc_traffic_approx.json): KB -> bytes, and
-    FETCH_SIZE doubled (gfx950 counts 128-byte requests as 64 B, MI355X_MICROARCH.md).  None if absent."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic_approx.json")
+    """HBM bytes per sweep-1 launch from the committed rocprofv3 PMC passes of this same command (separate --pmc
+    FETCH_SIZE / WRITE_SIZE runs; newest profiles/r*_pmc_traffic_approx.json): KB -> bytes, FETCH_SIZE doubled
+    (gfx950 counts 128-byte requests as 64 B, MI355X_MICROARCH.md).  None if absent."""
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic_approx.json")), reverse=True):
+        try:
+            d = json.load(open(path))
+            per = {n: 2.0 * k["FETCH_SIZE"]["per_launch_KB_mean"] * 1024 + k["WRITE_SIZE"]["per_launch_KB_mean"] * 1024
+                   for n, k in d.items()}
+            name = [n for n in per if n.startswith("approx_kernel<1>") or n.startswith("sweep1")][0]
+            return {"bytes_per_launch": per[name], "source": os.path.relpath(path, ROOT), "per_kernel_bytes": per}
+        except (OSError, KeyError, ValueError, IndexError):
+            continue
+    return None
+
+
+def opencv_found():
     try:
-        d = json.load(open(path))
-        per = {n: 2.0 * k["FETCH_SIZE"]["per_launch_KB_mean"] * 1024 + k["WRITE_SIZE"]["per_launch_KB_mean"] * 1024
-               for n, k in d.items()}
-        return {"bytes_per_launch": per["approx_kernel<1>"], "source": "profiles/r01_pmc_traffic_approx.json",
-                "per_kernel_bytes": per}
-    except (OSError, KeyError, ValueError):
-        return None
+        import cv2
+        return cv2.__version__
+    except Exception:
+        return False
 
 
-def build_workload(args, world=1):
-    from monocularsfm_amd import synth
-    rng = np.random.default_rng(args.seed)
-    if args.workload == "south-building":
-        # weak scaling: the image set grows with sqrt(world) so that every GPU keeps ~8128 image pairs
-        # (128 images at N=1 = BASELINE.json configs[1]; 181 / 256 / 362 images at N = 2 / 4 / 8)
-        n_images = args.images or int(round(128 * np.sqrt(world)))
-        counts = rng.integers(4600, 5401, n_images) if args.desc is None else np.full(n_images, args.desc)
-        imgs = synth.rootsift_images(n_images, counts.tolist(), seed=args.seed, n_proto=20000, sigma=0.05)
-        name = "south-building-shaped synthetic: %d images x ~%d f32 RootSIFT-like desc, brute-force all pairs" % (
-            n_images, int(np.mean(counts)))
-    elif args.workload == "synthetic-u8":
-        n_images = args.images or 64
-        nd = args.desc or 8192
-        imgs = synth.u8_images(n_images, nd, seed=args.seed, as_float=True)
-        name = "synthetic u8-valued: %d images x %d desc (f32-holding-integers), brute-force all pairs" % (n_images, nd)
-    else:
-        raise SystemExit("unknown workload " + args.workload)
-    pairs = np.array([(i, j) for i in range(n_images) for j in range(i)], np.int32)
-    return imgs, pairs, name
-
-
-def cpu_baseline(imgs, pairs, budget_s=20.0, max_pairs=256, seed=0):
-    """CPU oracle on a seeded sample of the same pairs, all host hardware threads."""
+def cpu_baseline(imgs, pairs, budget_s=20.0, max_pairs=1024, seed=0):
+    """CPU oracle on a seeded sample of the same pairs: one persistent pool over image pairs on all host threads
+    (orc_match_pairs_mt), plus the single-thread figure (how the reference itself runs: one pair after the other)."""
     from oracle import c_oracle as co
     co.build()
     threads = os.cpu_count() or 1
     rng = np.random.default_rng(seed)
     order = rng.permutation(len(pairs))
-    # calibrate on one pair, then size the sample to the budget
-    i, j = pairs[order[0]]
+    f32 = {}
+
+    def need(sel):
+        for i in np.unique(pairs[sel]):
+            if int(i) not in f32:
+                f32[int(i)] = np.ascontiguousarray(imgs[int(i)], dtype=np.float32)
+
+    def work(sel):
+        return int(sum(len(imgs[i]) * len(imgs[j]) for i, j in pairs[sel]))
+
+    # single thread: calibrates the sample size too
+    one = order[:1]
+    need(one)
     t0 = time.perf_counter()
-    co.match_pair(imgs[i], imgs[j], nthreads=threads)
-    t1 = time.perf_counter() - t0
-    n = int(max(4, min(max_pairs, budget_s / max(t1, 1e-4))))
-    sample = order[:n]
-    work = 0
-    t0 = time.perf_counter()
-    for p in sample:
-        i, j = pairs[p]
-        co.match_pair(imgs[i], imgs[j], nthreads=threads)
-        work += len(imgs[i]) * len(imgs[j])
-    dt = time.perf_counter() - t0
-    # single-thread figure on a few pairs (the reference's own code is single-threaded; OpenCV's
-    # batchDistance may fan out over its thread pool)
-    k = min(2, n)
-    t0 = time.perf_counter()
-    w1 = 0
-    for p in sample[:k]:
-        i, j = pairs[p]
-        co.match_pair(imgs[i], imgs[j], nthreads=1)
-        w1 += len(imgs[i]) * len(imgs[j])
+    co.match_pairs(f32, pairs[one], nthreads=1)
     dt1 = time.perf_counter() - t0
+    w1 = work(one)
+    single = w1 / dt1
+    # all threads: assume >= 0.5 x threads x single-thread to size a sample of roughly budget_s
+    n = int(max(threads, min(max_pairs, len(pairs), budget_s * single * 0.5 * threads / max(w1, 1))))
+    n = min(n, len(pairs))
+    sample = order[:n]
+    need(sample)
+    t0 = time.perf_counter()
+    offs, _, _, _ = co.match_pairs(f32, pairs[sample], nthreads=threads)
+    dt = time.perf_counter() - t0
+    w = work(sample)
     model = "unknown"
     try:
         for line in open("/proc/cpuinfo"):
@@ -112,10 +109,12 @@ def cpu_baseline(imgs, pairs, budget_s=20.0, max_pairs=256, seed=0):
     except OSError:
         pass
     return {
-        "value": work / dt, "unit": "descriptor-pairs/s", "cores": threads, "kind": "port",
-        "sample": "%d of %d image pairs (seeded), both kNN-2 sweeps + ratio + cross-check + distance cut per pair, "
-                  "%.1f s wall; restated CPU BFMatcher (SSE order, pthreads over query rows), not OpenCV" % (n, len(pairs), dt),
-        "image_pairs_per_s": n / dt, "single_thread_value": w1 / dt1, "cpu_model": model,
+        "value": w / dt, "unit": "descriptor-pairs/s", "cores": threads, "kind": "port",
+        "sample": "%d of %d image pairs (seeded), both kNN-2 sweeps + ratio + cross-check + distance cut per pair, %.1f s "
+                  "wall; restated CPU BFMatcher (SSE order), persistent pthread pool over image pairs, not OpenCV" % (n, len(pairs), dt),
+        "image_pairs_per_s": n / dt, "matches_in_sample": int(offs[-1]),
+        "single_thread_value": single, "parallel_efficiency": (w / dt) / (single * threads), "cpu_model": model,
+        "opencv_found": opencv_found(),
     }
 
 
@@ -124,7 +123,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="south-building")
+    ap.add_argument("--workload", default="south-building", choices=["south-building", "synthetic-u8"])
     ap.add_argument("--images", type=int, default=None)
     ap.add_argument("--desc", type=int, default=None)
     ap.add_argument("--seed", type=int, default=1234)
@@ -136,13 +135,16 @@ def main():
     ap.add_argument("--force-collectives", action="store_true",
                     help="run the RCCL exchange step even with one rank (sanity check of the multi-GPU path on a 1-GPU box)")
     ap.add_argument("--no-prefilter", action="store_true",
-                    help="brute-force exact-order kernel for every pair (same results, ~6x slower)")
+                    help="brute-force exact-order kernel for every pair (same results, ~20x slower)")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
+    ap.add_argument("--u8-images", type=int, default=192,
+                    help="images of the secondary strong-scaling job (subset of the 1329 x 8192 u8 config); 0 = skip")
+    ap.add_argument("--u8-steps", type=int, default=2)
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
-    from monocularsfm_amd import _lib
+    from monocularsfm_amd import _lib, synth
     from monocularsfm_amd.sharding import ShardedMatcher
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -159,7 +161,8 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     coll_dev = dev if args.backend == "nccl" else torch.device("cpu")   # where the collectives' tensors live
-    if world > 1 or args.force_collectives:
+    multi = world > 1 or args.force_collectives
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         if args.backend == "nccl":
@@ -167,69 +170,83 @@ def main():
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
 
-    imgs, pairs, wl_name = build_workload(args, world)
-    n_rows = np.array([len(x) for x in imgs], np.int64)
-    total_desc_pairs = int((n_rows[pairs[:, 0]] * n_rows[pairs[:, 1]]).sum())
-
-    ctx = _lib.Context(local_rank, order=args.order)
-    if args.no_prefilter:
-        ctx.set_prefilter(False)
-    t_up = time.perf_counter()
-    for i, im in enumerate(imgs):
-        ctx.upload_image(i, im)   # resident in HBM before the timed region
-    upload_s = time.perf_counter() - t_up   # host buffers -> HBM (PCIe) + the on-device layout / fp16 / norm passes
-    # the step ends with the match lists in host memory (the library's page-locked result buffers; "view" = no second copy)
-    sm = ShardedMatcher(ctx=ctx, device=coll_dev, force_collectives=args.force_collectives, fetch="view")
-
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    kern_ms, kern_launches, local_pairs_work = 0.0, 0, 0
-    pf_ms, pf_launches, pf_pairs_work, exact_pairs_work, cand, rows_work, fallback = 0.0, 0, 0, 0, 0, 0, 0
-    s2_ms, s2_launches, s2_pairs_work, compacted = 0.0, 0, 0, 0
-    algo_bytes_step = 0
-    result = None
-    for _ in range(args.warmup):
-        result = sm.match_to_writer(pairs, n_rows, dst=0, with_dist=False)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        result = sm.match_to_writer(pairs, n_rows, dst=0, with_dist=False)
-        p = ctx.profile()
-        kern_ms += p["dist_kernel_ms"]
-        kern_launches += p["dist_kernel_launches"]
-        local_pairs_work += p["descriptor_pairs"]
-        algo_bytes_step = p["dist_algo_bytes"]
-        pf_ms += p["approx_kernel_ms"]
-        pf_launches += p["approx_kernel_launches"]
-        pf_pairs_work += p["prefilter_descriptor_pairs"]
-        exact_pairs_work += p["exact_descriptor_pairs"]
-        cand += p["candidates"]
-        fallback += p["fallback_pairs"]
-        s2_ms += p["sweep2_ms"]
-        s2_launches += p["sweep2_launches"]
-        s2_pairs_work += p["sweep2_descriptor_pairs"]
-        compacted += p["compacted_pairs"]
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-    offs, qt, dd = result
-    n_matches = int(offs[-1])
-    rows_work = float((n_rows[pairs[:, 0]] + n_rows[pairs[:, 1]]).sum()) * args.steps / max(world, 1)
+    ctx = _lib.Context(local_rank, order=args.order)
+    if args.no_prefilter:
+        ctx.set_prefilter(False)
 
+    def run_job(imgs, pairs, steps, warmup, collect=None):
+        """Upload, W untimed + K timed steps; -> (seconds of the K steps: max over ranks, result of the last step,
+        upload seconds, per-rank [compute_ms, exchange_ms] means)."""
+        n_rows = np.array([len(x) for x in imgs], np.int64)
+        ctx.clear_images()
+        t_up = time.perf_counter()
+        for i, im in enumerate(imgs):
+            ctx.upload_image(i, im)   # resident in HBM before the timed region
+        upload_s = time.perf_counter() - t_up   # host buffers -> HBM (PCIe) + the on-device layout / fp16 / norm passes
+        sm = ShardedMatcher(ctx=ctx, device=coll_dev, force_collectives=args.force_collectives)
+
+        def step():
+            if not multi:
+                # one rank: the step ends with the lists in the library's page-locked host buffers ("view": no second copy)
+                t = time.perf_counter()
+                offs, qt, _ = ctx.match_pairs(pairs, fetch="view")
+                sm.last = {"compute_ms": (time.perf_counter() - t) * 1e3, "exchange_ms": 0.0}
+                return offs, qt, None
+            return sm.match_to_writer(pairs, n_rows, dst=0, with_dist=False)
+
+        result = None
+        for _ in range(warmup):
+            result = step()
+        barrier()
+        phases = np.zeros(2)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            result = step()
+            phases += (sm.last["compute_ms"], sm.last["exchange_ms"])
+            if collect is not None:
+                collect(ctx.profile())
+        barrier()
+        dt = time.perf_counter() - t0
+        per_rank = [(phases / steps).tolist()]
+        if world > 1:
+            t = torch.tensor([dt] + (phases / steps).tolist(), dtype=torch.float64, device=coll_dev)
+            allt = [torch.zeros_like(t) for _ in range(world)]
+            dist.all_gather(allt, t)
+            allt = torch.stack(allt).cpu().numpy()
+            dt = float(allt[:, 0].max())
+            per_rank = allt[:, 1:].tolist()
+        return dt, result, upload_s, per_rank, n_rows
+
+    # ---- main workload -----------------------------------------------------------------------------------------
+    imgs, pairs, wl_name = synth.job(args.workload, args.images, args.desc, seed=args.seed)
+    acc = {k: 0 for k in ("dist_kernel_ms", "dist_kernel_launches", "approx_kernel_ms", "approx_kernel_launches",
+                          "prefilter_descriptor_pairs", "exact_descriptor_pairs", "candidates", "fallback_pairs", "sweep2_ms",
+                          "sweep2_launches", "sweep2_descriptor_pairs", "compacted_pairs", "total_device_ms", "sub_batches")}
+    last_prof = {}
+
+    def collect(p):
+        for k in acc:
+            acc[k] += p[k]
+        last_prof.update(p)
+
+    dt, result, upload_s, per_rank, n_rows = run_job(imgs, pairs, args.steps, args.warmup, collect)
+    total_desc_pairs = int((n_rows[pairs[:, 0]] * n_rows[pairs[:, 1]]).sum())
+    offs = result[0]
+    n_matches = int(offs[-1])
     value = total_desc_pairs * args.steps / dt
+    u8_store = imgs[0].dtype == np.uint8
     out = {
         "metric": "descriptor-pairs/sec (and image-pairs/sec); match-index bit-parity vs CPU",
         "value": value, "unit": "descriptor-pairs/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "path": "brute-force exact fp32" if args.no_prefilter else "fp16 MFMA prefilter + exact fp32 re-check (bit-identical results)",
+        "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "path": "brute-force exact fp32" if args.no_prefilter else "MFMA prefilter + exact fp32 re-check (bit-identical results)",
         "image_pairs_per_s": len(pairs) * args.steps / dt,
         # not `value`: one-time store upload (PCIe + layout kernels) added to one step (which already
         # includes the result copy-out to host memory)
@@ -238,44 +255,55 @@ def main():
         "config": {"workload": wl_name, "image_pairs": int(len(pairs)), "descriptor_pairs_per_step": total_desc_pairs,
                    "matches_per_step": n_matches, "accum_order": "opencv-sse4x4-nofma" if args.order == 0 else "opencv-avx2-fma",
                    "ratio": 0.8, "cross_check": True, "max_distance": 0.7, "preemptive_filter": False,
-                   "parallelism": "image pairs sharded over %d GPU(s) (contiguous cost-balanced ranges, store replicated); "
-                                  "exchange = all_reduce of per-pair counts + gather of the (q, t) lists to the writer rank" % world},
+                   "parallelism": "the SAME job at every N: image pairs cut into %d contiguous cost-balanced range(s), store "
+                                  "replicated; exchange = all_reduce of per-pair counts + RCCL send of the (q, t) lists from HBM "
+                                  "to the writer rank" % world},
+        # this rank's view per step (ms): matcher call (sweeps + epilogue + copy into the send buffer) vs exchange
+        "per_rank_ms": [{"compute": c, "exchange": e} for c, e in per_rank],
+        "device_ms_per_step_rank0": acc["total_device_ms"] / args.steps,
+        "sub_batches_per_step": acc["sub_batches"] // max(1, args.steps),
     }
+    pf_ms, pf_launches = acc["approx_kernel_ms"], acc["approx_kernel_launches"]
     if pf_launches > 0:
-        # dominant kernel of the default path: approx_kernel<1> (MFMA fp16 32x32x16), sweep 1: every descriptor
-        # pair of the batch once.  Sweep 2 only revisits the rows / columns the ratio and distance tests left alive.
+        # dominant kernel of the default path: sweep 1 of the prefilter (every descriptor pair of the rank's range once).
+        # Sweep 2 only revisits the rows / columns the ratio and distance tests left alive.
+        i8 = bool(last_prof.get("sweep1_i8_launches", 0))
+        peak = PEAK_I8_MFMA_TOPS if i8 else PEAK_F16_MFMA_TFLOPS
+        pf_pairs_work = acc["prefilter_descriptor_pairs"]
         avg_ms = pf_ms / pf_launches
         flops = 256.0 * pf_pairs_work   # GEMM form: 128 x (mul, add) per descriptor pair
         achieved = flops / (pf_ms * 1e-3) / 1e12
         tr = pmc_traffic()
+        algo_bytes_step = last_prof.get("dist_algo_bytes", 0)
+        rows_work = float((n_rows[pairs[:, 0]] + n_rows[pairs[:, 1]]).sum()) * args.steps / max(world, 1)
         out["roofline"] = {
-            "kernel": "approx_kernel<1> (MFMA prefilter sweep 1; sweep 2 and the exact fp32 re-check only touch survivors)",
-            "bound": "mfma", "achieved": achieved, "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": achieved / PEAK_F16_MFMA_TFLOPS,
-            # a loop of nothing but independent v_mfma_f32_32x32x16_f16 sustains 2 MFMA / 32.1 ns per SIMD on this part
-            # (profiles/r01_ubench_mfma_valu.txt): 2.09 PFLOP/s, not the 2.5 of the data sheet
-            "measured_mfma_issue_ceiling": MEASURED_MFMA_TFLOPS, "frac_of_measured_ceiling": achieved / MEASURED_MFMA_TFLOPS,
+            "kernel": "sweep 1 of the MFMA prefilter (%s); sweep 2 and the exact fp32 re-check only touch survivors"
+                      % ("v_mfma_i32_32x32x32_i8" if i8 else "v_mfma_f32_32x32x16_f16"),
+            "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TOP/s" if i8 else "TFLOP/s",
+            "frac": achieved / peak,
             "traffic": tr["bytes_per_launch"] if tr else None, "traffic_unit": "HBM bytes/launch (PMC)", "traffic_detail": tr,
             "avg_launch_ms": avg_ms, "launches": pf_launches, "flops_per_desc_pair": 256.0,
             "descriptor_pairs_per_launch": pf_pairs_work / pf_launches,
             "algorithmic_bytes_per_launch": algo_bytes_step * args.steps / pf_launches,
-            "sweep2": {"ms_per_step": s2_ms / args.steps, "launches": s2_launches, "compacted_image_pairs": compacted // max(1, args.steps),
-                       "work_fraction_of_sweep1": s2_pairs_work / max(1, pf_pairs_work)},
+            "sweep2": {"ms_per_step": acc["sweep2_ms"] / args.steps, "launches": acc["sweep2_launches"],
+                       "compacted_image_pairs": acc["compacted_pairs"] // max(1, args.steps),
+                       "work_fraction_of_sweep1": acc["sweep2_descriptor_pairs"] / max(1, pf_pairs_work)},
             "sweep1_ms_per_step": pf_ms / args.steps,
-            "candidates_per_row": cand / max(1.0, rows_work),
-            "fallback_pairs": fallback,
+            "step_over_sweep1": (dt / args.steps * 1e3) / max(1e-9, pf_ms / args.steps),
+            "candidates_per_row": acc["candidates"] / max(1.0, rows_work),
+            "fallback_pairs": acc["fallback_pairs"],
             "hbm": {"algorithmic_bytes_per_step": algo_bytes_step,
                     "achieved_GBps": (algo_bytes_step * args.steps / (pf_ms * 1e-3)) / 1e9, "peak_GBps": PEAK_HBM_GBPS,
                     "frac": (algo_bytes_step * args.steps / (pf_ms * 1e-3)) / 1e9 / PEAK_HBM_GBPS},
         }
-    if kern_launches > 0:
-        avg_ms = kern_ms / kern_launches
-        flops_per_launch = FLOPS_PER_DESC_PAIR * exact_pairs_work / kern_launches
+    if acc["dist_kernel_launches"] > 0:
+        avg_ms = acc["dist_kernel_ms"] / acc["dist_kernel_launches"]
+        flops_per_launch = FLOPS_PER_DESC_PAIR * acc["exact_descriptor_pairs"] / acc["dist_kernel_launches"]
         achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
         exact = {
             "kernel": "dist_top2_kernel (brute-force exact-order path)", "bound": "valu", "achieved": achieved,
             "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_VALU_TFLOPS, "traffic": None,
-            "avg_launch_ms": avg_ms, "launches": kern_launches, "flops_per_desc_pair": FLOPS_PER_DESC_PAIR,
+            "avg_launch_ms": avg_ms, "launches": acc["dist_kernel_launches"], "flops_per_desc_pair": FLOPS_PER_DESC_PAIR,
             "note": "384 unfusable sub/mul/add per descriptor pair: 78.6 TFLOP/s (half the FMA peak) is the "
                     "attainable ceiling; frac_of_nofma_ceiling reports against that",
             "frac_of_nofma_ceiling": achieved / (PEAK_FP32_VALU_TFLOPS / 2),
@@ -284,6 +312,29 @@ def main():
             out["roofline_exact_path"] = exact
         else:
             out["roofline"] = exact
+
+    # ---- secondary strong-scaling job: a subset of the 1329 x 8192 u8 config -------------------------------------
+    if args.u8_images > 1 and args.workload == "south-building" and not args.no_prefilter:
+        u_imgs, u_pairs, u_name = synth.job("synthetic-u8", args.u8_images, 8192, seed=1329)
+        u_acc = {"approx_kernel_ms": 0.0, "prefilter_descriptor_pairs": 0, "sweep1_i8_launches": 0}
+
+        def u_collect(p):
+            for k in u_acc:
+                u_acc[k] += p.get(k, 0)
+
+        u_dt, u_res, _, u_per_rank, u_rows = run_job(u_imgs, u_pairs, args.u8_steps, 1, u_collect)
+        u_total = int((u_rows[u_pairs[:, 0]] * u_rows[u_pairs[:, 1]]).sum())
+        i8 = u_acc["sweep1_i8_launches"] > 0
+        u_ach = 256.0 * u_acc["prefilter_descriptor_pairs"] / max(1e-9, u_acc["approx_kernel_ms"] * 1e-3) / 1e12
+        out["strong_u8"] = {
+            "workload": u_name + " (seeded subset of BASELINE configs[3]: %d of 1329 images, full per-image size)" % args.u8_images,
+            "value": u_total * args.u8_steps / u_dt, "unit": "descriptor-pairs/s", "ms_per_step": u_dt / args.u8_steps * 1e3,
+            "steps": args.u8_steps, "image_pairs": int(len(u_pairs)), "matches_per_step": int(u_res[0][-1]),
+            "per_rank_ms": [{"compute": c, "exchange": e} for c, e in u_per_rank],
+            "sweep1": {"instruction": "v_mfma_i32_32x32x32_i8" if i8 else "v_mfma_f32_32x32x16_f16", "achieved": u_ach,
+                       "frac": u_ach / (PEAK_I8_MFMA_TOPS if i8 else PEAK_F16_MFMA_TFLOPS)},
+            "full_config_seconds_at_this_rate": 882456 * 8192.0 * 8192.0 / (u_total * args.u8_steps / u_dt),
+        }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(imgs, pairs, budget_s=args.cpu_budget)
         out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]

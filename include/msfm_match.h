@@ -81,6 +81,8 @@ typedef struct msfm_profile {
     int compacted_pairs;       /* pairs whose sweep 2 ran on the compacted live rows only */
     int64_t sweep2_descriptor_pairs; /* descriptor pairs sweep 2 actually multiplied (padded rows included) */
     double verify_ms;          /* geometric verification kernels (msfm_match_pairs_verified) */
+    int sub_batches;           /* device sub-batches the call was cut into (msfm_set_limits) */
+    int tie_queue_regrows;     /* sub-batches re-run because the sqrt-space tie queue had to grow */
 } msfm_profile;
 
 /* ---- context ------------------------------------------------------------------------- */
@@ -94,6 +96,12 @@ int msfm_set_accum_order(msfm_ctx* ctx, int order);
  * Results are bit-identical either way. */
 int msfm_set_prefilter(msfm_ctx* ctx, int enable);
 int msfm_get_profile(const msfm_ctx* ctx, msfm_profile* out);
+/* msfm_match_pairs cuts a call into device sub-batches of at most `max_pairs_per_batch` image pairs and
+ * `scratch_bytes` of partial-result scratch (defaults 16384 pairs / 48 GiB; also MSFM_MAX_PAIRS_PER_BATCH and
+ * MSFM_SCRATCH_MIB in the environment at msfm_create).  Results do not depend on the cut (tests force small limits
+ * to cross it); a value <= 0 restores that default.  The reference's counterpart is the 100-pair flush of
+ * BruteFeatureMatcher::RunMatching (src/Feature/FeatureMatching.cpp:118-139, max_pairs_size_). */
+int msfm_set_limits(msfm_ctx* ctx, int max_pairs_per_batch, int64_t scratch_bytes);
 
 /* ---- descriptor store -------------------------------------------------------------------
  * Replaces the per-pair Database::ReadDescriptors calls of MatchImagePairs
@@ -132,6 +140,10 @@ int msfm_fetch_matches(msfm_ctx* ctx, int32_t* out_qt, float* out_dist);
 /* The same lists without the copy: pointers into the context's page-locked result buffers
  * (2 * count int32, count float), valid until the next matching call on this context or msfm_destroy. */
 int msfm_view_matches(msfm_ctx* ctx, const int32_t** out_qt, const float** out_dist, int64_t* out_count);
+/* The same lists copied device-to-device into CALLER-OWNED DEVICE memory on the context's GPU (2 * count int32 /
+ * count float; either pointer may be NULL): the multi-GPU exchange step sends them over RCCL straight from HBM
+ * instead of staging them through the host.  Complete when the call returns. */
+int msfm_fetch_matches_device(msfm_ctx* ctx, int32_t* d_out_qt, float* d_out_dist);
 
 /* ---- batch of pairs with the geometric verification hand-off -------------------------------
  * Lines 36-60 of FeatureMatching.cpp in one call: matching as above, then FeatureUtils::FilterMatches

@@ -22,7 +22,7 @@ EXPORTS = [
     "msfm_get_profile", "msfm_upload_image", "msfm_image_rows", "msfm_clear_images",
     "msfm_match_pair", "msfm_match_pairs", "msfm_fetch_matches", "msfm_knn2_pair",
     "msfm_topscale_select", "msfm_pair_id", "msfm_pair_from_id", "msfm_swap_image_pair",
-    "msfm_version", "msfm_upload_keypoints", "msfm_match_pairs_verified", "msfm_subset_image", "msfm_view_matches",
+    "msfm_version", "msfm_upload_keypoints", "msfm_match_pairs_verified", "msfm_subset_image", "msfm_view_matches", "msfm_set_limits", "msfm_fetch_matches_device",
 ]
 
 
@@ -42,7 +42,8 @@ class Profile(C.Structure):
                 ("candidates", C.c_int64), ("prefilter_descriptor_pairs", C.c_int64),
                 ("exact_descriptor_pairs", C.c_int64), ("tie_rows", C.c_int64),
                 ("sweep2_ms", C.c_double), ("sweep2_launches", C.c_int), ("compacted_pairs", C.c_int),
-                ("sweep2_descriptor_pairs", C.c_int64), ("verify_ms", C.c_double)]
+                ("sweep2_descriptor_pairs", C.c_int64), ("verify_ms", C.c_double),
+                ("sub_batches", C.c_int), ("tie_queue_regrows", C.c_int)]
 
 
 class MsfmError(RuntimeError):
@@ -74,6 +75,7 @@ def load():
     L.msfm_set_accum_order.argtypes = [vp, C.c_int]
     L.msfm_set_prefilter.argtypes = [vp, C.c_int]
     L.msfm_get_profile.argtypes = [vp, C.POINTER(Profile)]
+    L.msfm_set_limits.argtypes = [vp, C.c_int, C.c_int64]
     L.msfm_upload_image.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int]
     L.msfm_image_rows.argtypes = [vp, C.c_int, C.POINTER(C.c_int)]
     L.msfm_subset_image.argtypes = [vp, C.c_int, C.c_int, ip, C.c_int]
@@ -82,6 +84,7 @@ def load():
     L.msfm_match_pairs.argtypes = [vp, ip, C.c_int, C.POINTER(MatchParams), C.POINTER(C.c_int64)]
     L.msfm_fetch_matches.argtypes = [vp, ip, fp]
     L.msfm_view_matches.argtypes = [vp, C.POINTER(ip), C.POINTER(fp), C.POINTER(C.c_int64)]
+    L.msfm_fetch_matches_device.argtypes = [vp, vp, vp]
     L.msfm_upload_keypoints.argtypes = [vp, C.c_int, fp, C.c_int, C.c_int]
     L.msfm_match_pairs_verified.argtypes = [vp, ip, C.c_int, C.POINTER(MatchParams), C.POINTER(VerifyParams),
                                             C.POINTER(C.c_int64)]
@@ -152,6 +155,10 @@ class Context:
     def set_prefilter(self, enable):
         """True (default): MFMA prefilter + exact re-check; False: brute-force exact kernel only."""
         self._chk(self._L.msfm_set_prefilter(self._h, int(bool(enable))))
+
+    def set_limits(self, max_pairs_per_batch=0, scratch_bytes=0):
+        """Sub-batch limits of match_pairs (<= 0: default).  Results do not depend on them."""
+        self._chk(self._L.msfm_set_limits(self._h, int(max_pairs_per_batch), int(scratch_bytes)))
 
     def profile(self):
         p = Profile()
@@ -224,6 +231,11 @@ class Context:
         d = np.empty(max(M, 1), np.float32)
         self._chk(self._L.msfm_fetch_matches(self._h, _ip(qt), _fp(d)))
         return offs, qt[:M], d[:M]
+
+    def fetch_matches_device(self, qt_ptr, dist_ptr=None):
+        """Copy the last call's lists into caller-owned DEVICE memory on this context's GPU (raw pointers, e.g.
+        torch.Tensor.data_ptr() of an int32 [M, 2] / float32 [M] tensor; None skips one)."""
+        self._chk(self._L.msfm_fetch_matches_device(self._h, C.c_void_p(qt_ptr or 0), C.c_void_p(dist_ptr or 0)))
 
     def upload_keypoints(self, image_id, kpts):
         """kpts: n x k float32 (k >= 2), x and y in the first two columns."""

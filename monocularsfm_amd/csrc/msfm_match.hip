@@ -39,6 +39,26 @@ struct DevBuf {
         if (e == hipSuccess) cap = want;
         return e;
     }
+    // grow and keep the first `keep` bytes (the match lists of a call accumulate over its sub-batches)
+    hipError_t ensure_keep(size_t bytes, size_t keep, hipStream_t stream) {
+        if (bytes <= cap) return hipSuccess;
+        const size_t want = bytes + bytes / 2 + 4096;
+        void* q = nullptr;
+        hipError_t e = hipMalloc(&q, want);
+        if (e != hipSuccess) return e;
+        if (p && keep) {
+            e = hipMemcpyAsync(q, p, keep, hipMemcpyDeviceToDevice, stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(stream);
+            if (e != hipSuccess) {
+                (void)hipFree(q);
+                return e;
+            }
+        }
+        if (p) (void)hipFree(p);
+        p = q;
+        cap = want;
+        return hipSuccess;
+    }
     void release() {
         if (p) (void)hipFree(p);
         p = nullptr;
@@ -99,7 +119,10 @@ void free_image(Image& im) {
     im = Image{};
 }
 
-constexpr int kSlots = 2 * MSFM_MAX_IMAGES;  // ids >= MSFM_MAX_IMAGES: auxiliary (top-scale subsets)
+constexpr int kSlots = 2 * MSFM_MAX_IMAGES + 2;  // ids >= MSFM_MAX_IMAGES: auxiliary (top-scale subsets, two operator-level scratch slots)
+// sub-batches of msfm_match_pairs are bounded by the partial-result scratch (4-byte units: ~48 GiB of the 288 GB) and a pair count
+constexpr long long kDefaultScratchElems = (long long)12 << 30;
+constexpr int kDefaultMaxPairsPerBatch = 16384;
 
 }  // namespace
 
@@ -117,6 +140,11 @@ struct msfm_ctx {
     DevBuf d_k_i0, d_k_d0, d_k_d1;
     DevBuf d_st_qt, d_st_d, d_counts, d_offsets, d_out_qt, d_out_d;
     DevBuf d_fix_count, d_fix_list;
+    int fix_cap = 1 << 16;            // entries of the sqrt-space tie queue; grows on overflow (the sub-batch is re-run)
+    int fix_cap_eff = 0;              // capacity handed to the kernels of the current batch (0: ties need no fix-up)
+    // sub-batch limits of msfm_match_pairs (msfm_set_limits / MSFM_MAX_PAIRS_PER_BATCH / MSFM_SCRATCH_MIB)
+    int max_pairs_per_batch = kDefaultMaxPairsPerBatch;
+    long long scratch_elems = kDefaultScratchElems;
     // prefilter path
     int prefilter = 1;
     DevBuf d_pf, d_tu, d_tv, d_cand, d_cand_s, d_cand_count, d_best, d_second, d_maxima;
@@ -150,7 +178,6 @@ int fail(msfm_ctx* ctx, int code, const std::string& msg) {
                         std::string(#call) + ": " + hipGetErrorString(e__));                  \
     } while (0)
 
-constexpr int kFixCap = 1 << 16;
 
 // MSFM_DEBUG_TIMING=1: host-side wall clock of the orchestration phases of each batch on stderr
 struct HostClock {
@@ -650,7 +677,7 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
     }
     hipLaunchKernelGGL(pf_finalize_kernel, mgrid, dim3(256), 0, ctx->stream, dp, dpf, (const float*)tuv, ctx->d_best.as<unsigned long long>(),
                        ctx->d_second.as<unsigned long long>(), ctx->d_k_i0.as<int>(), ctx->d_k_d0.as<float>(),
-                       ctx->d_k_d1.as<float>(), ctx->d_fix_count.as<int>(), ctx->d_fix_list.as<int4>(), kFixCap);
+                       ctx->d_k_d1.as<float>(), ctx->d_fix_count.as<int>(), ctx->d_fix_list.as<int4>(), ctx->fix_cap_eff);
     HIPCHK(ctx, hipGetLastError());
     DBGSYNC(ctx, "pf_finalize_kernel");
 
@@ -731,21 +758,25 @@ int run_exact(msfm_ctx* ctx, Batch& b, size_t ev_base) {
                        ctx->d_rp_s0.as<float>(), ctx->d_rp_i0.as<int>(), ctx->d_rp_s1.as<float>(),
                        ctx->d_cp_s0.as<float>(), ctx->d_cp_i0.as<int>(), ctx->d_cp_s1.as<float>(),
                        ctx->d_k_i0.as<int>(), ctx->d_k_d0.as<float>(), ctx->d_k_d1.as<float>(),
-                       ctx->d_fix_count.as<int>(), ctx->d_fix_list.as<int4>(), kFixCap);
+                       ctx->d_fix_count.as<int>(), ctx->d_fix_list.as<int4>(), ctx->fix_cap_eff);
     HIPCHK(ctx, hipGetLastError());
     return MSFM_OK;
 }
 
 // kNN-2 of both directions for every pair of the batch (device arrays left in the ctx buffers):
 // prefilter path where eligible, brute-force exact path for the rest, then the sqrt-space tie fix-up
-int run_knn(msfm_ctx* ctx, Batch& b, size_t ev_base, bool* exact_launched, PruneParams prune) {
+//   need_fix: the caller can observe WHICH index a sqrt-space tie resolves to (knnMatch-level API, ratio > 1).
+//   For match lists with ratio <= 1 a row with d0 == d1 fails `d0 < ratio * d1` in both directions, so its
+//   index never reaches a list: the queue is not filled and nothing is re-scanned.
+int run_knn(msfm_ctx* ctx, Batch& b, size_t ev_base, bool* exact_launched, PruneParams prune, bool need_fix) {
     assign_common(b);
+    ctx->fix_cap_eff = need_fix ? ctx->fix_cap : 0;
     const long long kn = std::max<long long>(1, b.kf_elems + b.kr_elems);
     HIPCHK(ctx, ctx->d_k_i0.ensure(kn * 4));
     HIPCHK(ctx, ctx->d_k_d0.ensure(kn * 4));
     HIPCHK(ctx, ctx->d_k_d1.ensure(kn * 4));
     HIPCHK(ctx, ctx->d_fix_count.ensure(4));
-    HIPCHK(ctx, ctx->d_fix_list.ensure((size_t)kFixCap * sizeof(int4)));
+    HIPCHK(ctx, ctx->d_fix_list.ensure((size_t)ctx->fix_cap * sizeof(int4)));
     HIPCHK(ctx, hipMemsetAsync(ctx->d_fix_count.p, 0, 4, ctx->stream));
     bool any_pf = false, any_exact = false;
     for (auto& pd : b.pairs) any_pf |= (pd.valid && pd.path == 1);
@@ -767,11 +798,11 @@ int run_knn(msfm_ctx* ctx, Batch& b, size_t ev_base, bool* exact_launched, Prune
     if (any_pf || any_exact) {
         if (ctx->order == MSFM_ORDER_SSE4X4)
             hipLaunchKernelGGL(tie_fixup_kernel<0>, dim3(256), dim3(64), 0, ctx->stream, ctx->d_pairs.as<PairDesc>(),
-                               ctx->d_fix_count.as<int>(), ctx->d_fix_list.as<int4>(), kFixCap,
+                               ctx->d_fix_count.as<int>(), ctx->d_fix_list.as<int4>(), ctx->fix_cap_eff,
                                ctx->d_k_i0.as<int>(), ctx->d_k_d0.as<float>());
         else
             hipLaunchKernelGGL(tie_fixup_kernel<1>, dim3(256), dim3(64), 0, ctx->stream, ctx->d_pairs.as<PairDesc>(),
-                               ctx->d_fix_count.as<int>(), ctx->d_fix_list.as<int4>(), kFixCap,
+                               ctx->d_fix_count.as<int>(), ctx->d_fix_list.as<int4>(), ctx->fix_cap_eff,
                                ctx->d_k_i0.as<int>(), ctx->d_k_d0.as<float>());
         HIPCHK(ctx, hipGetLastError());
     }
@@ -780,13 +811,21 @@ int run_knn(msfm_ctx* ctx, Batch& b, size_t ev_base, bool* exact_launched, Prune
     return MSFM_OK;
 }
 
-int check_fix_overflow(msfm_ctx* ctx) {
+// Synchronises the stream.  *retry = true: more tied rows than the queue holds -- the queue has been grown to
+// fit, the caller re-runs the batch (rare: duplicate descriptors on the brute-force path with ratio > 1 or
+// through the knnMatch-level API).
+int check_fix_overflow(msfm_ctx* ctx, bool* retry) {
     int nfix = 0;
+    *retry = false;
     HIPCHK(ctx, hipMemcpyAsync(&nfix, ctx->d_fix_count.p, 4, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->fix_cap_eff > 0 && nfix > ctx->fix_cap_eff) {
+        ctx->fix_cap = nfix + nfix / 8 + 1024;
+        ctx->prof.tie_queue_regrows += 1;
+        *retry = true;
+        return MSFM_OK;
+    }
     ctx->prof.tie_rows += nfix;
-    if (nfix > kFixCap)
-        return fail(ctx, MSFM_E_CAPACITY, "tie fix-up list overflow (" + std::to_string(nfix) + " tied rows in one batch)");
     return MSFM_OK;
 }
 
@@ -857,6 +896,10 @@ int msfm_create(int device_ordinal, msfm_ctx** out_ctx) {
         return MSFM_E_DEVICE;
     }
     if (const char* e = std::getenv("MSFM_PREFILTER")) ctx->prefilter = (e[0] != '0');
+    if (const char* e = std::getenv("MSFM_MAX_PAIRS_PER_BATCH"))
+        if (std::atoi(e) > 0) ctx->max_pairs_per_batch = std::atoi(e);
+    if (const char* e = std::getenv("MSFM_SCRATCH_MIB"))
+        if (std::atoll(e) > 0) ctx->scratch_elems = std::atoll(e) * (1 << 20) / 4;
     *out_ctx = ctx;
     return MSFM_OK;
 }
@@ -916,6 +959,13 @@ int msfm_set_accum_order(msfm_ctx* ctx, int order) {
 int msfm_set_prefilter(msfm_ctx* ctx, int enable) {
     if (!ctx) return MSFM_E_INVALID;
     ctx->prefilter = enable ? 1 : 0;
+    return MSFM_OK;
+}
+
+int msfm_set_limits(msfm_ctx* ctx, int max_pairs_per_batch, int64_t scratch_bytes) {
+    if (!ctx) return MSFM_E_INVALID;
+    ctx->max_pairs_per_batch = max_pairs_per_batch > 0 ? max_pairs_per_batch : kDefaultMaxPairsPerBatch;
+    ctx->scratch_elems = scratch_bytes > 0 ? std::max<long long>(1, scratch_bytes / 4) : kDefaultScratchElems;
     return MSFM_OK;
 }
 
@@ -1073,16 +1123,19 @@ static int match_pairs_impl(msfm_ctx* ctx, const int32_t* pairs, int n_pairs, co
     if (!ev_begin || !ev_end) return fail(ctx, MSFM_E_DEVICE, "hipEventCreate failed");
     HIPCHK(ctx, hipEventRecord(ev_begin, ctx->stream));
 
-    // sub-batches bounded by the partial-result scratch (12 B per partial entry)
-    const long long kScratchElems = (long long)12 << 30;  // ~48 GiB of scratch (4-byte units) at most, of 288 GB HBM
-    const int kMaxPairsPerBatch = 16384;
+    // sub-batches bounded by the partial-result scratch (12 B per partial entry) and a pair count
+    const long long kScratchElems = ctx->scratch_elems;
+    const int kMaxPairsPerBatch = ctx->max_pairs_per_batch;
+    // a tie in sqrt space can only surface in a match list when a row with d0 == d1 can pass the ratio test
+    const bool need_fix = !(prm.ratio <= 1.f);
     size_t ev_next = 2;
-    std::vector<size_t> ev_of_batch;
     int begin = 0;
     while (begin < n_pairs) {
+      int end = begin;
+      for (int attempt = 0;; ++attempt) {   // a sub-batch is re-run when its tie queue was too small (grown by then)
         Batch b;
         long long est = 0;
-        int end = begin;
+        end = begin;
         while (end < n_pairs && (end - begin) < kMaxPairsPerBatch) {
             PairDesc pd;
             PfPair pp;
@@ -1106,15 +1159,18 @@ static int match_pairs_impl(msfm_ctx* ctx, const int32_t* pairs, int n_pairs, co
         }
         const size_t P = b.pairs.size();
         const size_t ev_base = ev_next;
-        ev_next += 8;
+        if (attempt == 0) ev_next += 8;
         bool exact_launched = false;
-        int rc = run_knn(ctx, b, ev_base, &exact_launched, prune);
+        int rc = run_knn(ctx, b, ev_base, &exact_launched, prune, need_fix);
         if (rc != MSFM_OK) return rc;
 
         HIPCHK(ctx, ctx->d_st_qt.ensure(std::max<long long>(1, b.out_elems) * sizeof(int2)));
         HIPCHK(ctx, ctx->d_st_d.ensure(std::max<long long>(1, b.out_elems) * 4));
-        HIPCHK(ctx, ctx->d_out_qt.ensure(std::max<long long>(1, b.out_elems) * sizeof(int2)));
-        HIPCHK(ctx, ctx->d_out_d.ensure(std::max<long long>(1, b.out_elems) * 4));
+        // the lists of the whole call stay on the device too (msfm_fetch_matches_device): this sub-batch appends
+        // at most out_elems matches behind the res_count already there
+        const size_t base = ctx->res_count;
+        HIPCHK(ctx, ctx->d_out_qt.ensure_keep((base + (size_t)std::max<long long>(1, b.out_elems)) * sizeof(int2), base * sizeof(int2), ctx->stream));
+        HIPCHK(ctx, ctx->d_out_d.ensure_keep((base + (size_t)std::max<long long>(1, b.out_elems)) * 4, base * 4, ctx->stream));
         HIPCHK(ctx, ctx->d_counts.ensure(P * 4));
         HIPCHK(ctx, ctx->d_offsets.ensure((P + 1) * 8));
         EpiParams ep = {prm.ratio, prm.cross_check, prm.max_distance};
@@ -1176,21 +1232,23 @@ static int match_pairs_impl(msfm_ctx* ctx, const int32_t* pairs, int n_pairs, co
         HIPCHK(ctx, hipGetLastError());
         hipLaunchKernelGGL(gather_kernel, dim3((unsigned)P), dim3(256), 0, ctx->stream, ctx->d_pairs.as<PairDesc>(),
                            d_counts, ctx->d_offsets.as<long long>(), d_st_qt,
-                           d_st_d, ctx->d_out_qt.as<int2>(), ctx->d_out_d.as<float>());
+                           d_st_d, ctx->d_out_qt.as<int2>() + base, ctx->d_out_d.as<float>() + base);
         HIPCHK(ctx, hipGetLastError());
 
         std::vector<long long> offs(P + 1);
         HIPCHK(ctx, hipMemcpyAsync(offs.data(), ctx->d_offsets.p, (P + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
-        rc = check_fix_overflow(ctx);  // synchronises the stream
+        bool retry = false;
+        rc = check_fix_overflow(ctx, &retry);  // synchronises the stream
         if (rc != MSFM_OK) return rc;
+        if (retry && attempt < 4) continue;
+        if (retry) return fail(ctx, MSFM_E_DEVICE, "tie fix-up queue kept overflowing");
         const long long total = offs[P];
-        const size_t base = ctx->res_count;
         HIPCHK(ctx, ctx->res_qt.ensure((base + (size_t)total + 1) * 8, base * 8));
         HIPCHK(ctx, ctx->res_dist.ensure((base + (size_t)total + 1) * 4, base * 4));
         ctx->res_count = base + (size_t)total;
         if (total > 0) {
-            HIPCHK(ctx, hipMemcpyAsync(ctx->res_qt.as<int32_t>() + 2 * base, ctx->d_out_qt.p, (size_t)total * 8, hipMemcpyDeviceToHost, ctx->stream));
-            HIPCHK(ctx, hipMemcpyAsync(ctx->res_dist.as<float>() + base, ctx->d_out_d.p, (size_t)total * 4, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(ctx, hipMemcpyAsync(ctx->res_qt.as<int32_t>() + 2 * base, ctx->d_out_qt.as<int2>() + base, (size_t)total * 8, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(ctx, hipMemcpyAsync(ctx->res_dist.as<float>() + base, ctx->d_out_d.as<float>() + base, (size_t)total * 4, hipMemcpyDeviceToHost, ctx->stream));
             HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         }
         for (size_t p = 0; p < P; ++p) ctx->res_offsets[(size_t)begin + p + 1] = (int64_t)base + offs[p + 1];
@@ -1201,7 +1259,10 @@ static int match_pairs_impl(msfm_ctx* ctx, const int32_t* pairs, int n_pairs, co
             HIPCHK(ctx, hipEventElapsedTime(&vms, ctx->ev_pool[ev_base + 6], ctx->ev_pool[ev_base + 7]));
             ctx->prof.verify_ms += vms;
         }
-        begin = end;
+        ctx->prof.sub_batches += 1;
+        break;
+      }
+      begin = end;
     }
     HIPCHK(ctx, hipEventRecord(ev_end, ctx->stream));
     HIPCHK(ctx, hipEventSynchronize(ev_end));
@@ -1255,6 +1316,18 @@ int msfm_fetch_matches(msfm_ctx* ctx, int32_t* out_qt, float* out_dist) {
     return MSFM_OK;
 }
 
+int msfm_fetch_matches_device(msfm_ctx* ctx, int32_t* d_out_qt, float* d_out_dist) {
+    if (!ctx) return MSFM_E_INVALID;
+    if (!ctx->have_results) return fail(ctx, MSFM_E_STATE, "msfm_fetch_matches_device without a completed msfm_match_pairs");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (d_out_qt && ctx->res_count)
+        HIPCHK(ctx, hipMemcpyAsync(d_out_qt, ctx->d_out_qt.p, ctx->res_count * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    if (d_out_dist && ctx->res_count)
+        HIPCHK(ctx, hipMemcpyAsync(d_out_dist, ctx->d_out_d.p, ctx->res_count * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return MSFM_OK;
+}
+
 int msfm_view_matches(msfm_ctx* ctx, const int32_t** out_qt, const float** out_dist, int64_t* out_count) {
     if (!ctx) return MSFM_E_INVALID;
     if (!ctx->have_results) return fail(ctx, MSFM_E_STATE, "msfm_view_matches without a completed msfm_match_pairs");
@@ -1289,10 +1362,24 @@ int msfm_knn2_pair(msfm_ctx* ctx, int id1, int id2, int32_t* fwd_idx0, float* fw
     b.pairs.push_back(pd);
     b.pf.push_back(pp);
     bool exact_launched = false;
-    rc = run_knn(ctx, b, 2, &exact_launched, PruneParams{0, 0.f, 0.f});  // knnMatch twin: every row keeps its neighbours
-    if (rc != MSFM_OK) return rc;
-    rc = check_fix_overflow(ctx);
-    if (rc != MSFM_OK) return rc;
+    int regrows = 0;
+    for (int attempt = 0;; ++attempt) {
+        b.items.clear();
+        b.rp_elems = b.cp_elems = b.kf_elems = b.kr_elems = b.out_elems = b.cand_elems = 0;
+        b.desc_pairs = b.algo_bytes = 0;
+        b.pairs[0].path = b.pf[0].use = pp.use;
+        ctx->prof = msfm_profile{};
+        rc = run_knn(ctx, b, 2, &exact_launched, PruneParams{0, 0.f, 0.f}, true);  // knnMatch twin: every row keeps its neighbours
+        if (rc != MSFM_OK) return rc;
+        bool retry = false;
+        rc = check_fix_overflow(ctx, &retry);
+        if (rc != MSFM_OK) return rc;
+        if (!retry) break;
+        ++regrows;
+        if (attempt >= 4) return fail(ctx, MSFM_E_DEVICE, "tie fix-up queue kept overflowing");
+    }
+    ctx->prof.tie_queue_regrows = regrows;
+    ctx->prof.sub_batches = 1;
     rc = accumulate_kernel_time(ctx, 2, exact_launched);
     if (rc != MSFM_OK) return rc;
     const PairDesc& q = b.pairs[0];

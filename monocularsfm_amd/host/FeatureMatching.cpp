@@ -203,13 +203,14 @@ void FeatureMatcher::MatchImagePairGroups(const std::vector<std::vector<std::pai
         std::vector<int32_t> qt_merged;   // several devices: their lists concatenated in pair order
         std::vector<float> dist_merged;
         const bool verify_on_device = geometric_verification_ && !verification_on_host_;
-        auto run_on = [&](msfm_ctx* c, const int32_t* pairs, int n, int64_t* out_offs) {
-            if (verify_on_device) MSFM_CALL(c, msfm_match_pairs_verified(c, pairs, n, &prm, nullptr, out_offs));  // FilterMatches' constants
-            else MSFM_CALL(c, msfm_match_pairs(c, pairs, n, &prm, out_offs));
+        // returns the status: device worker threads must not exit() the process while their siblings run
+        auto run_on = [&](msfm_ctx* c, const int32_t* pairs, int n, int64_t* out_offs) -> int {
+            if (verify_on_device) return msfm_match_pairs_verified(c, pairs, n, &prm, nullptr, out_offs);  // FilterMatches' constants
+            return msfm_match_pairs(c, pairs, n, &prm, out_offs);
         };
         if (extra_ctxs_.empty()) {
             Lap l(&g_clock.device);
-            run_on(ctx_, todo.data(), P, offs.data());
+            MSFM_CALL(ctx_, run_on(ctx_, todo.data(), P, offs.data()));
             MSFM_CALL(ctx_, msfm_view_matches(ctx_, &qt, &dist, nullptr));
         } else {
             // contiguous ranges of equal cost sum n1 * n2, one per device; every device needs the images of its range
@@ -237,12 +238,15 @@ void FeatureMatcher::MatchImagePairGroups(const std::vector<std::vector<std::pai
             Lap l(&g_clock.device);
             std::vector<std::vector<int64_t>> part_offs(G);
             std::vector<std::thread> workers;
+            std::vector<int> status(G, MSFM_OK);
             for (size_t g = 0; g < G; ++g) {
                 part_offs[g].assign((size_t)(cut[g + 1] - cut[g]) + 1, 0);
                 msfm_ctx* c = g == 0 ? ctx_ : extra_ctxs_[g - 1];
-                workers.emplace_back([&, g, c] { run_on(c, todo.data() + 2 * (size_t)cut[g], cut[g + 1] - cut[g], part_offs[g].data()); });
+                workers.emplace_back([&, g, c] { status[g] = run_on(c, todo.data() + 2 * (size_t)cut[g], cut[g + 1] - cut[g], part_offs[g].data()); });
             }
             for (auto& w : workers) w.join();
+            for (size_t g = 0; g < G; ++g)
+                if (status[g] != MSFM_OK) Die(g == 0 ? ctx_ : extra_ctxs_[g - 1], "msfm_match_pairs (device worker)", status[g]);
             int64_t total = 0;
             for (size_t g = 0; g < G; ++g) {
                 for (int p = cut[g]; p < cut[g + 1]; ++p) offs[(size_t)p + 1] = total + part_offs[g][(size_t)(p - cut[g]) + 1];
@@ -305,8 +309,10 @@ void FeatureMatcher::MatchImagePairGroups(const std::vector<std::vector<std::pai
     Lap le(&g_clock.emit);
     std::string out;
     char buf[160];
+    static const bool trace_txn = std::getenv("MSFM_TRACE_TRANSACTIONS") != nullptr;  // tests: one line per transaction
     for (size_t g = 0; g < groups.size(); ++g) {
         database_->BeginTransaction();
+        if (trace_txn) std::fprintf(stderr, "[msfm txn] %zu\n", groups[g].size());
         out.clear();
         for (size_t k = 0; k < groups[g].size(); ++k) {
             const image_t image_id1 = groups[g][k].first, image_id2 = groups[g][k].second;
@@ -329,7 +335,17 @@ void FeatureMatcher::MatchImagePairGroups(const std::vector<std::vector<std::pai
 }
 
 namespace {
-constexpr size_t kSuperBatchPairs = 16384;  // pairs computed per device call (the reference's groups are <= 100)
+// Pairs computed per device call (the reference's groups are <= 100 pairs; they are emitted unchanged afterwards).
+// Finished groups reach the database once per super-batch, so this is also what an interrupted run can lose:
+// MSFM_SUPER_BATCH_PAIRS lowers it (tests cross the boundary with tiny values).
+size_t SuperBatchPairs() {
+    static const size_t v = [] {
+        const char* e = std::getenv("MSFM_SUPER_BATCH_PAIRS");
+        const long long x = e ? std::atoll(e) : 0;
+        return x > 0 ? (size_t)x : (size_t)16384;
+    }();
+    return v;
+}
 }
 
 void SequentialFeatureMatcher::RunMatching() {
@@ -346,7 +362,7 @@ void SequentialFeatureMatcher::RunMatching() {
         }
         pending += image_pairs.size();
         groups.push_back(std::move(image_pairs));
-        if (pending >= kSuperBatchPairs) {
+        if (pending >= SuperBatchPairs()) {
             MatchImagePairGroups(groups);
             groups.clear();
             pending = 0;
@@ -386,7 +402,7 @@ void BruteFeatureMatcher::RunMatching() {
             pending += image_pairs.size();
             groups.push_back(image_pairs);
         }
-        if (pending >= kSuperBatchPairs) flush();
+        if (pending >= SuperBatchPairs()) flush();
     }
     flush();
     CloseDatabaseAndDevice();

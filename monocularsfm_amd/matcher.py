@@ -19,8 +19,8 @@ import numpy as np
 from . import _lib
 from .database import Database
 
-AUX0 = _lib.MAX_IMAGES          # auxiliary store slots: operator-level calls on raw arrays
-TOPSCALE_BASE = _lib.MAX_IMAGES  # + image id: cached top-scale subset of that image
+TOPSCALE_BASE = _lib.MAX_IMAGES  # + image id: cached top-scale subset of that image (slots MAX .. 2 MAX - 1)
+AUX0 = 2 * _lib.MAX_IMAGES       # two scratch slots behind them: operator-level calls on raw arrays
 
 
 class FeatureUtils:

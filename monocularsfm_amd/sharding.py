@@ -120,88 +120,100 @@ def _host_buffer(rows, cols, pinned, slot="recv"):
     return buf[:rows]
 
 
-def gather_to_writer(local_idx, local_offs, local_qt, local_dist, n_pairs, dst=0, group=None, device=None,
-                     with_dist=True, force_collectives=False):
-    """The exchange step of the CLI flow: only the rank that owns the SQLite handle needs the match lists.
+def _device_buffer(rows, cols, dev, slot):
+    """Reused device tensors of the exchange step (the writer's receive buffer, a rank's send buffer)."""
+    import torch
+    key = (slot, cols, str(dev))
+    buf = _staging.get(key)
+    if buf is None or buf.shape[0] < rows:
+        buf = torch.empty((max(rows, 1) * 5 // 4 + 1024, cols), dtype=torch.int32, device=dev)
+        _staging[key] = buf
+    return buf[:rows]
 
-    Every rank returns the global CSR offsets (one all_reduce of the per-pair counts); rank `dst` also returns
-    qt int32[M,2] (and dist float32[M] if with_dist) in global pair order, the other ranks return None for
-    them.  With with_dist=False the returned qt is a view of a reused staging buffer: valid until the next call.  The `matches` table stores index pairs only (Database.cpp:631-654), so with_dist=False is what the
-    writer needs; the payload then is 8 bytes per match.  Per-rank pair ranges must be contiguous and in rank
-    order (partition_pairs), so the payload is reassembled by concatenation."""
+
+def range_bounds(parts, n_pairs):
+    """partition_pairs' contiguous ranges -> bounds[world + 1]; rank r owns pairs [bounds[r], bounds[r+1]).
+    Every rank computes the same partition, so the bounds need no exchange."""
+    b = np.zeros(len(parts) + 1, np.int64)
+    for r, p in enumerate(parts):
+        if len(p) > 1 and not (np.diff(p) == 1).all():
+            raise ValueError("exchange needs contiguous per-rank pair ranges (partition_pairs)")
+        b[r + 1] = b[r] + len(p)
+        if len(p) and int(p[0]) != int(b[r]):
+            raise ValueError("exchange needs the rank ranges in rank order (partition_pairs)")
+    if int(b[-1]) != int(n_pairs):
+        raise ValueError("rank ranges do not cover the pair list")
+    return b
+
+
+def gather_to_writer(bounds, local_offs, local_payload, dst=0, group=None, device=None, force_collectives=False):
+    """The exchange step of the CLI flow: only the rank that owns the SQLite handle needs the lists.
+
+    bounds        : range_bounds(...) -- the same on every rank, no exchange needed (an empty range in the middle,
+                    which partition_pairs produces when one pair outweighs total / world, is just bounds[r] == bounds[r+1]).
+    local_offs    : CSR offsets of this rank's pairs (len = pairs of the rank + 1).
+    local_payload : int32 tensor [m_local, cols] ON `device` (cols = 2: (queryIdx, trainIdx) -- what the `matches` table
+                    stores, Database.cpp:631-654; cols = 3 adds the distance bits).  With RCCL it is the device tensor
+                    the library filled (msfm_fetch_matches_device): the lists never visit the host on the sender.
+    -> (global offsets int64[P+1] on every rank, payload int32[M, cols] as a NumPy view of a reused page-locked
+        host buffer on rank `dst` -- valid until the next call -- and None elsewhere).
+
+    One all_reduce(SUM) of the per-pair counts (disjoint supports: a concatenation), then every non-writer rank with
+    matches SENDS its block and the writer RECEIVES each block at its final position of one [M, cols] buffer: no rank
+    padding, no reassembly pass, one device-to-host copy on the writer.  MBs per rank: latency-bound on xGMI."""
     import torch
     import torch.distributed as dist
 
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    local_idx = np.asarray(local_idx, np.int64)
+    n_pairs = int(bounds[-1])
     local_counts = np.diff(np.asarray(local_offs, np.int64))
-    qt_local = np.ascontiguousarray(local_qt, dtype=np.int32).reshape(-1, 2)
-    if world == 1 and not (force_collectives and dist.is_initialized()):  # force: single-rank check of the RCCL path
-        offs = np.zeros(n_pairs + 1, np.int64)
-        cnt = np.zeros(n_pairs, np.int64)
-        cnt[local_idx] = local_counts
-        np.cumsum(cnt, out=offs[1:])
-        return offs, qt_local, (np.asarray(local_dist, np.float32) if with_dist else None)
     dev = device if device is not None else torch.device("cpu")
-    rank = dist.get_rank(group)
-    if len(local_idx) > 1 and not (np.diff(local_idx) == 1).all():
-        raise ValueError("gather_to_writer needs contiguous per-rank pair ranges (partition_pairs)")
-
+    multi = dist.is_available() and dist.is_initialized()
+    world = dist.get_world_size(group) if multi else 1
+    rank = dist.get_rank(group) if multi else 0
+    cols = int(local_payload.shape[1])
+    if len(local_counts) != int(bounds[rank + 1] - bounds[rank]):
+        raise ValueError("local result does not match this rank's range")
     counts = torch.zeros(n_pairs, dtype=torch.int32)
-    counts[torch.from_numpy(local_idx)] = torch.from_numpy(local_counts.astype(np.int32))
-    starts = torch.full((world,), n_pairs, dtype=torch.int32)
-    starts[rank] = int(local_idx[0]) if len(local_idx) else n_pairs
-    cs = torch.cat([counts, starts]).to(dev)
-    # counts: disjoint supports -> SUM is a concatenation; starts: every rank contributes its own slot on top
-    # of the n_pairs fill of the others -> subtract (world - 1) * n_pairs afterwards
-    dist.all_reduce(cs, op=dist.ReduceOp.SUM, group=group)
-    cs = cs.cpu().numpy().astype(np.int64)
-    counts_all, starts_all = cs[:n_pairs], cs[n_pairs:] - (world - 1) * n_pairs
-    if not (np.diff(starts_all) >= 0).all():
-        raise ValueError("gather_to_writer: rank ranges are not in rank order")
+    counts[int(bounds[rank]):int(bounds[rank + 1])] = torch.from_numpy(local_counts.astype(np.int32))
+    if world > 1 or (force_collectives and multi):
+        counts = counts.to(dev)
+        dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=group)
+        counts = counts.cpu()
     offs = np.zeros(n_pairs + 1, np.int64)
-    np.cumsum(counts_all, out=offs[1:])
-    bounds = np.concatenate([starts_all, [n_pairs]])
-    per_rank_total = np.array([offs[bounds[r + 1]] - offs[bounds[r]] for r in range(world)], np.int64)
-
-    cols = 3 if with_dist else 2
-    max_m = max(int(per_rank_total.max()), 1)
-    m_local = int(local_counts.sum())
+    np.cumsum(counts.numpy(), out=offs[1:])
+    blk = offs[np.asarray(bounds)]                      # block r = rows [blk[r], blk[r+1]) of the global payload
     pin = dev.type == "cuda"
-    # rank-padded payload; the padding rows are never read (receivers slice by the counts), so no zero fill
-    stage = _host_buffer(max_m, cols, pin, slot="send")
-    if m_local:
-        sv = stage.numpy()
-        sv[:m_local, 0:2] = qt_local
-        if with_dist:
-            sv[:m_local, 2] = np.ascontiguousarray(local_dist, dtype=np.float32).view(np.int32)
-    send = stage.to(dev, non_blocking=pin) if pin else stage.clone()
+    M = int(offs[-1])
     if rank == dst:
-        recv = [torch.empty_like(send) for _ in range(world)]
-        dist.gather(send, recv, dst=dst, group=group)
-        M = int(offs[-1])
-        out = _host_buffer(M, cols, pin, slot="recv")
-        at = 0
-        for r in range(world):
-            k = int(per_rank_total[r])
-            out[at:at + k].copy_(recv[r][:k], non_blocking=pin)
-            at += k
+        out = _device_buffer(M, cols, dev, "recv") if pin else _host_buffer(M, cols, False, "recv")
+        ops = [dist.P2POp(dist.irecv, out[int(blk[r]):int(blk[r + 1])], r, group)
+               for r in range(world) if r != dst and blk[r + 1] > blk[r]]
+        if ops:
+            reqs = dist.batch_isend_irecv(ops)
+        if blk[rank + 1] > blk[rank]:
+            out[int(blk[rank]):int(blk[rank + 1])].copy_(local_payload, non_blocking=pin)
+        if ops:
+            for q in reqs:
+                q.wait()
         if pin:
+            host = _host_buffer(M, cols, True, "host")
+            host.copy_(out, non_blocking=True)
             torch.cuda.synchronize(dev)
-        allm = out.numpy()   # a view of the reused staging buffer
-        if with_dist:
-            return offs, np.array(allm[:, 0:2], dtype=np.int32, order="C"), np.array(allm[:, 2], dtype=np.int32).view(np.float32)
-        # (q, t) only: the staging buffer IS the result -- no copy of 100+ MB; valid until the next call
-        return offs, allm, None
-    dist.gather(send, None, dst=dst, group=group)
-    return offs, None, None
+            return offs, host.numpy()
+        return offs, out.numpy()
+    if blk[rank + 1] > blk[rank]:
+        for q in dist.batch_isend_irecv([dist.P2POp(dist.isend, local_payload, dst, group)]):
+            q.wait()
+    return offs, None
 
 
 class ShardedMatcher:
     """All-pairs matching over the ranks of a torch.distributed process group.
 
-    match_fn(pairs_subset) -> (offsets, qt, dist) defaults to the GPU context's match_pairs;
-    the CPU (gloo) tests inject a stand-in to exercise partition + gather without a GPU."""
+    With a GPU context the match lists stay in HBM between the matcher and the exchange (exchange on `device` =
+    the context's GPU, backend nccl = RCCL); `device` = cpu (gloo: the CPU tests, or several ranks sharing one GPU)
+    stages them through the library's page-locked host buffers instead.  match_fn(pairs_subset) -> (offsets, qt,
+    dist) replaces the GPU context in the CPU tests."""
 
     def __init__(self, ctx=None, match_fn=None, group=None, device=None, force_collectives=False, **match_kw):
         if ctx is None and match_fn is None:
@@ -211,7 +223,9 @@ class ShardedMatcher:
         self.device = device
         self.match_kw = match_kw
         self.force_collectives = force_collectives
+        self._own_fn = match_fn is None   # the GPU context's own matcher: the lists can stay in HBM for the exchange
         self.match_fn = match_fn if match_fn is not None else (lambda p: ctx.match_pairs(p, **match_kw))
+        self.last = {}   # per-rank timing of the last match_to_writer call (ms): compute, exchange
 
     def _rank_world(self):
         import torch.distributed as dist
@@ -233,8 +247,48 @@ class ShardedMatcher:
         return gather_matches(mine, offs, qt, d, len(pairs), group=self.group, device=self.device)
 
     def match_to_writer(self, pairs, n_rows, dst=0, with_dist=False):
-        """The CLI flow: global offsets everywhere, the match lists only on rank `dst` (the SQLite writer)."""
+        """The CLI flow: global offsets everywhere, the match lists only on rank `dst` (the SQLite writer).
+        -> (offsets, qt int32[M, 2] or None, dist float32[M] or None); qt / dist are views of a reused host buffer."""
+        import time
+        import torch
+        rank, world = self._rank_world()
         pairs = np.asarray(pairs, np.int32).reshape(-1, 2)
-        mine, offs, qt, d = self.match_local(pairs, n_rows)
-        return gather_to_writer(mine, offs, qt, d, len(pairs), dst=dst, group=self.group, device=self.device,
-                                with_dist=with_dist, force_collectives=self.force_collectives)
+        parts = partition_pairs(pairs, n_rows, world)
+        bounds = range_bounds(parts, len(pairs))
+        mine = parts[rank]
+        dev = self.device if self.device is not None else torch.device("cpu")
+        cols = 3 if with_dist else 2
+        t0 = time.perf_counter()
+        if self._own_fn and dev.type == "cuda":
+            # lists stay in HBM: the library copies them device-to-device into the send tensor
+            kw = dict(self.match_kw)
+            kw.pop("fetch", None)
+            offs, _, _ = self.ctx.match_pairs(pairs[mine], fetch=False, **kw)
+            m = int(offs[-1])
+            if with_dist:
+                qt_t = _device_buffer(m, 2, dev, "send_qt")
+                d_t = _device_buffer(m, 1, dev, "send_d")
+                self.ctx.fetch_matches_device(qt_t.data_ptr() if m else 0, d_t.data_ptr() if m else 0)
+                payload = torch.cat([qt_t, d_t], dim=1)
+            else:
+                payload = _device_buffer(m, 2, dev, "send_qt")
+                self.ctx.fetch_matches_device(payload.data_ptr() if m else 0, 0)
+        else:
+            offs, qt, d = self.match_fn(pairs[mine])
+            m = int(offs[-1])
+            host = np.empty((m, cols), np.int32)
+            host[:, 0:2] = np.asarray(qt, np.int32).reshape(-1, 2)
+            if with_dist:
+                host[:, 2] = np.ascontiguousarray(d, dtype=np.float32).view(np.int32)
+            payload = torch.from_numpy(host).to(dev)
+        t1 = time.perf_counter()
+        goffs, allm = gather_to_writer(bounds, offs, payload, dst=dst, group=self.group, device=dev,
+                                       force_collectives=self.force_collectives)
+        t2 = time.perf_counter()
+        self.last = {"compute_ms": (t1 - t0) * 1e3, "exchange_ms": (t2 - t1) * 1e3, "local_pairs": int(len(mine)),
+                     "local_matches": m}
+        if allm is None:
+            return goffs, None, None
+        if with_dist:
+            return goffs, allm[:, 0:2], allm[:, 2].view(np.float32)
+        return goffs, allm, None

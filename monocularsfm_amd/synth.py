@@ -79,3 +79,32 @@ def keypoints(n, seed=0, width=3072, height=2304):
     k[:, 2] = rng.gamma(2.0, 2.0, n) + 1.0
     k[:, 3] = rng.uniform(0, 360, n)
     return k
+
+
+def all_pairs(n_images):
+    """BruteFeatureMatcher::RunMatching's enumeration (FeatureMatching.cpp:110-139): (i, j), j < i, i-major."""
+    return np.array([(i, j) for i in range(n_images) for j in range(i)], np.int32).reshape(-1, 2)
+
+
+def job(workload="south-building", n_images=None, n_desc=None, seed=1234):
+    """The seeded jobs of BASELINE.json -> (images, pairs, description).
+
+    south-building : configs[1] / [2]: n_images (default 128; 330 = Person-Hall-shaped) x 4600..5400 float32
+                     RootSIFT-like descriptors, brute-force all pairs.  bench.py's N = 1 workload.
+    synthetic-u8   : configs[3] / [4]: n_images x n_desc (default 8192) u8-valued descriptors; the full configs
+                     have 1329 x 8192 and 4096 x 16384 -- benches and tests run seeded subsets of the image set."""
+    rng = np.random.default_rng(seed)
+    if workload == "south-building":
+        n_images = n_images or 128
+        counts = rng.integers(4600, 5401, n_images) if n_desc is None else np.full(n_images, n_desc)
+        imgs = rootsift_images(n_images, counts.tolist(), seed=seed, n_proto=20000, sigma=0.05)
+        name = "south-building-shaped synthetic: %d images x ~%d f32 RootSIFT-like desc, brute-force all pairs" % (
+            n_images, int(np.mean(counts)))
+    elif workload == "synthetic-u8":
+        n_images = n_images or 64
+        nd = n_desc or 8192
+        imgs = u8_images(n_images, nd, seed=seed, as_float=False)
+        name = "synthetic u8 descriptors: %d images x %d desc, brute-force all pairs" % (n_images, nd)
+    else:
+        raise ValueError("unknown workload " + workload)
+    return imgs, all_pairs(n_images), name

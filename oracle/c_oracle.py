@@ -46,6 +46,9 @@ def lib():
         L.orc_match_pair.restype = C.c_int
         L.orc_match_pair.argtypes = [fp, C.c_int, fp, C.c_int, C.c_float, C.c_int, C.c_double,
                                      C.c_int, C.c_int, ip, ip, fp]
+        L.orc_match_pairs_mt.restype = C.c_int64
+        L.orc_match_pairs_mt.argtypes = [C.POINTER(fp), ip, ip, C.c_int, C.c_float, C.c_int, C.c_double, C.c_int, C.c_int,
+                                         lp, ip, ip, fp]
         L.orc_topscale_select.restype = C.c_int
         L.orc_topscale_select.argtypes = [fp, C.c_int, C.c_int, ip]
         L.orc_pair_id.restype = C.c_int32
@@ -145,6 +148,32 @@ def match_pair(d1, d2, ratio=0.8, cross_check=True, max_distance=0.7, order=ORDE
     m = lib().orc_match_pair(_f(d1), n1, _f(d2), d2.shape[0], np.float32(ratio), int(bool(cross_check)),
                              float(max_distance), order, nthreads, _i(q), _i(t), _f(d))
     return q[:m].copy(), t[:m].copy(), d[:m].copy()
+
+
+def match_pairs(images, pairs, ratio=0.8, cross_check=True, max_distance=0.7, order=ORDER_SSE4X4, nthreads=None):
+    """MatchImagePairs' loop over independent pairs, parallel over PAIRS (persistent pool, one pair per worker at a
+    time).  images: list / dict id -> n x 128 float32; pairs: P x 2 (query id, train id).
+    -> offsets int64[P+1], q int32[M], t int32[M], dist float32[M]."""
+    pairs = np.ascontiguousarray(np.asarray(pairs, dtype=np.int32).reshape(-1, 2))
+    P = pairs.shape[0]
+    ids = sorted(set(pairs.ravel().tolist()))
+    n_slots = (max(ids) + 1) if ids else 1
+    keep = {i: _desc(images[i]) for i in ids}
+    ptrs = (C.POINTER(C.c_float) * n_slots)()
+    rows = np.zeros(n_slots, np.int32)
+    for i, d in keep.items():
+        ptrs[i] = _f(d)
+        rows[i] = d.shape[0]
+    cap = int(rows[pairs[:, 0]].sum()) if P else 0
+    q = np.empty(max(cap, 1), np.int32)
+    t = np.empty(max(cap, 1), np.int32)
+    d = np.empty(max(cap, 1), np.float32)
+    offs = np.zeros(P + 1, np.int64)
+    if nthreads is None:
+        nthreads = os.cpu_count() or 1
+    m = lib().orc_match_pairs_mt(ptrs, _i(rows), _i(pairs), P, np.float32(ratio), int(bool(cross_check)), float(max_distance),
+                                 order, int(nthreads), offs.ctypes.data_as(C.POINTER(C.c_int64)), _i(q), _i(t), _f(d))
+    return offs, q[:m].copy(), t[:m].copy(), d[:m].copy()
 
 
 def topscale_select(kpts, k):

@@ -311,6 +311,77 @@ int orc_match_pair(const float* d1, int n1, const float* d2, int n2,
 /* ------------------------------------------------------------------------- */
 /* pre-emptive matching helper (FeatureUtils.cpp:68-96)                       */
 /* ------------------------------------------------------------------------- */
+/* a batch of independent pairs, parallel over pairs (FeatureMatching.cpp:14-49) */
+/* ------------------------------------------------------------------------- */
+typedef struct {
+    const float* const* images;
+    const int32_t* rows;
+    const int32_t* pairs;
+    int n_pairs;
+    float ratio;
+    int cross_check;
+    double max_distance;
+    int order;
+    const int64_t* cap_off;  /* where pair p's staging region starts */
+    int32_t *q, *t;
+    float* d;
+    int32_t* counts;
+    int next;                /* shared work counter */
+} pairs_job;
+
+static void* pairs_thread(void* arg)
+{
+    pairs_job* J = (pairs_job*)arg;
+    for (;;) {
+        const int p = __atomic_fetch_add(&J->next, 1, __ATOMIC_RELAXED);
+        if (p >= J->n_pairs) break;
+        const int32_t a = J->pairs[2 * p], b = J->pairs[2 * p + 1];
+        const int64_t o = J->cap_off[p];
+        J->counts[p] = orc_match_pair(J->images[a], J->rows[a], J->images[b], J->rows[b], J->ratio, J->cross_check,
+                                      J->max_distance, J->order, 1, J->q + o, J->t + o, J->d + o);
+    }
+    return NULL;
+}
+
+int64_t orc_match_pairs_mt(const float* const* images, const int32_t* rows, const int32_t* pairs, int n_pairs,
+                           float ratio, int cross_check, double max_distance, int order, int nthreads,
+                           int64_t* out_offsets, int32_t* out_q, int32_t* out_t, float* out_d)
+{
+    out_offsets[0] = 0;
+    if (n_pairs <= 0) return 0;
+    int64_t* cap_off = (int64_t*)malloc(sizeof(int64_t) * ((size_t)n_pairs + 1));
+    int32_t* counts = (int32_t*)calloc((size_t)n_pairs, sizeof(int32_t));
+    cap_off[0] = 0;
+    for (int p = 0; p < n_pairs; ++p) cap_off[p + 1] = cap_off[p] + (rows[pairs[2 * p]] > 0 ? rows[pairs[2 * p]] : 0);
+    pairs_job J = {images, rows, pairs, n_pairs, ratio, cross_check, max_distance, order, cap_off,
+                   out_q, out_t, out_d, counts, 0};
+    if (nthreads > n_pairs) nthreads = n_pairs;
+    if (nthreads <= 1) {
+        pairs_thread(&J);
+    } else {
+        pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * (size_t)nthreads);
+        for (int k = 0; k < nthreads; ++k) pthread_create(&th[k], NULL, pairs_thread, &J);
+        for (int k = 0; k < nthreads; ++k) pthread_join(th[k], NULL);
+        free(th);
+    }
+    /* compact the per-pair staging regions into CSR order (regions are ordered, so an in-place forward move is safe) */
+    int64_t at = 0;
+    for (int p = 0; p < n_pairs; ++p) {
+        const int64_t o = cap_off[p];
+        if (o != at && counts[p] > 0) {
+            memmove(out_q + at, out_q + o, sizeof(int32_t) * (size_t)counts[p]);
+            memmove(out_t + at, out_t + o, sizeof(int32_t) * (size_t)counts[p]);
+            memmove(out_d + at, out_d + o, sizeof(float) * (size_t)counts[p]);
+        }
+        at += counts[p];
+        out_offsets[p + 1] = at;
+    }
+    free(cap_off);
+    free(counts);
+    return at;
+}
+
+/* ------------------------------------------------------------------------- */
 
 typedef struct {
     float size;

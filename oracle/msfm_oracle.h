@@ -84,6 +84,17 @@ int orc_match_pair(const float* d1, int n1, const float* d2, int n2,
                    float ratio, int cross_check, double max_distance, int order, int nthreads,
                    int32_t* out_q, int32_t* out_t, float* out_d);
 
+/* The loop of FeatureMatcher::MatchImagePairs (FeatureMatching.cpp:14-49) over INDEPENDENT image pairs, one
+ * pair per worker at a time: `nthreads` pthreads pull pair indices from a shared counter and run orc_match_pair
+ * single-threaded (the reference runs its pairs one after the other; OpenCV fans each knnMatch out over query
+ * rows -- parallelising over pairs instead keeps all cores busy without a thread create/join per pair).
+ * images[id] -> n x 128 descriptors, rows[id] -> n; pairs = P x 2 ids (query, train).
+ * out_offsets: P+1 CSR offsets; out_q/out_t/out_d: capacity sum over pairs of rows[query].  Returns the
+ * number of matches. */
+int64_t orc_match_pairs_mt(const float* const* images, const int32_t* rows, const int32_t* pairs, int n_pairs,
+                           float ratio, int cross_check, double max_distance, int order, int nthreads,
+                           int64_t* out_offsets, int32_t* out_q, int32_t* out_t, float* out_d);
+
 /* FeatureUtils::ExtractTopScaleDescriptors' selection (FeatureUtils.cpp:68-96):
  * indices of the k largest KeyPoint.size (kpts = n x 4 floats x,y,size,angle).
  * The reference uses std::partial_sort (unspecified order among equal sizes);

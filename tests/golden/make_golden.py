@@ -88,5 +88,36 @@ def main():
     assert (0, 5) in cc1 and (7, 5) not in cc1 and (3, 6) not in cc1 and (9, 6) not in cc1, cc1
 
 
+def int_case():
+    """u8_int64_400x380.npz: expected outputs from the EXACT-INTEGER reference (oracle/int_oracle.py), i.e. what every
+    conforming OpenCV build returns for integer descriptors -- not from the restated SIMD order.  The C oracle must
+    agree under every order before the file is written; int_fwd_s0 / s1 are the integer S of both neighbours."""
+    from oracle import int_oracle as io
+    u = synth.u8_images(2, [400, 380], seed=105, dup_frac=0.15)
+    A, B = u[0], u[1]
+    B[7] = B[3]
+    B[90] = B[3]
+    A[10] = B[3]
+    A[0] = B[40]
+    out = {"desc1": A.astype(np.uint8), "desc2": B.astype(np.uint8), "max_distance": np.float64(1e9)}
+    f, r = io.knn2(A, B), io.knn2(B, A)
+    for o in (0, 1, 2):
+        for x, y in zip(f + r, co.knn2(A, B, o) + co.knn2(B, A, o)):
+            assert np.array_equal(x.view(np.int32), y.view(np.int32)), "C oracle != integer reference"
+    S = np.sort(io.s_matrix(A, B), axis=1)
+    out["int_fwd_s0"], out["int_fwd_s1"] = S[:, 0], S[:, 1]
+    for o in (0, 1):
+        out["o%d_fwd_idx0" % o], out["o%d_fwd_d0" % o], _, out["o%d_fwd_d1" % o] = f
+        out["o%d_rev_idx0" % o], out["o%d_rev_d0" % o], _, out["o%d_rev_d1" % o] = r
+        for cc in (1, 0):
+            out["o%d_cc%d_q" % (o, cc)], out["o%d_cc%d_t" % (o, cc)], out["o%d_cc%d_d" % (o, cc)] = io.match_pair(A, B, 0.8, bool(cc), 1e9)
+    np.savez_compressed(os.path.join(HERE, "u8_int64_400x380.npz"), **out)
+    print("u8_int64_400x380", {k: len(v) for k, v in out.items() if k.endswith("_q")})
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "int":
+        int_case()
+    else:
+        main()
+        int_case()

@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_bench_line_contract():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
-                        "--images", "24", "--cpu-budget", "2"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+                        "--images", "24", "--cpu-budget", "2", "--u8-images", "6"], capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, "exactly one JSON line on stdout"
@@ -23,7 +23,10 @@ def test_bench_line_contract():
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1
     assert d["higher_is_better"] is True and d["vs_baseline"] is None and d["data"] == "synthetic"
-    assert d["scaling"] in ("weak", "strong") and isinstance(d["config"].get("workload"), str)
+    assert d["scaling"] == "strong" and isinstance(d["config"].get("workload"), str)
+    assert len(d["per_rank_ms"]) == 1 and d["per_rank_ms"][0]["compute"] > 0
+    assert d["strong_u8"]["value"] > 0 and d["strong_u8"]["image_pairs"] == 15
+    assert "opencv_found" in d["cpu_baseline"] and d["cpu_baseline"]["parallel_efficiency"] > 0
     assert "model" not in d["config"]
     assert d["value"] > 0 and d["ms_per_step"] > 0
     # value = descriptor pairs of the job / step time
@@ -36,3 +39,26 @@ def test_bench_line_contract():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in cb, k
     assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0
+
+
+def test_bench_two_ranks_sharing_the_gpu():
+    """The multi-rank flow of bench.py (partition, per-rank match, count all_reduce, send of the lists to the writer)
+    with two ranks on this box's one GPU over gloo: RCCL itself needs a GPU per rank (driver's SCALE run)."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", "29517", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
+                        "--warmup", "1", "--images", "20", "--u8-images", "5", "--backend", "gloo", "--share-gpu"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and len(d["per_rank_ms"]) == 2
+    assert d["config"]["image_pairs"] == 190 and d["config"]["matches_per_step"] > 0
+    assert all(x["compute"] > 0 for x in d["per_rank_ms"]) and "cpu_baseline" not in d
+    # the same job on one rank gives the same number of matches
+    r1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--images", "20",
+                         "--u8-images", "0", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    d1 = json.loads([l for l in r1.stdout.splitlines() if l.startswith("{")][0])
+    assert d1["config"]["matches_per_step"] == d["config"]["matches_per_step"]

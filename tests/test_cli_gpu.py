@@ -271,3 +271,59 @@ def test_partial_resume_recomputes_only_missing_rows(exe, dataset, tmp_path):
     assert after == before
     assert out.count("Existing, Continue!") == len(before) - len(victims)
     assert out.count(" ... \n") == len(victims)
+
+
+def test_brute_mode_past_the_100_pair_flush_and_the_super_batch(exe, oracle, tmp_path):
+    """104 tiny images: rows i >= 100 of the pair matrix cross the reference's 100-pair flush
+    (/root/reference/src/Feature/FeatureMatching.cpp:118-139, max_pairs_size_) and, with the super-batch lowered to
+    250 pairs, the job takes ~20 device calls.  Rows, stdout order and transaction grouping must be what the
+    reference's control flow gives, and must not depend on the super-batch size."""
+    rng = np.random.default_rng(104)
+    n_img = 104
+    sizes = rng.integers(24, 64, n_img).tolist()
+    sizes[17] = 0        # an image without features
+    sizes[33] = 1
+    descs = synth.rootsift_images(n_img, sizes, seed=3104, n_proto=150, sigma=0.03, overlap=0.8)
+    descs = [np.ascontiguousarray(d, dtype=np.float32) for d in descs]
+    kps = [synth.keypoints(len(d), seed=700 + i) for i, d in enumerate(descs)]
+    # expectation: the reference's enumeration + flush boundaries, the pre-emptive test on the (whole: < 100 rows)
+    # images, the oracle's per-pair lists
+    pairs, batch_end = oracle.enumerate_brute(n_img, 100)
+    assert len(pairs) == n_img * (n_img - 1) // 2 and (np.diff(np.concatenate([[0], batch_end])) <= 100).all()
+    assert (np.diff(np.concatenate([[0], batch_end])) == 100).sum() >= 4     # rows 100..103 flush at 100 pairs
+    offs, q, t, _ = oracle.match_pairs(descs, pairs, 0.8, True, np.inf, nthreads=8)   # pre-emptive: no distance cut
+    keep = np.diff(offs) >= 4
+    o2, q2, t2, _ = oracle.match_pairs(descs, pairs, 0.8, True, 0.7, nthreads=8)
+    assert 0.2 < keep.mean() < 0.98, "test data: the pre-emptive filter should drop some pairs, not all"
+    groups, start = [], 0
+    for e in batch_end:
+        groups.append([p for p in range(start, int(e)) if keep[p]])
+        start = int(e)
+    outs = {}
+    for name, env in (("small", {"MSFM_SUPER_BATCH_PAIRS": "250"}), ("default", {})):
+        db_path = str(tmp_path / (name + ".db"))
+        database.write_synthetic_database(db_path, descs, kps)
+        cfg = tmp_path / (name + ".yaml")
+        cfg.write_text(YAML.format(db=db_path, mt=1))
+        env = dict(env, MSFM_GEOMETRIC_VERIFICATION="0", MSFM_TRACE_TRANSACTIONS="1")
+        e = dict(os.environ)
+        e.update(env)
+        r = subprocess.run([exe, str(cfg)], capture_output=True, text=True, env=e, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        txn = [int(x) for x in re.findall(r"\[msfm txn\] (\d+)", r.stderr)]
+        assert txn == [len(g) for g in groups], name                       # one transaction per reference group
+        seq = [(int(a), int(b_)) for a, b_ in re.findall(r"Compute Matches (\d+) - (\d+) \.\.\. ", r.stdout)]
+        assert seq == [tuple(int(x) for x in pairs[p]) for g in groups for p in g], name
+        db = database.Database(db_path)
+        assert db.db.execute("SELECT COUNT(*) FROM matches").fetchone()[0] == int(keep.sum())
+        rows = db.db.execute("SELECT pair_id, rows, cols, data FROM matches ORDER BY pair_id").fetchall()
+        db.Close()
+        outs[name] = rows
+        by_id = {r_[0]: r_ for r_ in rows}
+        for p in np.nonzero(keep)[0]:
+            i, j = int(pairs[p][0]), int(pairs[p][1])
+            m = np.stack([q2[o2[p]:o2[p + 1]], t2[o2[p]:o2[p + 1]]], 1).reshape(-1, 2)
+            row = by_id[database.ImagePairToPairId(i, j)]
+            assert row[1] == len(m) and row[2] == 2
+            assert np.array_equal(np.frombuffer(row[3], np.int32).reshape(-1, 2), m[:, ::-1]), (i, j)   # i > j: columns swapped
+    assert outs["small"] == outs["default"]

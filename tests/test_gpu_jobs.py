@@ -1,0 +1,244 @@
+"""Job-level parity: the paths only a full-size batch reaches.
+
+  (a) one msfm_match_pairs call forced into many device sub-batches (pair-count limit, scratch limit) ==
+      the unsplit call == the oracle, on both routes and with the geometric verification hand-off;
+  (b) the full BASELINE config-2 job -- 128 images x ~5000 descriptors, 8128 pairs in ONE launch per sweep (the
+      cross-pair grouping of compacted live rows in sweep 2 only exists at this size) -- with 64 seeded pairs
+      checked against the oracle and prefilter == brute force on a 500-pair subset;
+  (c) config 3 at 330 images in one call (54 285 pairs => several sub-batches with the default limits), sampled
+      pairs against the oracle;
+  (d) integer descriptors against the exact-integer reference (oracle/int_oracle.py), u8 upload path.
+The reference's counterpart of (a)-(c) is the pair loop of FeatureMatcher::MatchImagePairs and the 100-pair
+flush of BruteFeatureMatcher::RunMatching (/root/reference/src/Feature/FeatureMatching.cpp:14-49, 118-139)."""
+import numpy as np
+import pytest
+
+from monocularsfm_amd import synth
+
+pytestmark = pytest.mark.gpu
+F32 = np.float32
+
+
+def b(a):
+    a = np.asarray(a)
+    return a.view(np.int32) if a.dtype == np.float32 else a
+
+
+def same_result(x, y):
+    return np.array_equal(x[0], y[0]) and np.array_equal(x[1], y[1]) and np.array_equal(b(x[2]), b(y[2]))
+
+
+def check_pairs_vs_oracle(oracle, imgs, pairs, sel, offs, qt, d, nthreads=None, **kw):
+    o_offs, oq, ot, od = oracle.match_pairs(imgs, pairs[sel], nthreads=nthreads, **kw)
+    for k, p in enumerate(sel):
+        s, e = int(offs[p]), int(offs[p + 1])
+        os_, oe = int(o_offs[k]), int(o_offs[k + 1])
+        assert e - s == oe - os_, (p, pairs[p], e - s, oe - os_)
+        assert np.array_equal(qt[s:e, 0], oq[os_:oe]) and np.array_equal(qt[s:e, 1], ot[os_:oe]), (p, pairs[p])
+        assert np.array_equal(b(d[s:e]), b(od[os_:oe])), (p, pairs[p])
+    return int(o_offs[-1])
+
+
+# ---- (a) forced sub-batches ------------------------------------------------------------------------------
+
+@pytest.fixture(scope="module")
+def small_job():
+    sizes = [900, 640, 1300, 257, 1024, 700, 130, 999, 512, 1100, 64, 801]
+    imgs = synth.rootsift_images(len(sizes), sizes, seed=77, n_proto=2600)
+    return imgs, synth.all_pairs(len(sizes))
+
+
+@pytest.mark.parametrize("prefilter", [True, False])
+def test_forced_sub_batches_equal_the_unsplit_call_and_the_oracle(gpu_ctx, oracle, small_job, prefilter):
+    imgs, pairs = small_job
+    for i, im in enumerate(imgs):
+        gpu_ctx.upload_image(i, im)
+    gpu_ctx.set_prefilter(prefilter)
+    try:
+        gpu_ctx.set_limits(0, 0)
+        ref = gpu_ctx.match_pairs(pairs)
+        assert gpu_ctx.profile()["sub_batches"] == 1
+        assert ref[0][-1] > 1000
+        for limits, min_batches in (((7, 0), 10), ((25, 0), 3), ((0, 4 << 20), 3), ((1, 0), len(pairs))):
+            gpu_ctx.set_limits(*limits)
+            got = gpu_ctx.match_pairs(pairs)
+            nb = gpu_ctx.profile()["sub_batches"]
+            assert nb >= min_batches, (limits, nb)
+            assert same_result(ref, got), limits
+            view = gpu_ctx.match_pairs(pairs, fetch="view")      # the page-locked buffers accumulate over sub-batches
+            assert same_result(ref, view), limits
+    finally:
+        gpu_ctx.set_limits(0, 0)
+        gpu_ctx.set_prefilter(True)
+    total = check_pairs_vs_oracle(oracle, imgs, pairs, np.arange(len(pairs)), *ref, nthreads=8)
+    assert total == ref[0][-1]
+
+
+def test_forced_sub_batches_with_other_parameters_and_verification(gpu_ctx, small_job):
+    imgs, pairs = small_job
+    for i, im in enumerate(imgs):
+        gpu_ctx.upload_image(i, im)
+        gpu_ctx.upload_keypoints(i, synth.keypoints(len(im), seed=900 + i))
+    try:
+        for kw in ({"ratio": 0.9, "cross_check": False, "max_distance": 0.5}, {"ratio": 1.2, "cross_check": True, "max_distance": 10.0}):
+            gpu_ctx.set_limits(0, 0)
+            ref = gpu_ctx.match_pairs(pairs, **kw)
+            gpu_ctx.set_limits(9, 0)
+            assert same_result(ref, gpu_ctx.match_pairs(pairs, **kw)), kw
+        gpu_ctx.set_limits(0, 0)
+        ref = gpu_ctx.match_pairs_verified(pairs)
+        gpu_ctx.set_limits(11, 0)
+        got = gpu_ctx.match_pairs_verified(pairs)
+        assert gpu_ctx.profile()["sub_batches"] == 6
+        assert same_result(ref, got)
+    finally:
+        gpu_ctx.set_limits(0, 0)
+
+
+def test_limits_from_the_environment(gpu_ctx, small_job, monkeypatch):
+    from monocularsfm_amd import _lib
+    imgs, pairs = small_job
+    monkeypatch.setenv("MSFM_MAX_PAIRS_PER_BATCH", "5")
+    with _lib.Context(0) as ctx:
+        for i, im in enumerate(imgs[:6]):
+            ctx.upload_image(i, im)
+        ctx.match_pairs(pairs[:15])
+        assert ctx.profile()["sub_batches"] == 3
+
+
+# ---- (b) the full config-2 job ------------------------------------------------------------------------------
+
+def test_config2_full_job_one_launch(gpu_ctx, oracle):
+    imgs, pairs, _ = synth.job("south-building", 128, seed=1234)     # bench.py's N = 1 workload
+    assert len(pairs) == 8128
+    for i, im in enumerate(imgs):
+        gpu_ctx.upload_image(i, im)
+    gpu_ctx.set_limits(0, 0)
+    offs, qt, d = gpu_ctx.match_pairs(pairs)
+    p = gpu_ctx.profile()
+    assert p["sub_batches"] == 1 and p["approx_kernel_launches"] == 1      # ONE launch per sweep for the whole job
+    assert p["prefilter_pairs"] == 8128 and p["fallback_pairs"] == 0 and p["compacted_pairs"] > 7000
+    n = np.array([len(x) for x in imgs], np.int64)
+    assert p["descriptor_pairs"] == int((n[pairs[:, 0]] * n[pairs[:, 1]]).sum())
+    # ascending queryIdx inside every pair, indices in range
+    cnt = np.diff(offs)
+    pid = np.repeat(np.arange(len(pairs)), cnt)
+    assert (qt[:, 0] < n[pairs[pid, 0]]).all() and (qt[:, 1] < n[pairs[pid, 1]]).all() and (qt >= 0).all()
+    inner = np.ones(len(qt), bool)
+    inner[offs[:-1][cnt > 0]] = False
+    assert (np.diff(qt[:, 0])[inner[1:]] > 0).all()
+    assert (d <= F32(0.7)).all()
+    # 64 seeded pairs against the oracle
+    sel = np.sort(np.random.default_rng(2).choice(len(pairs), 64, replace=False))
+    total = check_pairs_vs_oracle(oracle, imgs, pairs, sel, offs, qt, d)
+    assert total > 64 * 50
+    # prefilter == brute force on a 500-pair subset
+    sub = np.sort(np.random.default_rng(3).choice(len(pairs), 500, replace=False))
+    a = gpu_ctx.match_pairs(pairs[sub])
+    gpu_ctx.set_prefilter(False)
+    try:
+        bres = gpu_ctx.match_pairs(pairs[sub])
+        assert gpu_ctx.profile()["prefilter_pairs"] == 0
+    finally:
+        gpu_ctx.set_prefilter(True)
+    assert same_result(a, bres)
+    # and the subset call returns exactly the slices of the full-job call
+    for k, pp in enumerate(sub):
+        s, e = offs[pp], offs[pp + 1]
+        assert np.array_equal(a[1][a[0][k]:a[0][k + 1]], qt[s:e])
+    # the job in 3 sub-batches == the job in one
+    gpu_ctx.set_limits(3000, 0)
+    try:
+        split = gpu_ctx.match_pairs(pairs)
+        assert gpu_ctx.profile()["sub_batches"] == 3
+    finally:
+        gpu_ctx.set_limits(0, 0)
+    assert same_result((offs, qt, d), split)
+
+
+# ---- (c) config 3 ---------------------------------------------------------------------------------------------
+
+def test_config3_330_images_in_one_call(gpu_ctx, oracle):
+    imgs, pairs, _ = synth.job("south-building", 330, seed=1235)
+    assert len(pairs) == 54285
+    for i, im in enumerate(imgs):
+        gpu_ctx.upload_image(i, im)
+    gpu_ctx.set_limits(0, 0)
+    offs, qt, d = gpu_ctx.match_pairs(pairs, fetch="view")
+    offs, qt, d = offs.copy(), qt.copy(), d.copy()
+    p = gpu_ctx.profile()
+    assert p["sub_batches"] >= 4 and p["prefilter_pairs"] == 54285 and p["fallback_pairs"] == 0
+    # sampled pairs, biased towards the sub-batch boundaries (multiples of 16384 pairs)
+    rng = np.random.default_rng(5)
+    edge = np.array([0, 16383, 16384, 32767, 32768, 49151, 49152, 54284])
+    sel = np.unique(np.concatenate([edge, rng.choice(len(pairs), 24, replace=False)]))
+    check_pairs_vs_oracle(oracle, imgs, pairs, sel, offs, qt, d)
+    # a different cut of the same job gives the same lists
+    gpu_ctx.set_limits(20000, 0)
+    try:
+        again = gpu_ctx.match_pairs(pairs, fetch="view")
+        assert gpu_ctx.profile()["sub_batches"] == 3
+        assert same_result((offs, qt, d), again)
+    finally:
+        gpu_ctx.set_limits(0, 0)
+    gpu_ctx.clear_images()
+
+
+# ---- (d) integer descriptors vs the exact-integer reference -----------------------------------------------------
+
+@pytest.mark.parametrize("prefilter", [True, False])
+def test_u8_job_equals_the_integer_reference(gpu_ctx, prefilter):
+    from oracle import int_oracle as io
+    sizes = [1500, 1201, 640, 2048, 300]
+    u = synth.u8_images(len(sizes), sizes, seed=4242, dup_frac=0.1, as_float=False)
+    u[1][7] = u[1][3]
+    u[0][10] = u[1][3]
+    u[0][0] = u[1][40]
+    pairs = synth.all_pairs(len(sizes))
+    for i, im in enumerate(u):
+        gpu_ctx.upload_image(i, im)      # uint8 upload
+    gpu_ctx.set_prefilter(prefilter)
+    try:
+        for kw in ({"ratio": 0.8, "cross_check": True, "max_distance": 1e9}, {"ratio": 0.95, "cross_check": False, "max_distance": 420.0}):
+            offs, qt, d = gpu_ctx.match_pairs(pairs, **kw)
+            for p, (i, j) in enumerate(pairs):
+                q, t, dd = io.match_pair(u[i], u[j], **kw)
+                s, e = offs[p], offs[p + 1]
+                assert np.array_equal(qt[s:e, 0], q) and np.array_equal(qt[s:e, 1], t) and np.array_equal(b(d[s:e]), b(dd)), (i, j, kw)
+        fwd, rev = gpu_ctx.knn2_pair(0, 1)
+        rf, rr = io.knn2(u[0], u[1]), io.knn2(u[1], u[0])
+        assert np.array_equal(fwd[0], rf[0]) and np.array_equal(b(fwd[1]), b(rf[1])) and np.array_equal(b(fwd[2]), b(rf[3]))
+        assert np.array_equal(rev[0], rr[0]) and np.array_equal(b(rev[1]), b(rr[1])) and np.array_equal(b(rev[2]), b(rr[3]))
+    finally:
+        gpu_ctx.set_prefilter(True)
+
+
+def test_tie_queue_grows_instead_of_failing(built_lib, oracle):
+    """More sqrt-space ties in one batch than the initial queue holds (duplicate train descriptors; kNN-level API
+    and ratio > 1 lists): the queue grows and the batch is re-run; round 1 returned MSFM_E_CAPACITY here."""
+    from monocularsfm_amd import _lib
+    rng = np.random.default_rng(11)
+    base = synth.u8_images(1, 600, seed=99, as_float=True)[0]
+    k = rng.integers(0, 40, 70000)
+    A = np.clip(base[k] + np.rint(rng.normal(0, 3.0, (70000, 128))), 0, 255).astype(F32)
+    B = np.concatenate([base[:40], base[:40], base[40:300]])      # train rows 0..39 == rows 40..79: every query ties
+    rows = rng.choice(len(A), 300, replace=False)
+    oi0, od0, _, od1 = oracle.knn2(A[rows], B, 0, 8)
+    assert (od0 == od1).all() and (od0 > 0).all() and (oi0 < 40).all()
+    oq, ot, od = oracle.match_pair(A[:2000], B, 1.5, False, 1e9, nthreads=8)
+    assert len(oq) == 2000
+    for mode in (True, False):
+        with _lib.Context(0) as ctx:           # a fresh context: the queue starts at its initial capacity
+            ctx.upload_image(0, A)
+            ctx.upload_image(1, B)
+            ctx.set_prefilter(mode)
+            fwd, rev = ctx.knn2_pair(0, 1)
+            prof = ctx.profile()
+            assert prof["tie_rows"] >= 70000 and prof["tie_queue_regrows"] == 1, prof
+            assert np.array_equal(fwd[0][rows], oi0) and np.array_equal(b(fwd[1][rows]), b(od0)) and np.array_equal(b(fwd[2][rows]), b(od1))
+            assert (fwd[0] < 40).all() and (fwd[1] == fwd[2]).all()
+            ctx.upload_image(2, A[:2000])
+            q, t, d = ctx.match_pair(2, 1, 1.5, False, 1e9)     # ratio > 1: tied rows DO reach the list
+            assert np.array_equal(q, oq) and np.array_equal(t, ot) and np.array_equal(b(d), b(od))
+            q, t, d = ctx.match_pair(0, 1, 0.8, True, 1e9)       # ratio <= 1: no fix-up needed, none queued
+            assert ctx.profile()["tie_queue_regrows"] == 0 and len(q) == 0

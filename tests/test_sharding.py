@@ -45,7 +45,11 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out_dir):
+SIZES = [90, 120, 60, 100, 2, 75, 110]
+SKEWED = [4, 5, 4, 6, 300, 310, 4, 5, 6]   # one pair outweighs total / world: middle ranks get EMPTY ranges
+
+
+def _worker(rank, world, port, out_dir, sizes=SIZES):
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
     from monocularsfm_amd import synth
@@ -54,9 +58,9 @@ def _worker(rank, world, port, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    imgs = synth.rootsift_images(7, [90, 120, 60, 100, 2, 75, 110], seed=21, n_proto=260)
+    imgs = synth.rootsift_images(len(sizes), sizes, seed=21, n_proto=260)
     n_rows = np.array([len(x) for x in imgs])
-    pairs = np.array([(i, j) for i in range(7) for j in range(i)], np.int32)
+    pairs = synth.all_pairs(len(sizes))
 
     def match_fn(sub):
         offs = [0]
@@ -87,12 +91,16 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_multi_rank_gather_equals_single_process(tmp_path, oracle, world):
+@pytest.mark.parametrize("world,sizes", [(2, SIZES), (3, SIZES), (4, SKEWED)], ids=["w2", "w3", "w4-skewed-empty-middle-ranks"])
+def test_multi_rank_gather_equals_single_process(tmp_path, oracle, world, sizes):
     from monocularsfm_amd import synth
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
-    imgs = synth.rootsift_images(7, [90, 120, 60, 100, 2, 75, 110], seed=21, n_proto=260)
-    pairs = [(i, j) for i in range(7) for j in range(i)]
+    from monocularsfm_amd.sharding import partition_pairs
+    if sizes is SKEWED:
+        parts = partition_pairs(synth.all_pairs(len(sizes)), np.array(sizes), world)
+        assert [len(p) for p in parts][1:3] == [0, 0] and len(parts[3]) > 0, "test data: middle ranks should be empty"
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), sizes), nprocs=world, join=True)
+    imgs = synth.rootsift_images(len(sizes), sizes, seed=21, n_proto=260)
+    pairs = [(i, j) for i in range(len(sizes)) for j in range(i)]
     exp_q, exp_d, exp_off = [], [], [0]
     for i, j in pairs:
         q, t, d = oracle.match_pair(imgs[i], imgs[j])
@@ -101,7 +109,7 @@ def test_multi_rank_gather_equals_single_process(tmp_path, oracle, world):
         exp_off.append(exp_off[-1] + len(q))
     exp_q = np.concatenate(exp_q)
     exp_d = np.concatenate(exp_d)
-    assert exp_off[-1] > 30
+    assert exp_off[-1] > 15
     for r in range(world):
         g = np.load(os.path.join(str(tmp_path), "r%d.npz" % r))
         assert np.array_equal(g["offs"], np.asarray(exp_off))
