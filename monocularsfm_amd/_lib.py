@@ -10,6 +10,8 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libmsfm_match.so")
+if os.environ.get("MSFM_LIBRARY"):   # development hook: an alternative build of the same C ABI (tools/variant_bench.sh)
+    LIB_PATH = os.path.abspath(os.environ["MSFM_LIBRARY"])
 
 OK, E_INVALID, E_DEVICE, E_NOIMAGE, E_CAPACITY, E_STATE = range(6)
 DTYPE_F32, DTYPE_U8 = 0, 1

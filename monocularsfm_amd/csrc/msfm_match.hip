@@ -507,9 +507,9 @@ int plan_sweep2(msfm_ctx* ctx, Batch& b, const std::vector<char>& compact, const
 
 // MFMA prefilter + exact re-check for the pairs on path 1.  On return pairs whose candidate list
 // overflowed have been moved to path 0.
-//   sweep 1 (approx_kernel<1>): S~ minima per row / column -> thresholds (with pruning for match lists)
-//   sweep 2: dense pairs re-sweep everything (approx_kernel<2>); pairs where pruning left few live rows
-//            and columns sweep only those, compacted per direction (approx_kernel<3>)
+//   sweep 1 (sweep_kernel<1>): S~ minima per row / column -> thresholds (with pruning for match lists)
+//   sweep 2: dense pairs re-sweep everything (sweep_kernel<2>); pairs where pruning left few live rows
+//            and columns sweep only those, compacted per direction (sweep_kernel<3>)
 //   exact pinned-order S of the candidates, 64-bit atomicMin reduce, finalize
 int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
     const size_t P = b.pairs.size();
@@ -548,12 +548,12 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
     float* tuv = ctx->d_tu.as<float>();  // rows at kf offsets, columns at kr offsets (one buffer)
     hc.lap("sweep-1 setup + uploads");
     HIPCHK(ctx, hipEventRecord(e0, ctx->stream));
-    hipLaunchKernelGGL(approx_kernel<1>, dim3((unsigned)b.items.size()), block, kPfLdsBytes, ctx->stream, dp, dpf,
+    hipLaunchKernelGGL(sweep_kernel<1>, dim3((unsigned)b.items.size()), block, kPfLdsBytes, ctx->stream, dp, dpf,
                        ctx->d_items.as<WorkItem>(), ctx->d_rp_s0.as<float>(), ctx->d_rp_s1.as<float>(),
                        ctx->d_cp_s0.as<float>(), ctx->d_cp_s1.as<float>(), (const float*)nullptr, (const float*)nullptr,
                        (int2*)nullptr, (unsigned long long*)nullptr);
     HIPCHK(ctx, hipGetLastError());
-    DBGSYNC(ctx, "approx_kernel<1>");
+    DBGSYNC(ctx, "sweep_kernel<1>");
     HIPCHK(ctx, hipEventRecord(e1, ctx->stream));
     ctx->prof.approx_kernel_launches += 1;
     const dim3 mgrid((unsigned)((b.max_npad + 255) / 256), (unsigned)P);
@@ -633,20 +633,20 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
     hc.lap("sweep-2 descriptors + uploads");
     HIPCHK(ctx, hipEventRecord(e2, ctx->stream));
     if (!ditems.empty()) {
-        hipLaunchKernelGGL(approx_kernel<2>, dim3((unsigned)ditems.size()), block, kPfLdsBytes, ctx->stream, dp, dpf,
+        hipLaunchKernelGGL(sweep_kernel<2>, dim3((unsigned)ditems.size()), block, kPfLdsBytes, ctx->stream, dp, dpf,
                            ctx->d_items.as<WorkItem>(), (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr,
                            (const float*)tuv, (const float*)tuv, ctx->d_cand.as<int2>(), ctx->d_cand_count.as<unsigned long long>());
         HIPCHK(ctx, hipGetLastError());
-    DBGSYNC(ctx, "approx_kernel<2>");
+    DBGSYNC(ctx, "sweep_kernel<2>");
         ctx->prof.sweep2_launches += 1;
     }
     if (V > 0) {
-        hipLaunchKernelGGL(approx_kernel<3>, dim3((unsigned)vitems.size()), block, kPfLdsBytes, ctx->stream,
+        hipLaunchKernelGGL(sweep_kernel<3>, dim3((unsigned)vitems.size()), block, kPfLdsBytes, ctx->stream,
                            ctx->d_vpairs.as<PairDesc>(), ctx->d_vpf.as<PfPair>(), ctx->d_vitems.as<WorkItem>(), (float*)nullptr,
                            (float*)nullptr, (float*)nullptr, (float*)nullptr, ctx->d_cmp_tu.as<float>(), (const float*)nullptr,
                            ctx->d_cand.as<int2>(), ctx->d_cand_count.as<unsigned long long>() + P);
         HIPCHK(ctx, hipGetLastError());
-    DBGSYNC(ctx, "approx_kernel<3>");
+    DBGSYNC(ctx, "sweep_kernel<3>");
         ctx->prof.sweep2_launches += 1;
     }
     HIPCHK(ctx, hipEventRecord(e3, ctx->stream));
@@ -883,11 +883,11 @@ int msfm_create(int device_ordinal, msfm_ctx** out_ctx) {
         delete ctx;
         return MSFM_E_DEVICE;
     }
-    hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(approx_kernel<1>),
+    hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(sweep_kernel<1>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, kPfLdsBytes);
-    hipError_t e3 = hipFuncSetAttribute(reinterpret_cast<const void*>(approx_kernel<2>),
+    hipError_t e3 = hipFuncSetAttribute(reinterpret_cast<const void*>(sweep_kernel<2>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, kPfLdsBytes);
-    hipError_t e4 = hipFuncSetAttribute(reinterpret_cast<const void*>(approx_kernel<3>),
+    hipError_t e4 = hipFuncSetAttribute(reinterpret_cast<const void*>(sweep_kernel<3>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, kPfLdsBytes);
     if (e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess) {
         std::fprintf(stderr, "msfm_create: cannot reserve %d bytes of LDS for the prefilter kernels\n", kPfLdsBytes);

@@ -52,21 +52,22 @@ constexpr float kEpsRel = 1.5e-3f;
 constexpr float kEpsAbs = 1.0e-6f;
 constexpr float kF16Safe = 6.0e4f;
 
-#ifndef MSFM_RB
-#define MSFM_RB 2
-#endif
-constexpr int kPfRB = MSFM_RB;            // 32-row MFMA blocks per wave (A fragments of 32 kPfRB rows stay in registers)
-constexpr int kPfWaveRows = 32 * kPfRB;
-constexpr int kPfWgRows = 4 * kPfWaveRows; // A rows per workgroup / work item
-constexpr int kPfThreads = 256;           // 4 waves
+constexpr int kPfRB = 2;                  // 32-row MFMA blocks per wave (their A fragments stay in registers)
+constexpr int kPfWaveRows = 32 * kPfRB;   // 64
+constexpr int kPfWaves = 8;               // two per SIMD: waves w and w + 4 share a SIMD and alternate roles (below)
+constexpr int kPfWgRows = kPfWaves * kPfWaveRows;  // 512 A rows per workgroup / work item
+constexpr int kPfThreads = 64 * kPfWaves;
 constexpr int kPfBT = 64;                 // B rows per tile
 constexpr int kHalfRowBytes = kDim * 2;   // one fp16 descriptor = 256 B = 16 granules of 16 B
-constexpr int kPfLdsB = kPfBT * kHalfRowBytes;  // 16 KiB per slot
-constexpr int kPfCandBuf = 256;                  // per-wave LDS candidate buffer (pass 2), int2 entries
-constexpr int kPfExtB = kPfBT * 16;              // the tile's norm quadruples: 16 B per row
-// B ring 48 KiB | per-wave quadruple rings 12 KiB | per-wave column-threshold rings 3 KiB | zero granule |
-// per-wave candidate buffers 8 KiB | column partials 6 KiB
-constexpr int kPfLdsBytes = 3 * kPfLdsB + 4 * 3 * kPfExtB + 4 * 3 * 64 * 4 + 64 + 4 * kPfCandBuf * 8 + 3 * 4 * 64 * 8;
+constexpr int kPfLdsB = kPfBT * kHalfRowBytes;  // 16 KiB per ring slot
+constexpr int kPfRing = 4;                // B tiles in LDS: DMA runs three tiles ahead
+constexpr int kPfColRing = 2;             // tiles of column partials in LDS
+constexpr int kPfCandBuf = 256;           // per-wave LDS candidate buffer (sweep 2), int2 entries
+constexpr int kPfExtB = kPfBT * 16;       // the tile's norm quadruples: 16 B per row
+// B ring 64 KiB | per-wave quadruple rings 32 KiB | per-wave column-threshold rings 8 KiB | zero granule 64 B |
+// per-wave candidate buffers 16 KiB | column partials 8 KiB  = 128 KiB + 64 B: one workgroup per CU
+constexpr int kPfLdsBytes = kPfRing * kPfLdsB + kPfWaves * kPfRing * kPfExtB + kPfWaves * kPfRing * 64 * 4 + 64 +
+                            kPfWaves * kPfCandBuf * 8 + kPfColRing * kPfWaves * 64 * 8;
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef float f16v __attribute__((ext_vector_type(16)));
@@ -155,587 +156,7 @@ __device__ __forceinline__ void v2_merge(float& s0, float& s1, float b0, float b
     s0 = fminf(s0, b0);
 }
 
-// ---------------------------------------------------------------------------------------------
-// approx_kernel<PASS>: one workgroup (4 waves) = one 256-row A block x a range of 64-row B tiles.
-//   Wave w owns A rows w*64..w*64+63 for the whole item: its fp16 A fragments (two 32-row MFMA
-//   blocks x 9 k-steps, the ninth holding the norm / threshold quadruple) live in registers, loaded
-//   once straight from HBM.  Only B tiles stream through LDS: a ring of three 16 KiB slots filled by
-//   LDS-DMA two tiles ahead, synchronised with raw s_barrier + COUNTED s_waitcnt vmcnt(N) so the two
-//   younger tiles stay in flight across the barrier.  The tile's norm quadruples (and the dense sweep's
-//   column thresholds) ride along as per-wave DMAs, so the loop contains no ordinary global load that
-//   would make hipcc drain vmcnt(0).
-//   Per tile and column block: 2 x (8 MFMA 32x32x16 f16 + 1 MFMA 32x32x8 f16 for the norm quadruple), then the
-//   epilogue on the 2 x 16 results.
-//   MFMA layout: lane l feeds A[row l&31][k (l>>5)*8..+7] and B[col l&31][same k]; it receives for
-//   column l&31 the 16 rows (r&3) + 8 (r>>2) + 4 (l>>5), r = 0..15.
-// PASS 1: accumulator = -S~/2.  Row maxima (1 op / element), column maxima (v_max3: 0.5 op / element);
-//         the two smallest S~ per row (merged over the 32 lanes at the end) and per column (lane pair
-//         merged, the four waves folded in LDS) are written as partials.
-// PASS 2: accumulator = -S~/2; append (q, t) where S~ <= T_row[q] or S~ <= T_col[t].
-// PASS 3: A = compacted live rows, accumulator = -(S~ - T_row)/2; append (k, t) where it is >= 0.
-//         PASS 2 / 3 first reduce the block to "any hit?" with v_max3 and only then build the bit mask.
-// VMEM LOADS per wave per tile (the counted wait depends on it): PASS 1 / 3: 5 DMA, PASS 2: 6 DMA.
-// Stores and the rare candidate flushes only add ops, which makes the wait more conservative.
-// ---------------------------------------------------------------------------------------------
-constexpr int kPfRing = 3;
-
-// Timing experiments only (results are WRONG unless 0): 1 no epilogue VALU, 2 no MFMA, 3 B fragments read
-// from LDS once per item instead of per block, 4 no barrier / DMA in the loop, 5 = 1 + 3, 6 = 1 + 3 + 4
-#ifndef MSFM_ABL
-#define MSFM_ABL 0
-#endif
-#ifndef MSFM_MERGE_LATE
-#define MSFM_MERGE_LATE 0
-#endif
-#ifndef MSFM_DMA_LATE
-#define MSFM_DMA_LATE 5
-#endif
-#ifndef MSFM_PIPE
-#define MSFM_PIPE 0    // 1: block-level software pipeline (experiment, see the loop)
-#endif
-#ifndef MSFM_SCHED
-#define MSFM_SCHED 0   // scheduling experiments (tools/variant_bench.sh); 0 = production
-#endif
-
-constexpr bool kAblNoEpi = MSFM_ABL == 1 || MSFM_ABL == 5 || MSFM_ABL == 6;
-constexpr bool kAblNoMfma = MSFM_ABL == 2;
-constexpr bool kAblNoLds = MSFM_ABL == 3 || MSFM_ABL == 5 || MSFM_ABL == 6;
-constexpr bool kAblNoSync = MSFM_ABL == 4 || MSFM_ABL == 6;
-
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-
-__device__ __forceinline__ float max3f(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }  // folds to v_max3_f32
-
-template <int PASS>
-__global__ __launch_bounds__(kPfThreads, kPfRB <= 2 ? 2 : 1) void approx_kernel(
-    const PairDesc* __restrict__ pairs, const PfPair* __restrict__ pf, const WorkItem* __restrict__ items,
-    float* __restrict__ rp_s0, float* __restrict__ rp_s1, float* __restrict__ cp_s0, float* __restrict__ cp_s1,
-    const float* __restrict__ tu, const float* __restrict__ tv, int2* __restrict__ cand,
-    unsigned long long* __restrict__ cand_count /* 64-bit: n1 * n2 hits of a flooded list do not fit 32 bits */) {
-    typedef const __attribute__((address_space(1))) float* gfloat_p;  // keep these loads off the FLAT path
-    typedef const __attribute__((address_space(1))) h8* gh8_p;
-    extern __shared__ __attribute__((aligned(16))) char pf_smem[];
-    char* sB = pf_smem;
-    char* sExt = pf_smem + kPfRing * kPfLdsB;                                    // [wave][slot][64 rows x 16 B]
-    float* sThr = reinterpret_cast<float*>(sExt + 4 * kPfRing * kPfExtB);        // [wave][slot][64]
-    char* sZero = reinterpret_cast<char*>(sThr + 4 * kPfRing * 64);              // 64 B, first 16 used
-    char* sCand = sZero + 64;
-
-    const WorkItem item = items[blockIdx.x];
-    if (item.pair < 0) return;
-    const PfPair pp = pf[item.pair];
-    if (!pp.use) return;
-    const PairDesc pd = pairs[item.pair];
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lcol = lane & 31, lhalf = lane >> 5;
-
-    // 64-row tiles; the last 128-row block of the B image may hold an all-padding second tile: skip it
-    const int t_begin = item.bt_begin * 2, t_end = min(item.bt_end * 2, max(item.bt_begin * 2 + 1, (pd.n2 + kPfBT - 1) / kPfBT));
-    const char* gB = reinterpret_cast<const char*>(pp.b_h);
-    const char* gE = reinterpret_cast<const char*>(pp.b_ext);
-    const gfloat_p g_anrm = (gfloat_p)pp.a_nrm;
-    const gfloat_p g_tu = (gfloat_p)tu;
-    char* ext_w = sExt + wave * (kPfRing * kPfExtB);   // this wave's private copies
-    float* thr_w = sThr + wave * (kPfRing * 64);
-
-    // DMA group of tile tt (clamped: the tail re-fetches the last tile so every iteration issues the
-    // same number of VMEM ops): this wave's quarter of the 16 KiB tile + its private quadruples / thresholds
-    auto dma_tile = [&](int tt) {
-        const int tc = tt < t_end ? tt : t_end - 1;
-        const int sl = (tt - t_begin) % kPfRing;
-        const char* g = gB + (size_t)tc * kPfLdsB + wave * 4096 + lane * 16;
-        char* l = sB + sl * kPfLdsB + wave * 4096;
-#pragma unroll
-        for (int k = 0; k < (MSFM_ABL == 9 ? 2 : 4); ++k)  // ablation 9: half of the tile DMA (timing experiment)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + k * 1024),
-                                             (__attribute__((address_space(3))) void*)(l + k * 1024), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gE + (size_t)tc * kPfExtB + lane * 16),
-                                         (__attribute__((address_space(3))) void*)(ext_w + sl * kPfExtB), 16, 0, 0);
-        if (PASS == 2)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(tv + pp.tv_off + tc * kPfBT + lane),
-                                             (__attribute__((address_space(3))) void*)(thr_w + sl * 64), 4, 0, 0);
-    };
-    constexpr int kDmaOps = ((PASS == 2) ? 6 : 5) - (MSFM_ABL == 9 ? 2 : 0);
-    // where tile t+2's DMA pieces are issued in iteration t: 0 right after the barrier, 1 at the end of the iteration,
-    // 2 / 3 between / before the epilogues (MSFM_DMA_LATE: 4 = end of iteration in sweep 1 only; 5 = the default:
-    // before the epilogues in sweep 1 (-2.4 .. -4.7 %: among the epilogue's VALU work a 1-KiB piece costs the wave
-    // less than among the ds_reads and MFMAs right after the barrier), right after the barrier in sweep 2)
-    constexpr int kDmaLate = (MSFM_DMA_LATE == 4) ? (PASS == 1 ? 1 : 0) : (MSFM_DMA_LATE == 5) ? (PASS == 1 ? 3 : 0) : MSFM_DMA_LATE;
-
-    dma_tile(t_begin);
-    dma_tile(t_begin + 1);
-    if (tid < 4) reinterpret_cast<float*>(sZero)[tid] = 0.f;
-
-    // A fragments: rows a_blk*256 + wave*64 + rb*32 + lcol, granule 2*ks + lhalf (stored at ^ (row & 15));
-    // ninth k-step: [-c, -c, x_hi, x_lo, 0...] in the lhalf == 0 lanes (k = 128..135), zeros in the others
-    h8 af[kPfRB][9];
-    const float inv_c = 1.f / pp.b_c;
-#pragma unroll
-    for (int rb = 0; rb < kPfRB; ++rb) {
-        const int frow = item.a_blk * kPfWgRows + wave * kPfWaveRows + rb * 32 + lcol;
-        const gh8_p ga = (gh8_p)(pp.a_h) + (size_t)frow * 16;
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks) af[rb][ks] = ga[(2 * ks + lhalf) ^ (frow & 15)];
-        // padding rows: X = -inf -> accumulator -inf, never a maximum, never a hit
-        float X;
-        if (PASS == 3) X = frow < pd.n1 ? 0.5f * g_tu[pp.tu_off + frow] : -f_inf();
-        else X = frow < pd.n1 ? -0.5f * g_anrm[frow] : -f_inf();
-        const float xs = X * inv_c;
-        const _Float16 hi = (_Float16)xs;
-        const float rest = xs - (float)hi;
-        const _Float16 lo = (rest == rest && fabsf(rest) < 3.0e38f) ? (_Float16)rest : (_Float16)0.f;
-        h8 e;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) e[j] = (_Float16)0.f;
-        if (lhalf == 0) {
-            e[0] = (_Float16)(-pp.b_c);
-            e[1] = (_Float16)(-pp.b_c);
-            e[2] = hi;
-            e[3] = lo;
-        }
-        af[rb][8] = e;
-    }
-
-    // this lane's 32 result rows: (rb, r) -> row = a_blk*256 + wave*64 + rb*32 + (r&3) + 8*(r>>2) + 4*lhalf
-    const int arow_base = item.a_blk * kPfWgRows + wave * kPfWaveRows + 4 * lhalf;
-    // rs0: PASS 1 running row maximum of the accumulator (-S~min/2); PASS 2 the row's hit level -T_row/2
-    float rs0[kPfRB][16];
-#pragma unroll
-    for (int rb = 0; rb < kPfRB; ++rb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int rr = arow_base + rb * 32 + (r & 3) + 8 * (r >> 2);
-            rs0[rb][r] = (PASS == 2) ? (rr < pd.n1 ? -0.5f * g_tu[pp.tu_off + rr] : f_inf()) : -f_inf();
-        }
-    // Make hipcc itself wait for the fragment loads here (a register use it can see): otherwise its
-    // scoreboard still holds them as pending at the first MFMA and it drains vmcnt(0) INSIDE the loop,
-    // which would serialise the DMA ring.
-#pragma unroll
-    for (int rb = 0; rb < kPfRB; ++rb)
-#pragma unroll
-        for (int ks = 0; ks < 9; ++ks) asm volatile("" ::"v"(af[rb][ks]));
-    wait_vmcnt<0>();  // prologue loads (and the first two DMA groups) are done: counted waits start clean
-
-    // sweep 2: wave-private candidate buffer in LDS
-    int2* cbuf = reinterpret_cast<int2*>(sCand) + wave * kPfCandBuf;
-    const unsigned cbuf_lds = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)cbuf;
-    // sweep 1: column partials of the four waves meet in LDS ([ring slot][wave][64 columns] x (s0, s1)) and
-    // are merged by one wave two tiles later: 4x less partial traffic to HBM than one slot per wave
-    const unsigned colbuf_lds = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)(sCand + 4 * kPfCandBuf * 8);
-    int n_buf = 0;  // wave-uniform
-    auto flush_candidates = [&]() {
-        if (n_buf == 0) return;
-        unsigned long long base64 = 0;
-        if (lane == 0) base64 = atomicAdd(&cand_count[item.pair], (unsigned long long)n_buf);
-        // beyond the capacity nothing is stored: the clamped base keeps the test below false for every k
-        const int base = __builtin_amdgcn_readfirstlane((int)(base64 < (unsigned long long)pp.cand_cap ? base64 : (unsigned long long)pp.cand_cap));
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the asm ds_writes below are not tracked by hipcc
-        for (int k = lane; k < n_buf; k += 64)
-            if (base + k < pp.cand_cap) cand[pp.cand_off + base + k] = cbuf[k];
-        n_buf = 0;
-    };
-
-    const int xb = lcol & 15;  // both column blocks: row & 15 == lcol & 15
-    const bool wave_active = item.a_blk * kPfWgRows + wave * kPfWaveRows < pd.n1;  // wave-uniform
-    if (PASS == 1 && !wave_active) {
-        // its column partials are never written: park (+inf, +inf) in all three ring slots once
-        const float2 pr = make_float2(f_inf(), f_inf());
-#pragma unroll
-        for (int sl = 0; sl < kPfRing; ++sl)
-            asm volatile("ds_write_b64 %0, %1" ::"v"(colbuf_lds + (unsigned)((sl * 4 + wave) * 64 + lane) * 8u), "v"(pr) : "memory");
-    }
-
-    // ---- the two halves of the software pipeline -------------------------------------------------
-    // A "block" is (tile, column block): per wave 2 x 16 MFMA results per lane.
-    // stage(): issue the 18 MFMAs of block k+1 into `nxt` while the VALU epilogue of block k (in `cur`)
-    // runs -- in ONE basic block, so the scheduler can interleave them: co-resident waves run in
-    // lockstep (same barriers), only the overlap inside a wave keeps both pipes busy.
-    struct BlockMeta { float hc; int col; int cslot; };  // hc: PASS 2 column hit level -T_col/2; cslot: LDS slot of the column partials
-    const int zero_off = (int)(sZero - pf_smem);
-    int abl_t = t_begin;
-    auto load_bf = [&](const char* pb, int pe_off, int cb, h8 (&bf)[9]) {
-        if (kAblNoLds && abl_t != t_begin) return;
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks)
-            bf[ks] = *reinterpret_cast<const h8*>(pb + cb * 32 * kHalfRowBytes + (((2 * ks + lhalf) ^ xb) << 4));
-        // ninth k-step: the quadruple of column cb*32 + lcol for k = 128..135, the zero granule for k = 136..143
-        // (one base pointer + selected offset: a select between two pointers makes hipcc drain vmcnt(0))
-        bf[8] = *reinterpret_cast<const h8*>(pf_smem + (lhalf == 0 ? pe_off + (cb * 32 + lcol) * 16 : zero_off));
-    };
-    auto mfma_block = [&](const h8 (&bf)[9], f16v (&acc)[kPfRB]) {
-        if (kAblNoMfma) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-#pragma unroll
-                for (int rb = 0; rb < kPfRB; ++rb) acc[rb][r] += (float)bf[(r + rb) & 7][0] + (float)bf[8][r & 7];
-            return;
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-#pragma unroll
-            for (int rb = 0; rb < kPfRB; ++rb) acc[rb][r] = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks)
-#pragma unroll
-            for (int rb = 0; rb < kPfRB; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[rb][ks], bf[ks], acc[rb], 0, 0, 0);
-        {   // the quadruple only fills k = 0..3: the K = 8 instruction (lane l: k = 4 (l >> 5) .. +3) takes half the passes
-            typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-            const h4 b4 = __builtin_shufflevector(bf[8], bf[8], 0, 1, 2, 3);
-#pragma unroll
-            for (int rb = 0; rb < kPfRB; ++rb)
-                acc[rb] = __builtin_amdgcn_mfma_f32_32x32x8f16(__builtin_shufflevector(af[rb][8], af[rb][8], 0, 1, 2, 3), b4, acc[rb], 0, 0, 0);
-        }
-    };
-    // branch-free part of the epilogue; returns "this lane saw a hit" for the sweep-2 variants
-    auto epilogue_valu = [&](const f16v (&acc)[kPfRB], const BlockMeta& bm, bool do_rows = true) -> bool {
-        if (kAblNoEpi) {
-            rs0[0][0] = fmaxf(rs0[0][0], acc[0][0] + acc[kPfRB - 1][15]);
-            return false;
-        }
-        // column maximum of the accumulator over this lane's 32 rows: 16 v_max3
-        float m = -f_inf();
-        if (PASS != 2) {
-#pragma unroll
-            for (int rb = 0; rb < kPfRB; ++rb)
-#pragma unroll
-                for (int r = 0; r < 16; r += 2) m = max3f(m, acc[rb][r], acc[rb][r + 1]);
-        }
-        if (PASS == 1) {
-            // Only MAXIMA are tracked: the second smallest of the minima of S~ over disjoint subsets is an
-            // upper bound of the true second-smallest S~, which is all the threshold needs (it is exact
-            // unless both neighbours fall into one subset).
-            if (do_rows) {
-#pragma unroll
-                for (int rb = 0; rb < kPfRB; ++rb)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) rs0[rb][r] = fmaxf(rs0[rb][r], acc[rb][r]);
-            }
-            // partner lane (l ^ 32): the other 32 rows of the wave
-            const float other = __shfl_xor(m, 32);
-            // (s0, s1) of this wave's 64 rows for column bm.col -> LDS (inline asm: see append_hits)
-            if (lhalf == 0) {
-                const float2 pr = make_float2(-2.f * fmaxf(m, other), -2.f * fminf(m, other));
-                asm volatile("ds_write_b64 %0, %1" ::"v"(colbuf_lds + (unsigned)(bm.cslot + lcol) * 8u), "v"(pr) : "memory");
-            }
-            return false;
-        } else if (PASS == 3) {
-            return m >= 0.f;
-        } else {
-            // row criterion: max over (acc - level_row) >= 0; column criterion: max over acc >= level_col
-            float mr = -f_inf(), mc = -f_inf();
-#pragma unroll
-            for (int rb = 0; rb < kPfRB; ++rb)
-#pragma unroll
-                for (int r = 0; r < 16; r += 2) {
-                    mr = max3f(mr, acc[rb][r] - rs0[rb][r], acc[rb][r + 1] - rs0[rb][r + 1]);
-                    mc = max3f(mc, acc[rb][r], acc[rb][r + 1]);
-                }
-            return mr >= 0.f || mc >= bm.hc;
-        }
-    };
-    // sweep 2, rare path: the block holds at least one hit -> bit mask per lane (element k = rb*16 + r at
-    // bit 31-k), slotted with ballot/popcount into this wave's LDS buffer -- no atomics in the loop --
-    // and flushed to the pair's global list when the buffer fills up
-    auto append_hits = [&](bool any, const f16v (&acc)[kPfRB], const BlockMeta& bm) {
-        if (__ballot(any) == 0ull) return;
-        unsigned long long mask = 0;   // element k = rb*16 + r at bit (16 kPfRB - 1 - k)
-        constexpr int kEl = 16 * kPfRB;
-#pragma unroll
-        for (int rb = 0; rb < kPfRB; ++rb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                // padding rows / columns hold -inf: with an infinite threshold (fewer than two real elements in
-                // a subset) the hit level is -inf as well, and -inf >= -inf must not count
-                const bool hit = (PASS == 3) ? (acc[rb][r] >= 0.f)
-                                             : (acc[rb][r] > -f_inf() && (acc[rb][r] >= rs0[rb][r] || acc[rb][r] >= bm.hc));
-                mask = mask + mask + (hit ? 1ull : 0ull);
-            }
-        while (__ballot(mask != 0ull) != 0ull) {
-            const bool hit = mask != 0ull;
-            const int k = __clzll((long long)mask) - (64 - kEl);  // first remaining element of this lane
-            const unsigned long long mm = __ballot(hit);
-            if (n_buf + 64 > kPfCandBuf) flush_candidates();
-            if (hit) {
-                mask &= ~(1ull << (kEl - 1 - k));
-                const int slt = n_buf + __popcll(mm & ((1ull << lane) - 1ull));
-                // inline asm on purpose: hipcc would first drain vmcnt(0) for a compiler-visible LDS store
-                const int2 e = make_int2(arow_base + (k >> 4) * 32 + (k & 3) + 8 * ((k & 15) >> 2), bm.col);
-                asm volatile("ds_write_b64 %0, %1" ::"v"(cbuf_lds + slt * 8), "v"(e) : "memory");
-            }
-            n_buf += __popcll(mm);
-        }
-    };
-    // sweep 1: lane = column of tile tt; fold the four waves' (s0, s1) and store one partial per A block
-    auto merge_columns = [&](int tt) {
-        const unsigned base = colbuf_lds + (unsigned)((((tt - t_begin) % kPfRing) * 4) * 64 + lane) * 8u;
-        float2 w0, w1, w2, w3;
-        asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %4 offset:512\n\tds_read_b64 %2, %4 offset:1024\n\t"
-                     "ds_read_b64 %3, %4 offset:1536\n\ts_waitcnt lgkmcnt(0)"
-                     : "=&v"(w0), "=&v"(w1), "=&v"(w2), "=&v"(w3) : "v"(base) : "memory");
-        v2_merge(w0.x, w0.y, w1.x, w1.y);
-        v2_merge(w2.x, w2.y, w3.x, w3.y);
-        v2_merge(w0.x, w0.y, w2.x, w2.y);
-        const long long o = pd.cp_off + (long long)item.a_blk * pd.n2pad + tt * kPfBT + lane;
-        cp_s0[o] = w0.x;
-        cp_s1[o] = w0.y;
-    };
-
-    if constexpr (MSFM_PIPE == 2) {
-        // EXPERIMENT (-DMSFM_PIPE=2): epilogue of block k-1 placed in the MFMA gaps of block k (one fragment buffer,
-        // two accumulator sets alternating statically; sched_barrier between the halves keeps hipcc from sinking the
-        // row updates across them, which is what cost 32 register copies per tile in the first version of this loop)
-        f16v accA[kPfRB], accB[kPfRB];
-#pragma unroll
-        for (int rb = 0; rb < kPfRB; ++rb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) accB[rb][r] = -f_inf();
-        BlockMeta metaA = {0.f, 0, 0}, metaB = {f_inf(), t_begin * kPfBT + 32 + lcol, (2 * 4 + wave) * 64 + 32};
-        auto hint = [&]() {
-#pragma unroll
-            for (int k = 0; k < 18; ++k) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
-            }
-        };
-#pragma unroll 1
-        for (int t = t_begin; t < t_end; ++t) {
-            if (t - t_begin >= 2) wait_vmcnt<kDmaOps>();
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            dma_tile(t + 2);
-            if (PASS == 1 && t - t_begin >= 2 && wave == (t & 3)) merge_columns(t - 2);
-            const int sl = (t - t_begin) % kPfRing;
-            const char* pb = sB + sl * kPfLdsB + lcol * kHalfRowBytes;
-            const int pe_off = (int)(ext_w - pf_smem) + sl * kPfExtB;
-            const float* thr = thr_w + sl * 64;
-            abl_t = t;
-            if (wave_active) {
-                h8 bf[9];
-                load_bf(pb, pe_off, 0, bf);
-                metaA.hc = (PASS == 2) ? -0.5f * thr[lcol] : 0.f;
-                metaA.col = t * kPfBT + lcol;
-                metaA.cslot = (sl * 4 + wave) * 64;
-                mfma_block(bf, accA);
-                const bool anyB = epilogue_valu(accB, metaB, true);
-                hint();
-                if (PASS >= 2) append_hits(anyB, accB, metaB);
-                __builtin_amdgcn_sched_barrier(0);
-                load_bf(pb, pe_off, 1, bf);
-                metaB.hc = (PASS == 2) ? -0.5f * thr[32 + lcol] : 0.f;
-                metaB.col = t * kPfBT + 32 + lcol;
-                metaB.cslot = (sl * 4 + wave) * 64 + 32;
-                mfma_block(bf, accB);
-                const bool anyA = epilogue_valu(accA, metaA, true);
-                hint();
-                if (PASS >= 2) append_hits(anyA, accA, metaA);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        if (wave_active) {
-            const bool any = epilogue_valu(accB, metaB, true);
-            if (PASS >= 2) append_hits(any, accB, metaB);
-        }
-    } else if constexpr (MSFM_PIPE == 1) {
-    // EXPERIMENT (-DMSFM_PIPE=1, measured and not adopted): software pipeline at block granularity.  At two waves
-    // per SIMD the second fragment buffer spills in sweep 1 (+35 %); in the compacted sweep it gains 1.6 %; at one
-    // wave per SIMD (MSFM_RB=4) the accumulators land in AGPRs and the epilogue pays v_accvgpr_read copies (+35 %).  While block k multiplies, the B fragments
-    // of block k+1 are read from LDS (second fragment buffer) and the epilogue of block k-1 runs on the other
-    // accumulator set; one barrier per tile at the start of its second half, DMA one tile ahead (vmcnt(0) there:
-    // the loads are a full tile old).
-    f16v accA[kPfRB], accB[kPfRB];
-#pragma unroll
-    for (int rb = 0; rb < kPfRB; ++rb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) accB[rb][r] = -f_inf();
-    BlockMeta metaA = {0.f, 0, 0}, metaB = {f_inf(), t_begin * kPfBT + 32 + lcol, (2 * 4 + wave) * 64 + 32};
-    h8 bfA[9], bfB[9];
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();  // tile t_begin is in LDS (every wave waited for its own DMA part above)
-    asm volatile("" ::: "memory");
-    if (wave_active) load_bf(sB + lcol * kHalfRowBytes, (int)(ext_w - pf_smem), 0, bfA);
-#pragma unroll 1
-    for (int t = t_begin; t < t_end; ++t) {
-        const int sl = (t - t_begin) % kPfRing;
-        const char* pb = sB + sl * kPfLdsB + lcol * kHalfRowBytes;
-        const int pe_off = (int)(ext_w - pf_smem) + sl * kPfExtB;
-        const float* thr = thr_w + sl * 64;
-        abl_t = t;
-        // ---- first half: block (t, 0) multiplies; fragments of (t, 1) arrive; epilogue of (t-1, 1) ----
-        if (wave_active) {
-            load_bf(pb, pe_off, 1, bfB);
-            metaA.hc = (PASS == 2) ? -0.5f * thr[lcol] : 0.f;
-            metaA.col = t * kPfBT + lcol;
-            metaA.cslot = (sl * 4 + wave) * 64;
-            mfma_block(bfA, accA);
-            const bool anyB = epilogue_valu(accB, metaB, true);
-            if (PASS >= 2) append_hits(anyB, accB, metaB);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- tile t+1 must have landed; tile t-1's slot is free for tile t+2 ----
-        wait_vmcnt<0>();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        dma_tile(t + 2);
-        if (PASS == 1 && t - t_begin >= 2 && wave == (t & 3)) merge_columns(t - 2);
-        // ---- second half: block (t, 1) multiplies; fragments of (t+1, 0) arrive; epilogue of (t, 0) ----
-        if (wave_active) {
-            const int tn = t + 1 < t_end ? t + 1 : t;   // the last prefetch re-reads the current tile (unused)
-            const int sn = (tn - t_begin) % kPfRing;
-            load_bf(sB + sn * kPfLdsB + lcol * kHalfRowBytes, (int)(ext_w - pf_smem) + sn * kPfExtB, 0, bfA);
-            metaB.hc = (PASS == 2) ? -0.5f * thr[32 + lcol] : 0.f;
-            metaB.col = t * kPfBT + 32 + lcol;
-            metaB.cslot = (sl * 4 + wave) * 64 + 32;
-            mfma_block(bfB, accB);
-            const bool anyA = epilogue_valu(accA, metaA, true);
-            if (PASS >= 2) append_hits(anyA, accA, metaA);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    if (wave_active) {   // drain: epilogue of the last block
-        const bool any = epilogue_valu(accB, metaB, true);
-        if (PASS >= 2) append_hits(any, accB, metaB);
-    }
-    } else {
-    // Both column blocks of a tile are multiplied first (four independent accumulator chains), then their
-    // epilogues run together: rows take ONE v_max3 per pair of elements (running maximum, block cb 0, block
-    // cb 1), and no accumulator lives across the loop back-edge -- carrying the second block's accumulator
-    // into the next iteration (to overlap its epilogue with the next MFMAs) cost 32 register copies per tile
-    // and bought nothing: MFMA and VALU issue of a SIMD do not overlap on this part (tools/ubench_mfma_valu).
-    f16v accA[kPfRB], accB[kPfRB];
-    BlockMeta metaA = {0.f, 0, 0}, metaB = {0.f, 0, 0};
-#if MSFM_ABL
-    h8 bf[9];  // must survive the iteration when the reads are ablated
-#endif
-#pragma unroll 1
-    for (int t = t_begin; t < t_end; ++t) {
-        // Tile t must have landed.  Its DMA group is followed by exactly one younger group of LOADS
-        // (tile t+1, kDmaOps of them).  Loads retire in order among themselves, but on gfx9-class
-        // vmcnt stores may retire out of order with respect to loads, so the count must not rely on
-        // the (sweep-1) stores: "at most kDmaOps outstanding" implies every load of tile t is done,
-        // because a pending load of tile t would keep all kDmaOps loads of tile t+1 pending as well.
-        if (!kAblNoSync) {
-            if (MSFM_ABL != 8 && t - t_begin >= 2) wait_vmcnt<kDmaOps>();  // ablation 8: do not wait for the DMA (timing experiment)
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (MSFM_ABL != 7 || ((t - t_begin) & 1) == 0)  // ablation 7: a barrier every other tile only (timing experiment)
-            __builtin_amdgcn_s_barrier();  // every wave's part of tile t is in LDS; slot of tile t-1 is free
-            asm volatile("" ::: "memory");
-            if (!kDmaLate) dma_tile(t + 2);
-        }
-        // tile t-2's column partials are complete in LDS (its epilogues ran before the previous barrier)
-        if (!MSFM_MERGE_LATE && PASS == 1 && t - t_begin >= 2 && wave == (t & 3)) merge_columns(t - 2);
-        const int sl = (t - t_begin) % kPfRing;
-        const char* pb = sB + sl * kPfLdsB + lcol * kHalfRowBytes;
-        const int pe_off = (int)(ext_w - pf_smem) + sl * kPfExtB;
-        const float* thr = thr_w + sl * 64;
-        abl_t = t;
-        // A wave whose 64 rows are all padding (tail of an image, tail of a compacted row set) still takes
-        // part in the DMA and the barriers, but leaves the matrix pipe to the co-resident workgroup
-        if (wave_active) {
-#if !MSFM_ABL
-            h8 bf[9];
-#endif
-#if MSFM_SCHED == 4
-            __builtin_amdgcn_iglp_opt(0);
-#elif MSFM_SCHED == 5
-            __builtin_amdgcn_iglp_opt(1);
-#endif
-            load_bf(pb, pe_off, 0, bf);
-            metaA.hc = (PASS == 2) ? -0.5f * thr[lcol] : 0.f;
-            metaA.col = t * kPfBT + lcol;
-            metaA.cslot = (sl * 4 + wave) * 64;
-#if MSFM_SCHED == 3
-            __builtin_amdgcn_s_setprio(2);
-#endif
-            mfma_block(bf, accA);
-#if MSFM_SCHED == 1
-            __builtin_amdgcn_sched_group_barrier(0x100, 9, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 18, 0);
-#endif
-#if MSFM_SCHED == 2
-            h8 bf2[9];
-            load_bf(pb, pe_off, 1, bf2);
-            mfma_block(bf2, accB);
-            __builtin_amdgcn_sched_group_barrier(0x100, 18, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 36, 0);
-#else
-            load_bf(pb, pe_off, 1, bf);
-            mfma_block(bf, accB);
-#endif
-#if MSFM_SCHED == 1
-            __builtin_amdgcn_sched_group_barrier(0x100, 9, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 18, 0);
-#endif
-#if MSFM_SCHED == 3
-            __builtin_amdgcn_s_setprio(0);
-#endif
-            metaB.hc = (PASS == 2) ? -0.5f * thr[32 + lcol] : 0.f;
-            metaB.col = t * kPfBT + 32 + lcol;
-            metaB.cslot = (sl * 4 + wave) * 64 + 32;
-            if (kDmaLate == 3 && !kAblNoSync) dma_tile(t + 2);
-            const bool anyA = epilogue_valu(accA, metaA, false);
-            if (kDmaLate == 2 && !kAblNoSync) dma_tile(t + 2);
-            const bool anyB = epilogue_valu(accB, metaB, false);
-            if (PASS == 1 && !kAblNoEpi) {
-#pragma unroll
-                for (int rb = 0; rb < kPfRB; ++rb)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) rs0[rb][r] = max3f(rs0[rb][r], accA[rb][r], accB[rb][r]);
-            }
-            if (PASS >= 2) {
-                append_hits(anyA, accA, metaA);
-                append_hits(anyB, accB, metaB);
-            }
-        }
-        // the slot of tile t-1 has been free since this iteration's barrier; issuing the pieces here, after the
-        // epilogue's VALU work, is cheaper than among the ds_reads and MFMAs right after the barrier
-        if ((kDmaLate == 1 || (kDmaLate >= 2 && !wave_active)) && !kAblNoSync) dma_tile(t + 2);
-        // (the merge of tile t-2's column partials may run anywhere in iteration t; at the end it keeps the head of
-        // the iteration -- the first cycles after the barrier release -- free of VALU work)
-        if (MSFM_MERGE_LATE && PASS == 1 && t - t_begin >= 2 && wave == (t & 3)) merge_columns(t - 2);
-    }
-    }
-    if (PASS >= 2) flush_candidates();
-    if (PASS == 1) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();  // every wave's last column partials are in LDS
-        asm volatile("" ::: "memory");
-        if (wave == 0 && t_end - 2 >= t_begin) merge_columns(t_end - 2);  // (a range may consist of a single tile)
-        if (wave == 1) merge_columns(t_end - 1);
-    }
-
-    if (PASS == 1) {
-        // rows: S~ = -2 * accumulator; the two smallest of the 32 lanes' minima; one partial slot per B range
-        float rs1[kPfRB][16];
-#pragma unroll
-        for (int rb = 0; rb < kPfRB; ++rb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                rs0[rb][r] = -2.f * rs0[rb][r];
-                rs1[rb][r] = f_inf();
-#pragma unroll
-                for (int m = 1; m < 32; m <<= 1)
-                    v2_merge(rs0[rb][r], rs1[rb][r], __shfl_xor(rs0[rb][r], m), __shfl_xor(rs1[rb][r], m));
-            }
-        if (lcol == 0) {
-            const long long o = pd.rp_off + (long long)item.range * pd.n1pad + arow_base;
-#pragma unroll
-            for (int rb = 0; rb < kPfRB; ++rb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int off = rb * 32 + (r & 3) + 8 * (r >> 2);
-                    rp_s0[o + off] = rs0[rb][r];
-                    rp_s1[o + off] = rs1[rb][r];
-                }
-        }
-    }
-}
+#include "msfm_sweep.hip.h"
 
 // thresholds: fold the pass-1 partials; T = S~(2) + 2 eps, stored in u- / v-space.
 // With `prune` (match lists, not the knnMatch-level API) a row / column that PROVABLY cannot yield a match
