@@ -65,7 +65,7 @@ def opencv_found():
         return False
 
 
-def cpu_baseline(imgs, pairs, budget_s=20.0, max_pairs=1024, seed=0):
+def cpu_baseline(imgs, pairs, budget_s=20.0, max_pairs=4096, seed=0):
     """CPU oracle on a seeded sample of the same pairs: one persistent pool over image pairs on all host threads
     (orc_match_pairs_mt), plus the single-thread figure (how the reference itself runs: one pair after the other)."""
     from oracle import c_oracle as co
@@ -83,23 +83,20 @@ def cpu_baseline(imgs, pairs, budget_s=20.0, max_pairs=1024, seed=0):
     def work(sel):
         return int(sum(len(imgs[i]) * len(imgs[j]) for i, j in pairs[sel]))
 
-    # single thread: calibrates the sample size too
+    # single thread (how the reference itself runs: one pair after the other)
     one = order[:1]
     need(one)
     t0 = time.perf_counter()
     co.match_pairs(f32, pairs[one], nthreads=1)
     dt1 = time.perf_counter() - t0
-    w1 = work(one)
-    single = w1 / dt1
-    # all threads: assume >= 0.5 x threads x single-thread to size a sample of roughly budget_s
-    n = int(max(threads, min(max_pairs, len(pairs), budget_s * single * 0.5 * threads / max(w1, 1))))
-    n = min(n, len(pairs))
-    sample = order[:n]
+    single = work(one) / dt1
+    # all threads: the seeded order is worked off until the budget is spent (no new pair is started after it)
+    sample = order[:min(max_pairs, len(pairs))]
     need(sample)
     t0 = time.perf_counter()
-    offs, _, _, _ = co.match_pairs(f32, pairs[sample], nthreads=threads)
+    offs, _, _, _, n = co.match_pairs(f32, pairs[sample], nthreads=threads, budget_s=budget_s, return_done=True)
     dt = time.perf_counter() - t0
-    w = work(sample)
+    w = work(sample[:n])
     model = "unknown"
     try:
         for line in open("/proc/cpuinfo"):
@@ -179,7 +176,7 @@ def main():
     if args.no_prefilter:
         ctx.set_prefilter(False)
 
-    def run_job(imgs, pairs, steps, warmup, collect=None):
+    def run_job(imgs, pairs, steps, warmup, collect=None, **match_kw):
         """Upload, W untimed + K timed steps; -> (seconds of the K steps: max over ranks, result of the last step,
         upload seconds, per-rank [compute_ms, exchange_ms] means)."""
         n_rows = np.array([len(x) for x in imgs], np.int64)
@@ -188,13 +185,13 @@ def main():
         for i, im in enumerate(imgs):
             ctx.upload_image(i, im)   # resident in HBM before the timed region
         upload_s = time.perf_counter() - t_up   # host buffers -> HBM (PCIe) + the on-device layout / fp16 / norm passes
-        sm = ShardedMatcher(ctx=ctx, device=coll_dev, force_collectives=args.force_collectives)
+        sm = ShardedMatcher(ctx=ctx, device=coll_dev, force_collectives=args.force_collectives, **match_kw)
 
         def step():
             if not multi:
                 # one rank: the step ends with the lists in the library's page-locked host buffers ("view": no second copy)
                 t = time.perf_counter()
-                offs, qt, _ = ctx.match_pairs(pairs, fetch="view")
+                offs, qt, _ = ctx.match_pairs(pairs, fetch="view", **match_kw)
                 sm.last = {"compute_ms": (time.perf_counter() - t) * 1e3, "exchange_ms": 0.0}
                 return offs, qt, None
             return sm.match_to_writer(pairs, n_rows, dst=0, with_dist=False)
@@ -224,6 +221,7 @@ def main():
 
     # ---- main workload -----------------------------------------------------------------------------------------
     imgs, pairs, wl_name = synth.job(args.workload, args.images, args.desc, seed=args.seed)
+    main_kw = {"max_distance": 1e9} if args.workload == "synthetic-u8" else {}
     acc = {k: 0 for k in ("dist_kernel_ms", "dist_kernel_launches", "approx_kernel_ms", "approx_kernel_launches",
                           "prefilter_descriptor_pairs", "exact_descriptor_pairs", "candidates", "fallback_pairs", "sweep2_ms",
                           "sweep2_launches", "sweep2_descriptor_pairs", "compacted_pairs", "total_device_ms", "sub_batches")}
@@ -234,7 +232,7 @@ def main():
             acc[k] += p[k]
         last_prof.update(p)
 
-    dt, result, upload_s, per_rank, n_rows = run_job(imgs, pairs, args.steps, args.warmup, collect)
+    dt, result, upload_s, per_rank, n_rows = run_job(imgs, pairs, args.steps, args.warmup, collect, **main_kw)
     total_desc_pairs = int((n_rows[pairs[:, 0]] * n_rows[pairs[:, 1]]).sum())
     offs = result[0]
     n_matches = int(offs[-1])
@@ -254,7 +252,7 @@ def main():
                            "value_incl_upload": total_desc_pairs / (upload_s + dt / args.steps)},
         "config": {"workload": wl_name, "image_pairs": int(len(pairs)), "descriptor_pairs_per_step": total_desc_pairs,
                    "matches_per_step": n_matches, "accum_order": "opencv-sse4x4-nofma" if args.order == 0 else "opencv-avx2-fma",
-                   "ratio": 0.8, "cross_check": True, "max_distance": 0.7, "preemptive_filter": False,
+                   "ratio": 0.8, "cross_check": True, "max_distance": main_kw.get("max_distance", 0.7), "preemptive_filter": False,
                    "parallelism": "the SAME job at every N: image pairs cut into %d contiguous cost-balanced range(s), store "
                                   "replicated; exchange = all_reduce of per-pair counts + RCCL send of the (q, t) lists from HBM "
                                   "to the writer rank" % world},
@@ -322,7 +320,8 @@ def main():
             for k in u_acc:
                 u_acc[k] += p.get(k, 0)
 
-        u_dt, u_res, _, u_per_rank, u_rows = run_job(u_imgs, u_pairs, args.u8_steps, 1, u_collect)
+        # u8 distances are hundreds, not fractions of a unit-norm descriptor: no distance cut (reference default 0.7 is for RootSIFT)
+        u_dt, u_res, _, u_per_rank, u_rows = run_job(u_imgs, u_pairs, args.u8_steps, 1, u_collect, max_distance=1e9)
         u_total = int((u_rows[u_pairs[:, 0]] * u_rows[u_pairs[:, 1]]).sum())
         i8 = u_acc["sweep1_i8_launches"] > 0
         u_ach = 256.0 * u_acc["prefilter_descriptor_pairs"] / max(1e-9, u_acc["approx_kernel_ms"] * 1e-3) / 1e12

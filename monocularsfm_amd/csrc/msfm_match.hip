@@ -690,6 +690,19 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
     float ms = 0.f;
     HIPCHK(ctx, hipEventElapsedTime(&ms, e0, e1));
     ctx->prof.approx_kernel_ms += ms;
+#ifdef MSFM_SWEEP_PROBE
+    {   // diagnostic build: average cycles per tile and wave of the four loop segments of sweep 1
+        unsigned long long pr[kPfWaves][8];
+        HIPCHK(ctx, hipMemcpyFromSymbol(pr, HIP_SYMBOL(g_sweep_probe), sizeof(pr)));
+        for (int w = 0; w < kPfWaves; ++w) {
+            const double n = (double)std::max<unsigned long long>(1, pr[w][4]);
+            std::fprintf(stderr, "[sweep probe] wave %d: MFMA %.0f | wait+barrier %.0f | EPI %.0f | wait+barrier %.0f cycles per tile (%.0f tiles), sweep 1 %.3f ms\n",
+                         w, pr[w][0] / n, pr[w][1] / n, pr[w][2] / n, pr[w][3] / n, n, ms);
+        }
+        std::memset(pr, 0, sizeof(pr));
+        HIPCHK(ctx, hipMemcpyToSymbol(HIP_SYMBOL(g_sweep_probe), pr, sizeof(pr)));
+    }
+#endif
     HIPCHK(ctx, hipEventElapsedTime(&ms, e2, e3));
     ctx->prof.sweep2_ms += ms;
     std::vector<char> overflow(P, 0);

@@ -43,6 +43,23 @@
 #pragma once
 // (included inside namespace msfm)
 
+// Diagnostic build only (tools/gpu_probe.sh, -DMSFM_SWEEP_PROBE): per-wave cycle sums of the four segments of a tile
+// (MFMA phase, its wait + barrier, EPI phase, its wait + barrier), printed by the library after every sweep 1.
+#ifdef MSFM_SWEEP_PROBE
+__device__ unsigned long long g_sweep_probe[kPfWaves][8];
+#define MSFM_PROBE_BEGIN unsigned long long pb_t = __builtin_amdgcn_s_memtime(), pb_acc[4] = {0, 0, 0, 0};
+#define MSFM_PROBE(k) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); pb_acc[k] += n_ - pb_t; pb_t = n_; }
+#define MSFM_PROBE_END                                                                                     \
+    if (PASS == 1 && lane == 0) {                                                                          \
+        for (int k_ = 0; k_ < 4; ++k_) atomicAdd(&g_sweep_probe[wave][k_], pb_acc[k_]);                    \
+        atomicAdd(&g_sweep_probe[wave][4], (unsigned long long)(t_end - t_begin));                         \
+    }
+#else
+#define MSFM_PROBE_BEGIN
+#define MSFM_PROBE(k)
+#define MSFM_PROBE_END
+#endif
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -350,6 +367,7 @@ __global__ __launch_bounds__(kPfThreads, 2) void sweep_kernel(
 
     f16v accA[kPfRB], accB[kPfRB];
     BlockMeta metaA = {0.f, 0, 0}, metaB = {0.f, 0, 0};
+    MSFM_PROBE_BEGIN
 #pragma unroll 1
     for (int t = t_begin; t < t_end; ++t) {
         const int sl = (t - t_begin) & (kPfRing - 1);
@@ -369,8 +387,10 @@ __global__ __launch_bounds__(kPfThreads, 2) void sweep_kernel(
         }
         // tile t+1 must be complete one phase before its first MFMA: this half waits here for its share (its DMA
         // group of tile t+2 may stay in flight), the other half at the end of its EPI phase
+        MSFM_PROBE(0)
         if (grp == 0) wait_vmcnt<kDmaOps>();
         lds_barrier();
+        MSFM_PROBE(1)
         // ---- EPI phase: everything that is not matrix work ---------------------------------------------------
         dma_tile(t + 3);   // into the slot of tile t-1, dead since the barrier before last
         if (wave_active) {
@@ -398,9 +418,12 @@ __global__ __launch_bounds__(kPfThreads, 2) void sweep_kernel(
         // the even half folds them
         if (PASS == 1 && grp == 0 && t > t_begin && wave == ((t - t_begin) & 3)) merge_columns(t - 1);
         if (kPreRead && wave_active && t + 1 < t_end) load_bf((sl + 1) & (kPfRing - 1), bf, be);   // pre-read: the next MFMA phase starts on registers
+        MSFM_PROBE(2)
         if (grp == 1) wait_vmcnt<kDmaOps>();
         lds_barrier();
+        MSFM_PROBE(3)
     }
+    MSFM_PROBE_END
     if (grp == 0) lds_barrier();   // the odd half's last EPI phase
     if (PASS >= 2) flush_candidates();
     if (PASS == 1 && wave == 0) merge_columns(t_end - 1);

@@ -37,6 +37,8 @@ def lib():
         L.orc_l2sqr.argtypes = [fp, fp, C.c_int]
         L.orc_knn2_mt.restype = None
         L.orc_knn2_mt.argtypes = [fp, C.c_int, fp, C.c_int, C.c_int, C.c_int, ip, fp, ip, fp]
+        L.orc_knn2_blocked.restype = None
+        L.orc_knn2_blocked.argtypes = [fp, C.c_int, fp, C.c_int, C.c_int, ip, fp, ip, fp]
         L.orc_compute_matches.restype = C.c_int
         L.orc_compute_matches.argtypes = [fp, C.c_int, fp, C.c_int, C.c_float, C.c_int, C.c_int, ip, ip, fp]
         L.orc_cross_check.restype = C.c_int
@@ -48,7 +50,7 @@ def lib():
                                      C.c_int, C.c_int, ip, ip, fp]
         L.orc_match_pairs_mt.restype = C.c_int64
         L.orc_match_pairs_mt.argtypes = [C.POINTER(fp), ip, ip, C.c_int, C.c_float, C.c_int, C.c_double, C.c_int, C.c_int,
-                                         lp, ip, ip, fp]
+                                         C.c_double, C.POINTER(C.c_int), lp, ip, ip, fp]
         L.orc_topscale_select.restype = C.c_int
         L.orc_topscale_select.argtypes = [fp, C.c_int, C.c_int, ip]
         L.orc_pair_id.restype = C.c_int32
@@ -95,6 +97,18 @@ def knn2(q, t, order=ORDER_SSE4X4, nthreads=1):
     d0 = np.empty(nq, np.float32)
     d1 = np.empty(nq, np.float32)
     lib().orc_knn2_mt(_f(q), nq, _f(t), nt, order, nthreads, _i(idx0), _f(d0), _i(idx1), _f(d1))
+    return idx0, d0, idx1, d1
+
+
+def knn2_blocked(q, t, order=ORDER_SSE4X4):
+    """knn2 from the cache-blocked loop order (the pair-parallel baseline's inner loop): identical results."""
+    q, t = _desc(q), _desc(t)
+    nq, nt = q.shape[0], t.shape[0]
+    idx0 = np.empty(nq, np.int32)
+    idx1 = np.empty(nq, np.int32)
+    d0 = np.empty(nq, np.float32)
+    d1 = np.empty(nq, np.float32)
+    lib().orc_knn2_blocked(_f(q), nq, _f(t), nt, order, _i(idx0), _f(d0), _i(idx1), _f(d1))
     return idx0, d0, idx1, d1
 
 
@@ -150,10 +164,12 @@ def match_pair(d1, d2, ratio=0.8, cross_check=True, max_distance=0.7, order=ORDE
     return q[:m].copy(), t[:m].copy(), d[:m].copy()
 
 
-def match_pairs(images, pairs, ratio=0.8, cross_check=True, max_distance=0.7, order=ORDER_SSE4X4, nthreads=None):
+def match_pairs(images, pairs, ratio=0.8, cross_check=True, max_distance=0.7, order=ORDER_SSE4X4, nthreads=None,
+                budget_s=0.0, return_done=False):
     """MatchImagePairs' loop over independent pairs, parallel over PAIRS (persistent pool, one pair per worker at a
     time).  images: list / dict id -> n x 128 float32; pairs: P x 2 (query id, train id).
-    -> offsets int64[P+1], q int32[M], t int32[M], dist float32[M]."""
+    -> offsets int64[P+1], q int32[M], t int32[M], dist float32[M].  budget_s > 0 stops starting new pairs after that
+    many seconds; with return_done the number of pairs computed (a prefix of the list) is returned as a fifth value."""
     pairs = np.ascontiguousarray(np.asarray(pairs, dtype=np.int32).reshape(-1, 2))
     P = pairs.shape[0]
     ids = sorted(set(pairs.ravel().tolist()))
@@ -171,8 +187,12 @@ def match_pairs(images, pairs, ratio=0.8, cross_check=True, max_distance=0.7, or
     offs = np.zeros(P + 1, np.int64)
     if nthreads is None:
         nthreads = os.cpu_count() or 1
+    done = C.c_int()
     m = lib().orc_match_pairs_mt(ptrs, _i(rows), _i(pairs), P, np.float32(ratio), int(bool(cross_check)), float(max_distance),
-                                 order, int(nthreads), offs.ctypes.data_as(C.POINTER(C.c_int64)), _i(q), _i(t), _f(d))
+                                 order, int(nthreads), float(budget_s), C.byref(done),
+                                 offs.ctypes.data_as(C.POINTER(C.c_int64)), _i(q), _i(t), _f(d))
+    if return_done:
+        return offs, q[:m].copy(), t[:m].copy(), d[:m].copy(), done.value
     return offs, q[:m].copy(), t[:m].copy(), d[:m].copy()
 
 

@@ -13,6 +13,7 @@
 #include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #if defined(__SSE2__)
 #include <emmintrin.h>
@@ -166,6 +167,66 @@ static void knn2_rows(const float* q, int q_begin, int q_end, const float* t, in
     free(buf);
 }
 
+/* The same computation re-tiled for the cache: a block of QB query rows against one tile of TT train rows at a
+ * time, tiles in ascending train order.  Per (query, train) element the arithmetic and the strict-< insertion are
+ * those of knn2_rows, and every query still sees its train rows in ascending order, so the results are identical
+ * bit for bit (tests/test_oracle_kat.py checks it); only the memory traffic differs (the train image is streamed once
+ * per QB query rows instead of once per row).  Used by the pair-parallel CPU baseline, where 256 threads streaming
+ * 2.5 MB per query row would measure the DRAM, not the cores. */
+#define ORC_QB 32
+#define ORC_TT 128
+static void knn2_rows_blocked(const float* q, int q_begin, int q_end, const float* t, int nt, int order,
+                              int32_t* idx0, float* d0, int32_t* idx1, float* d1)
+{
+    const int K = nt < 2 ? nt : 2;
+    int32_t dist[ORC_QB][2], nidx[ORC_QB][2];
+    for (int b0 = q_begin; b0 < q_end; b0 += ORC_QB) {
+        const int nb = (q_end - b0 < ORC_QB) ? q_end - b0 : ORC_QB;
+        for (int r = 0; r < nb; ++r) {
+            dist[r][0] = dist[r][1] = f2i(FLT_MAX);
+            nidx[r][0] = nidx[r][1] = -1;
+        }
+        for (int j0 = 0; j0 < nt && K > 0; j0 += ORC_TT) {
+            const int j1 = (nt - j0 < ORC_TT) ? nt : j0 + ORC_TT;
+            for (int r = 0; r < nb; ++r) {
+                const float* qi = q + (size_t)(b0 + r) * 128;
+                for (int j = j0; j < j1; ++j) {
+                    float s;
+                    switch (order) {
+                    case MSFM_ORC_ORDER_SSE4X4: s = l2sqr_sse4x4(qi, t + (size_t)j * 128); break;
+                    case MSFM_ORC_ORDER_AVX2_FMA: s = l2sqr_avx2_fma(qi, t + (size_t)j * 128); break;
+                    default: s = orc_l2sqr(qi, t + (size_t)j * 128, order);
+                    }
+                    const int32_t d = f2i(sqrtf(s));
+                    if (d < dist[r][K - 1]) {
+                        int k;
+                        for (k = K - 2; k >= 0 && dist[r][k] > d; --k) {
+                            nidx[r][k + 1] = nidx[r][k];
+                            dist[r][k + 1] = dist[r][k];
+                        }
+                        nidx[r][k + 1] = j;
+                        dist[r][k + 1] = d;
+                    }
+                }
+            }
+        }
+        for (int r = 0; r < nb; ++r) {
+            idx0[b0 + r] = nidx[r][0];
+            d0[b0 + r] = i2f(dist[r][0]);
+            idx1[b0 + r] = nidx[r][1];
+            d1[b0 + r] = i2f(dist[r][1]);
+        }
+    }
+}
+
+static __thread int g_use_blocked = 0;   /* set by the pair-parallel workers */
+
+void orc_knn2_blocked(const float* q, int nq, const float* t, int nt, int order,
+                      int32_t* idx0, float* d0, int32_t* idx1, float* d1)
+{
+    knn2_rows_blocked(q, 0, nq, t, nt, order, idx0, d0, idx1, d1);
+}
+
 void orc_knn2(const float* q, int nq, const float* t, int nt, int order,
               int32_t* idx0, float* d0, int32_t* idx1, float* d1)
 {
@@ -190,7 +251,8 @@ void orc_knn2_mt(const float* q, int nq, const float* t, int nt, int order, int 
                  int32_t* idx0, float* d0, int32_t* idx1, float* d1)
 {
     if (nthreads <= 1 || nq < 2 * nthreads) {
-        knn2_rows(q, 0, nq, t, nt, order, idx0, d0, idx1, d1);
+        if (g_use_blocked) knn2_rows_blocked(q, 0, nq, t, nt, order, idx0, d0, idx1, d1);
+        else knn2_rows(q, 0, nq, t, nt, order, idx0, d0, idx1, d1);
         return;
     }
     pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * (size_t)nthreads);
@@ -327,12 +389,22 @@ typedef struct {
     float* d;
     int32_t* counts;
     int next;                /* shared work counter */
+    double deadline;         /* CLOCK_MONOTONIC seconds after which no new pair is started (<= 0: none) */
 } pairs_job;
+
+static double now_s(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
 
 static void* pairs_thread(void* arg)
 {
     pairs_job* J = (pairs_job*)arg;
+    g_use_blocked = 1;   /* same results, cache-blocked loop order (knn2_rows_blocked) */
     for (;;) {
+        if (J->deadline > 0.0 && now_s() > J->deadline) break;
         const int p = __atomic_fetch_add(&J->next, 1, __ATOMIC_RELAXED);
         if (p >= J->n_pairs) break;
         const int32_t a = J->pairs[2 * p], b = J->pairs[2 * p + 1];
@@ -344,20 +416,24 @@ static void* pairs_thread(void* arg)
 }
 
 int64_t orc_match_pairs_mt(const float* const* images, const int32_t* rows, const int32_t* pairs, int n_pairs,
-                           float ratio, int cross_check, double max_distance, int order, int nthreads,
-                           int64_t* out_offsets, int32_t* out_q, int32_t* out_t, float* out_d)
+                           float ratio, int cross_check, double max_distance, int order, int nthreads, double budget_s,
+                           int* n_done, int64_t* out_offsets, int32_t* out_q, int32_t* out_t, float* out_d)
 {
     out_offsets[0] = 0;
+    if (n_done) *n_done = 0;
     if (n_pairs <= 0) return 0;
     int64_t* cap_off = (int64_t*)malloc(sizeof(int64_t) * ((size_t)n_pairs + 1));
     int32_t* counts = (int32_t*)calloc((size_t)n_pairs, sizeof(int32_t));
     cap_off[0] = 0;
     for (int p = 0; p < n_pairs; ++p) cap_off[p + 1] = cap_off[p] + (rows[pairs[2 * p]] > 0 ? rows[pairs[2 * p]] : 0);
     pairs_job J = {images, rows, pairs, n_pairs, ratio, cross_check, max_distance, order, cap_off,
-                   out_q, out_t, out_d, counts, 0};
+                   out_q, out_t, out_d, counts, 0, budget_s > 0.0 ? now_s() + budget_s : 0.0};
+    for (int p = 0; p < n_pairs; ++p) counts[p] = -1;   /* -1: not computed (budget ran out) */
     if (nthreads > n_pairs) nthreads = n_pairs;
     if (nthreads <= 1) {
+        const int keep = g_use_blocked;
         pairs_thread(&J);
+        g_use_blocked = keep;
     } else {
         pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * (size_t)nthreads);
         for (int k = 0; k < nthreads; ++k) pthread_create(&th[k], NULL, pairs_thread, &J);
@@ -366,6 +442,11 @@ int64_t orc_match_pairs_mt(const float* const* images, const int32_t* rows, cons
     }
     /* compact the per-pair staging regions into CSR order (regions are ordered, so an in-place forward move is safe) */
     int64_t at = 0;
+    int done = n_pairs;
+    for (int p = 0; p < n_pairs; ++p)
+        if (counts[p] < 0) { done = p; break; }   /* pairs are started in order: the computed ones are a prefix */
+    if (n_done) *n_done = done;
+    for (int p = done; p < n_pairs; ++p) counts[p] = 0;
     for (int p = 0; p < n_pairs; ++p) {
         const int64_t o = cap_off[p];
         if (o != at && counts[p] > 0) {

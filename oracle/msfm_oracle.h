@@ -59,6 +59,11 @@ float orc_l2sqr(const float* a, const float* b, int order);
 void orc_knn2(const float* q, int nq, const float* t, int nt, int order,
               int32_t* idx0, float* d0, int32_t* idx1, float* d1);
 
+/* same results from a cache-blocked loop order (32 query rows x 128 train rows at a time, train tiles ascending):
+ * what the pair-parallel baseline runs (orc_match_pairs_mt). */
+void orc_knn2_blocked(const float* q, int nq, const float* t, int nt, int order,
+                      int32_t* idx0, float* d0, int32_t* idx1, float* d1);
+
 /* same, query rows split over nthreads pthreads (mirrors OpenCV's parallel_for_). */
 void orc_knn2_mt(const float* q, int nq, const float* t, int nt, int order, int nthreads,
                  int32_t* idx0, float* d0, int32_t* idx1, float* d1);
@@ -89,11 +94,12 @@ int orc_match_pair(const float* d1, int n1, const float* d2, int n2,
  * single-threaded (the reference runs its pairs one after the other; OpenCV fans each knnMatch out over query
  * rows -- parallelising over pairs instead keeps all cores busy without a thread create/join per pair).
  * images[id] -> n x 128 descriptors, rows[id] -> n; pairs = P x 2 ids (query, train).
- * out_offsets: P+1 CSR offsets; out_q/out_t/out_d: capacity sum over pairs of rows[query].  Returns the
- * number of matches. */
+ * out_offsets: P+1 CSR offsets; out_q/out_t/out_d: capacity sum over pairs of rows[query].  budget_s > 0: no new
+ * pair is started after that many seconds (the timed CPU baseline); *n_done (nullable) receives the number of pairs
+ * computed, always a prefix of the list -- the rest get empty lists.  Returns the number of matches. */
 int64_t orc_match_pairs_mt(const float* const* images, const int32_t* rows, const int32_t* pairs, int n_pairs,
-                           float ratio, int cross_check, double max_distance, int order, int nthreads,
-                           int64_t* out_offsets, int32_t* out_q, int32_t* out_t, float* out_d);
+                           float ratio, int cross_check, double max_distance, int order, int nthreads, double budget_s,
+                           int* n_done, int64_t* out_offsets, int32_t* out_q, int32_t* out_t, float* out_d);
 
 /* FeatureUtils::ExtractTopScaleDescriptors' selection (FeatureUtils.cpp:68-96):
  * indices of the k largest KeyPoint.size (kpts = n x 4 floats x,y,size,angle).

@@ -217,3 +217,24 @@ def test_topscale_select(oracle):
     assert oracle.topscale_select(k, 4).tolist() == [1, 2, 5, 4]      # size desc, index asc on ties
     assert oracle.topscale_select(k, 6).tolist() == [1, 2, 5, 4, 0, 3]
     assert oracle.topscale_select(k, 7).tolist() == [0, 1, 2, 3, 4, 5]  # k > n: whole matrix, original order
+
+
+def test_cache_blocked_loop_order_gives_identical_results(oracle):
+    """orc_knn2_blocked (the pair-parallel CPU baseline's inner loop: 32 query rows x 128 train rows at a time) is a
+    re-tiling of batchDistance's row-at-a-time loop, not a different computation: identical bits, ties included."""
+    from monocularsfm_amd import synth
+    imgs = synth.rootsift_images(2, [333, 415], seed=31, n_proto=500)
+    u = synth.u8_images(2, [200, 257], seed=32, dup_frac=0.3)
+    u[1][7] = u[1][3]
+    u[1][140] = u[1][3]
+    u[0][5] = u[1][3]
+    for A, B in ((imgs[0], imgs[1]), (u[0], u[1]), (imgs[0][:1], imgs[1][:1]), (imgs[0][:40], imgs[1][:129]), (imgs[0][:3], imgs[1][:0])):
+        for order in (0, 1, 2):
+            for x, y in zip(oracle.knn2(A, B, order), oracle.knn2_blocked(A, B, order)):
+                assert np.array_equal(x.view(np.int32), y.view(np.int32))
+    # and the pair-parallel entry point (which uses it) equals the per-pair calls
+    offs, q, t, d = oracle.match_pairs([imgs[0], imgs[1], u[0], u[1]], [(0, 1), (1, 0), (2, 3)], max_distance=1e9, nthreads=3)
+    for p, (i, j) in enumerate([(0, 1), (1, 0), (2, 3)]):
+        oq, ot, od = oracle.match_pair([imgs[0], imgs[1], u[0], u[1]][i], [imgs[0], imgs[1], u[0], u[1]][j], max_distance=1e9)
+        assert np.array_equal(q[offs[p]:offs[p + 1]], oq) and np.array_equal(t[offs[p]:offs[p + 1]], ot)
+        assert np.array_equal(d[offs[p]:offs[p + 1]].view(np.int32), od.view(np.int32))
