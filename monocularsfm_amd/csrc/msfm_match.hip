@@ -97,11 +97,11 @@ struct Image {
     int nalloc = 0;  // allocated blocks (even: the prefilter walks 256-row A blocks); padding is zero-filled
     float* panel = nullptr;
     float* raw = nullptr;
-    // prefilter operands: fp16 swizzled blocks, row norms (+inf padded), maxima
+    // prefilter operands: fp16 rows of 272 B (128 halfs + the norm quadruple of the ninth MFMA k-step), row norms
+    // (+inf padded), maxima
     _Float16* h16 = nullptr;
     float* nrm = nullptr;
-    _Float16* ext = nullptr;  // norm quadruples for the ninth MFMA k-step
-    float c = 1.f;            // their scale (power of two)
+    float c = 1.f;            // scale of the quadruples (power of two)
     float nrm_max = 0.f, abs_max = 0.f;
     bool pf_safe = false;
     // keypoint coordinates (x, y) for the geometric verification; nk = -1: not uploaded
@@ -114,7 +114,6 @@ void free_image(Image& im) {
     if (im.raw) (void)hipFree(im.raw);
     if (im.h16) (void)hipFree(im.h16);
     if (im.nrm) (void)hipFree(im.nrm);
-    if (im.ext) (void)hipFree(im.ext);
     if (im.kxy) (void)hipFree(im.kxy);
     im = Image{};
 }
@@ -273,8 +272,6 @@ int fill_pair(msfm_ctx* ctx, int id1, int id2, PairDesc& pd, PfPair& pp) {
     pp.b_nrm = b.nrm;
     pp.a_nrm_max = a.nrm_max;
     pp.b_nrm_max = b.nrm_max;
-    pp.a_ext = a.ext;
-    pp.b_ext = b.ext;
     pp.a_c = a.c;
     pp.b_c = b.c;
     // the MFMA prefilter needs fp16-representable magnitudes on both sides, and norms of comparable scale
@@ -425,7 +422,7 @@ int plan_sweep2(msfm_ctx* ctx, Batch& b, const std::vector<char>& compact, const
         }
     }
     const size_t V = groups.size();
-    HIPCHK(ctx, ctx->d_cmp_h.ensure(std::max<long long>(1, cmp_rows) * kDim * 2));
+    HIPCHK(ctx, ctx->d_cmp_h.ensure(std::max<long long>(1, cmp_rows) * kPfRowBytes));
     HIPCHK(ctx, ctx->d_cmp_tu.ensure(std::max<long long>(1, cmp_rows) * 4));
     HIPCHK(ctx, ctx->d_live_idx.ensure(std::max<long long>(1, cmp_rows) * 4));
     HIPCHK(ctx, ctx->d_row_pair.ensure(std::max<long long>(1, cmp_rows) * 4));
@@ -464,10 +461,9 @@ int plan_sweep2(msfm_ctx* ctx, Batch& b, const std::vector<char>& compact, const
         if (v_ablocks < 8LL * ctx->cu_count)
             vd.ranges = (int)std::max<long long>(1, std::min<long long>((8LL * ctx->cu_count + v_ablocks - 1) / v_ablocks, vd.b_tiles));
         vp = PfPair{};
-        vp.a_h = ctx->d_cmp_h.as<_Float16>() + (size_t)g.row0 * kDim;
+        vp.a_h = ctx->d_cmp_h.as<_Float16>() + (size_t)g.row0 * kPfRowHalfs;
         vp.b_h = g.dir ? pp.a_h : pp.b_h;
         vp.b_nrm = g.dir ? pp.a_nrm : pp.b_nrm;
-        vp.b_ext = g.dir ? pp.a_ext : pp.b_ext;
         vp.b_c = g.dir ? pp.a_c : pp.b_c;
         vp.a_c = g.dir ? pp.b_c : pp.a_c;
         vp.tu_off = g.row0;
@@ -526,8 +522,8 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
     const long long kn = std::max<long long>(1, b.kf_elems + b.kr_elems);
     HIPCHK(ctx, ctx->d_rp_s0.ensure(std::max<long long>(1, b.rp_elems) * 4));
     HIPCHK(ctx, ctx->d_rp_s1.ensure(std::max<long long>(1, b.rp_elems) * 4));
-    HIPCHK(ctx, ctx->d_cp_s0.ensure(std::max<long long>(1, b.cp_elems) * 4));
-    HIPCHK(ctx, ctx->d_cp_s1.ensure(std::max<long long>(1, b.cp_elems) * 4));
+    // column partials of sweep 1: one float4 (four row-class maxima) per 512-row A block and column
+    HIPCHK(ctx, ctx->d_cp_s0.ensure(std::max<long long>(1, b.cp_elems) * 16));
     HIPCHK(ctx, ctx->d_tu.ensure(kn * 4));
     HIPCHK(ctx, ctx->d_best.ensure(kn * 8));
     HIPCHK(ctx, ctx->d_second.ensure(kn * 8));
@@ -550,7 +546,7 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
     HIPCHK(ctx, hipEventRecord(e0, ctx->stream));
     hipLaunchKernelGGL(sweep_kernel<1>, dim3((unsigned)b.items.size()), block, kPfLdsBytes, ctx->stream, dp, dpf,
                        ctx->d_items.as<WorkItem>(), ctx->d_rp_s0.as<float>(), ctx->d_rp_s1.as<float>(),
-                       ctx->d_cp_s0.as<float>(), ctx->d_cp_s1.as<float>(), (const float*)nullptr, (const float*)nullptr,
+                       ctx->d_cp_s0.as<float>(), (float*)nullptr, (const float*)nullptr, (const float*)nullptr,
                        (int2*)nullptr, (unsigned long long*)nullptr);
     HIPCHK(ctx, hipGetLastError());
     DBGSYNC(ctx, "sweep_kernel<1>");
@@ -558,7 +554,7 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
     ctx->prof.approx_kernel_launches += 1;
     const dim3 mgrid((unsigned)((b.max_npad + 255) / 256), (unsigned)P);
     hipLaunchKernelGGL(pf_thresholds_kernel, mgrid, dim3(256), 0, ctx->stream, dp, dpf, ctx->d_rp_s0.as<float>(),
-                       ctx->d_rp_s1.as<float>(), ctx->d_cp_s0.as<float>(), ctx->d_cp_s1.as<float>(), tuv, tuv, prune);
+                       ctx->d_rp_s1.as<float>(), ctx->d_cp_s0.as<float>(), (const float*)nullptr, tuv, tuv, prune);
     HIPCHK(ctx, hipGetLastError());
     DBGSYNC(ctx, "pf_thresholds_kernel");
 
@@ -1019,7 +1015,7 @@ static int build_image(msfm_ctx* ctx, Image& im, const unsigned char* src8) {
     HIPCHK(ctx, hipGetLastError());
     // prefilter operands (order-independent): fp16 swizzled blocks, norms, maxima
     const int npad = im.nalloc * kBM;
-    HIPCHK(ctx, hipMalloc((void**)&im.h16, (size_t)npad * kDim * 2));
+    HIPCHK(ctx, hipMalloc((void**)&im.h16, (size_t)npad * kPfRowBytes));
     HIPCHK(ctx, hipMalloc((void**)&im.nrm, (size_t)npad * 4));
     HIPCHK(ctx, ctx->d_maxima.ensure(8));
     HIPCHK(ctx, hipMemsetAsync(ctx->d_maxima.p, 0, 8, ctx->stream));
@@ -1042,8 +1038,7 @@ static int build_image(msfm_ctx* ctx, Image& im, const unsigned char* src8) {
         if (k > 15) im.pf_safe = false;
         else {
             im.c = std::ldexp(1.f, k);
-            HIPCHK(ctx, hipMalloc((void**)&im.ext, (size_t)npad * 16));
-            hipLaunchKernelGGL(pf_ext_kernel, dim3((npad + 255) / 256), dim3(256), 0, ctx->stream, im.nrm, im.ext, npad, im.c);
+            hipLaunchKernelGGL(pf_ext_kernel, dim3((npad + 255) / 256), dim3(256), 0, ctx->stream, im.nrm, im.h16, npad, im.c);
             HIPCHK(ctx, hipGetLastError());
             HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         }

@@ -54,31 +54,35 @@ constexpr float kF16Safe = 6.0e4f;
 
 constexpr int kPfRB = 2;                  // 32-row MFMA blocks per wave (their A fragments stay in registers)
 constexpr int kPfWaveRows = 32 * kPfRB;   // 64
-constexpr int kPfWaves = 8;               // two per SIMD: waves w and w + 4 share a SIMD and alternate roles (below)
+constexpr int kPfWaves = 8;               // two per SIMD: waves w and w + 4 share a SIMD and alternate roles (msfm_sweep.hip.h)
 constexpr int kPfWgRows = kPfWaves * kPfWaveRows;  // 512 A rows per workgroup / work item
 constexpr int kPfThreads = 64 * kPfWaves;
 constexpr int kPfBT = 64;                 // B rows per tile
-constexpr int kHalfRowBytes = kDim * 2;   // one fp16 descriptor = 256 B = 16 granules of 16 B
-constexpr int kPfLdsB = kPfBT * kHalfRowBytes;  // 16 KiB per ring slot
+// One fp16 descriptor row of the prefilter operand = 17 granules of 16 B: 16 data granules (128 halfs) + the norm
+// quadruple [h_hi, h_lo, c, c, 0, 0, 0, 0].  The odd granule count is the LDS bank swizzle: row r starts at bank
+// (68 r) mod 64 = (4 r) mod 64, so the 16 rows a ds_read_b128 lane group touches at one k-step cover all 64 banks, and a
+// k-step is a CONSTANT byte offset from the row (no XOR on the address: the operand reads are base + immediate).
+constexpr int kPfRowHalfs = 136;
+constexpr int kPfRowBytes = kPfRowHalfs * 2;    // 272
+constexpr int kPfTileBytes = kPfBT * kPfRowBytes;  // 17408 B = 17 LDS-DMA pieces of 1 KiB
+constexpr int kPfTilePieces = kPfTileBytes / 1024;
 constexpr int kPfRing = 4;                // B tiles in LDS: DMA runs three tiles ahead
-constexpr int kPfColRing = 2;             // tiles of column partials in LDS
+constexpr int kPfColClasses = 4;          // column partials: maxima over 4 disjoint row classes per 512-row block
 constexpr int kPfCandBuf = 256;           // per-wave LDS candidate buffer (sweep 2), int2 entries
-constexpr int kPfExtB = kPfBT * 16;       // the tile's norm quadruples: 16 B per row
-// B ring 64 KiB | per-wave quadruple rings 32 KiB | per-wave column-threshold rings 8 KiB | zero granule 64 B |
-// per-wave candidate buffers 16 KiB | column partials 8 KiB  = 128 KiB + 64 B: one workgroup per CU
-constexpr int kPfLdsBytes = kPfRing * kPfLdsB + kPfWaves * kPfRing * kPfExtB + kPfWaves * kPfRing * 64 * 4 + 64 +
-                            kPfWaves * kPfCandBuf * 8 + kPfColRing * kPfWaves * 64 * 8;
+// B ring 68 KiB | per-wave column-threshold rings 8 KiB (dense sweep 2) | per-wave candidate buffers 16 KiB (sweep 2) |
+// column class maxima 2 tiles x 64 x 4 floats = 2 KiB: one workgroup per CU
+constexpr int kPfLdsBytes = kPfRing * kPfTileBytes + kPfWaves * kPfRing * 64 * 4 + kPfWaves * kPfCandBuf * 8 +
+                            2 * kPfBT * kPfColClasses * 4;
+static_assert(kPfTileBytes % 1024 == 0 && kPfTilePieces == 17, "tile = 17 DMA pieces");
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef float f16v __attribute__((ext_vector_type(16)));
 
 struct PfPair {            // per-pair extras of the prefilter path (parallel to PairDesc)
-    const _Float16* a_h;   // fp16 swizzled blocks
+    const _Float16* a_h;   // fp16 operand rows [npad][136 halfs] (quadruple in the 17th granule)
     const _Float16* b_h;
     const float* a_nrm;    // |row|^2, +inf on padding rows
     const float* b_nrm;
-    const _Float16* a_ext; // norm quadruples [rows][8 halfs] (the A image's are used when it plays B in a compacted sweep)
-    const _Float16* b_ext;
     float a_c, b_c;        // the images' scales c (powers of two)
     float a_nrm_max, b_nrm_max;
     long long tu_off;      // row thresholds T (S-space) [n1pad]; compacted sweep: T - |a|^2 per live row
@@ -89,9 +93,7 @@ struct PfPair {            // per-pair extras of the prefilter path (parallel to
 };
 
 // ---------------------------------------------------------------------------------------------
-// upload-time preparation: fp16 swizzled blocks, row norms, maxima
-//   block layout: [64 rows][16 granules]; granule g of row r sits at position g ^ (r & 15), so a
-//   linear LDS-DMA of the block lands bank-conflict-free for the MFMA operand reads
+// upload-time preparation: fp16 operand rows (272 B each, see kPfRowBytes), row norms, maxima
 // ---------------------------------------------------------------------------------------------
 __global__ void pf_prepare_kernel(const float* __restrict__ raw, _Float16* __restrict__ h, float* __restrict__ nrm,
                                   unsigned* __restrict__ maxima /* [0]=nrm_max bits, [1]=abs_max bits */,
@@ -109,7 +111,7 @@ __global__ void pf_prepare_kernel(const float* __restrict__ raw, _Float16* __res
             amax = fmaxf(amax, fabsf(x));
             if (!(fabsf(x) <= 3.0e38f)) amax = f_inf();  // NaN / inf
         }
-        *reinterpret_cast<h8*>(h + ((size_t)row * 16 + (g ^ (row & 15))) * 8) = v;
+        *reinterpret_cast<h8*>(h + (size_t)row * kPfRowHalfs + g * 8) = v;
         if (amax > 0.f) atomicMax(&maxima[1], __float_as_uint(amax));
     }
     for (int row = blockIdx.x * blockDim.x + threadIdx.x; row < npad; row += gridDim.x * blockDim.x) {
@@ -123,11 +125,17 @@ __global__ void pf_prepare_kernel(const float* __restrict__ raw, _Float16* __res
             atomicMax(&maxima[0], __float_as_uint(s));  // s >= 0: uint order == float order; NaN bits sort high
         }
         nrm[row] = s;
+        // the quadruple granule: zero until pf_ext_kernel fills it (an image that is not fp16-safe never gets one)
+        h8 z;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) z[k] = (_Float16)0.f;
+        *reinterpret_cast<h8*>(h + (size_t)row * kPfRowHalfs + kDim) = z;
     }
 }
 
-// norm quadruples [h_hi, h_lo, c, c, 0, 0, 0, 0], h = |row|^2 / 2 / c (padding rows: +inf -> never selected)
-__global__ void pf_ext_kernel(const float* __restrict__ nrm, _Float16* __restrict__ ext, int npad, float c) {
+// norm quadruples [h_hi, h_lo, c, c, 0, 0, 0, 0], h = |row|^2 / 2 / c (padding rows: +inf -> never selected), into the
+// 17th granule of every operand row
+__global__ void pf_ext_kernel(const float* __restrict__ nrm, _Float16* __restrict__ h16, int npad, float c) {
     const float inv_c = 1.f / c;  // power of two: exact
     for (int row = blockIdx.x * blockDim.x + threadIdx.x; row < npad; row += gridDim.x * blockDim.x) {
         const float h = 0.5f * nrm[row] * inv_c;
@@ -137,7 +145,7 @@ __global__ void pf_ext_kernel(const float* __restrict__ nrm, _Float16* __restric
         h8 v;
         v[0] = hi; v[1] = lo; v[2] = (_Float16)c; v[3] = (_Float16)c;
         v[4] = v[5] = v[6] = v[7] = (_Float16)0.f;
-        *reinterpret_cast<h8*>(ext + (size_t)row * 8) = v;
+        *reinterpret_cast<h8*>(h16 + (size_t)row * kPfRowHalfs + kDim) = v;
     }
 }
 
@@ -205,10 +213,16 @@ __global__ void pf_thresholds_kernel(const PairDesc* __restrict__ pairs, const P
         tu[pp.tu_off + e] = live ? s1 + slack : -f_inf();
     }
     if (e < pd.n2pad) {
+        // column partials of sweep 1: per 512-row A block the accumulator maxima (-S~/2) over four disjoint row classes;
+        // the second smallest of all class minima is an upper bound of the column's second-smallest S~
         float s0 = f_inf(), s1 = f_inf();
+        const float4* cp4 = reinterpret_cast<const float4*>(cp_s0);
         for (int p = 0; p < pd.a_blocks256; ++p) {
-            const long long o = pd.cp_off + (long long)p * pd.n2pad + e;
-            v2_merge(s0, s1, cp_s0[o], cp_s1[o]);
+            const float4 m = cp4[pd.cp_off + (long long)p * pd.n2pad + e];
+            v2_merge(s0, s1, -2.f * m.x, f_inf());
+            v2_merge(s0, s1, -2.f * m.y, f_inf());
+            v2_merge(s0, s1, -2.f * m.z, f_inf());
+            v2_merge(s0, s1, -2.f * m.w, f_inf());
         }
         const float nb = pp.b_nrm[e];
         const float eps = kEpsRel * (nb + pp.a_nrm_max) + kEpsAbs * (sqrtf(nb) + sqrtf(pp.a_nrm_max)) + eps_norm;
@@ -404,21 +418,20 @@ __global__ void pf_gather_live_kernel(const GatherJob* __restrict__ jobs, const 
         __syncthreads();
     }
     const int cnt = running;
-    // fp16 rows: 16 threads per row, one 16-byte granule each; granule g of row r lives at g ^ (r & 15)
-    // (r = the row number inside its 256-aligned group: dst_row + k has the same low bits)
+    // fp16 rows: 16 threads per row, one 16-byte data granule each (the compacted matrix only plays the A role:
+    // its 17th granule is never read)
     for (int k = threadIdx.x >> 4; k < cnt; k += 16) {
         const int r = live_idx[J.dst_row + k];
         const int g = threadIdx.x & 15;
         const long long d = J.dst_row + k;
-        const h8 v = *reinterpret_cast<const h8*>(J.src_h + ((size_t)r * 16 + (g ^ (r & 15))) * 8);
-        *reinterpret_cast<h8*>(cmp_h + ((size_t)d * 16 + (g ^ (int)(d & 15))) * 8) = v;
+        *reinterpret_cast<h8*>(cmp_h + (size_t)d * kPfRowHalfs + g * 8) = *reinterpret_cast<const h8*>(J.src_h + (size_t)r * kPfRowHalfs + g * 8);
     }
-    // the group's tail up to the next multiple of 256 is swept too: zero it (its rows count as dead, but an
+    // the group's tail up to the next multiple of 512 is swept too: zero it (its rows count as dead, but an
     // fp16 inf / NaN from stale memory must not reach the matrix core)
     h8 z;
     for (int j = 0; j < 8; ++j) z[j] = (_Float16)0.f;
     for (long long d = J.dst_row + cnt + (threadIdx.x >> 4); d < J.zero_upto; d += 16)
-        *reinterpret_cast<h8*>(cmp_h + ((size_t)d * 16 + (threadIdx.x & 15)) * 8) = z;
+        *reinterpret_cast<h8*>(cmp_h + (size_t)d * kPfRowHalfs + (threadIdx.x & 15) * 8) = z;
 }
 
 // finalize: the same outputs as merge_knn_kernel (idx0, d0, d1, tie queue)

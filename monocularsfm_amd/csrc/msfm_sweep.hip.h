@@ -4,8 +4,8 @@
 //
 //   Wave w owns A rows w*64 .. w*64+63 for the whole work item: its fp16 A fragments (two 32-row MFMA blocks x
 //   9 k-steps, the ninth holding the norm / threshold quadruple) live in registers, loaded once from HBM.  Only B
-//   tiles stream through LDS: a ring of four 16 KiB slots filled by LDS-DMA three tiles ahead (every wave moves 2 KiB
-//   of a tile plus its private copy of the tile's norm quadruples).
+//   tiles stream through LDS: a ring of four 17 KiB slots (64 operand rows of 272 B: 128 halfs + the row's norm
+//   quadruple) filled by LDS-DMA three tiles ahead, 17 pieces of 1 KiB per tile dealt over the eight waves.
 //
 //   PING-PONG.  Waves w and w + 4 sit on the same SIMD (a workgroup's waves are dealt to the SIMDs cyclically).  The
 //   two halves of the workgroup run the same per-tile program half a tile apart:
@@ -15,31 +15,34 @@
 //        waves 4-7  EPI(t-1)+DMA(t+2) MFMA(t)            EPI(t)+DMA(t+3)    MFMA(t+1)
 //
 //   with one s_barrier between phases.  MFMA(t): the 36 matrix instructions of a tile (2 column blocks x 2 row blocks x
-//   9 k-steps) and the LDS reads of the second column block's fragments -- nothing else.  EPI(t): everything that is
-//   not matrix work -- the v_max3 epilogues on the 64 results per lane, the column partials, the DMA pieces of tile
-//   t+3, the fold of the previous tile's column partials, and the LDS reads of the NEXT tile's first fragments, so that
-//   the following MFMA phase starts on registers.  While one wave of a SIMD feeds the matrix pipe, the other one does
-//   its VALU / LDS / VMEM work: the pipe sees MFMAs back to back (MI355X_MICROARCH.md, "Two waves per SIMD"), where
-//   four unsynchronised waves of the round-1 kernel (each reads -> MFMAs -> epilogue) kept it 56 % busy.
+//   9 k-steps) and the LDS reads of the second column block's fragments (base + immediate offset, no address
+//   arithmetic) -- nothing else.  EPI(t): everything that is not matrix work -- the v_max3 epilogues on the 64 results per
+//   lane, the column maxima (one LDS atomic per wave and tile), the DMA pieces of tile t+3 and the LDS reads of the NEXT
+//   tile's first fragments, so that the following MFMA phase starts on registers.  While one wave of a SIMD feeds the
+//   matrix pipe, the other one does its VALU / LDS / VMEM work (MI355X_MICROARCH.md, "Two waves per SIMD").
 //
-//   Synchronisation: raw s_barrier + COUNTED s_waitcnt vmcnt(N) (loads only: stores may retire out of order), so
-//   the DMA groups of the two younger tiles stay in flight across barriers.  Tile u is complete in LDS one phase
-//   before its first MFMA (so it can be pre-read): waves 0-3 wait for their share at the end of MFMA(u-1), waves 4-7 at
-//   the end of EPI(u-2); both then have exactly one younger DMA group outstanding.  The loop contains no ordinary
-//   global load (hipcc would drain vmcnt(0) for it); LDS stores inside the loop are inline-asm ds_write_b64 for the
-//   same reason, and the A-fragment loads are pinned by a register-use asm before the loop.
+//   Synchronisation: raw s_barrier + COUNTED s_waitcnt vmcnt(N), so the DMA group of the youngest tile stays in flight
+//   across barriers.  Tile u is complete in LDS one phase before its first MFMA (so it can be pre-read): waves 0-3 wait
+//   for their share at the end of MFMA(u-1), waves 4-7 at the end of EPI(u-2); both then have exactly one younger DMA
+//   group outstanding.  (Loads retire in order among themselves; a store may retire out of order, so the count relies
+//   on loads only: with N = pieces per group, "at most N outstanding" implies the older group has landed, because one
+//   of its loads pending would keep all N younger loads pending as well.)  The loop contains no ordinary global load
+//   (hipcc would drain vmcnt(0) for it); the A-fragment loads are pinned by a register-use asm before the loop.
 //
 //   MFMA layout (v_mfma_f32_32x32x16_f16): lane l feeds A[row l&31][k (l>>5)*8..+7] and B[col l&31][same k]; it
-//   receives for column l&31 the 16 rows (r&3) + 8 (r>>2) + 4 (l>>5), r = 0..15.  The fp16 blocks are stored
-//   [row][granule ^ (row & 15)], so the lane-linear DMA image is bank-conflict-free for the ds_read_b128 operand reads.
+//   receives for column l&31 the 16 rows (r&3) + 8 (r>>2) + 4 (l>>5), r = 0..15.
 //
-// PASS 1: accumulator = -S~/2.  Row maxima (v_max3 over running / block 0 / block 1: 0.5 op per element), column
-//         maxima (v_max3 chains: 0.5 op per element); the two smallest S~ per row (merged over the 32 lanes at the
-//         end) and per column (lane pair merged, the eight waves folded in LDS) are written as partials.
+// PASS 1: accumulator = -S~/2.  Rows: running maxima (v_max3 over running / block 0 / block 1: 0.5 op per element),
+//         merged over the 32 lanes at the end of the item -> the two smallest S~ per row as one partial per B range.
+//         Columns: v_max3 chains over the lane's 32 rows (0.5 op per element), the two lane halves joined with
+//         v_permlane32_swap, then ONE ds_max_f32 per wave and tile into the tile's class array [64 columns][4 classes]
+//         (class = wave & 3: the maxima over four disjoint quarters of the 512 rows); a rotating wave copies the array
+//         of the previous tile to HBM (one float4 per column and A block).  pf_thresholds_kernel takes the minimum and
+//         the second smallest of the class minima: an upper bound of the column's second-smallest S~, which is all the
+//         threshold needs.
 // PASS 2: accumulator = -S~/2; append (q, t) where S~ <= T_row[q] or S~ <= T_col[t]   (dense sweep 2).
 // PASS 3: A = compacted live rows, accumulator = -(S~ - T_row)/2; append (k, t) where it is >= 0.
 //         PASS 2 / 3 first reduce a block to "any hit?" with v_max3 and only then build the bit mask.
-// VMEM LOADS per wave per tile (the counted wait depends on it): PASS 1 / 3: 3 DMA, PASS 2: 4 DMA.
 #pragma once
 // (included inside namespace msfm)
 
@@ -82,12 +85,10 @@ __global__ __launch_bounds__(kPfThreads, 2) void sweep_kernel(
     typedef const __attribute__((address_space(1))) float* gfloat_p;  // keep these loads off the FLAT path
     typedef const __attribute__((address_space(1))) h8* gh8_p;
     extern __shared__ __attribute__((aligned(16))) char pf_smem[];
-    char* sB = pf_smem;
-    char* sExt = pf_smem + kPfRing * kPfLdsB;                                          // [wave][slot][64 rows x 16 B]
-    float* sThr = reinterpret_cast<float*>(sExt + kPfWaves * kPfRing * kPfExtB);       // [wave][slot][64]
-    char* sZero = reinterpret_cast<char*>(sThr + kPfWaves * kPfRing * 64);             // 64 B, first 16 used
-    char* sCand = sZero + 64;                                                           // [wave][kPfCandBuf] int2
-    char* sCol = sCand + kPfWaves * kPfCandBuf * 8;                                     // [col slot][wave][64] float2
+    char* sB = pf_smem;                                                                // [ring slot][64 rows x 272 B]
+    float* sThr = reinterpret_cast<float*>(pf_smem + kPfRing * kPfTileBytes);          // [wave][slot][64] (PASS 2)
+    char* sCand = reinterpret_cast<char*>(sThr + kPfWaves * kPfRing * 64);             // [wave][kPfCandBuf] int2 (PASS 2 / 3)
+    float* sCol = reinterpret_cast<float*>(sCand + kPfWaves * kPfCandBuf * 8);         // [2 tiles][64 columns][4 classes] (PASS 1)
 
     const WorkItem item = items[blockIdx.x];
     if (item.pair < 0) return;
@@ -103,46 +104,51 @@ __global__ __launch_bounds__(kPfThreads, 2) void sweep_kernel(
     // 64-row tiles; the last 128-row block of the B image may hold an all-padding second tile: skip it
     const int t_begin = item.bt_begin * 2, t_end = min(item.bt_end * 2, max(item.bt_begin * 2 + 1, (pd.n2 + kPfBT - 1) / kPfBT));
     const char* gB = reinterpret_cast<const char*>(pp.b_h);
-    const char* gE = reinterpret_cast<const char*>(pp.b_ext);
     const gfloat_p g_anrm = (gfloat_p)pp.a_nrm;
     const gfloat_p g_tu = (gfloat_p)tu;
-    char* ext_w = sExt + wave * (kPfRing * kPfExtB);   // this wave's private copies
     float* thr_w = sThr + wave * (kPfRing * 64);
 
     // DMA group of tile tt (clamped: the tail re-fetches the last tile so every EPI phase issues the same number of
-    // VMEM loads): this wave's eighth of the 16 KiB tile + its private quadruples / thresholds
+    // VMEM loads): pieces w and w + 8 of the tile's 17 (wave 0: piece 16 as well) + in PASS 2 the wave's private copy of
+    // the tile's column thresholds
+    const char* g_lane = gB + wave * 1024 + lane * 16;
     auto dma_tile = [&](int tt) {
         const int tc = tt < t_end ? tt : t_end - 1;
         const int sl = (tt - t_begin) & (kPfRing - 1);
-        const char* g = gB + (size_t)tc * kPfLdsB + wave * 2048 + lane * 16;
-        char* l = sB + sl * kPfLdsB + wave * 2048;
-#pragma unroll
-        for (int k = 0; k < 2; ++k)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + k * 1024),
-                                             (__attribute__((address_space(3))) void*)(l + k * 1024), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gE + (size_t)tc * kPfExtB + lane * 16),
-                                         (__attribute__((address_space(3))) void*)(ext_w + sl * kPfExtB), 16, 0, 0);
+        const char* g = g_lane + (size_t)tc * kPfTileBytes;
+        char* l = sB + sl * kPfTileBytes + wave * 1024;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + 8192),
+                                         (__attribute__((address_space(3))) void*)(l + 8192), 16, 0, 0);
+        if (wave == 0)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + 16384),
+                                             (__attribute__((address_space(3))) void*)(l + 16384), 16, 0, 0);
         if (PASS == 2)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(tv + pp.tv_off + tc * kPfBT + lane),
                                              (__attribute__((address_space(3))) void*)(thr_w + sl * 64), 4, 0, 0);
     };
-    constexpr int kDmaOps = (PASS == 2) ? 4 : 3;
+    // loads per group: the counted waits below must name the issuing wave's own number
+    constexpr int kDmaOps = (PASS == 2) ? 3 : 2;   // waves 1..7; wave 0: one more
+    auto wait_older_group = [&]() {
+        if (wave == 0) wait_vmcnt<kDmaOps + 1>();
+        else wait_vmcnt<kDmaOps>();
+    };
 
     dma_tile(t_begin);
     dma_tile(t_begin + 1);
     dma_tile(t_begin + 2);
-    if (tid < 4) reinterpret_cast<float*>(sZero)[tid] = 0.f;
+    if (PASS == 1 && tid < 2 * kPfBT) reinterpret_cast<float4*>(sCol)[tid] = make_float4(-f_inf(), -f_inf(), -f_inf(), -f_inf());
 
-    // A fragments: rows a_blk*512 + wave*64 + rb*32 + lcol, granule 2*ks + lhalf (stored at ^ (row & 15));
+    // A fragments: rows a_blk*512 + wave*64 + rb*32 + lcol, granule 2*ks + lhalf;
     // ninth k-step: [-c, -c, x_hi, x_lo, 0...] in the lhalf == 0 lanes (k = 128..135), zeros in the others
     h8 af[kPfRB][9];
     const float inv_c = 1.f / pp.b_c;
 #pragma unroll
     for (int rb = 0; rb < kPfRB; ++rb) {
         const int frow = item.a_blk * kPfWgRows + wave * kPfWaveRows + rb * 32 + lcol;
-        const gh8_p ga = (gh8_p)(pp.a_h) + (size_t)frow * 16;
+        const gh8_p ga = (gh8_p)(pp.a_h + (size_t)frow * kPfRowHalfs);   // 272-byte rows: 17 aligned granules
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) af[rb][ks] = ga[(2 * ks + lhalf) ^ (frow & 15)];
+        for (int ks = 0; ks < 8; ++ks) af[rb][ks] = ga[2 * ks + lhalf];
         // padding rows: X = -inf -> accumulator -inf, never a maximum, never a hit
         float X;
         if (PASS == 3) X = frow < pd.n1 ? 0.5f * g_tu[pp.tu_off + frow] : -f_inf();
@@ -186,9 +192,6 @@ __global__ __launch_bounds__(kPfThreads, 2) void sweep_kernel(
     // sweep 2: wave-private candidate buffer in LDS
     int2* cbuf = reinterpret_cast<int2*>(sCand) + wave * kPfCandBuf;
     const unsigned cbuf_lds = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)cbuf;
-    // sweep 1: the column partials of the eight waves meet in LDS ([col slot][wave][64 columns] x (s0, s1)) and are
-    // folded by one wave a tile later: one partial per 512-row A block and column reaches HBM
-    const unsigned colbuf_lds = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)sCol;
     int n_buf = 0;  // wave-uniform
     auto flush_candidates = [&]() {
         if (n_buf == 0) return;
@@ -202,32 +205,24 @@ __global__ __launch_bounds__(kPfThreads, 2) void sweep_kernel(
         n_buf = 0;
     };
 
-    const int xb = lcol & 15;  // both column blocks: row & 15 == lcol & 15
     const bool wave_active = item.a_blk * kPfWgRows + wave * kPfWaveRows < pd.n1;  // wave-uniform
-    if (PASS == 1 && !wave_active) {
-        // its column partials are never written: park (+inf, +inf) in every slot once
-        const float2 pr = make_float2(f_inf(), f_inf());
-#pragma unroll
-        for (int sl = 0; sl < kPfColRing; ++sl)
-            asm volatile("ds_write_b64 %0, %1" ::"v"(colbuf_lds + (unsigned)((sl * kPfWaves + wave) * 64 + lane) * 8u), "v"(pr) : "memory");
-    }
 
-    struct BlockMeta { float hc; int col; int cslot; };  // hc: PASS 2 column hit level -T_col/2; cslot: LDS slot of the column partials
-    const int zero_off = (int)(sZero - pf_smem);
-    // B fragments of the tile in ring slot sl: the 8 data k-steps of column block 0, and the ninth k-step of BOTH
-    // column blocks -- the quadruple of column cb*32 + lcol for k = 128..131 in the lhalf == 0 lanes, zeros (k = 132..135)
-    // in the others (one base pointer + selected offset: a select between two pointers makes hipcc drain vmcnt(0)).
-    // The quadruple only fills k = 0..3 of its k-step: the K = 8 instruction (lane l: k = 4 (l >> 5) .. +3) takes half
-    // the passes of a K = 16 one.
+    struct BlockMeta { float hc; int col; };  // hc: PASS 2 column hit level -T_col/2
+    // B fragments of the tile in ring slot sl: the 8 data k-steps of column block 0 (row lcol of the slot, granule
+    // 2 ks + lhalf: a constant offset from the lane's row address), and the ninth k-step of BOTH column blocks -- the first
+    // 8 bytes of the row's 17th granule ([h_hi, h_lo, c, c] = k 128..131) in the lhalf == 0 lanes, its zero half
+    // (k 132..135) in the others.  The quadruple only fills k = 0..3 of its k-step: the K = 8 instruction (lane l:
+    // k = 4 (l >> 5) .. +3) takes half the passes of a K = 16 one.
     typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    const int lane_row_off = lcol * kPfRowBytes + lhalf * 16;
+    const int lane_ext_off = lcol * kPfRowBytes + 2 * kDim + lhalf * 8;
     auto load_bf = [&](int sl, h8 (&bf)[8], h4 (&be)[2]) {
-        const char* pb = sB + sl * kPfLdsB + lcol * kHalfRowBytes;
-        const int pe_off = (int)(ext_w - pf_smem) + sl * kPfExtB;
+        const char* pb = sB + sl * kPfTileBytes + lane_row_off;
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) bf[ks] = *reinterpret_cast<const h8*>(pb + (((2 * ks + lhalf) ^ xb) << 4));
-#pragma unroll
-        for (int cb = 0; cb < 2; ++cb)
-            be[cb] = *reinterpret_cast<const h4*>(pf_smem + (lhalf == 0 ? pe_off + (cb * 32 + lcol) * 16 : zero_off));
+        for (int ks = 0; ks < 8; ++ks) bf[ks] = *reinterpret_cast<const h8*>(pb + ks * 32);
+        const char* pe = sB + sl * kPfTileBytes + lane_ext_off;
+        be[0] = *reinterpret_cast<const h4*>(pe);
+        be[1] = *reinterpret_cast<const h4*>(pe + 32 * kPfRowBytes);
     };
     auto mfma_block = [&](const h8 (&bf)[8], h4 be, f16v (&acc)[kPfRB]) {
 #pragma unroll
@@ -246,7 +241,7 @@ __global__ __launch_bounds__(kPfThreads, 2) void sweep_kernel(
     // been issued its registers take the fragment of column block 1 (the read lands 16 MFMAs before it is needed).
     // The sched_group_barriers pin that interleave: left alone, hipcc issues all 18 MFMAs, then the reads, then waits.
     auto mfma_block_reload = [&](int sl, h8 (&bf)[8], h4 be, f16v (&acc)[kPfRB]) {
-        const char* pb = sB + sl * kPfLdsB + (32 + lcol) * kHalfRowBytes;
+        const char* pb = sB + sl * kPfTileBytes + 32 * kPfRowBytes + lane_row_off;
 #pragma unroll
         for (int r = 0; r < 16; ++r)
 #pragma unroll
@@ -255,7 +250,7 @@ __global__ __launch_bounds__(kPfThreads, 2) void sweep_kernel(
         for (int ks = 0; ks < 8; ++ks) {
 #pragma unroll
             for (int rb = 0; rb < kPfRB; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[rb][ks], bf[ks], acc[rb], 0, 0, 0);
-            bf[ks] = *reinterpret_cast<const h8*>(pb + (((2 * ks + lhalf) ^ xb) << 4));
+            bf[ks] = *reinterpret_cast<const h8*>(pb + ks * 32);
         }
 #pragma unroll
         for (int rb = 0; rb < kPfRB; ++rb)
@@ -267,41 +262,31 @@ __global__ __launch_bounds__(kPfThreads, 2) void sweep_kernel(
         }
         __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
     };
-    // branch-free part of the epilogue of one column block; returns "this lane saw a hit" for the sweep-2 variants
-    auto epilogue_valu = [&](const f16v (&acc)[kPfRB], const BlockMeta& bm) -> bool {
-        // column maximum of the accumulator over this lane's 32 rows: 16 v_max3
-        float m = -f_inf();
-        if (PASS != 2) {
+    // maximum of the accumulator over this lane's 32 rows of one column block: two independent v_max3 chains
+    auto column_max = [&](const f16v (&acc)[kPfRB]) -> float {
+        float m[kPfRB];
 #pragma unroll
-            for (int rb = 0; rb < kPfRB; ++rb)
+        for (int rb = 0; rb < kPfRB; ++rb) {
+            m[rb] = max3f(acc[rb][0], acc[rb][1], acc[rb][2]);
 #pragma unroll
-                for (int r = 0; r < 16; r += 2) m = max3f(m, acc[rb][r], acc[rb][r + 1]);
+            for (int r = 3; r < 15; r += 2) m[rb] = max3f(m[rb], acc[rb][r], acc[rb][r + 1]);
+            m[rb] = fmaxf(m[rb], acc[rb][15]);
         }
-        if (PASS == 1) {
-            // Only MAXIMA are tracked: the second smallest of the minima of S~ over disjoint subsets is an upper
-            // bound of the true second-smallest S~, which is all the threshold needs (it is exact unless both
-            // neighbours fall into one subset).  Partner lane (l ^ 32): the other 32 rows of the wave.
-            const float other = __shfl_xor(m, 32);
-            // (s0, s1) of this wave's 64 rows for column bm.col -> LDS (inline asm: see append_hits)
-            if (lhalf == 0) {
-                const float2 pr = make_float2(-2.f * fmaxf(m, other), -2.f * fminf(m, other));
-                asm volatile("ds_write_b64 %0, %1" ::"v"(colbuf_lds + (unsigned)(bm.cslot + lcol) * 8u), "v"(pr) : "memory");
+        return kPfRB == 2 ? fmaxf(m[0], m[1]) : m[0];
+    };
+    // sweep 2: "this lane saw a hit" in one column block
+    auto any_hit = [&](const f16v (&acc)[kPfRB], const BlockMeta& bm) -> bool {
+        if (PASS == 3) return column_max(acc) >= 0.f;
+        // row criterion: max over (acc - level_row) >= 0; column criterion: max over acc >= level_col
+        float mr = -f_inf(), mc = -f_inf();
+#pragma unroll
+        for (int rb = 0; rb < kPfRB; ++rb)
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                mr = max3f(mr, acc[rb][r] - rs0[rb][r], acc[rb][r + 1] - rs0[rb][r + 1]);
+                mc = max3f(mc, acc[rb][r], acc[rb][r + 1]);
             }
-            return false;
-        } else if (PASS == 3) {
-            return m >= 0.f;
-        } else {
-            // row criterion: max over (acc - level_row) >= 0; column criterion: max over acc >= level_col
-            float mr = -f_inf(), mc = -f_inf();
-#pragma unroll
-            for (int rb = 0; rb < kPfRB; ++rb)
-#pragma unroll
-                for (int r = 0; r < 16; r += 2) {
-                    mr = max3f(mr, acc[rb][r] - rs0[rb][r], acc[rb][r + 1] - rs0[rb][r + 1]);
-                    mc = max3f(mc, acc[rb][r], acc[rb][r + 1]);
-                }
-            return mr >= 0.f || mc >= bm.hc;
-        }
+        return mr >= 0.f || mc >= bm.hc;
     };
     // sweep 2, rare path: the block holds at least one hit -> bit mask per lane (element k = rb*16 + r at bit 31-k),
     // slotted with ballot/popcount into this wave's LDS buffer -- no atomics in the loop -- and flushed to the
@@ -335,38 +320,38 @@ __global__ __launch_bounds__(kPfThreads, 2) void sweep_kernel(
             n_buf += __popcll(mm);
         }
     };
-    // sweep 1: lane = column of tile tt; fold the eight waves' (s0, s1) and store one partial per A block
-    auto merge_columns = [&](int tt) {
-        const unsigned base = colbuf_lds + (unsigned)((((tt - t_begin) & (kPfColRing - 1)) * kPfWaves) * 64 + lane) * 8u;
-        float2 w[8];
-        asm volatile("ds_read_b64 %0, %8\n\tds_read_b64 %1, %8 offset:512\n\tds_read_b64 %2, %8 offset:1024\n\t"
-                     "ds_read_b64 %3, %8 offset:1536\n\tds_read_b64 %4, %8 offset:2048\n\tds_read_b64 %5, %8 offset:2560\n\t"
-                     "ds_read_b64 %6, %8 offset:3072\n\tds_read_b64 %7, %8 offset:3584\n\ts_waitcnt lgkmcnt(0)"
-                     : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3]), "=&v"(w[4]), "=&v"(w[5]), "=&v"(w[6]), "=&v"(w[7])
-                     : "v"(base) : "memory");
-        v2_merge(w[0].x, w[0].y, w[1].x, w[1].y);
-        v2_merge(w[2].x, w[2].y, w[3].x, w[3].y);
-        v2_merge(w[4].x, w[4].y, w[5].x, w[5].y);
-        v2_merge(w[6].x, w[6].y, w[7].x, w[7].y);
-        v2_merge(w[0].x, w[0].y, w[2].x, w[2].y);
-        v2_merge(w[4].x, w[4].y, w[6].x, w[6].y);
-        v2_merge(w[0].x, w[0].y, w[4].x, w[4].y);
-        const long long o = pd.cp_off + (long long)item.a_blk * pd.n2pad + tt * kPfBT + lane;
-        cp_s0[o] = w[0].x;
-        cp_s1[o] = w[0].y;
+    // sweep 1, columns.  Lane l holds the maxima of column l & 31 over its half's 32 rows for both column blocks (mA,
+    // mB).  v_permlane32_swap exchanges the upper half of mA with the lower half of mB; the maximum of the two results is,
+    // in lane l, the maximum over all 64 rows of the wave for tile column l (block 0 in lanes 0-31, block 1 in 32-63).
+    // One LDS atomic folds it into the tile's class array; inline asm keeps hipcc from draining vmcnt(0) for an LDS
+    // access it would see.
+    const unsigned col_lds = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)sCol +
+                             (unsigned)(lane * kPfColClasses + (wave & (kPfColClasses - 1))) * 4u;
+    auto fold_columns = [&](float mA, float mB, int cs) {
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mA), __float_as_uint(mB), false, false);
+        const float m = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+        asm volatile("ds_max_f32 %0, %1" ::"v"(col_lds + (unsigned)cs * (kPfBT * kPfColClasses * 4)), "v"(m) : "memory");
+    };
+    // sweep 1: lane = column of tile tt: copy its four class maxima to HBM and reset the array for tile tt + 2
+    const unsigned colrow_lds = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)sCol + (unsigned)lane * 16u;
+    auto store_columns = [&](int tt) {
+        const unsigned a = colrow_lds + (unsigned)((tt - t_begin) & 1) * (kPfBT * kPfColClasses * 4);
+        v4f v;
+        const v4f ninf = {-f_inf(), -f_inf(), -f_inf(), -f_inf()};
+        asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)\n\tds_write_b128 %1, %2" : "=&v"(v) : "v"(a), "v"(ninf) : "memory");
+        reinterpret_cast<v4f*>(cp_s0)[pd.cp_off + (long long)item.a_blk * pd.n2pad + tt * kPfBT + lane] = v;
     };
 
-    lds_barrier();   // every wave's share of tiles 0..2 (and the zero granule, the parked partials) is in LDS
+    lds_barrier();   // every wave's share of tiles 0..2 (and the column class arrays) is in LDS
     // pre-read of the next tile's first fragments at the end of the EPI phase (not in the dense sweep 2: its
     // epilogue keeps the row levels and the thresholds live as well, the 36 registers would spill)
     constexpr bool kPreRead = PASS != 2;
     h8 bf[8];
     h4 be[2];
     if (kPreRead && wave_active) load_bf(0, bf, be);   // first fragments of the first tile
-    if (grp == 1) lds_barrier();          // the odd half starts half a tile later
+    if (grp == 1) lds_barrier();                         // the odd half starts half a tile later
 
     f16v accA[kPfRB], accB[kPfRB];
-    BlockMeta metaA = {0.f, 0, 0}, metaB = {0.f, 0, 0};
     MSFM_PROBE_BEGIN
 #pragma unroll 1
     for (int t = t_begin; t < t_end; ++t) {
@@ -375,58 +360,49 @@ __global__ __launch_bounds__(kPfThreads, 2) void sweep_kernel(
         // A wave whose 64 rows are all padding (tail of an image / of a compacted row set) still takes part in the DMA
         // and the barriers, but leaves the matrix pipe alone
         if (wave_active) {
-#ifndef MSFM_SWEEP_NOPRIO
             __builtin_amdgcn_s_setprio(1);
-#endif
             if (!kPreRead) load_bf(sl, bf, be);
             mfma_block_reload(sl, bf, be[0], accA);
             mfma_block(bf, be[1], accB);
-#ifndef MSFM_SWEEP_NOPRIO
             __builtin_amdgcn_s_setprio(0);
-#endif
         }
+        MSFM_PROBE(0)
         // tile t+1 must be complete one phase before its first MFMA: this half waits here for its share (its DMA
         // group of tile t+2 may stay in flight), the other half at the end of its EPI phase
-        MSFM_PROBE(0)
-        if (grp == 0) wait_vmcnt<kDmaOps>();
+        if (grp == 0) wait_older_group();
         lds_barrier();
         MSFM_PROBE(1)
         // ---- EPI phase: everything that is not matrix work ---------------------------------------------------
+        // (the store comes before the DMA group: the counted wait then covers it together with the older group)
+        if (PASS == 1 && grp == 0 && t > t_begin && wave == ((t - t_begin) & 3)) store_columns(t - 1);
         dma_tile(t + 3);   // into the slot of tile t-1, dead since the barrier before last
         if (wave_active) {
-            const float* thr = thr_w + sl * 64;
-            metaA.hc = (PASS == 2) ? -0.5f * thr[lcol] : 0.f;
-            metaA.col = t * kPfBT + lcol;
-            metaA.cslot = (((t - t_begin) & (kPfColRing - 1)) * kPfWaves + wave) * 64;
-            metaB.hc = (PASS == 2) ? -0.5f * thr[32 + lcol] : 0.f;
-            metaB.col = t * kPfBT + 32 + lcol;
-            metaB.cslot = metaA.cslot + 32;
-            const bool anyA = epilogue_valu(accA, metaA);
-            const bool anyB = epilogue_valu(accB, metaB);
             if (PASS == 1) {
+                fold_columns(column_max(accA), column_max(accB), (t - t_begin) & 1);
 #pragma unroll
                 for (int rb = 0; rb < kPfRB; ++rb)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) rs0[rb][r] = max3f(rs0[rb][r], accA[rb][r], accB[rb][r]);
-            }
-            if (PASS >= 2) {
+            } else {
+                const float* thr = thr_w + sl * 64;
+                const BlockMeta metaA = {(PASS == 2) ? -0.5f * thr[lcol] : 0.f, t * kPfBT + lcol};
+                const BlockMeta metaB = {(PASS == 2) ? -0.5f * thr[32 + lcol] : 0.f, t * kPfBT + 32 + lcol};
+                const bool anyA = any_hit(accA, metaA);
+                const bool anyB = any_hit(accB, metaB);
                 append_hits(anyA, accA, metaA);
                 append_hits(anyB, accB, metaB);
             }
         }
-        // tile t-1's column partials are complete in LDS (both halves wrote them before the last barrier): one wave of
-        // the even half folds them
-        if (PASS == 1 && grp == 0 && t > t_begin && wave == ((t - t_begin) & 3)) merge_columns(t - 1);
-        if (kPreRead && wave_active && t + 1 < t_end) load_bf((sl + 1) & (kPfRing - 1), bf, be);   // pre-read: the next MFMA phase starts on registers
+        if (kPreRead && wave_active && t + 1 < t_end) load_bf((sl + 1) & (kPfRing - 1), bf, be);   // the next MFMA phase starts on registers
         MSFM_PROBE(2)
-        if (grp == 1) wait_vmcnt<kDmaOps>();
+        if (grp == 1) wait_older_group();
         lds_barrier();
         MSFM_PROBE(3)
     }
     MSFM_PROBE_END
     if (grp == 0) lds_barrier();   // the odd half's last EPI phase
     if (PASS >= 2) flush_candidates();
-    if (PASS == 1 && wave == 0) merge_columns(t_end - 1);
+    if (PASS == 1 && wave == 0) store_columns(t_end - 1);
 
     if (PASS == 1) {
         // rows: S~ = -2 * accumulator; the two smallest of the 32 lanes' minima; one partial slot per B range
@@ -454,4 +430,3 @@ __global__ __launch_bounds__(kPfThreads, 2) void sweep_kernel(
         }
     }
 }
-
