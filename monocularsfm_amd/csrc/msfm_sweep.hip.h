@@ -34,10 +34,10 @@
 //
 // PASS 1: accumulator = -S~/2.  Rows: running maxima (v_max3 over running / block 0 / block 1: 0.5 op per element),
 //         merged over the 32 lanes at the end of the item -> the two smallest S~ per row as one partial per B range.
-//         Columns: v_max3 chains over the lane's 32 rows (0.5 op per element), the two lane halves joined with
-//         v_permlane32_swap, then ONE ds_max_f32 per wave and tile into the tile's class array [64 columns][4 classes]
-//         (class = wave & 3: the maxima over four disjoint quarters of the 512 rows); a rotating wave copies the array
-//         of the previous tile to HBM (one float4 per column and A block).  pf_thresholds_kernel takes the minimum and
+//         Columns: v_max3 chains over the lane's 32 rows (0.5 op per element), then one ds_max_f32 per column block into
+//         the tile's class array [4 classes][64 columns] (class = 2 (wave & 1) + lane half: the maxima over four disjoint
+//         quarters of the 512 rows); a rotating wave copies the array of the previous tile to HBM (one float4 per column
+//         and A block).  pf_thresholds_kernel takes the minimum and
 //         the second smallest of the class minima: an upper bound of the column's second-smallest S~, which is all the
 //         threshold needs.
 // PASS 2: accumulator = -S~/2; append (q, t) where S~ <= T_row[q] or S~ <= T_col[t]   (dense sweep 2).
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(kPfThreads, 2) void sweep_kernel(
     dma_tile(t_begin);
     dma_tile(t_begin + 1);
     dma_tile(t_begin + 2);
-    if (PASS == 1 && tid < 2 * kPfBT) reinterpret_cast<float4*>(sCol)[tid] = make_float4(-f_inf(), -f_inf(), -f_inf(), -f_inf());
+    if (PASS == 1) sCol[tid] = -f_inf();   // 2 tiles x 4 classes x 64 columns = 512 floats
 
     // A fragments: rows a_blk*512 + wave*64 + rb*32 + lcol, granule 2*ks + lhalf;
     // ninth k-step: [-c, -c, x_hi, x_lo, 0...] in the lhalf == 0 lanes (k = 128..135), zeros in the others
@@ -320,25 +320,28 @@ __global__ __launch_bounds__(kPfThreads, 2) void sweep_kernel(
             n_buf += __popcll(mm);
         }
     };
-    // sweep 1, columns.  Lane l holds the maxima of column l & 31 over its half's 32 rows for both column blocks (mA,
-    // mB).  v_permlane32_swap exchanges the upper half of mA with the lower half of mB; the maximum of the two results is,
-    // in lane l, the maximum over all 64 rows of the wave for tile column l (block 0 in lanes 0-31, block 1 in 32-63).
-    // One LDS atomic folds it into the tile's class array; inline asm keeps hipcc from draining vmcnt(0) for an LDS
-    // access it would see.
+    // sweep 1, columns.  Lane l holds the maximum of column l & 31 over the 32 rows of its lane half, per column block.
+    // It goes, with one LDS atomic per column block, into the tile's class array [4 classes][64 columns], class =
+    // 2 (wave & 1) + lane half: the maxima over four disjoint quarters of the block's 512 rows (even / odd waves x the two
+    // row interleaves of the MFMA layout -- an image of a single wave still fills two classes).  Inline asm keeps hipcc
+    // from draining vmcnt(0) for an LDS access it would see.
     const unsigned col_lds = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)sCol +
-                             (unsigned)(lane * kPfColClasses + (wave & (kPfColClasses - 1))) * 4u;
+                             (unsigned)((2 * (wave & 1) + lhalf) * kPfBT + lcol) * 4u;
     auto fold_columns = [&](float mA, float mB, int cs) {
-        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mA), __float_as_uint(mB), false, false);
-        const float m = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
-        asm volatile("ds_max_f32 %0, %1" ::"v"(col_lds + (unsigned)cs * (kPfBT * kPfColClasses * 4)), "v"(m) : "memory");
+        const unsigned a = col_lds + (unsigned)cs * (kPfBT * kPfColClasses * 4);
+        asm volatile("ds_max_f32 %0, %1\n\tds_max_f32 %0, %2 offset:128" ::"v"(a), "v"(mA), "v"(mB) : "memory");
     };
-    // sweep 1: lane = column of tile tt: copy its four class maxima to HBM and reset the array for tile tt + 2
-    const unsigned colrow_lds = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)sCol + (unsigned)lane * 16u;
+    // sweep 1: lane = column of tile tt: copy its four class maxima to HBM (one float4 per column and A block) and
+    // reset them for tile tt + 2
+    const unsigned colrow_lds = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)sCol + (unsigned)lane * 4u;
     auto store_columns = [&](int tt) {
         const unsigned a = colrow_lds + (unsigned)((tt - t_begin) & 1) * (kPfBT * kPfColClasses * 4);
         v4f v;
-        const v4f ninf = {-f_inf(), -f_inf(), -f_inf(), -f_inf()};
-        asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)\n\tds_write_b128 %1, %2" : "=&v"(v) : "v"(a), "v"(ninf) : "memory");
+        const float ninf = -f_inf();
+        asm volatile("ds_read_b32 %0, %4\n\tds_read_b32 %1, %4 offset:256\n\tds_read_b32 %2, %4 offset:512\n\tds_read_b32 %3, %4 offset:768\n\t"
+                     "s_waitcnt lgkmcnt(0)\n\t"
+                     "ds_write_b32 %4, %5\n\tds_write_b32 %4, %5 offset:256\n\tds_write_b32 %4, %5 offset:512\n\tds_write_b32 %4, %5 offset:768"
+                     : "=&v"(v.x), "=&v"(v.y), "=&v"(v.z), "=&v"(v.w) : "v"(a), "v"(ninf) : "memory");
         reinterpret_cast<v4f*>(cp_s0)[pd.cp_off + (long long)item.a_blk * pd.n2pad + tt * kPfBT + lane] = v;
     };
 
@@ -378,7 +381,7 @@ __global__ __launch_bounds__(kPfThreads, 2) void sweep_kernel(
         dma_tile(t + 3);   // into the slot of tile t-1, dead since the barrier before last
         if (wave_active) {
             if (PASS == 1) {
-                fold_columns(column_max(accA), column_max(accB), (t - t_begin) & 1);
+                fold_columns(column_max(accA), column_max(accB), (t - t_begin) & 1);   // block 1: columns 32..63 = +128 B
 #pragma unroll
                 for (int rb = 0; rb < kPfRB; ++rb)
 #pragma unroll

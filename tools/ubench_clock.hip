@@ -1,0 +1,68 @@
+// ubench_clock.hip -- what does s_memtime count, and what clock does the part sustain under an MFMA-only / a VALU-only
+// loop?  Per kernel: wall time (HIP events), s_memtime ticks per iteration (one wave per SIMD reports) -> ticks per
+// instruction and ticks per microsecond.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+
+__global__ __launch_bounds__(256) void k_mfma(float* out, unsigned long long* ticks, int iters, unsigned seed) {
+    h8 a, b;
+    unsigned x = seed + threadIdx.x * 2654435761u + blockIdx.x * 40503u;
+    for (int i = 0; i < 8; ++i) { x = x * 1664525u + 1013904223u; a[i] = (_Float16)((x >> 8) * (1.f / 16777216.f)); x = x * 1664525u + 1013904223u; b[i] = (_Float16)((x >> 8) * (1.f / 16777216.f)); }
+    f16v c0, c1, c2, c3;
+    for (int r = 0; r < 16; ++r) { c0[r] = c1[r] = c2[r] = c3[r] = 0.f; }
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {
+        c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c1, 0, 0, 0);
+        c2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c2, 0, 0, 0);
+        c3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c3, 0, 0, 0);
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    float r = 0;
+    for (int i = 0; i < 16; ++i) r += c0[i] + c1[i] + c2[i] + c3[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = r;
+    if (threadIdx.x == 0 && blockIdx.x == 0) ticks[0] = t1 - t0;
+}
+
+__global__ __launch_bounds__(256) void k_valu(float* out, unsigned long long* ticks, int iters, unsigned seed) {
+    float v[8];
+    for (int i = 0; i < 8; ++i) v[i] = threadIdx.x * 0.001f + i + seed;
+    const float s = 1.0001f;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(v[i]) : "v"(s));
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    float r = 0;
+    for (int i = 0; i < 8; ++i) r += v[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = r;
+    if (threadIdx.x == 0 && blockIdx.x == 0) ticks[0] = t1 - t0;
+}
+
+int main() {
+    hipDeviceProp_t p; (void)hipGetDeviceProperties(&p, 0);
+    float* out; (void)hipMalloc(&out, 1 << 24);
+    unsigned long long* ticks; (void)hipMalloc(&ticks, 8);
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    for (int kind = 0; kind < 2; ++kind)
+        for (int blocks_per_cu = 1; blocks_per_cu <= 2; ++blocks_per_cu) {
+            const int iters = kind == 0 ? 200000 : 400000;
+            const int grid = p.multiProcessorCount * blocks_per_cu;
+            for (int rep = 0; rep < 2; ++rep) {
+                (void)hipEventRecord(e0);
+                if (kind == 0) hipLaunchKernelGGL(k_mfma, dim3(grid), dim3(256), 0, 0, out, ticks, iters, 7u);
+                else hipLaunchKernelGGL(k_valu, dim3(grid), dim3(256), 0, 0, out, ticks, iters, 7u);
+                (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+            }
+            float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+            unsigned long long t; (void)hipMemcpy(&t, ticks, 8, hipMemcpyDeviceToHost);
+            const double n_inst = (double)iters * (kind == 0 ? 4 : 8);
+            printf("%s waves/SIMD=%d: %.3f ms wall, %.2f ticks per instruction, %.1f ticks per microsecond, %.2f ns per instruction per wave\n",
+                   kind == 0 ? "MFMA-only (4 chains, random fp16)" : "VALU-only (8 chains v_fma)    ", blocks_per_cu, ms, t / n_inst, t / (ms * 1e3),
+                   ms * 1e6 / n_inst);
+        }
+    return 0;
+}
