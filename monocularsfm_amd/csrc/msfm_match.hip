@@ -557,6 +557,25 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
                        ctx->d_rp_s1.as<float>(), ctx->d_cp_s0.as<float>(), (const float*)nullptr, tuv, tuv, prune);
     HIPCHK(ctx, hipGetLastError());
     DBGSYNC(ctx, "pf_thresholds_kernel");
+#ifdef MSFM_SWEEP_PROBE
+    if (std::getenv("MSFM_DUMP_T")) {   // diagnostic build: thresholds and column class maxima of pair 0
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        const PairDesc& pd = b.pairs[0];
+        std::vector<float> t((size_t)pd.n1pad + pd.n2pad), cp((size_t)pd.a_blocks256 * pd.n2pad * 4);
+        HIPCHK(ctx, hipMemcpy(t.data(), tuv + b.pf[0].tu_off, (size_t)pd.n1pad * 4, hipMemcpyDeviceToHost));
+        HIPCHK(ctx, hipMemcpy(t.data() + pd.n1pad, tuv + b.pf[0].tv_off, (size_t)pd.n2pad * 4, hipMemcpyDeviceToHost));
+        HIPCHK(ctx, hipMemcpy(cp.data(), ctx->d_cp_s0.as<float>() + pd.cp_off * 4, cp.size() * 4, hipMemcpyDeviceToHost));
+        auto stat = [&](const char* what, const float* v, int n) {
+            int ninf = 0; double sum = 0; int cnt = 0;
+            for (int i = 0; i < n; ++i) { if (std::isinf(v[i])) ++ninf; else { sum += v[i]; ++cnt; } }
+            std::fprintf(stderr, "[dump] %s: n %d, inf %d, mean finite %.4f\n", what, n, ninf, cnt ? sum / cnt : 0.0);
+        };
+        stat("T rows", t.data(), pd.n1);
+        stat("T cols", t.data() + pd.n1pad, pd.n2);
+        for (int e = 0; e < 3 && e < pd.n2; ++e)
+            std::fprintf(stderr, "[dump] col %d classes (S-space): %.4f %.4f %.4f %.4f\n", e, -2 * cp[4 * e], -2 * cp[4 * e + 1], -2 * cp[4 * e + 2], -2 * cp[4 * e + 3]);
+    }
+#endif
 
     // ---- which pairs are worth compacting: needs the live counts on the host -------------------
     std::vector<int> live(2 * P, 0);
@@ -680,6 +699,22 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
     // candidate-list overflow -> brute-force exact path for that pair
     std::vector<unsigned long long> counts(P + V);
     HIPCHK(ctx, hipMemcpyAsync(counts.data(), ctx->d_cand_count.p, (P + V) * 8, hipMemcpyDeviceToHost, ctx->stream));
+#ifdef MSFM_SWEEP_PROBE
+    if (std::getenv("MSFM_DUMP_T")) {   // diagnostic build: the raw candidate records of list 0
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        unsigned long long n0 = 0;
+        HIPCHK(ctx, hipMemcpy(&n0, ctx->d_cand_count.p, 8, hipMemcpyDeviceToHost));
+        const int cap0 = lists[0].cap, take = (int)std::min<unsigned long long>(n0, (unsigned long long)cap0);
+        std::vector<int2> c((size_t)std::max(take, 1));
+        if (take) HIPCHK(ctx, hipMemcpy(c.data(), ctx->d_cand.as<int2>() + lists[0].off, (size_t)take * 8, hipMemcpyDeviceToHost));
+        std::map<std::pair<int, int>, int> seen;
+        int colhist[8] = {0}, rowhist[8] = {0};
+        for (int i = 0; i < take; ++i) { seen[{c[i].x, c[i].y}]++; colhist[(c[i].y >> 3) & 7]++; rowhist[(c[i].x >> 3) & 7]++; }
+        std::fprintf(stderr, "[dump] list 0: count %llu cap %d distinct %zu | cols by 8: %d %d %d %d %d %d %d %d | rows by 8: %d %d %d %d %d %d %d %d\n", n0, cap0,
+                     seen.size(), colhist[0], colhist[1], colhist[2], colhist[3], colhist[4], colhist[5], colhist[6], colhist[7],
+                     rowhist[0], rowhist[1], rowhist[2], rowhist[3], rowhist[4], rowhist[5], rowhist[6], rowhist[7]);
+    }
+#endif
     hc.lap("launch sweep 2 .. finalize");
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     hc.lap("wait for candidate counts (GPU)");

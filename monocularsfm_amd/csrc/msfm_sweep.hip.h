@@ -68,10 +68,19 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// Phase boundary.  sched_barrier(0): NOTHING may be scheduled across it, register-only instructions included.  The
+// "memory" clobbers only order memory operations; without the scheduling barriers hipcc hoisted the address arithmetic of
+// the next phase's DMA (a v_mad_i64_i32 whose carry-out lands in an SGPR pair, followed by an s_add into the same SGPR
+// that feeds M0) above the s_barrier, and with that placement single-active-wave workgroups issued DMA pieces to a wrong
+// LDS slot (observed on gfx950 / ROCm 7.2: thresholds right, sweep 2 flooded with spurious hits; any scheduling barrier
+// at the phase boundaries removes it).  The DMA addressing below also stays in 32-bit offsets from a uniform base so
+// that no VALU instruction with an SGPR carry-out is involved.
 __device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
 }
 
 __device__ __forceinline__ float max3f(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }  // folds to v_max3_f32
@@ -111,17 +120,17 @@ __global__ __launch_bounds__(kPfThreads, 2) void sweep_kernel(
     // DMA group of tile tt (clamped: the tail re-fetches the last tile so every EPI phase issues the same number of
     // VMEM loads): pieces w and w + 8 of the tile's 17 (wave 0: piece 16 as well) + in PASS 2 the wave's private copy of
     // the tile's column thresholds
-    const char* g_lane = gB + wave * 1024 + lane * 16;
+    const unsigned lane_off = (unsigned)(wave * 1024 + lane * 16);   // 32-bit offsets from the uniform image base
     auto dma_tile = [&](int tt) {
         const int tc = tt < t_end ? tt : t_end - 1;
         const int sl = (tt - t_begin) & (kPfRing - 1);
-        const char* g = g_lane + (size_t)tc * kPfTileBytes;
+        const unsigned off = (unsigned)tc * (unsigned)kPfTileBytes + lane_off;   // < 2^31: an image has < 2^18 rows of 272 B
         char* l = sB + sl * kPfTileBytes + wave * 1024;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + 8192),
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gB + off), (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gB + (off + 8192u)),
                                          (__attribute__((address_space(3))) void*)(l + 8192), 16, 0, 0);
         if (wave == 0)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + 16384),
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gB + (off + 16384u)),
                                              (__attribute__((address_space(3))) void*)(l + 16384), 16, 0, 0);
         if (PASS == 2)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(tv + pp.tv_off + tc * kPfBT + lane),
@@ -241,11 +250,28 @@ __global__ __launch_bounds__(kPfThreads, 2) void sweep_kernel(
     // been issued its registers take the fragment of column block 1 (the read lands 16 MFMAs before it is needed).
     // The sched_group_barriers pin that interleave: left alone, hipcc issues all 18 MFMAs, then the reads, then waits.
     auto mfma_block_reload = [&](int sl, h8 (&bf)[8], h4 be, f16v (&acc)[kPfRB]) {
-        const char* pb = sB + sl * kPfTileBytes + 32 * kPfRowBytes + lane_row_off;
 #pragma unroll
         for (int r = 0; r < 16; ++r)
 #pragma unroll
             for (int rb = 0; rb < kPfRB; ++rb) acc[rb][r] = 0.f;
+#ifdef MSFM_SWEEP_ASMREAD
+        // reads hidden from hipcc (it would wait for ALL of them before the first MFMA of column block 1); the counted
+        // waits are in mfma_block_counted below
+        const unsigned pb = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)sB +
+                            (unsigned)(sl * kPfTileBytes + 32 * kPfRowBytes + lane_row_off);
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+#pragma unroll
+            for (int rb = 0; rb < kPfRB; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[rb][ks], bf[ks], acc[rb], 0, 0, 0);
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bf[ks]) : "v"(pb), "n"(ks * 32));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int rb = 0; rb < kPfRB; ++rb)
+            acc[rb] = __builtin_amdgcn_mfma_f32_32x32x8f16(__builtin_shufflevector(af[rb][8], af[rb][8], 0, 1, 2, 3), be, acc[rb], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#else
+        const char* pb = sB + sl * kPfTileBytes + 32 * kPfRowBytes + lane_row_off;
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
 #pragma unroll
@@ -261,7 +287,28 @@ __global__ __launch_bounds__(kPfThreads, 2) void sweep_kernel(
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
         }
         __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+#endif
     };
+#ifdef MSFM_SWEEP_ASMREAD
+    // column block 1 on fragments whose reads (inline asm above) may still be in flight: fragment ks is the (ks+1)-th
+    // oldest of the 8 outstanding LDS reads
+    auto mfma_block_counted = [&](h8 (&bf)[8], h4 be, f16v (&acc)[kPfRB]) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+#pragma unroll
+            for (int rb = 0; rb < kPfRB; ++rb) acc[rb][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(bf[ks]) : "n"(7 - ks));
+#pragma unroll
+            for (int rb = 0; rb < kPfRB; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[rb][ks], bf[ks], acc[rb], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);   // keeps the next wait behind these MFMAs
+        }
+#pragma unroll
+        for (int rb = 0; rb < kPfRB; ++rb)
+            acc[rb] = __builtin_amdgcn_mfma_f32_32x32x8f16(__builtin_shufflevector(af[rb][8], af[rb][8], 0, 1, 2, 3), be, acc[rb], 0, 0, 0);
+    };
+#endif
     // maximum of the accumulator over this lane's 32 rows of one column block: two independent v_max3 chains
     auto column_max = [&](const f16v (&acc)[kPfRB]) -> float {
         float m[kPfRB];
@@ -366,7 +413,11 @@ __global__ __launch_bounds__(kPfThreads, 2) void sweep_kernel(
             __builtin_amdgcn_s_setprio(1);
             if (!kPreRead) load_bf(sl, bf, be);
             mfma_block_reload(sl, bf, be[0], accA);
+#ifdef MSFM_SWEEP_ASMREAD
+            mfma_block_counted(bf, be[1], accB);
+#else
             mfma_block(bf, be[1], accB);
+#endif
             __builtin_amdgcn_s_setprio(0);
         }
         MSFM_PROBE(0)

@@ -58,6 +58,32 @@ def test_prefilter_equals_bruteforce_and_oracle(gpu_ctx, oracle, shape, order):
         gpu_ctx.set_accum_order(0)
 
 
+@pytest.mark.parametrize("shape", [(64, 64), (33, 64), (64, 128), (64, 300), (20, 4000), (4000, 20), (64, 65), (1, 64), (5, 9)])
+def test_images_smaller_than_one_wave(gpu_ctx, oracle, shape):
+    """At most 64 rows on one side: a single wave of the 8-wave sweep workgroup is active, the other seven only move
+    tiles and meet at the barriers, so the phases of the active wave run back to back.  Round 2 found a code-placement
+    problem in exactly this regime (spurious sweep-2 hits -> candidate overflow -> silent fallback to the brute-force
+    kernel): the prefilter path itself must answer, with a handful of candidates per row / column."""
+    n1, n2 = shape
+    imgs = synth.rootsift_images(2, [n1, n2], seed=n1 + 3 * n2, n_proto=max(n1, n2) * 2)
+    out = knn_both_modes(gpu_ctx, imgs[0], imgs[1])
+    pp, _ = assert_same(out)
+    if min(n1, n2) >= 8:     # (fewer rows than a lane half: every element is a legitimate candidate)
+        assert pp["prefilter_pairs"] == 1 and pp["fallback_pairs"] == 0
+        assert pp["candidates"] <= 8 * (n1 + n2)
+    gpu_ctx.upload_image(0, imgs[0])
+    gpu_ctx.upload_image(1, imgs[1])
+    q, t, d = gpu_ctx.match_pair(0, 1, 0.8, True, 0.7)
+    pm = gpu_ctx.profile()
+    if min(n1, n2) >= 8:
+        assert pm["prefilter_pairs"] == 1 and pm["fallback_pairs"] == 0
+    oq, ot, od = oracle.match_pair(imgs[0], imgs[1], 0.8, True, 0.7, nthreads=4)
+    assert np.array_equal(q, oq) and np.array_equal(t, ot) and np.array_equal(b(d), b(od))
+    oi0, od0, _, od1 = oracle.knn2(imgs[0], imgs[1], 0, 8)
+    fwd = out[True][0][0]
+    assert np.array_equal(fwd[0], oi0) and np.array_equal(b(fwd[1]), b(od0)) and np.array_equal(b(fwd[2]), b(od1))
+
+
 def test_near_duplicate_swarm(gpu_ctx, oracle):
     """Many train rows within a few ulps of each other: the candidate margin must keep them all."""
     rng = np.random.default_rng(3)
