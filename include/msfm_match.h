@@ -83,6 +83,7 @@ typedef struct msfm_profile {
     double verify_ms;          /* geometric verification kernels (msfm_match_pairs_verified) */
     int sub_batches;           /* device sub-batches the call was cut into (msfm_set_limits) */
     int tie_queue_regrows;     /* sub-batches re-run because the sqrt-space tie queue had to grow */
+    int plan_regrows;          /* sub-batches re-run because the device-side sweep-2 plan outgrew its predicted buffers */
 } msfm_profile;
 
 /* ---- context ------------------------------------------------------------------------- */

@@ -45,7 +45,7 @@ class Profile(C.Structure):
                 ("exact_descriptor_pairs", C.c_int64), ("tie_rows", C.c_int64),
                 ("sweep2_ms", C.c_double), ("sweep2_launches", C.c_int), ("compacted_pairs", C.c_int),
                 ("sweep2_descriptor_pairs", C.c_int64), ("verify_ms", C.c_double),
-                ("sub_batches", C.c_int), ("tie_queue_regrows", C.c_int)]
+                ("sub_batches", C.c_int), ("tie_queue_regrows", C.c_int), ("plan_regrows", C.c_int)]
 
 
 class MsfmError(RuntimeError):

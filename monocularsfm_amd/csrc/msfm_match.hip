@@ -147,7 +147,19 @@ struct msfm_ctx {
     // prefilter path
     int prefilter = 1;
     DevBuf d_pf, d_tu, d_tv, d_cand, d_cand_s, d_cand_count, d_best, d_second, d_maxima;
-    DevBuf d_live_cnt, d_cmp_h, d_cmp_tu, d_live_idx, d_row_pair, d_cand_pair, d_active, d_vpairs, d_vpf, d_vitems, d_jobs, d_lists;
+    DevBuf d_cmp_h, d_cmp_tu, d_live_idx, d_row_pair, d_row_src, d_cand_pair, d_vpairs, d_vpf, d_vitems, d_lists;
+    // device-side plan of the compacted sweep 2 (msfm_plan.hip.h)
+    DevBuf d_colmask, d_groups, d_gmembers, d_member_pair, d_ppair, d_cnt, d_fill, d_mrow, d_summary, d_overflow, d_totals;
+    long long cmp_rows_hint = 0;      // compacted rows the previous batch needed (sizes the next batch's buffers)
+    struct PfPending {                // what the end-of-batch synchronisation has to look at
+        bool active = false, compact = false;
+        size_t n_lists = 0, P = 0;
+        long long rows_cap = 0, cand_cap = 0, items_cap = 0;
+        int compact_pairs = 0;
+        long long dense_swept = 0;
+        size_t ev_base = 0;
+    } pf_pending;
+    PinnedBuf h_summary;              // PlanSummary | totals[2] | overflow bytes
     // geometric verification
     DevBuf d_vf_pairs, d_vf_x1, d_vf_y1, d_vf_x2, d_vf_y2, d_vf_hyp, d_vf_best_it, d_vf_best_count, d_vf_flags,
         d_st2_qt, d_st2_d, d_counts2;
@@ -205,6 +217,7 @@ struct HostClock {
 struct Batch {
     std::vector<PairDesc> pairs;
     std::vector<PfPair> pf;
+    std::vector<int> id1, id2;       // store slots of the pairs' images
     std::vector<WorkItem> items;
     long long rp_elems = 0, cp_elems = 0, kf_elems = 0, kr_elems = 0, out_elems = 0, cand_elems = 0;
     int max_npad = 0;
@@ -358,164 +371,144 @@ std::vector<WorkItem> interleave_items(const std::vector<WorkItem>& lin) {
     return out;
 }
 
-// ---- host-side plan of sweep 2 ----------------------------------------------------------------
-struct VMember { int pair, dir, cnt; long long row; };                                   // one (pair, direction): a slice of a group's rows
-struct VGroup { const _Float16* b_h; int dir; int first, count; long long row0, rows; };  // the pairs streaming one image in one direction
-struct Sweep2Plan {
-    std::vector<VMember> members;
-    std::vector<VGroup> groups;
-    std::vector<PairDesc> vpairs;   // per group: the compacted "pair" (A = concatenated live rows, B = the streamed image)
-    std::vector<PfPair> vpf;
-    std::vector<GatherJob> jobs;    // per member
-    std::vector<CandList> lists;    // [0, P): dense lists of the pairs; [P, P+V): one per group
-    std::vector<WorkItem> ditems, vitems;
-    long long cand_elems = 0;
+// ---- static tables of the device-side plan of sweep 2 (msfm_plan.hip.h) -----------------------------------------
+struct CompactPlan {
+    std::vector<PlanGroup> groups;
+    std::vector<int> gmembers;      // member ids ordered by group
+    std::vector<int> member_pair;   // member -> pair of the batch
+    std::vector<PlanPair> ppair;    // per pair
+    long long rows_ub = 0;          // compacted rows if every row were alive (each live column counted once)
+    int pairs = 0;
 };
 
-// Which candidate lists exist, where the compacted rows go, which work items sweep them.  `compact[p]`: pair p
-// is swept through its compacted live rows (live[2p], live[2p+1] of them); the others get the dense sweep.
-int plan_sweep2(msfm_ctx* ctx, Batch& b, const std::vector<char>& compact, const std::vector<int>& live, Sweep2Plan& plan) {
+// Which groups exist and which (pair, direction[, block bit]) members they consist of: a function of the pair list
+// alone.  O(pairs + members): counting sort over dense image indices, no maps (this runs on the host while the GPU
+// is busy with sweep 1).
+void build_compact_plan(msfm_ctx* ctx, const Batch& b, CompactPlan& cp) {
     const size_t P = b.pairs.size();
-    // Compacted sweeps are GROUPED: the live rows of every pair that streams the same image in the same
-    // direction are concatenated into one dense matrix (blocks are then full except for one tail per group;
-    // a pair's own ~300 live rows would fill its last 256-row block to a fifth).
-    std::vector<VMember>& members = plan.members;
-    std::vector<VGroup>& groups = plan.groups;
-    long long cmp_rows = 0;
-    long long& cand_elems = plan.cand_elems;
-    cand_elems = 0;
-    {
-        std::map<std::pair<const void*, int>, std::vector<VMember>> by_key;
-        std::vector<std::pair<const void*, int>> key_order;
-        for (size_t p = 0; p < P; ++p) {
-            PairDesc& pd = b.pairs[p];
-            PfPair& pp = b.pf[p];
-            if (!pd.valid || !pp.use) continue;
-            if (!compact[p]) {
-                pp.cand_off = cand_elems;
-                pp.cand_cap = 8 * (pd.n1 + pd.n2) + 1024;
-                cand_elems += pp.cand_cap;
-                continue;
-            }
-            for (int dir = 0; dir < 2; ++dir) {
-                const int cnt = live[2 * p + dir];
-                if (cnt == 0) continue;
-                const std::pair<const void*, int> key(dir ? (const void*)pp.a_h : (const void*)pp.b_h, dir);
-                auto it = by_key.find(key);
-                if (it == by_key.end()) {
-                    key_order.push_back(key);
-                    it = by_key.emplace(key, std::vector<VMember>()).first;
-                }
-                it->second.push_back(VMember{(int)p, dir, cnt, 0});
-            }
+    cp.ppair.assign(P, PlanPair{-1, 0, 0, 0});
+    static thread_local std::vector<int> dense;   // store slot -> dense image index of this batch (-1: absent)
+    dense.assign((size_t)kSlots, -1);
+    std::vector<int> img_slot;                     // dense index -> store slot
+    auto dense_of = [&](int slot) {
+        if (dense[(size_t)slot] < 0) {
+            dense[(size_t)slot] = (int)img_slot.size();
+            img_slot.push_back(slot);
         }
-        for (const auto& key : key_order) {
-            std::vector<VMember>& ms = by_key[key];
-            VGroup g{(const _Float16*)key.first, key.second, (int)members.size(), (int)ms.size(), cmp_rows, 0};
-            for (VMember& m : ms) {
-                m.row = cmp_rows + g.rows;
-                g.rows += m.cnt;
-                members.push_back(m);
-            }
-            cmp_rows += (g.rows + kPfWgRows - 1) / kPfWgRows * kPfWgRows;
-            groups.push_back(g);
-        }
-    }
-    const size_t V = groups.size();
-    HIPCHK(ctx, ctx->d_cmp_h.ensure(std::max<long long>(1, cmp_rows) * kPfRowBytes));
-    HIPCHK(ctx, ctx->d_cmp_tu.ensure(std::max<long long>(1, cmp_rows) * 4));
-    HIPCHK(ctx, ctx->d_live_idx.ensure(std::max<long long>(1, cmp_rows) * 4));
-    HIPCHK(ctx, ctx->d_row_pair.ensure(std::max<long long>(1, cmp_rows) * 4));
-    std::vector<PairDesc>& vpairs = plan.vpairs;
-    std::vector<PfPair>& vpf = plan.vpf;
-    std::vector<GatherJob>& jobs = plan.jobs;
-    std::vector<CandList>& lists = plan.lists;
-    vpairs.assign(V, PairDesc{});
-    vpf.assign(V, PfPair{});
-    jobs.assign(members.size(), GatherJob{});
-    lists.assign(P + V, CandList{});
-    long long v_ablocks = 0;
-    for (size_t v = 0; v < V; ++v) v_ablocks += (groups[v].rows + kPfWgRows - 1) / kPfWgRows;
+        return dense[(size_t)slot];
+    };
+    // group keys: forward = streamed image id2; reverse = (streamed image id1, bit)
+    std::vector<int> fwd_group_of_img, rev_group0_of_img;   // dense image -> group id (-1: none yet)
+    struct Key { int group; };
+    std::vector<int> member_group;
     for (size_t p = 0; p < P; ++p) {
+        const PairDesc& pd = b.pairs[p];
         const PfPair& pp = b.pf[p];
-        lists[p] = CandList{(int)p, 0, pp.cand_off, (b.pairs[p].valid && pp.use && !compact[p]) ? pp.cand_cap : 0, 0, nullptr, nullptr};
-    }
-    std::vector<WorkItem> vlin;
-    for (size_t v = 0; v < V; ++v) {
-        const VGroup& g = groups[v];
-        const VMember& m0 = members[(size_t)g.first];
-        const PairDesc& pd = b.pairs[m0.pair];   // every member streams the same image: take its description from the first
-        const PfPair& pp = b.pf[m0.pair];
-        PairDesc& vd = vpairs[v];
-        PfPair& vp = vpf[v];
-        vd = PairDesc{};
-        vd.n1 = (int)g.rows;
-        vd.n2 = g.dir ? pd.n1 : pd.n2;
-        vd.a_blocks256 = (int)((g.rows + kPfWgRows - 1) / kPfWgRows);
-        vd.b_tiles = g.dir ? pd.a_blocks : pd.b_tiles;
-        vd.n1pad = vd.a_blocks256 * kPfWgRows;
-        vd.n2pad = g.dir ? pd.n1pad : pd.n2pad;
-        vd.valid = 1;
-        vd.path = 1;
-        vd.ranges = 1;
-        if (v_ablocks < 8LL * ctx->cu_count)
-            vd.ranges = (int)std::max<long long>(1, std::min<long long>((8LL * ctx->cu_count + v_ablocks - 1) / v_ablocks, vd.b_tiles));
-        vp = PfPair{};
-        vp.a_h = ctx->d_cmp_h.as<_Float16>() + (size_t)g.row0 * kPfRowHalfs;
-        vp.b_h = g.dir ? pp.a_h : pp.b_h;
-        vp.b_nrm = g.dir ? pp.a_nrm : pp.b_nrm;
-        vp.b_c = g.dir ? pp.a_c : pp.b_c;
-        vp.a_c = g.dir ? pp.b_c : pp.a_c;
-        vp.tu_off = g.row0;
-        vp.cand_off = cand_elems;
-        vp.cand_cap = (int)std::min<long long>(8 * g.rows + 1024, 1LL << 30);
-        vp.use = 1;
-        cand_elems += vp.cand_cap;
-        for (int k = 0; k < g.count; ++k) {
-            const VMember& m = members[(size_t)(g.first + k)];
-            const PairDesc& mpd = b.pairs[m.pair];
-            const PfPair& mpp = b.pf[m.pair];
-            const bool last = k + 1 == g.count;
-            jobs[(size_t)(g.first + k)] = GatherJob{m.dir ? mpp.b_h : mpp.a_h, m.dir ? mpp.b_nrm : mpp.a_nrm,
-                                                    m.dir ? mpp.tv_off : mpp.tu_off, m.row,
-                                                    last ? g.row0 + (long long)vd.n1pad : m.row + m.cnt,
-                                                    m.dir ? mpd.n2 : mpd.n1, m.pair};
+        if (!pd.valid || !pp.use) continue;
+        ++cp.pairs;
+        const int di = dense_of(b.id1[p]), dj = dense_of(b.id2[p]);
+        const size_t need = img_slot.size();
+        if (fwd_group_of_img.size() < need) {
+            fwd_group_of_img.resize(need, -1);
+            rev_group0_of_img.resize(need, -1);
         }
-        lists[P + v] = CandList{-1, 1 + g.dir, vp.cand_off, vp.cand_cap, 0, ctx->d_live_idx.as<int>() + g.row0,
-                                ctx->d_row_pair.as<int>() + g.row0};
-        for (int r = 0; r < vd.ranges; ++r) {
-            const int t0 = (int)((long long)vd.b_tiles * r / vd.ranges), t1 = (int)((long long)vd.b_tiles * (r + 1) / vd.ranges);
-            for (int ab = 0; ab < vd.a_blocks256; ++ab) vlin.push_back(WorkItem{(int)v, ab, t0, t1, r, {0, 0, 0}});
+        // forward: live rows of image 1 against all of image 2
+        if (fwd_group_of_img[(size_t)dj] < 0) {
+            fwd_group_of_img[(size_t)dj] = (int)cp.groups.size();
+            PlanGroup g = {};
+            g.b_h = pp.b_h;
+            g.b_nrm = pp.b_nrm;
+            g.b_c = pp.b_c;
+            g.a_c = pp.a_c;     // (per image: every image that meets image j in this batch has a compatible scale, see fill_pair)
+            g.dir = 0;
+            g.bt_begin = 0;
+            g.bt_end = pd.b_tiles;
+            g.n2 = pd.n2;
+            g.n2pad = pd.n2pad;
+            g.b_tiles = pd.b_tiles;
+            g.ranges = 1;
+            cp.groups.push_back(g);
         }
-        ctx->prof.sweep2_descriptor_pairs += (int64_t)vd.n1pad * vd.n2;
+        cp.ppair[p].fwd_member = (int)cp.member_pair.size();
+        cp.member_pair.push_back((int)p);
+        member_group.push_back(fwd_group_of_img[(size_t)dj]);
+        cp.rows_ub += pd.n1;
+        // reverse: live columns against the 512-row blocks of image 1 their mask names
+        const int nb = pd.a_blocks256, gshift = (nb + 31) / 32, bits = (nb + gshift - 1) / gshift;
+        if (rev_group0_of_img[(size_t)di] < 0) {
+            rev_group0_of_img[(size_t)di] = (int)cp.groups.size();
+            for (int bit = 0; bit < bits; ++bit) {
+                PlanGroup g = {};
+                g.b_h = pp.a_h;
+                g.b_nrm = pp.a_nrm;
+                g.b_c = pp.a_c;
+                g.a_c = pp.b_c;
+                g.dir = 1;
+                g.bt_begin = std::min(pd.a_blocks, bit * gshift * (kPfWgRows / kBM));
+                g.bt_end = std::min(pd.a_blocks, (bit + 1) * gshift * (kPfWgRows / kBM));
+                g.n2 = pd.n1;
+                g.n2pad = pd.n1pad;
+                g.b_tiles = pd.a_blocks;
+                g.ranges = 1;
+                cp.groups.push_back(g);
+            }
+        }
+        cp.ppair[p].rev_member0 = (int)cp.member_pair.size();
+        cp.ppair[p].rev_bits = bits;
+        for (int bit = 0; bit < bits; ++bit) {
+            cp.member_pair.push_back((int)p);
+            member_group.push_back(rev_group0_of_img[(size_t)di] + bit);
+        }
+        cp.rows_ub += pd.n2;
     }
-    // dense items: the sweep-1 list minus the compacted pairs
-    std::vector<WorkItem> dlin;
-    for (const WorkItem& w : b.items)
-        if (w.pair >= 0 && !compact[w.pair]) dlin.push_back(w);
-    for (size_t p = 0; p < P; ++p)
-        if (b.pairs[p].valid && b.pf[p].use && !compact[p]) ctx->prof.sweep2_descriptor_pairs += (int64_t)b.pairs[p].n1pad * b.pairs[p].n2;
-    plan.ditems = dlin.empty() ? dlin : interleave_items(dlin);
-    plan.vitems = vlin.empty() ? vlin : interleave_items(vlin);
-    return MSFM_OK;
+    // counting sort of the members by group
+    const size_t G = cp.groups.size(), M = cp.member_pair.size();
+    for (size_t m = 0; m < M; ++m) cp.groups[(size_t)member_group[m]].count += 1;
+    int at = 0;
+    for (size_t g = 0; g < G; ++g) {
+        cp.groups[g].first = at;
+        at += cp.groups[g].count;
+        cp.groups[g].count = 0;
+    }
+    cp.gmembers.assign(M, 0);
+    for (size_t m = 0; m < M; ++m) {
+        PlanGroup& g = cp.groups[(size_t)member_group[m]];
+        cp.gmembers[(size_t)(g.first + g.count++)] = (int)m;
+    }
+    // a small batch would leave most CUs idle with one work item per 512 compacted rows: split the streamed ranges
+    const long long target = 4LL * ctx->cu_count;
+    if ((long long)G < target)
+        for (PlanGroup& g : cp.groups) {
+            const long long r = (target + (long long)G - 1) / (long long)G;
+            g.ranges = (int)std::max<long long>(1, std::min<long long>(r, g.bt_end - g.bt_begin));
+        }
 }
 
-
-// MFMA prefilter + exact re-check for the pairs on path 1.  On return pairs whose candidate list
-// overflowed have been moved to path 0.
+// MFMA prefilter + exact re-check for the pairs on path 1, WITHOUT a host synchronisation: the caller looks at
+// ctx->pf_pending at the end of the batch (finish_prefilter) and re-runs the batch if a capacity was exceeded or a
+// candidate list overflowed.
 //   sweep 1 (sweep_kernel<1>): S~ minima per row / column -> thresholds (with pruning for match lists)
-//   sweep 2: dense pairs re-sweep everything (sweep_kernel<2>); pairs where pruning left few live rows
-//            and columns sweep only those, compacted per direction (sweep_kernel<3>)
+//   sweep 2: match lists: only the rows / columns pruning left alive, compacted and grouped per streamed image
+//            (sweep_kernel<3>, plan built on the device); kNN-level API: everything again (sweep_kernel<2>)
 //   exact pinned-order S of the candidates, 64-bit atomicMin reduce, finalize
 int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
     const size_t P = b.pairs.size();
     HostClock hc;
-    assign_partials(b, 1, 8 * ctx->cu_count);
+    ctx->pf_pending = msfm_ctx::PfPending{};
+    assign_partials(b, 1, 4 * ctx->cu_count);
+    const bool compact = prune.prune != 0;
+    long long dense_cand = 0;
     for (size_t p = 0; p < P; ++p) {
         b.pf[p].tu_off = b.pairs[p].kf_off;
         b.pf[p].tv_off = b.pairs[p].kr_off;  // same combined index space as the kNN arrays
         b.pf[p].cand_off = 0;
         b.pf[p].cand_cap = 0;
+        if (!compact && b.pairs[p].valid && b.pf[p].use) {
+            b.pf[p].cand_off = dense_cand;
+            b.pf[p].cand_cap = 16 * (b.pairs[p].n1 + b.pairs[p].n2) + 2048;
+            dense_cand += b.pf[p].cand_cap;
+            ctx->pf_pending.dense_swept += (long long)b.pairs[p].n1pad * b.pairs[p].n2;
+        }
     }
     build_items(b, 1);
     if (b.items.empty()) return MSFM_OK;
@@ -525,9 +518,9 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
     // column partials of sweep 1: one float4 (four row-class maxima) per 512-row A block and column
     HIPCHK(ctx, ctx->d_cp_s0.ensure(std::max<long long>(1, b.cp_elems) * 16));
     HIPCHK(ctx, ctx->d_tu.ensure(kn * 4));
+    HIPCHK(ctx, ctx->d_colmask.ensure(kn * 4));
     HIPCHK(ctx, ctx->d_best.ensure(kn * 8));
     HIPCHK(ctx, ctx->d_second.ensure(kn * 8));
-    HIPCHK(ctx, ctx->d_live_cnt.ensure(2 * P * 4));
     int rc = upload_pairs(ctx, b);
     if (rc != MSFM_OK) return rc;
     rc = upload_items(ctx, b);
@@ -539,152 +532,170 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
     hipEvent_t e2 = get_event(ctx, ev_base + 2), e3 = get_event(ctx, ev_base + 3);
     if (!e0 || !e1 || !e2 || !e3) return fail(ctx, MSFM_E_DEVICE, "hipEventCreate failed");
     const dim3 block(kPfThreads);
+    const unsigned sweep_grid = (unsigned)std::max(8, (ctx->cu_count / 8) * 8);   // one persistent workgroup per CU, a multiple of the 8 XCDs
     const PairDesc* dp = ctx->d_pairs.as<PairDesc>();
     const PfPair* dpf = ctx->d_pf.as<PfPair>();
     float* tuv = ctx->d_tu.as<float>();  // rows at kf offsets, columns at kr offsets (one buffer)
+    unsigned* colmask = ctx->d_colmask.as<unsigned>();
     hc.lap("sweep-1 setup + uploads");
     HIPCHK(ctx, hipEventRecord(e0, ctx->stream));
-    hipLaunchKernelGGL(sweep_kernel<1>, dim3((unsigned)b.items.size()), block, kPfLdsBytes, ctx->stream, dp, dpf,
+    hipLaunchKernelGGL(sweep_kernel<1>, dim3(std::min<unsigned>(sweep_grid, (unsigned)b.items.size())), block, kPfLdsBytes, ctx->stream, dp, dpf,
                        ctx->d_items.as<WorkItem>(), ctx->d_rp_s0.as<float>(), ctx->d_rp_s1.as<float>(),
                        ctx->d_cp_s0.as<float>(), (float*)nullptr, (const float*)nullptr, (const float*)nullptr,
-                       (int2*)nullptr, (unsigned long long*)nullptr);
+                       (int2*)nullptr, (unsigned long long*)nullptr, (const int*)nullptr, (int)b.items.size());
     HIPCHK(ctx, hipGetLastError());
     DBGSYNC(ctx, "sweep_kernel<1>");
     HIPCHK(ctx, hipEventRecord(e1, ctx->stream));
     ctx->prof.approx_kernel_launches += 1;
     const dim3 mgrid((unsigned)((b.max_npad + 255) / 256), (unsigned)P);
     hipLaunchKernelGGL(pf_thresholds_kernel, mgrid, dim3(256), 0, ctx->stream, dp, dpf, ctx->d_rp_s0.as<float>(),
-                       ctx->d_rp_s1.as<float>(), ctx->d_cp_s0.as<float>(), (const float*)nullptr, tuv, tuv, prune);
+                       ctx->d_rp_s1.as<float>(), ctx->d_cp_s0.as<float>(), compact ? colmask : (unsigned*)nullptr, tuv, tuv, prune);
     HIPCHK(ctx, hipGetLastError());
     DBGSYNC(ctx, "pf_thresholds_kernel");
-#ifdef MSFM_SWEEP_PROBE
-    if (std::getenv("MSFM_DUMP_T")) {   // diagnostic build: thresholds and column class maxima of pair 0
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-        const PairDesc& pd = b.pairs[0];
-        std::vector<float> t((size_t)pd.n1pad + pd.n2pad), cp((size_t)pd.a_blocks256 * pd.n2pad * 4);
-        HIPCHK(ctx, hipMemcpy(t.data(), tuv + b.pf[0].tu_off, (size_t)pd.n1pad * 4, hipMemcpyDeviceToHost));
-        HIPCHK(ctx, hipMemcpy(t.data() + pd.n1pad, tuv + b.pf[0].tv_off, (size_t)pd.n2pad * 4, hipMemcpyDeviceToHost));
-        HIPCHK(ctx, hipMemcpy(cp.data(), ctx->d_cp_s0.as<float>() + pd.cp_off * 4, cp.size() * 4, hipMemcpyDeviceToHost));
-        auto stat = [&](const char* what, const float* v, int n) {
-            int ninf = 0; double sum = 0; int cnt = 0;
-            for (int i = 0; i < n; ++i) { if (std::isinf(v[i])) ++ninf; else { sum += v[i]; ++cnt; } }
-            std::fprintf(stderr, "[dump] %s: n %d, inf %d, mean finite %.4f\n", what, n, ninf, cnt ? sum / cnt : 0.0);
-        };
-        stat("T rows", t.data(), pd.n1);
-        stat("T cols", t.data() + pd.n1pad, pd.n2);
-        for (int e = 0; e < 3 && e < pd.n2; ++e)
-            std::fprintf(stderr, "[dump] col %d classes (S-space): %.4f %.4f %.4f %.4f\n", e, -2 * cp[4 * e], -2 * cp[4 * e + 1], -2 * cp[4 * e + 2], -2 * cp[4 * e + 3]);
-    }
-#endif
+    hc.lap("launch sweep 1 + thresholds");
 
-    // ---- which pairs are worth compacting: needs the live counts on the host -------------------
-    std::vector<int> live(2 * P, 0);
-    std::vector<char> compact(P, 0);
-    if (prune.prune) {
-        hipLaunchKernelGGL(pf_count_live_kernel, dim3((unsigned)(2 * P)), dim3(256), 0, ctx->stream, dp, dpf,
-                           (const float*)tuv, ctx->d_live_cnt.as<int>());
-        HIPCHK(ctx, hipGetLastError());
-    DBGSYNC(ctx, "pf_count_live_kernel");
-        HIPCHK(ctx, hipMemcpyAsync(live.data(), ctx->d_live_cnt.p, 2 * P * 4, hipMemcpyDeviceToHost, ctx->stream));
-        hc.lap("launch sweep 1 .. count");
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-        hc.lap("wait for live counts (GPU)");
-        for (size_t p = 0; p < P; ++p) {
-            const PairDesc& pd = b.pairs[p];
-            if (!pd.valid || !b.pf[p].use) continue;
-            // both compact sweeps together must be clearly cheaper than the one dense sweep
-            const long long dense_cost = (long long)pd.a_blocks256 * pd.b_tiles;
-            const long long cmp_cost = (long long)((live[2 * p] + kPfWgRows - 1) / kPfWgRows) * pd.b_tiles +
-                                       (long long)((live[2 * p + 1] + kPfWgRows - 1) / kPfWgRows) * pd.a_blocks;
-            compact[p] = (2 * cmp_cost <= dense_cost) ? 1 : 0;
+    size_t n_lists = 0;
+    const CandList* dl = nullptr;
+    if (compact) {
+        // ---- static plan tables (the GPU is busy with sweep 1 meanwhile), buffers from the prediction ----------
+        CompactPlan cp;
+        build_compact_plan(ctx, b, cp);
+        const size_t G = cp.groups.size(), M = cp.member_pair.size();
+        n_lists = G;
+        long long max_ranges = 1;
+        for (const PlanGroup& g : cp.groups) max_ranges = std::max<long long>(max_ranges, g.ranges);
+        const long long slack = (long long)kPfWgRows * (long long)G + kPfWgRows;
+        const long long rows_cap = std::max<long long>(ctx->cmp_rows_hint + ctx->cmp_rows_hint / 2, cp.rows_ub / 4) + slack;
+        const long long cand_cap = 8 * rows_cap + 1024LL * (long long)G;
+        const long long items_cap = ((rows_cap / kPfWgRows + (long long)G) * max_ranges + 15) / 8 * 8;
+        HIPCHK(ctx, ctx->d_groups.ensure(std::max<size_t>(1, G) * sizeof(PlanGroup)));
+        HIPCHK(ctx, ctx->d_gmembers.ensure(std::max<size_t>(1, M) * 4));
+        HIPCHK(ctx, ctx->d_member_pair.ensure(std::max<size_t>(1, M) * 4));
+        HIPCHK(ctx, ctx->d_ppair.ensure(P * sizeof(PlanPair)));
+        HIPCHK(ctx, ctx->d_cnt.ensure(std::max<size_t>(1, M) * 4));
+        HIPCHK(ctx, ctx->d_fill.ensure(std::max<size_t>(1, M) * 4));
+        HIPCHK(ctx, ctx->d_mrow.ensure(std::max<size_t>(1, M) * 8));
+        HIPCHK(ctx, ctx->d_summary.ensure(sizeof(PlanSummary)));
+        HIPCHK(ctx, ctx->d_vpairs.ensure(std::max<size_t>(1, G) * sizeof(PairDesc)));
+        HIPCHK(ctx, ctx->d_vpf.ensure(std::max<size_t>(1, G) * sizeof(PfPair)));
+        HIPCHK(ctx, ctx->d_lists.ensure(std::max<size_t>(1, G) * sizeof(CandList)));
+        HIPCHK(ctx, ctx->d_vitems.ensure((size_t)items_cap * sizeof(WorkItem)));
+        HIPCHK(ctx, ctx->d_cmp_h.ensure((size_t)rows_cap * kPfRowBytes));
+        HIPCHK(ctx, ctx->d_cmp_tu.ensure((size_t)rows_cap * 4));
+        HIPCHK(ctx, ctx->d_live_idx.ensure((size_t)rows_cap * 4));
+        HIPCHK(ctx, ctx->d_row_pair.ensure((size_t)rows_cap * 4));
+        HIPCHK(ctx, ctx->d_row_src.ensure((size_t)rows_cap * 8));
+        HIPCHK(ctx, ctx->d_cand.ensure((size_t)cand_cap * sizeof(int2)));
+        HIPCHK(ctx, ctx->d_cand_s.ensure((size_t)cand_cap * 4));
+        HIPCHK(ctx, ctx->d_cand_pair.ensure((size_t)cand_cap * 4));
+        HIPCHK(ctx, ctx->d_cand_count.ensure(std::max<size_t>(1, G) * 8));
+        if (G > 0) {
+            HIPCHK(ctx, hipMemcpyAsync(ctx->d_groups.p, cp.groups.data(), G * sizeof(PlanGroup), hipMemcpyHostToDevice, ctx->stream));
+            HIPCHK(ctx, hipMemcpyAsync(ctx->d_gmembers.p, cp.gmembers.data(), M * 4, hipMemcpyHostToDevice, ctx->stream));
+            HIPCHK(ctx, hipMemcpyAsync(ctx->d_member_pair.p, cp.member_pair.data(), M * 4, hipMemcpyHostToDevice, ctx->stream));
         }
-    }
-
-    // ---- sweep-2 descriptors -------------------------------------------------------------------
-    Sweep2Plan plan;
-    rc = plan_sweep2(ctx, b, compact, live, plan);
-    if (rc != MSFM_OK) return rc;
-    const size_t V = plan.groups.size();
-    const std::vector<VMember>& members = plan.members;
-    const std::vector<VGroup>& groups = plan.groups;
-    const std::vector<PairDesc>& vpairs = plan.vpairs;
-    const std::vector<PfPair>& vpf = plan.vpf;
-    const std::vector<GatherJob>& jobs = plan.jobs;
-    const std::vector<CandList>& lists = plan.lists;
-    const std::vector<WorkItem>&ditems = plan.ditems, &vitems = plan.vitems;
-    const long long cand_elems = plan.cand_elems;
-    HIPCHK(ctx, ctx->d_cand.ensure(std::max<long long>(1, cand_elems) * sizeof(int2)));
-    HIPCHK(ctx, ctx->d_cand_s.ensure(std::max<long long>(1, cand_elems) * 4));
-    HIPCHK(ctx, ctx->d_cand_pair.ensure(std::max<long long>(1, cand_elems) * 4));
-    HIPCHK(ctx, ctx->d_cand_count.ensure((P + V) * 8));
-    HIPCHK(ctx, ctx->d_lists.ensure((P + V) * sizeof(CandList)));
-    HIPCHK(ctx, hipMemsetAsync(ctx->d_cand_count.p, 0, (P + V) * 8, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(ctx->d_lists.p, lists.data(), (P + V) * sizeof(CandList), hipMemcpyHostToDevice, ctx->stream));
-    std::vector<int> active;  // the exact / reduce kernels only visit lists that can hold candidates
-    for (size_t l = 0; l < P + V; ++l)
-        if (lists[l].cap > 0) active.push_back((int)l);
-    HIPCHK(ctx, ctx->d_active.ensure(std::max<size_t>(1, active.size()) * 4));
-    if (!active.empty())
-        HIPCHK(ctx, hipMemcpyAsync(ctx->d_active.p, active.data(), active.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(ctx->d_pf.p, b.pf.data(), P * sizeof(PfPair), hipMemcpyHostToDevice, ctx->stream));  // cand_off / cap
-    if (!ditems.empty()) {
-        HIPCHK(ctx, hipMemcpyAsync(ctx->d_items.p, ditems.data(), ditems.size() * sizeof(WorkItem), hipMemcpyHostToDevice, ctx->stream));
-    }
-    if (V > 0) {
-        HIPCHK(ctx, ctx->d_vpairs.ensure(V * sizeof(PairDesc)));
-        HIPCHK(ctx, ctx->d_vpf.ensure(V * sizeof(PfPair)));
-        HIPCHK(ctx, ctx->d_jobs.ensure(jobs.size() * sizeof(GatherJob)));
-        HIPCHK(ctx, ctx->d_vitems.ensure(vitems.size() * sizeof(WorkItem)));
-        HIPCHK(ctx, hipMemcpyAsync(ctx->d_vpairs.p, vpairs.data(), V * sizeof(PairDesc), hipMemcpyHostToDevice, ctx->stream));
-        HIPCHK(ctx, hipMemcpyAsync(ctx->d_vpf.p, vpf.data(), V * sizeof(PfPair), hipMemcpyHostToDevice, ctx->stream));
-        HIPCHK(ctx, hipMemcpyAsync(ctx->d_jobs.p, jobs.data(), jobs.size() * sizeof(GatherJob), hipMemcpyHostToDevice, ctx->stream));
-        HIPCHK(ctx, hipMemcpyAsync(ctx->d_vitems.p, vitems.data(), vitems.size() * sizeof(WorkItem), hipMemcpyHostToDevice, ctx->stream));
-        hipLaunchKernelGGL(pf_gather_live_kernel, dim3((unsigned)jobs.size()), dim3(256), 0, ctx->stream, ctx->d_jobs.as<GatherJob>(),
-                           (const float*)tuv, ctx->d_live_idx.as<int>(), ctx->d_row_pair.as<int>(), ctx->d_cmp_tu.as<float>(),
+        HIPCHK(ctx, hipMemcpyAsync(ctx->d_ppair.p, cp.ppair.data(), P * sizeof(PlanPair), hipMemcpyHostToDevice, ctx->stream));
+        // (the uploads above come from pageable vectors that die with this function: hipMemcpyAsync has staged them when it returns)
+        HIPCHK(ctx, hipMemsetAsync(ctx->d_cnt.p, 0, std::max<size_t>(1, M) * 4, ctx->stream));
+        HIPCHK(ctx, hipMemsetAsync(ctx->d_fill.p, 0, std::max<size_t>(1, M) * 4, ctx->stream));
+        HIPCHK(ctx, hipMemsetAsync(ctx->d_summary.p, 0, sizeof(PlanSummary), ctx->stream));
+        HIPCHK(ctx, hipMemsetAsync(ctx->d_vitems.p, 0xff, (size_t)items_cap * sizeof(WorkItem), ctx->stream));
+        HIPCHK(ctx, hipMemsetAsync(ctx->d_row_src.p, 0, (size_t)rows_cap * 8, ctx->stream));
+        HIPCHK(ctx, hipMemsetAsync(ctx->d_cand_count.p, 0, std::max<size_t>(1, G) * 8, ctx->stream));
+        hc.lap("plan tables + uploads");
+        const PlanPair* dpp = ctx->d_ppair.as<PlanPair>();
+        hipLaunchKernelGGL(pf_count_kernel, dim3((unsigned)(2 * P)), dim3(256), 0, ctx->stream, dp, dpf, dpp, (const float*)tuv,
+                           (const unsigned*)colmask, ctx->d_cnt.as<int>());
+        HIPCHK(ctx, hipGetLastError());
+        DBGSYNC(ctx, "pf_count_kernel");
+        PlanOut po = {};
+        po.vpairs = ctx->d_vpairs.as<PairDesc>();
+        po.vpf = ctx->d_vpf.as<PfPair>();
+        po.lists = ctx->d_lists.as<CandList>();
+        po.items = ctx->d_vitems.as<WorkItem>();
+        po.mrow = ctx->d_mrow.as<long long>();
+        po.summary = ctx->d_summary.as<PlanSummary>();
+        po.cmp_h = ctx->d_cmp_h.as<_Float16>();
+        po.live_idx = ctx->d_live_idx.as<int>();
+        po.row_pair = ctx->d_row_pair.as<int>();
+        po.rows_cap = rows_cap;
+        po.cand_cap = cand_cap;
+        po.items_cap = items_cap;
+        hipLaunchKernelGGL(pf_plan_kernel, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_groups.as<PlanGroup>(), (int)G,
+                           (const int*)ctx->d_gmembers.as<int>(), (const int*)ctx->d_cnt.as<int>(), po);
+        HIPCHK(ctx, hipGetLastError());
+        DBGSYNC(ctx, "pf_plan_kernel");
+        hipLaunchKernelGGL(pf_assign_kernel, dim3((unsigned)(2 * P)), dim3(256), 0, ctx->stream, dp, dpf, dpp, (const float*)tuv,
+                           (const unsigned*)colmask, (const long long*)ctx->d_mrow.as<long long>(), ctx->d_fill.as<int>(),
+                           ctx->d_live_idx.as<int>(), ctx->d_row_pair.as<int>(), ctx->d_cmp_tu.as<float>(),
+                           ctx->d_row_src.as<const _Float16*>());
+        HIPCHK(ctx, hipGetLastError());
+        DBGSYNC(ctx, "pf_assign_kernel");
+        hipLaunchKernelGGL(pf_copy_rows_kernel, dim3((unsigned)(8 * ctx->cu_count)), dim3(256), 0, ctx->stream,
+                           (const PlanSummary*)ctx->d_summary.as<PlanSummary>(), (const _Float16* const*)ctx->d_row_src.as<const _Float16*>(),
                            ctx->d_cmp_h.as<_Float16>());
         HIPCHK(ctx, hipGetLastError());
-    DBGSYNC(ctx, "pf_gather_live_kernel");
-    }
-    hc.lap("sweep-2 descriptors + uploads");
-    HIPCHK(ctx, hipEventRecord(e2, ctx->stream));
-    if (!ditems.empty()) {
-        hipLaunchKernelGGL(sweep_kernel<2>, dim3((unsigned)ditems.size()), block, kPfLdsBytes, ctx->stream, dp, dpf,
+        DBGSYNC(ctx, "pf_copy_rows_kernel");
+        HIPCHK(ctx, hipEventRecord(e2, ctx->stream));
+        hipLaunchKernelGGL(sweep_kernel<3>, dim3(sweep_grid), block, kPfLdsBytes, ctx->stream,
+                           (const PairDesc*)ctx->d_vpairs.as<PairDesc>(), (const PfPair*)ctx->d_vpf.as<PfPair>(),
+                           (const WorkItem*)ctx->d_vitems.as<WorkItem>(), (float*)nullptr, (float*)nullptr, (float*)nullptr,
+                           (float*)nullptr, (const float*)ctx->d_cmp_tu.as<float>(), (const float*)nullptr, ctx->d_cand.as<int2>(),
+                           ctx->d_cand_count.as<unsigned long long>(), (const int*)&ctx->d_summary.as<PlanSummary>()->n_items, 0);
+        HIPCHK(ctx, hipGetLastError());
+        DBGSYNC(ctx, "sweep_kernel<3>");
+        ctx->prof.sweep2_launches += 1;
+        HIPCHK(ctx, hipEventRecord(e3, ctx->stream));
+        dl = ctx->d_lists.as<CandList>();
+        ctx->pf_pending.compact = true;
+        ctx->pf_pending.rows_cap = rows_cap;
+        ctx->pf_pending.cand_cap = cand_cap;
+        ctx->pf_pending.items_cap = items_cap;
+        ctx->pf_pending.compact_pairs = cp.pairs;
+    } else {
+        // ---- dense sweep 2: the pairs' own lists, the sweep-1 items again ----------------------------------------
+        n_lists = P;
+        std::vector<CandList> lists(P);
+        for (size_t p = 0; p < P; ++p)
+            lists[p] = CandList{(int)p, 0, b.pf[p].cand_off, b.pf[p].cand_cap, 0, nullptr, nullptr};
+        HIPCHK(ctx, ctx->d_cand.ensure(std::max<long long>(1, dense_cand) * sizeof(int2)));
+        HIPCHK(ctx, ctx->d_cand_s.ensure(std::max<long long>(1, dense_cand) * 4));
+        HIPCHK(ctx, ctx->d_cand_pair.ensure(std::max<long long>(1, dense_cand) * 4));
+        HIPCHK(ctx, ctx->d_cand_count.ensure(P * 8));
+        HIPCHK(ctx, ctx->d_lists.ensure(P * sizeof(CandList)));
+        HIPCHK(ctx, hipMemsetAsync(ctx->d_cand_count.p, 0, P * 8, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(ctx->d_lists.p, lists.data(), P * sizeof(CandList), hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(ctx->d_pf.p, b.pf.data(), P * sizeof(PfPair), hipMemcpyHostToDevice, ctx->stream));  // cand_off / cap
+        HIPCHK(ctx, hipEventRecord(e2, ctx->stream));
+        hipLaunchKernelGGL(sweep_kernel<2>, dim3(std::min<unsigned>(sweep_grid, (unsigned)b.items.size())), block, kPfLdsBytes, ctx->stream, dp, dpf,
                            ctx->d_items.as<WorkItem>(), (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr,
-                           (const float*)tuv, (const float*)tuv, ctx->d_cand.as<int2>(), ctx->d_cand_count.as<unsigned long long>());
+                           (const float*)tuv, (const float*)tuv, ctx->d_cand.as<int2>(), ctx->d_cand_count.as<unsigned long long>(),
+                           (const int*)nullptr, (int)b.items.size());
         HIPCHK(ctx, hipGetLastError());
-    DBGSYNC(ctx, "sweep_kernel<2>");
+        DBGSYNC(ctx, "sweep_kernel<2>");
         ctx->prof.sweep2_launches += 1;
+        HIPCHK(ctx, hipEventRecord(e3, ctx->stream));
+        dl = ctx->d_lists.as<CandList>();
     }
-    if (V > 0) {
-        hipLaunchKernelGGL(sweep_kernel<3>, dim3((unsigned)vitems.size()), block, kPfLdsBytes, ctx->stream,
-                           ctx->d_vpairs.as<PairDesc>(), ctx->d_vpf.as<PfPair>(), ctx->d_vitems.as<WorkItem>(), (float*)nullptr,
-                           (float*)nullptr, (float*)nullptr, (float*)nullptr, ctx->d_cmp_tu.as<float>(), (const float*)nullptr,
-                           ctx->d_cand.as<int2>(), ctx->d_cand_count.as<unsigned long long>() + P);
-        HIPCHK(ctx, hipGetLastError());
-    DBGSYNC(ctx, "sweep_kernel<3>");
-        ctx->prof.sweep2_launches += 1;
-    }
-    HIPCHK(ctx, hipEventRecord(e3, ctx->stream));
 
-    if (!active.empty()) {
-        const CandList* dl = ctx->d_lists.as<CandList>();
-        const dim3 cgrid(64, (unsigned)std::max<size_t>(1, active.size()));
-        const int* dact = ctx->d_active.as<int>();
+    if (n_lists > 0) {
+        const dim3 cgrid(64, (unsigned)n_lists);
+        const unsigned long long* dcount = ctx->d_cand_count.as<unsigned long long>();
         if (ctx->order == MSFM_ORDER_SSE4X4)
-            hipLaunchKernelGGL(pf_exact_candidates_kernel<0>, cgrid, dim3(256), 0, ctx->stream, dp, dl, dact, (const unsigned long long*)ctx->d_cand_count.as<unsigned long long>(),
+            hipLaunchKernelGGL(pf_exact_candidates_kernel<0>, cgrid, dim3(256), 0, ctx->stream, dp, dl, dcount,
                                ctx->d_cand.as<int2>(), ctx->d_cand_s.as<float>(), ctx->d_cand_pair.as<int>());
         else
-            hipLaunchKernelGGL(pf_exact_candidates_kernel<1>, cgrid, dim3(256), 0, ctx->stream, dp, dl, dact, (const unsigned long long*)ctx->d_cand_count.as<unsigned long long>(),
+            hipLaunchKernelGGL(pf_exact_candidates_kernel<1>, cgrid, dim3(256), 0, ctx->stream, dp, dl, dcount,
                                ctx->d_cand.as<int2>(), ctx->d_cand_s.as<float>(), ctx->d_cand_pair.as<int>());
         HIPCHK(ctx, hipGetLastError());
-        DBGSYNC(ctx, "pf_exact_candidates_kernel<1>");
-        const dim3 rgrid(16, (unsigned)std::max<size_t>(1, active.size()));
-        hipLaunchKernelGGL(pf_reduce_best_kernel, rgrid, dim3(256), 0, ctx->stream, dp, dl, dact, (const unsigned long long*)ctx->d_cand_count.as<unsigned long long>(),
+        DBGSYNC(ctx, "pf_exact_candidates_kernel");
+        const dim3 rgrid(16, (unsigned)n_lists);
+        hipLaunchKernelGGL(pf_reduce_best_kernel, rgrid, dim3(256), 0, ctx->stream, dp, dl, dcount,
                            ctx->d_cand.as<int2>(), ctx->d_cand_s.as<float>(), (const int*)ctx->d_cand_pair.as<int>(),
                            ctx->d_best.as<unsigned long long>());
         HIPCHK(ctx, hipGetLastError());
         DBGSYNC(ctx, "pf_reduce_best_kernel");
-        hipLaunchKernelGGL(pf_reduce_second_kernel, rgrid, dim3(256), 0, ctx->stream, dp, dl, dact, (const unsigned long long*)ctx->d_cand_count.as<unsigned long long>(),
+        hipLaunchKernelGGL(pf_reduce_second_kernel, rgrid, dim3(256), 0, ctx->stream, dp, dl, dcount,
                            ctx->d_cand.as<int2>(), ctx->d_cand_s.as<float>(), (const int*)ctx->d_cand_pair.as<int>(),
                            ctx->d_best.as<unsigned long long>(), ctx->d_second.as<unsigned long long>());
         HIPCHK(ctx, hipGetLastError());
@@ -695,70 +706,80 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
                        ctx->d_k_d1.as<float>(), ctx->d_fix_count.as<int>(), ctx->d_fix_list.as<int4>(), ctx->fix_cap_eff);
     HIPCHK(ctx, hipGetLastError());
     DBGSYNC(ctx, "pf_finalize_kernel");
-
-    // candidate-list overflow -> brute-force exact path for that pair
-    std::vector<unsigned long long> counts(P + V);
-    HIPCHK(ctx, hipMemcpyAsync(counts.data(), ctx->d_cand_count.p, (P + V) * 8, hipMemcpyDeviceToHost, ctx->stream));
-#ifdef MSFM_SWEEP_PROBE
-    if (std::getenv("MSFM_DUMP_T")) {   // diagnostic build: the raw candidate records of list 0
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-        unsigned long long n0 = 0;
-        HIPCHK(ctx, hipMemcpy(&n0, ctx->d_cand_count.p, 8, hipMemcpyDeviceToHost));
-        const int cap0 = lists[0].cap, take = (int)std::min<unsigned long long>(n0, (unsigned long long)cap0);
-        std::vector<int2> c((size_t)std::max(take, 1));
-        if (take) HIPCHK(ctx, hipMemcpy(c.data(), ctx->d_cand.as<int2>() + lists[0].off, (size_t)take * 8, hipMemcpyDeviceToHost));
-        std::map<std::pair<int, int>, int> seen;
-        int colhist[8] = {0}, rowhist[8] = {0};
-        for (int i = 0; i < take; ++i) { seen[{c[i].x, c[i].y}]++; colhist[(c[i].y >> 3) & 7]++; rowhist[(c[i].x >> 3) & 7]++; }
-        std::fprintf(stderr, "[dump] list 0: count %llu cap %d distinct %zu | cols by 8: %d %d %d %d %d %d %d %d | rows by 8: %d %d %d %d %d %d %d %d\n", n0, cap0,
-                     seen.size(), colhist[0], colhist[1], colhist[2], colhist[3], colhist[4], colhist[5], colhist[6], colhist[7],
-                     rowhist[0], rowhist[1], rowhist[2], rowhist[3], rowhist[4], rowhist[5], rowhist[6], rowhist[7]);
+    // which pairs own an overflowed list, how many candidates were evaluated: read at the end of the batch
+    HIPCHK(ctx, ctx->d_overflow.ensure(P));
+    HIPCHK(ctx, ctx->d_totals.ensure(16));
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_overflow.p, 0, P, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_totals.p, 0, 16, ctx->stream));
+    if (n_lists > 0) {
+        hipLaunchKernelGGL(pf_overflow_kernel, dim3((unsigned)((n_lists + 255) / 256)), dim3(256), 0, ctx->stream, dl, (int)n_lists,
+                           (const unsigned long long*)ctx->d_cand_count.as<unsigned long long>(), (const PlanGroup*)ctx->d_groups.as<PlanGroup>(),
+                           (const int*)ctx->d_gmembers.as<int>(), (const int*)ctx->d_member_pair.as<int>(),
+                           ctx->d_overflow.as<unsigned char>(), ctx->d_totals.as<unsigned long long>());
+        HIPCHK(ctx, hipGetLastError());
     }
-#endif
+    HIPCHK(ctx, ctx->h_summary.ensure(sizeof(PlanSummary) + 16 + P + 64, 0));
+    char* hs = ctx->h_summary.as<char>();
+    if (compact) HIPCHK(ctx, hipMemcpyAsync(hs, ctx->d_summary.p, sizeof(PlanSummary), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(hs + sizeof(PlanSummary), ctx->d_totals.p, 16, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(hs + sizeof(PlanSummary) + 16, ctx->d_overflow.p, P, hipMemcpyDeviceToHost, ctx->stream));
+    ctx->pf_pending.active = true;
+    ctx->pf_pending.n_lists = n_lists;
+    ctx->pf_pending.P = P;
+    ctx->pf_pending.ev_base = ev_base;
     hc.lap("launch sweep 2 .. finalize");
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    hc.lap("wait for candidate counts (GPU)");
+    return MSFM_OK;
+}
+
+// After the batch's stream synchronisation: did the prefilter path complete?  *retry: run the batch again (buffers
+// grown / overflowed pairs moved to the brute-force path in `force_exact`).
+int finish_prefilter(msfm_ctx* ctx, Batch& b, std::vector<char>& force_exact, bool* retry) {
+    *retry = false;
+    msfm_ctx::PfPending& pe = ctx->pf_pending;
+    if (!pe.active) return MSFM_OK;
+    pe.active = false;
+    const char* hs = ctx->h_summary.as<char>();
+    PlanSummary sm = {};
+    unsigned long long totals[2] = {0, 0};
+    std::memcpy(totals, hs + sizeof(PlanSummary), 16);
     float ms = 0.f;
-    HIPCHK(ctx, hipEventElapsedTime(&ms, e0, e1));
+    HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev_pool[pe.ev_base], ctx->ev_pool[pe.ev_base + 1]));
     ctx->prof.approx_kernel_ms += ms;
-#ifdef MSFM_SWEEP_PROBE
-    {   // diagnostic build: average cycles per tile and wave of the four loop segments of sweep 1
-        unsigned long long pr[kPfWaves][8];
-        HIPCHK(ctx, hipMemcpyFromSymbol(pr, HIP_SYMBOL(g_sweep_probe), sizeof(pr)));
-        for (int w = 0; w < kPfWaves; ++w) {
-            const double n = (double)std::max<unsigned long long>(1, pr[w][4]);
-            std::fprintf(stderr, "[sweep probe] wave %d: MFMA %.0f | wait+barrier %.0f | EPI %.0f | wait+barrier %.0f cycles per tile (%.0f tiles), sweep 1 %.3f ms\n",
-                         w, pr[w][0] / n, pr[w][1] / n, pr[w][2] / n, pr[w][3] / n, n, ms);
-        }
-        std::memset(pr, 0, sizeof(pr));
-        HIPCHK(ctx, hipMemcpyToSymbol(HIP_SYMBOL(g_sweep_probe), pr, sizeof(pr)));
-    }
-#endif
-    HIPCHK(ctx, hipEventElapsedTime(&ms, e2, e3));
+    HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev_pool[pe.ev_base + 2], ctx->ev_pool[pe.ev_base + 3]));
     ctx->prof.sweep2_ms += ms;
-    std::vector<char> overflow(P, 0);
-    for (size_t l = 0; l < P + V; ++l) {
-        if (lists[l].cap == 0) continue;
-        if (counts[l] <= (unsigned long long)lists[l].cap) {
-            ctx->prof.candidates += counts[l];
-            continue;
+    if (pe.compact) {
+        std::memcpy(&sm, hs, sizeof(PlanSummary));
+        ctx->cmp_rows_hint = sm.cmp_rows;
+        if (!sm.ok) {   // the prediction was too small: the buffers are sized from the need now
+            ctx->prof.plan_regrows += 1;
+            *retry = true;
+            return MSFM_OK;
         }
-        if (l < P) overflow[l] = 1;
-        else  // a group's list: every pair that has rows in it
-            for (int k = 0; k < groups[l - P].count; ++k) overflow[(size_t)members[(size_t)(groups[l - P].first + k)].pair] = 1;
+        ctx->prof.sweep2_descriptor_pairs += sm.swept_desc_pairs;
+    } else {
+        ctx->prof.sweep2_descriptor_pairs += pe.dense_swept;
     }
-    for (size_t p = 0; p < P; ++p) {
+    const unsigned char* ov = reinterpret_cast<const unsigned char*>(hs + sizeof(PlanSummary) + 16);
+    int n_over = 0;
+    for (size_t p = 0; p < pe.P; ++p) {
         if (!b.pairs[p].valid || !b.pf[p].use) continue;
-        if (overflow[p]) {
-            b.pf[p].use = 0;
-            b.pairs[p].path = 0;
-            ctx->prof.fallback_pairs += 1;
-        } else {
+        if (ov[p]) {
+            force_exact[p] = 1;
+            ++n_over;
+        }
+    }
+    if (n_over > 0) {   // candidate-list overflow -> those pairs take the brute-force exact path in a second run
+        ctx->prof.fallback_pairs += n_over;
+        *retry = true;
+        return MSFM_OK;
+    }
+    ctx->prof.candidates += (int64_t)totals[0];
+    for (size_t p = 0; p < pe.P; ++p)
+        if (b.pairs[p].valid && b.pf[p].use) {
             ctx->prof.prefilter_pairs += 1;
             ctx->prof.prefilter_descriptor_pairs += (int64_t)b.pairs[p].n1 * b.pairs[p].n2;
-            if (compact[p]) ctx->prof.compacted_pairs += 1;
         }
-    }
+    if (pe.compact) ctx->prof.compacted_pairs += pe.compact_pairs;
     return MSFM_OK;
 }
 
@@ -850,8 +871,6 @@ int run_knn(msfm_ctx* ctx, Batch& b, size_t ev_base, bool* exact_launched, Prune
                                ctx->d_k_i0.as<int>(), ctx->d_k_d0.as<float>());
         HIPCHK(ctx, hipGetLastError());
     }
-    ctx->prof.descriptor_pairs += b.desc_pairs;
-    ctx->prof.dist_algo_bytes += b.algo_bytes;
     return MSFM_OK;
 }
 
@@ -958,12 +977,13 @@ void msfm_destroy(msfm_ctx* ctx) {
                       &ctx->d_st_qt, &ctx->d_st_d, &ctx->d_counts, &ctx->d_offsets, &ctx->d_out_qt,
                       &ctx->d_out_d, &ctx->d_fix_count, &ctx->d_fix_list, &ctx->d_pf, &ctx->d_tu, &ctx->d_tv,
                       &ctx->d_cand, &ctx->d_cand_s, &ctx->d_cand_count, &ctx->d_best, &ctx->d_second, &ctx->d_maxima,
-                      &ctx->d_live_cnt, &ctx->d_cmp_h, &ctx->d_cmp_tu, &ctx->d_live_idx, &ctx->d_vpairs, &ctx->d_vpf,
-                      &ctx->d_vitems, &ctx->d_jobs, &ctx->d_lists, &ctx->d_row_pair, &ctx->d_cand_pair, &ctx->d_active, &ctx->d_vf_pairs, &ctx->d_vf_x1, &ctx->d_vf_y1,
+                      &ctx->d_cmp_h, &ctx->d_cmp_tu, &ctx->d_live_idx, &ctx->d_vpairs, &ctx->d_vpf, &ctx->d_row_src, &ctx->d_colmask, &ctx->d_groups, &ctx->d_gmembers, &ctx->d_member_pair, &ctx->d_ppair, &ctx->d_cnt, &ctx->d_fill, &ctx->d_mrow, &ctx->d_summary, &ctx->d_overflow, &ctx->d_totals,
+                      &ctx->d_vitems, &ctx->d_lists, &ctx->d_row_pair, &ctx->d_cand_pair, &ctx->d_vf_pairs, &ctx->d_vf_x1, &ctx->d_vf_y1,
                       &ctx->d_vf_x2, &ctx->d_vf_y2, &ctx->d_vf_hyp, &ctx->d_vf_best_it, &ctx->d_vf_best_count,
                       &ctx->d_vf_flags, &ctx->d_st2_qt, &ctx->d_st2_d, &ctx->d_counts2};
     for (DevBuf* b : bufs) b->release();
     ctx->res_qt.release();
+    ctx->h_summary.release();
     ctx->res_dist.release();
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(ctx->stream);
@@ -1158,6 +1178,7 @@ static int match_pairs_impl(msfm_ctx* ctx, const int32_t* pairs, int n_pairs, co
     if (!(prm.max_distance >= 0.0)) prune.max_distance = __builtin_huge_valf();  // NaN / negative: no distance-based pruning
     HIPCHK(ctx, hipSetDevice(ctx->device));
     ctx->have_results = false;
+    ctx->pf_pending = msfm_ctx::PfPending{};
     ctx->res_offsets.assign((size_t)n_pairs + 1, 0);
     ctx->res_count = 0;
     ctx->prof = msfm_profile{};
@@ -1175,7 +1196,8 @@ static int match_pairs_impl(msfm_ctx* ctx, const int32_t* pairs, int n_pairs, co
     int begin = 0;
     while (begin < n_pairs) {
       int end = begin;
-      for (int attempt = 0;; ++attempt) {   // a sub-batch is re-run when its tie queue was too small (grown by then)
+      std::vector<char> force_exact;   // pairs of this sub-batch whose candidate list overflowed: brute-force path in the re-run
+      for (int attempt = 0;; ++attempt) {   // a sub-batch is re-run when a queue / plan buffer was too small (grown by then)
         Batch b;
         long long est = 0;
         end = begin;
@@ -1196,10 +1218,18 @@ static int match_pairs_impl(msfm_ctx* ctx, const int32_t* pairs, int n_pairs, co
                                                3 * (8LL * (pd.n1 + pd.n2) + 1024)) : 0;
             if (end > begin && est + need > kScratchElems) break;
             est += need;
+            const size_t k = b.pairs.size();
+            if (k < force_exact.size() && force_exact[k]) {
+                pp.use = 0;
+                pd.path = 0;
+            }
             b.pairs.push_back(pd);
             b.pf.push_back(pp);
+            b.id1.push_back(pairs[2 * end]);
+            b.id2.push_back(pairs[2 * end + 1]);
             ++end;
         }
+        force_exact.resize(b.pairs.size(), 0);
         const size_t P = b.pairs.size();
         const size_t ev_base = ev_next;
         if (attempt == 0) ev_next += 8;
@@ -1280,11 +1310,15 @@ static int match_pairs_impl(msfm_ctx* ctx, const int32_t* pairs, int n_pairs, co
 
         std::vector<long long> offs(P + 1);
         HIPCHK(ctx, hipMemcpyAsync(offs.data(), ctx->d_offsets.p, (P + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
-        bool retry = false;
+        bool retry = false, retry_pf = false;
         rc = check_fix_overflow(ctx, &retry);  // synchronises the stream
         if (rc != MSFM_OK) return rc;
-        if (retry && attempt < 4) continue;
-        if (retry) return fail(ctx, MSFM_E_DEVICE, "tie fix-up queue kept overflowing");
+        rc = finish_prefilter(ctx, b, force_exact, &retry_pf);
+        if (rc != MSFM_OK) return rc;
+        if ((retry || retry_pf) && attempt < 6) continue;
+        if (retry || retry_pf) return fail(ctx, MSFM_E_DEVICE, "batch kept overflowing its queues");
+        ctx->prof.descriptor_pairs += b.desc_pairs;
+        ctx->prof.dist_algo_bytes += b.algo_bytes;
         const long long total = offs[P];
         HIPCHK(ctx, ctx->res_qt.ensure((base + (size_t)total + 1) * 8, base * 8));
         HIPCHK(ctx, ctx->res_dist.ensure((base + (size_t)total + 1) * 4, base * 4));
@@ -1404,25 +1438,34 @@ int msfm_knn2_pair(msfm_ctx* ctx, int id1, int id2, int32_t* fwd_idx0, float* fw
     if (rc != MSFM_OK) return rc;
     b.pairs.push_back(pd);
     b.pf.push_back(pp);
+    b.id1.push_back(id1);
+    b.id2.push_back(id2);
     bool exact_launched = false;
-    int regrows = 0;
+    int regrows = 0, fallbacks = 0;
+    std::vector<char> force_exact(1, 0);
     for (int attempt = 0;; ++attempt) {
         b.items.clear();
         b.rp_elems = b.cp_elems = b.kf_elems = b.kr_elems = b.out_elems = b.cand_elems = 0;
         b.desc_pairs = b.algo_bytes = 0;
-        b.pairs[0].path = b.pf[0].use = pp.use;
+        b.pairs[0].path = b.pf[0].use = force_exact[0] ? 0 : pp.use;
         ctx->prof = msfm_profile{};
         rc = run_knn(ctx, b, 2, &exact_launched, PruneParams{0, 0.f, 0.f}, true);  // knnMatch twin: every row keeps its neighbours
         if (rc != MSFM_OK) return rc;
-        bool retry = false;
+        bool retry = false, retry_pf = false;
         rc = check_fix_overflow(ctx, &retry);
         if (rc != MSFM_OK) return rc;
-        if (!retry) break;
-        ++regrows;
-        if (attempt >= 4) return fail(ctx, MSFM_E_DEVICE, "tie fix-up queue kept overflowing");
+        rc = finish_prefilter(ctx, b, force_exact, &retry_pf);
+        if (rc != MSFM_OK) return rc;
+        if (!retry && !retry_pf) break;
+        if (retry) ++regrows;
+        if (retry_pf) fallbacks += ctx->prof.fallback_pairs;
+        if (attempt >= 6) return fail(ctx, MSFM_E_DEVICE, "batch kept overflowing its queues");
     }
     ctx->prof.tie_queue_regrows = regrows;
+    ctx->prof.fallback_pairs = fallbacks;
     ctx->prof.sub_batches = 1;
+    ctx->prof.descriptor_pairs += b.desc_pairs;
+    ctx->prof.dist_algo_bytes += b.algo_bytes;
     rc = accumulate_kernel_time(ctx, 2, exact_launched);
     if (rc != MSFM_OK) return rc;
     const PairDesc& q = b.pairs[0];

@@ -1,0 +1,311 @@
+// msfm_plan.hip.h -- the plan of the compacted sweep 2, built ON THE DEVICE (included by msfm_prefilter.hip.h).
+//
+// After sweep 1 and pf_thresholds_kernel every row / column of every pair is either dead (it provably cannot yield a
+// match: threshold -inf) or alive, and for every live column a bit mask names the 512-row blocks of image 1 that can
+// hold a candidate of it.  Sweep 2 only multiplies live rows:
+//
+//   forward group  (streamed image j):             the live ROWS of image i of every pair (i, j) of the batch, one after
+//                                                  the other, against ALL tiles of image j;
+//   reverse group  (streamed image i, block bit b): the live COLUMNS (rows of image j) of every pair (i, j) whose mask has
+//                                                  bit b, against the tiles of THAT block of image i only.
+//
+// Which groups exist, which (pair, direction[, bit]) slices ("members") they consist of and in which order is a function
+// of the pair list alone: the host builds those tables before the first launch.  How many rows each member contributes
+// is only known on the device; round 1 copied the counts to the host, planned there and uploaded the plan -- two stream
+// synchronisations and a std::map in the middle of the pipeline.  Now:
+//
+//   pf_count_kernel    live rows per member                                          grid = 2 x pairs
+//   pf_plan_kernel     prefix sums -> row ranges of members and groups (512-aligned), the groups' sweep descriptors
+//                      (PairDesc / PfPair / CandList), the work-item list, capacity check   one workgroup
+//   pf_assign_kernel   every live row gets its slot(s): index, pair, threshold, source row   grid = 2 x pairs
+//   pf_copy_rows_kernel compacted fp16 operand rows (zero rows where no source: group tails)  grid-stride
+//
+// and the sweep kernels take the number of work items from device memory.  Buffers are sized from a prediction (the
+// previous call's need, or a fraction of the row total); if the plan does not fit, it marks itself invalid, everything
+// downstream degenerates to a no-op and the host -- which looks at the summary together with the results, at the one
+// synchronisation at the end of the batch -- grows the buffers and runs the batch again.
+#pragma once
+// (included inside namespace msfm)
+
+struct PlanGroup {            // static description of one compacted sweep (host-built)
+    const _Float16* b_h;      // streamed image: fp16 operand rows
+    const float* b_nrm;
+    float b_c, a_c;           // scales of the streamed image's / the compacted rows' norm quadruples
+    int dir;                  // 0: forward (candidate records (k, t)), 1: reverse (records (k, q))
+    int bt_begin, bt_end;     // streamed range, in 128-row blocks of the streamed image
+    int n2, n2pad, b_tiles;   // rows / padded rows / 128-row blocks of the streamed image
+    int first, count;         // members: gmembers[first .. first + count)
+    int ranges;               // B-range split of its work items (1 unless the batch is small)
+    int pad;
+};
+
+struct PlanPair {             // where the members of a pair sit in the member arrays
+    int fwd_member;           // -1: the pair is not on the compacted path
+    int rev_member0;          // members rev_member0 + bit, bit < rev_bits
+    int rev_bits;
+    int pad;
+};
+
+struct PlanSummary {
+    int ok;                   // 0: a capacity was exceeded, nothing downstream ran
+    int n_items;              // work items of the compacted sweep (a multiple of 8: XCD interleave)
+    long long cmp_rows;       // rows of the compacted matrices incl. the 512-alignment of the groups
+    long long cand_elems;     // candidate-list capacity the plan wants
+    long long items_needed;
+    long long swept_desc_pairs;  // descriptor pairs the compacted sweep multiplies (padding included)
+};
+
+// live rows per member.  dir 0: rows of image 1 with a threshold; dir 1: per mask bit, the live columns that carry it.
+__global__ void pf_count_kernel(const PairDesc* __restrict__ pairs, const PfPair* __restrict__ pf, const PlanPair* __restrict__ pp_plan,
+                                const float* __restrict__ tuv, const unsigned* __restrict__ colmask, int* __restrict__ cnt) {
+    const int p = blockIdx.x >> 1, dir = blockIdx.x & 1;
+    const PlanPair pl = pp_plan[p];
+    if (pl.fwd_member < 0) return;
+    const PairDesc pd = pairs[p];
+    const PfPair pp = pf[p];
+    __shared__ int hist[33];
+    if (threadIdx.x < 33) hist[threadIdx.x] = 0;
+    __syncthreads();
+    if (dir == 0) {
+        int c = 0;
+        for (int e = threadIdx.x; e < pd.n1; e += blockDim.x) c += (tuv[pp.tu_off + e] != -f_inf()) ? 1 : 0;
+        for (int m = 32; m >= 1; m >>= 1) c += __shfl_xor(c, m);
+        if ((threadIdx.x & 63) == 0) atomicAdd(&hist[32], c);
+        __syncthreads();
+        if (threadIdx.x == 0) cnt[pl.fwd_member] = hist[32];
+    } else {
+        for (int e = threadIdx.x; e < pd.n2; e += blockDim.x) {
+            unsigned m = (tuv[pp.tv_off + e] != -f_inf()) ? colmask[pp.tv_off + e] : 0u;
+            while (m) {
+                const int b = __builtin_ctz(m);
+                m &= m - 1;
+                atomicAdd(&hist[b], 1);
+            }
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < pl.rev_bits) cnt[pl.rev_member0 + threadIdx.x] = hist[threadIdx.x];
+    }
+}
+
+// One workgroup of 1024 threads.  All loops are strided over groups / members; the two exclusive scans (rows and work
+// items / candidate capacity over groups) run as chunked scans through LDS.
+struct PlanOut {
+    PairDesc* vpairs;         // [n_groups] sweep descriptors
+    PfPair* vpf;
+    CandList* lists;          // [n_groups]
+    WorkItem* items;          // [items_cap], pre-filled with pair = -1
+    long long* mrow;          // [n_members] first compact row of the member
+    PlanSummary* summary;
+    _Float16* cmp_h;          // compacted operand rows
+    int* live_idx;            // per compact row: row index in its image
+    int* row_pair;            // per compact row: pair of the batch
+    long long rows_cap, cand_cap, items_cap;
+};
+
+__device__ __forceinline__ long long plan_block_exclusive_scan(long long v, long long* total) {
+    // exclusive scan of one value per thread over the 1024-thread workgroup
+    __shared__ long long wsum[16];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    long long inc = v;
+    for (int d = 1; d < 64; d <<= 1) {
+        const long long o = __shfl_up(inc, d);
+        if (lane >= d) inc += o;
+    }
+    __syncthreads();
+    if (lane == 63) wsum[w] = inc;
+    __syncthreads();
+    long long base = 0, tot = 0;
+    for (int k = 0; k < 16; ++k) {
+        if (k < w) base += wsum[k];
+        tot += wsum[k];
+    }
+    *total = tot;
+    __syncthreads();
+    return base + inc - v;
+}
+
+__global__ __launch_bounds__(1024) void pf_plan_kernel(const PlanGroup* __restrict__ groups, int n_groups,
+                                                         const int* __restrict__ gmembers, const int* __restrict__ cnt, PlanOut out) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    __shared__ long long s_base_rows, s_base_items, s_base_cand;
+    __shared__ int s_ok;
+    if (tid == 0) { s_base_rows = 0; s_base_items = 0; s_base_cand = 0; s_ok = 1; }
+    __syncthreads();
+    // pass 1: totals (does the plan fit?)   pass 2: write it
+    long long tot_rows = 0, tot_items = 0, tot_cand = 0, tot_swept = 0;
+    for (int pass = 0; pass < 2; ++pass) {
+        if (pass == 1) {
+            __syncthreads();
+            if (tid == 0) {
+                s_ok = (tot_rows <= out.rows_cap && tot_cand <= out.cand_cap && ((tot_items + 7) / 8) * 8 <= out.items_cap) ? 1 : 0;
+                s_base_rows = s_base_items = s_base_cand = 0;
+                PlanSummary sm;
+                sm.ok = s_ok;
+                sm.n_items = s_ok ? (int)(((tot_items + 7) / 8) * 8) : 0;
+                sm.cmp_rows = tot_rows;
+                sm.cand_elems = tot_cand;
+                sm.items_needed = ((tot_items + 7) / 8) * 8;
+                sm.swept_desc_pairs = tot_swept;
+                *out.summary = sm;
+            }
+            __syncthreads();
+        }
+        const int ok = s_ok;
+        const long long per = (tot_items + 7) / 8;   // XCD interleave of the item list: position (k % per) * 8 + k / per
+        for (int g0 = 0; g0 < n_groups; g0 += nt) {
+            const int g = g0 + tid;
+            long long rows = 0;
+            PlanGroup G = {};
+            if (g < n_groups) {
+                G = groups[g];
+                for (int k = 0; k < G.count; ++k) rows += cnt[gmembers[G.first + k]];
+            }
+            const long long rows512 = (rows + kPfWgRows - 1) / kPfWgRows * kPfWgRows;
+            const long long ablocks = rows512 / kPfWgRows;
+            const long long items = ablocks * (g < n_groups ? G.ranges : 0);
+            const long long cap = rows > 0 ? (8 * rows + 1024 < (1LL << 30) ? 8 * rows + 1024 : (1LL << 30)) : 0;
+            long long tr, ti, tc;
+            const long long row0 = s_base_rows + plan_block_exclusive_scan(rows512, &tr);
+            const long long item0 = s_base_items + plan_block_exclusive_scan(items, &ti);
+            const long long cand0 = s_base_cand + plan_block_exclusive_scan(cap, &tc);
+            if (pass == 0) {
+                tot_rows += tr;
+                tot_items += ti;
+                tot_cand += tc;
+                long long swept = (g < n_groups) ? rows512 * (long long)min(G.n2 - min(G.n2, G.bt_begin * kBN), (G.bt_end - G.bt_begin) * kBN) : 0, ts;
+                (void)plan_block_exclusive_scan(swept, &ts);
+                tot_swept += ts;
+            } else if (g < n_groups) {
+                // the group's sweep descriptor: A = its compacted rows, B = the streamed image
+                PairDesc vd = {};
+                vd.n1 = ok ? (int)rows : 0;
+                vd.n2 = G.n2;
+                vd.a_blocks256 = ok ? (int)ablocks : 0;
+                vd.b_tiles = G.b_tiles;
+                vd.n1pad = ok ? (int)rows512 : 0;
+                vd.n2pad = G.n2pad;
+                vd.valid = 1;
+                vd.path = 1;
+                vd.ranges = G.ranges;
+                out.vpairs[g] = vd;
+                PfPair vp = {};
+                vp.a_h = out.cmp_h + (size_t)row0 * kPfRowHalfs;
+                vp.b_h = G.b_h;
+                vp.b_nrm = G.b_nrm;
+                vp.b_c = G.b_c;
+                vp.a_c = G.a_c;
+                vp.tu_off = row0;
+                vp.cand_off = cand0;
+                vp.cand_cap = ok ? (int)cap : 0;
+                vp.use = (ok && rows > 0) ? 1 : 0;
+                out.vpf[g] = vp;
+                CandList L = {};
+                L.pair = -1;
+                L.mode = 1 + G.dir;
+                L.off = cand0;
+                L.cap = ok ? (int)cap : 0;
+                L.live_idx = out.live_idx + row0;
+                L.row_pair = out.row_pair + row0;
+                out.lists[g] = L;
+                long long r = row0;
+                for (int k = 0; k < G.count; ++k) {
+                    const int m = gmembers[G.first + k];
+                    out.mrow[m] = ok ? r : -1;
+                    r += cnt[m];
+                }
+                if (ok) {
+                    const int nblk = G.bt_end - G.bt_begin;
+                    long long k = item0;
+                    for (int rg = 0; rg < G.ranges; ++rg) {
+                        const int t0 = G.bt_begin + (int)((long long)nblk * rg / G.ranges), t1 = G.bt_begin + (int)((long long)nblk * (rg + 1) / G.ranges);
+                        for (int ab = 0; ab < (int)ablocks; ++ab, ++k) {
+                            WorkItem w = {};
+                            w.pair = g;
+                            w.a_blk = ab;
+                            w.bt_begin = t0;
+                            w.bt_end = t1;
+                            w.range = rg;
+                            out.items[(k % per) * 8 + k / per] = w;
+                        }
+                    }
+                }
+            }
+            if (tid == 0) {
+                s_base_rows += tr;
+                s_base_items += ti;
+                s_base_cand += tc;
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// every live row takes its slot(s) in the compacted matrices: index, pair, threshold (sweep 2 folds (T - |a|^2)/2 into
+// the MFMA), and where its fp16 operand row comes from
+__global__ void pf_assign_kernel(const PairDesc* __restrict__ pairs, const PfPair* __restrict__ pf, const PlanPair* __restrict__ pp_plan,
+                                 const float* __restrict__ tuv, const unsigned* __restrict__ colmask, const long long* __restrict__ mrow,
+                                 int* __restrict__ fill, int* __restrict__ live_idx, int* __restrict__ row_pair, float* __restrict__ cmp_tu,
+                                 const _Float16** __restrict__ row_src) {
+    const int p = blockIdx.x >> 1, dir = blockIdx.x & 1;
+    const PlanPair pl = pp_plan[p];
+    if (pl.fwd_member < 0) return;
+    const PairDesc pd = pairs[p];
+    const PfPair pp = pf[p];
+    const int n = dir ? pd.n2 : pd.n1;
+    const long long off = dir ? pp.tv_off : pp.tu_off;
+    const float* nrm = dir ? pp.b_nrm : pp.a_nrm;
+    const _Float16* src = dir ? pp.b_h : pp.a_h;
+    for (int e = threadIdx.x; e < n; e += blockDim.x) {
+        const float t = tuv[off + e];
+        if (t == -f_inf()) continue;
+        unsigned m = dir ? colmask[off + e] : 1u;
+        while (m) {
+            const int b = __builtin_ctz(m);
+            m &= m - 1;
+            const int mem = dir ? pl.rev_member0 + b : pl.fwd_member;
+            const long long r0 = mrow[mem];
+            if (r0 < 0) continue;   // invalid plan
+            const long long k = r0 + atomicAdd(&fill[mem], 1);
+            live_idx[k] = e;
+            row_pair[k] = p;
+            cmp_tu[k] = t - nrm[e];
+            row_src[k] = src + (size_t)e * kPfRowHalfs;
+        }
+    }
+}
+
+// compacted operand rows: 16 threads per row, one 16-byte data granule each; rows without a source (the tails of the
+// groups up to the next multiple of 512, swept too) are zero: an fp16 inf / NaN from stale memory must not reach the
+// matrix core.  The compacted matrix only plays the A role: its 17th granule is never read.
+__global__ void pf_copy_rows_kernel(const PlanSummary* __restrict__ summary, const _Float16* const* __restrict__ row_src,
+                                    _Float16* __restrict__ cmp_h) {
+    const PlanSummary sm = *summary;
+    if (!sm.ok) return;
+    const int g = threadIdx.x & 15;
+    h8 z;
+    for (int j = 0; j < 8; ++j) z[j] = (_Float16)0.f;
+    for (long long k = (long long)blockIdx.x * (blockDim.x >> 4) + (threadIdx.x >> 4); k < sm.cmp_rows; k += (long long)gridDim.x * (blockDim.x >> 4)) {
+        const _Float16* s = row_src[k];
+        *reinterpret_cast<h8*>(cmp_h + (size_t)k * kPfRowHalfs + g * 8) = s ? *reinterpret_cast<const h8*>(s + g * 8) : z;
+    }
+}
+
+// after the candidate kernels: which pairs own a list that overflowed (they are re-run on the brute-force path), how
+// many candidates were evaluated
+__global__ void pf_overflow_kernel(const CandList* __restrict__ lists, int n_lists, const unsigned long long* __restrict__ cand_count,
+                                   const PlanGroup* __restrict__ groups, const int* __restrict__ gmembers, const int* __restrict__ member_pair,
+                                   unsigned char* __restrict__ overflow_pair, unsigned long long* __restrict__ totals /* [0] candidates, [1] overflowed lists */) {
+    for (int l = blockIdx.x * blockDim.x + threadIdx.x; l < n_lists; l += gridDim.x * blockDim.x) {
+        const CandList L = lists[l];
+        if (L.cap == 0) continue;
+        const unsigned long long c = cand_count[l];
+        if (c <= (unsigned long long)L.cap) {
+            atomicAdd(&totals[0], c);
+            continue;
+        }
+        atomicAdd(&totals[1], 1ull);
+        if (L.mode == 0) overflow_pair[L.pair] = 1;
+        else
+            for (int k = 0; k < groups[l].count; ++k) overflow_pair[member_pair[gmembers[groups[l].first + k]]] = 1;
+    }
+}

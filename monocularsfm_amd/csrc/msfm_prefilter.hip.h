@@ -192,7 +192,7 @@ __device__ __forceinline__ bool pf_dead(float s0, float s1, float nrm, float eps
 
 __global__ void pf_thresholds_kernel(const PairDesc* __restrict__ pairs, const PfPair* __restrict__ pf,
                                      const float* __restrict__ rp_s0, const float* __restrict__ rp_s1,
-                                     const float* __restrict__ cp_s0, const float* __restrict__ cp_s1,
+                                     const float* __restrict__ cp_s0, unsigned* __restrict__ colmask,
                                      float* __restrict__ tu, float* __restrict__ tv, PruneParams pr) {
     const PairDesc pd = pairs[blockIdx.y];
     const PfPair pp = pf[blockIdx.y];
@@ -228,7 +228,22 @@ __global__ void pf_thresholds_kernel(const PairDesc* __restrict__ pairs, const P
         const float eps = kEpsRel * (nb + pp.a_nrm_max) + kEpsAbs * (sqrtf(nb) + sqrtf(pp.a_nrm_max)) + eps_norm;
         const float slack = 2.f * eps + 1e-5f * (fabsf(s1) + nb + pp.a_nrm_max);
         const bool live = (e < pd.n2) && !pf_dead(s0, s1, nb, eps, pp.a_nrm_max, pr);
-        tv[pp.tv_off + e] = live ? s1 + slack : -f_inf();
+        const float T = live ? s1 + slack : -f_inf();
+        tv[pp.tv_off + e] = T;
+        if (colmask) {
+            // which 512-row blocks of image 1 can hold a candidate of this column at all: the block's smallest S~ must
+            // not exceed T.  Bit b covers blocks [b g, (b + 1) g), g = ceil(blocks / 32) (1 up to 16384 rows).  The
+            // reverse direction of sweep 2 only visits those blocks (pf_plan.hip.h).
+            const int g = (pd.a_blocks256 + 31) / 32;
+            unsigned mask = 0;
+            if (live)
+                for (int p = 0; p < pd.a_blocks256; ++p) {
+                    const float4 m = cp4[pd.cp_off + (long long)p * pd.n2pad + e];
+                    const float smin = -2.f * fmaxf(fmaxf(m.x, m.y), fmaxf(m.z, m.w));
+                    if (smin <= T) mask |= 1u << (p / g);
+                }
+            colmask[pp.tv_off + e] = mask;
+        }
     }
 }
 
@@ -251,10 +266,9 @@ struct CandList {
 // Records are rewritten in place as real (q, t).   grid = (x, n_lists)
 template <int ORDER>
 __global__ void pf_exact_candidates_kernel(const PairDesc* __restrict__ pairs, const CandList* __restrict__ lists,
-                                           const int* __restrict__ active /* ids of the non-empty lists */,
                                            const unsigned long long* __restrict__ cand_count, int2* __restrict__ cand,
                                            float* __restrict__ cand_s, int* __restrict__ cand_pair) {
-    const int lid = active[blockIdx.y];
+    const int lid = blockIdx.y;
     const CandList L = lists[lid];
     if (L.cap == 0) return;
     const int n = (int)(cand_count[lid] < (unsigned long long)L.cap ? cand_count[lid] : (unsigned long long)L.cap);
@@ -321,10 +335,10 @@ __device__ __forceinline__ unsigned long long pf_key(float s, int idx) {
 // A mode-1 list only serves the row direction, a mode-2 list only the column direction: the live
 // rows of the OTHER direction get their complete candidate sets from their own list.
 __global__ void pf_reduce_best_kernel(const PairDesc* __restrict__ pairs, const CandList* __restrict__ lists,
-                                      const int* __restrict__ active, const unsigned long long* __restrict__ cand_count,
+                                      const unsigned long long* __restrict__ cand_count,
                                       const int2* __restrict__ cand, const float* __restrict__ cand_s,
                                       const int* __restrict__ cand_pair, unsigned long long* __restrict__ best) {
-    const int lid = active[blockIdx.y];
+    const int lid = blockIdx.y;
     const CandList L = lists[lid];
     if (L.cap == 0) return;
     const int n = (int)(cand_count[lid] < (unsigned long long)L.cap ? cand_count[lid] : (unsigned long long)L.cap);
@@ -339,11 +353,11 @@ __global__ void pf_reduce_best_kernel(const PairDesc* __restrict__ pairs, const 
 }
 // reduce phase B: second best = min over the candidates that are not the best one
 __global__ void pf_reduce_second_kernel(const PairDesc* __restrict__ pairs, const CandList* __restrict__ lists,
-                                        const int* __restrict__ active, const unsigned long long* __restrict__ cand_count,
+                                        const unsigned long long* __restrict__ cand_count,
                                         const int2* __restrict__ cand, const float* __restrict__ cand_s,
                                         const int* __restrict__ cand_pair, const unsigned long long* __restrict__ best,
                                         unsigned long long* __restrict__ second) {
-    const int lid = active[blockIdx.y];
+    const int lid = blockIdx.y;
     const CandList L = lists[lid];
     if (L.cap == 0) return;
     const int n = (int)(cand_count[lid] < (unsigned long long)L.cap ? cand_count[lid] : (unsigned long long)L.cap);
@@ -358,81 +372,7 @@ __global__ void pf_reduce_second_kernel(const PairDesc* __restrict__ pairs, cons
     }
 }
 
-// live rows (threshold > -inf) per (pair, direction); grid = 2 * n_pairs blocks of 256
-__global__ void pf_count_live_kernel(const PairDesc* __restrict__ pairs, const PfPair* __restrict__ pf,
-                                     const float* __restrict__ tuv, int* __restrict__ live_cnt) {
-    const int p = blockIdx.x >> 1, dir = blockIdx.x & 1;
-    const PairDesc pd = pairs[p];
-    const PfPair pp = pf[p];
-    __shared__ int total;
-    if (threadIdx.x == 0) total = 0;
-    __syncthreads();
-    if (pd.valid && pp.use) {
-        const int n = dir ? pd.n2 : pd.n1;
-        const long long off = dir ? pp.tv_off : pp.tu_off;
-        int c = 0;
-        for (int e = threadIdx.x; e < n; e += blockDim.x) c += (tuv[off + e] != -f_inf()) ? 1 : 0;
-        for (int m = 32; m >= 1; m >>= 1) c += __shfl_xor(c, m);
-        if ((threadIdx.x & 63) == 0) atomicAdd(&total, c);
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) live_cnt[blockIdx.x] = total;
-}
-
-// compaction of the live rows of one (pair, direction): indices, thresholds and the fp16 rows
-// (re-swizzled for their new row number).   grid = n_jobs blocks of 256
-struct GatherJob {
-    const _Float16* src_h;   // image's fp16 blocks
-    const float* src_nrm;    // its |row|^2
-    long long src_thr_off;   // into tuv
-    long long dst_row;       // first row of this job in the compact arrays (its group starts at a multiple of 256)
-    long long zero_upto;     // rows [dst_row + live, zero_upto) are zero-filled (the group's tail; else == dst_row + live)
-    int n;                   // rows of the image
-    int pair;                // batch index of the pair the rows belong to
-};
-__global__ void pf_gather_live_kernel(const GatherJob* __restrict__ jobs, const float* __restrict__ tuv,
-                                      int* __restrict__ live_idx, int* __restrict__ row_pair, float* __restrict__ cmp_tu,
-                                      _Float16* __restrict__ cmp_h) {
-    const GatherJob J = jobs[blockIdx.x];
-    __shared__ int wsum[4];
-    __shared__ int running;
-    if (threadIdx.x == 0) running = 0;
-    __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int e0 = 0; e0 < J.n; e0 += 256) {
-        const int e = e0 + threadIdx.x;
-        const float t = e < J.n ? tuv[J.src_thr_off + e] : -f_inf();
-        const bool live = t != -f_inf();
-        const unsigned long long bal = __ballot(live);
-        if (lane == 0) wsum[wave] = __popcll(bal);
-        __syncthreads();
-        int k = running + __popcll(bal & ((1ull << lane) - 1ull));
-        for (int w = 0; w < wave; ++w) k += wsum[w];
-        if (live) {
-            live_idx[J.dst_row + k] = e;
-            row_pair[J.dst_row + k] = J.pair;
-            cmp_tu[J.dst_row + k] = t - J.src_nrm[e];  // sweep 2 folds (T - |a|^2)/2 into the MFMA
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) running += wsum[0] + wsum[1] + wsum[2] + wsum[3];
-        __syncthreads();
-    }
-    const int cnt = running;
-    // fp16 rows: 16 threads per row, one 16-byte data granule each (the compacted matrix only plays the A role:
-    // its 17th granule is never read)
-    for (int k = threadIdx.x >> 4; k < cnt; k += 16) {
-        const int r = live_idx[J.dst_row + k];
-        const int g = threadIdx.x & 15;
-        const long long d = J.dst_row + k;
-        *reinterpret_cast<h8*>(cmp_h + (size_t)d * kPfRowHalfs + g * 8) = *reinterpret_cast<const h8*>(J.src_h + (size_t)r * kPfRowHalfs + g * 8);
-    }
-    // the group's tail up to the next multiple of 512 is swept too: zero it (its rows count as dead, but an
-    // fp16 inf / NaN from stale memory must not reach the matrix core)
-    h8 z;
-    for (int j = 0; j < 8; ++j) z[j] = (_Float16)0.f;
-    for (long long d = J.dst_row + cnt + (threadIdx.x >> 4); d < J.zero_upto; d += 16)
-        *reinterpret_cast<h8*>(cmp_h + (size_t)d * kPfRowHalfs + (threadIdx.x & 15) * 8) = z;
-}
+#include "msfm_plan.hip.h"
 
 // finalize: the same outputs as merge_knn_kernel (idx0, d0, d1, tie queue)
 __global__ void pf_finalize_kernel(const PairDesc* __restrict__ pairs, const PfPair* __restrict__ pf,

@@ -90,7 +90,8 @@ __global__ __launch_bounds__(kPfThreads, 2) void sweep_kernel(
     const PairDesc* __restrict__ pairs, const PfPair* __restrict__ pf, const WorkItem* __restrict__ items,
     float* __restrict__ rp_s0, float* __restrict__ rp_s1, float* __restrict__ cp_s0, float* __restrict__ cp_s1,
     const float* __restrict__ tu, const float* __restrict__ tv, int2* __restrict__ cand,
-    unsigned long long* __restrict__ cand_count /* 64-bit: n1 * n2 hits of a flooded list do not fit 32 bits */) {
+    unsigned long long* __restrict__ cand_count /* 64-bit: n1 * n2 hits of a flooded list do not fit 32 bits */,
+    const int* __restrict__ n_items_dev /* item count in device memory (a plan built on the device), or null */, int n_items_host) {
     typedef const __attribute__((address_space(1))) float* gfloat_p;  // keep these loads off the FLAT path
     typedef const __attribute__((address_space(1))) h8* gh8_p;
     extern __shared__ __attribute__((aligned(16))) char pf_smem[];
@@ -99,10 +100,17 @@ __global__ __launch_bounds__(kPfThreads, 2) void sweep_kernel(
     char* sCand = reinterpret_cast<char*>(sThr + kPfWaves * kPfRing * 64);             // [wave][kPfCandBuf] int2 (PASS 2 / 3)
     float* sCol = reinterpret_cast<float*>(sCand + kPfWaves * kPfCandBuf * 8);         // [2 tiles][64 columns][4 classes] (PASS 1)
 
-    const WorkItem item = items[blockIdx.x];
-    if (item.pair < 0) return;
+    // Persistent workgroups: one per CU (the LDS ring allows no more), striding over the item list.  The list is
+    // XCD-interleaved (item i belongs to XCD i % 8) and the grid is a multiple of 8, so a workgroup keeps streaming the B
+    // panels its XCD's L2 already holds.
+    const int n_items = n_items_dev ? *n_items_dev : n_items_host;
+#pragma unroll 1
+    for (int it = blockIdx.x; it < n_items; it += gridDim.x) {
+    if (it != (int)blockIdx.x) lds_barrier();   // the previous item's last LDS accesses (column class arrays) are done
+    const WorkItem item = items[it];
+    if (item.pair < 0) continue;
     const PfPair pp = pf[item.pair];
-    if (!pp.use) return;
+    if (!pp.use) continue;
     const PairDesc pd = pairs[item.pair];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -483,4 +491,5 @@ __global__ __launch_bounds__(kPfThreads, 2) void sweep_kernel(
                 }
         }
     }
+    }   // item loop
 }
