@@ -147,9 +147,9 @@ struct msfm_ctx {
     // prefilter path
     int prefilter = 1;
     DevBuf d_pf, d_tu, d_tv, d_cand, d_cand_s, d_cand_count, d_best, d_second, d_maxima;
-    DevBuf d_cmp_h, d_cmp_tu, d_live_idx, d_row_pair, d_row_src, d_cand_pair, d_vpairs, d_vpf, d_vitems, d_lists;
+    DevBuf d_zero_row, d_cmp_tu, d_live_idx, d_row_pair, d_row_src, d_cand_pair, d_vpairs, d_vpf, d_vitems, d_lists;
     // device-side plan of the compacted sweep 2 (msfm_plan.hip.h)
-    DevBuf d_colmask, d_groups, d_gmembers, d_member_pair, d_ppair, d_cnt, d_fill, d_mrow, d_summary, d_overflow, d_totals;
+    DevBuf d_colmask, d_groups, d_gmembers, d_member_pair, d_ppair, d_cnt, d_mrow, d_summary, d_overflow, d_totals;
     long long cmp_rows_hint = 0;      // compacted rows the previous batch needed (sizes the next batch's buffers)
     struct PfPending {                // what the end-of-batch synchronisation has to look at
         bool active = false, compact = false;
@@ -496,7 +496,10 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
     HostClock hc;
     ctx->pf_pending = msfm_ctx::PfPending{};
     assign_partials(b, 1, 4 * ctx->cu_count);
-    const bool compact = prune.prune != 0;
+    // Sweep 2 on the compacted live rows, or on everything again?  Decided per batch, before any result exists: the Lowe
+    // test is what kills rows (~94 % at ratio 0.8 on SIFT-like data); with a ratio near or above 1 almost every row stays
+    // alive and the compacted sweep (both directions separately) would multiply up to twice what the dense one does.
+    const bool compact = prune.prune != 0 && prune.ratio > 0.f && prune.ratio <= 0.95f;
     long long dense_cand = 0;
     for (size_t p = 0; p < P; ++p) {
         b.pf[p].tu_off = b.pairs[p].kf_off;
@@ -573,14 +576,16 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
         HIPCHK(ctx, ctx->d_member_pair.ensure(std::max<size_t>(1, M) * 4));
         HIPCHK(ctx, ctx->d_ppair.ensure(P * sizeof(PlanPair)));
         HIPCHK(ctx, ctx->d_cnt.ensure(std::max<size_t>(1, M) * 4));
-        HIPCHK(ctx, ctx->d_fill.ensure(std::max<size_t>(1, M) * 4));
         HIPCHK(ctx, ctx->d_mrow.ensure(std::max<size_t>(1, M) * 8));
         HIPCHK(ctx, ctx->d_summary.ensure(sizeof(PlanSummary)));
         HIPCHK(ctx, ctx->d_vpairs.ensure(std::max<size_t>(1, G) * sizeof(PairDesc)));
         HIPCHK(ctx, ctx->d_vpf.ensure(std::max<size_t>(1, G) * sizeof(PfPair)));
         HIPCHK(ctx, ctx->d_lists.ensure(std::max<size_t>(1, G) * sizeof(CandList)));
         HIPCHK(ctx, ctx->d_vitems.ensure((size_t)items_cap * sizeof(WorkItem)));
-        HIPCHK(ctx, ctx->d_cmp_h.ensure((size_t)rows_cap * kPfRowBytes));
+        if (!ctx->d_zero_row.p) {
+            HIPCHK(ctx, ctx->d_zero_row.ensure(kPfRowBytes));
+            HIPCHK(ctx, hipMemsetAsync(ctx->d_zero_row.p, 0, kPfRowBytes, ctx->stream));
+        }
         HIPCHK(ctx, ctx->d_cmp_tu.ensure((size_t)rows_cap * 4));
         HIPCHK(ctx, ctx->d_live_idx.ensure((size_t)rows_cap * 4));
         HIPCHK(ctx, ctx->d_row_pair.ensure((size_t)rows_cap * 4));
@@ -597,7 +602,6 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
         HIPCHK(ctx, hipMemcpyAsync(ctx->d_ppair.p, cp.ppair.data(), P * sizeof(PlanPair), hipMemcpyHostToDevice, ctx->stream));
         // (the uploads above come from pageable vectors that die with this function: hipMemcpyAsync has staged them when it returns)
         HIPCHK(ctx, hipMemsetAsync(ctx->d_cnt.p, 0, std::max<size_t>(1, M) * 4, ctx->stream));
-        HIPCHK(ctx, hipMemsetAsync(ctx->d_fill.p, 0, std::max<size_t>(1, M) * 4, ctx->stream));
         HIPCHK(ctx, hipMemsetAsync(ctx->d_summary.p, 0, sizeof(PlanSummary), ctx->stream));
         HIPCHK(ctx, hipMemsetAsync(ctx->d_vitems.p, 0xff, (size_t)items_cap * sizeof(WorkItem), ctx->stream));
         HIPCHK(ctx, hipMemsetAsync(ctx->d_row_src.p, 0, (size_t)rows_cap * 8, ctx->stream));
@@ -615,7 +619,8 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
         po.items = ctx->d_vitems.as<WorkItem>();
         po.mrow = ctx->d_mrow.as<long long>();
         po.summary = ctx->d_summary.as<PlanSummary>();
-        po.cmp_h = ctx->d_cmp_h.as<_Float16>();
+        po.row_src = ctx->d_row_src.as<const _Float16*>();
+        po.zero_row = ctx->d_zero_row.as<_Float16>();
         po.live_idx = ctx->d_live_idx.as<int>();
         po.row_pair = ctx->d_row_pair.as<int>();
         po.rows_cap = rows_cap;
@@ -626,16 +631,11 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
         HIPCHK(ctx, hipGetLastError());
         DBGSYNC(ctx, "pf_plan_kernel");
         hipLaunchKernelGGL(pf_assign_kernel, dim3((unsigned)(2 * P)), dim3(256), 0, ctx->stream, dp, dpf, dpp, (const float*)tuv,
-                           (const unsigned*)colmask, (const long long*)ctx->d_mrow.as<long long>(), ctx->d_fill.as<int>(),
+                           (const unsigned*)colmask, (const long long*)ctx->d_mrow.as<long long>(),
                            ctx->d_live_idx.as<int>(), ctx->d_row_pair.as<int>(), ctx->d_cmp_tu.as<float>(),
                            ctx->d_row_src.as<const _Float16*>());
         HIPCHK(ctx, hipGetLastError());
         DBGSYNC(ctx, "pf_assign_kernel");
-        hipLaunchKernelGGL(pf_copy_rows_kernel, dim3((unsigned)(8 * ctx->cu_count)), dim3(256), 0, ctx->stream,
-                           (const PlanSummary*)ctx->d_summary.as<PlanSummary>(), (const _Float16* const*)ctx->d_row_src.as<const _Float16*>(),
-                           ctx->d_cmp_h.as<_Float16>());
-        HIPCHK(ctx, hipGetLastError());
-        DBGSYNC(ctx, "pf_copy_rows_kernel");
         HIPCHK(ctx, hipEventRecord(e2, ctx->stream));
         hipLaunchKernelGGL(sweep_kernel<3>, dim3(sweep_grid), block, kPfLdsBytes, ctx->stream,
                            (const PairDesc*)ctx->d_vpairs.as<PairDesc>(), (const PfPair*)ctx->d_vpf.as<PfPair>(),
@@ -977,7 +977,7 @@ void msfm_destroy(msfm_ctx* ctx) {
                       &ctx->d_st_qt, &ctx->d_st_d, &ctx->d_counts, &ctx->d_offsets, &ctx->d_out_qt,
                       &ctx->d_out_d, &ctx->d_fix_count, &ctx->d_fix_list, &ctx->d_pf, &ctx->d_tu, &ctx->d_tv,
                       &ctx->d_cand, &ctx->d_cand_s, &ctx->d_cand_count, &ctx->d_best, &ctx->d_second, &ctx->d_maxima,
-                      &ctx->d_cmp_h, &ctx->d_cmp_tu, &ctx->d_live_idx, &ctx->d_vpairs, &ctx->d_vpf, &ctx->d_row_src, &ctx->d_colmask, &ctx->d_groups, &ctx->d_gmembers, &ctx->d_member_pair, &ctx->d_ppair, &ctx->d_cnt, &ctx->d_fill, &ctx->d_mrow, &ctx->d_summary, &ctx->d_overflow, &ctx->d_totals,
+                      &ctx->d_zero_row, &ctx->d_cmp_tu, &ctx->d_live_idx, &ctx->d_vpairs, &ctx->d_vpf, &ctx->d_row_src, &ctx->d_colmask, &ctx->d_groups, &ctx->d_gmembers, &ctx->d_member_pair, &ctx->d_ppair, &ctx->d_cnt, &ctx->d_mrow, &ctx->d_summary, &ctx->d_overflow, &ctx->d_totals,
                       &ctx->d_vitems, &ctx->d_lists, &ctx->d_row_pair, &ctx->d_cand_pair, &ctx->d_vf_pairs, &ctx->d_vf_x1, &ctx->d_vf_y1,
                       &ctx->d_vf_x2, &ctx->d_vf_y2, &ctx->d_vf_hyp, &ctx->d_vf_best_it, &ctx->d_vf_best_count,
                       &ctx->d_vf_flags, &ctx->d_st2_qt, &ctx->d_st2_d, &ctx->d_counts2};

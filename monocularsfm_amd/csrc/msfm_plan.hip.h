@@ -17,8 +17,8 @@
 //   pf_count_kernel    live rows per member                                          grid = 2 x pairs
 //   pf_plan_kernel     prefix sums -> row ranges of members and groups (512-aligned), the groups' sweep descriptors
 //                      (PairDesc / PfPair / CandList), the work-item list, capacity check   one workgroup
-//   pf_assign_kernel   every live row gets its slot(s): index, pair, threshold, source row   grid = 2 x pairs
-//   pf_copy_rows_kernel compacted fp16 operand rows (zero rows where no source: group tails)  grid-stride
+//   pf_assign_kernel   every live row gets its slot(s): index, pair, threshold, address of its operand row (the sweep
+//                      reads its A fragments through that table: no compacted copy of the rows)   grid = 2 x pairs
 //
 // and the sweep kernels take the number of work items from device memory.  Buffers are sized from a prediction (the
 // previous call's need, or a fraction of the row total); if the plan does not fit, it marks itself invalid, everything
@@ -96,7 +96,8 @@ struct PlanOut {
     WorkItem* items;          // [items_cap], pre-filled with pair = -1
     long long* mrow;          // [n_members] first compact row of the member
     PlanSummary* summary;
-    _Float16* cmp_h;          // compacted operand rows
+    const _Float16* const* row_src;  // per compact row: its operand row (filled by pf_assign_kernel)
+    const _Float16* zero_row;        // 272 zero bytes
     int* live_idx;            // per compact row: row index in its image
     int* row_pair;            // per compact row: pair of the batch
     long long rows_cap, cand_cap, items_cap;
@@ -189,7 +190,8 @@ __global__ __launch_bounds__(1024) void pf_plan_kernel(const PlanGroup* __restri
                 vd.ranges = G.ranges;
                 out.vpairs[g] = vd;
                 PfPair vp = {};
-                vp.a_h = out.cmp_h + (size_t)row0 * kPfRowHalfs;
+                vp.a_h = out.zero_row;
+                vp.a_rows = out.row_src + row0;
                 vp.b_h = G.b_h;
                 vp.b_nrm = G.b_nrm;
                 vp.b_c = G.b_c;
@@ -240,11 +242,12 @@ __global__ __launch_bounds__(1024) void pf_plan_kernel(const PlanGroup* __restri
     }
 }
 
-// every live row takes its slot(s) in the compacted matrices: index, pair, threshold (sweep 2 folds (T - |a|^2)/2 into
-// the MFMA), and where its fp16 operand row comes from
+// every live row takes its slot(s) in the compacted row set: index, pair, threshold (sweep 2 folds (T - |a|^2)/2 into
+// the MFMA), and the address of its fp16 operand row.  Every member is filled by exactly one workgroup (the forward
+// member by (pair, 0), the reverse members by (pair, 1)), so the fill cursors live in LDS.
 __global__ void pf_assign_kernel(const PairDesc* __restrict__ pairs, const PfPair* __restrict__ pf, const PlanPair* __restrict__ pp_plan,
                                  const float* __restrict__ tuv, const unsigned* __restrict__ colmask, const long long* __restrict__ mrow,
-                                 int* __restrict__ fill, int* __restrict__ live_idx, int* __restrict__ row_pair, float* __restrict__ cmp_tu,
+                                 int* __restrict__ live_idx, int* __restrict__ row_pair, float* __restrict__ cmp_tu,
                                  const _Float16** __restrict__ row_src) {
     const int p = blockIdx.x >> 1, dir = blockIdx.x & 1;
     const PlanPair pl = pp_plan[p];
@@ -255,6 +258,14 @@ __global__ void pf_assign_kernel(const PairDesc* __restrict__ pairs, const PfPai
     const long long off = dir ? pp.tv_off : pp.tu_off;
     const float* nrm = dir ? pp.b_nrm : pp.a_nrm;
     const _Float16* src = dir ? pp.b_h : pp.a_h;
+    __shared__ int cursor[32];
+    __shared__ long long base[32];
+    if (threadIdx.x < 32) {
+        cursor[threadIdx.x] = 0;
+        const int bits = dir ? pl.rev_bits : 1;
+        base[threadIdx.x] = (int)threadIdx.x < bits ? mrow[(dir ? pl.rev_member0 : pl.fwd_member) + threadIdx.x] : -1;
+    }
+    __syncthreads();
     for (int e = threadIdx.x; e < n; e += blockDim.x) {
         const float t = tuv[off + e];
         if (t == -f_inf()) continue;
@@ -262,31 +273,14 @@ __global__ void pf_assign_kernel(const PairDesc* __restrict__ pairs, const PfPai
         while (m) {
             const int b = __builtin_ctz(m);
             m &= m - 1;
-            const int mem = dir ? pl.rev_member0 + b : pl.fwd_member;
-            const long long r0 = mrow[mem];
+            const long long r0 = base[b];
             if (r0 < 0) continue;   // invalid plan
-            const long long k = r0 + atomicAdd(&fill[mem], 1);
+            const long long k = r0 + atomicAdd(&cursor[b], 1);
             live_idx[k] = e;
             row_pair[k] = p;
             cmp_tu[k] = t - nrm[e];
             row_src[k] = src + (size_t)e * kPfRowHalfs;
         }
-    }
-}
-
-// compacted operand rows: 16 threads per row, one 16-byte data granule each; rows without a source (the tails of the
-// groups up to the next multiple of 512, swept too) are zero: an fp16 inf / NaN from stale memory must not reach the
-// matrix core.  The compacted matrix only plays the A role: its 17th granule is never read.
-__global__ void pf_copy_rows_kernel(const PlanSummary* __restrict__ summary, const _Float16* const* __restrict__ row_src,
-                                    _Float16* __restrict__ cmp_h) {
-    const PlanSummary sm = *summary;
-    if (!sm.ok) return;
-    const int g = threadIdx.x & 15;
-    h8 z;
-    for (int j = 0; j < 8; ++j) z[j] = (_Float16)0.f;
-    for (long long k = (long long)blockIdx.x * (blockDim.x >> 4) + (threadIdx.x >> 4); k < sm.cmp_rows; k += (long long)gridDim.x * (blockDim.x >> 4)) {
-        const _Float16* s = row_src[k];
-        *reinterpret_cast<h8*>(cmp_h + (size_t)k * kPfRowHalfs + g * 8) = s ? *reinterpret_cast<const h8*>(s + g * 8) : z;
     }
 }
 

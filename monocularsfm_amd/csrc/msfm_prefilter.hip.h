@@ -79,8 +79,9 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef float f16v __attribute__((ext_vector_type(16)));
 
 struct PfPair {            // per-pair extras of the prefilter path (parallel to PairDesc)
-    const _Float16* a_h;   // fp16 operand rows [npad][136 halfs] (quadruple in the 17th granule)
+    const _Float16* a_h;   // fp16 operand rows [npad][136 halfs] (quadruple in the 17th granule); compacted sweep: a zero row
     const _Float16* b_h;
+    const _Float16* const* a_rows;  // compacted sweep only: per compacted row the address of its operand row (null: none)
     const float* a_nrm;    // |row|^2, +inf on padding rows
     const float* b_nrm;
     float a_c, b_c;        // the images' scales c (powers of two)

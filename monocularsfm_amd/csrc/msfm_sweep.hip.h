@@ -163,7 +163,14 @@ __global__ __launch_bounds__(kPfThreads, 2) void sweep_kernel(
 #pragma unroll
     for (int rb = 0; rb < kPfRB; ++rb) {
         const int frow = item.a_blk * kPfWgRows + wave * kPfWaveRows + rb * 32 + lcol;
-        const gh8_p ga = (gh8_p)(pp.a_h + (size_t)frow * kPfRowHalfs);   // 272-byte rows: 17 aligned granules
+        // 272-byte rows: 17 aligned granules.  Compacted sweep: the A rows are live rows of many images, named by a
+        // pointer table (a row without a source -- the tail of a group -- reads the image-independent zero row)
+        const _Float16* arow = pp.a_h + (size_t)frow * kPfRowHalfs;
+        if (PASS == 3) {
+            const _Float16* r = pp.a_rows[frow];
+            arow = r ? r : pp.a_h;
+        }
+        const gh8_p ga = (gh8_p)arow;
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) af[rb][ks] = ga[2 * ks + lhalf];
         // padding rows: X = -inf -> accumulator -inf, never a maximum, never a hit
@@ -224,7 +231,6 @@ __global__ __launch_bounds__(kPfThreads, 2) void sweep_kernel(
 
     const bool wave_active = item.a_blk * kPfWgRows + wave * kPfWaveRows < pd.n1;  // wave-uniform
 
-    struct BlockMeta { float hc; int col; };  // hc: PASS 2 column hit level -T_col/2
     // B fragments of the tile in ring slot sl: the 8 data k-steps of column block 0 (row lcol of the slot, granule
     // 2 ks + lhalf: a constant offset from the lane's row address), and the ninth k-step of BOTH column blocks -- the first
     // 8 bytes of the row's 17th granule ([h_hi, h_lo, c, c] = k 128..131) in the lhalf == 0 lanes, its zero half
@@ -329,10 +335,42 @@ __global__ __launch_bounds__(kPfThreads, 2) void sweep_kernel(
         }
         return kPfRB == 2 ? fmaxf(m[0], m[1]) : m[0];
     };
-    // sweep 2: "this lane saw a hit" in one column block
-    auto any_hit = [&](const f16v (&acc)[kPfRB], const BlockMeta& bm) -> bool {
-        if (PASS == 3) return column_max(acc) >= 0.f;
-        // row criterion: max over (acc - level_row) >= 0; column criterion: max over acc >= level_col
+    // ---- sweep 2: recording hits ---------------------------------------------------------------------------------
+    // A hit goes, slotted with ballot / popcount, into this wave's LDS buffer -- no atomics in the loop -- and the buffer
+    // is flushed to the list in HBM when it fills up.  (Inline asm store: hipcc would drain vmcnt(0) for an LDS store
+    // it can see.)
+    auto record_hits = [&](bool hit, int row, int col) {
+        const unsigned long long mm = __ballot(hit);
+        if (mm == 0ull) return;
+        if (n_buf + 64 > kPfCandBuf) flush_candidates();
+        if (hit) {
+            const int slt = n_buf + __popcll(mm & ((1ull << lane) - 1ull));
+            const int2 e = make_int2(row, col);
+            asm volatile("ds_write_b64 %0, %1" ::"v"(cbuf_lds + slt * 8), "v"(e) : "memory");
+        }
+        n_buf += __popcll(mm);
+    };
+    // Compacted sweep (PASS 3): a hit is accumulator >= 0.  With every A row alive a 64 x 32 block holds about one hit,
+    // so "no hit in the block" is not the common case; what is rare is a hit in a given group of 4 result registers.
+    // Per column block: the maxima of the 8 register quads (12 ops per 16 elements), one ballot per quad, and only a
+    // quad that holds a hit somewhere in the wave has its 4 elements tested.
+    auto scan_hits3 = [&](const f16v (&acc)[kPfRB], int col) {
+#pragma unroll
+        for (int rb = 0; rb < kPfRB; ++rb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float m = fmaxf(max3f(acc[rb][4 * q], acc[rb][4 * q + 1], acc[rb][4 * q + 2]), acc[rb][4 * q + 3]);
+                if (__ballot(m >= 0.f) == 0ull) continue;   // wave-uniform
+#pragma unroll
+                for (int r = 4 * q; r < 4 * q + 4; ++r)
+                    record_hits(acc[rb][r] >= 0.f, arow_base + rb * 32 + (r & 3) + 8 * (r >> 2), col);
+            }
+    };
+    // Dense sweep (PASS 2, the kNN-level API): row criterion acc >= level_row, column criterion acc >= level_col; a block
+    // is first reduced to "any hit?" with v_max3, then every element is tested.  Padding rows / columns hold -inf: with
+    // an infinite threshold (fewer than two real elements in a subset) the hit level is -inf as well, and -inf >= -inf
+    // must not count.
+    auto scan_hits2 = [&](const f16v (&acc)[kPfRB], float hc, int col) {
         float mr = -f_inf(), mc = -f_inf();
 #pragma unroll
         for (int rb = 0; rb < kPfRB; ++rb)
@@ -341,39 +379,13 @@ __global__ __launch_bounds__(kPfThreads, 2) void sweep_kernel(
                 mr = max3f(mr, acc[rb][r] - rs0[rb][r], acc[rb][r + 1] - rs0[rb][r + 1]);
                 mc = max3f(mc, acc[rb][r], acc[rb][r + 1]);
             }
-        return mr >= 0.f || mc >= bm.hc;
-    };
-    // sweep 2, rare path: the block holds at least one hit -> bit mask per lane (element k = rb*16 + r at bit 31-k),
-    // slotted with ballot/popcount into this wave's LDS buffer -- no atomics in the loop -- and flushed to the
-    // pair's global list when the buffer fills up
-    auto append_hits = [&](bool any, const f16v (&acc)[kPfRB], const BlockMeta& bm) {
-        if (__ballot(any) == 0ull) return;
-        unsigned long long mask = 0;   // element k = rb*16 + r at bit (16 kPfRB - 1 - k)
-        constexpr int kEl = 16 * kPfRB;
+        if (__ballot(mr >= 0.f || mc >= hc) == 0ull) return;
 #pragma unroll
         for (int rb = 0; rb < kPfRB; ++rb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                // padding rows / columns hold -inf: with an infinite threshold (fewer than two real elements in
-                // a subset) the hit level is -inf as well, and -inf >= -inf must not count
-                const bool hit = (PASS == 3) ? (acc[rb][r] >= 0.f)
-                                             : (acc[rb][r] > -f_inf() && (acc[rb][r] >= rs0[rb][r] || acc[rb][r] >= bm.hc));
-                mask = mask + mask + (hit ? 1ull : 0ull);
-            }
-        while (__ballot(mask != 0ull) != 0ull) {
-            const bool hit = mask != 0ull;
-            const int k = __clzll((long long)mask) - (64 - kEl);  // first remaining element of this lane
-            const unsigned long long mm = __ballot(hit);
-            if (n_buf + 64 > kPfCandBuf) flush_candidates();
-            if (hit) {
-                mask &= ~(1ull << (kEl - 1 - k));
-                const int slt = n_buf + __popcll(mm & ((1ull << lane) - 1ull));
-                // inline asm on purpose: hipcc would first drain vmcnt(0) for a compiler-visible LDS store
-                const int2 e = make_int2(arow_base + (k >> 4) * 32 + (k & 3) + 8 * ((k & 15) >> 2), bm.col);
-                asm volatile("ds_write_b64 %0, %1" ::"v"(cbuf_lds + slt * 8), "v"(e) : "memory");
-            }
-            n_buf += __popcll(mm);
-        }
+            for (int r = 0; r < 16; ++r)
+                record_hits(acc[rb][r] > -f_inf() && (acc[rb][r] >= rs0[rb][r] || acc[rb][r] >= hc),
+                            arow_base + rb * 32 + (r & 3) + 8 * (r >> 2), col);
     };
     // sweep 1, columns.  Lane l holds the maximum of column l & 31 over the 32 rows of its lane half, per column block.
     // It goes, with one LDS atomic per column block, into the tile's class array [4 classes][64 columns], class =
@@ -445,14 +457,13 @@ __global__ __launch_bounds__(kPfThreads, 2) void sweep_kernel(
                 for (int rb = 0; rb < kPfRB; ++rb)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) rs0[rb][r] = max3f(rs0[rb][r], accA[rb][r], accB[rb][r]);
+            } else if (PASS == 3) {
+                scan_hits3(accA, t * kPfBT + lcol);
+                scan_hits3(accB, t * kPfBT + 32 + lcol);
             } else {
-                const float* thr = thr_w + sl * 64;
-                const BlockMeta metaA = {(PASS == 2) ? -0.5f * thr[lcol] : 0.f, t * kPfBT + lcol};
-                const BlockMeta metaB = {(PASS == 2) ? -0.5f * thr[32 + lcol] : 0.f, t * kPfBT + 32 + lcol};
-                const bool anyA = any_hit(accA, metaA);
-                const bool anyB = any_hit(accB, metaB);
-                append_hits(anyA, accA, metaA);
-                append_hits(anyB, accB, metaB);
+                const float* thr = thr_w + sl * 64;   // column hit levels -T_col / 2
+                scan_hits2(accA, -0.5f * thr[lcol], t * kPfBT + lcol);
+                scan_hits2(accB, -0.5f * thr[32 + lcol], t * kPfBT + 32 + lcol);
             }
         }
         if (kPreRead && wave_active && t + 1 < t_end) load_bf((sl + 1) & (kPfRing - 1), bf, be);   // the next MFMA phase starts on registers
