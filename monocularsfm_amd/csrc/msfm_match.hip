@@ -151,6 +151,7 @@ struct msfm_ctx {
     // device-side plan of the compacted sweep 2 (msfm_plan.hip.h)
     DevBuf d_colmask, d_groups, d_gmembers, d_member_pair, d_ppair, d_cnt, d_mrow, d_summary, d_overflow, d_totals;
     long long cmp_rows_hint = 0;      // compacted rows the previous batch needed (sizes the next batch's buffers)
+    long long items_hint = 0, cand_hint = 0;   // likewise: work items, candidate-list capacity
     struct PfPending {                // what the end-of-batch synchronisation has to look at
         bool active = false, compact = false;
         size_t n_lists = 0, P = 0;
@@ -569,8 +570,9 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
         for (const PlanGroup& g : cp.groups) max_ranges = std::max<long long>(max_ranges, g.ranges);
         const long long slack = (long long)kPfWgRows * (long long)G + kPfWgRows;
         const long long rows_cap = std::max<long long>(ctx->cmp_rows_hint + ctx->cmp_rows_hint / 2, cp.rows_ub / 4) + slack;
-        const long long cand_cap = 8 * rows_cap + 1024LL * (long long)G;
-        const long long items_cap = ((rows_cap / kPfWgRows + (long long)G) * max_ranges + 15) / 8 * 8;
+        const long long cand_cap = std::max<long long>(8 * rows_cap + 1024LL * (long long)G, ctx->cand_hint);
+        // (the list holds 8 x the longest per-XCD sub-list: twice the balanced size leaves room for skew)
+        const long long items_cap = std::max<long long>(2 * ((rows_cap / kPfWgRows + (long long)G) * max_ranges + 64) / 8 * 8, (ctx->items_hint + 64) / 8 * 8);
         HIPCHK(ctx, ctx->d_groups.ensure(std::max<size_t>(1, G) * sizeof(PlanGroup)));
         HIPCHK(ctx, ctx->d_gmembers.ensure(std::max<size_t>(1, M) * 4));
         HIPCHK(ctx, ctx->d_member_pair.ensure(std::max<size_t>(1, M) * 4));
@@ -750,6 +752,8 @@ int finish_prefilter(msfm_ctx* ctx, Batch& b, std::vector<char>& force_exact, bo
     if (pe.compact) {
         std::memcpy(&sm, hs, sizeof(PlanSummary));
         ctx->cmp_rows_hint = sm.cmp_rows;
+        ctx->items_hint = sm.items_needed;
+        ctx->cand_hint = sm.cand_elems;
         if (!sm.ok) {   // the prediction was too small: the buffers are sized from the need now
             ctx->prof.plan_regrows += 1;
             *retry = true;

@@ -128,31 +128,40 @@ __device__ __forceinline__ long long plan_block_exclusive_scan(long long v, long
 __global__ __launch_bounds__(1024) void pf_plan_kernel(const PlanGroup* __restrict__ groups, int n_groups,
                                                          const int* __restrict__ gmembers, const int* __restrict__ cnt, PlanOut out) {
     const int tid = threadIdx.x, nt = blockDim.x;
-    __shared__ long long s_base_rows, s_base_items, s_base_cand;
+    __shared__ long long s_base_rows, s_base_cand, s_base_items[8];
     __shared__ int s_ok;
-    if (tid == 0) { s_base_rows = 0; s_base_items = 0; s_base_cand = 0; s_ok = 1; }
+    if (tid == 0) { s_base_rows = 0; s_base_cand = 0; s_ok = 1; }
+    if (tid < 8) s_base_items[tid] = 0;
     __syncthreads();
-    // pass 1: totals (does the plan fit?)   pass 2: write it
-    long long tot_rows = 0, tot_items = 0, tot_cand = 0, tot_swept = 0;
+    // Work items: all items of a group go to XCD (group & 7) -- they stream the same image through that XCD's L2 -- and
+    // item j of XCD x sits at list position 8 j + x (workgroup b runs on XCD b % 8 and strides over the list by a
+    // multiple of 8).  Groups alternate between long forward sweeps and short reverse ones in creation order, so the
+    // residue classes carry comparable work; a contiguous chunk of the list per XCD (as for the uniform sweep-1 items)
+    // would give some XCDs all the long items.
+    // pass 0: totals (does the plan fit?)   pass 1: write it
+    long long tot_rows = 0, tot_cand = 0, tot_swept = 0, tot_items_x[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long n_items = 0;
     for (int pass = 0; pass < 2; ++pass) {
         if (pass == 1) {
+            for (int x = 0; x < 8; ++x) n_items = tot_items_x[x] > n_items ? tot_items_x[x] : n_items;
+            n_items *= 8;
             __syncthreads();
             if (tid == 0) {
-                s_ok = (tot_rows <= out.rows_cap && tot_cand <= out.cand_cap && ((tot_items + 7) / 8) * 8 <= out.items_cap) ? 1 : 0;
-                s_base_rows = s_base_items = s_base_cand = 0;
+                s_ok = (tot_rows <= out.rows_cap && tot_cand <= out.cand_cap && n_items <= out.items_cap) ? 1 : 0;
+                s_base_rows = s_base_cand = 0;
                 PlanSummary sm;
                 sm.ok = s_ok;
-                sm.n_items = s_ok ? (int)(((tot_items + 7) / 8) * 8) : 0;
+                sm.n_items = s_ok ? (int)n_items : 0;
                 sm.cmp_rows = tot_rows;
                 sm.cand_elems = tot_cand;
-                sm.items_needed = ((tot_items + 7) / 8) * 8;
+                sm.items_needed = n_items;
                 sm.swept_desc_pairs = tot_swept;
                 *out.summary = sm;
             }
+            if (tid < 8) s_base_items[tid] = 0;
             __syncthreads();
         }
         const int ok = s_ok;
-        const long long per = (tot_items + 7) / 8;   // XCD interleave of the item list: position (k % per) * 8 + k / per
         for (int g0 = 0; g0 < n_groups; g0 += nt) {
             const int g = g0 + tid;
             long long rows = 0;
@@ -165,14 +174,17 @@ __global__ __launch_bounds__(1024) void pf_plan_kernel(const PlanGroup* __restri
             const long long ablocks = rows512 / kPfWgRows;
             const long long items = ablocks * (g < n_groups ? G.ranges : 0);
             const long long cap = rows > 0 ? (8 * rows + 1024 < (1LL << 30) ? 8 * rows + 1024 : (1LL << 30)) : 0;
-            long long tr, ti, tc;
+            long long tr, tc, ti[8], item0 = 0;
             const long long row0 = s_base_rows + plan_block_exclusive_scan(rows512, &tr);
-            const long long item0 = s_base_items + plan_block_exclusive_scan(items, &ti);
             const long long cand0 = s_base_cand + plan_block_exclusive_scan(cap, &tc);
+            for (int x = 0; x < 8; ++x) {
+                const long long l = plan_block_exclusive_scan((g & 7) == x ? items : 0, &ti[x]);
+                if ((g & 7) == x) item0 = s_base_items[x] + l;
+            }
             if (pass == 0) {
                 tot_rows += tr;
-                tot_items += ti;
                 tot_cand += tc;
+                for (int x = 0; x < 8; ++x) tot_items_x[x] += ti[x];
                 long long swept = (g < n_groups) ? rows512 * (long long)min(G.n2 - min(G.n2, G.bt_begin * kBN), (G.bt_end - G.bt_begin) * kBN) : 0, ts;
                 (void)plan_block_exclusive_scan(swept, &ts);
                 tot_swept += ts;
@@ -227,16 +239,16 @@ __global__ __launch_bounds__(1024) void pf_plan_kernel(const PlanGroup* __restri
                             w.bt_begin = t0;
                             w.bt_end = t1;
                             w.range = rg;
-                            out.items[(k % per) * 8 + k / per] = w;
+                            out.items[k * 8 + (g & 7)] = w;
                         }
                     }
                 }
             }
             if (tid == 0) {
                 s_base_rows += tr;
-                s_base_items += ti;
                 s_base_cand += tc;
             }
+            if (tid < 8) s_base_items[tid] += ti[tid];
             __syncthreads();
         }
     }
