@@ -531,6 +531,9 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
     if (rc != MSFM_OK) return rc;
     HIPCHK(ctx, hipMemsetAsync(ctx->d_best.p, 0xff, kn * 8, ctx->stream));
     HIPCHK(ctx, hipMemsetAsync(ctx->d_second.p, 0xff, kn * 8, ctx->stream));
+    HIPCHK(ctx, ctx->d_overflow.ensure(P));
+    HIPCHK(ctx, ctx->d_totals.ensure(64));   // [0..1] candidate / overflow totals (64-bit), ints [8..15]: per-XCD item cursors of sweep 2
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_totals.p, 0, 64, ctx->stream));
 
     hipEvent_t e0 = get_event(ctx, ev_base), e1 = get_event(ctx, ev_base + 1);
     hipEvent_t e2 = get_event(ctx, ev_base + 2), e3 = get_event(ctx, ev_base + 3);
@@ -546,7 +549,7 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
     hipLaunchKernelGGL(sweep_kernel<1>, dim3(std::min<unsigned>(sweep_grid, (unsigned)b.items.size())), block, kPfLdsBytes, ctx->stream, dp, dpf,
                        ctx->d_items.as<WorkItem>(), ctx->d_rp_s0.as<float>(), ctx->d_rp_s1.as<float>(),
                        ctx->d_cp_s0.as<float>(), (float*)nullptr, (const float*)nullptr, (const float*)nullptr,
-                       (int2*)nullptr, (unsigned long long*)nullptr, (const int*)nullptr, (int)b.items.size());
+                       (int2*)nullptr, (unsigned long long*)nullptr, (const int*)nullptr, (int)b.items.size(), (int*)nullptr);
     HIPCHK(ctx, hipGetLastError());
     DBGSYNC(ctx, "sweep_kernel<1>");
     HIPCHK(ctx, hipEventRecord(e1, ctx->stream));
@@ -643,7 +646,8 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
                            (const PairDesc*)ctx->d_vpairs.as<PairDesc>(), (const PfPair*)ctx->d_vpf.as<PfPair>(),
                            (const WorkItem*)ctx->d_vitems.as<WorkItem>(), (float*)nullptr, (float*)nullptr, (float*)nullptr,
                            (float*)nullptr, (const float*)ctx->d_cmp_tu.as<float>(), (const float*)nullptr, ctx->d_cand.as<int2>(),
-                           ctx->d_cand_count.as<unsigned long long>(), (const int*)&ctx->d_summary.as<PlanSummary>()->n_items, 0);
+                           ctx->d_cand_count.as<unsigned long long>(), (const int*)&ctx->d_summary.as<PlanSummary>()->n_items, 0,
+                           ctx->d_totals.as<int>() + 8);
         HIPCHK(ctx, hipGetLastError());
         DBGSYNC(ctx, "sweep_kernel<3>");
         ctx->prof.sweep2_launches += 1;
@@ -672,7 +676,7 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
         hipLaunchKernelGGL(sweep_kernel<2>, dim3(std::min<unsigned>(sweep_grid, (unsigned)b.items.size())), block, kPfLdsBytes, ctx->stream, dp, dpf,
                            ctx->d_items.as<WorkItem>(), (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr,
                            (const float*)tuv, (const float*)tuv, ctx->d_cand.as<int2>(), ctx->d_cand_count.as<unsigned long long>(),
-                           (const int*)nullptr, (int)b.items.size());
+                           (const int*)nullptr, (int)b.items.size(), (int*)nullptr);
         HIPCHK(ctx, hipGetLastError());
         DBGSYNC(ctx, "sweep_kernel<2>");
         ctx->prof.sweep2_launches += 1;
@@ -709,10 +713,7 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
     HIPCHK(ctx, hipGetLastError());
     DBGSYNC(ctx, "pf_finalize_kernel");
     // which pairs own an overflowed list, how many candidates were evaluated: read at the end of the batch
-    HIPCHK(ctx, ctx->d_overflow.ensure(P));
-    HIPCHK(ctx, ctx->d_totals.ensure(16));
     HIPCHK(ctx, hipMemsetAsync(ctx->d_overflow.p, 0, P, ctx->stream));
-    HIPCHK(ctx, hipMemsetAsync(ctx->d_totals.p, 0, 16, ctx->stream));
     if (n_lists > 0) {
         hipLaunchKernelGGL(pf_overflow_kernel, dim3((unsigned)((n_lists + 255) / 256)), dim3(256), 0, ctx->stream, dl, (int)n_lists,
                            (const unsigned long long*)ctx->d_cand_count.as<unsigned long long>(), (const PlanGroup*)ctx->d_groups.as<PlanGroup>(),

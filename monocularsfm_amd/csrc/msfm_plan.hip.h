@@ -128,7 +128,7 @@ __device__ __forceinline__ long long plan_block_exclusive_scan(long long v, long
 __global__ __launch_bounds__(1024) void pf_plan_kernel(const PlanGroup* __restrict__ groups, int n_groups,
                                                          const int* __restrict__ gmembers, const int* __restrict__ cnt, PlanOut out) {
     const int tid = threadIdx.x, nt = blockDim.x;
-    __shared__ long long s_base_rows, s_base_cand, s_base_items[8];
+    __shared__ long long s_base_rows, s_base_cand, s_base_items[8], s_base_rev[8];
     __shared__ int s_ok;
     if (tid == 0) { s_base_rows = 0; s_base_cand = 0; s_ok = 1; }
     if (tid < 8) s_base_items[tid] = 0;
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(1024) void pf_plan_kernel(const PlanGroup* __restri
     // residue classes carry comparable work; a contiguous chunk of the list per XCD (as for the uniform sweep-1 items)
     // would give some XCDs all the long items.
     // pass 0: totals (does the plan fit?)   pass 1: write it
-    long long tot_rows = 0, tot_cand = 0, tot_swept = 0, tot_items_x[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long tot_rows = 0, tot_cand = 0, tot_swept = 0, tot_items_x[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tot_fwd_x[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     long long n_items = 0;
     for (int pass = 0; pass < 2; ++pass) {
         if (pass == 1) {
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(1024) void pf_plan_kernel(const PlanGroup* __restri
                 sm.swept_desc_pairs = tot_swept;
                 *out.summary = sm;
             }
-            if (tid < 8) s_base_items[tid] = 0;
+            if (tid < 8) { s_base_items[tid] = 0; s_base_rev[tid] = tot_fwd_x[tid]; }   // reverse items behind all forward ones
             __syncthreads();
         }
         const int ok = s_ok;
@@ -174,17 +174,22 @@ __global__ __launch_bounds__(1024) void pf_plan_kernel(const PlanGroup* __restri
             const long long ablocks = rows512 / kPfWgRows;
             const long long items = ablocks * (g < n_groups ? G.ranges : 0);
             const long long cap = rows > 0 ? (8 * rows + 1024 < (1LL << 30) ? 8 * rows + 1024 : (1LL << 30)) : 0;
-            long long tr, tc, ti[8], item0 = 0;
+            long long tr, tc, ti[8], ti_rev[8], item0 = 0;
             const long long row0 = s_base_rows + plan_block_exclusive_scan(rows512, &tr);
             const long long cand0 = s_base_cand + plan_block_exclusive_scan(cap, &tc);
+            // (forward groups -- the long sweeps -- come first in every XCD's list: they are fetched first)
             for (int x = 0; x < 8; ++x) {
-                const long long l = plan_block_exclusive_scan((g & 7) == x ? items : 0, &ti[x]);
-                if ((g & 7) == x) item0 = s_base_items[x] + l;
+                long long tf, tb;
+                const long long lf = plan_block_exclusive_scan(((g & 7) == x && G.dir == 0) ? items : 0, &tf);
+                const long long lb = plan_block_exclusive_scan(((g & 7) == x && G.dir == 1) ? items : 0, &tb);
+                ti[x] = tf;          // forward items of this stride
+                ti_rev[x] = tb;
+                if ((g & 7) == x) item0 = G.dir == 0 ? s_base_items[x] + lf : s_base_rev[x] + lb;
             }
             if (pass == 0) {
                 tot_rows += tr;
                 tot_cand += tc;
-                for (int x = 0; x < 8; ++x) tot_items_x[x] += ti[x];
+                for (int x = 0; x < 8; ++x) { tot_items_x[x] += ti[x] + ti_rev[x]; tot_fwd_x[x] += ti[x]; }
                 long long swept = (g < n_groups) ? rows512 * (long long)min(G.n2 - min(G.n2, G.bt_begin * kBN), (G.bt_end - G.bt_begin) * kBN) : 0, ts;
                 (void)plan_block_exclusive_scan(swept, &ts);
                 tot_swept += ts;
@@ -248,7 +253,7 @@ __global__ __launch_bounds__(1024) void pf_plan_kernel(const PlanGroup* __restri
                 s_base_rows += tr;
                 s_base_cand += tc;
             }
-            if (tid < 8) s_base_items[tid] += ti[tid];
+            if (tid < 8) { s_base_items[tid] += ti[tid]; s_base_rev[tid] += ti_rev[tid]; }
             __syncthreads();
         }
     }

@@ -91,7 +91,8 @@ __global__ __launch_bounds__(kPfThreads, 2) void sweep_kernel(
     float* __restrict__ rp_s0, float* __restrict__ rp_s1, float* __restrict__ cp_s0, float* __restrict__ cp_s1,
     const float* __restrict__ tu, const float* __restrict__ tv, int2* __restrict__ cand,
     unsigned long long* __restrict__ cand_count /* 64-bit: n1 * n2 hits of a flooded list do not fit 32 bits */,
-    const int* __restrict__ n_items_dev /* item count in device memory (a plan built on the device), or null */, int n_items_host) {
+    const int* __restrict__ n_items_dev /* item count in device memory (a plan built on the device), or null */, int n_items_host,
+    int* __restrict__ dyn_next /* 8 per-XCD cursors: items are fetched dynamically (sweep 2: unequal items), or null */) {
     typedef const __attribute__((address_space(1))) float* gfloat_p;  // keep these loads off the FLAT path
     typedef const __attribute__((address_space(1))) h8* gh8_p;
     extern __shared__ __attribute__((aligned(16))) char pf_smem[];
@@ -103,10 +104,21 @@ __global__ __launch_bounds__(kPfThreads, 2) void sweep_kernel(
     // Persistent workgroups: one per CU (the LDS ring allows no more), striding over the item list.  The list is
     // XCD-interleaved (item i belongs to XCD i % 8) and the grid is a multiple of 8, so a workgroup keeps streaming the B
     // panels its XCD's L2 already holds.
+    // Uniform items (sweep 1) are taken in a fixed stride; the unequal items of the compacted sweep 2 (79-tile forward
+    // sweeps next to 8-tile reverse ones) are fetched from a per-XCD cursor, longest first.
     const int n_items = n_items_dev ? *n_items_dev : n_items_host;
+    __shared__ int s_next_item;
+    bool first_item = true;
 #pragma unroll 1
-    for (int it = blockIdx.x; it < n_items; it += gridDim.x) {
-    if (it != (int)blockIdx.x) lds_barrier();   // the previous item's last LDS accesses (column class arrays) are done
+    for (int it = blockIdx.x;; it += gridDim.x) {
+    if (!first_item || dyn_next) lds_barrier();   // the previous item's last LDS accesses (class arrays, the cursor) are done
+    first_item = false;
+    if (dyn_next) {
+        if (threadIdx.x == 0) s_next_item = atomicAdd(&dyn_next[blockIdx.x & 7], 1);
+        lds_barrier();
+        it = s_next_item * 8 + (int)(blockIdx.x & 7);
+    }
+    if (it >= n_items) break;
     const WorkItem item = items[it];
     if (item.pair < 0) continue;
     const PfPair pp = pf[item.pair];
