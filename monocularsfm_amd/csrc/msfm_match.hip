@@ -750,6 +750,27 @@ int finish_prefilter(msfm_ctx* ctx, Batch& b, std::vector<char>& force_exact, bo
     ctx->prof.approx_kernel_ms += ms;
     HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev_pool[pe.ev_base + 2], ctx->ev_pool[pe.ev_base + 3]));
     ctx->prof.sweep2_ms += ms;
+#ifdef MSFM_SWEEP_PROBE
+    for (int which = 0; which < 2; ++which) {   // diagnostic build: average cycles per tile and wave of the four loop segments
+        unsigned long long pr[kPfWaves][8];
+        if (which == 0) HIPCHK(ctx, hipMemcpyFromSymbol(pr, HIP_SYMBOL(g_sweep_probe), sizeof(pr)));
+        else HIPCHK(ctx, hipMemcpyFromSymbol(pr, HIP_SYMBOL(g_sweep_probe3), sizeof(pr)));
+        for (int w = 0; w < kPfWaves; w += 3) {
+            const double n = (double)std::max<unsigned long long>(1, pr[w][4]);
+            std::fprintf(stderr, "[sweep %d probe] wave %d: MFMA %.0f | wait+barrier %.0f | EPI %.0f | wait+barrier %.0f cycles per tile (%.0f tiles, %llu items)\n",
+                         which == 0 ? 1 : 3, w, pr[w][0] / n, pr[w][1] / n, pr[w][2] / n, pr[w][3] / n, n, pr[w][5]);
+        }
+        std::memset(pr, 0, sizeof(pr));
+        if (which == 0) HIPCHK(ctx, hipMemcpyToSymbol(HIP_SYMBOL(g_sweep_probe), pr, sizeof(pr)));
+        else HIPCHK(ctx, hipMemcpyToSymbol(HIP_SYMBOL(g_sweep_probe3), pr, sizeof(pr)));
+    }
+#endif
+    if (std::getenv("MSFM_DEBUG_TIMING") && pe.compact) {
+        PlanSummary d;
+        std::memcpy(&d, hs, sizeof(PlanSummary));
+        std::fprintf(stderr, "[msfm plan] ok %d, items %d, compacted rows %lld, candidate capacity %lld, swept descriptor pairs %lld; sweep 1 %.3f ms, sweep 2 %.3f ms\n",
+                     d.ok, d.n_items, d.cmp_rows, d.cand_elems, d.swept_desc_pairs, ctx->prof.approx_kernel_ms, ms);
+    }
     if (pe.compact) {
         std::memcpy(&sm, hs, sizeof(PlanSummary));
         ctx->cmp_rows_hint = sm.cmp_rows;

@@ -50,12 +50,15 @@
 // (MFMA phase, its wait + barrier, EPI phase, its wait + barrier), printed by the library after every sweep 1.
 #ifdef MSFM_SWEEP_PROBE
 __device__ unsigned long long g_sweep_probe[kPfWaves][8];
+__device__ unsigned long long g_sweep_probe3[kPfWaves][8];   // the compacted sweep 2
 #define MSFM_PROBE_BEGIN unsigned long long pb_t = __builtin_amdgcn_s_memtime(), pb_acc[4] = {0, 0, 0, 0};
 #define MSFM_PROBE(k) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); pb_acc[k] += n_ - pb_t; pb_t = n_; }
 #define MSFM_PROBE_END                                                                                     \
-    if (PASS == 1 && lane == 0) {                                                                          \
-        for (int k_ = 0; k_ < 4; ++k_) atomicAdd(&g_sweep_probe[wave][k_], pb_acc[k_]);                    \
-        atomicAdd(&g_sweep_probe[wave][4], (unsigned long long)(t_end - t_begin));                         \
+    if (PASS != 2 && lane == 0) {                                                                          \
+        unsigned long long (*pr_)[8] = PASS == 1 ? g_sweep_probe : g_sweep_probe3;                         \
+        for (int k_ = 0; k_ < 4; ++k_) atomicAdd(&pr_[wave][k_], pb_acc[k_]);                              \
+        atomicAdd(&pr_[wave][4], (unsigned long long)(t_end - t_begin));                                   \
+        atomicAdd(&pr_[wave][5], 1ull);                                                                    \
     }
 #else
 #define MSFM_PROBE_BEGIN
@@ -362,20 +365,36 @@ __global__ __launch_bounds__(kPfThreads, 2) void sweep_kernel(
         }
         n_buf += __popcll(mm);
     };
-    // Compacted sweep (PASS 3): a hit is accumulator >= 0.  With every A row alive a 64 x 32 block holds about one hit,
-    // so "no hit in the block" is not the common case; what is rare is a hit in a given group of 4 result registers.
-    // Per column block: the maxima of the 8 register quads (12 ops per 16 elements), one ballot per quad, and only a
-    // quad that holds a hit somewhere in the wave has its 4 elements tested.
+    // Compacted sweep (PASS 3): a hit is accumulator >= 0.  With every A row alive a 64 x 32 block holds about one hit:
+    // "no hit in the block" is not the common case, a hit in a given group of 4 result registers is rare.  Per column
+    // block: the maxima of the 8 register quads (2 ops per quad), one ballot per quad, and for a quad with a hit the
+    // bookkeeping is SCALAR: the hit lanes are visited one by one (usually there is one), the lane's 4 values are read
+    // with v_readlane and tested on the scalar unit, and that lane alone stores its (row, column) record -- the epilogue
+    // phase stays short enough to hide behind the partner wave's MFMA phase (measured: 2150 -> cycles per tile with the
+    // all-lane ballot / popcount slotting the dense variant below still uses).
     auto scan_hits3 = [&](const f16v (&acc)[kPfRB], int col) {
 #pragma unroll
         for (int rb = 0; rb < kPfRB; ++rb)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const float m = fmaxf(max3f(acc[rb][4 * q], acc[rb][4 * q + 1], acc[rb][4 * q + 2]), acc[rb][4 * q + 3]);
-                if (__ballot(m >= 0.f) == 0ull) continue;   // wave-uniform
+                unsigned long long bal = __ballot(m >= 0.f);
+                while (bal != 0ull) {   // wave-uniform
+                    const int L = __builtin_ctzll(bal);
+                    bal &= bal - 1ull;
 #pragma unroll
-                for (int r = 4 * q; r < 4 * q + 4; ++r)
-                    record_hits(acc[rb][r] >= 0.f, arow_base + rb * 32 + (r & 3) + 8 * (r >> 2), col);
+                    for (int r = 4 * q; r < 4 * q + 4; ++r) {
+                        const float v = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, acc[rb][r]), L));
+                        if (v >= 0.f) {   // scalar
+                            if (n_buf + 1 > kPfCandBuf) flush_candidates();
+                            if (lane == L) {
+                                const int2 e = make_int2(arow_base + rb * 32 + (r & 3) + 8 * (r >> 2), col);
+                                asm volatile("ds_write_b64 %0, %1" ::"v"(cbuf_lds + n_buf * 8), "v"(e) : "memory");
+                            }
+                            n_buf += 1;
+                        }
+                    }
+                }
             }
     };
     // Dense sweep (PASS 2, the kNN-level API): row criterion acc >= level_row, column criterion acc >= level_col; a block
