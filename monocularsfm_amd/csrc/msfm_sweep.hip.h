@@ -365,27 +365,41 @@ __global__ __launch_bounds__(kPfThreads, 2) void sweep_kernel(
         }
         n_buf += __popcll(mm);
     };
-    // Compacted sweep (PASS 3): a hit is accumulator >= 0.  With every A row alive a 64 x 32 block holds about one hit:
-    // "no hit in the block" is not the common case, a hit in a given group of 4 result registers is rare.  Per column
-    // block: the maxima of the 8 register quads (2 ops per quad), one ballot per quad, and for a quad with a hit the
-    // bookkeeping is SCALAR: the hit lanes are visited one by one (usually there is one), the lane's 4 values are read
-    // with v_readlane and tested on the scalar unit, and that lane alone stores its (row, column) record -- the epilogue
-    // phase stays short enough to hide behind the partner wave's MFMA phase (measured: 2150 -> cycles per tile with the
-    // all-lane ballot / popcount slotting the dense variant below still uses).
+    // Compacted sweep (PASS 3): a hit is accumulator >= 0, i.e. sign bit clear (the accumulator starts at +0 and a sum
+    // that cancels exactly rounds to +0: -0 cannot occur; NaN cannot either on fp16-safe operands).  With every A row
+    // alive a 64 x 32 block holds one or two hits: "no hit in the block" is not the common case, but a hit in a given
+    // quad of result registers is rare.  Per column block and lane: the AND of each quad's bit patterns has its sign
+    // clear iff the quad holds a hit; the 8 sign bits are packed into one mask (4 integer ops per quad, no compare), ONE
+    // ballot asks whether any lane saw a hit, and the rest is scalar: hit lanes are visited one by one, the lane's mask
+    // and the 4 values of a hit quad are read with v_readlane, tested on the scalar unit, and that lane alone stores its
+    // (row, column) record.  (A ballot + branch per quad, or ballot / popcount slotting over all lanes, cost the epilogue
+    // phase 2100 - 2600 cycles per tile -- measured -- against the 1300 of the partner wave's MFMA phase it has to hide
+    // behind.)
     auto scan_hits3 = [&](const f16v (&acc)[kPfRB], int col) {
+        unsigned miss = 0;   // bit rb*4+q set: no hit in that quad
 #pragma unroll
         for (int rb = 0; rb < kPfRB; ++rb)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const float m = fmaxf(max3f(acc[rb][4 * q], acc[rb][4 * q + 1], acc[rb][4 * q + 2]), acc[rb][4 * q + 3]);
-                unsigned long long bal = __ballot(m >= 0.f);
-                while (bal != 0ull) {   // wave-uniform
-                    const int L = __builtin_ctzll(bal);
-                    bal &= bal - 1ull;
+                const unsigned a = __float_as_uint(acc[rb][4 * q]) & __float_as_uint(acc[rb][4 * q + 1]) &
+                                   __float_as_uint(acc[rb][4 * q + 2]) & __float_as_uint(acc[rb][4 * q + 3]);
+                miss |= (a >> 31) << (rb * 4 + q);
+            }
+        constexpr unsigned kAll = (1u << (4 * kPfRB)) - 1u;
+        unsigned long long bal = __ballot(miss != kAll);
+        while (bal != 0ull) {   // wave-uniform; one iteration per lane with a hit
+            const int L = __builtin_ctzll(bal);
+            bal &= bal - 1ull;
+            const unsigned missL = (unsigned)__builtin_amdgcn_readlane((int)miss, L);
+#pragma unroll
+            for (int rb = 0; rb < kPfRB; ++rb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if ((missL >> (rb * 4 + q)) & 1u) continue;   // scalar
 #pragma unroll
                     for (int r = 4 * q; r < 4 * q + 4; ++r) {
-                        const float v = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, acc[rb][r]), L));
-                        if (v >= 0.f) {   // scalar
+                        const int v = __builtin_amdgcn_readlane(__builtin_bit_cast(int, acc[rb][r]), L);
+                        if (v >= 0) {   // scalar: sign clear
                             if (n_buf + 1 > kPfCandBuf) flush_candidates();
                             if (lane == L) {
                                 const int2 e = make_int2(arow_base + rb * 32 + (r & 3) + 8 * (r >> 2), col);
@@ -395,7 +409,7 @@ __global__ __launch_bounds__(kPfThreads, 2) void sweep_kernel(
                         }
                     }
                 }
-            }
+        }
     };
     // Dense sweep (PASS 2, the kNN-level API): row criterion acc >= level_row, column criterion acc >= level_col; a block
     // is first reduced to "any hit?" with v_max3, then every element is tested.  Padding rows / columns hold -inf: with
