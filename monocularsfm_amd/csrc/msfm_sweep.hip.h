@@ -375,40 +375,52 @@ __global__ __launch_bounds__(kPfThreads, 2) void sweep_kernel(
     // (row, column) record.  (A ballot + branch per quad, or ballot / popcount slotting over all lanes, cost the epilogue
     // phase 2100 - 2600 cycles per tile -- measured -- against the 1300 of the partner wave's MFMA phase it has to hide
     // behind.)
-    auto scan_hits3 = [&](const f16v (&acc)[kPfRB], int col) {
-        unsigned miss = 0;   // bit rb*4+q set: no hit in that quad
+    auto scan_hits3 = [&](const f16v (&a0)[kPfRB], const f16v (&a1)[kPfRB], int col0) {
+        static_assert(kPfRB == 2, "quad numbering below: bit = 8 block + 4 rb + q");
+        unsigned miss = 0;   // bit set: no hit in that quad
 #pragma unroll
-        for (int rb = 0; rb < kPfRB; ++rb)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const unsigned a = __float_as_uint(acc[rb][4 * q]) & __float_as_uint(acc[rb][4 * q + 1]) &
-                                   __float_as_uint(acc[rb][4 * q + 2]) & __float_as_uint(acc[rb][4 * q + 3]);
-                miss |= (a >> 31) << (rb * 4 + q);
-            }
-        constexpr unsigned kAll = (1u << (4 * kPfRB)) - 1u;
-        unsigned long long bal = __ballot(miss != kAll);
-        while (bal != 0ull) {   // wave-uniform; one iteration per lane with a hit
-            const int L = __builtin_ctzll(bal);
-            bal &= bal - 1ull;
-            const unsigned missL = (unsigned)__builtin_amdgcn_readlane((int)miss, L);
+        for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
             for (int rb = 0; rb < kPfRB; ++rb)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    if ((missL >> (rb * 4 + q)) & 1u) continue;   // scalar
-#pragma unroll
-                    for (int r = 4 * q; r < 4 * q + 4; ++r) {
-                        const int v = __builtin_amdgcn_readlane(__builtin_bit_cast(int, acc[rb][r]), L);
-                        if (v >= 0) {   // scalar: sign clear
-                            if (n_buf + 1 > kPfCandBuf) flush_candidates();
-                            if (lane == L) {
-                                const int2 e = make_int2(arow_base + rb * 32 + (r & 3) + 8 * (r >> 2), col);
-                                asm volatile("ds_write_b64 %0, %1" ::"v"(cbuf_lds + n_buf * 8), "v"(e) : "memory");
-                            }
-                            n_buf += 1;
-                        }
-                    }
+                    const f16v& v = blk ? a1[rb] : a0[rb];
+                    const unsigned a = __float_as_uint(v[4 * q]) & __float_as_uint(v[4 * q + 1]) & __float_as_uint(v[4 * q + 2]) &
+                                       __float_as_uint(v[4 * q + 3]);
+                    miss |= (a >> 31) << (blk * 8 + rb * 4 + q);
                 }
+        unsigned long long bal = __ballot(miss != 0xffffu);
+        while (bal != 0ull) {   // wave-uniform; one iteration per lane with a hit
+            const int L = __builtin_ctzll(bal);
+            bal &= bal - 1ull;
+            unsigned hitq = ~(unsigned)__builtin_amdgcn_readlane((int)miss, L) & 0xffffu;
+            while (hitq != 0u) {   // scalar: the quads of lane L that hold a hit
+                const int qi = __builtin_ctz(hitq);
+                hitq &= hitq - 1u;
+                int v[4] = {-1, -1, -1, -1};
+#define MSFM_QUAD_CASE(B, RB, Q)                                                                                        \
+    case (B) * 8 + (RB) * 4 + (Q):                                                                                      \
+        for (int k_ = 0; k_ < 4; ++k_) v[k_] = __builtin_amdgcn_readlane(__builtin_bit_cast(int, ((B) ? a1 : a0)[RB][4 * (Q) + k_]), L); \
+        break;
+                switch (qi) {
+                    MSFM_QUAD_CASE(0, 0, 0) MSFM_QUAD_CASE(0, 0, 1) MSFM_QUAD_CASE(0, 0, 2) MSFM_QUAD_CASE(0, 0, 3)
+                    MSFM_QUAD_CASE(0, 1, 0) MSFM_QUAD_CASE(0, 1, 1) MSFM_QUAD_CASE(0, 1, 2) MSFM_QUAD_CASE(0, 1, 3)
+                    MSFM_QUAD_CASE(1, 0, 0) MSFM_QUAD_CASE(1, 0, 1) MSFM_QUAD_CASE(1, 0, 2) MSFM_QUAD_CASE(1, 0, 3)
+                    MSFM_QUAD_CASE(1, 1, 0) MSFM_QUAD_CASE(1, 1, 1) MSFM_QUAD_CASE(1, 1, 2) MSFM_QUAD_CASE(1, 1, 3)
+                }
+#undef MSFM_QUAD_CASE
+                unsigned hb = (v[0] >= 0 ? 1u : 0u) | (v[1] >= 0 ? 2u : 0u) | (v[2] >= 0 ? 4u : 0u) | (v[3] >= 0 ? 8u : 0u);
+                while (hb != 0u) {   // ONE record site: the flush code exists once
+                    const int k = __builtin_ctz(hb);
+                    hb &= hb - 1u;
+                    if (n_buf + 1 > kPfCandBuf) flush_candidates();
+                    if (lane == L) {
+                        const int2 e = make_int2(arow_base + ((qi >> 2) & 1) * 32 + k + 8 * (qi & 3), col0 + (qi >> 3) * 32);
+                        asm volatile("ds_write_b64 %0, %1" ::"v"(cbuf_lds + n_buf * 8), "v"(e) : "memory");
+                    }
+                    n_buf += 1;
+                }
+            }
         }
     };
     // Dense sweep (PASS 2, the kNN-level API): row criterion acc >= level_row, column criterion acc >= level_col; a block
@@ -503,8 +515,7 @@ __global__ __launch_bounds__(kPfThreads, 2) void sweep_kernel(
 #pragma unroll
                     for (int r = 0; r < 16; ++r) rs0[rb][r] = max3f(rs0[rb][r], accA[rb][r], accB[rb][r]);
             } else if (PASS == 3) {
-                scan_hits3(accA, t * kPfBT + lcol);
-                scan_hits3(accB, t * kPfBT + 32 + lcol);
+                scan_hits3(accA, accB, t * kPfBT + lcol);
             } else {
                 const float* thr = thr_w + sl * 64;   // column hit levels -T_col / 2
                 scan_hits2(accA, -0.5f * thr[lcol], t * kPfBT + lcol);
