@@ -367,59 +367,37 @@ __global__ __launch_bounds__(kPfThreads, 2) void sweep_kernel(
     };
     // Compacted sweep (PASS 3): a hit is accumulator >= 0, i.e. sign bit clear (the accumulator starts at +0 and a sum
     // that cancels exactly rounds to +0: -0 cannot occur; NaN cannot either on fp16-safe operands).  With every A row
-    // alive a 64 x 32 block holds one or two hits: "no hit in the block" is not the common case, but a hit in a given
-    // quad of result registers is rare.  Per column block and lane: the AND of each quad's bit patterns has its sign
-    // clear iff the quad holds a hit; the 8 sign bits are packed into one mask (4 integer ops per quad, no compare), ONE
-    // ballot asks whether any lane saw a hit, and the rest is scalar: hit lanes are visited one by one, the lane's mask
-    // and the 4 values of a hit quad are read with v_readlane, tested on the scalar unit, and that lane alone stores its
-    // (row, column) record.  (A ballot + branch per quad, or ballot / popcount slotting over all lanes, cost the epilogue
-    // phase 2100 - 2600 cycles per tile -- measured -- against the 1300 of the partner wave's MFMA phase it has to hide
-    // behind.)
+    // alive a 64 x 32 block holds one or two hits, so there is no "nothing here" shortcut worth a branch: every lane
+    // shifts the 32 sign bits of a column block into one mask, ONE v_alignbit per element (element k = rb*16 + r ends up
+    // at bit 31 - k), and the hits are slotted with ballot / popcount into the wave's LDS buffer, one hit per lane and
+    // round (usually one or two rounds).  Measured alternatives, cycles of the epilogue phase per tile against the 1300
+    // of the partner wave's MFMA phase it should hide behind: compare + select mask 2150, a ballot + branch per register
+    // quad 2600, scalar bookkeeping with v_readlane 2200 (every VALU -> SGPR -> branch round trip costs ~50 cycles).
     auto scan_hits3 = [&](const f16v (&a0)[kPfRB], const f16v (&a1)[kPfRB], int col0) {
-        static_assert(kPfRB == 2, "quad numbering below: bit = 8 block + 4 rb + q");
-        unsigned miss = 0;   // bit set: no hit in that quad
+        unsigned nm[2] = {0u, 0u};   // bit set: sign set, no hit
 #pragma unroll
         for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
             for (int rb = 0; rb < kPfRB; ++rb)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const f16v& v = blk ? a1[rb] : a0[rb];
-                    const unsigned a = __float_as_uint(v[4 * q]) & __float_as_uint(v[4 * q + 1]) & __float_as_uint(v[4 * q + 2]) &
-                                       __float_as_uint(v[4 * q + 3]);
-                    miss |= (a >> 31) << (blk * 8 + rb * 4 + q);
+                for (int r = 0; r < 16; ++r) nm[blk] = __builtin_amdgcn_alignbit(nm[blk], __float_as_uint((blk ? a1 : a0)[rb][r]), 31);
+        static_assert(kPfRB == 2, "32 elements per column block and mask");
+#pragma unroll 1
+        for (int blk = 0; blk < 2; ++blk) {   // a runtime loop: the flush code below exists once
+            unsigned hm = ~(blk ? nm[1] : nm[0]);
+            const int col = col0 + blk * 32;
+            while (__ballot(hm != 0u) != 0ull) {
+                const bool hit = hm != 0u;
+                const int k = __clz((int)hm);   // first remaining element of this lane
+                const unsigned long long mm = __ballot(hit);
+                if (n_buf + 64 > kPfCandBuf) flush_candidates();
+                if (hit) {
+                    hm &= ~(0x80000000u >> k);
+                    const int slt = n_buf + __popcll(mm & ((1ull << lane) - 1ull));
+                    const int2 e = make_int2(arow_base + (k >> 4) * 32 + (k & 3) + 8 * ((k & 15) >> 2), col);
+                    asm volatile("ds_write_b64 %0, %1" ::"v"(cbuf_lds + slt * 8), "v"(e) : "memory");
                 }
-        unsigned long long bal = __ballot(miss != 0xffffu);
-        while (bal != 0ull) {   // wave-uniform; one iteration per lane with a hit
-            const int L = __builtin_ctzll(bal);
-            bal &= bal - 1ull;
-            unsigned hitq = ~(unsigned)__builtin_amdgcn_readlane((int)miss, L) & 0xffffu;
-            while (hitq != 0u) {   // scalar: the quads of lane L that hold a hit
-                const int qi = __builtin_ctz(hitq);
-                hitq &= hitq - 1u;
-                int v[4] = {-1, -1, -1, -1};
-#define MSFM_QUAD_CASE(B, RB, Q)                                                                                        \
-    case (B) * 8 + (RB) * 4 + (Q):                                                                                      \
-        for (int k_ = 0; k_ < 4; ++k_) v[k_] = __builtin_amdgcn_readlane(__builtin_bit_cast(int, ((B) ? a1 : a0)[RB][4 * (Q) + k_]), L); \
-        break;
-                switch (qi) {
-                    MSFM_QUAD_CASE(0, 0, 0) MSFM_QUAD_CASE(0, 0, 1) MSFM_QUAD_CASE(0, 0, 2) MSFM_QUAD_CASE(0, 0, 3)
-                    MSFM_QUAD_CASE(0, 1, 0) MSFM_QUAD_CASE(0, 1, 1) MSFM_QUAD_CASE(0, 1, 2) MSFM_QUAD_CASE(0, 1, 3)
-                    MSFM_QUAD_CASE(1, 0, 0) MSFM_QUAD_CASE(1, 0, 1) MSFM_QUAD_CASE(1, 0, 2) MSFM_QUAD_CASE(1, 0, 3)
-                    MSFM_QUAD_CASE(1, 1, 0) MSFM_QUAD_CASE(1, 1, 1) MSFM_QUAD_CASE(1, 1, 2) MSFM_QUAD_CASE(1, 1, 3)
-                }
-#undef MSFM_QUAD_CASE
-                unsigned hb = (v[0] >= 0 ? 1u : 0u) | (v[1] >= 0 ? 2u : 0u) | (v[2] >= 0 ? 4u : 0u) | (v[3] >= 0 ? 8u : 0u);
-                while (hb != 0u) {   // ONE record site: the flush code exists once
-                    const int k = __builtin_ctz(hb);
-                    hb &= hb - 1u;
-                    if (n_buf + 1 > kPfCandBuf) flush_candidates();
-                    if (lane == L) {
-                        const int2 e = make_int2(arow_base + ((qi >> 2) & 1) * 32 + k + 8 * (qi & 3), col0 + (qi >> 3) * 32);
-                        asm volatile("ds_write_b64 %0, %1" ::"v"(cbuf_lds + n_buf * 8), "v"(e) : "memory");
-                    }
-                    n_buf += 1;
-                }
+                n_buf += __popcll(mm);
             }
         }
     };
