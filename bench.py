@@ -65,12 +65,34 @@ def opencv_found():
         return False
 
 
+def usable_cores():
+    """Host cores this process may actually use: the affinity mask, cut by the cgroup CPU quota (a container on a 256-thread
+    host is often given far fewer; os.cpu_count() reports the host)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(period)
+    except (OSError, ValueError):
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / period
+        except (OSError, ValueError):
+            pass
+    if quota:
+        n = max(1, min(n, int(round(quota))))
+    return n, (os.cpu_count() or 1), quota
+
+
 def cpu_baseline(imgs, pairs, budget_s=20.0, max_pairs=4096, seed=0):
     """CPU oracle on a seeded sample of the same pairs: one persistent pool over image pairs on all host threads
     (orc_match_pairs_mt), plus the single-thread figure (how the reference itself runs: one pair after the other)."""
     from oracle import c_oracle as co
     co.build()
-    threads = os.cpu_count() or 1
+    threads, host_threads, quota = usable_cores()
     rng = np.random.default_rng(seed)
     order = rng.permutation(len(pairs))
     f32 = {}
@@ -111,6 +133,7 @@ def cpu_baseline(imgs, pairs, budget_s=20.0, max_pairs=4096, seed=0):
                   "wall; restated CPU BFMatcher (SSE order), persistent pthread pool over image pairs, not OpenCV" % (n, len(pairs), dt),
         "image_pairs_per_s": n / dt, "matches_in_sample": int(offs[-1]),
         "single_thread_value": single, "parallel_efficiency": (w / dt) / (single * threads), "cpu_model": model,
+        "host_hardware_threads": host_threads, "cgroup_cpu_quota": quota,
         "opencv_found": opencv_found(),
     }
 

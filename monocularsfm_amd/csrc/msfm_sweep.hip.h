@@ -386,10 +386,9 @@ __global__ __launch_bounds__(kPfThreads, 2) void sweep_kernel(
         for (int blk = 0; blk < 2; ++blk) {   // a runtime loop: the flush code below exists once
             unsigned hm = ~(blk ? nm[1] : nm[0]);
             const int col = col0 + blk * 32;
-            while (__ballot(hm != 0u) != 0ull) {
+            for (unsigned long long mm = __ballot(hm != 0u); mm != 0ull; mm = __ballot(hm != 0u)) {   // one ballot per round
                 const bool hit = hm != 0u;
                 const int k = __clz((int)hm);   // first remaining element of this lane
-                const unsigned long long mm = __ballot(hit);
                 if (n_buf + 64 > kPfCandBuf) flush_candidates();
                 if (hit) {
                     hm &= ~(0x80000000u >> k);
