@@ -146,6 +146,67 @@ Descriptors Database::ReadDescriptors(const image_t image_id) const {
     return d;
 }
 
+namespace {
+size_t VisitTable(sqlite3* db, const char* sql, size_t elem_size, Database::BlobVisitor visit, void* user) {
+    sqlite3_stmt* stmt = nullptr;
+    SQL_CALL(Sqlite().prepare_v2(db, sql, -1, &stmt, nullptr));
+    size_t n = 0;
+    int rc;
+    while ((rc = SQL_CALL(Sqlite().step(stmt))) == msfm_host::SQLITE_ROW_) {
+        const image_t id = (image_t)Sqlite().column_int64(stmt, 0);
+        const size_t rows = (size_t)Sqlite().column_int64(stmt, 1), cols = (size_t)Sqlite().column_int64(stmt, 2);
+        const size_t num_bytes = (size_t)Sqlite().column_bytes(stmt, 3);
+        if (rows * cols * elem_size != num_bytes) {
+            std::fprintf(stderr, "Database: blob of %zu bytes does not match rows=%zu cols=%zu (image %d)\n", num_bytes, rows, cols, (int)id);
+            std::exit(EXIT_FAILURE);
+        }
+        visit(user, id, num_bytes ? Sqlite().column_blob(stmt, 3) : nullptr, rows, cols, elem_size);
+        ++n;
+    }
+    SQL_CALL(Sqlite().finalize(stmt));
+    return n;
+}
+}  // namespace
+
+size_t Database::VisitAllDescriptors(BlobVisitor visit, void* user) const {
+    return VisitTable(database_, "SELECT image_id, rows, cols, data FROM descriptors ORDER BY image_id;", sizeof(float), visit, user);
+}
+
+size_t Database::VisitAllKeyPoints(BlobVisitor visit, void* user) const {
+    return VisitTable(database_, "SELECT image_id, rows, cols, data FROM keypoints ORDER BY image_id;", sizeof(float), visit, user);
+}
+
+bool Database::HasDescriptorsU8() const {
+    sqlite3_stmt* stmt = nullptr;
+    SQL_CALL(Sqlite().prepare_v2(database_, "SELECT 1 FROM sqlite_master WHERE type = 'table' AND name = 'descriptors_u8';", -1, &stmt, nullptr));
+    const bool has = SQL_CALL(Sqlite().step(stmt)) == msfm_host::SQLITE_ROW_;
+    SQL_CALL(Sqlite().finalize(stmt));
+    return has;
+}
+
+void Database::CreateDescriptorsU8Table() const {
+    Exec(database_,
+         "CREATE TABLE IF NOT EXISTS descriptors_u8"
+         "  (image_id    INTEGER    PRIMARY KEY    NOT NULL,"
+         "   rows        INTEGER                   NOT NULL,"
+         "   cols        INTEGER                   NOT NULL,"
+         "   data        BLOB,"
+         "FOREIGN KEY(image_id) REFERENCES images(image_id) ON DELETE CASCADE)");
+}
+
+void Database::WriteDescriptorsU8(const image_t image_id, const unsigned char* data, size_t rows, size_t cols) const {
+    sqlite3_stmt* stmt = nullptr;
+    SQL_CALL(Sqlite().prepare_v2(database_, "INSERT OR REPLACE INTO descriptors_u8(image_id, rows, cols, data) VALUES(?, ?, ?, ?);", -1, &stmt, nullptr));
+    SQL_CALL(Sqlite().bind_int64(stmt, 1, image_id));
+    WriteBlob<unsigned char>(stmt, data, rows, cols, 2);
+    SQL_CALL(Sqlite().step(stmt));
+    SQL_CALL(Sqlite().finalize(stmt));
+}
+
+size_t Database::VisitAllDescriptorsU8(BlobVisitor visit, void* user) const {
+    return VisitTable(database_, "SELECT image_id, rows, cols, data FROM descriptors_u8 ORDER BY image_id;", 1, visit, user);
+}
+
 std::vector<DMatch> Database::ReadMatches(const image_t image_id1, const image_t image_id2) const {
     SQL_CALL(Sqlite().bind_int64(sql_stmt_read_matches_, 1, ImagePairToPairId(image_id1, image_id2)));
     const int rc = SQL_CALL(Sqlite().step(sql_stmt_read_matches_));

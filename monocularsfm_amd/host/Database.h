@@ -42,6 +42,23 @@ public:
     std::vector<DMatch> ReadMatches(const image_t image_id1, const image_t image_id2) const;
     std::vector<std::pair<image_pair_t, std::vector<DMatch>>> ReadAllMatches() const;
 
+    // ---- bulk loader --------------------------------------------------------------------------------
+    // One `SELECT image_id, rows, cols, data FROM descriptors ORDER BY image_id` sweep instead of one prepared-statement
+    // read per image (the reference: two per PAIR, FeatureMatching.cpp:32-33; Database.cpp:482-523).  The callback gets
+    // the BLOB in SQLite's own buffer (valid during the call only): the matcher uploads it to the GPU from there, the
+    // rows never pass through a host-side container.  elem_size is 4 (float32, the reference's table) or 1 (uint8, the
+    // optional side table below).  Returns the number of rows visited.
+    typedef void (*BlobVisitor)(void* user, image_t image_id, const void* data, size_t rows, size_t cols, size_t elem_size);
+    size_t VisitAllDescriptors(BlobVisitor visit, void* user) const;
+    size_t VisitAllKeyPoints(BlobVisitor visit, void* user) const;
+    // Optional side table `descriptors_u8(image_id, rows, cols, data BLOB)`: raw SIFT descriptors are integers 0..255; stored
+    // as bytes they are a quarter of the float table and feed the library's uint8 upload (integer distances are exact
+    // on the matrix cores).  Not part of the reference's schema: only read when present, only written on request.
+    bool HasDescriptorsU8() const;
+    void CreateDescriptorsU8Table() const;
+    void WriteDescriptorsU8(const image_t image_id, const unsigned char* data, size_t rows, size_t cols) const;
+    size_t VisitAllDescriptorsU8(BlobVisitor visit, void* user) const;
+
     image_t WriteImage(const Image& image, const bool use_image_id = false) const;
     void WriteKeyPoints(const image_t image_id, const std::vector<KeyPoint>& keypoints) const;
     void WriteDescriptors(const image_t image_id, const Descriptors& descriptors) const;

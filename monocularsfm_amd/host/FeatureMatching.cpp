@@ -13,6 +13,7 @@
 #include <thread>
 
 #include "GeometricVerification.h"
+#include "MatchEmission.h"
 #include "Timer.h"
 
 namespace MonocularSfM {
@@ -147,6 +148,44 @@ void FeatureMatcher::EnsureResident(image_t image_id) {
         MSFM_CALL(ctx_, msfm_upload_keypoints(ctx_, image_id, reinterpret_cast<const float*>(kpts.data()), (int)kpts.size(), 4));
     }
     resident_.insert(image_id);
+}
+
+void FeatureMatcher::PreloadAllImages() {
+    if (const char* e = std::getenv("MSFM_BULK_LOAD"))
+        if (e[0] == '0') return;
+    Lap l(&g_clock.read_desc);
+    struct Sink {
+        FeatureMatcher* self;
+        bool keypoints;
+    } sink{this, false};
+    // visitors run on this thread while SQLite holds the row: upload from its buffer, keep nothing
+    auto visit = [](void* user, image_t id, const void* data, size_t rows, size_t cols, size_t elem) {
+        Sink* s = static_cast<Sink*>(user);
+        FeatureMatcher* m = s->self;
+        if (id < 0 || id >= MSFM_MAX_IMAGES) return;
+        std::vector<msfm_ctx*> ctxs(1, m->ctx_);
+        ctxs.insert(ctxs.end(), m->extra_ctxs_.begin(), m->extra_ctxs_.end());
+        if (!s->keypoints) {
+            if (m->resident_.count(id)) return;
+            for (msfm_ctx* c : ctxs)
+                MSFM_CALL(c, msfm_upload_image(c, id, data, (int)rows, rows ? (int)cols : MSFM_DIM, elem == 1 ? MSFM_DTYPE_U8 : MSFM_DTYPE_F32));
+            m->resident_.insert(id);
+            for (auto& have : m->extra_resident_) have.insert(id);
+        } else {
+            std::vector<KeyPoint>& kps = m->keypoints_cache_[id];
+            kps.resize(rows);
+            if (rows) std::memcpy(kps.data(), data, rows * sizeof(KeyPoint));
+            if (m->geometric_verification_ && !m->verification_on_host_ && m->resident_.count(id))
+                for (msfm_ctx* c : ctxs)
+                    MSFM_CALL(c, msfm_upload_keypoints(c, id, static_cast<const float*>(data), (int)rows, 4));
+        }
+    };
+    static_assert(sizeof(KeyPoint) == 16, "KeyPoint must be 4 packed floats");
+    if (database_->HasDescriptorsU8()) database_->VisitAllDescriptorsU8(visit, &sink);
+    database_->VisitAllDescriptors(visit, &sink);   // images the side table does not cover
+    sink.keypoints = true;
+    database_->VisitAllKeyPoints(visit, &sink);
+    bulk_loaded_ = true;
 }
 
 void FeatureMatcher::MatchImagePairs(const std::vector<std::pair<image_t, image_t>>& image_pairs) {
@@ -307,6 +346,7 @@ void FeatureMatcher::MatchImagePairGroups(const std::vector<std::vector<std::pai
     }
     // emission: the reference's order, one transaction per group
     Lap le(&g_clock.emit);
+    static const EmissionOptions emission = EmissionOptions::FromEnvironment();
     std::string out;
     char buf[160];
     static const bool trace_txn = std::getenv("MSFM_TRACE_TRANSACTIONS") != nullptr;  // tests: one line per transaction
@@ -322,6 +362,7 @@ void FeatureMatcher::MatchImagePairGroups(const std::vector<std::vector<std::pai
                 out += buf;
                 continue;
             }
+            ApplyEmissionOptions(emission, image_id1, image_id2, &verified[(size_t)p]);
             std::snprintf(buf, sizeof(buf), "Compute Matches %d - %d ... \n\t matches num : %zu\n\t ", image_id1, image_id2,
                           verified[(size_t)p].size());
             out += buf;
@@ -350,6 +391,7 @@ size_t SuperBatchPairs() {
 
 void SequentialFeatureMatcher::RunMatching() {
     OpenDatabaseAndDevice();
+    PreloadAllImages();
     const std::vector<Database::Image> images = database_->ReadAllImages();
     std::vector<std::vector<std::pair<image_t, image_t>>> groups;
     size_t pending = 0;
@@ -374,6 +416,7 @@ void SequentialFeatureMatcher::RunMatching() {
 
 void BruteFeatureMatcher::RunMatching() {
     OpenDatabaseAndDevice();
+    PreloadAllImages();
     const std::vector<Database::Image> images = database_->ReadAllImages();
     // the reference's groups: a flush every max_pairs_size_ pairs and at the end of every row i
     std::vector<std::vector<std::pair<image_t, image_t>>> groups;

@@ -41,6 +41,10 @@ protected:
     void OpenDatabaseAndDevice();
     void CloseDatabaseAndDevice();
     void EnsureResident(image_t image_id);
+    // every image's descriptors (and keypoints) in ONE table sweep, uploaded straight from SQLite's
+    // buffers; uses the optional `descriptors_u8` side table when the database has one.  MSFM_BULK_LOAD=0 falls back
+    // to the per-image reads.
+    void PreloadAllImages();
     const std::vector<KeyPoint>& KeyPointsOf(image_t image_id);  // read once per image
 
     std::string database_path_;
@@ -53,6 +57,7 @@ protected:
     Database* database_ = nullptr;
     msfm_ctx* ctx_ = nullptr;             // primary device (MSFM_DEVICE, or the first entry of MSFM_DEVICES)
     std::set<image_t> resident_;
+    bool bulk_loaded_ = false;
     // MSFM_DEVICES="0,1,...": the pairs of a super-batch are split over these GPUs (one context and one host
     // thread per device, the whole descriptor store replicated on each; SQLite stays on the calling thread)
     std::vector<msfm_ctx*> extra_ctxs_;                 // devices 1..G-1

@@ -6,6 +6,7 @@
 
 #include "Database.h"
 #include "GeometricVerification.h"
+#include "MatchEmission.h"
 #include "YamlConfig.h"
 
 using namespace MonocularSfM;
@@ -119,6 +120,81 @@ int host_db_read_matches(const char* path, int id1, int id2, int* qt, int cap_pa
 }
 
 int host_pair_id(int id1, int id2) { return Database::ImagePairToPairId(id1, id2); }
+
+// ---- bulk loader + u8 side table --------------------------------------------------------------------
+int host_db_write_descriptors_u8(const char* path, int image_id, const unsigned char* data, int rows, int cols) {
+    Database db;
+    db.Open(path);
+    db.CreateDescriptorsU8Table();
+    db.BeginTransaction();
+    db.WriteDescriptorsU8(image_id, data, (size_t)rows, (size_t)cols);
+    db.EndTransaction();
+    db.Close();
+    return 0;
+}
+
+// One sweep over a table (which: 0 descriptors, 1 keypoints, 2 descriptors_u8): per row image id, rows, cols, a checksum
+// of the blob bytes; returns the number of rows visited (-1: the u8 side table does not exist).
+int host_db_visit_all(const char* path, int which, int* ids, int* rows, int* cols, unsigned long long* checksums, int cap) {
+    struct Acc {
+        int *ids, *rows, *cols;
+        unsigned long long* sums;
+        int cap, n;
+    } acc{ids, rows, cols, checksums, cap, 0};
+    auto visit = [](void* user, image_t id, const void* data, size_t r, size_t c, size_t elem) {
+        Acc* a = static_cast<Acc*>(user);
+        if (a->n < a->cap) {
+            unsigned long long h = 1469598103934665603ull;   // FNV-1a over the blob
+            const unsigned char* b = static_cast<const unsigned char*>(data);
+            for (size_t i = 0; i < r * c * elem; ++i) h = (h ^ b[i]) * 1099511628211ull;
+            a->ids[a->n] = (int)id;
+            a->rows[a->n] = (int)r;
+            a->cols[a->n] = (int)c;
+            a->sums[a->n] = h;
+        }
+        a->n += 1;
+    };
+    Database db;
+    db.Open(path);
+    size_t n = 0;
+    if (which == 2 && !db.HasDescriptorsU8()) {
+        db.Close();
+        return -1;
+    }
+    if (which == 0) n = db.VisitAllDescriptors(visit, &acc);
+    else if (which == 1) n = db.VisitAllKeyPoints(visit, &acc);
+    else n = db.VisitAllDescriptorsU8(visit, &acc);
+    db.Close();
+    return (int)n;
+}
+
+// ---- row emission -------------------------------------------------------------------------------------
+// in / out: m (queryIdx, trainIdx) pairs of pair (id1, id2); returns the new count
+int host_apply_emission(int id1, int id2, int scene_graph_order, int min_num_matches, int* qt, int m) {
+    std::vector<DMatch> ms((size_t)m);
+    for (int i = 0; i < m; ++i) {
+        ms[(size_t)i].queryIdx = qt[2 * i];
+        ms[(size_t)i].trainIdx = qt[2 * i + 1];
+    }
+    EmissionOptions o;
+    o.scene_graph_order = scene_graph_order != 0;
+    o.min_num_matches = min_num_matches;
+    ApplyEmissionOptions(o, id1, id2, &ms);
+    for (size_t i = 0; i < ms.size(); ++i) {
+        qt[2 * i] = ms[i].queryIdx;
+        qt[2 * i + 1] = ms[i].trainIdx;
+    }
+    return (int)ms.size();
+}
+
+int host_check_row_contract(const int* qt, int m, int num_keypoints1, int num_keypoints2) {
+    std::vector<DMatch> ms((size_t)m);
+    for (int i = 0; i < m; ++i) {
+        ms[(size_t)i].queryIdx = qt[2 * i];
+        ms[(size_t)i].trainIdx = qt[2 * i + 1];
+    }
+    return CheckRowContract(ms, (size_t)num_keypoints1, (size_t)num_keypoints2);
+}
 
 // mask length n (0/1); returns number of mask entries written (0 if no model)
 int host_fundamental_ransac(const float* p1, const float* p2, int n, unsigned char* mask) {

@@ -327,3 +327,66 @@ def test_brute_mode_past_the_100_pair_flush_and_the_super_batch(exe, oracle, tmp
             assert row[1] == len(m) and row[2] == 2
             assert np.array_equal(np.frombuffer(row[3], np.int32).reshape(-1, 2), m[:, ::-1]), (i, j)   # i > j: columns swapped
     assert outs["small"] == outs["default"]
+
+
+def test_bulk_load_u8_side_table_and_scene_graph_order(exe, oracle, tmp_path):
+    """SURVEY 8f-2 / 8f-4 through the CLI: (1) the bulk loader gives the same table as the per-image reads
+    (MSFM_BULK_LOAD=0); (2) with a `descriptors_u8` side table the matcher uploads the bytes (integer descriptors: the
+    rows equal the exact-integer reference's); (3) MSFM_SCENEGRAPH_ORDER=1 stores every row sorted by column 0 with the
+    same match set, default rows are byte-identical to the reference order."""
+    import ctypes as C
+    from oracle import int_oracle as io
+    sizes = [300, 257, 64, 512, 130, 40]
+    u = synth.u8_images(len(sizes), sizes, seed=77, dup_frac=0.3, as_float=False)
+    kps = [synth.keypoints(len(d), seed=900 + i) for i, d in enumerate(u)]
+    host = C.CDLL(os.path.join(HOST, "libmsfm_host.so"))
+    host.host_db_write_descriptors_u8.argtypes = [C.c_char_p, C.c_int, C.c_void_p, C.c_int, C.c_int]
+
+    def make_db(name, side_table):
+        path = str(tmp_path / (name + ".db"))
+        # the float table holds HALF the value where a side table exists: a run that ignored the side table would differ
+        floats = [(x.astype(np.float32) * (0.5 if side_table else 1.0)) for x in u]
+        database.write_synthetic_database(path, floats, kps)
+        if side_table:
+            for i, x in enumerate(u):
+                host.host_db_write_descriptors_u8(path.encode(), i, x.ctypes.data_as(C.c_void_p) if len(x) else None, len(x), 128)
+        cfg = tmp_path / (name + ".yaml")
+        # the reference's max_distance 0.7 suits unit-norm descriptors; these are 0..255 integers: the YAML carries a wide one
+        # and MSFM_HONOUR_YAML_MATCH_PARAMS=1 makes the CLI use it (the reference itself ignores the three values)
+        cfg.write_text('%YAML:1.0\ndatabase_path : "{}"\nSIFTmatch.match_type : 0\nSIFTmatch.max_distance : 1000000000.0\n'
+                       'SIFTmatch.distance_ratio : 0.8\nSIFTmatch.cross_check : 1\n'.format(path))
+        return path, cfg
+
+    def rows_of(path):
+        db = database.Database(path)
+        r = db.db.execute("SELECT pair_id, rows, cols, data FROM matches ORDER BY pair_id").fetchall()
+        db.Close()
+        return r
+
+    env = {"MSFM_GEOMETRIC_VERIFICATION": "0", "MSFM_HONOUR_YAML_MATCH_PARAMS": "1"}
+    p_bulk, c_bulk = make_db("bulk", False)
+    p_single, c_single = make_db("single", False)
+    p_u8, c_u8 = make_db("u8", True)
+    p_ord, c_ord = make_db("ord", False)
+    run_cli(exe, c_bulk, env)
+    run_cli(exe, c_single, dict(env, MSFM_BULK_LOAD="0"))
+    run_cli(exe, c_u8, env)
+    run_cli(exe, c_ord, dict(env, MSFM_SCENEGRAPH_ORDER="1"))
+    r_bulk, r_single, r_u8, r_ord = rows_of(p_bulk), rows_of(p_single), rows_of(p_u8), rows_of(p_ord)
+    assert len(r_bulk) > 3 and r_bulk == r_single          # (1)
+    assert r_u8 == r_bulk                                   # (2): the bytes of the side table, not the halved floats
+    # against the exact-integer reference, over the sequential mode's pair list (no pre-emptive filter there)
+    pairs, _ = oracle.enumerate_sequential(len(sizes), 3)
+    assert len(r_bulk) == len(pairs)
+    db = database.Database(p_u8)
+    for i, j in pairs:
+        q, t, _ = io.match_pair(u[int(i)], u[int(j)], 0.8, True, 1e9)
+        assert np.array_equal(db.ReadMatches(int(i), int(j)), np.stack([q, t], 1).reshape(-1, 2)), (i, j)
+    db.Close()
+    # (3) same match sets, column 0 ascending
+    assert [x[0] for x in r_ord] == [x[0] for x in r_bulk]
+    for a, b_ in zip(r_bulk, r_ord):
+        ma = np.frombuffer(a[3], np.int32).reshape(-1, 2)
+        mb = np.frombuffer(b_[3], np.int32).reshape(-1, 2)
+        assert {tuple(x) for x in ma} == {tuple(x) for x in mb}
+        assert (np.diff(mb[:, 0]) > 0).all()

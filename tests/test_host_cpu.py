@@ -188,3 +188,134 @@ def test_cli_fails_loudly_without_gpu(host, tmp_path):
     db = database.Database(db_path)
     assert len(db.ReadAllMatches()) == 0 and not db.ExistMatches(1, 0)   # nothing was written
     db.Close()
+
+
+# ---- bulk loader, u8 side table ---------------------------------------------------------------------------
+
+def _fnv1a(b):
+    h = 1469598103934665603
+    for x in bytes(b):
+        h = ((h ^ x) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
+def test_bulk_visitors_see_every_row_once_in_id_order(host, tmp_path):
+    """One SELECT per table instead of one prepared-statement read per image (the reference: two per PAIR,
+    /root/reference/src/Feature/FeatureMatching.cpp:32-33, src/Database/Database.cpp:482-523): same bytes."""
+    from monocularsfm_amd import database, synth
+    sizes = [40, 0, 17, 300, 1]
+    descs = [np.ascontiguousarray(d, np.float32) for d in synth.rootsift_images(len(sizes), sizes, seed=5, n_proto=400)]
+    kps = [synth.keypoints(len(d), seed=10 + i) for i, d in enumerate(descs)]
+    path = str(tmp_path / "bulk.db")
+    database.write_synthetic_database(path, descs, kps)
+    host.host_db_visit_all.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                       C.POINTER(C.c_ulonglong), C.c_int]
+    for which, arrays, cols_expected in ((0, descs, 128), (1, kps, 4)):
+        ids, rows, cols = (np.zeros(16, np.int32) for _ in range(3))
+        sums = np.zeros(16, np.uint64)
+        n = host.host_db_visit_all(path.encode(), which, ids.ctypes.data_as(C.POINTER(C.c_int)), rows.ctypes.data_as(C.POINTER(C.c_int)),
+                                   cols.ctypes.data_as(C.POINTER(C.c_int)), sums.ctypes.data_as(C.POINTER(C.c_ulonglong)), 16)
+        assert n == len(sizes) and list(ids[:n]) == list(range(len(sizes))) and list(rows[:n]) == sizes
+        for i in range(n):
+            assert int(sums[i]) == _fnv1a(np.ascontiguousarray(arrays[i], np.float32).tobytes())
+            assert rows[i] == 0 or cols[i] == cols_expected
+    # no side table yet
+    assert host.host_db_visit_all(path.encode(), 2, None, None, None, None, 0) == -1
+
+
+def test_u8_side_table_round_trip(host, tmp_path):
+    from monocularsfm_amd import database, synth
+    u = synth.u8_images(3, [50, 33, 0], seed=6, as_float=False)
+    path = str(tmp_path / "u8.db")
+    database.write_synthetic_database(path, [x.astype(np.float32) for x in u], None)
+    host.host_db_write_descriptors_u8.argtypes = [C.c_char_p, C.c_int, C.c_void_p, C.c_int, C.c_int]
+    for i, x in enumerate(u):
+        host.host_db_write_descriptors_u8(path.encode(), i, x.ctypes.data_as(C.c_void_p) if len(x) else None, len(x), 128)
+    host.host_db_visit_all.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                       C.POINTER(C.c_ulonglong), C.c_int]
+    ids, rows, cols = (np.zeros(8, np.int32) for _ in range(3))
+    sums = np.zeros(8, np.uint64)
+    n = host.host_db_visit_all(path.encode(), 2, ids.ctypes.data_as(C.POINTER(C.c_int)), rows.ctypes.data_as(C.POINTER(C.c_int)),
+                               cols.ctypes.data_as(C.POINTER(C.c_int)), sums.ctypes.data_as(C.POINTER(C.c_ulonglong)), 8)
+    assert n == 3 and list(rows[:3]) == [50, 33, 0]
+    for i in range(3):
+        assert int(sums[i]) == _fnv1a(u[i].tobytes())
+    # the reference's own tables are untouched: the Python twin still reads the float descriptors
+    db = database.Database(path)
+    assert np.array_equal(db.ReadDescriptors(0), u[0].astype(np.float32))
+    db.Close()
+
+
+# ---- SURVEY 8f-4: SceneGraph-friendly emission ---------------------------------------------------------------------------
+
+def scene_graph_add_correspondences(rows, num_keypoints):
+    """SceneGraph::Load + AddCorrespondences (/root/reference/src/Reconstruction/SceneGraph.cpp:59-76, 170-251) on stored
+    rows {pair_id: m x 2 (column 0 = index in the smaller image id)}: -> (corrs per (image, point), warnings, find_if steps)."""
+    corrs = {}
+    warnings = steps = 0
+    for pair_id in sorted(rows):                                   # ReadAllMatches: primary-key order
+        id2 = pair_id % 10000
+        id1 = (pair_id - id2) // 10000
+        for a, b in rows[pair_id]:
+            if not (0 <= a < num_keypoints[id1] and 0 <= b < num_keypoints[id2]):
+                warnings += 1
+                continue
+            lst = corrs.setdefault((id1, int(a)), [])
+            steps += len(lst)                                       # the linear std::find_if
+            if (id2, int(b)) in lst:
+                warnings += 1
+                continue
+            lst.append((id2, int(b)))
+            corrs.setdefault((id2, int(b)), []).append((id1, int(a)))
+    return corrs, warnings, steps
+
+
+def test_emission_default_is_identity_and_scene_graph_order_sorts_column_zero(host):
+    rng = np.random.default_rng(3)
+    host.host_apply_emission.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int]
+    host.host_check_row_contract.argtypes = [C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int]
+    q = np.sort(rng.choice(500, 120, replace=False)).astype(np.int32)       # a matcher list: ascending distinct queryIdx
+    t = rng.choice(400, 120, replace=False).astype(np.int32)                # cross-checked: distinct trainIdx
+    qt = np.ascontiguousarray(np.stack([q, t], 1))
+    p = lambda a: a.ctypes.data_as(C.POINTER(C.c_int))
+    assert host.host_check_row_contract(p(qt), 120, 500, 400) == 0
+    same = qt.copy()
+    assert host.host_apply_emission(7, 3, 0, 0, p(same), 120) == 120 and np.array_equal(same, qt)      # default: untouched
+    srt = qt.copy()
+    assert host.host_apply_emission(7, 3, 1, 0, p(srt), 120) == 120
+    # id1 = 7 > id2 = 3: column 0 of the stored row is the trainIdx
+    assert (np.diff(srt[:, 1]) > 0).all() and {tuple(x) for x in srt} == {tuple(x) for x in qt}
+    srt2 = qt.copy()
+    assert host.host_apply_emission(3, 7, 1, 0, p(srt2), 120) == 120 and np.array_equal(srt2, qt)       # already by queryIdx
+    few = qt[:5].copy()
+    assert host.host_apply_emission(7, 3, 0, 16, p(few), 5) == 0                                          # below min_num_matches
+    # the contract check sees what AddCorrespondences would warn about
+    bad = qt.copy()
+    bad[3] = bad[2]
+    assert host.host_check_row_contract(p(bad), 120, 500, 400) == 2
+    assert host.host_check_row_contract(p(qt), 120, 100, 400) == 1
+
+
+def test_scene_graph_consumer_sees_the_same_graph_with_fewer_steps(host):
+    """The consumer emulation on reference-order rows and on MSFM_SCENEGRAPH_ORDER rows: identical correspondences, no
+    warnings, and the ordered rows never pay for a find_if longer than the unordered ones."""
+    rng = np.random.default_rng(9)
+    host.host_apply_emission.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int]
+    nk = {i: 300 for i in range(5)}
+    rows_ref, rows_ord = {}, {}
+    for i in range(5):
+        for j in range(i):
+            m = int(rng.integers(20, 120))
+            q = np.sort(rng.choice(300, m, replace=False)).astype(np.int32)
+            t = rng.choice(300, m, replace=False).astype(np.int32)
+            for order, store in ((0, rows_ref), (1, rows_ord)):
+                qt = np.ascontiguousarray(np.stack([q, t], 1))
+                n = host.host_apply_emission(i, j, order, 0, qt.ctypes.data_as(C.POINTER(C.c_int)), m)
+                store[10000 * j + i] = qt[:n, ::-1].copy()          # i > j: WriteMatches swaps the columns
+    g_ref, w_ref, s_ref = scene_graph_add_correspondences(rows_ref, nk)
+    g_ord, w_ord, s_ord = scene_graph_add_correspondences(rows_ord, nk)
+    assert w_ref == w_ord == 0
+    assert {k: sorted(v) for k, v in g_ref.items()} == {k: sorted(v) for k, v in g_ord.items()}
+    assert s_ord == s_ref                                           # same work, sequential instead of scattered access
+    for pid, r in rows_ord.items():
+        assert (np.diff(r[:, 0]) > 0).all()
