@@ -283,23 +283,6 @@ __global__ __launch_bounds__(kPfThreads, 2) void sweep_kernel(
         for (int r = 0; r < 16; ++r)
 #pragma unroll
             for (int rb = 0; rb < kPfRB; ++rb) acc[rb][r] = 0.f;
-#ifdef MSFM_SWEEP_ASMREAD
-        // reads hidden from hipcc (it would wait for ALL of them before the first MFMA of column block 1); the counted
-        // waits are in mfma_block_counted below
-        const unsigned pb = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)sB +
-                            (unsigned)(sl * kPfTileBytes + 32 * kPfRowBytes + lane_row_off);
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-#pragma unroll
-            for (int rb = 0; rb < kPfRB; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[rb][ks], bf[ks], acc[rb], 0, 0, 0);
-            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bf[ks]) : "v"(pb), "n"(ks * 32));
-            __builtin_amdgcn_sched_barrier(0);
-        }
-#pragma unroll
-        for (int rb = 0; rb < kPfRB; ++rb)
-            acc[rb] = __builtin_amdgcn_mfma_f32_32x32x8f16(__builtin_shufflevector(af[rb][8], af[rb][8], 0, 1, 2, 3), be, acc[rb], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-#else
         const char* pb = sB + sl * kPfTileBytes + 32 * kPfRowBytes + lane_row_off;
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
@@ -316,28 +299,7 @@ __global__ __launch_bounds__(kPfThreads, 2) void sweep_kernel(
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
         }
         __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-#endif
     };
-#ifdef MSFM_SWEEP_ASMREAD
-    // column block 1 on fragments whose reads (inline asm above) may still be in flight: fragment ks is the (ks+1)-th
-    // oldest of the 8 outstanding LDS reads
-    auto mfma_block_counted = [&](h8 (&bf)[8], h4 be, f16v (&acc)[kPfRB]) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-#pragma unroll
-            for (int rb = 0; rb < kPfRB; ++rb) acc[rb][r] = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-            asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(bf[ks]) : "n"(7 - ks));
-#pragma unroll
-            for (int rb = 0; rb < kPfRB; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[rb][ks], bf[ks], acc[rb], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);   // keeps the next wait behind these MFMAs
-        }
-#pragma unroll
-        for (int rb = 0; rb < kPfRB; ++rb)
-            acc[rb] = __builtin_amdgcn_mfma_f32_32x32x8f16(__builtin_shufflevector(af[rb][8], af[rb][8], 0, 1, 2, 3), be, acc[rb], 0, 0, 0);
-    };
-#endif
     // maximum of the accumulator over this lane's 32 rows of one column block: two independent v_max3 chains
     auto column_max = [&](const f16v (&acc)[kPfRB]) -> float {
         float m[kPfRB];
@@ -467,11 +429,7 @@ __global__ __launch_bounds__(kPfThreads, 2) void sweep_kernel(
             __builtin_amdgcn_s_setprio(1);
             if (!kPreRead) load_bf(sl, bf, be);
             mfma_block_reload(sl, bf, be[0], accA);
-#ifdef MSFM_SWEEP_ASMREAD
-            mfma_block_counted(bf, be[1], accB);
-#else
             mfma_block(bf, be[1], accB);
-#endif
             __builtin_amdgcn_s_setprio(0);
         }
         MSFM_PROBE(0)
