@@ -156,6 +156,7 @@ def main():
                     help="run the RCCL exchange step even with one rank (sanity check of the multi-GPU path on a 1-GPU box)")
     ap.add_argument("--no-prefilter", action="store_true",
                     help="brute-force exact-order kernel for every pair (same results, ~20x slower)")
+    ap.add_argument("--f16-only", action="store_true", help="byte stores on the fp16 matrix cores too (default: integer matrix cores)")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--u8-images", type=int, default=192,
                     help="images of the secondary strong-scaling job (subset of the 1329 x 8192 u8 config); 0 = skip")
@@ -198,6 +199,8 @@ def main():
     ctx = _lib.Context(local_rank, order=args.order)
     if args.no_prefilter:
         ctx.set_prefilter(False)
+    elif args.f16_only:
+        ctx.set_prefilter(2)
 
     def run_job(imgs, pairs, steps, warmup, collect=None, **match_kw):
         """Upload, W untimed + K timed steps; -> (seconds of the K steps: max over ranks, result of the last step,

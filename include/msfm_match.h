@@ -84,6 +84,7 @@ typedef struct msfm_profile {
     int sub_batches;           /* device sub-batches the call was cut into (msfm_set_limits) */
     int tie_queue_regrows;     /* sub-batches re-run because the sqrt-space tie queue had to grow */
     int plan_regrows;          /* sub-batches re-run because the device-side sweep-2 plan outgrew its predicted buffers */
+    int sweep1_i8_launches;     /* sweep-1 launches on the integer matrix cores (byte stores, msfm_sweep_i8.hip.h) */
 } msfm_profile;
 
 /* ---- context ------------------------------------------------------------------------- */
@@ -93,8 +94,9 @@ const char* msfm_last_error(const msfm_ctx* ctx);
 /* device name + CU count of the context's GPU (for bench reports); name_cap >= 64 */
 int msfm_device_info(const msfm_ctx* ctx, char* name, int name_cap, int* cu_count, int* clock_mhz);
 int msfm_set_accum_order(msfm_ctx* ctx, int order);
-/* 1 (default): MFMA prefilter + exact re-check where safe; 0: always the brute-force exact kernel.
- * Results are bit-identical either way. */
+/* 1 (default): MFMA prefilter + exact re-check where safe -- byte images (MSFM_DTYPE_U8 uploads) on the integer matrix
+ * cores (v_mfma_i32_32x32x32_i8), everything else on the fp16 ones; 2: fp16 matrix cores for every image; 0: always the
+ * brute-force exact kernel.  Results are bit-identical in all three.  Env: MSFM_PREFILTER=0|1|2. */
 int msfm_set_prefilter(msfm_ctx* ctx, int enable);
 int msfm_get_profile(const msfm_ctx* ctx, msfm_profile* out);
 /* msfm_match_pairs cuts a call into device sub-batches of at most `max_pairs_per_batch` image pairs and

@@ -45,7 +45,8 @@ class Profile(C.Structure):
                 ("exact_descriptor_pairs", C.c_int64), ("tie_rows", C.c_int64),
                 ("sweep2_ms", C.c_double), ("sweep2_launches", C.c_int), ("compacted_pairs", C.c_int),
                 ("sweep2_descriptor_pairs", C.c_int64), ("verify_ms", C.c_double),
-                ("sub_batches", C.c_int), ("tie_queue_regrows", C.c_int), ("plan_regrows", C.c_int)]
+                ("sub_batches", C.c_int), ("tie_queue_regrows", C.c_int), ("plan_regrows", C.c_int),
+                ("sweep1_i8_launches", C.c_int)]
 
 
 class MsfmError(RuntimeError):
@@ -155,8 +156,9 @@ class Context:
         self._chk(self._L.msfm_set_accum_order(self._h, int(order)))
 
     def set_prefilter(self, enable):
-        """True (default): MFMA prefilter + exact re-check; False: brute-force exact kernel only."""
-        self._chk(self._L.msfm_set_prefilter(self._h, int(bool(enable))))
+        """True / 1 (default): MFMA prefilter + exact re-check (byte images on the integer matrix cores); 2: fp16 matrix
+        cores only; False / 0: brute-force exact kernel only."""
+        self._chk(self._L.msfm_set_prefilter(self._h, 2 if enable == 2 and enable is not True else int(bool(enable))))
 
     def set_limits(self, max_pairs_per_batch=0, scratch_bytes=0):
         """Sub-batch limits of match_pairs (<= 0: default).  Results do not depend on them."""

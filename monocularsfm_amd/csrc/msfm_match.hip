@@ -104,6 +104,12 @@ struct Image {
     float c = 1.f;            // scale of the quadruples (power of two)
     float nrm_max = 0.f, abs_max = 0.f;
     bool pf_safe = false;
+    // byte stores (MSFM_DTYPE_U8 uploads and their subsets): signed operand rows of 144 B for the integer matrix cores
+    // and the float "norms" 2 floor(|x - 128|^2 / 2) (msfm_sweep_i8.hip.h)
+    bool is_u8 = false;
+    signed char* i8 = nullptr;
+    float* nrm_i8 = nullptr;
+    float nrm_i8_max = 0.f;
     // keypoint coordinates (x, y) for the geometric verification; nk = -1: not uploaded
     float2* kxy = nullptr;
     int nk = -1;
@@ -114,6 +120,8 @@ void free_image(Image& im) {
     if (im.raw) (void)hipFree(im.raw);
     if (im.h16) (void)hipFree(im.h16);
     if (im.nrm) (void)hipFree(im.nrm);
+    if (im.i8) (void)hipFree(im.i8);
+    if (im.nrm_i8) (void)hipFree(im.nrm_i8);
     if (im.kxy) (void)hipFree(im.kxy);
     im = Image{};
 }
@@ -145,7 +153,7 @@ struct msfm_ctx {
     int max_pairs_per_batch = kDefaultMaxPairsPerBatch;
     long long scratch_elems = kDefaultScratchElems;
     // prefilter path
-    int prefilter = 1;
+    int prefilter = 1;                // 0: brute force only; 1: MFMA prefilter, integer matrix cores for byte stores; 2: fp16 MFMA only
     DevBuf d_pf, d_tu, d_tv, d_cand, d_cand_s, d_cand_count, d_best, d_second, d_maxima;
     DevBuf d_zero_row, d_cmp_tu, d_live_idx, d_row_pair, d_row_src, d_cand_pair, d_vpairs, d_vpf, d_vitems, d_lists;
     // device-side plan of the compacted sweep 2 (msfm_plan.hip.h)
@@ -153,7 +161,7 @@ struct msfm_ctx {
     long long cmp_rows_hint = 0;      // compacted rows the previous batch needed (sizes the next batch's buffers)
     long long items_hint = 0, cand_hint = 0;   // likewise: work items, candidate-list capacity
     struct PfPending {                // what the end-of-batch synchronisation has to look at
-        bool active = false, compact = false;
+        bool active = false, compact = false, i8 = false;
         size_t n_lists = 0, P = 0;
         long long rows_cap = 0, cand_cap = 0, items_cap = 0;
         int compact_pairs = 0;
@@ -501,6 +509,27 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
     // test is what kills rows (~94 % at ratio 0.8 on SIFT-like data); with a ratio near or above 1 almost every row stays
     // alive and the compacted sweep (both directions separately) would multiply up to twice what the dense one does.
     const bool compact = prune.prune != 0 && prune.ratio > 0.f && prune.ratio <= 0.95f;
+    // Byte stores: both sweeps on the integer matrix cores (msfm_sweep_i8.hip.h) when every prefiltered pair of the batch
+    // joins two byte images (a store is bytes throughout or not at all; a mixed batch takes the fp16 kernels)
+    bool i8 = compact && ctx->prefilter == 1;
+    for (size_t p = 0; p < P && i8; ++p)
+        if (b.pairs[p].valid && b.pf[p].use) i8 = ctx->images[b.id1[p]].is_u8 && ctx->images[b.id2[p]].is_u8;
+    if (i8)
+        for (size_t p = 0; p < P; ++p) {
+            if (!b.pairs[p].valid || !b.pf[p].use) continue;
+            const Image& ia = ctx->images[b.id1[p]];
+            const Image& ib = ctx->images[b.id2[p]];
+            PfPair& pp = b.pf[p];
+            pp.i8 = 1;
+            pp.a_h = reinterpret_cast<const _Float16*>(ia.i8);   // 144-byte rows behind the same pointers
+            pp.b_h = reinterpret_cast<const _Float16*>(ib.i8);
+            pp.a_nrm = ia.nrm_i8;
+            pp.b_nrm = ib.nrm_i8;
+            pp.a_nrm_max = ia.nrm_i8_max;
+            pp.b_nrm_max = ib.nrm_i8_max;
+            pp.a_c = pp.b_c = 0.f;
+        }
+    ctx->pf_pending.i8 = i8;
     long long dense_cand = 0;
     for (size_t p = 0; p < P; ++p) {
         b.pf[p].tu_off = b.pairs[p].kf_off;
@@ -546,14 +575,20 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
     unsigned* colmask = ctx->d_colmask.as<unsigned>();
     hc.lap("sweep-1 setup + uploads");
     HIPCHK(ctx, hipEventRecord(e0, ctx->stream));
-    hipLaunchKernelGGL(sweep_kernel<1>, dim3(std::min<unsigned>(sweep_grid, (unsigned)b.items.size())), block, kPfLdsBytes, ctx->stream, dp, dpf,
-                       ctx->d_items.as<WorkItem>(), ctx->d_rp_s0.as<float>(), ctx->d_rp_s1.as<float>(),
-                       ctx->d_cp_s0.as<float>(), (float*)nullptr, (const float*)nullptr, (const float*)nullptr,
-                       (int2*)nullptr, (unsigned long long*)nullptr, (const int*)nullptr, (int)b.items.size(), (int*)nullptr);
+    if (i8)
+        hipLaunchKernelGGL(sweep_i8_kernel<1>, dim3(std::min<unsigned>(sweep_grid, (unsigned)b.items.size())), block, kI8LdsBytes, ctx->stream, dp, dpf,
+                           ctx->d_items.as<WorkItem>(), ctx->d_rp_s0.as<float>(), ctx->d_rp_s1.as<float>(), ctx->d_cp_s0.as<float>(),
+                           (const float*)nullptr, (int2*)nullptr, (unsigned long long*)nullptr, (const int*)nullptr, (int)b.items.size(), (int*)nullptr);
+    else
+        hipLaunchKernelGGL(sweep_kernel<1>, dim3(std::min<unsigned>(sweep_grid, (unsigned)b.items.size())), block, kPfLdsBytes, ctx->stream, dp, dpf,
+                           ctx->d_items.as<WorkItem>(), ctx->d_rp_s0.as<float>(), ctx->d_rp_s1.as<float>(),
+                           ctx->d_cp_s0.as<float>(), (float*)nullptr, (const float*)nullptr, (const float*)nullptr,
+                           (int2*)nullptr, (unsigned long long*)nullptr, (const int*)nullptr, (int)b.items.size(), (int*)nullptr);
     HIPCHK(ctx, hipGetLastError());
     DBGSYNC(ctx, "sweep_kernel<1>");
     HIPCHK(ctx, hipEventRecord(e1, ctx->stream));
     ctx->prof.approx_kernel_launches += 1;
+    if (i8) ctx->prof.sweep1_i8_launches += 1;
     const dim3 mgrid((unsigned)((b.max_npad + 255) / 256), (unsigned)P);
     hipLaunchKernelGGL(pf_thresholds_kernel, mgrid, dim3(256), 0, ctx->stream, dp, dpf, ctx->d_rp_s0.as<float>(),
                        ctx->d_rp_s1.as<float>(), ctx->d_cp_s0.as<float>(), compact ? colmask : (unsigned*)nullptr, tuv, tuv, prune);
@@ -638,16 +673,24 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
         hipLaunchKernelGGL(pf_assign_kernel, dim3((unsigned)(2 * P)), dim3(256), 0, ctx->stream, dp, dpf, dpp, (const float*)tuv,
                            (const unsigned*)colmask, (const long long*)ctx->d_mrow.as<long long>(),
                            ctx->d_live_idx.as<int>(), ctx->d_row_pair.as<int>(), ctx->d_cmp_tu.as<float>(),
-                           ctx->d_row_src.as<const _Float16*>());
+                           ctx->d_row_src.as<const _Float16*>(), i8 ? kI8RowBytes / 2 : kPfRowHalfs);
         HIPCHK(ctx, hipGetLastError());
         DBGSYNC(ctx, "pf_assign_kernel");
         HIPCHK(ctx, hipEventRecord(e2, ctx->stream));
-        hipLaunchKernelGGL(sweep_kernel<3>, dim3(sweep_grid), block, kPfLdsBytes, ctx->stream,
-                           (const PairDesc*)ctx->d_vpairs.as<PairDesc>(), (const PfPair*)ctx->d_vpf.as<PfPair>(),
-                           (const WorkItem*)ctx->d_vitems.as<WorkItem>(), (float*)nullptr, (float*)nullptr, (float*)nullptr,
-                           (float*)nullptr, (const float*)ctx->d_cmp_tu.as<float>(), (const float*)nullptr, ctx->d_cand.as<int2>(),
-                           ctx->d_cand_count.as<unsigned long long>(), (const int*)&ctx->d_summary.as<PlanSummary>()->n_items, 0,
-                           ctx->d_totals.as<int>() + 8);
+        if (i8)
+            hipLaunchKernelGGL(sweep_i8_kernel<3>, dim3(sweep_grid), block, kI8LdsBytes, ctx->stream,
+                               (const PairDesc*)ctx->d_vpairs.as<PairDesc>(), (const PfPair*)ctx->d_vpf.as<PfPair>(),
+                               (const WorkItem*)ctx->d_vitems.as<WorkItem>(), (float*)nullptr, (float*)nullptr, (float*)nullptr,
+                               (const float*)ctx->d_cmp_tu.as<float>(), ctx->d_cand.as<int2>(),
+                               ctx->d_cand_count.as<unsigned long long>(), (const int*)&ctx->d_summary.as<PlanSummary>()->n_items, 0,
+                               ctx->d_totals.as<int>() + 8);
+        else
+            hipLaunchKernelGGL(sweep_kernel<3>, dim3(sweep_grid), block, kPfLdsBytes, ctx->stream,
+                               (const PairDesc*)ctx->d_vpairs.as<PairDesc>(), (const PfPair*)ctx->d_vpf.as<PfPair>(),
+                               (const WorkItem*)ctx->d_vitems.as<WorkItem>(), (float*)nullptr, (float*)nullptr, (float*)nullptr,
+                               (float*)nullptr, (const float*)ctx->d_cmp_tu.as<float>(), (const float*)nullptr, ctx->d_cand.as<int2>(),
+                               ctx->d_cand_count.as<unsigned long long>(), (const int*)&ctx->d_summary.as<PlanSummary>()->n_items, 0,
+                               ctx->d_totals.as<int>() + 8);
         HIPCHK(ctx, hipGetLastError());
         DBGSYNC(ctx, "sweep_kernel<3>");
         ctx->prof.sweep2_launches += 1;
@@ -984,7 +1027,7 @@ int msfm_create(int device_ordinal, msfm_ctx** out_ctx) {
         delete ctx;
         return MSFM_E_DEVICE;
     }
-    if (const char* e = std::getenv("MSFM_PREFILTER")) ctx->prefilter = (e[0] != '0');
+    if (const char* e = std::getenv("MSFM_PREFILTER")) ctx->prefilter = e[0] == '2' ? 2 : (e[0] != '0');
     if (const char* e = std::getenv("MSFM_MAX_PAIRS_PER_BATCH"))
         if (std::atoi(e) > 0) ctx->max_pairs_per_batch = std::atoi(e);
     if (const char* e = std::getenv("MSFM_SCRATCH_MIB"))
@@ -1048,7 +1091,7 @@ int msfm_set_accum_order(msfm_ctx* ctx, int order) {
 
 int msfm_set_prefilter(msfm_ctx* ctx, int enable) {
     if (!ctx) return MSFM_E_INVALID;
-    ctx->prefilter = enable ? 1 : 0;
+    ctx->prefilter = enable == 2 ? 2 : (enable ? 1 : 0);
     return MSFM_OK;
 }
 
@@ -1079,8 +1122,9 @@ static int alloc_image(msfm_ctx* ctx, Image& im, int n) {
 
 // everything derived from the row-major fp32 copy `im.raw` (src8 != nullptr: u8 rows still to be widened
 // into im.raw by the layout kernel): panels in accumulation order, prefilter operands
-static int build_image(msfm_ctx* ctx, Image& im, const unsigned char* src8) {
+static int build_image(msfm_ctx* ctx, Image& im, const unsigned char* src8, bool is_u8) {
     const int n = im.n;
+    im.is_u8 = is_u8;
     const int blocks = std::min(4096, im.nalloc * 16);
     if (!src8) {
         if (ctx->order == MSFM_ORDER_SSE4X4)
@@ -1098,17 +1142,25 @@ static int build_image(msfm_ctx* ctx, Image& im, const unsigned char* src8) {
     const int npad = im.nalloc * kBM;
     HIPCHK(ctx, hipMalloc((void**)&im.h16, (size_t)npad * kPfRowBytes));
     HIPCHK(ctx, hipMalloc((void**)&im.nrm, (size_t)npad * 4));
-    HIPCHK(ctx, ctx->d_maxima.ensure(8));
-    HIPCHK(ctx, hipMemsetAsync(ctx->d_maxima.p, 0, 8, ctx->stream));
+    HIPCHK(ctx, ctx->d_maxima.ensure(12));
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_maxima.p, 0, 12, ctx->stream));
     hipLaunchKernelGGL(pf_prepare_kernel, dim3(std::min(2048, (npad * 16 + 255) / 256)), dim3(256), 0, ctx->stream,
                        im.raw, im.h16, im.nrm, ctx->d_maxima.as<unsigned>(), n, npad);
     HIPCHK(ctx, hipGetLastError());
-    unsigned mx[2] = {0, 0};
-    HIPCHK(ctx, hipMemcpyAsync(mx, ctx->d_maxima.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (is_u8) {
+        HIPCHK(ctx, hipMalloc((void**)&im.i8, (size_t)npad * kI8RowBytes));
+        HIPCHK(ctx, hipMalloc((void**)&im.nrm_i8, (size_t)npad * 4));
+        hipLaunchKernelGGL(pf_prepare_i8_kernel, dim3(std::min(2048, (npad * 8 + 255) / 256)), dim3(256), 0, ctx->stream,
+                           (const float*)im.raw, im.i8, im.nrm_i8, ctx->d_maxima.as<unsigned>(), n, npad);
+        HIPCHK(ctx, hipGetLastError());
+    }
+    unsigned mx[3] = {0, 0, 0};
+    HIPCHK(ctx, hipMemcpyAsync(mx, ctx->d_maxima.p, 12, hipMemcpyDeviceToHost, ctx->stream));
     // the caller may free/reuse its buffer (and we reuse d_stage) as soon as we return
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     std::memcpy(&im.nrm_max, &mx[0], 4);
     std::memcpy(&im.abs_max, &mx[1], 4);
+    std::memcpy(&im.nrm_i8_max, &mx[2], 4);
     im.pf_safe = (im.abs_max <= kF16Safe) && (im.nrm_max < 3.0e38f);  // NaN/inf compare false
     if (im.pf_safe) {
         // c = 2^k with max|row|^2 / 2 / c in (2^11, 2^12]; k must keep c an exact fp16 value
@@ -1140,11 +1192,11 @@ int msfm_upload_image(msfm_ctx* ctx, int image_id, const void* desc, int n, int 
     if (rc != MSFM_OK || n == 0) return rc;
     if (dtype == MSFM_DTYPE_F32) {
         HIPCHK(ctx, hipMemcpyAsync(im.raw, desc, (size_t)n * kDim * 4, hipMemcpyHostToDevice, ctx->stream));
-        return build_image(ctx, im, nullptr);
+        return build_image(ctx, im, nullptr, false);
     }
     HIPCHK(ctx, ctx->d_stage.ensure((size_t)n * kDim));
     HIPCHK(ctx, hipMemcpyAsync(ctx->d_stage.p, desc, (size_t)n * kDim, hipMemcpyHostToDevice, ctx->stream));
-    return build_image(ctx, im, ctx->d_stage.as<unsigned char>());
+    return build_image(ctx, im, ctx->d_stage.as<unsigned char>(), true);
 }
 
 namespace {
@@ -1172,7 +1224,7 @@ int msfm_subset_image(msfm_ctx* ctx, int src_image_id, int dst_image_id, const i
     hipLaunchKernelGGL(subset_rows_kernel, dim3(std::min(1024, (count * kDim + 255) / 256)), dim3(256), 0, ctx->stream,
                        (const float*)ctx->images[src_image_id].raw, (const int*)ctx->d_stage.as<int>(), im.raw, count);
     HIPCHK(ctx, hipGetLastError());
-    return build_image(ctx, im, nullptr);
+    return build_image(ctx, im, nullptr, ctx->images[src_image_id].is_u8);   // rows of a byte image are bytes
 }
 
 int msfm_image_rows(const msfm_ctx* ctx, int image_id, int* out_n) {

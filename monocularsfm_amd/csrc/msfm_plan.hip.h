@@ -265,7 +265,7 @@ __global__ __launch_bounds__(1024) void pf_plan_kernel(const PlanGroup* __restri
 __global__ void pf_assign_kernel(const PairDesc* __restrict__ pairs, const PfPair* __restrict__ pf, const PlanPair* __restrict__ pp_plan,
                                  const float* __restrict__ tuv, const unsigned* __restrict__ colmask, const long long* __restrict__ mrow,
                                  int* __restrict__ live_idx, int* __restrict__ row_pair, float* __restrict__ cmp_tu,
-                                 const _Float16** __restrict__ row_src) {
+                                 const _Float16** __restrict__ row_src, int row_halfs /* 136: fp16 rows, 72: byte rows */) {
     const int p = blockIdx.x >> 1, dir = blockIdx.x & 1;
     const PlanPair pl = pp_plan[p];
     if (pl.fwd_member < 0) return;
@@ -296,7 +296,7 @@ __global__ void pf_assign_kernel(const PairDesc* __restrict__ pairs, const PfPai
             live_idx[k] = e;
             row_pair[k] = p;
             cmp_tu[k] = t - nrm[e];
-            row_src[k] = src + (size_t)e * kPfRowHalfs;
+            row_src[k] = src + (size_t)e * row_halfs;
         }
     }
 }

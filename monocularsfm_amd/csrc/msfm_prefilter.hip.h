@@ -91,6 +91,9 @@ struct PfPair {            // per-pair extras of the prefilter path (parallel to
     long long cand_off;    // candidate list base
     int cand_cap;
     int use;               // 1: prefiltered; 0: not safe -> exact brute force
+    int i8;                // 1: byte images on the integer matrix cores: a_h / b_h are 144-byte rows, the norms are 2 h
+                           //    (msfm_sweep_i8.hip.h), eps = 2
+    int pad;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -166,6 +169,7 @@ __device__ __forceinline__ void v2_merge(float& s0, float& s1, float b0, float b
 }
 
 #include "msfm_sweep.hip.h"
+#include "msfm_sweep_i8.hip.h"
 
 // thresholds: fold the pass-1 partials; T = S~(2) + 2 eps, stored in u- / v-space.
 // With `prune` (match lists, not the knnMatch-level API) a row / column that PROVABLY cannot yield a match
@@ -208,8 +212,9 @@ __global__ void pf_thresholds_kernel(const PairDesc* __restrict__ pairs, const P
         }
         // s1 = S~(2); eps_row = rel*(na + nb_max) + abs*(sqrt(na)+sqrt(nb_max)) + eps_norm; threshold in S-space
         const float na = pp.a_nrm[e];
-        const float eps = kEpsRel * (na + pp.b_nrm_max) + kEpsAbs * (sqrtf(na) + sqrtf(pp.b_nrm_max)) + eps_norm;
-        const float slack = 2.f * eps + 1e-5f * (fabsf(s1) + na + pp.b_nrm_max);  // + roundings here and in sweep 2's test
+        const float eps = pp.i8 ? kI8Eps : kEpsRel * (na + pp.b_nrm_max) + kEpsAbs * (sqrtf(na) + sqrtf(pp.b_nrm_max)) + eps_norm;
+        // + roundings here and in sweep 2's test (none on the integer path: S~, T and the test are exact integers)
+        const float slack = pp.i8 ? 2.f * eps : 2.f * eps + 1e-5f * (fabsf(s1) + na + pp.b_nrm_max);
         const bool live = (e < pd.n1) && !pf_dead(s0, s1, na, eps, pp.b_nrm_max, pr);
         tu[pp.tu_off + e] = live ? s1 + slack : -f_inf();
     }
@@ -226,8 +231,8 @@ __global__ void pf_thresholds_kernel(const PairDesc* __restrict__ pairs, const P
             v2_merge(s0, s1, -2.f * m.w, f_inf());
         }
         const float nb = pp.b_nrm[e];
-        const float eps = kEpsRel * (nb + pp.a_nrm_max) + kEpsAbs * (sqrtf(nb) + sqrtf(pp.a_nrm_max)) + eps_norm;
-        const float slack = 2.f * eps + 1e-5f * (fabsf(s1) + nb + pp.a_nrm_max);
+        const float eps = pp.i8 ? kI8Eps : kEpsRel * (nb + pp.a_nrm_max) + kEpsAbs * (sqrtf(nb) + sqrtf(pp.a_nrm_max)) + eps_norm;
+        const float slack = pp.i8 ? 2.f * eps : 2.f * eps + 1e-5f * (fabsf(s1) + nb + pp.a_nrm_max);
         const bool live = (e < pd.n2) && !pf_dead(s0, s1, nb, eps, pp.a_nrm_max, pr);
         const float T = live ? s1 + slack : -f_inf();
         tv[pp.tv_off + e] = T;

@@ -217,7 +217,12 @@ __global__ __launch_bounds__(kPfThreads, 2) void sweep_kernel(
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int rr = arow_base + rb * 32 + (r & 3) + 8 * (r >> 2);
-            rs0[rb][r] = (PASS == 2) ? (rr < pd.n1 ? -0.5f * g_tu[pp.tu_off + rr] : f_inf()) : -f_inf();
+            if (PASS == 2) {
+                const float lvl = -0.5f * g_tu[pp.tu_off + rr];   // unconditional: the threshold array covers the padded rows
+                rs0[rb][r] = rr < pd.n1 ? lvl : f_inf();
+            } else {
+                rs0[rb][r] = -f_inf();
+            }
         }
     // Make hipcc itself wait for the fragment loads here (a register use it can see): otherwise its scoreboard
     // still holds them as pending at the first MFMA and it drains vmcnt(0) INSIDE the loop, which would serialise

@@ -1,0 +1,368 @@
+// msfm_sweep_i8.hip.h -- the sweeps of the prefilter path on the INTEGER matrix cores, for stores whose descriptors are
+// bytes (`descriptors_u8` side table / MSFM_DTYPE_U8 uploads).  Included by msfm_prefilter.hip.h after msfm_sweep.hip.h.
+//
+// A byte descriptor x (0..255) is stored as the signed byte x' = x - 128 (= x ^ 0x80): the distance is shift invariant,
+// |a - b|^2 = |a' - b'|^2 = n'_a + n'_b - 2 a'.b' with n' = |x'|^2 <= 2^21, and v_mfma_i32_32x32x32_i8 computes a'.b'
+// EXACTLY -- twice the k-depth of the fp16 instruction in the same 8 passes.  Per row the store keeps h = floor(n'/2)
+// (an int32 behind the 128 operand bytes: rows of 144 B = 9 granules, the same odd-granule bank swizzle as the fp16
+// rows) and 2h as a float (the path's "norm" array).  The accumulator is
+//
+//        acc = a'.b' - h_a - h_b        ->   S~ = -2 acc = S - (n'_a & 1) - (n'_b & 1),   |S~ - S| <= 2 =: eps
+//
+// with -h_a (sweep 1) or floor((T_row - 2 h_a) / 2) (compacted sweep 2: a hit is acc >= 0  <=>  S~ <= T_row) held in 32
+// registers per lane for the whole work item and -h_b read from the B tile; their sum initialises the accumulator (a
+// v_add per register where the fp16 kernel has an inline-constant zero).  Everything downstream (thresholds, plan, exact
+// re-check in the pinned fp32 order, reduce) is the float pipeline unchanged: the results leave this kernel as floats
+// (exact: |acc| < 2^23).  On byte data the pinned fp32 order is itself exact integer arithmetic (every partial sum is an
+// integer below 2^24; oracle/int_oracle.py pins that), so eps = 2 instead of ~1.5e-3 (n_a + n_b) ~ 2000: far fewer
+// candidates, and half the matrix time.
+//
+// Same program as sweep_kernel (msfm_sweep.hip.h): 8 waves x 64 A rows, MFMA / EPI ping-pong between the two waves of
+// a SIMD, 4-slot LDS ring filled by LDS-DMA three tiles ahead (9 pieces of 1 KiB per tile: wave w piece w, wave 0
+// piece 8 as well), counted vmcnt waits, persistent workgroups.  PASS 1 and PASS 3 only: the dense sweep 2 (kNN-level
+// API, ratio > 0.95) stays on the fp16 kernel.
+#pragma once
+// (included inside namespace msfm)
+
+constexpr int kI8RowBytes = 144;                        // 128 operand bytes + [h, 0, 0, 0] (int32)
+constexpr int kI8TileBytes = kPfBT * kI8RowBytes;       // 9216 B = 9 DMA pieces
+constexpr int kI8LdsBytes = kPfRing * kI8TileBytes + kPfWaves * kPfCandBuf * 8 + 2 * kPfBT * kPfColClasses * 4;
+constexpr int kI8Pad = -(1 << 29);                      // "-inf" of a padding row / column (two of them still fit an int32)
+constexpr int kI8PadTest = -(1 << 27);                  // anything below is padding
+constexpr float kI8Eps = 2.f;
+static_assert(kI8TileBytes % 1024 == 0 && kI8TileBytes / 1024 == 9, "tile = 9 DMA pieces");
+
+typedef int i4v __attribute__((ext_vector_type(4)));
+typedef int i16v __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ int max3i(int a, int b, int c) { return max(max(a, b), c); }  // folds to v_max3_i32
+
+// upload-time preparation of a byte image: signed operand rows, h, the float "norms" 2h (+inf on padding rows).
+// `raw` holds the bytes widened to float (the store's row-major copy).  maxima[2] = max 2h (float bits).
+__global__ void pf_prepare_i8_kernel(const float* __restrict__ raw, signed char* __restrict__ rows, float* __restrict__ nrm2h,
+                                     unsigned* __restrict__ maxima, int n, int npad) {
+    const long long total = (long long)npad * 8;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const int row = (int)(e >> 3), g = (int)(e & 7);
+        i4v v = {0, 0, 0, 0};
+        if (row < n) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int x = (int)raw[(size_t)row * kDim + g * 16 + k] - 128;
+                v[k >> 2] |= (x & 255) << (8 * (k & 3));
+            }
+        }
+        *reinterpret_cast<i4v*>(rows + (size_t)row * kI8RowBytes + g * 16) = v;
+    }
+    for (int row = blockIdx.x * blockDim.x + threadIdx.x; row < npad; row += gridDim.x * blockDim.x) {
+        int h = -kI8Pad;   // padding rows: -h = "-inf"
+        float f = f_inf();
+        if (row < n) {
+            int s = 0;
+            for (int k = 0; k < kDim; ++k) {
+                const int x = (int)raw[(size_t)row * kDim + k] - 128;
+                s += x * x;
+            }
+            h = s >> 1;
+            f = (float)(2 * h);
+            atomicMax(&maxima[2], __float_as_uint(f));
+        }
+        nrm2h[row] = f;
+        const i4v ext = {h, 0, 0, 0};
+        *reinterpret_cast<i4v*>(rows + (size_t)row * kI8RowBytes + kDim) = ext;
+    }
+}
+
+template <int PASS>
+__global__ __launch_bounds__(kPfThreads, 2) void sweep_i8_kernel(
+    const PairDesc* __restrict__ pairs, const PfPair* __restrict__ pf, const WorkItem* __restrict__ items,
+    float* __restrict__ rp_s0, float* __restrict__ rp_s1, float* __restrict__ cp_s0, const float* __restrict__ tu,
+    int2* __restrict__ cand, unsigned long long* __restrict__ cand_count, const int* __restrict__ n_items_dev, int n_items_host,
+    int* __restrict__ dyn_next) {
+    static_assert(PASS == 1 || PASS == 3, "sweep 1 and the compacted sweep 2");
+    typedef const __attribute__((address_space(1))) float* gfloat_p;
+    typedef const __attribute__((address_space(1))) i4v* gi4_p;
+    extern __shared__ __attribute__((aligned(16))) char pf_smem[];
+    char* sB = pf_smem;                                                   // [ring slot][64 rows x 144 B]
+    char* sCand = pf_smem + kPfRing * kI8TileBytes;                       // [wave][kPfCandBuf] int2 (PASS 3)
+    int* sCol = reinterpret_cast<int*>(sCand + kPfWaves * kPfCandBuf * 8);  // [2 tiles][4 classes][64 columns] (PASS 1)
+
+    const int n_items = n_items_dev ? *n_items_dev : n_items_host;
+    __shared__ int s_next_item;
+    bool first_item = true;
+#pragma unroll 1
+    for (int it = blockIdx.x;; it += gridDim.x) {
+    if (!first_item || dyn_next) lds_barrier();
+    first_item = false;
+    if (dyn_next) {
+        if (threadIdx.x == 0) s_next_item = atomicAdd(&dyn_next[blockIdx.x & 7], 1);
+        lds_barrier();
+        it = s_next_item * 8 + (int)(blockIdx.x & 7);
+    }
+    if (it >= n_items) break;
+    const WorkItem item = items[it];
+    if (item.pair < 0) continue;
+    const PfPair pp = pf[item.pair];
+    if (!pp.use) continue;
+    const PairDesc pd = pairs[item.pair];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2;
+    const int lcol = lane & 31, lhalf = lane >> 5;
+
+    const int t_begin = item.bt_begin * 2, t_end = min(item.bt_end * 2, max(item.bt_begin * 2 + 1, (pd.n2 + kPfBT - 1) / kPfBT));
+    const char* gB = reinterpret_cast<const char*>(pp.b_h);
+    const gfloat_p g_anrm = (gfloat_p)pp.a_nrm;
+    const gfloat_p g_tu = (gfloat_p)tu;
+
+    // DMA group of tile tt: piece `wave` of the tile's 9 (wave 0: piece 8 as well)
+    const unsigned lane_off = (unsigned)(wave * 1024 + lane * 16);
+    auto dma_tile = [&](int tt) {
+        const int tc = tt < t_end ? tt : t_end - 1;
+        const int sl = (tt - t_begin) & (kPfRing - 1);
+        const unsigned off = (unsigned)tc * (unsigned)kI8TileBytes + lane_off;
+        char* l = sB + sl * kI8TileBytes + wave * 1024;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gB + off), (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+        if (wave == 0)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gB + (off + 8192u)),
+                                             (__attribute__((address_space(3))) void*)(l + 8192), 16, 0, 0);
+    };
+    auto wait_older_group = [&]() {
+        if (wave == 0) wait_vmcnt<2>();
+        else wait_vmcnt<1>();
+    };
+
+    dma_tile(t_begin);
+    dma_tile(t_begin + 1);
+    dma_tile(t_begin + 2);
+    if (PASS == 1) sCol[tid] = (int)0x80000000;   // 2 tiles x 4 classes x 64 columns = 512 ints
+
+    // A fragments: rows a_blk*512 + wave*64 + rb*32 + lcol, k-step ks = bytes 32 ks + 16 lhalf .. + 15
+    i4v af[kPfRB][4];
+#pragma unroll
+    for (int rb = 0; rb < kPfRB; ++rb) {
+        const int frow = item.a_blk * kPfWgRows + wave * kPfWaveRows + rb * 32 + lcol;
+        const char* arow = reinterpret_cast<const char*>(pp.a_h) + (size_t)frow * kI8RowBytes;
+        if (PASS == 3) {
+            const char* r = reinterpret_cast<const char*>(pp.a_rows[frow]);
+            arow = r ? r : reinterpret_cast<const char*>(pp.a_h);   // no source: the zero row
+        }
+        const gi4_p ga = (gi4_p)arow;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) af[rb][ks] = ga[2 * ks + lhalf];
+    }
+    // this lane's 32 result rows: (rb, r) -> row = a_blk*512 + wave*64 + rb*32 + (r&3) + 8*(r>>2) + 4*lhalf; their constants
+    const int arow_base = item.a_blk * kPfWgRows + wave * kPfWaveRows + 4 * lhalf;
+    i16v rowc[kPfRB];
+#pragma unroll
+    for (int rb = 0; rb < kPfRB; ++rb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int rr = arow_base + rb * 32 + (r & 3) + 8 * (r >> 2);
+            // PASS 1: -h_a (the norm array holds 2 h_a, +inf on padding rows).  PASS 3: floor((T - 2 h_a) / 2), T = +inf ->
+            // everything hits.  Unconditional loads (both arrays cover the padded rows): 32 loads in flight, not 32 round trips
+            const float x = PASS == 3 ? 0.5f * g_tu[pp.tu_off + rr] : -0.5f * g_anrm[rr];
+            const int c = rr < pd.n1 ? (int)floorf(fminf(fmaxf(x, -5.0e8f), 5.0e8f)) : kI8Pad;
+            rowc[rb][r] = c;
+        }
+    int rs0[kPfRB][16];   // PASS 1: running row maximum of the accumulator
+#pragma unroll
+    for (int rb = 0; rb < kPfRB; ++rb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) rs0[rb][r] = (int)0x80000000;
+    // pin the prologue loads before the loop (see sweep_kernel)
+#pragma unroll
+    for (int rb = 0; rb < kPfRB; ++rb) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) asm volatile("" ::"v"(af[rb][ks]));
+        asm volatile("" ::"v"(rowc[rb]));
+    }
+    wait_vmcnt<0>();
+
+    int2* cbuf = reinterpret_cast<int2*>(sCand) + wave * kPfCandBuf;
+    const unsigned cbuf_lds = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)cbuf;
+    int n_buf = 0;
+    auto flush_candidates = [&]() {
+        if (n_buf == 0) return;
+        unsigned long long base64 = 0;
+        if (lane == 0) base64 = atomicAdd(&cand_count[item.pair], (unsigned long long)n_buf);
+        const int base = __builtin_amdgcn_readfirstlane((int)(base64 < (unsigned long long)pp.cand_cap ? base64 : (unsigned long long)pp.cand_cap));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        for (int k = lane; k < n_buf; k += 64)
+            if (base + k < pp.cand_cap) cand[pp.cand_off + base + k] = cbuf[k];
+        n_buf = 0;
+    };
+
+    const bool wave_active = item.a_blk * kPfWgRows + wave * kPfWaveRows < pd.n1;
+
+    // B fragments of column block 0 of the tile in ring slot sl, and -h_b of this lane's column in both column blocks
+    const int lane_row_off = lcol * kI8RowBytes + lhalf * 16;
+    const int lane_ext_off = lcol * kI8RowBytes + kDim;
+    auto load_bf = [&](int sl, i4v (&bf)[4], int (&hb)[2]) {
+        const char* pb = sB + sl * kI8TileBytes + lane_row_off;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) bf[ks] = *reinterpret_cast<const i4v*>(pb + ks * 32);
+        const char* pe = sB + sl * kI8TileBytes + lane_ext_off;
+        hb[0] = *reinterpret_cast<const int*>(pe);
+        hb[1] = *reinterpret_cast<const int*>(pe + 32 * kI8RowBytes);
+    };
+    auto init_acc = [&](i16v (&acc)[kPfRB], int hb) {
+#pragma unroll
+        for (int rb = 0; rb < kPfRB; ++rb) acc[rb] = rowc[rb] - hb;
+    };
+    auto mfma_block = [&](const i4v (&bf)[4], i16v (&acc)[kPfRB]) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int rb = 0; rb < kPfRB; ++rb) acc[rb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[rb][ks], bf[ks], acc[rb], 0, 0, 0);
+    };
+    // column block 0 on the fragments in `bf`; each k-step's registers then take the fragment of column block 1
+    auto mfma_block_reload = [&](int sl, i4v (&bf)[4], i16v (&acc)[kPfRB]) {
+        const char* pb = sB + sl * kI8TileBytes + 32 * kI8RowBytes + lane_row_off;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+            for (int rb = 0; rb < kPfRB; ++rb) acc[rb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[rb][ks], bf[ks], acc[rb], 0, 0, 0);
+            bf[ks] = *reinterpret_cast<const i4v*>(pb + ks * 32);
+        }
+    };
+    auto column_max = [&](const i16v (&acc)[kPfRB]) -> int {
+        int m[kPfRB];
+#pragma unroll
+        for (int rb = 0; rb < kPfRB; ++rb) {
+            m[rb] = max3i(acc[rb][0], acc[rb][1], acc[rb][2]);
+#pragma unroll
+            for (int r = 3; r < 15; r += 2) m[rb] = max3i(m[rb], acc[rb][r], acc[rb][r + 1]);
+            m[rb] = max(m[rb], acc[rb][15]);
+        }
+        return kPfRB == 2 ? max(m[0], m[1]) : m[0];
+    };
+    // compacted sweep: a hit is accumulator >= 0, sign bit clear (see scan_hits3 of sweep_kernel)
+    auto scan_hits3 = [&](const i16v (&a0)[kPfRB], const i16v (&a1)[kPfRB], int col0) {
+        unsigned nm[2] = {0u, 0u};
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+            for (int rb = 0; rb < kPfRB; ++rb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) nm[blk] = __builtin_amdgcn_alignbit(nm[blk], (unsigned)(blk ? a1 : a0)[rb][r], 31);
+        static_assert(kPfRB == 2, "32 elements per column block and mask");
+#pragma unroll 1
+        for (int blk = 0; blk < 2; ++blk) {
+            unsigned hm = ~(blk ? nm[1] : nm[0]);
+            const int col = col0 + blk * 32;
+            for (unsigned long long mm = __ballot(hm != 0u); mm != 0ull; mm = __ballot(hm != 0u)) {
+                const bool hit = hm != 0u;
+                const int k = __clz((int)hm);
+                if (n_buf + 64 > kPfCandBuf) flush_candidates();
+                if (hit) {
+                    hm &= ~(0x80000000u >> k);
+                    const int slt = n_buf + __popcll(mm & ((1ull << lane) - 1ull));
+                    const int2 e = make_int2(arow_base + (k >> 4) * 32 + (k & 3) + 8 * ((k & 15) >> 2), col);
+                    asm volatile("ds_write_b64 %0, %1" ::"v"(cbuf_lds + slt * 8), "v"(e) : "memory");
+                }
+                n_buf += __popcll(mm);
+            }
+        }
+    };
+    // sweep 1, columns: one LDS atomic per column block into the tile's class array (see sweep_kernel)
+    const unsigned col_lds = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)sCol +
+                             (unsigned)((2 * (wave & 1) + lhalf) * kPfBT + lcol) * 4u;
+    auto fold_columns = [&](int mA, int mB, int cs) {
+        const unsigned a = col_lds + (unsigned)cs * (kPfBT * kPfColClasses * 4);
+        asm volatile("ds_max_i32 %0, %1\n\tds_max_i32 %0, %2 offset:128" ::"v"(a), "v"(mA), "v"(mB) : "memory");
+    };
+    const unsigned colrow_lds = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)sCol + (unsigned)lane * 4u;
+    auto store_columns = [&](int tt) {
+        const unsigned a = colrow_lds + (unsigned)((tt - t_begin) & 1) * (kPfBT * kPfColClasses * 4);
+        i4v v;
+        const int reset = (int)0x80000000;
+        asm volatile("ds_read_b32 %0, %4\n\tds_read_b32 %1, %4 offset:256\n\tds_read_b32 %2, %4 offset:512\n\tds_read_b32 %3, %4 offset:768\n\t"
+                     "s_waitcnt lgkmcnt(0)\n\t"
+                     "ds_write_b32 %4, %5\n\tds_write_b32 %4, %5 offset:256\n\tds_write_b32 %4, %5 offset:512\n\tds_write_b32 %4, %5 offset:768"
+                     : "=&v"(v.x), "=&v"(v.y), "=&v"(v.z), "=&v"(v.w) : "v"(a), "v"(reset) : "memory");
+        v4f f;   // the float pipeline's format: accumulator maxima (-S~/2), -inf where the class saw no real row
+        f.x = v.x > kI8PadTest ? (float)v.x : -f_inf();
+        f.y = v.y > kI8PadTest ? (float)v.y : -f_inf();
+        f.z = v.z > kI8PadTest ? (float)v.z : -f_inf();
+        f.w = v.w > kI8PadTest ? (float)v.w : -f_inf();
+        reinterpret_cast<v4f*>(cp_s0)[pd.cp_off + (long long)item.a_blk * pd.n2pad + tt * kPfBT + lane] = f;
+    };
+
+    lds_barrier();
+    i4v bf[4];
+    int hb[2];
+    if (wave_active) load_bf(0, bf, hb);
+    if (grp == 1) lds_barrier();
+
+    i16v accA[kPfRB], accB[kPfRB];
+    MSFM_PROBE_BEGIN
+#pragma unroll 1
+    for (int t = t_begin; t < t_end; ++t) {
+        const int sl = (t - t_begin) & (kPfRing - 1);
+        // ---- MFMA phase ----------------------------------------------------------------------------------------
+        if (wave_active) {
+            __builtin_amdgcn_s_setprio(1);
+            init_acc(accA, hb[0]);
+            mfma_block_reload(sl, bf, accA);
+            init_acc(accB, hb[1]);
+            mfma_block(bf, accB);
+            __builtin_amdgcn_s_setprio(0);
+        }
+        MSFM_PROBE(0)
+        if (grp == 0) wait_older_group();
+        lds_barrier();
+        MSFM_PROBE(1)
+        // ---- EPI phase -----------------------------------------------------------------------------------------
+        if (PASS == 1 && grp == 0 && t > t_begin && wave == ((t - t_begin) & 3)) store_columns(t - 1);
+        dma_tile(t + 3);
+        if (wave_active) {
+            if (PASS == 1) {
+                fold_columns(column_max(accA), column_max(accB), (t - t_begin) & 1);
+#pragma unroll
+                for (int rb = 0; rb < kPfRB; ++rb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) rs0[rb][r] = max3i(rs0[rb][r], accA[rb][r], accB[rb][r]);
+            } else {
+                scan_hits3(accA, accB, t * kPfBT + lcol);
+            }
+        }
+        if (wave_active && t + 1 < t_end) load_bf((sl + 1) & (kPfRing - 1), bf, hb);
+        MSFM_PROBE(2)
+        if (grp == 1) wait_older_group();
+        lds_barrier();
+        MSFM_PROBE(3)
+    }
+    MSFM_PROBE_END
+    if (grp == 0) lds_barrier();
+    if (PASS == 3) flush_candidates();
+    if (PASS == 1 && wave == 0) store_columns(t_end - 1);
+
+    if (PASS == 1) {
+        // rows: S~ = -2 * accumulator as a float (exact); the two smallest of the 32 lanes' minima
+        float fs0[kPfRB][16], fs1[kPfRB][16];
+#pragma unroll
+        for (int rb = 0; rb < kPfRB; ++rb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                fs0[rb][r] = rs0[rb][r] > kI8PadTest ? (float)(-2 * rs0[rb][r]) : f_inf();
+                fs1[rb][r] = f_inf();
+#pragma unroll
+                for (int m = 1; m < 32; m <<= 1)
+                    v2_merge(fs0[rb][r], fs1[rb][r], __shfl_xor(fs0[rb][r], m), __shfl_xor(fs1[rb][r], m));
+            }
+        if (lcol == 0) {
+            const long long o = pd.rp_off + (long long)item.range * pd.n1pad + arow_base;
+#pragma unroll
+            for (int rb = 0; rb < kPfRB; ++rb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int off = rb * 32 + (r & 3) + 8 * (r >> 2);
+                    rp_s0[o + off] = fs0[rb][r];
+                    rp_s1[o + off] = fs1[rb][r];
+                }
+        }
+    }
+    }   // item loop
+}

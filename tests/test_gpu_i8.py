@@ -1,0 +1,138 @@
+"""Byte stores on the integer matrix cores (monocularsfm_amd/csrc/msfm_sweep_i8.hip.h): the three routes -- i8 MFMA
+prefilter, fp16 MFMA prefilter, brute-force exact kernel -- must return the same bits, and those must be the exact-integer
+reference's (oracle/int_oracle.py: on 0..255 data the reference's fp32 arithmetic is exact integer arithmetic,
+/root/reference/src/Feature/FeatureMatching.cpp:171-190 through cv::BFMatcher)."""
+import numpy as np
+import pytest
+
+from monocularsfm_amd import synth
+
+pytestmark = pytest.mark.gpu
+F32 = np.float32
+I8, F16, BRUTE = 1, 2, 0
+
+
+def b(a):
+    a = np.asarray(a)
+    return a.view(np.int32) if a.dtype == np.float32 else a
+
+
+def same_result(x, y):
+    return np.array_equal(x[0], y[0]) and np.array_equal(x[1], y[1]) and np.array_equal(b(x[2]), b(y[2]))
+
+
+def run_modes(ctx, pairs, **kw):
+    out = {}
+    try:
+        for mode in (I8, F16, BRUTE):
+            ctx.set_prefilter(mode)
+            out[mode] = ctx.match_pairs(pairs, **kw)
+            out[mode, "i8"] = ctx.profile()["sweep1_i8_launches"]   # (the profile describes the last call)
+    finally:
+        ctx.set_prefilter(True)
+    return out
+
+
+def check_vs_int_reference(u, pairs, res, **kw):
+    from oracle import int_oracle as io
+    offs, qt, d = res
+    total = 0
+    for p, (i, j) in enumerate(pairs):
+        q, t, dd = io.match_pair(u[i], u[j], **kw)
+        s, e = offs[p], offs[p + 1]
+        assert np.array_equal(qt[s:e, 0], q) and np.array_equal(qt[s:e, 1], t) and np.array_equal(b(d[s:e]), b(dd)), (i, j, kw)
+        total += len(q)
+    return total
+
+
+def test_three_routes_agree_with_the_integer_reference(gpu_ctx):
+    """Ragged sizes (below one wave, one row, not a multiple of anything, an empty image), duplicates (ties), rows of all
+    0 / all 255 (the extreme shifted norms 2^21 and 127^2 * 128), pairs of an image with itself excluded."""
+    sizes = [700, 513, 64, 1, 1290, 33, 0, 2049]
+    u = synth.u8_images(len(sizes), sizes, seed=808, dup_frac=0.15, as_float=False)
+    u[0][5] = 0
+    u[0][6] = 255
+    u[1][9] = 0
+    u[1][10] = 255
+    u[4][100] = u[0][7]
+    u[4][101] = u[0][7]          # two identical train rows: a distance tie for query 7 of image 0
+    pairs = synth.all_pairs(len(sizes))
+    for i, im in enumerate(u):
+        gpu_ctx.upload_image(i, im)
+    for kw in ({"ratio": 0.8, "cross_check": True, "max_distance": 1e9},
+               {"ratio": 0.9, "cross_check": False, "max_distance": 500.0},
+               {"ratio": 0.6, "cross_check": True, "max_distance": 300.0}):
+        r = run_modes(gpu_ctx, pairs, **kw)
+        assert r[I8, "i8"] >= 1 and r[F16, "i8"] == 0 and r[BRUTE, "i8"] == 0
+        assert same_result(r[I8], r[F16]) and same_result(r[I8], r[BRUTE]), kw
+        n = check_vs_int_reference(u, pairs, r[I8], **kw)
+        assert n > 100, "test data: the pairs should have matches"
+    gpu_ctx.clear_images()
+
+
+def test_candidate_sets_are_tighter_on_the_integer_cores(gpu_ctx):
+    """eps = 2 instead of ~1.5e-3 (n_a + n_b): the exact re-check sees fewer candidates, same result."""
+    u = synth.u8_images(4, 3000, seed=31, as_float=False)
+    pairs = synth.all_pairs(4)
+    for i, im in enumerate(u):
+        gpu_ctx.upload_image(i, im)
+    cands = {}
+    try:
+        res = {}
+        for mode in (I8, F16):
+            gpu_ctx.set_prefilter(mode)
+            res[mode] = gpu_ctx.match_pairs(pairs, ratio=0.8, cross_check=True, max_distance=1e9)
+            cands[mode] = gpu_ctx.profile()["candidates"]
+    finally:
+        gpu_ctx.set_prefilter(True)
+    assert same_result(res[I8], res[F16])
+    assert 0 < cands[I8] <= cands[F16], cands
+    gpu_ctx.clear_images()
+
+
+def test_mixed_batch_takes_the_fp16_kernels(gpu_ctx, oracle):
+    """A batch that joins a byte image with a float image cannot use the integer cores; a float upload of byte VALUES
+    is a float image.  The result does not depend on it."""
+    u = synth.u8_images(3, [800, 900, 700], seed=5, as_float=False)
+    gpu_ctx.upload_image(0, u[0])
+    gpu_ctx.upload_image(1, u[1].astype(F32))
+    gpu_ctx.upload_image(2, u[2])
+    kw = {"ratio": 0.8, "cross_check": True, "max_distance": 1e9}
+    pairs = synth.all_pairs(3)
+    mixed = gpu_ctx.match_pairs(pairs, **kw)
+    assert gpu_ctx.profile()["sweep1_i8_launches"] == 0
+    check_vs_int_reference(u, pairs, mixed, **kw)
+    only_bytes = gpu_ctx.match_pairs(np.array([[2, 0]], np.int32), **kw)
+    assert gpu_ctx.profile()["sweep1_i8_launches"] == 1
+    check_vs_int_reference(u, [(2, 0)], only_bytes, **kw)
+    gpu_ctx.clear_images()
+
+
+def test_subsets_of_byte_images_stay_bytes(gpu_ctx):
+    """msfm_subset_image (the top-scale subsets of the pre-emptive filter) of a byte image is a byte image."""
+    from monocularsfm_amd.matcher import AUX0
+    u = synth.u8_images(2, [1500, 1400], seed=77, dup_frac=0.2, as_float=False)
+    rng = np.random.default_rng(3)
+    rows = [np.sort(rng.choice(len(x), 600, replace=False)).astype(np.int32) for x in u]
+    for i, im in enumerate(u):
+        gpu_ctx.upload_image(i, im)
+        gpu_ctx.subset_image(i, AUX0 + i, rows[i])
+    a, bb = AUX0, AUX0 + 1
+    kw = {"ratio": 0.8, "cross_check": True, "max_distance": 1e9}
+    res = gpu_ctx.match_pairs(np.array([[a, bb]], np.int32), **kw)
+    assert gpu_ctx.profile()["sweep1_i8_launches"] == 1
+    check_vs_int_reference({a: u[0][rows[0]], bb: u[1][rows[1]]}, [(a, bb)], res, **kw)
+    gpu_ctx.clear_images()
+
+
+def test_full_size_byte_pair_on_all_routes(gpu_ctx):
+    """16384 x 16384 (BASELINE config 5's shape): 32 work items per direction, several mask bits in the reverse plan."""
+    u = synth.u8_images(2, 16384, seed=4096, as_float=False)
+    for i, im in enumerate(u):
+        gpu_ctx.upload_image(i, im)
+    kw = {"ratio": 0.8, "cross_check": True, "max_distance": 1e9}
+    r = run_modes(gpu_ctx, np.array([[0, 1]], np.int32), **kw)
+    assert r[I8, "i8"] == 1
+    assert same_result(r[I8], r[F16]) and same_result(r[I8], r[BRUTE])
+    assert len(r[I8][1]) > 500
+    gpu_ctx.clear_images()

@@ -1,4 +1,5 @@
 #!/bin/bash
+# VB_WORKLOAD=u8: byte images (integer-core sweeps).
 # usage: tools/variant_bench.sh "<name>=<extra hipcc flags>" ...   -> sweep times of each build on the 32 x 5000 job
 set -u
 ROOT=$(pwd)
@@ -13,7 +14,10 @@ python - "${names[@]}" <<'PY'
 import sys, ctypes, numpy as np
 sys.path.insert(0, '.')
 from monocularsfm_amd import _lib, synth
-imgs = synth.rootsift_images(32, 5000, seed=11)
+import os
+U8 = os.environ.get("VB_WORKLOAD", "") == "u8"     # byte store: the integer-core sweeps
+imgs = synth.u8_images(32, 5000, seed=11, as_float=False) if U8 else synth.rootsift_images(32, 5000, seed=11)
+kw = {"max_distance": 1e9} if U8 else {}
 pairs = np.array([(i, j) for i in range(32) for j in range(i)], np.int32)
 names = sys.argv[1:]
 ctxs = {}
@@ -29,7 +33,7 @@ same = {}
 for rnd in range(30):
     for name in names:
         ctx = ctxs[name]
-        offs, qt, d = ctx.match_pairs(pairs)
+        offs, qt, d = ctx.match_pairs(pairs, **kw)
         p = ctx.profile()
         if rnd >= 5:
             res[name][0].append(p["approx_kernel_ms"]); res[name][1].append(p["sweep2_ms"])
