@@ -50,7 +50,7 @@ def pmc_traffic():
             d = json.load(open(path))
             per = {n: 2.0 * k["FETCH_SIZE"]["per_launch_KB_mean"] * 1024 + k["WRITE_SIZE"]["per_launch_KB_mean"] * 1024
                    for n, k in d.items()}
-            name = [n for n in per if n.startswith("approx_kernel<1>") or n.startswith("sweep1")][0]
+            name = [n for n in per if n.startswith(("approx_kernel<1>", "sweep1", "sweep_kernel<1>"))][0]
             return {"bytes_per_launch": per[name], "source": os.path.relpath(path, ROOT), "per_kernel_bytes": per}
         except (OSError, KeyError, ValueError, IndexError):
             continue

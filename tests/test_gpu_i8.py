@@ -136,3 +136,19 @@ def test_full_size_byte_pair_on_all_routes(gpu_ctx):
     assert same_result(r[I8], r[F16]) and same_result(r[I8], r[BRUTE])
     assert len(r[I8][1]) > 500
     gpu_ctx.clear_images()
+
+
+def test_golden_byte_fixture_through_the_integer_cores(gpu_ctx):
+    """tests/golden/u8_int64_400x380.npz (made by tests/golden/make_golden.py: C oracle == exact int64 reference): the
+    match lists of the byte upload on the default route, which must be the integer-core one."""
+    import glob
+    import os
+    g = np.load(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "u8_int64_400x380.npz"))[0])
+    gpu_ctx.upload_image(0, g["desc1"])
+    gpu_ctx.upload_image(1, g["desc2"])
+    md = float(g["max_distance"])
+    for cc in (1, 0):
+        q, t, d = gpu_ctx.match_pair(0, 1, 0.8, bool(cc), md)
+        assert gpu_ctx.profile()["sweep1_i8_launches"] == 1
+        assert np.array_equal(q, g["o0_cc%d_q" % cc]) and np.array_equal(t, g["o0_cc%d_t" % cc]) and np.array_equal(b(d), b(g["o0_cc%d_d" % cc]))
+    gpu_ctx.clear_images()

@@ -17,6 +17,6 @@ timeout 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- 
 cd $ROOT
 DB=$(find $OUT/prof_stats -name '*.db' | head -1)
 python tools/rocprof_summary.py "$DB" "$BENCH" > $OUT/kernel_stats.txt 2>&1; head -12 $OUT/kernel_stats.txt | cut -c1-170
-python tools/pmc_summary.py $OUT/pmc_traffic.json "sweep_kernel<1>,sweep_kernel<2>,sweep_kernel<3>" $OUT/pmc_fetch $OUT/pmc_write | tail -40
+python tools/pmc_summary.py $OUT/pmc_traffic.json "sweep_kernel<1>,sweep_kernel<3>,sweep_i8_kernel<1>,sweep_i8_kernel<3>,pf_thresholds_kernel,pf_exact_candidates_kernel" $OUT/pmc_fetch $OUT/pmc_write | tail -40
 # keep the merge-back small
 find $OUT/prof_stats $OUT/pmc_fetch $OUT/pmc_write -type f -size +8M -delete
