@@ -239,7 +239,16 @@ struct Batch {
 // same B panels share one L2.
 void build_items(Batch& b, int path) {
     std::vector<WorkItem> lin;
-    for (size_t p = 0; p < b.pairs.size(); ++p) {
+    // Pairs in the order of their STREAMED image (id2): the 32 workgroups of an XCD walk 32 consecutive items of their
+    // chunk at a time, and those then stream the same B image -- one image (1.4 MB at 5000 rows) stays in the XCD's 4 MB
+    // L2 while ~30 workgroups read it, instead of three or four images evicting one another (pair order = id1-major:
+    // measured 69 GB of L2 misses per sweep-1 launch on the bench job against 11 GB of distinct B bytes).
+    std::vector<int> order(b.pairs.size());
+    for (size_t p = 0; p < order.size(); ++p) order[p] = (int)p;
+    if (b.id2.size() == b.pairs.size())
+        std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return b.id2[(size_t)x] < b.id2[(size_t)y]; });
+    for (size_t q = 0; q < order.size(); ++q) {
+        const size_t p = (size_t)order[q];
         PairDesc& pd = b.pairs[p];
         if (!pd.valid || pd.path != path) continue;
         for (int r = 0; r < pd.ranges; ++r) {
@@ -548,8 +557,8 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
     const long long kn = std::max<long long>(1, b.kf_elems + b.kr_elems);
     HIPCHK(ctx, ctx->d_rp_s0.ensure(std::max<long long>(1, b.rp_elems) * 4));
     HIPCHK(ctx, ctx->d_rp_s1.ensure(std::max<long long>(1, b.rp_elems) * 4));
-    // column partials of sweep 1: one float4 (four row-class maxima) per 512-row A block and column
-    HIPCHK(ctx, ctx->d_cp_s0.ensure(std::max<long long>(1, b.cp_elems) * 16));
+    // column partials of sweep 1: one float2 (the two largest of four row-class maxima) per 512-row A block and column
+    HIPCHK(ctx, ctx->d_cp_s0.ensure(std::max<long long>(1, b.cp_elems) * 8));
     HIPCHK(ctx, ctx->d_tu.ensure(kn * 4));
     HIPCHK(ctx, ctx->d_colmask.ensure(kn * 4));
     HIPCHK(ctx, ctx->d_best.ensure(kn * 8));
@@ -666,7 +675,7 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
         po.rows_cap = rows_cap;
         po.cand_cap = cand_cap;
         po.items_cap = items_cap;
-        hipLaunchKernelGGL(pf_plan_kernel, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_groups.as<PlanGroup>(), (int)G,
+        hipLaunchKernelGGL(pf_plan_kernel, dim3(1), dim3(kPlanThreads), 0, ctx->stream, ctx->d_groups.as<PlanGroup>(), (int)G,
                            (const int*)ctx->d_gmembers.as<int>(), (const int*)ctx->d_cnt.as<int>(), po);
         HIPCHK(ctx, hipGetLastError());
         DBGSYNC(ctx, "pf_plan_kernel");

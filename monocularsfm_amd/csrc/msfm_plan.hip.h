@@ -87,7 +87,8 @@ __global__ void pf_count_kernel(const PairDesc* __restrict__ pairs, const PfPair
     }
 }
 
-// One workgroup of 1024 threads.  All loops are strided over groups / members; the two exclusive scans (rows and work
+constexpr int kPlanThreads = 512;   // (1024 would halve the registers per thread: the per-XCD totals then spill)
+// One workgroup of kPlanThreads threads.  All loops are strided over groups / members; the two exclusive scans (rows and work
 // items / candidate capacity over groups) run as chunked scans through LDS.
 struct PlanOut {
     PairDesc* vpairs;         // [n_groups] sweep descriptors
@@ -104,7 +105,7 @@ struct PlanOut {
 };
 
 __device__ __forceinline__ long long plan_block_exclusive_scan(long long v, long long* total) {
-    // exclusive scan of one value per thread over the 1024-thread workgroup
+    // exclusive scan of one value per thread over the workgroup (<= 1024 threads)
     __shared__ long long wsum[16];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     long long inc = v;
@@ -116,7 +117,7 @@ __device__ __forceinline__ long long plan_block_exclusive_scan(long long v, long
     if (lane == 63) wsum[w] = inc;
     __syncthreads();
     long long base = 0, tot = 0;
-    for (int k = 0; k < 16; ++k) {
+    for (int k = 0; k < (int)(blockDim.x >> 6); ++k) {
         if (k < w) base += wsum[k];
         tot += wsum[k];
     }
@@ -125,7 +126,7 @@ __device__ __forceinline__ long long plan_block_exclusive_scan(long long v, long
     return base + inc - v;
 }
 
-__global__ __launch_bounds__(1024) void pf_plan_kernel(const PlanGroup* __restrict__ groups, int n_groups,
+__global__ __launch_bounds__(kPlanThreads) void pf_plan_kernel(const PlanGroup* __restrict__ groups, int n_groups,
                                                          const int* __restrict__ gmembers, const int* __restrict__ cnt, PlanOut out) {
     const int tid = threadIdx.x, nt = blockDim.x;
     __shared__ long long s_base_rows, s_base_cand, s_base_items[8], s_base_rev[8];

@@ -219,16 +219,13 @@ __global__ void pf_thresholds_kernel(const PairDesc* __restrict__ pairs, const P
         tu[pp.tu_off + e] = live ? s1 + slack : -f_inf();
     }
     if (e < pd.n2pad) {
-        // column partials of sweep 1: per 512-row A block the accumulator maxima (-S~/2) over four disjoint row classes;
-        // the second smallest of all class minima is an upper bound of the column's second-smallest S~
+        // column partials of sweep 1: per 512-row A block the two largest of the accumulator maxima (-S~/2) over four
+        // disjoint row classes; the second smallest S~ over all of them is an upper bound of the column's second-smallest
         float s0 = f_inf(), s1 = f_inf();
-        const float4* cp4 = reinterpret_cast<const float4*>(cp_s0);
+        const float2* cp2 = reinterpret_cast<const float2*>(cp_s0);
         for (int p = 0; p < pd.a_blocks256; ++p) {
-            const float4 m = cp4[pd.cp_off + (long long)p * pd.n2pad + e];
-            v2_merge(s0, s1, -2.f * m.x, f_inf());
-            v2_merge(s0, s1, -2.f * m.y, f_inf());
-            v2_merge(s0, s1, -2.f * m.z, f_inf());
-            v2_merge(s0, s1, -2.f * m.w, f_inf());
+            const float2 m = cp2[pd.cp_off + (long long)p * pd.n2pad + e];
+            v2_merge(s0, s1, -2.f * m.x, -2.f * m.y);
         }
         const float nb = pp.b_nrm[e];
         const float eps = pp.i8 ? kI8Eps : kEpsRel * (nb + pp.a_nrm_max) + kEpsAbs * (sqrtf(nb) + sqrtf(pp.a_nrm_max)) + eps_norm;
@@ -244,8 +241,7 @@ __global__ void pf_thresholds_kernel(const PairDesc* __restrict__ pairs, const P
             unsigned mask = 0;
             if (live)
                 for (int p = 0; p < pd.a_blocks256; ++p) {
-                    const float4 m = cp4[pd.cp_off + (long long)p * pd.n2pad + e];
-                    const float smin = -2.f * fmaxf(fmaxf(m.x, m.y), fmaxf(m.z, m.w));
+                    const float smin = -2.f * cp2[pd.cp_off + (long long)p * pd.n2pad + e].x;
                     if (smin <= T) mask |= 1u << (p / g);
                 }
             colmask[pp.tv_off + e] = mask;

@@ -410,7 +410,13 @@ __global__ __launch_bounds__(kPfThreads, 2) void sweep_kernel(
                      "s_waitcnt lgkmcnt(0)\n\t"
                      "ds_write_b32 %4, %5\n\tds_write_b32 %4, %5 offset:256\n\tds_write_b32 %4, %5 offset:512\n\tds_write_b32 %4, %5 offset:768"
                      : "=&v"(v.x), "=&v"(v.y), "=&v"(v.z), "=&v"(v.w) : "v"(a), "v"(ninf) : "memory");
-        reinterpret_cast<v4f*>(cp_s0)[pd.cp_off + (long long)item.a_blk * pd.n2pad + tt * kPfBT + lane] = v;
+        // only the two largest of the four class maxima travel (the thresholds need the block's smallest S~ and an upper
+        // bound of its second smallest): 8 B per column and A block
+        const float m01 = fmaxf(v.x, v.y), n01 = fminf(v.x, v.y), m23 = fmaxf(v.z, v.w), n23 = fminf(v.z, v.w);
+        v2f o;
+        o.x = fmaxf(m01, m23);
+        o.y = fmaxf(fminf(m01, m23), fmaxf(n01, n23));
+        reinterpret_cast<v2f*>(cp_s0)[pd.cp_off + (long long)item.a_blk * pd.n2pad + tt * kPfBT + lane] = o;
     };
 
     lds_barrier();   // every wave's share of tiles 0..2 (and the column class arrays) is in LDS

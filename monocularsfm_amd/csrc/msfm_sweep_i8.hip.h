@@ -282,12 +282,14 @@ __global__ __launch_bounds__(kPfThreads, 2) void sweep_i8_kernel(
                      "s_waitcnt lgkmcnt(0)\n\t"
                      "ds_write_b32 %4, %5\n\tds_write_b32 %4, %5 offset:256\n\tds_write_b32 %4, %5 offset:512\n\tds_write_b32 %4, %5 offset:768"
                      : "=&v"(v.x), "=&v"(v.y), "=&v"(v.z), "=&v"(v.w) : "v"(a), "v"(reset) : "memory");
-        v4f f;   // the float pipeline's format: accumulator maxima (-S~/2), -inf where the class saw no real row
-        f.x = v.x > kI8PadTest ? (float)v.x : -f_inf();
-        f.y = v.y > kI8PadTest ? (float)v.y : -f_inf();
-        f.z = v.z > kI8PadTest ? (float)v.z : -f_inf();
-        f.w = v.w > kI8PadTest ? (float)v.w : -f_inf();
-        reinterpret_cast<v4f*>(cp_s0)[pd.cp_off + (long long)item.a_blk * pd.n2pad + tt * kPfBT + lane] = f;
+        // the float pipeline's format: the two largest of the four class maxima of the accumulator (-S~/2), -inf where a
+        // class saw no real row
+        const int m01 = max(v.x, v.y), n01 = min(v.x, v.y), m23 = max(v.z, v.w), n23 = min(v.z, v.w);
+        const int hi = max(m01, m23), lo = max(min(m01, m23), max(n01, n23));
+        v2f o;
+        o.x = hi > kI8PadTest ? (float)hi : -f_inf();
+        o.y = lo > kI8PadTest ? (float)lo : -f_inf();
+        reinterpret_cast<v2f*>(cp_s0)[pd.cp_off + (long long)item.a_blk * pd.n2pad + tt * kPfBT + lane] = o;
     };
 
     lds_barrier();
