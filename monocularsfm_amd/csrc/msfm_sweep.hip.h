@@ -254,8 +254,9 @@ __global__ __launch_bounds__(kPfThreads, 2) void sweep_kernel(
     // B fragments of the tile in ring slot sl: the 8 data k-steps of column block 0 (row lcol of the slot, granule
     // 2 ks + lhalf: a constant offset from the lane's row address), and the ninth k-step of BOTH column blocks -- the first
     // 8 bytes of the row's 17th granule ([h_hi, h_lo, c, c] = k 128..131) in the lhalf == 0 lanes, its zero half
-    // (k 132..135) in the others.  The quadruple only fills k = 0..3 of its k-step: the K = 8 instruction (lane l:
-    // k = 4 (l >> 5) .. +3) takes half the passes of a K = 16 one.
+    // (k 132..135) in the others.  The quadruple only fills k = 0..3 of its k-step, so the K = 8 instruction (lane l:
+    // k = 4 (l >> 5) .. +3) carries it with half the operand registers; it occupies the pipe as long as a K = 16 one
+    // (32 cycles, tools/ubench_clock.hip), i.e. the norm k-step is 4 of a tile's 36 MFMA slots.
     typedef _Float16 h4 __attribute__((ext_vector_type(4)));
     const int lane_row_off = lcol * kPfRowBytes + lhalf * 16;
     const int lane_ext_off = lcol * kPfRowBytes + 2 * kDim + lhalf * 8;

@@ -26,6 +26,40 @@ __global__ __launch_bounds__(256) void k_mfma(float* out, unsigned long long* ti
     if (threadIdx.x == 0 && blockIdx.x == 0) ticks[0] = t1 - t0;
 }
 
+// other matrix instructions, same 4-chain loop: ticks per instruction
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef int i4v __attribute__((ext_vector_type(4)));
+typedef int i16v __attribute__((ext_vector_type(16)));
+template <int KIND>
+__global__ __launch_bounds__(256) void k_mfma_kind(float* out, unsigned long long* ticks, int iters, unsigned seed) {
+    unsigned x = seed + threadIdx.x * 2654435761u + blockIdx.x * 40503u;
+    h4 a4, b4;
+    i4v ai, bi;
+    for (int i = 0; i < 4; ++i) {
+        x = x * 1664525u + 1013904223u; a4[i] = (_Float16)((x >> 8) * (1.f / 16777216.f)); ai[i] = (int)x;
+        x = x * 1664525u + 1013904223u; b4[i] = (_Float16)((x >> 8) * (1.f / 16777216.f)); bi[i] = (int)x;
+    }
+    f16v c[4];
+    i16v d[4];
+    for (int k = 0; k < 4; ++k)
+        for (int r = 0; r < 16; ++r) { c[k][r] = 0.f; d[k][r] = 0; }
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (KIND == 0) c[k] = __builtin_amdgcn_mfma_f32_32x32x8f16(a4, b4, c[k], 0, 0, 0);
+            if (KIND == 1) d[k] = __builtin_amdgcn_mfma_i32_32x32x32_i8(ai, bi, d[k], 0, 0, 0);
+            if (KIND == 2) d[k] = __builtin_amdgcn_mfma_i32_32x32x16_i8(((long*)&ai)[0], ((long*)&bi)[0], d[k], 0, 0, 0);
+        }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    float r = 0;
+    for (int k = 0; k < 4; ++k)
+        for (int i = 0; i < 16; ++i) r += c[k][i] + (float)d[k][i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = r;
+    if (threadIdx.x == 0 && blockIdx.x == 0) ticks[0] = t1 - t0;
+}
+
 __global__ __launch_bounds__(256) void k_valu(float* out, unsigned long long* ticks, int iters, unsigned seed) {
     float v[8];
     for (int i = 0; i < 8; ++i) v[i] = threadIdx.x * 0.001f + i + seed;
@@ -64,5 +98,19 @@ int main() {
                    kind == 0 ? "MFMA-only (4 chains, random fp16)" : "VALU-only (8 chains v_fma)    ", blocks_per_cu, ms, t / n_inst, t / (ms * 1e3),
                    ms * 1e6 / n_inst);
         }
+    const char* names[3] = {"v_mfma_f32_32x32x8_f16 (legacy K=8) ", "v_mfma_i32_32x32x32_i8             ", "v_mfma_i32_32x32x16_i8 (legacy)    "};
+    for (int kind = 0; kind < 3; ++kind) {
+        const int iters = 100000;
+        for (int rep = 0; rep < 2; ++rep) {
+            (void)hipEventRecord(e0);
+            if (kind == 0) hipLaunchKernelGGL(k_mfma_kind<0>, dim3(p.multiProcessorCount), dim3(256), 0, 0, out, ticks, iters, 7u);
+            if (kind == 1) hipLaunchKernelGGL(k_mfma_kind<1>, dim3(p.multiProcessorCount), dim3(256), 0, 0, out, ticks, iters, 7u);
+            if (kind == 2) hipLaunchKernelGGL(k_mfma_kind<2>, dim3(p.multiProcessorCount), dim3(256), 0, 0, out, ticks, iters, 7u);
+            (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+        }
+        float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+        unsigned long long t; (void)hipMemcpy(&t, ticks, 8, hipMemcpyDeviceToHost);
+        printf("%s waves/SIMD=1: %.3f ms wall, %.2f ticks per instruction, %.1f ticks per microsecond\n", names[kind], ms, t / (iters * 4.0), t / (ms * 1e3));
+    }
     return 0;
 }
