@@ -261,8 +261,33 @@ MSFM_UNROLL
 // The adaptive iteration count of the sequential RANSAC, replayed over per-hypothesis inlier counts:
 // returns the index of the winning hypothesis (-1: none reached 8 inliers) -- what a loop
 // "for it < iters: if count[it] > best: best = count[it]; iters = min(iters, need(best))" ends with.
-template <typename CountFn, typename LogFn>
-MSFM_HD int replay_adaptive(int n, int max_iters, double confidence, CountFn count_at, LogFn logfn, int* best_count_out) {
+// Natural logarithm from + - x / and bit operations only: the host twin and the device must agree on ceil(need) below,
+// and libm's log and the device library's log are different functions.  x > 0, finite, normal.
+// x = m 2^e with m in [sqrt(1/2), sqrt(2)); log m = 2 atanh(y), y = (m - 1) / (m + 1), |y| < 0.172: 20 odd terms reach
+// 1e-32 relative -- far below the double rounding of the sum.
+MSFM_HD double det_log(double x) {
+    unsigned long long bits;
+    static_assert(sizeof(bits) == sizeof(x), "64-bit double");
+    __builtin_memcpy(&bits, &x, 8);
+    int e = (int)((bits >> 52) & 0x7ff) - 1023;
+    bits = (bits & 0x000fffffffffffffull) | 0x3ff0000000000000ull;
+    double m;
+    __builtin_memcpy(&m, &bits, 8);        // [1, 2)
+    if (m > 1.4142135623730951) {
+        m = m * 0.5;
+        e += 1;
+    }
+    const double y = (m - 1.0) / (m + 1.0), y2 = y * y;
+    double term = y, sum = 0.0;
+    for (int k = 0; k < 20; ++k) {
+        sum = sum + term / (double)(2 * k + 1);
+        term = term * y2;
+    }
+    return 2.0 * sum + (double)e * 0.6931471805599453;
+}
+
+template <typename CountFn>
+MSFM_HD int replay_adaptive(int n, int max_iters, double confidence, CountFn count_at, int* best_count_out) {
     int best = 0, best_it = -1, iters = max_iters;
     for (int it = 0; it < iters; ++it) {
         const int c = count_at(it);
@@ -273,7 +298,7 @@ MSFM_HD int replay_adaptive(int n, int max_iters, double confidence, CountFn cou
             const double w2 = w * w, w4 = w2 * w2, w8 = w4 * w4;
             double q = 1.0 - w8;
             if (q < 1e-300) q = 1e-300;
-            const double need = logfn(1.0 - confidence) / logfn(q);
+            const double need = det_log(1.0 - confidence) / det_log(q);
             if (need > 0.0 && need < (double)iters) {  // q == 1 (tiny consensus) gives -inf / NaN: no bound
                 int ni = (int)need;
                 if ((double)ni < need) ni += 1;  // ceil

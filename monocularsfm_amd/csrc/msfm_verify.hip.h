@@ -92,7 +92,7 @@ __global__ void vf_select_kernel(const int* __restrict__ counts, const int* __re
     if (n >= 8) {
         const int* hc = hyp_counts + (long long)p * prm.max_iters;
         bi = msfm_fmat::replay_adaptive(n, prm.max_iters, prm.confidence, [&](int it) { return hc[it]; },
-                                        [](double v) { return log(v); }, &bc);
+                                        &bc);
     }
     best_it[p] = bi;
     best_count[p] = bc;

@@ -43,7 +43,7 @@ std::vector<unsigned char> FundamentalRansacMask(const std::vector<Point2f>& pts
         return count_inliers(F, nullptr);
     };
     int best_count = 0;
-    const int best_it = replay_adaptive(n, max_iters, confidence, count_at, [](double v) { return std::log(v); }, &best_count);
+    const int best_it = replay_adaptive(n, max_iters, confidence, count_at, &best_count);
     std::vector<unsigned char> best((size_t)n, 0);
     if (best_it < 0) return best;
     double F[9];
