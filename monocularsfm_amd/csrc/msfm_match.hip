@@ -585,7 +585,7 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
     hc.lap("sweep-1 setup + uploads");
     HIPCHK(ctx, hipEventRecord(e0, ctx->stream));
     if (i8)
-        hipLaunchKernelGGL(sweep_i8_kernel<1>, dim3(std::min<unsigned>(sweep_grid, (unsigned)b.items.size())), block, kI8LdsBytes, ctx->stream, dp, dpf,
+        hipLaunchKernelGGL(sweep_i8_kernel<1>, dim3(std::min<unsigned>(sweep_grid, (unsigned)b.items.size())), dim3(kI8Threads), kI8LdsBytes, ctx->stream, dp, dpf,
                            ctx->d_items.as<WorkItem>(), ctx->d_rp_s0.as<float>(), ctx->d_rp_s1.as<float>(), ctx->d_cp_s0.as<float>(),
                            (const float*)nullptr, (int2*)nullptr, (unsigned long long*)nullptr, (const int*)nullptr, (int)b.items.size(), (int*)nullptr);
     else
@@ -687,7 +687,7 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
         DBGSYNC(ctx, "pf_assign_kernel");
         HIPCHK(ctx, hipEventRecord(e2, ctx->stream));
         if (i8)
-            hipLaunchKernelGGL(sweep_i8_kernel<3>, dim3(sweep_grid), block, kI8LdsBytes, ctx->stream,
+            hipLaunchKernelGGL(sweep_i8_kernel<3>, dim3(sweep_grid), dim3(kI8Threads), kI8LdsBytes, ctx->stream,
                                (const PairDesc*)ctx->d_vpairs.as<PairDesc>(), (const PfPair*)ctx->d_vpf.as<PfPair>(),
                                (const WorkItem*)ctx->d_vitems.as<WorkItem>(), (float*)nullptr, (float*)nullptr, (float*)nullptr,
                                (const float*)ctx->d_cmp_tu.as<float>(), ctx->d_cand.as<int2>(),
@@ -804,10 +804,10 @@ int finish_prefilter(msfm_ctx* ctx, Batch& b, std::vector<char>& force_exact, bo
     ctx->prof.sweep2_ms += ms;
 #ifdef MSFM_SWEEP_PROBE
     for (int which = 0; which < 2; ++which) {   // diagnostic build: average cycles per tile and wave of the four loop segments
-        unsigned long long pr[kPfWaves][8];
+        unsigned long long pr[16][8];
         if (which == 0) HIPCHK(ctx, hipMemcpyFromSymbol(pr, HIP_SYMBOL(g_sweep_probe), sizeof(pr)));
         else HIPCHK(ctx, hipMemcpyFromSymbol(pr, HIP_SYMBOL(g_sweep_probe3), sizeof(pr)));
-        for (int w = 0; w < kPfWaves; w += 3) {
+        for (int w = 0; w < (pe.i8 ? 16 : kPfWaves); w += (pe.i8 ? 1 : 3)) {
             const double n = (double)std::max<unsigned long long>(1, pr[w][4]);
             std::fprintf(stderr, "[sweep %d probe] wave %d: MFMA %.0f | wait+barrier %.0f | EPI %.0f | wait+barrier %.0f cycles per tile (%.0f tiles, %llu items)\n",
                          which == 0 ? 1 : 3, w, pr[w][0] / n, pr[w][1] / n, pr[w][2] / n, pr[w][3] / n, n, pr[w][5]);
@@ -1030,6 +1030,11 @@ int msfm_create(int device_ordinal, msfm_ctx** out_ctx) {
                                         hipFuncAttributeMaxDynamicSharedMemorySize, kPfLdsBytes);
     hipError_t e4 = hipFuncSetAttribute(reinterpret_cast<const void*>(sweep_kernel<3>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, kPfLdsBytes);
+    hipError_t e5 = hipFuncSetAttribute(reinterpret_cast<const void*>(sweep_i8_kernel<1>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, kI8LdsBytes);
+    hipError_t e6 = hipFuncSetAttribute(reinterpret_cast<const void*>(sweep_i8_kernel<3>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, kI8LdsBytes);
+    if (e5 != hipSuccess || e6 != hipSuccess) e2 = e5 != hipSuccess ? e5 : e6;
     if (e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess) {
         std::fprintf(stderr, "msfm_create: cannot reserve %d bytes of LDS for the prefilter kernels\n", kPfLdsBytes);
         (void)hipStreamDestroy(ctx->stream);

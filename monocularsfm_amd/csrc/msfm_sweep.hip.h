@@ -49,8 +49,8 @@
 // Diagnostic build only (tools/gpu_probe.sh, -DMSFM_SWEEP_PROBE): per-wave cycle sums of the four segments of a tile
 // (MFMA phase, its wait + barrier, EPI phase, its wait + barrier), printed by the library after every sweep 1.
 #ifdef MSFM_SWEEP_PROBE
-__device__ unsigned long long g_sweep_probe[kPfWaves][8];
-__device__ unsigned long long g_sweep_probe3[kPfWaves][8];   // the compacted sweep 2
+__device__ unsigned long long g_sweep_probe[16][8];    // (16: the integer-core kernels run sixteen waves)
+__device__ unsigned long long g_sweep_probe3[16][8];   // the compacted sweep 2
 #define MSFM_PROBE_BEGIN unsigned long long pb_t = __builtin_amdgcn_s_memtime(), pb_acc[4] = {0, 0, 0, 0};
 #define MSFM_PROBE(k) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); pb_acc[k] += n_ - pb_t; pb_t = n_; }
 #define MSFM_PROBE_END                                                                                     \
@@ -306,17 +306,21 @@ __global__ __launch_bounds__(kPfThreads, 2) void sweep_kernel(
         }
         __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
     };
-    // maximum of the accumulator over this lane's 32 rows of one column block: two independent v_max3 chains
+    // maximum of the accumulator over this lane's 32 rows of one column block: two independent v_max3 chains.  The odd
+    // element out goes through a raw v_max_f32: fmaxf() would first canonicalise both operands (v_max_f32 x, x, x), three
+    // extra VALU instructions per column block -- and every VALU instruction is SIMD time here.
     auto column_max = [&](const f16v (&acc)[kPfRB]) -> float {
+        static_assert(kPfRB == 2, "two chains");
         float m[kPfRB];
 #pragma unroll
         for (int rb = 0; rb < kPfRB; ++rb) {
             m[rb] = max3f(acc[rb][0], acc[rb][1], acc[rb][2]);
 #pragma unroll
             for (int r = 3; r < 15; r += 2) m[rb] = max3f(m[rb], acc[rb][r], acc[rb][r + 1]);
-            m[rb] = fmaxf(m[rb], acc[rb][15]);
         }
-        return kPfRB == 2 ? fmaxf(m[0], m[1]) : m[0];
+        float last;
+        asm("v_max_f32 %0, %1, %2" : "=v"(last) : "v"(acc[0][15]), "v"(acc[1][15]));
+        return max3f(m[0], m[1], last);
     };
     // ---- sweep 2: recording hits ---------------------------------------------------------------------------------
     // A hit goes, slotted with ballot / popcount, into this wave's LDS buffer -- no atomics in the loop -- and the buffer

@@ -26,7 +26,18 @@
 
 constexpr int kI8RowBytes = 144;                        // 128 operand bytes + [h, 0, 0, 0] (int32)
 constexpr int kI8TileBytes = kPfBT * kI8RowBytes;       // 9216 B = 9 DMA pieces
-constexpr int kI8LdsBytes = kPfRing * kI8TileBytes + kPfWaves * kPfCandBuf * 8 + 2 * kPfBT * kPfColClasses * 4;
+// SIXTEEN waves of 32 rows (four per SIMD): on the integer cores a tile's matrix phase is 16 x 34 cycles per SIMD, and one
+// wave issues a VALU instruction every 8 cycles at best -- with two 64-row waves per SIMD the ~130 VALU instructions per
+// tile and wave set the pace (profiles/r02_i8_sweep_ablation.txt); four 32-row waves give the epilogue twice the issue slots
+// per matrix slot.  Waves w, w+4, w+8, w+12 share a SIMD; the ping-pong halves are (w >> 2) & 1.
+constexpr int kI8Waves = 16;
+constexpr int kI8Threads = 64 * kI8Waves;
+constexpr int kI8WaveRows = kPfWgRows / kI8Waves;       // 32: one MFMA row block per wave
+// Ring of EIGHT tiles, DMA seven tiles ahead: a phase is ~600 cycles here, so the three-tile lead of the fp16 kernel
+// (1.6 us there) would be 0.75 us -- less than an L2 miss.
+constexpr int kI8Ring = 8;
+constexpr int kI8LdsBytes = kI8Ring * kI8TileBytes + kI8Waves * kPfCandBuf * 8 + 2 * kPfBT * kPfColClasses * 4;
+static_assert(kI8WaveRows == 32, "one 32-row block per wave");
 constexpr int kI8Pad = -(1 << 29);                      // "-inf" of a padding row / column (two of them still fit an int32)
 constexpr int kI8PadTest = -(1 << 27);                  // anything below is padding
 constexpr float kI8Eps = 2.f;
@@ -74,7 +85,7 @@ __global__ void pf_prepare_i8_kernel(const float* __restrict__ raw, signed char*
 }
 
 template <int PASS>
-__global__ __launch_bounds__(kPfThreads, 2) void sweep_i8_kernel(
+__global__ __launch_bounds__(kI8Threads) void sweep_i8_kernel(
     const PairDesc* __restrict__ pairs, const PfPair* __restrict__ pf, const WorkItem* __restrict__ items,
     float* __restrict__ rp_s0, float* __restrict__ rp_s1, float* __restrict__ cp_s0, const float* __restrict__ tu,
     int2* __restrict__ cand, unsigned long long* __restrict__ cand_count, const int* __restrict__ n_items_dev, int n_items_host,
@@ -84,8 +95,8 @@ __global__ __launch_bounds__(kPfThreads, 2) void sweep_i8_kernel(
     typedef const __attribute__((address_space(1))) i4v* gi4_p;
     extern __shared__ __attribute__((aligned(16))) char pf_smem[];
     char* sB = pf_smem;                                                   // [ring slot][64 rows x 144 B]
-    char* sCand = pf_smem + kPfRing * kI8TileBytes;                       // [wave][kPfCandBuf] int2 (PASS 3)
-    int* sCol = reinterpret_cast<int*>(sCand + kPfWaves * kPfCandBuf * 8);  // [2 tiles][4 classes][64 columns] (PASS 1)
+    char* sCand = pf_smem + kI8Ring * kI8TileBytes;                       // [wave][kPfCandBuf] int2 (PASS 3)
+    int* sCol = reinterpret_cast<int*>(sCand + kI8Waves * kPfCandBuf * 8);  // [2 tiles][4 classes][64 columns] (PASS 1)
 
     const int n_items = n_items_dev ? *n_items_dev : n_items_host;
     __shared__ int s_next_item;
@@ -108,7 +119,7 @@ __global__ __launch_bounds__(kPfThreads, 2) void sweep_i8_kernel(
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int grp = wave >> 2;
+    const int grp = (wave >> 2) & 1;    // 0: MFMA in the even phases, 1: in the odd ones; two waves of each on every SIMD
     const int lcol = lane & 31, lhalf = lane >> 5;
 
     const int t_begin = item.bt_begin * 2, t_end = min(item.bt_end * 2, max(item.bt_begin * 2 + 1, (pd.n2 + kPfBT - 1) / kPfBT));
@@ -116,33 +127,31 @@ __global__ __launch_bounds__(kPfThreads, 2) void sweep_i8_kernel(
     const gfloat_p g_anrm = (gfloat_p)pp.a_nrm;
     const gfloat_p g_tu = (gfloat_p)tu;
 
-    // DMA group of tile tt: piece `wave` of the tile's 9 (wave 0: piece 8 as well)
+    // DMA group of tile tt: the tile's 9 pieces go to waves 0..8, one each
+    const bool dma_wave = wave < kI8TileBytes / 1024;   // wave-uniform
     const unsigned lane_off = (unsigned)(wave * 1024 + lane * 16);
     auto dma_tile = [&](int tt) {
+        if (!dma_wave) return;
         const int tc = tt < t_end ? tt : t_end - 1;
-        const int sl = (tt - t_begin) & (kPfRing - 1);
+        const int sl = (tt - t_begin) & (kI8Ring - 1);
         const unsigned off = (unsigned)tc * (unsigned)kI8TileBytes + lane_off;
         char* l = sB + sl * kI8TileBytes + wave * 1024;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gB + off), (__attribute__((address_space(3))) void*)l, 16, 0, 0);
-        if (wave == 0)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gB + (off + 8192u)),
-                                             (__attribute__((address_space(3))) void*)(l + 8192), 16, 0, 0);
     };
+    // One load per group and DMA wave.  At either wait the wave has issued the groups up to tile u + kI8Ring - 3 and needs
+    // tile u: "at most kI8Ring - 3 outstanding" = tile u has landed (loads retire in order; see sweep_kernel).
     auto wait_older_group = [&]() {
-        if (wave == 0) wait_vmcnt<2>();
-        else wait_vmcnt<1>();
+        if (dma_wave) wait_vmcnt<kI8Ring - 3>();
     };
 
-    dma_tile(t_begin);
-    dma_tile(t_begin + 1);
-    dma_tile(t_begin + 2);
-    if (PASS == 1) sCol[tid] = (int)0x80000000;   // 2 tiles x 4 classes x 64 columns = 512 ints
-
-    // A fragments: rows a_blk*512 + wave*64 + rb*32 + lcol, k-step ks = bytes 32 ks + 16 lhalf .. + 15
-    i4v af[kPfRB][4];
 #pragma unroll
-    for (int rb = 0; rb < kPfRB; ++rb) {
-        const int frow = item.a_blk * kPfWgRows + wave * kPfWaveRows + rb * 32 + lcol;
+    for (int k = 0; k < kI8Ring - 1; ++k) dma_tile(t_begin + k);
+    if (PASS == 1 && tid < 2 * kPfBT * kPfColClasses) sCol[tid] = (int)0x80000000;
+
+    // A fragments: row a_blk*512 + wave*32 + lcol, k-step ks = bytes 32 ks + 16 lhalf .. + 15
+    i4v af[4];
+    {
+        const int frow = item.a_blk * kPfWgRows + wave * kI8WaveRows + lcol;
         const char* arow = reinterpret_cast<const char*>(pp.a_h) + (size_t)frow * kI8RowBytes;
         if (PASS == 3) {
             const char* r = reinterpret_cast<const char*>(pp.a_rows[frow]);
@@ -150,34 +159,37 @@ __global__ __launch_bounds__(kPfThreads, 2) void sweep_i8_kernel(
         }
         const gi4_p ga = (gi4_p)arow;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) af[rb][ks] = ga[2 * ks + lhalf];
+        for (int ks = 0; ks < 4; ++ks) af[ks] = ga[2 * ks + lhalf];
     }
-    // this lane's 32 result rows: (rb, r) -> row = a_blk*512 + wave*64 + rb*32 + (r&3) + 8*(r>>2) + 4*lhalf; their constants
-    const int arow_base = item.a_blk * kPfWgRows + wave * kPfWaveRows + 4 * lhalf;
-    i16v rowc[kPfRB];
-#pragma unroll
-    for (int rb = 0; rb < kPfRB; ++rb)
+    // this lane's 16 result rows: r -> row = a_blk*512 + wave*32 + (r&3) + 8*(r>>2) + 4*lhalf; their constants
+    const int arow_base = item.a_blk * kPfWgRows + wave * kI8WaveRows + 4 * lhalf;
+    // PASS 1: -h_a (the norm array holds 2 h_a, +inf on padding rows).  PASS 3: floor((T - 2 h_a) / 2), T = +inf -> everything
+    // hits.  The loads are unconditional (both arrays cover the padded rows) and pinned by a register use: hipcc otherwise
+    // sinks each of them into its `rr < n1` branch and waits for it there -- 16 round trips instead of 16 loads in flight.
+    i16v rowc;
+    {
+        float xs[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int rr = arow_base + rb * 32 + (r & 3) + 8 * (r >> 2);
-            // PASS 1: -h_a (the norm array holds 2 h_a, +inf on padding rows).  PASS 3: floor((T - 2 h_a) / 2), T = +inf ->
-            // everything hits.  Unconditional loads (both arrays cover the padded rows): 32 loads in flight, not 32 round trips
-            const float x = PASS == 3 ? 0.5f * g_tu[pp.tu_off + rr] : -0.5f * g_anrm[rr];
-            const int c = rr < pd.n1 ? (int)floorf(fminf(fmaxf(x, -5.0e8f), 5.0e8f)) : kI8Pad;
-            rowc[rb][r] = c;
+            const int rr = arow_base + (r & 3) + 8 * (r >> 2);
+            xs[r] = PASS == 3 ? g_tu[pp.tu_off + rr] : g_anrm[rr];
         }
-    int rs0[kPfRB][16];   // PASS 1: running row maximum of the accumulator
 #pragma unroll
-    for (int rb = 0; rb < kPfRB; ++rb)
+        for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(xs[r]));
 #pragma unroll
-        for (int r = 0; r < 16; ++r) rs0[rb][r] = (int)0x80000000;
+        for (int r = 0; r < 16; ++r) {
+            const int rr = arow_base + (r & 3) + 8 * (r >> 2);
+            const float x = PASS == 3 ? 0.5f * xs[r] : -0.5f * xs[r];
+            rowc[r] = rr < pd.n1 ? (int)floorf(fminf(fmaxf(x, -5.0e8f), 5.0e8f)) : kI8Pad;
+        }
+    }
+    int rs0[16];   // PASS 1: running row maximum of the accumulator
+#pragma unroll
+    for (int r = 0; r < 16; ++r) rs0[r] = (int)0x80000000;
     // pin the prologue loads before the loop (see sweep_kernel)
 #pragma unroll
-    for (int rb = 0; rb < kPfRB; ++rb) {
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) asm volatile("" ::"v"(af[rb][ks]));
-        asm volatile("" ::"v"(rowc[rb]));
-    }
+    for (int ks = 0; ks < 4; ++ks) asm volatile("" ::"v"(af[ks]));
+    asm volatile("" ::"v"(rowc));
     wait_vmcnt<0>();
 
     int2* cbuf = reinterpret_cast<int2*>(sCand) + wave * kPfCandBuf;
@@ -194,72 +206,56 @@ __global__ __launch_bounds__(kPfThreads, 2) void sweep_i8_kernel(
         n_buf = 0;
     };
 
-    const bool wave_active = item.a_blk * kPfWgRows + wave * kPfWaveRows < pd.n1;
+    const bool wave_active = item.a_blk * kPfWgRows + wave * kI8WaveRows < pd.n1;
 
-    // B fragments of column block 0 of the tile in ring slot sl, and -h_b of this lane's column in both column blocks
+    // B fragments.  The two column blocks of a tile are two independent accumulator chains (a single dependent MFMA
+    // chain runs at 3/4 of the rate, profiles/r01_ubench_mfma_chains.txt), so a k-step needs BOTH blocks' fragments:
+    // k-steps 0 and 1 are pre-read in the EPI phase of the previous tile, k-steps 2 and 3 are read behind the first and the
+    // second MFMA pair into the registers they free (the SIMD's other matrix-phase wave fills the wait; three k-steps in
+    // registers would not fit 128 VGPRs).  hb = h_b of this lane's column in the two blocks.
     const int lane_row_off = lcol * kI8RowBytes + lhalf * 16;
     const int lane_ext_off = lcol * kI8RowBytes + kDim;
-    auto load_bf = [&](int sl, i4v (&bf)[4], int (&hb)[2]) {
+    auto preread = [&](int sl, i4v (&bf)[2][2], int (&hb)[2]) {
         const char* pb = sB + sl * kI8TileBytes + lane_row_off;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) bf[ks] = *reinterpret_cast<const i4v*>(pb + ks * 32);
+        for (int ks = 0; ks < 2; ++ks) {
+            bf[ks][0] = *reinterpret_cast<const i4v*>(pb + ks * 32);
+            bf[ks][1] = *reinterpret_cast<const i4v*>(pb + 32 * kI8RowBytes + ks * 32);
+        }
         const char* pe = sB + sl * kI8TileBytes + lane_ext_off;
         hb[0] = *reinterpret_cast<const int*>(pe);
         hb[1] = *reinterpret_cast<const int*>(pe + 32 * kI8RowBytes);
     };
-    auto init_acc = [&](i16v (&acc)[kPfRB], int hb) {
+    auto column_max = [&](const i16v& acc) -> int {
+        int m0 = max3i(acc[0], acc[1], acc[2]), m1 = max3i(acc[3], acc[4], acc[5]);
 #pragma unroll
-        for (int rb = 0; rb < kPfRB; ++rb) acc[rb] = rowc[rb] - hb;
-    };
-    auto mfma_block = [&](const i4v (&bf)[4], i16v (&acc)[kPfRB]) {
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-            for (int rb = 0; rb < kPfRB; ++rb) acc[rb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[rb][ks], bf[ks], acc[rb], 0, 0, 0);
-    };
-    // column block 0 on the fragments in `bf`; each k-step's registers then take the fragment of column block 1
-    auto mfma_block_reload = [&](int sl, i4v (&bf)[4], i16v (&acc)[kPfRB]) {
-        const char* pb = sB + sl * kI8TileBytes + 32 * kI8RowBytes + lane_row_off;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-#pragma unroll
-            for (int rb = 0; rb < kPfRB; ++rb) acc[rb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[rb][ks], bf[ks], acc[rb], 0, 0, 0);
-            bf[ks] = *reinterpret_cast<const i4v*>(pb + ks * 32);
+        for (int r = 6; r < 14; r += 4) {
+            m0 = max3i(m0, acc[r], acc[r + 1]);
+            m1 = max3i(m1, acc[r + 2], acc[r + 3]);
         }
+        return max3i(max(m0, acc[14]), m1, acc[15]);
     };
-    auto column_max = [&](const i16v (&acc)[kPfRB]) -> int {
-        int m[kPfRB];
-#pragma unroll
-        for (int rb = 0; rb < kPfRB; ++rb) {
-            m[rb] = max3i(acc[rb][0], acc[rb][1], acc[rb][2]);
-#pragma unroll
-            for (int r = 3; r < 15; r += 2) m[rb] = max3i(m[rb], acc[rb][r], acc[rb][r + 1]);
-            m[rb] = max(m[rb], acc[rb][15]);
-        }
-        return kPfRB == 2 ? max(m[0], m[1]) : m[0];
-    };
-    // compacted sweep: a hit is accumulator >= 0, sign bit clear (see scan_hits3 of sweep_kernel)
-    auto scan_hits3 = [&](const i16v (&a0)[kPfRB], const i16v (&a1)[kPfRB], int col0) {
+    // compacted sweep: a hit is accumulator >= 0, sign bit clear (see scan_hits3 of sweep_kernel); 16 elements per lane
+    // and column block: element r ends up at bit 15 - r of the block's mask
+    auto scan_hits3 = [&](const i16v& a0, const i16v& a1, int col0) {
         unsigned nm[2] = {0u, 0u};
 #pragma unroll
-        for (int blk = 0; blk < 2; ++blk)
-#pragma unroll
-            for (int rb = 0; rb < kPfRB; ++rb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) nm[blk] = __builtin_amdgcn_alignbit(nm[blk], (unsigned)(blk ? a1 : a0)[rb][r], 31);
-        static_assert(kPfRB == 2, "32 elements per column block and mask");
+        for (int r = 0; r < 16; ++r) {
+            nm[0] = __builtin_amdgcn_alignbit(nm[0], (unsigned)a0[r], 31);
+            nm[1] = __builtin_amdgcn_alignbit(nm[1], (unsigned)a1[r], 31);
+        }
 #pragma unroll 1
         for (int blk = 0; blk < 2; ++blk) {
-            unsigned hm = ~(blk ? nm[1] : nm[0]);
+            unsigned hm = ~(blk ? nm[1] : nm[0]) & 0xffffu;
             const int col = col0 + blk * 32;
             for (unsigned long long mm = __ballot(hm != 0u); mm != 0ull; mm = __ballot(hm != 0u)) {
                 const bool hit = hm != 0u;
-                const int k = __clz((int)hm);
+                const int k = __clz((int)hm) - 16;   // first remaining element of this lane
                 if (n_buf + 64 > kPfCandBuf) flush_candidates();
                 if (hit) {
-                    hm &= ~(0x80000000u >> k);
+                    hm &= ~(0x8000u >> k);
                     const int slt = n_buf + __popcll(mm & ((1ull << lane) - 1ull));
-                    const int2 e = make_int2(arow_base + (k >> 4) * 32 + (k & 3) + 8 * ((k & 15) >> 2), col);
+                    const int2 e = make_int2(arow_base + (k & 3) + 8 * (k >> 2), col);
                     asm volatile("ds_write_b64 %0, %1" ::"v"(cbuf_lds + slt * 8), "v"(e) : "memory");
                 }
                 n_buf += __popcll(mm);
@@ -293,23 +289,34 @@ __global__ __launch_bounds__(kPfThreads, 2) void sweep_i8_kernel(
     };
 
     lds_barrier();
-    i4v bf[4];
+    i4v bf[2][2];
     int hb[2];
-    if (wave_active) load_bf(0, bf, hb);
+    if (wave_active) preread(0, bf, hb);
     if (grp == 1) lds_barrier();
 
-    i16v accA[kPfRB], accB[kPfRB];
+    i16v accA, accB;
     MSFM_PROBE_BEGIN
 #pragma unroll 1
     for (int t = t_begin; t < t_end; ++t) {
-        const int sl = (t - t_begin) & (kPfRing - 1);
+        const int sl = (t - t_begin) & (kI8Ring - 1);
         // ---- MFMA phase ----------------------------------------------------------------------------------------
         if (wave_active) {
             __builtin_amdgcn_s_setprio(1);
-            init_acc(accA, hb[0]);
-            mfma_block_reload(sl, bf, accA);
-            init_acc(accB, hb[1]);
-            mfma_block(bf, accB);
+            const char* pb2 = sB + sl * kI8TileBytes + lane_row_off + 2 * 32;
+            accA = rowc - hb[0];
+            accB = rowc - hb[1];
+            accA = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[0], bf[0][0], accA, 0, 0, 0);
+            accB = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[0], bf[0][1], accB, 0, 0, 0);
+            bf[0][0] = *reinterpret_cast<const i4v*>(pb2);                          // k-step 2 into the registers of k-step 0
+            bf[0][1] = *reinterpret_cast<const i4v*>(pb2 + 32 * kI8RowBytes);
+            accA = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[1], bf[1][0], accA, 0, 0, 0);
+            accB = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[1], bf[1][1], accB, 0, 0, 0);
+            bf[1][0] = *reinterpret_cast<const i4v*>(pb2 + 32);                     // k-step 3 into those of k-step 1
+            bf[1][1] = *reinterpret_cast<const i4v*>(pb2 + 32 * kI8RowBytes + 32);
+            accA = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[2], bf[0][0], accA, 0, 0, 0);
+            accB = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[2], bf[0][1], accB, 0, 0, 0);
+            accA = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[3], bf[1][0], accA, 0, 0, 0);
+            accB = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[3], bf[1][1], accB, 0, 0, 0);
             __builtin_amdgcn_s_setprio(0);
         }
         MSFM_PROBE(0)
@@ -318,19 +325,17 @@ __global__ __launch_bounds__(kPfThreads, 2) void sweep_i8_kernel(
         MSFM_PROBE(1)
         // ---- EPI phase -----------------------------------------------------------------------------------------
         if (PASS == 1 && grp == 0 && t > t_begin && wave == ((t - t_begin) & 3)) store_columns(t - 1);
-        dma_tile(t + 3);
+        dma_tile(t + kI8Ring - 1);
         if (wave_active) {
             if (PASS == 1) {
                 fold_columns(column_max(accA), column_max(accB), (t - t_begin) & 1);
 #pragma unroll
-                for (int rb = 0; rb < kPfRB; ++rb)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) rs0[rb][r] = max3i(rs0[rb][r], accA[rb][r], accB[rb][r]);
+                for (int r = 0; r < 16; ++r) rs0[r] = max3i(rs0[r], accA[r], accB[r]);
             } else {
                 scan_hits3(accA, accB, t * kPfBT + lcol);
             }
         }
-        if (wave_active && t + 1 < t_end) load_bf((sl + 1) & (kPfRing - 1), bf, hb);
+        if (wave_active && t + 1 < t_end) preread((sl + 1) & (kI8Ring - 1), bf, hb);
         MSFM_PROBE(2)
         if (grp == 1) wait_older_group();
         lds_barrier();
@@ -343,27 +348,22 @@ __global__ __launch_bounds__(kPfThreads, 2) void sweep_i8_kernel(
 
     if (PASS == 1) {
         // rows: S~ = -2 * accumulator as a float (exact); the two smallest of the 32 lanes' minima
-        float fs0[kPfRB][16], fs1[kPfRB][16];
+        float fs0[16], fs1[16];
 #pragma unroll
-        for (int rb = 0; rb < kPfRB; ++rb)
+        for (int r = 0; r < 16; ++r) {
+            fs0[r] = rs0[r] > kI8PadTest ? (float)(-2 * rs0[r]) : f_inf();
+            fs1[r] = f_inf();
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                fs0[rb][r] = rs0[rb][r] > kI8PadTest ? (float)(-2 * rs0[rb][r]) : f_inf();
-                fs1[rb][r] = f_inf();
-#pragma unroll
-                for (int m = 1; m < 32; m <<= 1)
-                    v2_merge(fs0[rb][r], fs1[rb][r], __shfl_xor(fs0[rb][r], m), __shfl_xor(fs1[rb][r], m));
-            }
+            for (int m = 1; m < 32; m <<= 1) v2_merge(fs0[r], fs1[r], __shfl_xor(fs0[r], m), __shfl_xor(fs1[r], m));
+        }
         if (lcol == 0) {
             const long long o = pd.rp_off + (long long)item.range * pd.n1pad + arow_base;
 #pragma unroll
-            for (int rb = 0; rb < kPfRB; ++rb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int off = rb * 32 + (r & 3) + 8 * (r >> 2);
-                    rp_s0[o + off] = fs0[rb][r];
-                    rp_s1[o + off] = fs1[rb][r];
-                }
+            for (int r = 0; r < 16; ++r) {
+                const int off = (r & 3) + 8 * (r >> 2);
+                rp_s0[o + off] = fs0[r];
+                rp_s1[o + off] = fs1[r];
+            }
         }
     }
     }   // item loop
