@@ -1257,6 +1257,13 @@ int msfm_clear_images(msfm_ctx* ctx) {
     return MSFM_OK;
 }
 
+// An error return may leave launches of the failed batch in flight: drain the stream before handing control back, so
+// that the caller can free or reuse its buffers and a following call starts from an idle stream.
+static int drained(msfm_ctx* ctx, int rc) {
+    if (rc != MSFM_OK && ctx && ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    return rc;
+}
+
 static int match_pairs_impl(msfm_ctx* ctx, const int32_t* pairs, int n_pairs, const msfm_match_params* params,
                             const msfm_verify_params* verify, int64_t* out_offsets) {
     if (!ctx) return MSFM_E_INVALID;
@@ -1445,7 +1452,7 @@ static int match_pairs_impl(msfm_ctx* ctx, const int32_t* pairs, int n_pairs, co
 
 int msfm_match_pairs(msfm_ctx* ctx, const int32_t* pairs, int n_pairs, const msfm_match_params* params,
                      int64_t* out_offsets) {
-    return match_pairs_impl(ctx, pairs, n_pairs, params, nullptr, out_offsets);
+    return drained(ctx, match_pairs_impl(ctx, pairs, n_pairs, params, nullptr, out_offsets));
 }
 
 int msfm_match_pairs_verified(msfm_ctx* ctx, const int32_t* pairs, int n_pairs, const msfm_match_params* params,
@@ -1454,7 +1461,7 @@ int msfm_match_pairs_verified(msfm_ctx* ctx, const int32_t* pairs, int n_pairs, 
     if (verify) v = *verify;
     if (!(v.threshold >= 0.0) || !(v.confidence > 0.0) || !(v.confidence < 1.0) || v.max_iters < 1 || v.max_iters > (1 << 16))
         return fail(ctx, MSFM_E_INVALID, "bad verification parameters");
-    return match_pairs_impl(ctx, pairs, n_pairs, params, &v, out_offsets);
+    return drained(ctx, match_pairs_impl(ctx, pairs, n_pairs, params, &v, out_offsets));
 }
 
 int msfm_upload_keypoints(msfm_ctx* ctx, int image_id, const float* kpts, int n, int stride_floats) {

@@ -213,6 +213,36 @@ def test_u8_job_equals_the_integer_reference(gpu_ctx, prefilter):
         gpu_ctx.set_prefilter(True)
 
 
+@pytest.mark.parametrize("n_images,n_desc,seed", [(24, 8192, 1329), (10, 16384, 4096)])
+def test_config4_and_5_byte_jobs_on_the_integer_cores(gpu_ctx, oracle, n_images, n_desc, seed):
+    """BASELINE configs[3] / [4] at full per-image size, a seeded subset of the image set in ONE call: the cross-pair
+    grouping of sweep 2 (several images share a streamed image, several mask bits per image at 16384 rows) on the
+    integer-core route; sampled pairs against the C oracle, every pair against the fp16 route, a forced 3-way cut."""
+    u, pairs, _ = synth.job("synthetic-u8", n_images, n_desc, seed=seed)
+    for i, im in enumerate(u):
+        gpu_ctx.upload_image(i, im)
+    kw = {"ratio": 0.8, "cross_check": True, "max_distance": 1e9}
+    offs, qt, d = gpu_ctx.match_pairs(pairs, **kw)
+    p = gpu_ctx.profile()
+    assert p["sweep1_i8_launches"] == 1 and p["sub_batches"] == 1 and p["fallback_pairs"] == 0 and p["prefilter_pairs"] == len(pairs)
+    assert offs[-1] > 100 * len(pairs) // 4
+    rng = np.random.default_rng(seed)
+    sel = np.sort(rng.choice(len(pairs), 4, replace=False))
+    check_pairs_vs_oracle(oracle, [x.astype(F32) for x in u], pairs, sel, offs, qt, d, **kw)
+    try:
+        gpu_ctx.set_prefilter(2)          # fp16 matrix cores on the same bytes
+        assert same_result((offs, qt, d), gpu_ctx.match_pairs(pairs, **kw))
+        assert gpu_ctx.profile()["sweep1_i8_launches"] == 0
+        gpu_ctx.set_prefilter(True)
+        gpu_ctx.set_limits((len(pairs) + 2) // 3, 0)
+        assert same_result((offs, qt, d), gpu_ctx.match_pairs(pairs, **kw))
+        assert gpu_ctx.profile()["sub_batches"] == 3 and gpu_ctx.profile()["sweep1_i8_launches"] == 3
+    finally:
+        gpu_ctx.set_prefilter(True)
+        gpu_ctx.set_limits(0, 0)
+    gpu_ctx.clear_images()
+
+
 def test_tie_queue_grows_instead_of_failing(built_lib, oracle):
     """More sqrt-space ties in one batch than the initial queue holds (duplicate train descriptors; kNN-level API
     and ratio > 1 lists): the queue grows and the batch is re-run; round 1 returned MSFM_E_CAPACITY here."""
