@@ -362,3 +362,50 @@ def test_fuzz_prefilter_equals_bruteforce(gpu_ctx, oracle):
                     assert np.array_equal(got[1][s:e, 0], oq) and np.array_equal(got[1][s:e, 1], ot) and np.array_equal(b(got[2][s:e]), b(od)), tag
         finally:
             gpu_ctx.set_accum_order(0)
+
+
+def _unit(x):
+    x = np.asarray(x, np.float64)
+    return np.ascontiguousarray((x / np.linalg.norm(x, axis=1, keepdims=True)).astype(F32))
+
+
+@pytest.mark.parametrize("sizes", [[700, 650, 300], [65, 1000, 513, 63], [2, 64, 5000]])
+def test_unit_norm_descriptors_of_either_sign(gpu_ctx, oracle, sizes):
+    """L2-normalised descriptors of EITHER sign (unit Gaussian directions: dot products are negative half of the time, so
+    a zero padding row / column that lost its -inf would win maxima): the lists equal the brute-force route's and the
+    oracle's.  Sizes leave partially filled waves, tiles and A blocks.  (Written for a sweep-1 variant without the norm
+    k-step for constant-norm stores; that variant was 3 % SLOWER at 11 % fewer MFMAs -- DESIGN.md 5.1.3 -- and is gone,
+    the test stays.)"""
+    rng = np.random.default_rng(sum(sizes))
+    imgs = [_unit(rng.normal(size=(n, 128))) for n in sizes]
+    for k in range(1, len(imgs)):                      # planted near-duplicates so that matches exist
+        m = min(len(imgs[0]), len(imgs[k]), 40)
+        imgs[k][:m] = _unit(imgs[0][:m] + 0.05 * rng.normal(size=(m, 128)))
+    pairs = synth.all_pairs(len(sizes))
+    for i, im in enumerate(imgs):
+        gpu_ctx.upload_image(i, im)
+    res = {}
+    try:
+        for mode in (True, False):
+            gpu_ctx.set_prefilter(mode)
+            res[mode] = gpu_ctx.match_pairs(pairs, ratio=0.8, cross_check=True, max_distance=np.inf)
+            if mode:
+                assert gpu_ctx.profile()["fallback_pairs"] == 0
+        fwd = {m: None for m in (True, False)}
+        for mode in (True, False):
+            gpu_ctx.set_prefilter(mode)
+            fwd[mode] = gpu_ctx.knn2_pair(1, 0)
+    finally:
+        gpu_ctx.set_prefilter(True)
+    for x, y in zip(res[True], res[False]):
+        assert np.array_equal(b(x), b(y))
+    for d in (0, 1):
+        for k in range(3):
+            assert np.array_equal(b(fwd[True][d][k]), b(fwd[False][d][k]))
+    offs, qt, dist = res[True]
+    assert offs[-1] >= 3
+    for p, (i, j) in enumerate(pairs):
+        oq, ot, od = oracle.match_pair(imgs[i], imgs[j], 0.8, True, np.inf, nthreads=4)
+        s, e = offs[p], offs[p + 1]
+        assert np.array_equal(qt[s:e, 0], oq) and np.array_equal(qt[s:e, 1], ot) and np.array_equal(b(dist[s:e]), b(od)), (i, j)
+    gpu_ctx.clear_images()
