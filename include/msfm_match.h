@@ -67,8 +67,8 @@ typedef struct msfm_profile {
     double total_device_ms;    /* first launch -> last result copy of the call */
     int64_t descriptor_pairs;  /* sum n1*n2 over the pairs of the call */
     int64_t dist_algo_bytes;   /* compulsory HBM bytes of the distance kernel */
-    /* MFMA prefilter path (two approx_kernel sweeps per batch + exact re-check of the candidates) */
-    double approx_kernel_ms;   /* sum over batches of sweep 1 (approx_kernel<1>: every descriptor pair once) */
+    /* MFMA prefilter path (two sweep_kernel launches per batch + exact re-check of the candidates) */
+    double approx_kernel_ms;   /* sum over batches of sweep 1 (sweep_kernel<1> / sweep_i8_kernel<1>: every descriptor pair once; the field keeps its round-1 name) */
     int approx_kernel_launches;
     int prefilter_pairs;       /* pairs answered through the prefilter path */
     int fallback_pairs;        /* pairs whose candidate list overflowed -> brute-force exact kernel */
@@ -76,7 +76,7 @@ typedef struct msfm_profile {
     int64_t prefilter_descriptor_pairs;
     int64_t exact_descriptor_pairs; /* descriptor pairs that went through the brute-force kernel */
     int64_t tie_rows;          /* rows re-scanned by the sqrt-space tie fix-up */
-    double sweep2_ms;          /* sum over batches of sweep 2 (approx_kernel<2> dense / <3> compacted live rows) */
+    double sweep2_ms;          /* sum over batches of sweep 2 (sweep_kernel<2> dense / <3> compacted live rows, sweep_i8_kernel<3>) */
     int sweep2_launches;
     int compacted_pairs;       /* pairs whose sweep 2 ran on the compacted live rows only */
     int64_t sweep2_descriptor_pairs; /* descriptor pairs sweep 2 actually multiplied (padded rows included) */

@@ -5,14 +5,14 @@
 // finds a small, PROVABLY sufficient candidate set with the matrix cores and evaluates the pinned
 // fp32 order only on it:
 //
-//   sweep 1  approx_kernel<1>  S~ = |a|^2 + |b|^2 - 2 a~.b~ with fp16 operands on
+//   sweep 1  sweep_kernel<1>   S~ = |a|^2 + |b|^2 - 2 a~.b~ with fp16 operands on
 //                              v_mfma_f32_32x32x16_f16 -- the norms ride in a ninth k-step (below), so the
 //                              accumulator IS -S~/2; per row / column the two smallest S~ values.
 //   thresholds_kernel          T = S~(2) + 2*eps, eps = rigorous bound on |S~ - S_exact| (below); rows /
 //                              columns that provably cannot match get T = -inf (match lists only).
-//   sweep 2  approx_kernel<3>  live rows of one image (compacted) against the other image, per direction:
+//   sweep 2  sweep_kernel<3>   live rows of one image (compacted) against the other image, per direction:
 //                              the row threshold rides in the ninth k-step too, a hit is accumulator >= 0;
-//            approx_kernel<2>  dense variant (nothing pruned): S~ <= T_row[q] or S~ <= T_col[t];
+//            sweep_kernel<2>   dense variant (nothing pruned): S~ <= T_row[q] or S~ <= T_col[t];
 //                              hits are appended to the pair's candidate list (a few per row).
 //   exact_candidates_kernel    S_exact in the pinned accumulation order for the candidates only.
 //   reduce (3 tiny kernels)    per row / column the best and second best (S_exact, index) among
