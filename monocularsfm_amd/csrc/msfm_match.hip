@@ -157,7 +157,7 @@ struct msfm_ctx {
     DevBuf d_pf, d_tu, d_tv, d_cand, d_cand_s, d_cand_count, d_best, d_second, d_maxima;
     DevBuf d_zero_row, d_cmp_tu, d_live_idx, d_row_pair, d_row_src, d_cand_pair, d_vpairs, d_vpf, d_vitems, d_lists;
     // device-side plan of the compacted sweep 2 (msfm_plan.hip.h)
-    DevBuf d_colmask, d_groups, d_gmembers, d_member_pair, d_ppair, d_cnt, d_mrow, d_summary, d_overflow, d_totals;
+    DevBuf d_colmask, d_groups, d_gmembers, d_member_pair, d_member_group, d_gtot, d_grow0, d_ppair, d_cnt, d_mrow, d_summary, d_overflow, d_totals;
     long long cmp_rows_hint = 0;      // compacted rows the previous batch needed (sizes the next batch's buffers)
     long long items_hint = 0, cand_hint = 0;   // likewise: work items, candidate-list capacity
     struct PfPending {                // what the end-of-batch synchronisation has to look at
@@ -392,6 +392,7 @@ std::vector<WorkItem> interleave_items(const std::vector<WorkItem>& lin) {
 // ---- static tables of the device-side plan of sweep 2 (msfm_plan.hip.h) -----------------------------------------
 struct CompactPlan {
     std::vector<PlanGroup> groups;
+    std::vector<int> member_group;  // member -> group
     std::vector<int> gmembers;      // member ids ordered by group
     std::vector<int> member_pair;   // member -> pair of the batch
     std::vector<PlanPair> ppair;    // per pair
@@ -417,8 +418,7 @@ void build_compact_plan(msfm_ctx* ctx, const Batch& b, CompactPlan& cp) {
     };
     // group keys: forward = streamed image id2; reverse = (streamed image id1, bit)
     std::vector<int> fwd_group_of_img, rev_group0_of_img;   // dense image -> group id (-1: none yet)
-    struct Key { int group; };
-    std::vector<int> member_group;
+    std::vector<int>& member_group = cp.member_group;
     for (size_t p = 0; p < P; ++p) {
         const PairDesc& pd = b.pairs[p];
         const PfPair& pp = b.pf[p];
@@ -623,6 +623,9 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
         HIPCHK(ctx, ctx->d_groups.ensure(std::max<size_t>(1, G) * sizeof(PlanGroup)));
         HIPCHK(ctx, ctx->d_gmembers.ensure(std::max<size_t>(1, M) * 4));
         HIPCHK(ctx, ctx->d_member_pair.ensure(std::max<size_t>(1, M) * 4));
+        HIPCHK(ctx, ctx->d_member_group.ensure(std::max<size_t>(1, M) * 4));
+        HIPCHK(ctx, ctx->d_gtot.ensure(std::max<size_t>(1, G) * 4));
+        HIPCHK(ctx, ctx->d_grow0.ensure(std::max<size_t>(1, G) * 8));
         HIPCHK(ctx, ctx->d_ppair.ensure(P * sizeof(PlanPair)));
         HIPCHK(ctx, ctx->d_cnt.ensure(std::max<size_t>(1, M) * 4));
         HIPCHK(ctx, ctx->d_mrow.ensure(std::max<size_t>(1, M) * 8));
@@ -647,7 +650,9 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
             HIPCHK(ctx, hipMemcpyAsync(ctx->d_groups.p, cp.groups.data(), G * sizeof(PlanGroup), hipMemcpyHostToDevice, ctx->stream));
             HIPCHK(ctx, hipMemcpyAsync(ctx->d_gmembers.p, cp.gmembers.data(), M * 4, hipMemcpyHostToDevice, ctx->stream));
             HIPCHK(ctx, hipMemcpyAsync(ctx->d_member_pair.p, cp.member_pair.data(), M * 4, hipMemcpyHostToDevice, ctx->stream));
+            HIPCHK(ctx, hipMemcpyAsync(ctx->d_member_group.p, cp.member_group.data(), M * 4, hipMemcpyHostToDevice, ctx->stream));
         }
+        HIPCHK(ctx, hipMemsetAsync(ctx->d_gtot.p, 0, std::max<size_t>(1, G) * 4, ctx->stream));
         HIPCHK(ctx, hipMemcpyAsync(ctx->d_ppair.p, cp.ppair.data(), P * sizeof(PlanPair), hipMemcpyHostToDevice, ctx->stream));
         // (the uploads above come from pageable vectors that die with this function: hipMemcpyAsync has staged them when it returns)
         HIPCHK(ctx, hipMemsetAsync(ctx->d_cnt.p, 0, std::max<size_t>(1, M) * 4, ctx->stream));
@@ -658,7 +663,7 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
         hc.lap("plan tables + uploads");
         const PlanPair* dpp = ctx->d_ppair.as<PlanPair>();
         hipLaunchKernelGGL(pf_count_kernel, dim3((unsigned)(2 * P)), dim3(256), 0, ctx->stream, dp, dpf, dpp, (const float*)tuv,
-                           (const unsigned*)colmask, ctx->d_cnt.as<int>());
+                           (const unsigned*)colmask, ctx->d_cnt.as<int>(), (const int*)ctx->d_member_group.as<int>(), ctx->d_gtot.as<int>());
         HIPCHK(ctx, hipGetLastError());
         DBGSYNC(ctx, "pf_count_kernel");
         PlanOut po = {};
@@ -666,7 +671,7 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
         po.vpf = ctx->d_vpf.as<PfPair>();
         po.lists = ctx->d_lists.as<CandList>();
         po.items = ctx->d_vitems.as<WorkItem>();
-        po.mrow = ctx->d_mrow.as<long long>();
+        po.grow0 = ctx->d_grow0.as<long long>();
         po.summary = ctx->d_summary.as<PlanSummary>();
         po.row_src = ctx->d_row_src.as<const _Float16*>();
         po.zero_row = ctx->d_zero_row.as<_Float16>();
@@ -676,9 +681,15 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
         po.cand_cap = cand_cap;
         po.items_cap = items_cap;
         hipLaunchKernelGGL(pf_plan_kernel, dim3(1), dim3(kPlanThreads), 0, ctx->stream, ctx->d_groups.as<PlanGroup>(), (int)G,
-                           (const int*)ctx->d_gmembers.as<int>(), (const int*)ctx->d_cnt.as<int>(), po);
+                           (const int*)ctx->d_gtot.as<int>(), po);
         HIPCHK(ctx, hipGetLastError());
         DBGSYNC(ctx, "pf_plan_kernel");
+        if (G > 0)
+            hipLaunchKernelGGL(pf_member_rows_kernel, dim3((unsigned)((G + 3) / 4)), dim3(256), 0, ctx->stream, ctx->d_groups.as<PlanGroup>(), (int)G,
+                               (const int*)ctx->d_gmembers.as<int>(), (const int*)ctx->d_cnt.as<int>(),
+                               (const long long*)ctx->d_grow0.as<long long>(), ctx->d_mrow.as<long long>());
+        HIPCHK(ctx, hipGetLastError());
+        DBGSYNC(ctx, "pf_member_rows_kernel");
         hipLaunchKernelGGL(pf_assign_kernel, dim3((unsigned)(2 * P)), dim3(256), 0, ctx->stream, dp, dpf, dpp, (const float*)tuv,
                            (const unsigned*)colmask, (const long long*)ctx->d_mrow.as<long long>(),
                            ctx->d_live_idx.as<int>(), ctx->d_row_pair.as<int>(), ctx->d_cmp_tu.as<float>(),
@@ -1060,7 +1071,7 @@ void msfm_destroy(msfm_ctx* ctx) {
                       &ctx->d_st_qt, &ctx->d_st_d, &ctx->d_counts, &ctx->d_offsets, &ctx->d_out_qt,
                       &ctx->d_out_d, &ctx->d_fix_count, &ctx->d_fix_list, &ctx->d_pf, &ctx->d_tu, &ctx->d_tv,
                       &ctx->d_cand, &ctx->d_cand_s, &ctx->d_cand_count, &ctx->d_best, &ctx->d_second, &ctx->d_maxima,
-                      &ctx->d_zero_row, &ctx->d_cmp_tu, &ctx->d_live_idx, &ctx->d_vpairs, &ctx->d_vpf, &ctx->d_row_src, &ctx->d_colmask, &ctx->d_groups, &ctx->d_gmembers, &ctx->d_member_pair, &ctx->d_ppair, &ctx->d_cnt, &ctx->d_mrow, &ctx->d_summary, &ctx->d_overflow, &ctx->d_totals,
+                      &ctx->d_zero_row, &ctx->d_cmp_tu, &ctx->d_live_idx, &ctx->d_vpairs, &ctx->d_vpf, &ctx->d_row_src, &ctx->d_colmask, &ctx->d_groups, &ctx->d_gmembers, &ctx->d_member_pair, &ctx->d_member_group, &ctx->d_gtot, &ctx->d_grow0, &ctx->d_ppair, &ctx->d_cnt, &ctx->d_mrow, &ctx->d_summary, &ctx->d_overflow, &ctx->d_totals,
                       &ctx->d_vitems, &ctx->d_lists, &ctx->d_row_pair, &ctx->d_cand_pair, &ctx->d_vf_pairs, &ctx->d_vf_x1, &ctx->d_vf_y1,
                       &ctx->d_vf_x2, &ctx->d_vf_y2, &ctx->d_vf_hyp, &ctx->d_vf_best_it, &ctx->d_vf_best_count,
                       &ctx->d_vf_flags, &ctx->d_st2_qt, &ctx->d_st2_d, &ctx->d_counts2};

@@ -15,8 +15,9 @@
 // synchronisations and a std::map in the middle of the pipeline.  Now:
 //
 //   pf_count_kernel    live rows per member                                          grid = 2 x pairs
-//   pf_plan_kernel     prefix sums -> row ranges of members and groups (512-aligned), the groups' sweep descriptors
+//   pf_plan_kernel     prefix sums -> row ranges of the groups (512-aligned), the groups' sweep descriptors
 //                      (PairDesc / PfPair / CandList), the work-item list, capacity check   one workgroup
+//   pf_member_rows_kernel  first compact row of every member (a wave-level scan per group)   one wave per group
 //   pf_assign_kernel   every live row gets its slot(s): index, pair, threshold, address of its operand row (the sweep
 //                      reads its A fragments through that table: no compacted copy of the rows)   grid = 2 x pairs
 //
@@ -57,7 +58,8 @@ struct PlanSummary {
 
 // live rows per member.  dir 0: rows of image 1 with a threshold; dir 1: per mask bit, the live columns that carry it.
 __global__ void pf_count_kernel(const PairDesc* __restrict__ pairs, const PfPair* __restrict__ pf, const PlanPair* __restrict__ pp_plan,
-                                const float* __restrict__ tuv, const unsigned* __restrict__ colmask, int* __restrict__ cnt) {
+                                const float* __restrict__ tuv, const unsigned* __restrict__ colmask, int* __restrict__ cnt,
+                                const int* __restrict__ member_group, int* __restrict__ gtot /* rows per group (zeroed) */) {
     const int p = blockIdx.x >> 1, dir = blockIdx.x & 1;
     const PlanPair pl = pp_plan[p];
     if (pl.fwd_member < 0) return;
@@ -72,7 +74,10 @@ __global__ void pf_count_kernel(const PairDesc* __restrict__ pairs, const PfPair
         for (int m = 32; m >= 1; m >>= 1) c += __shfl_xor(c, m);
         if ((threadIdx.x & 63) == 0) atomicAdd(&hist[32], c);
         __syncthreads();
-        if (threadIdx.x == 0) cnt[pl.fwd_member] = hist[32];
+        if (threadIdx.x == 0) {
+            cnt[pl.fwd_member] = hist[32];
+            atomicAdd(&gtot[member_group[pl.fwd_member]], hist[32]);
+        }
     } else {
         for (int e = threadIdx.x; e < pd.n2; e += blockDim.x) {
             unsigned m = (tuv[pp.tv_off + e] != -f_inf()) ? colmask[pp.tv_off + e] : 0u;
@@ -83,7 +88,10 @@ __global__ void pf_count_kernel(const PairDesc* __restrict__ pairs, const PfPair
             }
         }
         __syncthreads();
-        if ((int)threadIdx.x < pl.rev_bits) cnt[pl.rev_member0 + threadIdx.x] = hist[threadIdx.x];
+        if ((int)threadIdx.x < pl.rev_bits) {
+            cnt[pl.rev_member0 + threadIdx.x] = hist[threadIdx.x];
+            if (hist[threadIdx.x]) atomicAdd(&gtot[member_group[pl.rev_member0 + threadIdx.x]], hist[threadIdx.x]);
+        }
     }
 }
 
@@ -95,7 +103,7 @@ struct PlanOut {
     PfPair* vpf;
     CandList* lists;          // [n_groups]
     WorkItem* items;          // [items_cap], pre-filled with pair = -1
-    long long* mrow;          // [n_members] first compact row of the member
+    long long* grow0;         // [n_groups] first compact row of the group (-1: invalid plan); pf_member_rows_kernel -> mrow
     PlanSummary* summary;
     const _Float16* const* row_src;  // per compact row: its operand row (filled by pf_assign_kernel)
     const _Float16* zero_row;        // 272 zero bytes
@@ -127,7 +135,7 @@ __device__ __forceinline__ long long plan_block_exclusive_scan(long long v, long
 }
 
 __global__ __launch_bounds__(kPlanThreads) void pf_plan_kernel(const PlanGroup* __restrict__ groups, int n_groups,
-                                                         const int* __restrict__ gmembers, const int* __restrict__ cnt, PlanOut out) {
+                                                         const int* __restrict__ gtot, PlanOut out) {
     const int tid = threadIdx.x, nt = blockDim.x;
     __shared__ long long s_base_rows, s_base_cand, s_base_items[8], s_base_rev[8];
     __shared__ int s_ok;
@@ -169,7 +177,7 @@ __global__ __launch_bounds__(kPlanThreads) void pf_plan_kernel(const PlanGroup* 
             PlanGroup G = {};
             if (g < n_groups) {
                 G = groups[g];
-                for (int k = 0; k < G.count; ++k) rows += cnt[gmembers[G.first + k]];
+                rows = gtot[g];   // (summed by pf_count_kernel: a serial loop over up to 127 members here was most of this kernel)
             }
             const long long rows512 = (rows + kPfWgRows - 1) / kPfWgRows * kPfWgRows;
             const long long ablocks = rows512 / kPfWgRows;
@@ -227,12 +235,7 @@ __global__ __launch_bounds__(kPlanThreads) void pf_plan_kernel(const PlanGroup* 
                 L.live_idx = out.live_idx + row0;
                 L.row_pair = out.row_pair + row0;
                 out.lists[g] = L;
-                long long r = row0;
-                for (int k = 0; k < G.count; ++k) {
-                    const int m = gmembers[G.first + k];
-                    out.mrow[m] = ok ? r : -1;
-                    r += cnt[m];
-                }
+                out.grow0[g] = ok ? row0 : -1;
                 if (ok) {
                     const int nblk = G.bt_end - G.bt_begin;
                     long long k = item0;
@@ -257,6 +260,28 @@ __global__ __launch_bounds__(kPlanThreads) void pf_plan_kernel(const PlanGroup* 
             if (tid < 8) { s_base_items[tid] += ti[tid]; s_base_rev[tid] += ti_rev[tid]; }
             __syncthreads();
         }
+    }
+}
+
+// first compact row of every member: the group's first row + the rows of the members before it.  One wave per group.
+__global__ void pf_member_rows_kernel(const PlanGroup* __restrict__ groups, int n_groups, const int* __restrict__ gmembers,
+                                      const int* __restrict__ cnt, const long long* __restrict__ grow0, long long* __restrict__ mrow) {
+    const int g = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (g >= n_groups) return;
+    const PlanGroup G = groups[g];
+    const long long row0 = grow0[g];
+    long long base = 0;
+    for (int k0 = 0; k0 < G.count; k0 += 64) {
+        const int k = k0 + lane;
+        const int m = k < G.count ? gmembers[G.first + k] : -1;
+        const int c = m >= 0 ? cnt[m] : 0;
+        int inc = c;
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(inc, d);
+            if (lane >= d) inc += o;
+        }
+        if (m >= 0) mrow[m] = row0 >= 0 ? row0 + base + (inc - c) : -1;
+        base += __shfl(inc, 63);
     }
 }
 
