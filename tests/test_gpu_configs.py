@@ -79,3 +79,43 @@ def test_config5_u8_16384(gpu_ctx, oracle):
     p = gpu_ctx.profile()
     assert p["descriptor_pairs"] == prof_pairs and p["prefilter_pairs"] == 1
     assert len(q) > 400 and (np.diff(q) > 0).all()
+
+
+@pytest.mark.parametrize("byte_store", [False, True])
+def test_very_tall_image_against_a_small_one(gpu_ctx, byte_store):
+    """Edge of the size range: 140 005 rows (274 A blocks of 512 rows: the 32-bit block mask of the reverse plan covers
+    9 blocks per bit) against 700 rows, both orientations, every matrix-core route against the brute-force one."""
+    rng = np.random.default_rng(140005)
+    if byte_store:
+        small = synth.u8_images(1, 700, seed=3, dup_frac=0.0, as_float=False)[0]
+        tall = synth.u8_images(1, 140005, seed=4, dup_frac=0.0, as_float=False)[0]
+        rows = rng.choice(len(tall), 300, replace=False)
+        tall[rows] = np.clip(small[:300].astype(np.int32) + rng.integers(-2, 3, (300, 128)), 0, 255).astype(np.uint8)
+        kw = {"ratio": 0.8, "cross_check": True, "max_distance": 1e9}
+        modes = (1, 2, 0)
+    else:
+        small = synth.rootsift_images(1, 700, seed=3, n_proto=1500)[0]
+        tall = synth.rootsift_images(1, 140005, seed=4, n_proto=200000)[0]
+        rows = rng.choice(len(tall), 300, replace=False)
+        v = np.abs(small[:300] * (1 + 0.03 * rng.standard_normal((300, 128)).astype(F32)))
+        tall[rows] = v / np.linalg.norm(v, axis=1, keepdims=True)
+        kw = {"ratio": 0.8, "cross_check": True, "max_distance": 0.7}
+        modes = (1, 0)
+    gpu_ctx.upload_image(0, tall)
+    gpu_ctx.upload_image(1, small)
+    pairs = np.array([[0, 1], [1, 0]], np.int32)
+    res = {}
+    try:
+        for m in modes:
+            gpu_ctx.set_prefilter(m)
+            res[m] = gpu_ctx.match_pairs(pairs, **kw)
+            if m:
+                assert gpu_ctx.profile()["fallback_pairs"] == 0
+    finally:
+        gpu_ctx.set_prefilter(True)
+    for m in modes[:-1]:
+        for x, y in zip(res[m], res[0]):
+            assert np.array_equal(b(x), b(y)), m
+    offs = res[0][0]
+    assert offs[1] >= 200 and offs[2] - offs[1] >= 200          # the planted rows match in both orientations
+    gpu_ctx.clear_images()
