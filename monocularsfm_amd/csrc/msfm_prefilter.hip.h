@@ -220,30 +220,52 @@ __global__ void pf_thresholds_kernel(const PairDesc* __restrict__ pairs, const P
     }
     if (e < pd.n2pad) {
         // column partials of sweep 1: per 512-row A block the two largest of the accumulator maxima (-S~/2) over four
-        // disjoint row classes; the second smallest S~ over all of them is an upper bound of the column's second-smallest
+        // disjoint row classes; the second smallest S~ over all of them is an upper bound of the column's second-smallest.
+        // Up to 16 blocks (8192 rows) the blocks' minima stay in registers for the mask below.
         float s0 = f_inf(), s1 = f_inf();
         const float2* cp2 = reinterpret_cast<const float2*>(cp_s0);
-        for (int p = 0; p < pd.a_blocks256; ++p) {
-            const float2 m = cp2[pd.cp_off + (long long)p * pd.n2pad + e];
-            v2_merge(s0, s1, -2.f * m.x, -2.f * m.y);
+        const int nb = pd.a_blocks256;
+        float bmin[16];
+        if (nb <= 16) {
+#pragma unroll
+            for (int p = 0; p < 16; ++p) {
+                bmin[p] = f_inf();
+                if (p < nb) {
+                    const float2 m = cp2[pd.cp_off + (long long)p * pd.n2pad + e];
+                    bmin[p] = -2.f * m.x;
+                    v2_merge(s0, s1, -2.f * m.x, -2.f * m.y);
+                }
+            }
+        } else {
+            for (int p = 0; p < nb; ++p) {
+                const float2 m = cp2[pd.cp_off + (long long)p * pd.n2pad + e];
+                v2_merge(s0, s1, -2.f * m.x, -2.f * m.y);
+            }
         }
-        const float nb = pp.b_nrm[e];
-        const float eps = pp.i8 ? kI8Eps : kEpsRel * (nb + pp.a_nrm_max) + kEpsAbs * (sqrtf(nb) + sqrtf(pp.a_nrm_max)) + eps_norm;
-        const float slack = pp.i8 ? 2.f * eps : 2.f * eps + 1e-5f * (fabsf(s1) + nb + pp.a_nrm_max);
-        const bool live = (e < pd.n2) && !pf_dead(s0, s1, nb, eps, pp.a_nrm_max, pr);
+        const float nb_ = pp.b_nrm[e];
+        const float eps = pp.i8 ? kI8Eps : kEpsRel * (nb_ + pp.a_nrm_max) + kEpsAbs * (sqrtf(nb_) + sqrtf(pp.a_nrm_max)) + eps_norm;
+        const float slack = pp.i8 ? 2.f * eps : 2.f * eps + 1e-5f * (fabsf(s1) + nb_ + pp.a_nrm_max);
+        const bool live = (e < pd.n2) && !pf_dead(s0, s1, nb_, eps, pp.a_nrm_max, pr);
         const float T = live ? s1 + slack : -f_inf();
         tv[pp.tv_off + e] = T;
         if (colmask) {
             // which 512-row blocks of image 1 can hold a candidate of this column at all: the block's smallest S~ must
             // not exceed T.  Bit b covers blocks [b g, (b + 1) g), g = ceil(blocks / 32) (1 up to 16384 rows).  The
             // reverse direction of sweep 2 only visits those blocks (pf_plan.hip.h).
-            const int g = (pd.a_blocks256 + 31) / 32;
+            const int g = (nb + 31) / 32;
             unsigned mask = 0;
-            if (live)
-                for (int p = 0; p < pd.a_blocks256; ++p) {
-                    const float smin = -2.f * cp2[pd.cp_off + (long long)p * pd.n2pad + e].x;
-                    if (smin <= T) mask |= 1u << (p / g);
+            if (live) {
+                if (nb <= 16) {
+#pragma unroll
+                    for (int p = 0; p < 16; ++p)
+                        if (p < nb && bmin[p] <= T) mask |= 1u << p;   // (g = 1)
+                } else {
+                    for (int p = 0; p < nb; ++p) {
+                        const float smin = -2.f * cp2[pd.cp_off + (long long)p * pd.n2pad + e].x;
+                        if (smin <= T) mask |= 1u << (p / g);
+                    }
                 }
+            }
             colmask[pp.tv_off + e] = mask;
         }
     }
