@@ -142,7 +142,7 @@ struct msfm_ctx {
     std::vector<Image> images;
     std::string err;
 
-    DevBuf d_pairs, d_items, d_stage;
+    DevBuf d_pairs, d_items, d_item_base, d_stage;
     DevBuf d_rp_s0, d_rp_i0, d_rp_s1, d_cp_s0, d_cp_i0, d_cp_s1;
     DevBuf d_k_i0, d_k_d0, d_k_d1;
     DevBuf d_st_qt, d_st_d, d_counts, d_offsets, d_out_qt, d_out_d;
@@ -227,18 +227,19 @@ struct Batch {
     std::vector<PairDesc> pairs;
     std::vector<PfPair> pf;
     std::vector<int> id1, id2;       // store slots of the pairs' images
-    std::vector<WorkItem> items;
+    std::vector<int> item_base;      // per pair: index of its first work item in the linear list (-1: none on this path)
+    size_t n_items = 0, items_per_xcd = 0;   // length of the XCD-interleaved list (a multiple of 8), items per XCD chunk
     long long rp_elems = 0, cp_elems = 0, kf_elems = 0, kr_elems = 0, out_elems = 0, cand_elems = 0;
     int max_npad = 0;
     int64_t desc_pairs = 0;
     int64_t algo_bytes = 0;
 };
 
-// Work items of the pairs whose `path` matches.  Items of one pair are contiguous; the list is then
-// interleaved over the 8 XCDs (workgroup b runs on XCD b % 8) so that the workgroups streaming the
-// same B panels share one L2.
+// Work items of the pairs whose `path` matches: only their NUMBERING is made on the host -- per pair the index of its
+// first item in the linear list -- the list itself (85 000 items of 32 B for the bench job) is written by
+// build_items_kernel from the pair descriptors.  Items of one pair are contiguous; the linear list is cut into 8 chunks,
+// one per XCD (workgroup b runs on XCD b % 8): linear item k sits at position (k % per) * 8 + k / per.
 void build_items(Batch& b, int path) {
-    std::vector<WorkItem> lin;
     // Pairs in the order of their STREAMED image (id2): the 32 workgroups of an XCD walk 32 consecutive items of their
     // chunk at a time, and those then stream the same B image -- one image (1.4 MB at 5000 rows) stays in the XCD's 4 MB
     // L2 while ~30 workgroups read it, instead of three or four images evicting one another (pair order = id1-major:
@@ -247,31 +248,37 @@ void build_items(Batch& b, int path) {
     for (size_t p = 0; p < order.size(); ++p) order[p] = (int)p;
     if (b.id2.size() == b.pairs.size())
         std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return b.id2[(size_t)x] < b.id2[(size_t)y]; });
+    b.item_base.assign(b.pairs.size(), -1);
+    long long n = 0;
     for (size_t q = 0; q < order.size(); ++q) {
         const size_t p = (size_t)order[q];
-        PairDesc& pd = b.pairs[p];
+        const PairDesc& pd = b.pairs[p];
         if (!pd.valid || pd.path != path) continue;
-        for (int r = 0; r < pd.ranges; ++r) {
-            const int t0 = (int)((long long)pd.b_tiles * r / pd.ranges);
-            const int t1 = (int)((long long)pd.b_tiles * (r + 1) / pd.ranges);
-            const int nab = path == 1 ? pd.a_blocks256 : pd.a_blocks;
-            for (int ab = 0; ab < nab; ++ab) {
-                WorkItem w = {};
-                w.pair = (int)p;
-                w.a_blk = ab;
-                w.bt_begin = t0;
-                w.bt_end = t1;
-                w.range = r;
-                lin.push_back(w);
-            }
-        }
+        b.item_base[p] = (int)n;
+        n += (long long)pd.ranges * (path == 1 ? pd.a_blocks256 : pd.a_blocks);
     }
-    const size_t n = lin.size();
-    const size_t per = (n + 7) / 8;
-    b.items.assign(per * 8, WorkItem{-1, 0, 0, 0, 0, {0, 0, 0}});
-    for (size_t k = 0; k < n; ++k) {
-        const size_t x = k / per, j = k % per;
-        b.items[j * 8 + x] = lin[k];
+    b.items_per_xcd = (size_t)((n + 7) / 8);
+    b.n_items = b.items_per_xcd * 8;
+}
+
+// one workgroup per pair: its items, in the order (range, A block), at their XCD-interleaved positions
+__global__ void build_items_kernel(const PairDesc* __restrict__ pairs, const int* __restrict__ item_base, int path, int per,
+                                   WorkItem* __restrict__ items) {
+    const int p = blockIdx.x;
+    const int base = item_base[p];
+    if (base < 0) return;
+    const PairDesc pd = pairs[p];
+    const int nab = path == 1 ? pd.a_blocks256 : pd.a_blocks;
+    for (int i = threadIdx.x; i < pd.ranges * nab; i += blockDim.x) {
+        const int r = i / nab, ab = i - r * nab;
+        WorkItem w = {};
+        w.pair = p;
+        w.a_blk = ab;
+        w.bt_begin = (int)((long long)pd.b_tiles * r / pd.ranges);
+        w.bt_end = (int)((long long)pd.b_tiles * (r + 1) / pd.ranges);
+        w.range = r;
+        const int k = base + i;
+        items[(size_t)(k % per) * 8 + (size_t)(k / per)] = w;
     }
 }
 
@@ -373,20 +380,17 @@ int upload_pairs(msfm_ctx* ctx, Batch& b) {
     return MSFM_OK;
 }
 
-int upload_items(msfm_ctx* ctx, Batch& b) {
-    HIPCHK(ctx, ctx->d_items.ensure(std::max<size_t>(1, b.items.size()) * sizeof(WorkItem)));
-    if (!b.items.empty())
-        HIPCHK(ctx, hipMemcpyAsync(ctx->d_items.p, b.items.data(), b.items.size() * sizeof(WorkItem), hipMemcpyHostToDevice, ctx->stream));
+int upload_items(msfm_ctx* ctx, Batch& b, int path) {
+    const size_t P = b.pairs.size();
+    HIPCHK(ctx, ctx->d_items.ensure(std::max<size_t>(1, b.n_items) * sizeof(WorkItem)));
+    if (b.n_items == 0) return MSFM_OK;
+    HIPCHK(ctx, ctx->d_item_base.ensure(P * 4));
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_items.p, 0xff, b.n_items * sizeof(WorkItem), ctx->stream));   // pair = -1: padding item
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_item_base.p, b.item_base.data(), P * 4, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(build_items_kernel, dim3((unsigned)P), dim3(64), 0, ctx->stream, (const PairDesc*)ctx->d_pairs.as<PairDesc>(),
+                       (const int*)ctx->d_item_base.as<int>(), path, (int)b.items_per_xcd, ctx->d_items.as<WorkItem>());
+    HIPCHK(ctx, hipGetLastError());
     return MSFM_OK;
-}
-
-// XCD interleave of a linear item list (see build_items)
-std::vector<WorkItem> interleave_items(const std::vector<WorkItem>& lin) {
-    const size_t n = lin.size();
-    const size_t per = (n + 7) / 8;
-    std::vector<WorkItem> out(per * 8, WorkItem{-1, 0, 0, 0, 0, {0, 0, 0}});
-    for (size_t k = 0; k < n; ++k) out[(k % per) * 8 + k / per] = lin[k];
-    return out;
 }
 
 // ---- static tables of the device-side plan of sweep 2 (msfm_plan.hip.h) -----------------------------------------
@@ -553,7 +557,7 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
         }
     }
     build_items(b, 1);
-    if (b.items.empty()) return MSFM_OK;
+    if (b.n_items == 0) return MSFM_OK;
     const long long kn = std::max<long long>(1, b.kf_elems + b.kr_elems);
     HIPCHK(ctx, ctx->d_rp_s0.ensure(std::max<long long>(1, b.rp_elems) * 4));
     HIPCHK(ctx, ctx->d_rp_s1.ensure(std::max<long long>(1, b.rp_elems) * 4));
@@ -565,7 +569,7 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
     HIPCHK(ctx, ctx->d_second.ensure(kn * 8));
     int rc = upload_pairs(ctx, b);
     if (rc != MSFM_OK) return rc;
-    rc = upload_items(ctx, b);
+    rc = upload_items(ctx, b, 1);
     if (rc != MSFM_OK) return rc;
     HIPCHK(ctx, hipMemsetAsync(ctx->d_best.p, 0xff, kn * 8, ctx->stream));
     HIPCHK(ctx, hipMemsetAsync(ctx->d_second.p, 0xff, kn * 8, ctx->stream));
@@ -585,14 +589,14 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
     hc.lap("sweep-1 setup + uploads");
     HIPCHK(ctx, hipEventRecord(e0, ctx->stream));
     if (i8)
-        hipLaunchKernelGGL(sweep_i8_kernel<1>, dim3(std::min<unsigned>(sweep_grid, (unsigned)b.items.size())), dim3(kI8Threads), kI8LdsBytes, ctx->stream, dp, dpf,
+        hipLaunchKernelGGL(sweep_i8_kernel<1>, dim3(std::min<unsigned>(sweep_grid, (unsigned)b.n_items)), dim3(kI8Threads), kI8LdsBytes, ctx->stream, dp, dpf,
                            ctx->d_items.as<WorkItem>(), ctx->d_rp_s0.as<float>(), ctx->d_rp_s1.as<float>(), ctx->d_cp_s0.as<float>(),
-                           (const float*)nullptr, (int2*)nullptr, (unsigned long long*)nullptr, (const int*)nullptr, (int)b.items.size(), (int*)nullptr);
+                           (const float*)nullptr, (int2*)nullptr, (unsigned long long*)nullptr, (const int*)nullptr, (int)b.n_items, (int*)nullptr);
     else
-        hipLaunchKernelGGL(sweep_kernel<1>, dim3(std::min<unsigned>(sweep_grid, (unsigned)b.items.size())), block, kPfLdsBytes, ctx->stream, dp, dpf,
+        hipLaunchKernelGGL(sweep_kernel<1>, dim3(std::min<unsigned>(sweep_grid, (unsigned)b.n_items)), block, kPfLdsBytes, ctx->stream, dp, dpf,
                            ctx->d_items.as<WorkItem>(), ctx->d_rp_s0.as<float>(), ctx->d_rp_s1.as<float>(),
                            ctx->d_cp_s0.as<float>(), (float*)nullptr, (const float*)nullptr, (const float*)nullptr,
-                           (int2*)nullptr, (unsigned long long*)nullptr, (const int*)nullptr, (int)b.items.size(), (int*)nullptr);
+                           (int2*)nullptr, (unsigned long long*)nullptr, (const int*)nullptr, (int)b.n_items, (int*)nullptr);
     HIPCHK(ctx, hipGetLastError());
     DBGSYNC(ctx, "sweep_kernel<1>");
     HIPCHK(ctx, hipEventRecord(e1, ctx->stream));
@@ -736,10 +740,10 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
         HIPCHK(ctx, hipMemcpyAsync(ctx->d_lists.p, lists.data(), P * sizeof(CandList), hipMemcpyHostToDevice, ctx->stream));
         HIPCHK(ctx, hipMemcpyAsync(ctx->d_pf.p, b.pf.data(), P * sizeof(PfPair), hipMemcpyHostToDevice, ctx->stream));  // cand_off / cap
         HIPCHK(ctx, hipEventRecord(e2, ctx->stream));
-        hipLaunchKernelGGL(sweep_kernel<2>, dim3(std::min<unsigned>(sweep_grid, (unsigned)b.items.size())), block, kPfLdsBytes, ctx->stream, dp, dpf,
+        hipLaunchKernelGGL(sweep_kernel<2>, dim3(std::min<unsigned>(sweep_grid, (unsigned)b.n_items)), block, kPfLdsBytes, ctx->stream, dp, dpf,
                            ctx->d_items.as<WorkItem>(), (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr,
                            (const float*)tuv, (const float*)tuv, ctx->d_cand.as<int2>(), ctx->d_cand_count.as<unsigned long long>(),
-                           (const int*)nullptr, (int)b.items.size(), (int*)nullptr);
+                           (const int*)nullptr, (int)b.n_items, (int*)nullptr);
         HIPCHK(ctx, hipGetLastError());
         DBGSYNC(ctx, "sweep_kernel<2>");
         ctx->prof.sweep2_launches += 1;
@@ -877,7 +881,7 @@ int run_exact(msfm_ctx* ctx, Batch& b, size_t ev_base) {
     const size_t P = b.pairs.size();
     assign_partials(b, 0, 4 * ctx->cu_count);
     build_items(b, 0);
-    if (b.items.empty()) return MSFM_OK;
+    if (b.n_items == 0) return MSFM_OK;
     HIPCHK(ctx, ctx->d_rp_s0.ensure(std::max<long long>(1, b.rp_elems) * 4));
     HIPCHK(ctx, ctx->d_rp_i0.ensure(std::max<long long>(1, b.rp_elems) * 4));
     HIPCHK(ctx, ctx->d_rp_s1.ensure(std::max<long long>(1, b.rp_elems) * 4));
@@ -886,12 +890,12 @@ int run_exact(msfm_ctx* ctx, Batch& b, size_t ev_base) {
     HIPCHK(ctx, ctx->d_cp_s1.ensure(std::max<long long>(1, b.cp_elems) * 4));
     int rc = upload_pairs(ctx, b);
     if (rc != MSFM_OK) return rc;
-    rc = upload_items(ctx, b);
+    rc = upload_items(ctx, b, 0);
     if (rc != MSFM_OK) return rc;
     hipEvent_t e0 = get_event(ctx, ev_base), e1 = get_event(ctx, ev_base + 1);
     if (!e0 || !e1) return fail(ctx, MSFM_E_DEVICE, "hipEventCreate failed");
     HIPCHK(ctx, hipEventRecord(e0, ctx->stream));
-    const dim3 grid((unsigned)b.items.size()), block(kThreads);
+    const dim3 grid((unsigned)b.n_items), block(kThreads);
     if (ctx->order == MSFM_ORDER_SSE4X4)
         hipLaunchKernelGGL(dist_top2_kernel<0>, grid, block, kLdsBytes, ctx->stream,
                            ctx->d_pairs.as<PairDesc>(), ctx->d_items.as<WorkItem>(),
@@ -944,7 +948,7 @@ int run_knn(msfm_ctx* ctx, Batch& b, size_t ev_base, bool* exact_launched, Prune
     if (any_exact) {
         rc = run_exact(ctx, b, ev_base);
         if (rc != MSFM_OK) return rc;
-        *exact_launched = !b.items.empty();
+        *exact_launched = b.n_items != 0;
     } else if (!any_pf) {
         rc = upload_pairs(ctx, b);  // later kernels still read the (all-invalid) pair table
         if (rc != MSFM_OK) return rc;
@@ -1066,7 +1070,7 @@ void msfm_destroy(msfm_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     for (auto& im : ctx->images) free_image(im);
-    DevBuf* bufs[] = {&ctx->d_pairs, &ctx->d_items, &ctx->d_stage, &ctx->d_rp_s0, &ctx->d_rp_i0, &ctx->d_rp_s1,
+    DevBuf* bufs[] = {&ctx->d_pairs, &ctx->d_items, &ctx->d_item_base, &ctx->d_stage, &ctx->d_rp_s0, &ctx->d_rp_i0, &ctx->d_rp_s1,
                       &ctx->d_cp_s0, &ctx->d_cp_i0, &ctx->d_cp_s1, &ctx->d_k_i0, &ctx->d_k_d0, &ctx->d_k_d1,
                       &ctx->d_st_qt, &ctx->d_st_d, &ctx->d_counts, &ctx->d_offsets, &ctx->d_out_qt,
                       &ctx->d_out_d, &ctx->d_fix_count, &ctx->d_fix_list, &ctx->d_pf, &ctx->d_tu, &ctx->d_tv,
@@ -1554,7 +1558,7 @@ int msfm_knn2_pair(msfm_ctx* ctx, int id1, int id2, int32_t* fwd_idx0, float* fw
     int regrows = 0, fallbacks = 0;
     std::vector<char> force_exact(1, 0);
     for (int attempt = 0;; ++attempt) {
-        b.items.clear();
+        b.n_items = 0;
         b.rp_elems = b.cp_elems = b.kf_elems = b.kr_elems = b.out_elems = b.cand_elems = 0;
         b.desc_pairs = b.algo_bytes = 0;
         b.pairs[0].path = b.pf[0].use = force_exact[0] ? 0 : pp.use;
