@@ -571,8 +571,10 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
     if (rc != MSFM_OK) return rc;
     rc = upload_items(ctx, b, 1);
     if (rc != MSFM_OK) return rc;
-    HIPCHK(ctx, hipMemsetAsync(ctx->d_best.p, 0xff, kn * 8, ctx->stream));
-    HIPCHK(ctx, hipMemsetAsync(ctx->d_second.p, 0xff, kn * 8, ctx->stream));
+    if (!compact) {   // (compacted sweep 2: pf_assign_kernel initialises the live slots only)
+        HIPCHK(ctx, hipMemsetAsync(ctx->d_best.p, 0xff, kn * 8, ctx->stream));
+        HIPCHK(ctx, hipMemsetAsync(ctx->d_second.p, 0xff, kn * 8, ctx->stream));
+    }
     HIPCHK(ctx, ctx->d_overflow.ensure(P));
     HIPCHK(ctx, ctx->d_totals.ensure(64));   // [0..1] candidate / overflow totals (64-bit), ints [8..15]: per-XCD item cursors of sweep 2
     HIPCHK(ctx, hipMemsetAsync(ctx->d_totals.p, 0, 64, ctx->stream));
@@ -697,7 +699,8 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
         hipLaunchKernelGGL(pf_assign_kernel, dim3((unsigned)(2 * P)), dim3(256), 0, ctx->stream, dp, dpf, dpp, (const float*)tuv,
                            (const unsigned*)colmask, (const long long*)ctx->d_mrow.as<long long>(),
                            ctx->d_live_idx.as<int>(), ctx->d_row_pair.as<int>(), ctx->d_cmp_tu.as<float>(),
-                           ctx->d_row_src.as<const _Float16*>(), i8 ? kI8RowBytes / 2 : kPfRowHalfs);
+                           ctx->d_row_src.as<const _Float16*>(), i8 ? kI8RowBytes / 2 : kPfRowHalfs,
+                           ctx->d_best.as<unsigned long long>(), ctx->d_second.as<unsigned long long>());
         HIPCHK(ctx, hipGetLastError());
         DBGSYNC(ctx, "pf_assign_kernel");
         HIPCHK(ctx, hipEventRecord(e2, ctx->stream));

@@ -291,7 +291,8 @@ __global__ void pf_member_rows_kernel(const PlanGroup* __restrict__ groups, int 
 __global__ void pf_assign_kernel(const PairDesc* __restrict__ pairs, const PfPair* __restrict__ pf, const PlanPair* __restrict__ pp_plan,
                                  const float* __restrict__ tuv, const unsigned* __restrict__ colmask, const long long* __restrict__ mrow,
                                  int* __restrict__ live_idx, int* __restrict__ row_pair, float* __restrict__ cmp_tu,
-                                 const _Float16** __restrict__ row_src, int row_halfs /* 136: fp16 rows, 72: byte rows */) {
+                                 const _Float16** __restrict__ row_src, int row_halfs /* 136: fp16 rows, 72: byte rows */,
+                                 unsigned long long* __restrict__ best, unsigned long long* __restrict__ second) {
     const int p = blockIdx.x >> 1, dir = blockIdx.x & 1;
     const PlanPair pl = pp_plan[p];
     if (pl.fwd_member < 0) return;
@@ -312,6 +313,10 @@ __global__ void pf_assign_kernel(const PairDesc* __restrict__ pairs, const PfPai
     for (int e = threadIdx.x; e < n; e += blockDim.x) {
         const float t = tuv[off + e];
         if (t == -f_inf()) continue;
+        // the reduce kernels only ever touch the slots of live rows / columns (and pf_finalize_kernel reads no others):
+        // "no candidate yet" is written here, for the 6 % that are alive, instead of a memset over every slot of the batch
+        best[off + e] = ~0ull;
+        second[off + e] = ~0ull;
         unsigned m = dir ? colmask[off + e] : 1u;
         while (m) {
             const int b = __builtin_ctz(m);
