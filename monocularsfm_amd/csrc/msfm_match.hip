@@ -110,6 +110,7 @@ struct Image {
     signed char* i8 = nullptr;
     float* nrm_i8 = nullptr;
     float nrm_i8_max = 0.f;
+    int h0_i8 = 0;            // centre of the rows' h = floor(|x - 128|^2 / 2): the digit k-step carries H0 - h
     // keypoint coordinates (x, y) for the geometric verification; nk = -1: not uploaded
     float2* kxy = nullptr;
     int nk = -1;
@@ -442,6 +443,7 @@ void build_compact_plan(msfm_ctx* ctx, const Batch& b, CompactPlan& cp) {
             g.b_nrm = pp.b_nrm;
             g.b_c = pp.b_c;
             g.a_c = pp.a_c;     // (per image: every image that meets image j in this batch has a compatible scale, see fill_pair)
+            g.b_h0 = pp.b_h0;
             g.dir = 0;
             g.bt_begin = 0;
             g.bt_end = pd.b_tiles;
@@ -465,6 +467,7 @@ void build_compact_plan(msfm_ctx* ctx, const Batch& b, CompactPlan& cp) {
                 g.b_nrm = pp.a_nrm;
                 g.b_c = pp.a_c;
                 g.a_c = pp.b_c;
+                g.b_h0 = pp.a_h0;
                 g.dir = 1;
                 g.bt_begin = std::min(pd.a_blocks, bit * gshift * (kPfWgRows / kBM));
                 g.bt_end = std::min(pd.a_blocks, (bit + 1) * gshift * (kPfWgRows / kBM));
@@ -541,6 +544,8 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
             pp.a_nrm_max = ia.nrm_i8_max;
             pp.b_nrm_max = ib.nrm_i8_max;
             pp.a_c = pp.b_c = 0.f;
+            pp.a_h0 = ia.h0_i8;
+            pp.b_h0 = ib.h0_i8;
         }
     ctx->pf_pending.i8 = i8;
     long long dense_cand = 0;
@@ -1174,25 +1179,46 @@ static int build_image(msfm_ctx* ctx, Image& im, const unsigned char* src8, bool
     const int npad = im.nalloc * kBM;
     HIPCHK(ctx, hipMalloc((void**)&im.h16, (size_t)npad * kPfRowBytes));
     HIPCHK(ctx, hipMalloc((void**)&im.nrm, (size_t)npad * 4));
-    HIPCHK(ctx, ctx->d_maxima.ensure(12));
-    HIPCHK(ctx, hipMemsetAsync(ctx->d_maxima.p, 0, 12, ctx->stream));
+    HIPCHK(ctx, ctx->d_maxima.ensure(16));
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_maxima.p, 0, 16, ctx->stream));
     hipLaunchKernelGGL(pf_prepare_kernel, dim3(std::min(2048, (npad * 16 + 255) / 256)), dim3(256), 0, ctx->stream,
                        im.raw, im.h16, im.nrm, ctx->d_maxima.as<unsigned>(), n, npad);
     HIPCHK(ctx, hipGetLastError());
     if (is_u8) {
         HIPCHK(ctx, hipMalloc((void**)&im.i8, (size_t)npad * kI8RowBytes));
         HIPCHK(ctx, hipMalloc((void**)&im.nrm_i8, (size_t)npad * 4));
-        hipLaunchKernelGGL(pf_prepare_i8_kernel, dim3(std::min(2048, (npad * 8 + 255) / 256)), dim3(256), 0, ctx->stream,
+        hipLaunchKernelGGL(pf_prepare_i8_kernel, dim3(std::min(2048, (npad * 11 + 255) / 256)), dim3(256), 0, ctx->stream,
                            (const float*)im.raw, im.i8, im.nrm_i8, ctx->d_maxima.as<unsigned>(), n, npad);
         HIPCHK(ctx, hipGetLastError());
     }
-    unsigned mx[3] = {0, 0, 0};
-    HIPCHK(ctx, hipMemcpyAsync(mx, ctx->d_maxima.p, 12, hipMemcpyDeviceToHost, ctx->stream));
+    unsigned mx[4] = {0, 0, 0, 0};
+    HIPCHK(ctx, hipMemcpyAsync(mx, ctx->d_maxima.p, 16, hipMemcpyDeviceToHost, ctx->stream));
     // the caller may free/reuse its buffer (and we reuse d_stage) as soon as we return
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     std::memcpy(&im.nrm_max, &mx[0], 4);
     std::memcpy(&im.abs_max, &mx[1], 4);
     std::memcpy(&im.nrm_i8_max, &mx[2], 4);
+    if (is_u8) {
+        // the digit k-step represents H0 - h in [kI8DigitLo, kI8DigitHi]: centre H0 between the smallest and the largest h
+        const unsigned min_bits = ~mx[3];
+        float nrm_i8_min = 0.f;
+        std::memcpy(&nrm_i8_min, &min_bits, 4);
+        const long long hmax = (long long)(0.5f * im.nrm_i8_max), hmin = (long long)(0.5f * nrm_i8_min);
+        const long long h0 = (hmin + hmax) / 2;
+        if (hmin <= hmax && h0 - hmax >= kI8DigitLo && h0 - hmin <= kI8DigitHi) {
+            im.h0_i8 = (int)h0;
+            hipLaunchKernelGGL(pf_digits_i8_kernel, dim3(std::min(1024, (n + 255) / 256)), dim3(256), 0, ctx->stream,
+                               (const float*)im.nrm_i8, im.i8, n, im.h0_i8);
+            HIPCHK(ctx, hipGetLastError());
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        } else {   // (an all-zero next to an all-128 descriptor: not SIFT) -- the image is served by the fp16 kernels
+            (void)hipFree(im.i8);
+            (void)hipFree(im.nrm_i8);
+            im.i8 = nullptr;
+            im.nrm_i8 = nullptr;
+            im.is_u8 = false;
+        }
+    }
     im.pf_safe = (im.abs_max <= kF16Safe) && (im.nrm_max < 3.0e38f);  // NaN/inf compare false
     if (im.pf_safe) {
         // c = 2^k with max|row|^2 / 2 / c in (2^11, 2^12]; k must keep c an exact fp16 value

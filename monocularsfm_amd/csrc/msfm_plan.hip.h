@@ -37,7 +37,7 @@ struct PlanGroup {            // static description of one compacted sweep (host
     int n2, n2pad, b_tiles;   // rows / padded rows / 128-row blocks of the streamed image
     int first, count;         // members: gmembers[first .. first + count)
     int ranges;               // B-range split of its work items (1 unless the batch is small)
-    int pad;
+    int b_h0;                 // integer-core route: the streamed image's centre H0
 };
 
 struct PlanPair {             // where the members of a pair sit in the member arrays
@@ -222,6 +222,7 @@ __global__ __launch_bounds__(kPlanThreads) void pf_plan_kernel(const PlanGroup* 
                 vp.b_nrm = G.b_nrm;
                 vp.b_c = G.b_c;
                 vp.a_c = G.a_c;
+                vp.b_h0 = G.b_h0;
                 vp.tu_off = row0;
                 vp.cand_off = cand0;
                 vp.cand_cap = ok ? (int)cap : 0;

@@ -91,8 +91,9 @@ struct PfPair {            // per-pair extras of the prefilter path (parallel to
     long long cand_off;    // candidate list base
     int cand_cap;
     int use;               // 1: prefiltered; 0: not safe -> exact brute force
-    int i8;                // 1: byte images on the integer matrix cores: a_h / b_h are 144-byte rows, the norms are 2 h
+    int i8;                // 1: byte images on the integer matrix cores: a_h / b_h are 176-byte rows, the norms are 2 h
                            //    (msfm_sweep_i8.hip.h), eps = 2
+    int a_h0, b_h0;        // i8: the images' centres H0 (the digit k-step of a row carries H0 - h)
     int pad;
 };
 

@@ -3,29 +3,35 @@
 //
 // A byte descriptor x (0..255) is stored as the signed byte x' = x - 128 (= x ^ 0x80): the distance is shift invariant,
 // |a - b|^2 = |a' - b'|^2 = n'_a + n'_b - 2 a'.b' with n' = |x'|^2 <= 2^21, and v_mfma_i32_32x32x32_i8 computes a'.b'
-// EXACTLY -- twice the k-depth of the fp16 instruction in the same 8 passes.  Per row the store keeps h = floor(n'/2)
-// (an int32 behind the 128 operand bytes: rows of 144 B = 9 granules, the same odd-granule bank swizzle as the fp16
-// rows) and 2h as a float (the path's "norm" array).  The accumulator is
+// EXACTLY -- twice the k-depth of the fp16 instruction in (nearly) the same pipe time.  With h = floor(n'/2) the accumulator
 //
 //        acc = a'.b' - h_a - h_b        ->   S~ = -2 acc = S - (n'_a & 1) - (n'_b & 1),   |S~ - S| <= 2 =: eps
 //
-// with -h_a (sweep 1) or floor((T_row - 2 h_a) / 2) (compacted sweep 2: a hit is acc >= 0  <=>  S~ <= T_row) held in 32
-// registers per lane for the whole work item and -h_b read from the B tile; their sum initialises the accumulator (a
-// v_add per register where the fp16 kernel has an inline-constant zero).  Everything downstream (thresholds, plan, exact
-// re-check in the pinned fp32 order, reduce) is the float pipeline unchanged: the results leave this kernel as floats
-// (exact: |acc| < 2^23).  On byte data the pinned fp32 order is itself exact integer arithmetic (every partial sum is an
-// integer below 2^24; oracle/int_oracle.py pins that), so eps = 2 instead of ~1.5e-3 (n_a + n_b) ~ 2000: far fewer
-// candidates, and half the matrix time.
+// is built WITHOUT a VALU instruction (every VALU instruction is SIMD time here):
+//   * -h_a (sweep 1) or floor((T_row - 2 h_a) / 2) (compacted sweep 2: a hit is acc >= 0  <=>  S~ <= T_row), minus the
+//     streamed image's centre H0_b, sits in 16 registers per lane for the whole work item and is the C OPERAND of the
+//     tile's first MFMA;
+//   * -(h_b - H0_b) rides in a FIFTH k-step: the B row carries 32 signed digits d behind its 128 operand bytes, the A
+//     side of that step is the constant vector c = [1, -128, -128, ...]: sum c_k d_k = d_0 - 128 (d_1 + ... + d_31)
+//     represents every integer in [-504 064, 507 903] -- an image whose h values spread further than that around their
+//     centre H0 (they cannot all be SIFT descriptors) is not a byte image for this path and takes the fp16 kernels.
+// Rows are 176 B = 11 granules (128 operand bytes, 32 digits, 16 B of padding: the same odd-granule bank swizzle as the
+// fp16 rows); the float "norm" array of the path holds 2h.  Padding COLUMNS carry zero digits, i.e. they look like a
+// real column: the image's last tile masks them in its epilogue (padding ROWS hold the "-inf" kI8Pad in their constant).
+// Everything downstream (thresholds, plan, exact re-check in the pinned fp32 order, reduce) is the float pipeline
+// unchanged: the results leave this kernel as floats (exact: |acc| < 2^23).  On byte data the pinned fp32 order is itself
+// exact integer arithmetic (every partial sum is an integer below 2^24; oracle/int_oracle.py pins that), so eps = 2
+// instead of ~1.5e-3 (n_a + n_b) ~ 1000: fewer candidates, and half the matrix time.
 //
-// Same program as sweep_kernel (msfm_sweep.hip.h): 8 waves x 64 A rows, MFMA / EPI ping-pong between the two waves of
-// a SIMD, 4-slot LDS ring filled by LDS-DMA three tiles ahead (9 pieces of 1 KiB per tile: wave w piece w, wave 0
-// piece 8 as well), counted vmcnt waits, persistent workgroups.  PASS 1 and PASS 3 only: the dense sweep 2 (kNN-level
-// API, ratio > 0.95) stays on the fp16 kernel.
+// Same program as sweep_kernel (msfm_sweep.hip.h): MFMA / EPI ping-pong between waves of a SIMD, LDS ring filled by
+// LDS-DMA, counted vmcnt waits, persistent workgroups.  PASS 1 and PASS 3 only: the dense sweep 2 (kNN-level API,
+// ratio > 0.95) stays on the fp16 kernel.
 #pragma once
 // (included inside namespace msfm)
 
-constexpr int kI8RowBytes = 144;                        // 128 operand bytes + [h, 0, 0, 0] (int32)
-constexpr int kI8TileBytes = kPfBT * kI8RowBytes;       // 9216 B = 9 DMA pieces
+constexpr int kI8RowBytes = 176;                        // 128 operand bytes + 32 digits of -(h - H0) + 16 B padding
+constexpr int kI8TileBytes = kPfBT * kI8RowBytes;       // 11264 B = 11 DMA pieces
+constexpr int kI8DigitLo = -504064, kI8DigitHi = 507903;   // representable H0 - h (see pf_digits_i8_kernel)
 // SIXTEEN waves of 32 rows (four per SIMD): on the integer cores a tile's matrix phase is 16 x 34 cycles per SIMD, and one
 // wave issues a VALU instruction every 8 cycles at best -- with two 64-row waves per SIMD the ~130 VALU instructions per
 // tile and wave set the pace (profiles/r02_i8_sweep_ablation.txt); four 32-row waves give the epilogue twice the issue slots
@@ -33,30 +39,31 @@ constexpr int kI8TileBytes = kPfBT * kI8RowBytes;       // 9216 B = 9 DMA pieces
 constexpr int kI8Waves = 16;
 constexpr int kI8Threads = 64 * kI8Waves;
 constexpr int kI8WaveRows = kPfWgRows / kI8Waves;       // 32: one MFMA row block per wave
-// Ring of EIGHT tiles, DMA seven tiles ahead: a phase is ~600 cycles here, so the three-tile lead of the fp16 kernel
-// (1.6 us there) would be 0.75 us -- less than an L2 miss.
+// Ring of EIGHT 11-KiB tiles, DMA seven tiles ahead: a phase is ~600 cycles here, so the three-tile lead of the fp16
+// kernel (1.6 us there) would be 0.75 us -- less than an L2 miss.
 constexpr int kI8Ring = 8;
 constexpr int kI8LdsBytes = kI8Ring * kI8TileBytes + kI8Waves * kPfCandBuf * 8 + 2 * kPfBT * kPfColClasses * 4;
 static_assert(kI8WaveRows == 32, "one 32-row block per wave");
 constexpr int kI8Pad = -(1 << 29);                      // "-inf" of a padding row / column (two of them still fit an int32)
 constexpr int kI8PadTest = -(1 << 27);                  // anything below is padding
 constexpr float kI8Eps = 2.f;
-static_assert(kI8TileBytes % 1024 == 0 && kI8TileBytes / 1024 == 9, "tile = 9 DMA pieces");
+static_assert(kI8TileBytes % 1024 == 0 && kI8TileBytes / 1024 == 11, "tile = 11 DMA pieces");
 
 typedef int i4v __attribute__((ext_vector_type(4)));
 typedef int i16v __attribute__((ext_vector_type(16)));
 
 __device__ __forceinline__ int max3i(int a, int b, int c) { return max(max(a, b), c); }  // folds to v_max3_i32
 
-// upload-time preparation of a byte image: signed operand rows, h, the float "norms" 2h (+inf on padding rows).
-// `raw` holds the bytes widened to float (the store's row-major copy).  maxima[2] = max 2h (float bits).
+// upload-time preparation of a byte image: signed operand rows (digits zero until pf_digits_i8_kernel), the float "norms"
+// 2h (+inf on padding rows).  `raw` holds the bytes widened to float (the store's row-major copy).
+// maxima[2] = max 2h, maxima[3] = ~(min 2h) (float bits).
 __global__ void pf_prepare_i8_kernel(const float* __restrict__ raw, signed char* __restrict__ rows, float* __restrict__ nrm2h,
                                      unsigned* __restrict__ maxima, int n, int npad) {
-    const long long total = (long long)npad * 8;
+    const long long total = (long long)npad * 11;
     for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
-        const int row = (int)(e >> 3), g = (int)(e & 7);
+        const int row = (int)(e / 11), g = (int)(e - (long long)row * 11);
         i4v v = {0, 0, 0, 0};
-        if (row < n) {
+        if (row < n && g < 8) {
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
                 const int x = (int)raw[(size_t)row * kDim + g * 16 + k] - 128;
@@ -66,7 +73,6 @@ __global__ void pf_prepare_i8_kernel(const float* __restrict__ raw, signed char*
         *reinterpret_cast<i4v*>(rows + (size_t)row * kI8RowBytes + g * 16) = v;
     }
     for (int row = blockIdx.x * blockDim.x + threadIdx.x; row < npad; row += gridDim.x * blockDim.x) {
-        int h = -kI8Pad;   // padding rows: -h = "-inf"
         float f = f_inf();
         if (row < n) {
             int s = 0;
@@ -74,13 +80,38 @@ __global__ void pf_prepare_i8_kernel(const float* __restrict__ raw, signed char*
                 const int x = (int)raw[(size_t)row * kDim + k] - 128;
                 s += x * x;
             }
-            h = s >> 1;
-            f = (float)(2 * h);
+            f = (float)(2 * (s >> 1));
             atomicMax(&maxima[2], __float_as_uint(f));
+            atomicMax(&maxima[3], ~__float_as_uint(f));
         }
         nrm2h[row] = f;
-        const i4v ext = {h, 0, 0, 0};
-        *reinterpret_cast<i4v*>(rows + (size_t)row * kI8RowBytes + kDim) = ext;
+    }
+}
+
+// the 32 digits of V = H0 - h behind every real row's operand bytes: V = d_0 - 128 (d_1 + ... + d_31), d_0 in [-128, -1],
+// the rest filled greedily (the host has checked that every row of the image is inside [kI8DigitLo, kI8DigitHi])
+__global__ void pf_digits_i8_kernel(const float* __restrict__ nrm2h, signed char* __restrict__ rows, int n, int h0) {
+    for (int row = blockIdx.x * blockDim.x + threadIdx.x; row < n; row += gridDim.x * blockDim.x) {
+        const int h = (int)(0.5f * nrm2h[row]);
+        const int V = h0 - h;
+        const int Wp = (V + 128) >> 7;          // floor((V + 128) / 128)
+        signed char d[32];
+        d[0] = (signed char)(V - (Wp << 7));    // [-128, -1]
+        int R = -Wp;                            // d_1 + ... + d_31
+#pragma unroll
+        for (int k = 1; k < 32; ++k) {
+            const int x = R < -128 ? -128 : (R > 127 ? 127 : R);
+            d[k] = (signed char)x;
+            R -= x;
+        }
+        i4v lo, hi;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            lo[w] = (d[4 * w] & 255) | ((d[4 * w + 1] & 255) << 8) | ((d[4 * w + 2] & 255) << 16) | ((d[4 * w + 3] & 255) << 24);
+            hi[w] = (d[16 + 4 * w] & 255) | ((d[17 + 4 * w] & 255) << 8) | ((d[18 + 4 * w] & 255) << 16) | ((d[19 + 4 * w] & 255) << 24);
+        }
+        *reinterpret_cast<i4v*>(rows + (size_t)row * kI8RowBytes + kDim) = lo;
+        *reinterpret_cast<i4v*>(rows + (size_t)row * kI8RowBytes + kDim + 16) = hi;
     }
 }
 
@@ -94,7 +125,7 @@ __global__ __launch_bounds__(kI8Threads) void sweep_i8_kernel(
     typedef const __attribute__((address_space(1))) float* gfloat_p;
     typedef const __attribute__((address_space(1))) i4v* gi4_p;
     extern __shared__ __attribute__((aligned(16))) char pf_smem[];
-    char* sB = pf_smem;                                                   // [ring slot][64 rows x 144 B]
+    char* sB = pf_smem;                                                   // [ring slot][64 rows x 176 B]
     char* sCand = pf_smem + kI8Ring * kI8TileBytes;                       // [wave][kPfCandBuf] int2 (PASS 3)
     int* sCol = reinterpret_cast<int*>(sCand + kI8Waves * kPfCandBuf * 8);  // [2 tiles][4 classes][64 columns] (PASS 1)
 
@@ -127,7 +158,7 @@ __global__ __launch_bounds__(kI8Threads) void sweep_i8_kernel(
     const gfloat_p g_anrm = (gfloat_p)pp.a_nrm;
     const gfloat_p g_tu = (gfloat_p)tu;
 
-    // DMA group of tile tt: the tile's 9 pieces go to waves 0..8, one each
+    // DMA group of tile tt: the tile's 11 pieces go to waves 0..10, one each
     const bool dma_wave = wave < kI8TileBytes / 1024;   // wave-uniform
     const unsigned lane_off = (unsigned)(wave * 1024 + lane * 16);
     auto dma_tile = [&](int tt) {
@@ -163,9 +194,11 @@ __global__ __launch_bounds__(kI8Threads) void sweep_i8_kernel(
     }
     // this lane's 16 result rows: r -> row = a_blk*512 + wave*32 + (r&3) + 8*(r>>2) + 4*lhalf; their constants
     const int arow_base = item.a_blk * kPfWgRows + wave * kI8WaveRows + 4 * lhalf;
-    // PASS 1: -h_a (the norm array holds 2 h_a, +inf on padding rows).  PASS 3: floor((T - 2 h_a) / 2), T = +inf -> everything
-    // hits.  The loads are unconditional (both arrays cover the padded rows) and pinned by a register use: hipcc otherwise
-    // sinks each of them into its `rr < n1` branch and waits for it there -- 16 round trips instead of 16 loads in flight.
+    // The lane's 16 row constants = the C operand of the tile's first MFMA.  PASS 1: -h_a (the norm array holds 2 h_a, +inf
+    // on padding rows).  PASS 3: floor((T - 2 h_a) / 2), T = +inf -> everything hits.  Both minus the streamed image's
+    // centre H0_b (the digit k-step adds H0_b - h_b).  The loads are unconditional (both arrays cover the padded rows) and
+    // pinned by a register use: hipcc otherwise sinks each of them into its `rr < n1` branch and waits for it there -- 16
+    // round trips instead of 16 loads in flight.
     i16v rowc;
     {
         float xs[16];
@@ -180,9 +213,11 @@ __global__ __launch_bounds__(kI8Threads) void sweep_i8_kernel(
         for (int r = 0; r < 16; ++r) {
             const int rr = arow_base + (r & 3) + 8 * (r >> 2);
             const float x = PASS == 3 ? 0.5f * xs[r] : -0.5f * xs[r];
-            rowc[r] = rr < pd.n1 ? (int)floorf(fminf(fmaxf(x, -5.0e8f), 5.0e8f)) : kI8Pad;
+            rowc[r] = rr < pd.n1 ? (int)floorf(fminf(fmaxf(x, -5.0e8f), 5.0e8f)) - pp.b_h0 : kI8Pad;
         }
     }
+    // the A side of the digit k-step: c = [1, -128 x 31] (this lane: k = 16 lhalf .. + 15)
+    const i4v a_digit = {lhalf == 0 ? (int)0x80808001u : (int)0x80808080u, (int)0x80808080u, (int)0x80808080u, (int)0x80808080u};
     int rs0[16];   // PASS 1: running row maximum of the accumulator
 #pragma unroll
     for (int r = 0; r < 16; ++r) rs0[r] = (int)0x80000000;
@@ -210,21 +245,17 @@ __global__ __launch_bounds__(kI8Threads) void sweep_i8_kernel(
 
     // B fragments.  The two column blocks of a tile are two independent accumulator chains (a single dependent MFMA
     // chain runs at 3/4 of the rate, profiles/r01_ubench_mfma_chains.txt), so a k-step needs BOTH blocks' fragments:
-    // k-steps 0 and 1 are pre-read in the EPI phase of the previous tile, k-steps 2 and 3 are read behind the first and the
-    // second MFMA pair into the registers they free (the SIMD's other matrix-phase wave fills the wait; three k-steps in
-    // registers would not fit 128 VGPRs).  hb = h_b of this lane's column in the two blocks.
+    // k-steps 0 and 1 are pre-read in the EPI phase of the previous tile; k-step 2, k-step 3 and the digits are read
+    // behind the first, second and third MFMA pair into the registers those free (the SIMD's other matrix-phase wave
+    // fills the waits; more fragments in registers would not fit 128 VGPRs).
     const int lane_row_off = lcol * kI8RowBytes + lhalf * 16;
-    const int lane_ext_off = lcol * kI8RowBytes + kDim;
-    auto preread = [&](int sl, i4v (&bf)[2][2], int (&hb)[2]) {
+    auto preread = [&](int sl, i4v (&bf)[2][2]) {
         const char* pb = sB + sl * kI8TileBytes + lane_row_off;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             bf[ks][0] = *reinterpret_cast<const i4v*>(pb + ks * 32);
             bf[ks][1] = *reinterpret_cast<const i4v*>(pb + 32 * kI8RowBytes + ks * 32);
         }
-        const char* pe = sB + sl * kI8TileBytes + lane_ext_off;
-        hb[0] = *reinterpret_cast<const int*>(pe);
-        hb[1] = *reinterpret_cast<const int*>(pe + 32 * kI8RowBytes);
     };
     auto column_max = [&](const i16v& acc) -> int {
         int m0 = max3i(acc[0], acc[1], acc[2]), m1 = max3i(acc[3], acc[4], acc[5]);
@@ -290,8 +321,7 @@ __global__ __launch_bounds__(kI8Threads) void sweep_i8_kernel(
 
     lds_barrier();
     i4v bf[2][2];
-    int hb[2];
-    if (wave_active) preread(0, bf, hb);
+    if (wave_active) preread(0, bf);
     if (grp == 1) lds_barrier();
 
     i16v accA, accB;
@@ -303,10 +333,8 @@ __global__ __launch_bounds__(kI8Threads) void sweep_i8_kernel(
         if (wave_active) {
             __builtin_amdgcn_s_setprio(1);
             const char* pb2 = sB + sl * kI8TileBytes + lane_row_off + 2 * 32;
-            accA = rowc - hb[0];
-            accB = rowc - hb[1];
-            accA = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[0], bf[0][0], accA, 0, 0, 0);
-            accB = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[0], bf[0][1], accB, 0, 0, 0);
+            accA = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[0], bf[0][0], rowc, 0, 0, 0);   // C = the row constants: no init
+            accB = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[0], bf[0][1], rowc, 0, 0, 0);
             bf[0][0] = *reinterpret_cast<const i4v*>(pb2);                          // k-step 2 into the registers of k-step 0
             bf[0][1] = *reinterpret_cast<const i4v*>(pb2 + 32 * kI8RowBytes);
             accA = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[1], bf[1][0], accA, 0, 0, 0);
@@ -315,8 +343,12 @@ __global__ __launch_bounds__(kI8Threads) void sweep_i8_kernel(
             bf[1][1] = *reinterpret_cast<const i4v*>(pb2 + 32 * kI8RowBytes + 32);
             accA = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[2], bf[0][0], accA, 0, 0, 0);
             accB = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[2], bf[0][1], accB, 0, 0, 0);
+            bf[0][0] = *reinterpret_cast<const i4v*>(pb2 + 64);                     // the digits (bytes 128 + 16 lhalf ..)
+            bf[0][1] = *reinterpret_cast<const i4v*>(pb2 + 32 * kI8RowBytes + 64);
             accA = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[3], bf[1][0], accA, 0, 0, 0);
             accB = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[3], bf[1][1], accB, 0, 0, 0);
+            accA = __builtin_amdgcn_mfma_i32_32x32x32_i8(a_digit, bf[0][0], accA, 0, 0, 0);   // + H0_b - h_b
+            accB = __builtin_amdgcn_mfma_i32_32x32x32_i8(a_digit, bf[0][1], accB, 0, 0, 0);
             __builtin_amdgcn_s_setprio(0);
         }
         MSFM_PROBE(0)
@@ -327,6 +359,20 @@ __global__ __launch_bounds__(kI8Threads) void sweep_i8_kernel(
         if (PASS == 1 && grp == 0 && t > t_begin && wave == ((t - t_begin) & 3)) store_columns(t - 1);
         dma_tile(t + kI8Ring - 1);
         if (wave_active) {
+            // the image's last tile: columns >= n2 carry zero digits (they look like a column with h = H0): mask them
+            const bool last_tile = (t + 1) * kPfBT > pd.n2;   // wave-uniform
+            if (PASS == 1 && last_tile) {
+                const bool v0 = t * kPfBT + lcol < pd.n2, v1 = t * kPfBT + 32 + lcol < pd.n2;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    accA[r] = v0 ? accA[r] : kI8Pad;
+                    accB[r] = v1 ? accB[r] : kI8Pad;
+                }
+            }
+            if (PASS == 3 && last_tile) {       // (sign bit set = no hit)
+                if (!(t * kPfBT + lcol < pd.n2)) accA = i16v(-1);
+                if (!(t * kPfBT + 32 + lcol < pd.n2)) accB = i16v(-1);
+            }
             if (PASS == 1) {
                 fold_columns(column_max(accA), column_max(accB), (t - t_begin) & 1);
 #pragma unroll
@@ -335,7 +381,7 @@ __global__ __launch_bounds__(kI8Threads) void sweep_i8_kernel(
                 scan_hits3(accA, accB, t * kPfBT + lcol);
             }
         }
-        if (wave_active && t + 1 < t_end) preread((sl + 1) & (kI8Ring - 1), bf, hb);
+        if (wave_active && t + 1 < t_end) preread((sl + 1) & (kI8Ring - 1), bf);
         MSFM_PROBE(2)
         if (grp == 1) wait_older_group();
         lds_barrier();

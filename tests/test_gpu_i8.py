@@ -152,3 +152,23 @@ def test_golden_byte_fixture_through_the_integer_cores(gpu_ctx):
         assert gpu_ctx.profile()["sweep1_i8_launches"] == 1
         assert np.array_equal(q, g["o0_cc%d_q" % cc]) and np.array_equal(t, g["o0_cc%d_t" % cc]) and np.array_equal(b(d), b(g["o0_cc%d_d" % cc]))
     gpu_ctx.clear_images()
+
+
+def test_norm_spread_beyond_the_digit_range_takes_the_fp16_kernels(gpu_ctx):
+    """The digit k-step carries H0 - h within [-504 064, 507 903]: an image holding an all-128 row (h = 0) next to an
+    all-0 row (h = 2^20) cannot be centred, is stored as a float image and matched on the fp16 cores -- same lists."""
+    u = synth.u8_images(2, [500, 450], seed=9, dup_frac=0.3, as_float=False)
+    wide = u[0].copy()
+    wide[3] = 128
+    wide[4] = 0
+    gpu_ctx.upload_image(0, wide)
+    gpu_ctx.upload_image(1, u[1])
+    gpu_ctx.upload_image(2, u[0])
+    kw = {"ratio": 0.8, "cross_check": True, "max_distance": 1e9}
+    res = gpu_ctx.match_pairs(np.array([[0, 1]], np.int32), **kw)
+    assert gpu_ctx.profile()["sweep1_i8_launches"] == 0 and gpu_ctx.profile()["prefilter_pairs"] == 1
+    check_vs_int_reference({0: wide, 1: u[1]}, [(0, 1)], res, **kw)
+    res = gpu_ctx.match_pairs(np.array([[2, 1]], np.int32), **kw)
+    assert gpu_ctx.profile()["sweep1_i8_launches"] == 1
+    check_vs_int_reference({2: u[0], 1: u[1]}, [(2, 1)], res, **kw)
+    gpu_ctx.clear_images()
