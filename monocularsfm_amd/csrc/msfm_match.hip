@@ -610,11 +610,13 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
     ctx->prof.approx_kernel_launches += 1;
     if (i8) ctx->prof.sweep1_i8_launches += 1;
     const dim3 mgrid((unsigned)((b.max_npad + 255) / 256), (unsigned)P);
-    hipLaunchKernelGGL(pf_thresholds_kernel, mgrid, dim3(256), 0, ctx->stream, dp, dpf, ctx->d_rp_s0.as<float>(),
-                       ctx->d_rp_s1.as<float>(), ctx->d_cp_s0.as<float>(), compact ? colmask : (unsigned*)nullptr, tuv, tuv, prune);
-    HIPCHK(ctx, hipGetLastError());
-    DBGSYNC(ctx, "pf_thresholds_kernel");
-    hc.lap("launch sweep 1 + thresholds");
+    if (!compact) {
+        hipLaunchKernelGGL(pf_thresholds_kernel, mgrid, dim3(256), 0, ctx->stream, dp, dpf, ctx->d_rp_s0.as<float>(),
+                           ctx->d_rp_s1.as<float>(), ctx->d_cp_s0.as<float>(), (unsigned*)nullptr, tuv, tuv, prune, PlanCounts{});
+        HIPCHK(ctx, hipGetLastError());
+        DBGSYNC(ctx, "pf_thresholds_kernel");
+    }
+    hc.lap("launch sweep 1 (+ thresholds)");
 
     size_t n_lists = 0;
     const CandList* dl = nullptr;
@@ -673,10 +675,12 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
         HIPCHK(ctx, hipMemsetAsync(ctx->d_cand_count.p, 0, std::max<size_t>(1, G) * 8, ctx->stream));
         hc.lap("plan tables + uploads");
         const PlanPair* dpp = ctx->d_ppair.as<PlanPair>();
-        hipLaunchKernelGGL(pf_count_kernel, dim3((unsigned)(2 * P)), dim3(256), 0, ctx->stream, dp, dpf, dpp, (const float*)tuv,
-                           (const unsigned*)colmask, ctx->d_cnt.as<int>(), (const int*)ctx->d_member_group.as<int>(), ctx->d_gtot.as<int>());
+        // thresholds + live counts per member / group (the plan tables above are uploaded by now; sweep 1 is still running)
+        PlanCounts pc = {dpp, (const int*)ctx->d_member_group.as<int>(), ctx->d_cnt.as<int>(), ctx->d_gtot.as<int>()};
+        hipLaunchKernelGGL(pf_thresholds_kernel, mgrid, dim3(256), 0, ctx->stream, dp, dpf, ctx->d_rp_s0.as<float>(),
+                           ctx->d_rp_s1.as<float>(), ctx->d_cp_s0.as<float>(), colmask, tuv, tuv, prune, pc);
         HIPCHK(ctx, hipGetLastError());
-        DBGSYNC(ctx, "pf_count_kernel");
+        DBGSYNC(ctx, "pf_thresholds_kernel");
         PlanOut po = {};
         po.vpairs = ctx->d_vpairs.as<PairDesc>();
         po.vpf = ctx->d_vpf.as<PfPair>();
@@ -764,18 +768,15 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
         const unsigned long long* dcount = ctx->d_cand_count.as<unsigned long long>();
         if (ctx->order == MSFM_ORDER_SSE4X4)
             hipLaunchKernelGGL(pf_exact_candidates_kernel<0>, cgrid, dim3(256), 0, ctx->stream, dp, dl, dcount,
-                               ctx->d_cand.as<int2>(), ctx->d_cand_s.as<float>(), ctx->d_cand_pair.as<int>());
+                               ctx->d_cand.as<int2>(), ctx->d_cand_s.as<float>(), ctx->d_cand_pair.as<int>(),
+                               ctx->d_best.as<unsigned long long>());
         else
             hipLaunchKernelGGL(pf_exact_candidates_kernel<1>, cgrid, dim3(256), 0, ctx->stream, dp, dl, dcount,
-                               ctx->d_cand.as<int2>(), ctx->d_cand_s.as<float>(), ctx->d_cand_pair.as<int>());
+                               ctx->d_cand.as<int2>(), ctx->d_cand_s.as<float>(), ctx->d_cand_pair.as<int>(),
+                               ctx->d_best.as<unsigned long long>());
         HIPCHK(ctx, hipGetLastError());
         DBGSYNC(ctx, "pf_exact_candidates_kernel");
         const dim3 rgrid(16, (unsigned)n_lists);
-        hipLaunchKernelGGL(pf_reduce_best_kernel, rgrid, dim3(256), 0, ctx->stream, dp, dl, dcount,
-                           ctx->d_cand.as<int2>(), ctx->d_cand_s.as<float>(), (const int*)ctx->d_cand_pair.as<int>(),
-                           ctx->d_best.as<unsigned long long>());
-        HIPCHK(ctx, hipGetLastError());
-        DBGSYNC(ctx, "pf_reduce_best_kernel");
         hipLaunchKernelGGL(pf_reduce_second_kernel, rgrid, dim3(256), 0, ctx->stream, dp, dl, dcount,
                            ctx->d_cand.as<int2>(), ctx->d_cand_s.as<float>(), (const int*)ctx->d_cand_pair.as<int>(),
                            ctx->d_best.as<unsigned long long>(), ctx->d_second.as<unsigned long long>());

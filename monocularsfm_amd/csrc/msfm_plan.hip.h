@@ -14,7 +14,7 @@
 // is only known on the device; round 1 copied the counts to the host, planned there and uploaded the plan -- two stream
 // synchronisations and a std::map in the middle of the pipeline.  Now:
 //
-//   pf_count_kernel    live rows per member                                          grid = 2 x pairs
+//   (pf_thresholds_kernel counts the live rows per member and per group while it writes the thresholds)
 //   pf_plan_kernel     prefix sums -> row ranges of the groups (512-aligned), the groups' sweep descriptors
 //                      (PairDesc / PfPair / CandList), the work-item list, capacity check   one workgroup
 //   pf_member_rows_kernel  first compact row of every member (a wave-level scan per group)   one wave per group
@@ -40,13 +40,6 @@ struct PlanGroup {            // static description of one compacted sweep (host
     int b_h0;                 // integer-core route: the streamed image's centre H0
 };
 
-struct PlanPair {             // where the members of a pair sit in the member arrays
-    int fwd_member;           // -1: the pair is not on the compacted path
-    int rev_member0;          // members rev_member0 + bit, bit < rev_bits
-    int rev_bits;
-    int pad;
-};
-
 struct PlanSummary {
     int ok;                   // 0: a capacity was exceeded, nothing downstream ran
     int n_items;              // work items of the compacted sweep (a multiple of 8: XCD interleave)
@@ -55,45 +48,6 @@ struct PlanSummary {
     long long items_needed;
     long long swept_desc_pairs;  // descriptor pairs the compacted sweep multiplies (padding included)
 };
-
-// live rows per member.  dir 0: rows of image 1 with a threshold; dir 1: per mask bit, the live columns that carry it.
-__global__ void pf_count_kernel(const PairDesc* __restrict__ pairs, const PfPair* __restrict__ pf, const PlanPair* __restrict__ pp_plan,
-                                const float* __restrict__ tuv, const unsigned* __restrict__ colmask, int* __restrict__ cnt,
-                                const int* __restrict__ member_group, int* __restrict__ gtot /* rows per group (zeroed) */) {
-    const int p = blockIdx.x >> 1, dir = blockIdx.x & 1;
-    const PlanPair pl = pp_plan[p];
-    if (pl.fwd_member < 0) return;
-    const PairDesc pd = pairs[p];
-    const PfPair pp = pf[p];
-    __shared__ int hist[33];
-    if (threadIdx.x < 33) hist[threadIdx.x] = 0;
-    __syncthreads();
-    if (dir == 0) {
-        int c = 0;
-        for (int e = threadIdx.x; e < pd.n1; e += blockDim.x) c += (tuv[pp.tu_off + e] != -f_inf()) ? 1 : 0;
-        for (int m = 32; m >= 1; m >>= 1) c += __shfl_xor(c, m);
-        if ((threadIdx.x & 63) == 0) atomicAdd(&hist[32], c);
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            cnt[pl.fwd_member] = hist[32];
-            atomicAdd(&gtot[member_group[pl.fwd_member]], hist[32]);
-        }
-    } else {
-        for (int e = threadIdx.x; e < pd.n2; e += blockDim.x) {
-            unsigned m = (tuv[pp.tv_off + e] != -f_inf()) ? colmask[pp.tv_off + e] : 0u;
-            while (m) {
-                const int b = __builtin_ctz(m);
-                m &= m - 1;
-                atomicAdd(&hist[b], 1);
-            }
-        }
-        __syncthreads();
-        if ((int)threadIdx.x < pl.rev_bits) {
-            cnt[pl.rev_member0 + threadIdx.x] = hist[threadIdx.x];
-            if (hist[threadIdx.x]) atomicAdd(&gtot[member_group[pl.rev_member0 + threadIdx.x]], hist[threadIdx.x]);
-        }
-    }
-}
 
 constexpr int kPlanThreads = 512;   // (1024 would halve the registers per thread: the per-XCD totals then spill)
 // One workgroup of kPlanThreads threads.  All loops are strided over groups / members; the two exclusive scans (rows and work

@@ -15,8 +15,8 @@
 //            sweep_kernel<2>   dense variant (nothing pruned): S~ <= T_row[q] or S~ <= T_col[t];
 //                              hits are appended to the pair's candidate list (a few per row).
 //   exact_candidates_kernel    S_exact in the pinned accumulation order for the candidates only.
-//   reduce (3 tiny kernels)    per row / column the best and second best (S_exact, index) among
-//                              the candidates -> the same kNN arrays merge_knn_kernel produces.
+//   reduce + finalize          per row / column the best (atomicMin inside exact_candidates_kernel) and second best
+//                              (S_exact, index) among the candidates -> the same kNN arrays merge_knn_kernel produces.
 //
 // Why the candidates suffice.  Let |S~ - S_exact| <= eps for every element of a row.  The two
 // elements with the smallest S~ have S_exact <= S~(2) + eps, so the true second-smallest S_exact is
@@ -196,14 +196,33 @@ __device__ __forceinline__ bool pf_dead(float s0, float s1, float nrm, float eps
     return ratio_fails || too_far;
 }
 
+struct PlanPair {             // where the members of a pair sit in the member arrays
+    int fwd_member;           // -1: the pair is not on the compacted path
+    int rev_member0;          // members rev_member0 + bit, bit < rev_bits
+    int rev_bits;
+    int pad;
+};
+
+
+// live counting for the plan of the compacted sweep 2 (msfm_plan.hip.h), done while the thresholds are in registers:
+// rows per member (dir 0: live rows of image 1; dir 1: per mask bit the live columns that carry it) and per group
+struct PlanCounts {
+    const PlanPair* pp_plan;     // null: no plan (dense sweep 2)
+    const int* member_group;
+    int* cnt;                    // [members], zeroed
+    int* gtot;                   // [groups], zeroed
+};
+
 __global__ void pf_thresholds_kernel(const PairDesc* __restrict__ pairs, const PfPair* __restrict__ pf,
                                      const float* __restrict__ rp_s0, const float* __restrict__ rp_s1,
                                      const float* __restrict__ cp_s0, unsigned* __restrict__ colmask,
-                                     float* __restrict__ tu, float* __restrict__ tv, PruneParams pr) {
+                                     float* __restrict__ tu, float* __restrict__ tv, PruneParams pr, PlanCounts plan) {
     const PairDesc pd = pairs[blockIdx.y];
     const PfPair pp = pf[blockIdx.y];
     if (!pd.valid || !pp.use) return;
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    bool row_live = false;       // for the plan counts below
+    unsigned col_bits = 0;
     const float eps_norm = 4.8828125e-4f * fmaxf(pp.a_c, pp.b_c);  // 2^-11 c: fp16 subnormal flush of the norm quadruples
     if (e < pd.n1pad) {
         float s0 = f_inf(), s1 = f_inf();
@@ -218,6 +237,7 @@ __global__ void pf_thresholds_kernel(const PairDesc* __restrict__ pairs, const P
         const float slack = pp.i8 ? 2.f * eps : 2.f * eps + 1e-5f * (fabsf(s1) + na + pp.b_nrm_max);
         const bool live = (e < pd.n1) && !pf_dead(s0, s1, na, eps, pp.b_nrm_max, pr);
         tu[pp.tu_off + e] = live ? s1 + slack : -f_inf();
+        row_live = live;
     }
     if (e < pd.n2pad) {
         // column partials of sweep 1: per 512-row A block the two largest of the accumulator maxima (-S~/2) over four
@@ -268,6 +288,30 @@ __global__ void pf_thresholds_kernel(const PairDesc* __restrict__ pairs, const P
                 }
             }
             colmask[pp.tv_off + e] = mask;
+            col_bits = mask;
+        }
+    }
+    if (plan.pp_plan) {
+        const PlanPair pl = plan.pp_plan[blockIdx.y];
+        if (pl.fwd_member < 0) return;   // (block-uniform)
+        __shared__ int hist[33];
+        if (threadIdx.x < 33) hist[threadIdx.x] = 0;
+        __syncthreads();
+        const unsigned long long rl = __ballot(row_live);
+        if ((threadIdx.x & 63) == 0 && rl) atomicAdd(&hist[32], __popcll(rl));
+        while (col_bits) {
+            const int bit = __builtin_ctz(col_bits);
+            col_bits &= col_bits - 1;
+            atomicAdd(&hist[bit], 1);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0 && hist[32]) {
+            atomicAdd(&plan.cnt[pl.fwd_member], hist[32]);
+            atomicAdd(&plan.gtot[plan.member_group[pl.fwd_member]], hist[32]);
+        }
+        if ((int)threadIdx.x < pl.rev_bits && hist[threadIdx.x]) {
+            atomicAdd(&plan.cnt[pl.rev_member0 + threadIdx.x], hist[threadIdx.x]);
+            atomicAdd(&plan.gtot[plan.member_group[pl.rev_member0 + threadIdx.x]], hist[threadIdx.x]);
         }
     }
 }
@@ -286,13 +330,18 @@ struct CandList {
     const int* row_pair;
 };
 
+__device__ __forceinline__ unsigned long long pf_key(float s, int idx) {
+    return ((unsigned long long)__float_as_uint(s) << 32) | (unsigned)idx;  // s >= 0: uint order == float order
+}
+
 // exact pinned-order S for every candidate: 16 lanes per candidate (SSE order: lane L owns the
 // lane partial k = L mod 16; AVX2 order: 32 partials -> 2 per lane), coalesced 64-B row reads.
 // Records are rewritten in place as real (q, t).   grid = (x, n_lists)
 template <int ORDER>
 __global__ void pf_exact_candidates_kernel(const PairDesc* __restrict__ pairs, const CandList* __restrict__ lists,
                                            const unsigned long long* __restrict__ cand_count, int2* __restrict__ cand,
-                                           float* __restrict__ cand_s, int* __restrict__ cand_pair) {
+                                           float* __restrict__ cand_s, int* __restrict__ cand_pair,
+                                           unsigned long long* __restrict__ best /* reduce phase A rides along */) {
     const int lid = blockIdx.y;
     const CandList L = lists[lid];
     if (L.cap == 0) return;
@@ -348,34 +397,18 @@ __global__ void pf_exact_candidates_kernel(const PairDesc* __restrict__ pairs, c
             cand[L.off + c] = qt;
             cand_s[L.off + c] = res;
             cand_pair[L.off + c] = pair;
+            // reduce phase A: best (S, idx) per row and per column among the candidates (64-bit atomicMin).  A mode-1 list
+            // only serves the row direction, a mode-2 list only the column direction: the live rows of the OTHER
+            // direction get their complete candidate sets from their own list.
+            if (res < f_inf()) {   // batchDistance never inserts a distance >= FLT_MAX
+                if (L.mode != 2) atomicMin(&best[pairs[pair].kf_off + qt.x], pf_key(res, qt.y));
+                if (L.mode != 1) atomicMin(&best[pairs[pair].kr_off + qt.y], pf_key(res, qt.x));
+            }
         }
     }
 }
 
-__device__ __forceinline__ unsigned long long pf_key(float s, int idx) {
-    return ((unsigned long long)__float_as_uint(s) << 32) | (unsigned)idx;  // s >= 0: uint order == float order
-}
 
-// reduce phase A: best (S, idx) per row and per column among the candidates (64-bit atomicMin).
-// A mode-1 list only serves the row direction, a mode-2 list only the column direction: the live
-// rows of the OTHER direction get their complete candidate sets from their own list.
-__global__ void pf_reduce_best_kernel(const PairDesc* __restrict__ pairs, const CandList* __restrict__ lists,
-                                      const unsigned long long* __restrict__ cand_count,
-                                      const int2* __restrict__ cand, const float* __restrict__ cand_s,
-                                      const int* __restrict__ cand_pair, unsigned long long* __restrict__ best) {
-    const int lid = blockIdx.y;
-    const CandList L = lists[lid];
-    if (L.cap == 0) return;
-    const int n = (int)(cand_count[lid] < (unsigned long long)L.cap ? cand_count[lid] : (unsigned long long)L.cap);
-    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < n; c += gridDim.x * blockDim.x) {
-        const int2 qt = cand[L.off + c];
-        const float s = cand_s[L.off + c];
-        if (!(s < f_inf())) continue;  // batchDistance never inserts a distance >= FLT_MAX
-        const int pair = cand_pair[L.off + c];
-        if (L.mode != 2) atomicMin(&best[pairs[pair].kf_off + qt.x], pf_key(s, qt.y));
-        if (L.mode != 1) atomicMin(&best[pairs[pair].kr_off + qt.y], pf_key(s, qt.x));
-    }
-}
 // reduce phase B: second best = min over the candidates that are not the best one
 __global__ void pf_reduce_second_kernel(const PairDesc* __restrict__ pairs, const CandList* __restrict__ lists,
                                         const unsigned long long* __restrict__ cand_count,
