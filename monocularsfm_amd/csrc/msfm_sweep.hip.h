@@ -485,29 +485,29 @@ __global__ __launch_bounds__(kPfThreads, 2) void sweep_kernel(
     if (PASS == 1 && wave == 0) store_columns(t_end - 1);
 
     if (PASS == 1) {
-        // rows: S~ = -2 * accumulator; the two smallest of the 32 lanes' minima; one partial slot per B range
-        float rs1[kPfRB][16];
+        wait_vmcnt<0>();   // the tail's DMA groups (re-fetches of the last tile) still write into the ring ...
+        lds_barrier();     // ... everybody's have landed: the ring is scratch now
+        // rows: lane (lcol, lhalf) holds, for each of its 32 rows, the accumulator maximum over ITS columns; a row's result is
+        // the two largest of its 32 lane values (S~ = -2 acc: the smallest S~ and an upper bound of the second smallest).
+        // Transposed through the wave's share of the (now idle) B ring -- [64 rows][32 lanes + 1] floats -- so that lane l
+        // reduces row l of the wave serially: 32 writes, 32 reads and ~100 VALU per lane instead of 32 x 5 butterfly steps
+        // (~1000 shuffles + VALU).  LDS operations of one wave execute in order: no barrier.
+        float* tr = reinterpret_cast<float*>(sB) + wave * (kPfWaveRows * 33);
+        static_assert(kPfWaves * kPfWaveRows * 33 * 4 <= kPfRing * kPfTileBytes, "the transposition fits the ring");
 #pragma unroll
         for (int rb = 0; rb < kPfRB; ++rb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                rs0[rb][r] = -2.f * rs0[rb][r];
-                rs1[rb][r] = f_inf();
-#pragma unroll
-                for (int m = 1; m < 32; m <<= 1)
-                    v2_merge(rs0[rb][r], rs1[rb][r], __shfl_xor(rs0[rb][r], m), __shfl_xor(rs1[rb][r], m));
-            }
-        if (lcol == 0) {
-            const long long o = pd.rp_off + (long long)item.range * pd.n1pad + arow_base;
-#pragma unroll
-            for (int rb = 0; rb < kPfRB; ++rb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int off = rb * 32 + (r & 3) + 8 * (r >> 2);
-                    rp_s0[o + off] = rs0[rb][r];
-                    rp_s1[o + off] = rs1[rb][r];
-                }
+            for (int r = 0; r < 16; ++r) tr[(rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf) * 33 + lcol] = rs0[rb][r];
+        float m0 = -f_inf(), m1 = -f_inf();
+#pragma unroll 8
+        for (int k = 0; k < 32; ++k) {
+            const float v = tr[lane * 33 + k];
+            m1 = fmaxf(m1, fminf(m0, v));
+            m0 = fmaxf(m0, v);
         }
+        const long long o = pd.rp_off + (long long)item.range * pd.n1pad + item.a_blk * kPfWgRows + wave * kPfWaveRows + lane;
+        rp_s0[o] = -2.f * m0;      // padding rows: -inf -> +inf
+        rp_s1[o] = -2.f * m1;
     }
     }   // item loop
 }

@@ -393,23 +393,26 @@ __global__ __launch_bounds__(kI8Threads) void sweep_i8_kernel(
     if (PASS == 1 && wave == 0) store_columns(t_end - 1);
 
     if (PASS == 1) {
-        // rows: S~ = -2 * accumulator as a float (exact); the two smallest of the 32 lanes' minima
-        float fs0[16], fs1[16];
+        // rows: the two largest of a row's 32 lane maxima, transposed through the wave's share of the idle ring
+        // ([32 rows][32 lanes + 1] ints; see sweep_kernel): lane l < 32 reduces row l of the wave
+        wait_vmcnt<0>();   // the tail's DMA groups still write into the ring ...
+        lds_barrier();     // ... everybody's have landed
+        int* tr = reinterpret_cast<int*>(sB) + wave * (kI8WaveRows * 33);
+        static_assert(kI8Waves * kI8WaveRows * 33 * 4 <= kI8Ring * kI8TileBytes, "the transposition fits the ring");
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            fs0[r] = rs0[r] > kI8PadTest ? (float)(-2 * rs0[r]) : f_inf();
-            fs1[r] = f_inf();
-#pragma unroll
-            for (int m = 1; m < 32; m <<= 1) v2_merge(fs0[r], fs1[r], __shfl_xor(fs0[r], m), __shfl_xor(fs1[r], m));
-        }
-        if (lcol == 0) {
-            const long long o = pd.rp_off + (long long)item.range * pd.n1pad + arow_base;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int off = (r & 3) + 8 * (r >> 2);
-                rp_s0[o + off] = fs0[r];
-                rp_s1[o + off] = fs1[r];
+        for (int r = 0; r < 16; ++r) tr[((r & 3) + 8 * (r >> 2) + 4 * lhalf) * 33 + lcol] = rs0[r];
+        if (lane < kI8WaveRows) {
+            int m0 = (int)0x80000000, m1 = (int)0x80000000;
+#pragma unroll 8
+            for (int k = 0; k < 32; ++k) {
+                const int v = tr[lane * 33 + k];
+                m1 = max(m1, min(m0, v));
+                m0 = max(m0, v);
             }
+            // S~ = -2 * accumulator as a float (exact); padding -> +inf
+            const long long o = pd.rp_off + (long long)item.range * pd.n1pad + item.a_blk * kPfWgRows + wave * kI8WaveRows + lane;
+            rp_s0[o] = m0 > kI8PadTest ? (float)(-2 * m0) : f_inf();
+            rp_s1[o] = m1 > kI8PadTest ? (float)(-2 * m1) : f_inf();
         }
     }
     }   // item loop
