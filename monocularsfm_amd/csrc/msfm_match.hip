@@ -833,8 +833,11 @@ int finish_prefilter(msfm_ctx* ctx, Batch& b, std::vector<char>& force_exact, bo
         else HIPCHK(ctx, hipMemcpyFromSymbol(pr, HIP_SYMBOL(g_sweep_probe3), sizeof(pr)));
         for (int w = 0; w < (pe.i8 ? 16 : kPfWaves); w += (pe.i8 ? 1 : 3)) {
             const double n = (double)std::max<unsigned long long>(1, pr[w][4]);
-            std::fprintf(stderr, "[sweep %d probe] wave %d: MFMA %.0f | wait+barrier %.0f | EPI %.0f | wait+barrier %.0f cycles per tile (%.0f tiles, %llu items)\n",
-                         which == 0 ? 1 : 3, w, pr[w][0] / n, pr[w][1] / n, pr[w][2] / n, pr[w][3] / n, n, pr[w][5]);
+            const double it_n = (double)std::max<unsigned long long>(1, pr[w][5]);
+            std::fprintf(stderr, "[sweep %d probe] wave %d: MFMA %.0f | wait+barrier %.0f | EPI %.0f | wait+barrier %.0f cycles per tile (%.0f tiles, %llu items); per item: %.0f cycles in the loop, %.0f outside it (descriptor fetch, A loads, first DMA, row merge)\n",
+                         which == 0 ? 1 : 3, w, pr[w][0] / n, pr[w][1] / n, pr[w][2] / n, pr[w][3] / n, n, pr[w][5],
+                         (double)(pr[w][0] + pr[w][1] + pr[w][2] + pr[w][3]) / it_n,
+                         ((double)pr[w][6] - (double)(pr[w][0] + pr[w][1] + pr[w][2] + pr[w][3])) / it_n);
         }
         std::memset(pr, 0, sizeof(pr));
         if (which == 0) HIPCHK(ctx, hipMemcpyToSymbol(HIP_SYMBOL(g_sweep_probe), pr, sizeof(pr)));

@@ -53,6 +53,12 @@ __device__ unsigned long long g_sweep_probe[16][8];    // (16: the integer-core 
 __device__ unsigned long long g_sweep_probe3[16][8];   // the compacted sweep 2
 #define MSFM_PROBE_BEGIN unsigned long long pb_t = __builtin_amdgcn_s_memtime(), pb_acc[4] = {0, 0, 0, 0};
 #define MSFM_PROBE(k) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); pb_acc[k] += n_ - pb_t; pb_t = n_; }
+#define MSFM_PROBE_ITEM_BEGIN const unsigned long long pb_item0 = __builtin_amdgcn_s_memtime();
+#define MSFM_PROBE_ITEM_END                                                                                \
+    if (PASS != 2 && lane == 0) {                                                                          \
+        unsigned long long (*pi_)[8] = PASS == 1 ? g_sweep_probe : g_sweep_probe3;                         \
+        atomicAdd(&pi_[wave][6], (unsigned long long)(__builtin_amdgcn_s_memtime() - pb_item0));          \
+    }
 #define MSFM_PROBE_END                                                                                     \
     if (PASS != 2 && lane == 0) {                                                                          \
         unsigned long long (*pr_)[8] = PASS == 1 ? g_sweep_probe : g_sweep_probe3;                         \
@@ -64,6 +70,8 @@ __device__ unsigned long long g_sweep_probe3[16][8];   // the compacted sweep 2
 #define MSFM_PROBE_BEGIN
 #define MSFM_PROBE(k)
 #define MSFM_PROBE_END
+#define MSFM_PROBE_ITEM_BEGIN
+#define MSFM_PROBE_ITEM_END
 #endif
 
 template <int N>
@@ -122,6 +130,7 @@ __global__ __launch_bounds__(kPfThreads, 2) void sweep_kernel(
         it = s_next_item * 8 + (int)(blockIdx.x & 7);
     }
     if (it >= n_items) break;
+    MSFM_PROBE_ITEM_BEGIN
     const WorkItem item = items[it];
     if (item.pair < 0) continue;
     const PfPair pp = pf[item.pair];
@@ -509,5 +518,6 @@ __global__ __launch_bounds__(kPfThreads, 2) void sweep_kernel(
         rp_s0[o] = -2.f * m0;      // padding rows: -inf -> +inf
         rp_s1[o] = -2.f * m1;
     }
+    MSFM_PROBE_ITEM_END
     }   // item loop
 }
