@@ -49,19 +49,21 @@
 // Diagnostic build only (tools/gpu_probe.sh, -DMSFM_SWEEP_PROBE): per-wave cycle sums of the four segments of a tile
 // (MFMA phase, its wait + barrier, EPI phase, its wait + barrier), printed by the library after every sweep 1.
 #ifdef MSFM_SWEEP_PROBE
-__device__ unsigned long long g_sweep_probe[16][8];    // (16: the integer-core kernels run sixteen waves)
-__device__ unsigned long long g_sweep_probe3[16][8];   // the compacted sweep 2
+__device__ unsigned long long g_sweep_probe[16][16];    // (16: the integer-core kernels run sixteen waves)
+__device__ unsigned long long g_sweep_probe3[16][16];   // the compacted sweep 2
 #define MSFM_PROBE_BEGIN unsigned long long pb_t = __builtin_amdgcn_s_memtime(), pb_acc[4] = {0, 0, 0, 0};
 #define MSFM_PROBE(k) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); pb_acc[k] += n_ - pb_t; pb_t = n_; }
-#define MSFM_PROBE_ITEM_BEGIN const unsigned long long pb_item0 = __builtin_amdgcn_s_memtime();
+#define MSFM_PROBE_ITEM_BEGIN const unsigned long long pb_item0 = __builtin_amdgcn_s_memtime(); unsigned long long pb_it = pb_item0;
+// item-level segments: 8 descriptor fetch | 9 A loads + first DMA (vmcnt 0) | 10 barrier + pre-read + offset | 11 loop | 12 drain | 13 row merge
+#define MSFM_PROBE_SEG(k) if (PASS != 2 && lane == 0) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); atomicAdd(&(PASS == 1 ? g_sweep_probe : g_sweep_probe3)[wave][k], n_ - pb_it); pb_it = n_; }
 #define MSFM_PROBE_ITEM_END                                                                                \
     if (PASS != 2 && lane == 0) {                                                                          \
-        unsigned long long (*pi_)[8] = PASS == 1 ? g_sweep_probe : g_sweep_probe3;                         \
+        unsigned long long (*pi_)[16] = PASS == 1 ? g_sweep_probe : g_sweep_probe3;                         \
         atomicAdd(&pi_[wave][6], (unsigned long long)(__builtin_amdgcn_s_memtime() - pb_item0));          \
     }
 #define MSFM_PROBE_END                                                                                     \
     if (PASS != 2 && lane == 0) {                                                                          \
-        unsigned long long (*pr_)[8] = PASS == 1 ? g_sweep_probe : g_sweep_probe3;                         \
+        unsigned long long (*pr_)[16] = PASS == 1 ? g_sweep_probe : g_sweep_probe3;                         \
         for (int k_ = 0; k_ < 4; ++k_) atomicAdd(&pr_[wave][k_], pb_acc[k_]);                              \
         atomicAdd(&pr_[wave][4], (unsigned long long)(t_end - t_begin));                                   \
         atomicAdd(&pr_[wave][5], 1ull);                                                                    \
@@ -72,6 +74,7 @@ __device__ unsigned long long g_sweep_probe3[16][8];   // the compacted sweep 2
 #define MSFM_PROBE_END
 #define MSFM_PROBE_ITEM_BEGIN
 #define MSFM_PROBE_ITEM_END
+#define MSFM_PROBE_SEG(k)
 #endif
 
 template <int N>
@@ -139,6 +142,7 @@ __global__ __launch_bounds__(kPfThreads, 2) void sweep_kernel(
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    MSFM_PROBE_SEG(8)
     const int grp = wave >> 2;          // 0: MFMA in the even phases, 1: in the odd ones
     const int lcol = lane & 31, lhalf = lane >> 5;
 
@@ -241,6 +245,7 @@ __global__ __launch_bounds__(kPfThreads, 2) void sweep_kernel(
 #pragma unroll
         for (int ks = 0; ks < 9; ++ks) asm volatile("" ::"v"(af[rb][ks]));
     wait_vmcnt<0>();  // prologue loads and the first three DMA groups are done: counted waits start clean
+    MSFM_PROBE_SEG(9)
 
     // sweep 2: wave-private candidate buffer in LDS
     int2* cbuf = reinterpret_cast<int2*>(sCand) + wave * kPfCandBuf;
@@ -443,6 +448,7 @@ __global__ __launch_bounds__(kPfThreads, 2) void sweep_kernel(
     if (grp == 1) lds_barrier();                         // the odd half starts half a tile later
 
     f16v accA[kPfRB], accB[kPfRB];
+    MSFM_PROBE_SEG(10)
     MSFM_PROBE_BEGIN
 #pragma unroll 1
     for (int t = t_begin; t < t_end; ++t) {
@@ -489,6 +495,7 @@ __global__ __launch_bounds__(kPfThreads, 2) void sweep_kernel(
         MSFM_PROBE(3)
     }
     MSFM_PROBE_END
+    MSFM_PROBE_SEG(11)
     if (grp == 0) lds_barrier();   // the odd half's last EPI phase
     if (PASS >= 2) flush_candidates();
     if (PASS == 1 && wave == 0) store_columns(t_end - 1);
@@ -496,6 +503,7 @@ __global__ __launch_bounds__(kPfThreads, 2) void sweep_kernel(
     if (PASS == 1) {
         wait_vmcnt<0>();   // the tail's DMA groups (re-fetches of the last tile) still write into the ring ...
         lds_barrier();     // ... everybody's have landed: the ring is scratch now
+        MSFM_PROBE_SEG(12)
         // rows: lane (lcol, lhalf) holds, for each of its 32 rows, the accumulator maximum over ITS columns; a row's result is
         // the two largest of its 32 lane values (S~ = -2 acc: the smallest S~ and an upper bound of the second smallest).
         // Transposed through the wave's share of the (now idle) B ring -- [64 rows][32 lanes + 1] floats -- so that lane l
@@ -518,6 +526,7 @@ __global__ __launch_bounds__(kPfThreads, 2) void sweep_kernel(
         rp_s0[o] = -2.f * m0;      // padding rows: -inf -> +inf
         rp_s1[o] = -2.f * m1;
     }
+    MSFM_PROBE_SEG(13)
     MSFM_PROBE_ITEM_END
     }   // item loop
 }
