@@ -57,6 +57,15 @@ def pmc_traffic():
     return None
 
 
+def result_checksum(result):
+    import zlib
+    offs, qt = result[0], result[1]
+    c = zlib.crc32(np.ascontiguousarray(offs, dtype=np.int64).tobytes())
+    if qt is not None:
+        c = zlib.crc32(np.ascontiguousarray(qt, dtype=np.int32).tobytes(), c)
+    return int(c)
+
+
 def opencv_found():
     try:
         import cv2
@@ -161,6 +170,9 @@ def main():
     ap.add_argument("--u8-images", type=int, default=192,
                     help="images of the secondary strong-scaling job (subset of the 1329 x 8192 u8 config); 0 = skip")
     ap.add_argument("--u8-steps", type=int, default=2)
+    ap.add_argument("--sustained-steps", type=int, default=200,
+                    help="extra untimed-for-`value` run of this many steps after the K timed ones -> sustained_ms_per_step "
+                         "(the part's clock is set by a power budget: a 1 s burst and a 10 s run differ); 0 = skip")
     args = ap.parse_args()
 
     import torch
@@ -202,7 +214,7 @@ def main():
     elif args.f16_only:
         ctx.set_prefilter(2)
 
-    def run_job(imgs, pairs, steps, warmup, collect=None, **match_kw):
+    def run_job(imgs, pairs, steps, warmup, collect=None, sustained_steps=0, **match_kw):
         """Upload, W untimed + K timed steps; -> (seconds of the K steps: max over ranks, result of the last step,
         upload seconds, per-rank [compute_ms, exchange_ms] means)."""
         n_rows = np.array([len(x) for x in imgs], np.int64)
@@ -235,6 +247,13 @@ def main():
                 collect(ctx.profile())
         barrier()
         dt = time.perf_counter() - t0
+        sustained = None
+        if sustained_steps > 0:   # after the timed region: the same step, long enough for the power / thermal state to settle
+            t1 = time.perf_counter()
+            for _ in range(sustained_steps):
+                result = step()
+            barrier()
+            sustained = (time.perf_counter() - t1) / sustained_steps
         per_rank = [(phases / steps).tolist()]
         if world > 1:
             t = torch.tensor([dt] + (phases / steps).tolist(), dtype=torch.float64, device=coll_dev)
@@ -243,6 +262,11 @@ def main():
             allt = torch.stack(allt).cpu().numpy()
             dt = float(allt[:, 0].max())
             per_rank = allt[:, 1:].tolist()
+            if sustained is not None:
+                t = torch.tensor([sustained], dtype=torch.float64, device=coll_dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                sustained = float(t.cpu()[0])
+        run_job.sustained = sustained
         return dt, result, upload_s, per_rank, n_rows
 
     # ---- main workload -----------------------------------------------------------------------------------------
@@ -258,7 +282,8 @@ def main():
             acc[k] += p[k]
         last_prof.update(p)
 
-    dt, result, upload_s, per_rank, n_rows = run_job(imgs, pairs, args.steps, args.warmup, collect, **main_kw)
+    dt, result, upload_s, per_rank, n_rows = run_job(imgs, pairs, args.steps, args.warmup, collect, args.sustained_steps, **main_kw)
+    sustained = run_job.sustained
     total_desc_pairs = int((n_rows[pairs[:, 0]] * n_rows[pairs[:, 1]]).sum())
     offs = result[0]
     n_matches = int(offs[-1])
@@ -285,6 +310,12 @@ def main():
         # this rank's view per step (ms): matcher call (sweeps + epilogue + copy into the send buffer) vs exchange
         "per_rank_ms": [{"compute": c, "exchange": e} for c, e in per_rank],
         "device_ms_per_step_rank0": acc["total_device_ms"] / args.steps,
+        # the same step repeated --sustained-steps times right after the timed region (power / thermal steady state)
+        "sustained_ms_per_step": None if sustained is None else sustained * 1e3,
+        "sustained_steps": args.sustained_steps,
+        "sustained_value": None if sustained is None else total_desc_pairs / sustained,
+        # CRC-32 of the writer rank's (offsets, (q, t) rows) of the last step: equal across N and across exchange paths
+        "exchange_checksum": result_checksum(result) if rank == 0 else None,
         "sub_batches_per_step": acc["sub_batches"] // max(1, args.steps),
     }
     pf_ms, pf_launches = acc["approx_kernel_ms"], acc["approx_kernel_launches"]
@@ -306,6 +337,8 @@ def main():
             "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TOP/s" if i8 else "TFLOP/s",
             "frac": achieved / peak,
             "traffic": tr["bytes_per_launch"] if tr else None, "traffic_unit": "HBM bytes/launch (PMC)", "traffic_detail": tr,
+            # not measured by THIS run: rocprofv3 --pmc passes cannot run inside the timed process
+            "traffic_source": ("committed PMC pass of this command: " + tr["source"]) if tr else None,
             "avg_launch_ms": avg_ms, "launches": pf_launches, "flops_per_desc_pair": 256.0,
             "descriptor_pairs_per_launch": pf_pairs_work / pf_launches,
             "algorithmic_bytes_per_launch": algo_bytes_step * args.steps / pf_launches,

@@ -131,6 +131,7 @@ constexpr int kSlots = 2 * MSFM_MAX_IMAGES + 2;  // ids >= MSFM_MAX_IMAGES: auxi
 // sub-batches of msfm_match_pairs are bounded by the partial-result scratch (4-byte units: ~48 GiB of the 288 GB) and a pair count
 constexpr long long kDefaultScratchElems = (long long)12 << 30;
 constexpr int kDefaultMaxPairsPerBatch = 16384;
+constexpr int kMaxPairsPerBatchLimit = 65535;   // gridDim.y
 
 }  // namespace
 
@@ -764,22 +765,22 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
     }
 
     if (n_lists > 0) {
-        const dim3 cgrid(64, (unsigned)n_lists);
+        const dim3 cgrid(64, (unsigned)std::min<size_t>(n_lists, 65535));   // (the kernels stride over the lists in y)
         const unsigned long long* dcount = ctx->d_cand_count.as<unsigned long long>();
         if (ctx->order == MSFM_ORDER_SSE4X4)
             hipLaunchKernelGGL(pf_exact_candidates_kernel<0>, cgrid, dim3(256), 0, ctx->stream, dp, dl, dcount,
                                ctx->d_cand.as<int2>(), ctx->d_cand_s.as<float>(), ctx->d_cand_pair.as<int>(),
-                               ctx->d_best.as<unsigned long long>());
+                               ctx->d_best.as<unsigned long long>(), (int)n_lists);
         else
             hipLaunchKernelGGL(pf_exact_candidates_kernel<1>, cgrid, dim3(256), 0, ctx->stream, dp, dl, dcount,
                                ctx->d_cand.as<int2>(), ctx->d_cand_s.as<float>(), ctx->d_cand_pair.as<int>(),
-                               ctx->d_best.as<unsigned long long>());
+                               ctx->d_best.as<unsigned long long>(), (int)n_lists);
         HIPCHK(ctx, hipGetLastError());
         DBGSYNC(ctx, "pf_exact_candidates_kernel");
-        const dim3 rgrid(16, (unsigned)n_lists);
+        const dim3 rgrid(16, (unsigned)std::min<size_t>(n_lists, 65535));
         hipLaunchKernelGGL(pf_reduce_second_kernel, rgrid, dim3(256), 0, ctx->stream, dp, dl, dcount,
                            ctx->d_cand.as<int2>(), ctx->d_cand_s.as<float>(), (const int*)ctx->d_cand_pair.as<int>(),
-                           ctx->d_best.as<unsigned long long>(), ctx->d_second.as<unsigned long long>());
+                           ctx->d_best.as<unsigned long long>(), ctx->d_second.as<unsigned long long>(), (int)n_lists);
         HIPCHK(ctx, hipGetLastError());
         DBGSYNC(ctx, "pf_reduce_second_kernel");
     }
@@ -1073,7 +1074,7 @@ int msfm_create(int device_ordinal, msfm_ctx** out_ctx) {
     }
     if (const char* e = std::getenv("MSFM_PREFILTER")) ctx->prefilter = e[0] == '2' ? 2 : (e[0] != '0');
     if (const char* e = std::getenv("MSFM_MAX_PAIRS_PER_BATCH"))
-        if (std::atoi(e) > 0) ctx->max_pairs_per_batch = std::atoi(e);
+        if (std::atoi(e) > 0) ctx->max_pairs_per_batch = std::min(std::atoi(e), kMaxPairsPerBatchLimit);
     if (const char* e = std::getenv("MSFM_SCRATCH_MIB"))
         if (std::atoll(e) > 0) ctx->scratch_elems = std::atoll(e) * (1 << 20) / 4;
     *out_ctx = ctx;
@@ -1141,7 +1142,8 @@ int msfm_set_prefilter(msfm_ctx* ctx, int enable) {
 
 int msfm_set_limits(msfm_ctx* ctx, int max_pairs_per_batch, int64_t scratch_bytes) {
     if (!ctx) return MSFM_E_INVALID;
-    ctx->max_pairs_per_batch = max_pairs_per_batch > 0 ? max_pairs_per_batch : kDefaultMaxPairsPerBatch;
+    // (the pair index of a sub-batch is gridDim.y of several kernels: at most 65535)
+    ctx->max_pairs_per_batch = max_pairs_per_batch > 0 ? std::min(max_pairs_per_batch, kMaxPairsPerBatchLimit) : kDefaultMaxPairsPerBatch;
     ctx->scratch_elems = scratch_bytes > 0 ? std::max<long long>(1, scratch_bytes / 4) : kDefaultScratchElems;
     return MSFM_OK;
 }
@@ -1347,6 +1349,7 @@ static int match_pairs_impl(msfm_ctx* ctx, const int32_t* pairs, int n_pairs, co
     while (begin < n_pairs) {
       int end = begin;
       std::vector<char> force_exact;   // pairs of this sub-batch whose candidate list overflowed: brute-force path in the re-run
+      msfm_profile prof_at_batch = ctx->prof;
       for (int attempt = 0;; ++attempt) {   // a sub-batch is re-run when a queue / plan buffer was too small (grown by then)
         Batch b;
         long long est = 0;
@@ -1383,6 +1386,14 @@ static int match_pairs_impl(msfm_ctx* ctx, const int32_t* pairs, int n_pairs, co
         const size_t P = b.pairs.size();
         const size_t ev_base = ev_next;
         if (attempt == 0) ev_next += 8;
+        if (attempt == 0) prof_at_batch = ctx->prof;
+        else {   // a re-run: times / launches / work of the dropped attempt do not count, the re-run counters do
+            msfm_profile keep = prof_at_batch;
+            keep.tie_queue_regrows = ctx->prof.tie_queue_regrows;
+            keep.plan_regrows = ctx->prof.plan_regrows;
+            keep.fallback_pairs = ctx->prof.fallback_pairs;
+            ctx->prof = keep;
+        }
         bool exact_launched = false;
         int rc = run_knn(ctx, b, ev_base, &exact_launched, prune, need_fix);
         if (rc != MSFM_OK) return rc;
@@ -1576,11 +1587,20 @@ int msfm_match_pair(msfm_ctx* ctx, int id1, int id2, float ratio, int cross_chec
     return msfm_fetch_matches(ctx, out_qt, out_dist);
 }
 
+static int knn2_pair_impl(msfm_ctx* ctx, int id1, int id2, int32_t* fwd_idx0, float* fwd_d0, float* fwd_d1,
+                          int32_t* rev_idx0, float* rev_d0, float* rev_d1);
+
 int msfm_knn2_pair(msfm_ctx* ctx, int id1, int id2, int32_t* fwd_idx0, float* fwd_d0, float* fwd_d1,
                    int32_t* rev_idx0, float* rev_d0, float* rev_d1) {
     if (!ctx) return MSFM_E_INVALID;
+    return drained(ctx, knn2_pair_impl(ctx, id1, id2, fwd_idx0, fwd_d0, fwd_d1, rev_idx0, rev_d0, rev_d1));
+}
+
+static int knn2_pair_impl(msfm_ctx* ctx, int id1, int id2, int32_t* fwd_idx0, float* fwd_d0, float* fwd_d1,
+                          int32_t* rev_idx0, float* rev_d0, float* rev_d1) {
     HIPCHK(ctx, hipSetDevice(ctx->device));
     ctx->prof = msfm_profile{};
+    ctx->pf_pending = msfm_ctx::PfPending{};   // (a failed earlier batch may have left its end-of-batch state behind)
     Batch b;
     PairDesc pd;
     PfPair pp;

@@ -341,10 +341,10 @@ template <int ORDER>
 __global__ void pf_exact_candidates_kernel(const PairDesc* __restrict__ pairs, const CandList* __restrict__ lists,
                                            const unsigned long long* __restrict__ cand_count, int2* __restrict__ cand,
                                            float* __restrict__ cand_s, int* __restrict__ cand_pair,
-                                           unsigned long long* __restrict__ best /* reduce phase A rides along */) {
-    const int lid = blockIdx.y;
+                                           unsigned long long* __restrict__ best /* reduce phase A rides along */, int n_lists) {
+  for (int lid = blockIdx.y; lid < n_lists; lid += gridDim.y) {   // (more lists than gridDim.y allows: stride)
     const CandList L = lists[lid];
-    if (L.cap == 0) return;
+    if (L.cap == 0) continue;
     const int n = (int)(cand_count[lid] < (unsigned long long)L.cap ? cand_count[lid] : (unsigned long long)L.cap);
     const int sub = threadIdx.x & 15;
     for (int c = (blockIdx.x * blockDim.x + threadIdx.x) >> 4; c < ((n + 3) & ~3); c += (gridDim.x * blockDim.x) >> 4) {
@@ -406,6 +406,7 @@ __global__ void pf_exact_candidates_kernel(const PairDesc* __restrict__ pairs, c
             }
         }
     }
+  }
 }
 
 
@@ -414,10 +415,10 @@ __global__ void pf_reduce_second_kernel(const PairDesc* __restrict__ pairs, cons
                                         const unsigned long long* __restrict__ cand_count,
                                         const int2* __restrict__ cand, const float* __restrict__ cand_s,
                                         const int* __restrict__ cand_pair, const unsigned long long* __restrict__ best,
-                                        unsigned long long* __restrict__ second) {
-    const int lid = blockIdx.y;
+                                        unsigned long long* __restrict__ second, int n_lists) {
+  for (int lid = blockIdx.y; lid < n_lists; lid += gridDim.y) {
     const CandList L = lists[lid];
-    if (L.cap == 0) return;
+    if (L.cap == 0) continue;
     const int n = (int)(cand_count[lid] < (unsigned long long)L.cap ? cand_count[lid] : (unsigned long long)L.cap);
     for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < n; c += gridDim.x * blockDim.x) {
         const int2 qt = cand[L.off + c];
@@ -428,6 +429,7 @@ __global__ void pf_reduce_second_kernel(const PairDesc* __restrict__ pairs, cons
         if (L.mode != 2 && kf != best[kfo + qt.x]) atomicMin(&second[kfo + qt.x], kf);
         if (L.mode != 1 && kr != best[kro + qt.y]) atomicMin(&second[kro + qt.y], kr);
     }
+  }
 }
 
 #include "msfm_plan.hip.h"

@@ -172,6 +172,11 @@ void FeatureMatcher::PreloadAllImages() {
             m->resident_.insert(id);
             for (auto& have : m->extra_resident_) have.insert(id);
         } else {
+            // Database::ReadKeyPoints asserts cols == 4 (x, y, size, angle); a narrower blob would be over-read below
+            if (rows > 0 && cols != 4) {
+                std::cerr << "ERROR: keypoints of image " << id << " have " << cols << " columns, expected 4" << std::endl;
+                std::exit(EXIT_FAILURE);
+            }
             std::vector<KeyPoint>& kps = m->keypoints_cache_[id];
             kps.resize(rows);
             if (rows) std::memcpy(kps.data(), data, rows * sizeof(KeyPoint));
@@ -181,7 +186,14 @@ void FeatureMatcher::PreloadAllImages() {
         }
     };
     static_assert(sizeof(KeyPoint) == 16, "KeyPoint must be 4 packed floats");
-    if (database_->HasDescriptorsU8()) database_->VisitAllDescriptorsU8(visit, &sink);
+    // The byte side table replaces the float descriptors ONLY on request (MSFM_USE_DESCRIPTORS_U8=1): the reference always
+    // stores L1-root normalised floats, raw bytes give different distances, and a stale or foreign `descriptors_u8`
+    // table must not change the results silently.
+    const char* use_u8 = std::getenv("MSFM_USE_DESCRIPTORS_U8");
+    if (use_u8 && use_u8[0] == '1' && database_->HasDescriptorsU8()) {
+        std::cout << "Using byte descriptors of the descriptors_u8 side table (MSFM_USE_DESCRIPTORS_U8=1)" << std::endl;
+        database_->VisitAllDescriptorsU8(visit, &sink);
+    }
     database_->VisitAllDescriptors(visit, &sink);   // images the side table does not cover
     sink.keypoints = true;
     database_->VisitAllKeyPoints(visit, &sink);

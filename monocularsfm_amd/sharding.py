@@ -184,9 +184,11 @@ def gather_to_writer(bounds, local_offs, local_payload, dst=0, group=None, devic
     blk = offs[np.asarray(bounds)]                      # block r = rows [blk[r], blk[r+1]) of the global payload
     pin = dev.type == "cuda"
     M = int(offs[-1])
+    # P2POp's peer is a GLOBAL rank; r / dst are ranks of `group`
+    peer = (lambda r: dist.get_global_rank(group, r)) if (multi and group is not None) else (lambda r: r)
     if rank == dst:
         out = _device_buffer(M, cols, dev, "recv") if pin else _host_buffer(M, cols, False, "recv")
-        ops = [dist.P2POp(dist.irecv, out[int(blk[r]):int(blk[r + 1])], r, group)
+        ops = [dist.P2POp(dist.irecv, out[int(blk[r]):int(blk[r + 1])], peer(r), group)
                for r in range(world) if r != dst and blk[r + 1] > blk[r]]
         if ops:
             reqs = dist.batch_isend_irecv(ops)
@@ -202,7 +204,7 @@ def gather_to_writer(bounds, local_offs, local_payload, dst=0, group=None, devic
             return offs, host.numpy()
         return offs, out.numpy()
     if blk[rank + 1] > blk[rank]:
-        for q in dist.batch_isend_irecv([dist.P2POp(dist.isend, local_payload, dst, group)]):
+        for q in dist.batch_isend_irecv([dist.P2POp(dist.isend, local_payload, peer(dst), group)]):
             q.wait()
     return offs, None
 

@@ -370,11 +370,22 @@ def test_bulk_load_u8_side_table_and_scene_graph_order(exe, oracle, tmp_path):
     p_ord, c_ord = make_db("ord", False)
     run_cli(exe, c_bulk, env)
     run_cli(exe, c_single, dict(env, MSFM_BULK_LOAD="0"))
-    run_cli(exe, c_u8, env)
+    out_u8 = run_cli(exe, c_u8, dict(env, MSFM_USE_DESCRIPTORS_U8="1"))
+    assert "descriptors_u8 side table" in out_u8            # the switch to byte descriptors is announced
+    # the side table is OPT-IN: without the switch a (possibly stale / foreign) table is ignored -- the halved floats rule
+    p_off, c_off = make_db("u8_off", True)
+    out_off = run_cli(exe, c_off, env)
+    assert "descriptors_u8" not in out_off
     run_cli(exe, c_ord, dict(env, MSFM_SCENEGRAPH_ORDER="1"))
     r_bulk, r_single, r_u8, r_ord = rows_of(p_bulk), rows_of(p_single), rows_of(p_u8), rows_of(p_ord)
     assert len(r_bulk) > 3 and r_bulk == r_single          # (1)
     assert r_u8 == r_bulk                                   # (2): the bytes of the side table, not the halved floats
+    # (halving every value scales all distances by 0.5: the same matches survive ratio + cross-check, so compare via the oracle)
+    db_off = database.Database(p_off)
+    i0, j0 = 1, 0
+    qh, th, _ = io.match_pair(u[i0], u[j0], 0.8, True, 1e9)
+    assert np.array_equal(db_off.ReadMatches(i0, j0), np.stack([qh, th], 1).reshape(-1, 2))   # same indices (scale-invariant tests)
+    db_off.Close()
     # against the exact-integer reference, over the sequential mode's pair list (no pre-emptive filter there)
     pairs, _ = oracle.enumerate_sequential(len(sizes), 3)
     assert len(r_bulk) == len(pairs)

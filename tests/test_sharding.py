@@ -115,3 +115,43 @@ def test_multi_rank_gather_equals_single_process(tmp_path, oracle, world, sizes)
         assert np.array_equal(g["offs"], np.asarray(exp_off))
         assert np.array_equal(g["qt"], exp_q)
         assert np.array_equal(g["d"].view(np.int32), exp_d.view(np.int32))
+
+
+def _subgroup_worker(rank, world, port, out_dir):
+    """World of 3, the job runs on the sub-group {1, 2}: group rank != global rank, so a P2POp peer given as a group
+    rank would address the wrong process (torch's P2POp peers are global ranks)."""
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from monocularsfm_amd.sharding import ShardedMatcher
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    grp = dist.new_group([1, 2])
+    if rank in (1, 2):
+        n_rows = np.array([30, 40, 50, 60])
+        pairs = np.array([(i, j) for i in range(4) for j in range(i)], np.int32)
+
+        def match_fn(sub):   # a deterministic stand-in: pair (i, j) "matches" i + j rows
+            offs, rows = [0], []
+            for i, j in sub:
+                m = int(i + j)
+                rows.append(np.stack([np.arange(m) + 100 * i, np.arange(m) + 100 * j], 1).astype(np.int32).reshape(-1, 2))
+                offs.append(offs[-1] + m)
+            return np.asarray(offs, np.int64), (np.concatenate(rows) if rows else np.zeros((0, 2), np.int32)), np.zeros(offs[-1], np.float32)
+
+        sm = ShardedMatcher(match_fn=match_fn, group=grp)
+        offs, qt, _ = sm.match_to_writer(pairs, n_rows, dst=0)          # group rank 0 = global rank 1
+        e_offs, e_qt, _ = match_fn(pairs)
+        assert np.array_equal(offs, e_offs)
+        if rank == 1:
+            assert np.array_equal(qt, e_qt)
+            np.save(os.path.join(out_dir, "sub.npy"), qt)
+        else:
+            assert qt is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_exchange_on_a_sub_group(tmp_path):
+    mp.spawn(_subgroup_worker, args=(3, _free_port(), str(tmp_path)), nprocs=3, join=True)
+    assert os.path.exists(os.path.join(str(tmp_path), "sub.npy"))

@@ -1,0 +1,151 @@
+"""BASELINE configs[3] IN FULL on one MI355X: 1329 images x 8192 byte descriptors, all 882 456 pairs in ONE
+msfm_match_pairs call (the N = 1 anchor of north_star's >= 6x strong-scaling target).
+
+    python tools/config4_full.py [--images 1329] [--desc 8192] [--oracle-pairs 24] > gpurun_out/config4_full.json
+
+Checks: (1) the call's sub-batch count equals the count predicted from the library's scratch formula, (2) sampled
+pairs -- the first and the last pair of several sub-batches, plus seeded random ones -- against the C oracle, and two of
+them against the exact-integer reference (oracle/int_oracle.py), (3) size-independent properties of the whole result:
+offsets monotone, every (q, t) in range, q strictly ascending inside a pair, no t twice inside a pair (cross-check).
+Reports wall time, device time, peak device / page-locked memory.  Test infrastructure (imports oracle/).
+Replaces at this size: the pair loop of /root/reference/src/Feature/FeatureMatching.cpp:102-145."""
+import argparse
+import ctypes
+import json
+import os
+import resource
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from monocularsfm_amd import _lib, synth  # noqa: E402
+
+
+def mem_info():
+    hip = ctypes.CDLL("libamdhip64.so")
+    free, total = ctypes.c_size_t(), ctypes.c_size_t()
+    hip.hipMemGetInfo(ctypes.byref(free), ctypes.byref(total))
+    return free.value, total.value
+
+
+def predicted_sub_batches(n_rows, pairs, max_pairs=16384, scratch_elems=12 << 30):
+    """The cut of match_pairs_impl (csrc/msfm_match.hip): pairs are taken until the pair limit or the scratch estimate."""
+    bounds = [0]
+    est, cnt = 0, 0
+    for k, (i, j) in enumerate(pairs):
+        n1, n2 = int(n_rows[i]), int(n_rows[j])
+        n1pad = (n1 + 511) // 512 * 512
+        n2pad = (n2 + 511) // 512 * 512
+        need = n1pad + 2 * ((n1 + 127) // 128) * n2pad + 3 * (8 * (n1 + n2) + 1024) if n1 and n2 else 0
+        if cnt > 0 and (cnt >= max_pairs or est + need > scratch_elems):
+            bounds.append(k)
+            est, cnt = 0, 0
+        est += need
+        cnt += 1
+    bounds.append(len(pairs))
+    return bounds
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--images", type=int, default=1329)
+    ap.add_argument("--desc", type=int, default=8192)
+    ap.add_argument("--oracle-pairs", type=int, default=24)
+    ap.add_argument("--int-oracle-pairs", type=int, default=2)
+    args = ap.parse_args()
+
+    t0 = time.perf_counter()
+    imgs, pairs, name = synth.job("synthetic-u8", args.images, args.desc, seed=1329)
+    gen_s = time.perf_counter() - t0
+    n_rows = np.array([len(x) for x in imgs], np.int64)
+    total_desc_pairs = int((n_rows[pairs[:, 0]] * n_rows[pairs[:, 1]]).sum())
+    free0, total_mem = mem_info()
+    ctx = _lib.Context(0)
+    t0 = time.perf_counter()
+    for i, im in enumerate(imgs):
+        ctx.upload_image(i, im)
+    upload_s = time.perf_counter() - t0
+    free_store, _ = mem_info()
+    t0 = time.perf_counter()
+    offs, qt, d = ctx.match_pairs(pairs, max_distance=1e9, fetch="view")
+    wall_s = time.perf_counter() - t0
+    prof = ctx.profile()
+    free_after, _ = mem_info()
+    M = int(offs[-1])
+    bounds = predicted_sub_batches(n_rows, pairs)
+
+    # (3) whole-result properties, in chunks of pairs (3.6e8 matches: the index arrays of one pass would be tens of GB)
+    assert (np.diff(offs) >= 0).all()
+    in_range = q_ascending = t_unique = True
+    for p0 in range(0, len(pairs), 20000):
+        p1 = min(len(pairs), p0 + 20000)
+        s, e = int(offs[p0]), int(offs[p1])
+        if e == s:
+            continue
+        cq, ct = np.asarray(qt[s:e, 0]), np.asarray(qt[s:e, 1])
+        pair_of = np.repeat(np.arange(p0, p1), np.diff(offs[p0:p1 + 1]))
+        in_range &= bool(((cq >= 0) & (cq < n_rows[pairs[pair_of, 0]]) & (ct >= 0) & (ct < n_rows[pairs[pair_of, 1]])).all())
+        same_pair = pair_of[1:] == pair_of[:-1]
+        q_ascending &= bool((np.diff(cq.astype(np.int64))[same_pair] > 0).all())
+        key = np.sort((pair_of - p0).astype(np.int64) * (1 << 20) + ct)
+        t_unique &= bool((np.diff(key) != 0).all())      # cross-check: a train row is matched at most once per pair
+
+    # (2) sampled pairs against the oracles
+    from oracle import c_oracle, int_oracle
+    c_oracle.build()
+    rng = np.random.default_rng(4)
+    cut_pairs = []
+    for b in bounds[1:-1][:: max(1, (len(bounds) - 2) // 5 or 1)][:5]:
+        cut_pairs += [b - 1, b]                          # last pair of one sub-batch, first of the next
+    sel = sorted(set([0, len(pairs) - 1] + cut_pairs + rng.choice(len(pairs), max(0, args.oracle_pairs - 2 - len(cut_pairs)), replace=False).tolist()))
+    sel = np.asarray(sel, np.int64)
+    f32 = {int(i): imgs[int(i)].astype(np.float32) for i in np.unique(pairs[sel])}
+    t0 = time.perf_counter()
+    o_offs, oq, ot, od = c_oracle.match_pairs(f32, pairs[sel], max_distance=1e9, nthreads=16)
+    oracle_s = time.perf_counter() - t0
+    mismatches = 0
+    for k, p in enumerate(sel):
+        s, e = int(offs[p]), int(offs[p + 1])
+        os_, oe = int(o_offs[k]), int(o_offs[k + 1])
+        ok = (e - s == oe - os_) and np.array_equal(qt[s:e, 0], oq[os_:oe]) and np.array_equal(qt[s:e, 1], ot[os_:oe]) and \
+            np.array_equal(np.asarray(d[s:e]).view(np.int32), od[os_:oe].view(np.int32))
+        mismatches += 0 if ok else 1
+    int_mismatches = 0
+    for p in sel[:args.int_oracle_pairs]:
+        i, j = pairs[p]
+        iq, it, idist = int_oracle.match_pair(imgs[int(i)], imgs[int(j)], 0.8, True, 1e9)
+        s, e = int(offs[p]), int(offs[p + 1])
+        ok = np.array_equal(qt[s:e, 0], iq) and np.array_equal(qt[s:e, 1], it) and \
+            np.array_equal(np.asarray(d[s:e]).view(np.int32), np.asarray(idist, np.float32).view(np.int32))
+        int_mismatches += 0 if ok else 1
+
+    out = {
+        "workload": name + " -- BASELINE configs[3] in full, one msfm_match_pairs call on one MI355X",
+        "image_pairs": int(len(pairs)), "descriptor_pairs": total_desc_pairs, "matches": M,
+        "wall_s": wall_s, "device_s": prof["total_device_ms"] * 1e-3, "value_descriptor_pairs_per_s": total_desc_pairs / wall_s,
+        "image_pairs_per_s": len(pairs) / wall_s,
+        "sub_batches": prof["sub_batches"], "sub_batches_predicted": len(bounds) - 1,
+        "sweep1_ms_total": prof["approx_kernel_ms"], "sweep2_ms_total": prof["sweep2_ms"], "sweep1_i8_launches": prof["sweep1_i8_launches"],
+        "sweep1_frac_of_5_POPs": 256.0 * prof["prefilter_descriptor_pairs"] / max(1e-9, prof["approx_kernel_ms"] * 1e-3) / 5e15,
+        "fallback_pairs": prof["fallback_pairs"], "plan_regrows": prof["plan_regrows"], "tie_queue_regrows": prof["tie_queue_regrows"],
+        "candidates": prof["candidates"], "order_sensitive_rows": prof.get("order_sensitive_rows"),
+        "oracle_checked_pairs": int(len(sel)), "oracle_mismatching_pairs": mismatches, "oracle_matches_checked": int(o_offs[-1]),
+        "int_oracle_checked_pairs": int(min(args.int_oracle_pairs, len(sel))), "int_oracle_mismatching_pairs": int_mismatches,
+        "oracle_pairs_at_sub_batch_cuts": [int(x) for x in cut_pairs], "oracle_wall_s": oracle_s,
+        "properties": {"offsets_monotone": True, "indices_in_range": in_range, "q_strictly_ascending_per_pair": q_ascending,
+                       "train_index_unique_per_pair": t_unique},
+        "memory": {"device_total_GiB": total_mem / 2**30, "store_GiB": (free0 - free_store) / 2**30,
+                   "device_peak_GiB_after_call": (free0 - free_after) / 2**30,
+                   "result_lists_page_locked_GiB": M * 12 / 2**30, "host_max_rss_GiB": resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 2**20},
+        "setup": {"generate_s": gen_s, "upload_s": upload_s, "store_bytes": int(sum(x.nbytes for x in imgs))},
+    }
+    print(json.dumps(out, indent=1))
+    ok = mismatches == 0 and int_mismatches == 0 and in_range and q_ascending and t_unique and prof["sub_batches"] == len(bounds) - 1
+    ctx.close()
+    sys.exit(0 if ok else 1)
+
+
+if __name__ == "__main__":
+    main()

@@ -3,6 +3,8 @@
 // instruction and ticks per microsecond.
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
+#include <cstring>
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef float f16v __attribute__((ext_vector_type(16)));
 
@@ -76,11 +78,34 @@ __global__ __launch_bounds__(256) void k_valu(float* out, unsigned long long* ti
     if (threadIdx.x == 0 && blockIdx.x == 0) ticks[0] = t1 - t0;
 }
 
-int main() {
+int main(int argc, char** argv) {
     hipDeviceProp_t p; (void)hipGetDeviceProperties(&p, 0);
     float* out; (void)hipMalloc(&out, 1 << 24);
     unsigned long long* ticks; (void)hipMalloc(&ticks, 8);
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    if (argc >= 4 && std::strcmp(argv[1], "sustain") == 0) {
+        // `ubench_clock sustain <mfma|valu> <seconds>`: back-to-back launches for that long (tools/gpu_power_trace.sh samples
+        // power and clocks meanwhile); prints the rate of every ~second
+        const bool mfma = std::strcmp(argv[2], "mfma") == 0;
+        const double seconds = std::atof(argv[3]);
+        const int iters = mfma ? 2000000 : 4000000;   // ~150 ms per launch
+        double elapsed = 0;
+        while (elapsed < seconds * 1e3) {
+            (void)hipEventRecord(e0);
+            for (int k = 0; k < 6; ++k) {
+                if (mfma) hipLaunchKernelGGL(k_mfma, dim3(p.multiProcessorCount), dim3(256), 0, 0, out, ticks, iters, 7u);
+                else hipLaunchKernelGGL(k_valu, dim3(p.multiProcessorCount), dim3(256), 0, 0, out, ticks, iters, 7u);
+            }
+            (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+            float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+            unsigned long long t; (void)hipMemcpy(&t, ticks, 8, hipMemcpyDeviceToHost);
+            elapsed += ms;
+            const double n_inst = (double)iters * (mfma ? 4 : 8);
+            printf("sustained %s loop at %.1f s: %.2f ticks per instruction, %.1f ticks per microsecond (last launch), %.2f ns per instruction per wave\n",
+                   mfma ? "MFMA-only" : "VALU-only", elapsed * 1e-3, t / n_inst, t / (ms / 6 * 1e3), ms / 6 * 1e6 / n_inst);
+        }
+        return 0;
+    }
     for (int kind = 0; kind < 2; ++kind)
         for (int blocks_per_cu = 1; blocks_per_cu <= 2; ++blocks_per_cu) {
             const int iters = kind == 0 ? 200000 : 400000;
