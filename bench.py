@@ -316,6 +316,9 @@ def main():
         "sustained_value": None if sustained is None else total_desc_pairs / sustained,
         # CRC-32 of the writer rank's (offsets, (q, t) rows) of the last step: equal across N and across exchange paths
         "exchange_checksum": result_checksum(result) if rank == 0 else None,
+        # rows / columns of this rank's pairs whose decisions are NOT certified order-invariant (msfm_fetch_order_certificate):
+        # 0 => the index lists are the same under any conforming fp32 order of OpenCV's normL2Sqr_
+        "order_sensitive_rows": int(last_prof.get("order_sensitive_rows", -1)),
         "sub_batches_per_step": acc["sub_batches"] // max(1, args.steps),
     }
     pf_ms, pf_launches = acc["approx_kernel_ms"], acc["approx_kernel_launches"]

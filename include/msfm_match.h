@@ -85,6 +85,9 @@ typedef struct msfm_profile {
     int tie_queue_regrows;     /* sub-batches re-run because the sqrt-space tie queue had to grow */
     int plan_regrows;          /* sub-batches re-run because the device-side sweep-2 plan outgrew its predicted buffers */
     int sweep1_i8_launches;     /* sweep-1 launches on the integer matrix cores (byte stores, msfm_sweep_i8.hip.h) */
+    int64_t order_sensitive_rows; /* rows / columns of the call WITHOUT an order-invariance certificate (see
+                                     msfm_fetch_order_certificate); 0 => the stored (queryIdx, trainIdx) rows are the same
+                                     under any conforming fp32 evaluation order of hal::normL2Sqr_ */
 } msfm_profile;
 
 /* ---- context ------------------------------------------------------------------------- */
@@ -140,6 +143,14 @@ int msfm_match_pair(msfm_ctx* ctx, int id1, int id2, float ratio, int cross_chec
 int msfm_match_pairs(msfm_ctx* ctx, const int32_t* pairs, int n_pairs,
                      const msfm_match_params* params, int64_t* out_offsets);
 int msfm_fetch_matches(msfm_ctx* ctx, int32_t* out_qt, float* out_dist);
+/* Order-invariance certificate of the last msfm_match_pairs / _verified call: per pair the number of query rows (and,
+ * with cross_check, train rows) for which a decision the reference makes -- which element is the first neighbour,
+ * d0 < ratio * d1, d0 <= max_distance -- has a margin below the worst-case fp32 reassociation bound of a 128-term sum
+ * of squares (relative 1e-5 on a distance, derivation in csrc/msfm_kernels.hip.h).  The reference delegates S(q,t) to an
+ * unpinned OpenCV (cv::BFMatcher::knnMatch, src/Feature/FeatureUtils.cpp:146-149) whose accumulation order depends on the
+ * build; a pair with 0 sensitive rows has the same (queryIdx, trainIdx) list under ANY such build.  Pairs of byte images
+ * are exact integers under every order (always 0).  out_sensitive_rows: n_pairs int32. */
+int msfm_fetch_order_certificate(msfm_ctx* ctx, int32_t* out_sensitive_rows);
 /* The same lists without the copy: pointers into the context's page-locked result buffers
  * (2 * count int32, count float), valid until the next matching call on this context or msfm_destroy. */
 int msfm_view_matches(msfm_ctx* ctx, const int32_t** out_qt, const float** out_dist, int64_t* out_count);

@@ -25,6 +25,7 @@ EXPORTS = [
     "msfm_match_pair", "msfm_match_pairs", "msfm_fetch_matches", "msfm_knn2_pair",
     "msfm_topscale_select", "msfm_pair_id", "msfm_pair_from_id", "msfm_swap_image_pair",
     "msfm_version", "msfm_upload_keypoints", "msfm_match_pairs_verified", "msfm_subset_image", "msfm_view_matches", "msfm_set_limits", "msfm_fetch_matches_device",
+    "msfm_fetch_order_certificate",
 ]
 
 
@@ -46,7 +47,7 @@ class Profile(C.Structure):
                 ("sweep2_ms", C.c_double), ("sweep2_launches", C.c_int), ("compacted_pairs", C.c_int),
                 ("sweep2_descriptor_pairs", C.c_int64), ("verify_ms", C.c_double),
                 ("sub_batches", C.c_int), ("tie_queue_regrows", C.c_int), ("plan_regrows", C.c_int),
-                ("sweep1_i8_launches", C.c_int)]
+                ("sweep1_i8_launches", C.c_int), ("order_sensitive_rows", C.c_int64)]
 
 
 class MsfmError(RuntimeError):
@@ -88,6 +89,7 @@ def load():
     L.msfm_fetch_matches.argtypes = [vp, ip, fp]
     L.msfm_view_matches.argtypes = [vp, C.POINTER(ip), C.POINTER(fp), C.POINTER(C.c_int64)]
     L.msfm_fetch_matches_device.argtypes = [vp, vp, vp]
+    L.msfm_fetch_order_certificate.argtypes = [vp, ip]
     L.msfm_upload_keypoints.argtypes = [vp, C.c_int, fp, C.c_int, C.c_int]
     L.msfm_match_pairs_verified.argtypes = [vp, ip, C.c_int, C.POINTER(MatchParams), C.POINTER(VerifyParams),
                                             C.POINTER(C.c_int64)]
@@ -240,6 +242,13 @@ class Context:
         """Copy the last call's lists into caller-owned DEVICE memory on this context's GPU (raw pointers, e.g.
         torch.Tensor.data_ptr() of an int32 [M, 2] / float32 [M] tensor; None skips one)."""
         self._chk(self._L.msfm_fetch_matches_device(self._h, C.c_void_p(qt_ptr or 0), C.c_void_p(dist_ptr or 0)))
+
+    def order_certificate(self, n_pairs):
+        """Per pair of the last match_pairs call: rows / columns whose decisions are within the fp32 reassociation bound
+        of flipping under another accumulation order (0 everywhere: the index lists are order-invariant)."""
+        out = np.zeros(max(int(n_pairs), 1), np.int32)
+        self._chk(self._L.msfm_fetch_order_certificate(self._h, _ip(out)))
+        return out[:int(n_pairs)]
 
     def upload_keypoints(self, image_id, kpts):
         """kpts: n x k float32 (k >= 2), x and y in the first two columns."""

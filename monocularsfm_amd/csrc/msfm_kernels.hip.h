@@ -77,6 +77,7 @@ struct PairDesc {
     int valid;             // 0: a side is empty -> no neighbours, no device work
     int path;              // 0: brute-force exact kernel, 1: MFMA prefilter + exact re-check
     int a_blocks256;       // 256-row A blocks (prefilter work items)
+    int exact_int;         // both images were uploaded as bytes: S is an exact integer under ANY accumulation order
     long long rp_off;      // row partials  [ranges][n1pad]
     long long cp_off;      // column partials [a_blocks][n2pad]
     long long kf_off;      // final forward knn arrays [n1pad]
@@ -528,28 +529,69 @@ struct EpiParams {
     double max_distance;
 };
 
+// ---- order-invariance certificate ------------------------------------------------------------------------------
+// The database stores (queryIdx, trainIdx) only.  Which rows could come out differently under ANOTHER conforming fp32
+// evaluation order of hal::normL2Sqr_ (a different OpenCV build: other SIMD width, other reduction tree, FMA or not)?
+//
+// Bound.  S = sum of 128 non-negative terms (a_c - b_c)^2.  In fp32 (u = 2^-24) each term carries the rounding of the
+// difference (twice, it is squared) and of the product (none if fused), and passes through at most 127 additions in any
+// association: |S^ - S| <= gamma_130 S, gamma_k = k u / (1 - k u) = 7.75e-6 (Higham, Accuracy and Stability, 4.2 / 3.1;
+// valid for every order because all terms are >= 0).  d = sqrtf(S^) adds one rounding: d in sqrt(S) (1 +- (gamma/2 + u)).
+// Two conforming builds therefore differ by at most a relative kOrderEps = 1e-5 > gamma_130 + 2 u + the rounding of
+// fl(ratio * d1) in any distance they report.
+//
+// What this path knows per row: (i0, d0, d1) in the pinned order, and that every other element j has S^_j >= S^_1
+// (brute force: by selection; prefilter: non-candidates are provably worse than the true second neighbour).  Hence under
+// any other order B:  d0_B >= d0 (1 - e),  d1_B <= d1 (1 + e)  always, and if d0 (1 + e) < d1 (1 - e) the first
+// neighbour is the same element with d0_B <= d0 (1 + e), d1_B >= d1 (1 - e) -- and no tie in sqrt space can hand the
+// index to a lower-numbered element.  A row is CERTIFIED when the reference's decisions are the same on the whole
+// interval:
+//     passes the ratio test:  d0 (1+e) < ratio d1 (1-e)  and  d0 (1+e) < d1 (1-e)  and the distance cut does not
+//                             straddle max_distance (forward direction only: FilterMatchesByDistance sees forward d0);
+//     fails it:               d0 (1-e) >= ratio d1 (1+e)   (whichever element is first: it yields no match);
+//     beyond the cut:         d0 (1-e) > max_distance      (forward: no match whatever the ratio test says).
+// Rows pruned by the prefilter are dead with a margin of eps >= 1.5e-3 (na + nb) >> gamma S (msfm_prefilter.hip.h).
+// Pairs of byte images are exact integers under every order.  Rows that are not certified are "order-sensitive";
+// zero of them in a call <=> the stored rows are identical under any conforming normL2Sqr_ build.
+constexpr double kOrderEps = 1.0e-5;
+
+__device__ __forceinline__ bool order_sensitive(int i0, float d0, float d1, float ratio, double max_distance, bool forward) {
+    if (i0 < 0 || !(d1 < 3.402823466e+38f)) return false;   // no match under any order (pruned with margin / < 2 neighbours)
+    const double lo0 = (double)d0 * (1.0 - kOrderEps), hi0 = (double)d0 * (1.0 + kOrderEps);
+    const double lo1 = (double)d1 * (1.0 - kOrderEps), hi1 = (double)d1 * (1.0 + kOrderEps);
+    if (forward && lo0 > max_distance) return false;        // cut by FilterMatchesByDistance whatever the ratio test says
+    const bool pass = d0 < ratio * d1;
+    bool certified;
+    if (pass)
+        certified = hi0 < (double)ratio * lo1 && hi0 < lo1 && (!forward || hi0 <= max_distance || lo0 > max_distance);
+    else
+        certified = lo0 >= (double)ratio * hi1;
+    return !certified;
+}
+
 __global__ __launch_bounds__(256) void epilogue_kernel(const PairDesc* __restrict__ pairs, EpiParams prm,
                                                        const int* __restrict__ k_i0,
                                                        const float* __restrict__ k_d0,
                                                        const float* __restrict__ k_d1,
                                                        int2* __restrict__ st_qt, float* __restrict__ st_d,
-                                                       int* __restrict__ counts) {
+                                                       int* __restrict__ counts, int* __restrict__ sens_counts) {
     const PairDesc pd = pairs[blockIdx.x];
     __shared__ int wsum[4];
-    __shared__ int running;
-    if (threadIdx.x == 0) running = 0;
+    __shared__ int running, n_sens;
+    if (threadIdx.x == 0) { running = 0; n_sens = 0; }
     __syncthreads();
     // The reference indexes m[1] unconditionally (FeatureUtils.cpp:152): a direction whose train
     // set has < 2 rows is undefined there.  Build-defined: that direction yields no matches, and a
     // cross-checked pair with such a direction yields none at all.
     if (!pd.valid || pd.n2 < 2 || (prm.cross_check && pd.n1 < 2)) {
-        if (threadIdx.x == 0) counts[blockIdx.x] = 0;
+        if (threadIdx.x == 0) { counts[blockIdx.x] = 0; sens_counts[blockIdx.x] = 0; }
         return;
     }
+    const bool certify = !pd.exact_int;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int q0 = 0; q0 < pd.n1; q0 += 256) {
         const int q = q0 + threadIdx.x;
-        bool keep = false;
+        bool keep = false, sens = false;
         int t = -1;
         float d0 = 0.f;
         if (q < pd.n1) {
@@ -558,6 +600,7 @@ __global__ __launch_bounds__(256) void epilogue_kernel(const PairDesc* __restric
             const float d1 = k_d1[pd.kf_off + q];
             // m[0].distance < distance_ratio * m[1].distance, fp32 product, strict
             keep = (t >= 0) && (d1 < 3.402823466e+38f) && (d0 < prm.ratio * d1);
+            sens = certify && order_sensitive(t, d0, d1, prm.ratio, prm.max_distance, true);
             if (keep && prm.cross_check) {
                 const int rq = k_i0[pd.kr_off + t];
                 const float rd0 = k_d0[pd.kr_off + t];
@@ -568,6 +611,8 @@ __global__ __launch_bounds__(256) void epilogue_kernel(const PairDesc* __restric
             }
             if (keep && ((double)d0 > prm.max_distance)) keep = false;
         }
+        const unsigned long long sb = __ballot(sens);
+        if (lane == 0 && sb) atomicAdd(&n_sens, __popcll(sb));
         const unsigned long long bal = __ballot(keep);
         const int before = __popcll(bal & ((1ull << lane) - 1ull));
         if (lane == 0) wsum[wave] = __popcll(bal);
@@ -582,7 +627,16 @@ __global__ __launch_bounds__(256) void epilogue_kernel(const PairDesc* __restric
         if (threadIdx.x == 0) running += wsum[0] + wsum[1] + wsum[2] + wsum[3];
         __syncthreads();
     }
-    if (threadIdx.x == 0) counts[blockIdx.x] = running;
+    // the reverse rows decide the cross-check
+    if (certify && prm.cross_check)
+        for (int t0 = 0; t0 < pd.n2; t0 += 256) {
+            const int t = t0 + threadIdx.x;
+            const bool s = t < pd.n2 && order_sensitive(k_i0[pd.kr_off + t], k_d0[pd.kr_off + t], k_d1[pd.kr_off + t], prm.ratio, prm.max_distance, false);
+            const unsigned long long sb = __ballot(s);
+            if (lane == 0 && sb) atomicAdd(&n_sens, __popcll(sb));
+        }
+    __syncthreads();
+    if (threadIdx.x == 0) { counts[blockIdx.x] = running; sens_counts[blockIdx.x] = n_sens; }
 }
 
 // exclusive scan of per-pair counts (single workgroup; P is at most a few thousand per batch)

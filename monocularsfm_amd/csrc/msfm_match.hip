@@ -107,6 +107,7 @@ struct Image {
     // byte stores (MSFM_DTYPE_U8 uploads and their subsets): signed operand rows of 144 B for the integer matrix cores
     // and the float "norms" 2 floor(|x - 128|^2 / 2) (msfm_sweep_i8.hip.h)
     bool is_u8 = false;
+    bool from_u8 = false;     // uploaded as MSFM_DTYPE_U8 (or a subset of such an image): integer values 0..255
     signed char* i8 = nullptr;
     float* nrm_i8 = nullptr;
     float nrm_i8_max = 0.f;
@@ -147,7 +148,7 @@ struct msfm_ctx {
     DevBuf d_pairs, d_items, d_item_base, d_stage;
     DevBuf d_rp_s0, d_rp_i0, d_rp_s1, d_cp_s0, d_cp_i0, d_cp_s1;
     DevBuf d_k_i0, d_k_d0, d_k_d1;
-    DevBuf d_st_qt, d_st_d, d_counts, d_offsets, d_out_qt, d_out_d;
+    DevBuf d_st_qt, d_st_d, d_counts, d_offsets, d_out_qt, d_out_d, d_sens;
     DevBuf d_fix_count, d_fix_list;
     int fix_cap = 1 << 16;            // entries of the sqrt-space tie queue; grows on overflow (the sub-batch is re-run)
     int fix_cap_eff = 0;              // capacity handed to the kernels of the current batch (0: ties need no fix-up)
@@ -178,6 +179,7 @@ struct msfm_ctx {
     // results of the last msfm_match_pairs call
     bool have_results = false;
     std::vector<int64_t> res_offsets;
+    std::vector<int32_t> res_sens;   // per pair: rows / columns without an order-invariance certificate
     PinnedBuf res_qt, res_dist;  // (q, t) int32 pairs and distances of res_count matches
     size_t res_count = 0;
 
@@ -305,6 +307,7 @@ int fill_pair(msfm_ctx* ctx, int id1, int id2, PairDesc& pd, PfPair& pp) {
     pd.ranges = 1;
     // empty query or train set: knnMatch returns nothing, no device work
     pd.valid = (a.n >= 1 && b.n >= 1) ? 1 : 0;
+    pd.exact_int = (a.from_u8 && b.from_u8) ? 1 : 0;
     pp = PfPair{};
     pp.a_h = a.h16;
     pp.b_h = b.h16;
@@ -1088,7 +1091,7 @@ void msfm_destroy(msfm_ctx* ctx) {
     for (auto& im : ctx->images) free_image(im);
     DevBuf* bufs[] = {&ctx->d_pairs, &ctx->d_items, &ctx->d_item_base, &ctx->d_stage, &ctx->d_rp_s0, &ctx->d_rp_i0, &ctx->d_rp_s1,
                       &ctx->d_cp_s0, &ctx->d_cp_i0, &ctx->d_cp_s1, &ctx->d_k_i0, &ctx->d_k_d0, &ctx->d_k_d1,
-                      &ctx->d_st_qt, &ctx->d_st_d, &ctx->d_counts, &ctx->d_offsets, &ctx->d_out_qt,
+                      &ctx->d_st_qt, &ctx->d_st_d, &ctx->d_counts, &ctx->d_offsets, &ctx->d_sens, &ctx->d_out_qt,
                       &ctx->d_out_d, &ctx->d_fix_count, &ctx->d_fix_list, &ctx->d_pf, &ctx->d_tu, &ctx->d_tv,
                       &ctx->d_cand, &ctx->d_cand_s, &ctx->d_cand_count, &ctx->d_best, &ctx->d_second, &ctx->d_maxima,
                       &ctx->d_zero_row, &ctx->d_cmp_tu, &ctx->d_live_idx, &ctx->d_vpairs, &ctx->d_vpf, &ctx->d_row_src, &ctx->d_colmask, &ctx->d_groups, &ctx->d_gmembers, &ctx->d_member_pair, &ctx->d_member_group, &ctx->d_gtot, &ctx->d_grow0, &ctx->d_ppair, &ctx->d_cnt, &ctx->d_mrow, &ctx->d_summary, &ctx->d_overflow, &ctx->d_totals,
@@ -1171,6 +1174,7 @@ static int alloc_image(msfm_ctx* ctx, Image& im, int n) {
 static int build_image(msfm_ctx* ctx, Image& im, const unsigned char* src8, bool is_u8) {
     const int n = im.n;
     im.is_u8 = is_u8;
+    im.from_u8 = is_u8;
     const int blocks = std::min(4096, im.nalloc * 16);
     if (!src8) {
         if (ctx->order == MSFM_ORDER_SSE4X4)
@@ -1332,6 +1336,7 @@ static int match_pairs_impl(msfm_ctx* ctx, const int32_t* pairs, int n_pairs, co
     ctx->have_results = false;
     ctx->pf_pending = msfm_ctx::PfPending{};
     ctx->res_offsets.assign((size_t)n_pairs + 1, 0);
+    ctx->res_sens.assign((size_t)n_pairs, 0);
     ctx->res_count = 0;
     ctx->prof = msfm_profile{};
 
@@ -1406,11 +1411,12 @@ static int match_pairs_impl(msfm_ctx* ctx, const int32_t* pairs, int n_pairs, co
         HIPCHK(ctx, ctx->d_out_qt.ensure_keep((base + (size_t)std::max<long long>(1, b.out_elems)) * sizeof(int2), base * sizeof(int2), ctx->stream));
         HIPCHK(ctx, ctx->d_out_d.ensure_keep((base + (size_t)std::max<long long>(1, b.out_elems)) * 4, base * 4, ctx->stream));
         HIPCHK(ctx, ctx->d_counts.ensure(P * 4));
+        HIPCHK(ctx, ctx->d_sens.ensure(P * 4));
         HIPCHK(ctx, ctx->d_offsets.ensure((P + 1) * 8));
         EpiParams ep = {prm.ratio, prm.cross_check, prm.max_distance};
         hipLaunchKernelGGL(epilogue_kernel, dim3((unsigned)P), dim3(256), 0, ctx->stream, ctx->d_pairs.as<PairDesc>(), ep,
                            ctx->d_k_i0.as<int>(), ctx->d_k_d0.as<float>(), ctx->d_k_d1.as<float>(),
-                           ctx->d_st_qt.as<int2>(), ctx->d_st_d.as<float>(), ctx->d_counts.as<int>());
+                           ctx->d_st_qt.as<int2>(), ctx->d_st_d.as<float>(), ctx->d_counts.as<int>(), ctx->d_sens.as<int>());
         HIPCHK(ctx, hipGetLastError());
         const int* d_counts = ctx->d_counts.as<int>();
         const int2* d_st_qt = ctx->d_st_qt.as<int2>();
@@ -1471,6 +1477,7 @@ static int match_pairs_impl(msfm_ctx* ctx, const int32_t* pairs, int n_pairs, co
 
         std::vector<long long> offs(P + 1);
         HIPCHK(ctx, hipMemcpyAsync(offs.data(), ctx->d_offsets.p, (P + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(ctx->res_sens.data() + begin, ctx->d_sens.p, P * 4, hipMemcpyDeviceToHost, ctx->stream));
         bool retry = false, retry_pf = false;
         rc = check_fix_overflow(ctx, &retry);  // synchronises the stream
         if (rc != MSFM_OK) return rc;
@@ -1490,6 +1497,7 @@ static int match_pairs_impl(msfm_ctx* ctx, const int32_t* pairs, int n_pairs, co
             HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         }
         for (size_t p = 0; p < P; ++p) ctx->res_offsets[(size_t)begin + p + 1] = (int64_t)base + offs[p + 1];
+        for (size_t p = 0; p < P; ++p) ctx->prof.order_sensitive_rows += ctx->res_sens[(size_t)begin + p];
         rc = accumulate_kernel_time(ctx, ev_base, exact_launched);
         if (rc != MSFM_OK) return rc;
         if (verify) {
@@ -1563,6 +1571,13 @@ int msfm_fetch_matches_device(msfm_ctx* ctx, int32_t* d_out_qt, float* d_out_dis
     if (d_out_dist && ctx->res_count)
         HIPCHK(ctx, hipMemcpyAsync(d_out_dist, ctx->d_out_d.p, ctx->res_count * 4, hipMemcpyDeviceToDevice, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return MSFM_OK;
+}
+
+int msfm_fetch_order_certificate(msfm_ctx* ctx, int32_t* out_sensitive_rows) {
+    if (!ctx) return MSFM_E_INVALID;
+    if (!ctx->have_results) return fail(ctx, MSFM_E_STATE, "msfm_fetch_order_certificate without a completed msfm_match_pairs");
+    if (out_sensitive_rows && !ctx->res_sens.empty()) std::memcpy(out_sensitive_rows, ctx->res_sens.data(), ctx->res_sens.size() * 4);
     return MSFM_OK;
 }
 
