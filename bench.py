@@ -320,6 +320,9 @@ def main():
         # 0 => the index lists are the same under any conforming fp32 order of OpenCV's normL2Sqr_
         "order_sensitive_rows": int(last_prof.get("order_sensitive_rows", -1)),
         "sub_batches_per_step": acc["sub_batches"] // max(1, args.steps),
+        # the step is cut into sub-batches launched alternately on two streams: the bandwidth-bound tail of one runs
+        # under the next one's sweep 1 (msfm_set_pipeline / MSFM_PIPELINE; 1 = one launch per sweep, no overlap)
+        "pipeline_env": os.environ.get("MSFM_PIPELINE"),
     }
     pf_ms, pf_launches = acc["approx_kernel_ms"], acc["approx_kernel_launches"]
     if pf_launches > 0:

@@ -103,11 +103,16 @@ int msfm_set_accum_order(msfm_ctx* ctx, int order);
 int msfm_set_prefilter(msfm_ctx* ctx, int enable);
 int msfm_get_profile(const msfm_ctx* ctx, msfm_profile* out);
 /* msfm_match_pairs cuts a call into device sub-batches of at most `max_pairs_per_batch` image pairs and
- * `scratch_bytes` of partial-result scratch (defaults 16384 pairs / 48 GiB; also MSFM_MAX_PAIRS_PER_BATCH and
+ * `scratch_bytes` of partial-result scratch (defaults 16384 pairs / 48 GiB -- shared by the two scratch sets of the pipeline; also MSFM_MAX_PAIRS_PER_BATCH and
  * MSFM_SCRATCH_MIB in the environment at msfm_create).  Results do not depend on the cut (tests force small limits
  * to cross it); a value <= 0 restores that default.  The reference's counterpart is the 100-pair flush of
  * BruteFeatureMatcher::RunMatching (src/Feature/FeatureMatching.cpp:118-139, max_pairs_size_). */
 int msfm_set_limits(msfm_ctx* ctx, int max_pairs_per_batch, int64_t scratch_bytes);
+/* A call of enough work (>= 1.5e10 descriptor pairs per part) is cut into at least `min_sub_batches` sub-batches, launched
+ * alternately on two streams / scratch sets: the bandwidth-bound tail of one (thresholds, sweep-2 plan, exact re-check,
+ * epilogue, copy-out) runs while the next one's sweep 1 owns the matrix cores.  Default 4; 1 = one sub-batch where memory
+ * allows (no overlap); <= 0 restores the default.  Env: MSFM_PIPELINE.  Results do not depend on it. */
+int msfm_set_pipeline(msfm_ctx* ctx, int min_sub_batches);
 
 /* ---- descriptor store -------------------------------------------------------------------
  * Replaces the per-pair Database::ReadDescriptors calls of MatchImagePairs

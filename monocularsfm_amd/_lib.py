@@ -25,7 +25,7 @@ EXPORTS = [
     "msfm_match_pair", "msfm_match_pairs", "msfm_fetch_matches", "msfm_knn2_pair",
     "msfm_topscale_select", "msfm_pair_id", "msfm_pair_from_id", "msfm_swap_image_pair",
     "msfm_version", "msfm_upload_keypoints", "msfm_match_pairs_verified", "msfm_subset_image", "msfm_view_matches", "msfm_set_limits", "msfm_fetch_matches_device",
-    "msfm_fetch_order_certificate",
+    "msfm_fetch_order_certificate", "msfm_set_pipeline",
 ]
 
 
@@ -80,6 +80,7 @@ def load():
     L.msfm_set_prefilter.argtypes = [vp, C.c_int]
     L.msfm_get_profile.argtypes = [vp, C.POINTER(Profile)]
     L.msfm_set_limits.argtypes = [vp, C.c_int, C.c_int64]
+    L.msfm_set_pipeline.argtypes = [vp, C.c_int]
     L.msfm_upload_image.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int]
     L.msfm_image_rows.argtypes = [vp, C.c_int, C.POINTER(C.c_int)]
     L.msfm_subset_image.argtypes = [vp, C.c_int, C.c_int, ip, C.c_int]
@@ -165,6 +166,11 @@ class Context:
     def set_limits(self, max_pairs_per_batch=0, scratch_bytes=0):
         """Sub-batch limits of match_pairs (<= 0: default).  Results do not depend on them."""
         self._chk(self._L.msfm_set_limits(self._h, int(max_pairs_per_batch), int(scratch_bytes)))
+
+    def set_pipeline(self, min_sub_batches=0):
+        """A large call is cut into at least this many sub-batches whose tails overlap the next one's sweep 1 (<= 0:
+        default 4; 1: off).  Results do not depend on it."""
+        self._chk(self._L.msfm_set_pipeline(self._h, int(min_sub_batches)))
 
     def profile(self):
         p = Profile()

@@ -40,9 +40,9 @@ struct DevBuf {
         return e;
     }
     // grow and keep the first `keep` bytes (the match lists of a call accumulate over its sub-batches)
-    hipError_t ensure_keep(size_t bytes, size_t keep, hipStream_t stream) {
+    hipError_t ensure_keep(size_t bytes, size_t keep, hipStream_t stream, size_t hint = 0) {
         if (bytes <= cap) return hipSuccess;
-        const size_t want = bytes + bytes / 2 + 4096;
+        const size_t want = std::max(bytes + bytes / 2 + 4096, hint);
         void* q = nullptr;
         hipError_t e = hipMalloc(&q, want);
         if (e != hipSuccess) return e;
@@ -71,9 +71,9 @@ struct DevBuf {
 struct PinnedBuf {
     void* p = nullptr;
     size_t cap = 0;
-    hipError_t ensure(size_t bytes, size_t keep) {
+    hipError_t ensure(size_t bytes, size_t keep, size_t hint = 0) {
         if (bytes <= cap) return hipSuccess;
-        size_t want = bytes + bytes / 2 + 4096;
+        size_t want = std::max(bytes + bytes / 2 + 4096, hint);
         void* q = nullptr;
         hipError_t e = hipHostMalloc(&q, want, hipHostMallocDefault);
         if (e != hipSuccess) return e;
@@ -133,48 +133,84 @@ constexpr int kSlots = 2 * MSFM_MAX_IMAGES + 2;  // ids >= MSFM_MAX_IMAGES: auxi
 constexpr long long kDefaultScratchElems = (long long)12 << 30;
 constexpr int kDefaultMaxPairsPerBatch = 16384;
 constexpr int kMaxPairsPerBatchLimit = 65535;   // gridDim.y
+// A call large enough is cut into at least this many sub-batches so that the bandwidth-bound tail of one (thresholds, plan,
+// exact re-check, epilogue, copy-out) runs under the next one's sweep 1; every sub-batch keeps >= kMinPipelineCost
+// descriptor pairs (a few ms of sweep 1) so that the fixed costs of a sub-batch stay small.
+constexpr int kDefaultPipeline = 4;
+constexpr long long kMinPipelineCost = 15000000000LL;
 
 }  // namespace
 
+// Everything ONE device sub-batch in flight owns: its stream, the partial / plan / candidate / result scratch, the
+// page-locked words the host reads at the end of the sub-batch, its share of the profile.  A context has two: while the
+// tail of sub-batch k (thresholds, plan, sweep 2, exact re-check, epilogue, copy-out) runs on one stream, sweep 1 of
+// sub-batch k + 1 already owns the matrix pipes on the other (match_pairs_impl).
+struct PfPending {                // what the end-of-batch synchronisation has to look at
+    bool active = false, compact = false, i8 = false;
+    size_t n_lists = 0, P = 0;
+    long long rows_cap = 0, cand_cap = 0, items_cap = 0;
+    int compact_pairs = 0;
+    long long dense_swept = 0;
+    size_t ev_base = 0;
+};
+
+struct Scratch {
+    hipStream_t stream = nullptr;
+    DevBuf d_pairs, d_items, d_item_base;
+    DevBuf d_rp_s0, d_rp_i0, d_rp_s1, d_cp_s0, d_cp_i0, d_cp_s1;
+    DevBuf d_k_i0, d_k_d0, d_k_d1;
+    DevBuf d_st_qt, d_st_d, d_counts, d_offsets, d_sens;
+    DevBuf d_sub_qt, d_sub_d;         // the sub-batch's match lists, compact (CSR order), before they join the call's lists
+    DevBuf d_fix_count, d_fix_list;
+    int fix_cap_eff = 0;              // capacity handed to the kernels of the current batch (0: ties need no fix-up)
+    // prefilter path
+    DevBuf d_pf, d_tu, d_tv, d_cand, d_cand_s, d_cand_count, d_best, d_second;
+    DevBuf d_cmp_tu, d_live_idx, d_row_pair, d_row_src, d_cand_pair, d_vpairs, d_vpf, d_vitems, d_lists;
+    // device-side plan of the compacted sweep 2 (msfm_plan.hip.h)
+    DevBuf d_colmask, d_groups, d_gmembers, d_member_pair, d_member_group, d_gtot, d_grow0, d_ppair, d_cnt, d_mrow, d_summary, d_overflow, d_totals;
+    PfPending pf_pending;
+    PinnedBuf h_summary;              // PlanSummary | totals[2] | overflow bytes
+    PinnedBuf h_tail;                 // tie-queue count | CSR offsets [P + 1] | certificate counts [P]: read at the end of the sub-batch
+    // geometric verification
+    DevBuf d_vf_pairs, d_vf_x1, d_vf_y1, d_vf_x2, d_vf_y2, d_vf_hyp, d_vf_best_it, d_vf_best_count, d_vf_flags,
+        d_st2_qt, d_st2_d, d_counts2;
+    msfm_profile prof = {};           // this sub-batch's share; joins the call's profile when the sub-batch is accepted
+    hipEvent_t sweep1_done = nullptr; // recorded behind sweep 1: the other stream's next sweep 1 waits for it
+    bool sweep1_recorded = false;
+    void release_all() {
+        DevBuf* bufs[] = {&d_pairs, &d_items, &d_item_base, &d_rp_s0, &d_rp_i0, &d_rp_s1, &d_cp_s0, &d_cp_i0, &d_cp_s1, &d_k_i0, &d_k_d0,
+                          &d_k_d1, &d_st_qt, &d_st_d, &d_counts, &d_offsets, &d_sens, &d_sub_qt, &d_sub_d, &d_fix_count, &d_fix_list, &d_pf, &d_tu,
+                          &d_tv, &d_cand, &d_cand_s, &d_cand_count, &d_best, &d_second, &d_cmp_tu, &d_live_idx, &d_row_pair, &d_row_src,
+                          &d_cand_pair, &d_vpairs, &d_vpf, &d_vitems, &d_lists, &d_colmask, &d_groups, &d_gmembers, &d_member_pair,
+                          &d_member_group, &d_gtot, &d_grow0, &d_ppair, &d_cnt, &d_mrow, &d_summary, &d_overflow, &d_totals, &d_vf_pairs,
+                          &d_vf_x1, &d_vf_y1, &d_vf_x2, &d_vf_y2, &d_vf_hyp, &d_vf_best_it, &d_vf_best_count, &d_vf_flags, &d_st2_qt,
+                          &d_st2_d, &d_counts2};
+        for (DevBuf* b : bufs) b->release();
+        h_summary.release();
+        h_tail.release();
+    }
+};
+
 struct msfm_ctx {
     int device = 0;
-    hipStream_t stream = nullptr;
     int order = MSFM_ORDER_SSE4X4;
     int cu_count = 0, clock_mhz = 0;
     char dev_name[256] = {0};
     std::vector<Image> images;
     std::string err;
 
-    DevBuf d_pairs, d_items, d_item_base, d_stage;
-    DevBuf d_rp_s0, d_rp_i0, d_rp_s1, d_cp_s0, d_cp_i0, d_cp_s1;
-    DevBuf d_k_i0, d_k_d0, d_k_d1;
-    DevBuf d_st_qt, d_st_d, d_counts, d_offsets, d_out_qt, d_out_d, d_sens;
-    DevBuf d_fix_count, d_fix_list;
+    Scratch sc[2];
+    Scratch* cur = &sc[0];            // the scratch set (and stream) the batch functions work on
+    DevBuf d_stage, d_maxima, d_zero_row;   // upload staging, upload-time maxima, the all-zero operand row
+    DevBuf d_out_qt, d_out_d;         // the match lists of the whole call (msfm_fetch_matches_device)
     int fix_cap = 1 << 16;            // entries of the sqrt-space tie queue; grows on overflow (the sub-batch is re-run)
-    int fix_cap_eff = 0;              // capacity handed to the kernels of the current batch (0: ties need no fix-up)
     // sub-batch limits of msfm_match_pairs (msfm_set_limits / MSFM_MAX_PAIRS_PER_BATCH / MSFM_SCRATCH_MIB)
     int max_pairs_per_batch = kDefaultMaxPairsPerBatch;
     long long scratch_elems = kDefaultScratchElems;
-    // prefilter path
+    int pipeline = kDefaultPipeline;  // sub-batches a large call is cut into at least, so that tails overlap sweeps (1: off)
     int prefilter = 1;                // 0: brute force only; 1: MFMA prefilter, integer matrix cores for byte stores; 2: fp16 MFMA only
-    DevBuf d_pf, d_tu, d_tv, d_cand, d_cand_s, d_cand_count, d_best, d_second, d_maxima;
-    DevBuf d_zero_row, d_cmp_tu, d_live_idx, d_row_pair, d_row_src, d_cand_pair, d_vpairs, d_vpf, d_vitems, d_lists;
-    // device-side plan of the compacted sweep 2 (msfm_plan.hip.h)
-    DevBuf d_colmask, d_groups, d_gmembers, d_member_pair, d_member_group, d_gtot, d_grow0, d_ppair, d_cnt, d_mrow, d_summary, d_overflow, d_totals;
     long long cmp_rows_hint = 0;      // compacted rows the previous batch needed (sizes the next batch's buffers)
     long long items_hint = 0, cand_hint = 0;   // likewise: work items, candidate-list capacity
-    struct PfPending {                // what the end-of-batch synchronisation has to look at
-        bool active = false, compact = false, i8 = false;
-        size_t n_lists = 0, P = 0;
-        long long rows_cap = 0, cand_cap = 0, items_cap = 0;
-        int compact_pairs = 0;
-        long long dense_swept = 0;
-        size_t ev_base = 0;
-    } pf_pending;
-    PinnedBuf h_summary;              // PlanSummary | totals[2] | overflow bytes
-    // geometric verification
-    DevBuf d_vf_pairs, d_vf_x1, d_vf_y1, d_vf_x2, d_vf_y2, d_vf_hyp, d_vf_best_it, d_vf_best_count, d_vf_flags,
-        d_st2_qt, d_st2_d, d_counts2;
 
     // results of the last msfm_match_pairs call
     bool have_results = false;
@@ -186,6 +222,8 @@ struct msfm_ctx {
     msfm_profile prof = {};
     std::vector<hipEvent_t> ev_pool;
 };
+
+#define SC (*ctx->cur)
 
 namespace {
 
@@ -222,7 +260,7 @@ struct HostClock {
         static const bool on__ = std::getenv("MSFM_DEBUG_SYNC") != nullptr;       \
         if (on__) {                                                               \
             std::fprintf(stderr, "[msfm] %s ...", name);                          \
-            hipError_t e__ = hipStreamSynchronize((ctx)->stream);                 \
+            hipError_t e__ = hipStreamSynchronize((ctx)->cur->stream);                \
             std::fprintf(stderr, " %s\n", hipGetErrorString(e__));                \
         }                                                                         \
     } while (0)
@@ -378,22 +416,22 @@ hipEvent_t get_event(msfm_ctx* ctx, size_t i) {
 
 int upload_pairs(msfm_ctx* ctx, Batch& b) {
     const size_t P = b.pairs.size();
-    HIPCHK(ctx, ctx->d_pairs.ensure(P * sizeof(PairDesc)));
-    HIPCHK(ctx, ctx->d_pf.ensure(P * sizeof(PfPair)));
-    HIPCHK(ctx, hipMemcpyAsync(ctx->d_pairs.p, b.pairs.data(), P * sizeof(PairDesc), hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(ctx->d_pf.p, b.pf.data(), P * sizeof(PfPair), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, SC.d_pairs.ensure(P * sizeof(PairDesc)));
+    HIPCHK(ctx, SC.d_pf.ensure(P * sizeof(PfPair)));
+    HIPCHK(ctx, hipMemcpyAsync(SC.d_pairs.p, b.pairs.data(), P * sizeof(PairDesc), hipMemcpyHostToDevice, SC.stream));
+    HIPCHK(ctx, hipMemcpyAsync(SC.d_pf.p, b.pf.data(), P * sizeof(PfPair), hipMemcpyHostToDevice, SC.stream));
     return MSFM_OK;
 }
 
 int upload_items(msfm_ctx* ctx, Batch& b, int path) {
     const size_t P = b.pairs.size();
-    HIPCHK(ctx, ctx->d_items.ensure(std::max<size_t>(1, b.n_items) * sizeof(WorkItem)));
+    HIPCHK(ctx, SC.d_items.ensure(std::max<size_t>(1, b.n_items) * sizeof(WorkItem)));
     if (b.n_items == 0) return MSFM_OK;
-    HIPCHK(ctx, ctx->d_item_base.ensure(P * 4));
-    HIPCHK(ctx, hipMemsetAsync(ctx->d_items.p, 0xff, b.n_items * sizeof(WorkItem), ctx->stream));   // pair = -1: padding item
-    HIPCHK(ctx, hipMemcpyAsync(ctx->d_item_base.p, b.item_base.data(), P * 4, hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(build_items_kernel, dim3((unsigned)P), dim3(64), 0, ctx->stream, (const PairDesc*)ctx->d_pairs.as<PairDesc>(),
-                       (const int*)ctx->d_item_base.as<int>(), path, (int)b.items_per_xcd, ctx->d_items.as<WorkItem>());
+    HIPCHK(ctx, SC.d_item_base.ensure(P * 4));
+    HIPCHK(ctx, hipMemsetAsync(SC.d_items.p, 0xff, b.n_items * sizeof(WorkItem), SC.stream));   // pair = -1: padding item
+    HIPCHK(ctx, hipMemcpyAsync(SC.d_item_base.p, b.item_base.data(), P * 4, hipMemcpyHostToDevice, SC.stream));
+    hipLaunchKernelGGL(build_items_kernel, dim3((unsigned)P), dim3(64), 0, SC.stream, (const PairDesc*)SC.d_pairs.as<PairDesc>(),
+                       (const int*)SC.d_item_base.as<int>(), path, (int)b.items_per_xcd, SC.d_items.as<WorkItem>());
     HIPCHK(ctx, hipGetLastError());
     return MSFM_OK;
 }
@@ -514,7 +552,7 @@ void build_compact_plan(msfm_ctx* ctx, const Batch& b, CompactPlan& cp) {
 }
 
 // MFMA prefilter + exact re-check for the pairs on path 1, WITHOUT a host synchronisation: the caller looks at
-// ctx->pf_pending at the end of the batch (finish_prefilter) and re-runs the batch if a capacity was exceeded or a
+// SC.pf_pending at the end of the batch (finish_prefilter) and re-runs the batch if a capacity was exceeded or a
 // candidate list overflowed.
 //   sweep 1 (sweep_kernel<1>): S~ minima per row / column -> thresholds (with pruning for match lists)
 //   sweep 2: match lists: only the rows / columns pruning left alive, compacted and grouped per streamed image
@@ -523,7 +561,7 @@ void build_compact_plan(msfm_ctx* ctx, const Batch& b, CompactPlan& cp) {
 int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
     const size_t P = b.pairs.size();
     HostClock hc;
-    ctx->pf_pending = msfm_ctx::PfPending{};
+    SC.pf_pending = PfPending{};
     assign_partials(b, 1, 4 * ctx->cu_count);
     // Sweep 2 on the compacted live rows, or on everything again?  Decided per batch, before any result exists: the Lowe
     // test is what kills rows (~94 % at ratio 0.8 on SIFT-like data); with a ratio near or above 1 almost every row stays
@@ -551,7 +589,7 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
             pp.a_h0 = ia.h0_i8;
             pp.b_h0 = ib.h0_i8;
         }
-    ctx->pf_pending.i8 = i8;
+    SC.pf_pending.i8 = i8;
     long long dense_cand = 0;
     for (size_t p = 0; p < P; ++p) {
         b.pf[p].tu_off = b.pairs[p].kf_off;
@@ -562,61 +600,70 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
             b.pf[p].cand_off = dense_cand;
             b.pf[p].cand_cap = 16 * (b.pairs[p].n1 + b.pairs[p].n2) + 2048;
             dense_cand += b.pf[p].cand_cap;
-            ctx->pf_pending.dense_swept += (long long)b.pairs[p].n1pad * b.pairs[p].n2;
+            SC.pf_pending.dense_swept += (long long)b.pairs[p].n1pad * b.pairs[p].n2;
         }
     }
     build_items(b, 1);
     if (b.n_items == 0) return MSFM_OK;
     const long long kn = std::max<long long>(1, b.kf_elems + b.kr_elems);
-    HIPCHK(ctx, ctx->d_rp_s0.ensure(std::max<long long>(1, b.rp_elems) * 4));
-    HIPCHK(ctx, ctx->d_rp_s1.ensure(std::max<long long>(1, b.rp_elems) * 4));
+    HIPCHK(ctx, SC.d_rp_s0.ensure(std::max<long long>(1, b.rp_elems) * 4));
+    HIPCHK(ctx, SC.d_rp_s1.ensure(std::max<long long>(1, b.rp_elems) * 4));
     // column partials of sweep 1: one float2 (the two largest of four row-class maxima) per 512-row A block and column
-    HIPCHK(ctx, ctx->d_cp_s0.ensure(std::max<long long>(1, b.cp_elems) * 8));
-    HIPCHK(ctx, ctx->d_tu.ensure(kn * 4));
-    HIPCHK(ctx, ctx->d_colmask.ensure(kn * 4));
-    HIPCHK(ctx, ctx->d_best.ensure(kn * 8));
-    HIPCHK(ctx, ctx->d_second.ensure(kn * 8));
+    HIPCHK(ctx, SC.d_cp_s0.ensure(std::max<long long>(1, b.cp_elems) * 8));
+    HIPCHK(ctx, SC.d_tu.ensure(kn * 4));
+    HIPCHK(ctx, SC.d_colmask.ensure(kn * 4));
+    HIPCHK(ctx, SC.d_best.ensure(kn * 8));
+    HIPCHK(ctx, SC.d_second.ensure(kn * 8));
     int rc = upload_pairs(ctx, b);
     if (rc != MSFM_OK) return rc;
     rc = upload_items(ctx, b, 1);
     if (rc != MSFM_OK) return rc;
     if (!compact) {   // (compacted sweep 2: pf_assign_kernel initialises the live slots only)
-        HIPCHK(ctx, hipMemsetAsync(ctx->d_best.p, 0xff, kn * 8, ctx->stream));
-        HIPCHK(ctx, hipMemsetAsync(ctx->d_second.p, 0xff, kn * 8, ctx->stream));
+        HIPCHK(ctx, hipMemsetAsync(SC.d_best.p, 0xff, kn * 8, SC.stream));
+        HIPCHK(ctx, hipMemsetAsync(SC.d_second.p, 0xff, kn * 8, SC.stream));
     }
-    HIPCHK(ctx, ctx->d_overflow.ensure(P));
-    HIPCHK(ctx, ctx->d_totals.ensure(64));   // [0..1] candidate / overflow totals (64-bit), ints [8..15]: per-XCD item cursors of sweep 2
-    HIPCHK(ctx, hipMemsetAsync(ctx->d_totals.p, 0, 64, ctx->stream));
+    HIPCHK(ctx, SC.d_overflow.ensure(P));
+    HIPCHK(ctx, SC.d_totals.ensure(64));   // [0..1] candidate / overflow totals (64-bit), ints [8..15]: per-XCD item cursors of sweep 2
+    HIPCHK(ctx, hipMemsetAsync(SC.d_totals.p, 0, 64, SC.stream));
 
     hipEvent_t e0 = get_event(ctx, ev_base), e1 = get_event(ctx, ev_base + 1);
     hipEvent_t e2 = get_event(ctx, ev_base + 2), e3 = get_event(ctx, ev_base + 3);
     if (!e0 || !e1 || !e2 || !e3) return fail(ctx, MSFM_E_DEVICE, "hipEventCreate failed");
     const dim3 block(kPfThreads);
     const unsigned sweep_grid = (unsigned)std::max(8, (ctx->cu_count / 8) * 8);   // one persistent workgroup per CU, a multiple of the 8 XCDs
-    const PairDesc* dp = ctx->d_pairs.as<PairDesc>();
-    const PfPair* dpf = ctx->d_pf.as<PfPair>();
-    float* tuv = ctx->d_tu.as<float>();  // rows at kf offsets, columns at kr offsets (one buffer)
-    unsigned* colmask = ctx->d_colmask.as<unsigned>();
+    const PairDesc* dp = SC.d_pairs.as<PairDesc>();
+    const PfPair* dpf = SC.d_pf.as<PfPair>();
+    float* tuv = SC.d_tu.as<float>();  // rows at kf offsets, columns at kr offsets (one buffer)
+    unsigned* colmask = SC.d_colmask.as<unsigned>();
     hc.lap("sweep-1 setup + uploads");
-    HIPCHK(ctx, hipEventRecord(e0, ctx->stream));
+    // Sweeps 1 of consecutive sub-batches are persistent one-workgroup-per-CU kernels: two of them cannot share the chip, and
+    // a launch that merely queues behind the other stream's sweep would be timed (events) with its wait.  So this one
+    // starts when the other stream's sweep 1 is done; what DOES overlap with it is that stream's tail.
+    {
+        Scratch& other = ctx->sc[ctx->cur == &ctx->sc[0] ? 1 : 0];
+        if (other.sweep1_recorded) HIPCHK(ctx, hipStreamWaitEvent(SC.stream, other.sweep1_done, 0));
+    }
+    HIPCHK(ctx, hipEventRecord(e0, SC.stream));
     if (i8)
-        hipLaunchKernelGGL(sweep_i8_kernel<1>, dim3(std::min<unsigned>(sweep_grid, (unsigned)b.n_items)), dim3(kI8Threads), kI8LdsBytes, ctx->stream, dp, dpf,
-                           ctx->d_items.as<WorkItem>(), ctx->d_rp_s0.as<float>(), ctx->d_rp_s1.as<float>(), ctx->d_cp_s0.as<float>(),
+        hipLaunchKernelGGL(sweep_i8_kernel<1>, dim3(std::min<unsigned>(sweep_grid, (unsigned)b.n_items)), dim3(kI8Threads), kI8LdsBytes, SC.stream, dp, dpf,
+                           SC.d_items.as<WorkItem>(), SC.d_rp_s0.as<float>(), SC.d_rp_s1.as<float>(), SC.d_cp_s0.as<float>(),
                            (const float*)nullptr, (int2*)nullptr, (unsigned long long*)nullptr, (const int*)nullptr, (int)b.n_items, (int*)nullptr);
     else
-        hipLaunchKernelGGL(sweep_kernel<1>, dim3(std::min<unsigned>(sweep_grid, (unsigned)b.n_items)), block, kPfLdsBytes, ctx->stream, dp, dpf,
-                           ctx->d_items.as<WorkItem>(), ctx->d_rp_s0.as<float>(), ctx->d_rp_s1.as<float>(),
-                           ctx->d_cp_s0.as<float>(), (float*)nullptr, (const float*)nullptr, (const float*)nullptr,
+        hipLaunchKernelGGL(sweep_kernel<1>, dim3(std::min<unsigned>(sweep_grid, (unsigned)b.n_items)), block, kPfLdsBytes, SC.stream, dp, dpf,
+                           SC.d_items.as<WorkItem>(), SC.d_rp_s0.as<float>(), SC.d_rp_s1.as<float>(),
+                           SC.d_cp_s0.as<float>(), (float*)nullptr, (const float*)nullptr, (const float*)nullptr,
                            (int2*)nullptr, (unsigned long long*)nullptr, (const int*)nullptr, (int)b.n_items, (int*)nullptr);
     HIPCHK(ctx, hipGetLastError());
     DBGSYNC(ctx, "sweep_kernel<1>");
-    HIPCHK(ctx, hipEventRecord(e1, ctx->stream));
-    ctx->prof.approx_kernel_launches += 1;
-    if (i8) ctx->prof.sweep1_i8_launches += 1;
+    HIPCHK(ctx, hipEventRecord(e1, SC.stream));
+    HIPCHK(ctx, hipEventRecord(SC.sweep1_done, SC.stream));
+    SC.sweep1_recorded = true;
+    SC.prof.approx_kernel_launches += 1;
+    if (i8) SC.prof.sweep1_i8_launches += 1;
     const dim3 mgrid((unsigned)((b.max_npad + 255) / 256), (unsigned)P);
     if (!compact) {
-        hipLaunchKernelGGL(pf_thresholds_kernel, mgrid, dim3(256), 0, ctx->stream, dp, dpf, ctx->d_rp_s0.as<float>(),
-                           ctx->d_rp_s1.as<float>(), ctx->d_cp_s0.as<float>(), (unsigned*)nullptr, tuv, tuv, prune, PlanCounts{});
+        hipLaunchKernelGGL(pf_thresholds_kernel, mgrid, dim3(256), 0, SC.stream, dp, dpf, SC.d_rp_s0.as<float>(),
+                           SC.d_rp_s1.as<float>(), SC.d_cp_s0.as<float>(), (unsigned*)nullptr, tuv, tuv, prune, PlanCounts{});
         HIPCHK(ctx, hipGetLastError());
         DBGSYNC(ctx, "pf_thresholds_kernel");
     }
@@ -637,179 +684,175 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
         const long long cand_cap = std::max<long long>(8 * rows_cap + 1024LL * (long long)G, ctx->cand_hint);
         // (the list holds 8 x the longest per-XCD sub-list: twice the balanced size leaves room for skew)
         const long long items_cap = std::max<long long>(2 * ((rows_cap / kPfWgRows + (long long)G) * max_ranges + 64) / 8 * 8, (ctx->items_hint + 64) / 8 * 8);
-        HIPCHK(ctx, ctx->d_groups.ensure(std::max<size_t>(1, G) * sizeof(PlanGroup)));
-        HIPCHK(ctx, ctx->d_gmembers.ensure(std::max<size_t>(1, M) * 4));
-        HIPCHK(ctx, ctx->d_member_pair.ensure(std::max<size_t>(1, M) * 4));
-        HIPCHK(ctx, ctx->d_member_group.ensure(std::max<size_t>(1, M) * 4));
-        HIPCHK(ctx, ctx->d_gtot.ensure(std::max<size_t>(1, G) * 4));
-        HIPCHK(ctx, ctx->d_grow0.ensure(std::max<size_t>(1, G) * 8));
-        HIPCHK(ctx, ctx->d_ppair.ensure(P * sizeof(PlanPair)));
-        HIPCHK(ctx, ctx->d_cnt.ensure(std::max<size_t>(1, M) * 4));
-        HIPCHK(ctx, ctx->d_mrow.ensure(std::max<size_t>(1, M) * 8));
-        HIPCHK(ctx, ctx->d_summary.ensure(sizeof(PlanSummary)));
-        HIPCHK(ctx, ctx->d_vpairs.ensure(std::max<size_t>(1, G) * sizeof(PairDesc)));
-        HIPCHK(ctx, ctx->d_vpf.ensure(std::max<size_t>(1, G) * sizeof(PfPair)));
-        HIPCHK(ctx, ctx->d_lists.ensure(std::max<size_t>(1, G) * sizeof(CandList)));
-        HIPCHK(ctx, ctx->d_vitems.ensure((size_t)items_cap * sizeof(WorkItem)));
-        if (!ctx->d_zero_row.p) {
-            HIPCHK(ctx, ctx->d_zero_row.ensure(kPfRowBytes));
-            HIPCHK(ctx, hipMemsetAsync(ctx->d_zero_row.p, 0, kPfRowBytes, ctx->stream));
-        }
-        HIPCHK(ctx, ctx->d_cmp_tu.ensure((size_t)rows_cap * 4));
-        HIPCHK(ctx, ctx->d_live_idx.ensure((size_t)rows_cap * 4));
-        HIPCHK(ctx, ctx->d_row_pair.ensure((size_t)rows_cap * 4));
-        HIPCHK(ctx, ctx->d_row_src.ensure((size_t)rows_cap * 8));
-        HIPCHK(ctx, ctx->d_cand.ensure((size_t)cand_cap * sizeof(int2)));
-        HIPCHK(ctx, ctx->d_cand_s.ensure((size_t)cand_cap * 4));
-        HIPCHK(ctx, ctx->d_cand_pair.ensure((size_t)cand_cap * 4));
-        HIPCHK(ctx, ctx->d_cand_count.ensure(std::max<size_t>(1, G) * 8));
+        HIPCHK(ctx, SC.d_groups.ensure(std::max<size_t>(1, G) * sizeof(PlanGroup)));
+        HIPCHK(ctx, SC.d_gmembers.ensure(std::max<size_t>(1, M) * 4));
+        HIPCHK(ctx, SC.d_member_pair.ensure(std::max<size_t>(1, M) * 4));
+        HIPCHK(ctx, SC.d_member_group.ensure(std::max<size_t>(1, M) * 4));
+        HIPCHK(ctx, SC.d_gtot.ensure(std::max<size_t>(1, G) * 4));
+        HIPCHK(ctx, SC.d_grow0.ensure(std::max<size_t>(1, G) * 8));
+        HIPCHK(ctx, SC.d_ppair.ensure(P * sizeof(PlanPair)));
+        HIPCHK(ctx, SC.d_cnt.ensure(std::max<size_t>(1, M) * 4));
+        HIPCHK(ctx, SC.d_mrow.ensure(std::max<size_t>(1, M) * 8));
+        HIPCHK(ctx, SC.d_summary.ensure(sizeof(PlanSummary)));
+        HIPCHK(ctx, SC.d_vpairs.ensure(std::max<size_t>(1, G) * sizeof(PairDesc)));
+        HIPCHK(ctx, SC.d_vpf.ensure(std::max<size_t>(1, G) * sizeof(PfPair)));
+        HIPCHK(ctx, SC.d_lists.ensure(std::max<size_t>(1, G) * sizeof(CandList)));
+        HIPCHK(ctx, SC.d_vitems.ensure((size_t)items_cap * sizeof(WorkItem)));
+        HIPCHK(ctx, SC.d_cmp_tu.ensure((size_t)rows_cap * 4));
+        HIPCHK(ctx, SC.d_live_idx.ensure((size_t)rows_cap * 4));
+        HIPCHK(ctx, SC.d_row_pair.ensure((size_t)rows_cap * 4));
+        HIPCHK(ctx, SC.d_row_src.ensure((size_t)rows_cap * 8));
+        HIPCHK(ctx, SC.d_cand.ensure((size_t)cand_cap * sizeof(int2)));
+        HIPCHK(ctx, SC.d_cand_s.ensure((size_t)cand_cap * 4));
+        HIPCHK(ctx, SC.d_cand_pair.ensure((size_t)cand_cap * 4));
+        HIPCHK(ctx, SC.d_cand_count.ensure(std::max<size_t>(1, G) * 8));
         if (G > 0) {
-            HIPCHK(ctx, hipMemcpyAsync(ctx->d_groups.p, cp.groups.data(), G * sizeof(PlanGroup), hipMemcpyHostToDevice, ctx->stream));
-            HIPCHK(ctx, hipMemcpyAsync(ctx->d_gmembers.p, cp.gmembers.data(), M * 4, hipMemcpyHostToDevice, ctx->stream));
-            HIPCHK(ctx, hipMemcpyAsync(ctx->d_member_pair.p, cp.member_pair.data(), M * 4, hipMemcpyHostToDevice, ctx->stream));
-            HIPCHK(ctx, hipMemcpyAsync(ctx->d_member_group.p, cp.member_group.data(), M * 4, hipMemcpyHostToDevice, ctx->stream));
+            HIPCHK(ctx, hipMemcpyAsync(SC.d_groups.p, cp.groups.data(), G * sizeof(PlanGroup), hipMemcpyHostToDevice, SC.stream));
+            HIPCHK(ctx, hipMemcpyAsync(SC.d_gmembers.p, cp.gmembers.data(), M * 4, hipMemcpyHostToDevice, SC.stream));
+            HIPCHK(ctx, hipMemcpyAsync(SC.d_member_pair.p, cp.member_pair.data(), M * 4, hipMemcpyHostToDevice, SC.stream));
+            HIPCHK(ctx, hipMemcpyAsync(SC.d_member_group.p, cp.member_group.data(), M * 4, hipMemcpyHostToDevice, SC.stream));
         }
-        HIPCHK(ctx, hipMemsetAsync(ctx->d_gtot.p, 0, std::max<size_t>(1, G) * 4, ctx->stream));
-        HIPCHK(ctx, hipMemcpyAsync(ctx->d_ppair.p, cp.ppair.data(), P * sizeof(PlanPair), hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, hipMemsetAsync(SC.d_gtot.p, 0, std::max<size_t>(1, G) * 4, SC.stream));
+        HIPCHK(ctx, hipMemcpyAsync(SC.d_ppair.p, cp.ppair.data(), P * sizeof(PlanPair), hipMemcpyHostToDevice, SC.stream));
         // (the uploads above come from pageable vectors that die with this function: hipMemcpyAsync has staged them when it returns)
-        HIPCHK(ctx, hipMemsetAsync(ctx->d_cnt.p, 0, std::max<size_t>(1, M) * 4, ctx->stream));
-        HIPCHK(ctx, hipMemsetAsync(ctx->d_summary.p, 0, sizeof(PlanSummary), ctx->stream));
-        HIPCHK(ctx, hipMemsetAsync(ctx->d_vitems.p, 0xff, (size_t)items_cap * sizeof(WorkItem), ctx->stream));
-        HIPCHK(ctx, hipMemsetAsync(ctx->d_row_src.p, 0, (size_t)rows_cap * 8, ctx->stream));
-        HIPCHK(ctx, hipMemsetAsync(ctx->d_cand_count.p, 0, std::max<size_t>(1, G) * 8, ctx->stream));
+        HIPCHK(ctx, hipMemsetAsync(SC.d_cnt.p, 0, std::max<size_t>(1, M) * 4, SC.stream));
+        HIPCHK(ctx, hipMemsetAsync(SC.d_summary.p, 0, sizeof(PlanSummary), SC.stream));
+        HIPCHK(ctx, hipMemsetAsync(SC.d_vitems.p, 0xff, (size_t)items_cap * sizeof(WorkItem), SC.stream));
+        HIPCHK(ctx, hipMemsetAsync(SC.d_row_src.p, 0, (size_t)rows_cap * 8, SC.stream));
+        HIPCHK(ctx, hipMemsetAsync(SC.d_cand_count.p, 0, std::max<size_t>(1, G) * 8, SC.stream));
         hc.lap("plan tables + uploads");
-        const PlanPair* dpp = ctx->d_ppair.as<PlanPair>();
+        const PlanPair* dpp = SC.d_ppair.as<PlanPair>();
         // thresholds + live counts per member / group (the plan tables above are uploaded by now; sweep 1 is still running)
-        PlanCounts pc = {dpp, (const int*)ctx->d_member_group.as<int>(), ctx->d_cnt.as<int>(), ctx->d_gtot.as<int>()};
-        hipLaunchKernelGGL(pf_thresholds_kernel, mgrid, dim3(256), 0, ctx->stream, dp, dpf, ctx->d_rp_s0.as<float>(),
-                           ctx->d_rp_s1.as<float>(), ctx->d_cp_s0.as<float>(), colmask, tuv, tuv, prune, pc);
+        PlanCounts pc = {dpp, (const int*)SC.d_member_group.as<int>(), SC.d_cnt.as<int>(), SC.d_gtot.as<int>()};
+        hipLaunchKernelGGL(pf_thresholds_kernel, mgrid, dim3(256), 0, SC.stream, dp, dpf, SC.d_rp_s0.as<float>(),
+                           SC.d_rp_s1.as<float>(), SC.d_cp_s0.as<float>(), colmask, tuv, tuv, prune, pc);
         HIPCHK(ctx, hipGetLastError());
         DBGSYNC(ctx, "pf_thresholds_kernel");
         PlanOut po = {};
-        po.vpairs = ctx->d_vpairs.as<PairDesc>();
-        po.vpf = ctx->d_vpf.as<PfPair>();
-        po.lists = ctx->d_lists.as<CandList>();
-        po.items = ctx->d_vitems.as<WorkItem>();
-        po.grow0 = ctx->d_grow0.as<long long>();
-        po.summary = ctx->d_summary.as<PlanSummary>();
-        po.row_src = ctx->d_row_src.as<const _Float16*>();
+        po.vpairs = SC.d_vpairs.as<PairDesc>();
+        po.vpf = SC.d_vpf.as<PfPair>();
+        po.lists = SC.d_lists.as<CandList>();
+        po.items = SC.d_vitems.as<WorkItem>();
+        po.grow0 = SC.d_grow0.as<long long>();
+        po.summary = SC.d_summary.as<PlanSummary>();
+        po.row_src = SC.d_row_src.as<const _Float16*>();
         po.zero_row = ctx->d_zero_row.as<_Float16>();
-        po.live_idx = ctx->d_live_idx.as<int>();
-        po.row_pair = ctx->d_row_pair.as<int>();
+        po.live_idx = SC.d_live_idx.as<int>();
+        po.row_pair = SC.d_row_pair.as<int>();
         po.rows_cap = rows_cap;
         po.cand_cap = cand_cap;
         po.items_cap = items_cap;
-        hipLaunchKernelGGL(pf_plan_kernel, dim3(1), dim3(kPlanThreads), 0, ctx->stream, ctx->d_groups.as<PlanGroup>(), (int)G,
-                           (const int*)ctx->d_gtot.as<int>(), po);
+        hipLaunchKernelGGL(pf_plan_kernel, dim3(1), dim3(kPlanThreads), 0, SC.stream, SC.d_groups.as<PlanGroup>(), (int)G,
+                           (const int*)SC.d_gtot.as<int>(), po);
         HIPCHK(ctx, hipGetLastError());
         DBGSYNC(ctx, "pf_plan_kernel");
         if (G > 0)
-            hipLaunchKernelGGL(pf_member_rows_kernel, dim3((unsigned)((G + 3) / 4)), dim3(256), 0, ctx->stream, ctx->d_groups.as<PlanGroup>(), (int)G,
-                               (const int*)ctx->d_gmembers.as<int>(), (const int*)ctx->d_cnt.as<int>(),
-                               (const long long*)ctx->d_grow0.as<long long>(), ctx->d_mrow.as<long long>());
+            hipLaunchKernelGGL(pf_member_rows_kernel, dim3((unsigned)((G + 3) / 4)), dim3(256), 0, SC.stream, SC.d_groups.as<PlanGroup>(), (int)G,
+                               (const int*)SC.d_gmembers.as<int>(), (const int*)SC.d_cnt.as<int>(),
+                               (const long long*)SC.d_grow0.as<long long>(), SC.d_mrow.as<long long>());
         HIPCHK(ctx, hipGetLastError());
         DBGSYNC(ctx, "pf_member_rows_kernel");
-        hipLaunchKernelGGL(pf_assign_kernel, dim3((unsigned)(2 * P)), dim3(256), 0, ctx->stream, dp, dpf, dpp, (const float*)tuv,
-                           (const unsigned*)colmask, (const long long*)ctx->d_mrow.as<long long>(),
-                           ctx->d_live_idx.as<int>(), ctx->d_row_pair.as<int>(), ctx->d_cmp_tu.as<float>(),
-                           ctx->d_row_src.as<const _Float16*>(), i8 ? kI8RowBytes / 2 : kPfRowHalfs,
-                           ctx->d_best.as<unsigned long long>(), ctx->d_second.as<unsigned long long>());
+        hipLaunchKernelGGL(pf_assign_kernel, dim3((unsigned)(2 * P)), dim3(256), 0, SC.stream, dp, dpf, dpp, (const float*)tuv,
+                           (const unsigned*)colmask, (const long long*)SC.d_mrow.as<long long>(),
+                           SC.d_live_idx.as<int>(), SC.d_row_pair.as<int>(), SC.d_cmp_tu.as<float>(),
+                           SC.d_row_src.as<const _Float16*>(), i8 ? kI8RowBytes / 2 : kPfRowHalfs,
+                           SC.d_best.as<unsigned long long>(), SC.d_second.as<unsigned long long>());
         HIPCHK(ctx, hipGetLastError());
         DBGSYNC(ctx, "pf_assign_kernel");
-        HIPCHK(ctx, hipEventRecord(e2, ctx->stream));
+        HIPCHK(ctx, hipEventRecord(e2, SC.stream));
         if (i8)
-            hipLaunchKernelGGL(sweep_i8_kernel<3>, dim3(sweep_grid), dim3(kI8Threads), kI8LdsBytes, ctx->stream,
-                               (const PairDesc*)ctx->d_vpairs.as<PairDesc>(), (const PfPair*)ctx->d_vpf.as<PfPair>(),
-                               (const WorkItem*)ctx->d_vitems.as<WorkItem>(), (float*)nullptr, (float*)nullptr, (float*)nullptr,
-                               (const float*)ctx->d_cmp_tu.as<float>(), ctx->d_cand.as<int2>(),
-                               ctx->d_cand_count.as<unsigned long long>(), (const int*)&ctx->d_summary.as<PlanSummary>()->n_items, 0,
-                               ctx->d_totals.as<int>() + 8);
+            hipLaunchKernelGGL(sweep_i8_kernel<3>, dim3(sweep_grid), dim3(kI8Threads), kI8LdsBytes, SC.stream,
+                               (const PairDesc*)SC.d_vpairs.as<PairDesc>(), (const PfPair*)SC.d_vpf.as<PfPair>(),
+                               (const WorkItem*)SC.d_vitems.as<WorkItem>(), (float*)nullptr, (float*)nullptr, (float*)nullptr,
+                               (const float*)SC.d_cmp_tu.as<float>(), SC.d_cand.as<int2>(),
+                               SC.d_cand_count.as<unsigned long long>(), (const int*)&SC.d_summary.as<PlanSummary>()->n_items, 0,
+                               SC.d_totals.as<int>() + 8);
         else
-            hipLaunchKernelGGL(sweep_kernel<3>, dim3(sweep_grid), block, kPfLdsBytes, ctx->stream,
-                               (const PairDesc*)ctx->d_vpairs.as<PairDesc>(), (const PfPair*)ctx->d_vpf.as<PfPair>(),
-                               (const WorkItem*)ctx->d_vitems.as<WorkItem>(), (float*)nullptr, (float*)nullptr, (float*)nullptr,
-                               (float*)nullptr, (const float*)ctx->d_cmp_tu.as<float>(), (const float*)nullptr, ctx->d_cand.as<int2>(),
-                               ctx->d_cand_count.as<unsigned long long>(), (const int*)&ctx->d_summary.as<PlanSummary>()->n_items, 0,
-                               ctx->d_totals.as<int>() + 8);
+            hipLaunchKernelGGL(sweep_kernel<3>, dim3(sweep_grid), block, kPfLdsBytes, SC.stream,
+                               (const PairDesc*)SC.d_vpairs.as<PairDesc>(), (const PfPair*)SC.d_vpf.as<PfPair>(),
+                               (const WorkItem*)SC.d_vitems.as<WorkItem>(), (float*)nullptr, (float*)nullptr, (float*)nullptr,
+                               (float*)nullptr, (const float*)SC.d_cmp_tu.as<float>(), (const float*)nullptr, SC.d_cand.as<int2>(),
+                               SC.d_cand_count.as<unsigned long long>(), (const int*)&SC.d_summary.as<PlanSummary>()->n_items, 0,
+                               SC.d_totals.as<int>() + 8);
         HIPCHK(ctx, hipGetLastError());
         DBGSYNC(ctx, "sweep_kernel<3>");
-        ctx->prof.sweep2_launches += 1;
-        HIPCHK(ctx, hipEventRecord(e3, ctx->stream));
-        dl = ctx->d_lists.as<CandList>();
-        ctx->pf_pending.compact = true;
-        ctx->pf_pending.rows_cap = rows_cap;
-        ctx->pf_pending.cand_cap = cand_cap;
-        ctx->pf_pending.items_cap = items_cap;
-        ctx->pf_pending.compact_pairs = cp.pairs;
+        SC.prof.sweep2_launches += 1;
+        HIPCHK(ctx, hipEventRecord(e3, SC.stream));
+        dl = SC.d_lists.as<CandList>();
+        SC.pf_pending.compact = true;
+        SC.pf_pending.rows_cap = rows_cap;
+        SC.pf_pending.cand_cap = cand_cap;
+        SC.pf_pending.items_cap = items_cap;
+        SC.pf_pending.compact_pairs = cp.pairs;
     } else {
         // ---- dense sweep 2: the pairs' own lists, the sweep-1 items again ----------------------------------------
         n_lists = P;
         std::vector<CandList> lists(P);
         for (size_t p = 0; p < P; ++p)
             lists[p] = CandList{(int)p, 0, b.pf[p].cand_off, b.pf[p].cand_cap, 0, nullptr, nullptr};
-        HIPCHK(ctx, ctx->d_cand.ensure(std::max<long long>(1, dense_cand) * sizeof(int2)));
-        HIPCHK(ctx, ctx->d_cand_s.ensure(std::max<long long>(1, dense_cand) * 4));
-        HIPCHK(ctx, ctx->d_cand_pair.ensure(std::max<long long>(1, dense_cand) * 4));
-        HIPCHK(ctx, ctx->d_cand_count.ensure(P * 8));
-        HIPCHK(ctx, ctx->d_lists.ensure(P * sizeof(CandList)));
-        HIPCHK(ctx, hipMemsetAsync(ctx->d_cand_count.p, 0, P * 8, ctx->stream));
-        HIPCHK(ctx, hipMemcpyAsync(ctx->d_lists.p, lists.data(), P * sizeof(CandList), hipMemcpyHostToDevice, ctx->stream));
-        HIPCHK(ctx, hipMemcpyAsync(ctx->d_pf.p, b.pf.data(), P * sizeof(PfPair), hipMemcpyHostToDevice, ctx->stream));  // cand_off / cap
-        HIPCHK(ctx, hipEventRecord(e2, ctx->stream));
-        hipLaunchKernelGGL(sweep_kernel<2>, dim3(std::min<unsigned>(sweep_grid, (unsigned)b.n_items)), block, kPfLdsBytes, ctx->stream, dp, dpf,
-                           ctx->d_items.as<WorkItem>(), (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr,
-                           (const float*)tuv, (const float*)tuv, ctx->d_cand.as<int2>(), ctx->d_cand_count.as<unsigned long long>(),
+        HIPCHK(ctx, SC.d_cand.ensure(std::max<long long>(1, dense_cand) * sizeof(int2)));
+        HIPCHK(ctx, SC.d_cand_s.ensure(std::max<long long>(1, dense_cand) * 4));
+        HIPCHK(ctx, SC.d_cand_pair.ensure(std::max<long long>(1, dense_cand) * 4));
+        HIPCHK(ctx, SC.d_cand_count.ensure(P * 8));
+        HIPCHK(ctx, SC.d_lists.ensure(P * sizeof(CandList)));
+        HIPCHK(ctx, hipMemsetAsync(SC.d_cand_count.p, 0, P * 8, SC.stream));
+        HIPCHK(ctx, hipMemcpyAsync(SC.d_lists.p, lists.data(), P * sizeof(CandList), hipMemcpyHostToDevice, SC.stream));
+        HIPCHK(ctx, hipMemcpyAsync(SC.d_pf.p, b.pf.data(), P * sizeof(PfPair), hipMemcpyHostToDevice, SC.stream));  // cand_off / cap
+        HIPCHK(ctx, hipEventRecord(e2, SC.stream));
+        hipLaunchKernelGGL(sweep_kernel<2>, dim3(std::min<unsigned>(sweep_grid, (unsigned)b.n_items)), block, kPfLdsBytes, SC.stream, dp, dpf,
+                           SC.d_items.as<WorkItem>(), (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr,
+                           (const float*)tuv, (const float*)tuv, SC.d_cand.as<int2>(), SC.d_cand_count.as<unsigned long long>(),
                            (const int*)nullptr, (int)b.n_items, (int*)nullptr);
         HIPCHK(ctx, hipGetLastError());
         DBGSYNC(ctx, "sweep_kernel<2>");
-        ctx->prof.sweep2_launches += 1;
-        HIPCHK(ctx, hipEventRecord(e3, ctx->stream));
-        dl = ctx->d_lists.as<CandList>();
+        SC.prof.sweep2_launches += 1;
+        HIPCHK(ctx, hipEventRecord(e3, SC.stream));
+        dl = SC.d_lists.as<CandList>();
     }
 
     if (n_lists > 0) {
         const dim3 cgrid(64, (unsigned)std::min<size_t>(n_lists, 65535));   // (the kernels stride over the lists in y)
-        const unsigned long long* dcount = ctx->d_cand_count.as<unsigned long long>();
+        const unsigned long long* dcount = SC.d_cand_count.as<unsigned long long>();
         if (ctx->order == MSFM_ORDER_SSE4X4)
-            hipLaunchKernelGGL(pf_exact_candidates_kernel<0>, cgrid, dim3(256), 0, ctx->stream, dp, dl, dcount,
-                               ctx->d_cand.as<int2>(), ctx->d_cand_s.as<float>(), ctx->d_cand_pair.as<int>(),
-                               ctx->d_best.as<unsigned long long>(), (int)n_lists);
+            hipLaunchKernelGGL(pf_exact_candidates_kernel<0>, cgrid, dim3(256), 0, SC.stream, dp, dl, dcount,
+                               SC.d_cand.as<int2>(), SC.d_cand_s.as<float>(), SC.d_cand_pair.as<int>(),
+                               SC.d_best.as<unsigned long long>(), (int)n_lists);
         else
-            hipLaunchKernelGGL(pf_exact_candidates_kernel<1>, cgrid, dim3(256), 0, ctx->stream, dp, dl, dcount,
-                               ctx->d_cand.as<int2>(), ctx->d_cand_s.as<float>(), ctx->d_cand_pair.as<int>(),
-                               ctx->d_best.as<unsigned long long>(), (int)n_lists);
+            hipLaunchKernelGGL(pf_exact_candidates_kernel<1>, cgrid, dim3(256), 0, SC.stream, dp, dl, dcount,
+                               SC.d_cand.as<int2>(), SC.d_cand_s.as<float>(), SC.d_cand_pair.as<int>(),
+                               SC.d_best.as<unsigned long long>(), (int)n_lists);
         HIPCHK(ctx, hipGetLastError());
         DBGSYNC(ctx, "pf_exact_candidates_kernel");
         const dim3 rgrid(16, (unsigned)std::min<size_t>(n_lists, 65535));
-        hipLaunchKernelGGL(pf_reduce_second_kernel, rgrid, dim3(256), 0, ctx->stream, dp, dl, dcount,
-                           ctx->d_cand.as<int2>(), ctx->d_cand_s.as<float>(), (const int*)ctx->d_cand_pair.as<int>(),
-                           ctx->d_best.as<unsigned long long>(), ctx->d_second.as<unsigned long long>(), (int)n_lists);
+        hipLaunchKernelGGL(pf_reduce_second_kernel, rgrid, dim3(256), 0, SC.stream, dp, dl, dcount,
+                           SC.d_cand.as<int2>(), SC.d_cand_s.as<float>(), (const int*)SC.d_cand_pair.as<int>(),
+                           SC.d_best.as<unsigned long long>(), SC.d_second.as<unsigned long long>(), (int)n_lists);
         HIPCHK(ctx, hipGetLastError());
         DBGSYNC(ctx, "pf_reduce_second_kernel");
     }
-    hipLaunchKernelGGL(pf_finalize_kernel, mgrid, dim3(256), 0, ctx->stream, dp, dpf, (const float*)tuv, ctx->d_best.as<unsigned long long>(),
-                       ctx->d_second.as<unsigned long long>(), ctx->d_k_i0.as<int>(), ctx->d_k_d0.as<float>(),
-                       ctx->d_k_d1.as<float>(), ctx->d_fix_count.as<int>(), ctx->d_fix_list.as<int4>(), ctx->fix_cap_eff);
+    hipLaunchKernelGGL(pf_finalize_kernel, mgrid, dim3(256), 0, SC.stream, dp, dpf, (const float*)tuv, SC.d_best.as<unsigned long long>(),
+                       SC.d_second.as<unsigned long long>(), SC.d_k_i0.as<int>(), SC.d_k_d0.as<float>(),
+                       SC.d_k_d1.as<float>(), SC.d_fix_count.as<int>(), SC.d_fix_list.as<int4>(), SC.fix_cap_eff);
     HIPCHK(ctx, hipGetLastError());
     DBGSYNC(ctx, "pf_finalize_kernel");
     // which pairs own an overflowed list, how many candidates were evaluated: read at the end of the batch
-    HIPCHK(ctx, hipMemsetAsync(ctx->d_overflow.p, 0, P, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(SC.d_overflow.p, 0, P, SC.stream));
     if (n_lists > 0) {
-        hipLaunchKernelGGL(pf_overflow_kernel, dim3((unsigned)((n_lists + 255) / 256)), dim3(256), 0, ctx->stream, dl, (int)n_lists,
-                           (const unsigned long long*)ctx->d_cand_count.as<unsigned long long>(), (const PlanGroup*)ctx->d_groups.as<PlanGroup>(),
-                           (const int*)ctx->d_gmembers.as<int>(), (const int*)ctx->d_member_pair.as<int>(),
-                           ctx->d_overflow.as<unsigned char>(), ctx->d_totals.as<unsigned long long>());
+        hipLaunchKernelGGL(pf_overflow_kernel, dim3((unsigned)((n_lists + 255) / 256)), dim3(256), 0, SC.stream, dl, (int)n_lists,
+                           (const unsigned long long*)SC.d_cand_count.as<unsigned long long>(), (const PlanGroup*)SC.d_groups.as<PlanGroup>(),
+                           (const int*)SC.d_gmembers.as<int>(), (const int*)SC.d_member_pair.as<int>(),
+                           SC.d_overflow.as<unsigned char>(), SC.d_totals.as<unsigned long long>());
         HIPCHK(ctx, hipGetLastError());
     }
-    HIPCHK(ctx, ctx->h_summary.ensure(sizeof(PlanSummary) + 16 + P + 64, 0));
-    char* hs = ctx->h_summary.as<char>();
-    if (compact) HIPCHK(ctx, hipMemcpyAsync(hs, ctx->d_summary.p, sizeof(PlanSummary), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(hs + sizeof(PlanSummary), ctx->d_totals.p, 16, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(hs + sizeof(PlanSummary) + 16, ctx->d_overflow.p, P, hipMemcpyDeviceToHost, ctx->stream));
-    ctx->pf_pending.active = true;
-    ctx->pf_pending.n_lists = n_lists;
-    ctx->pf_pending.P = P;
-    ctx->pf_pending.ev_base = ev_base;
+    HIPCHK(ctx, SC.h_summary.ensure(sizeof(PlanSummary) + 16 + P + 64, 0));
+    char* hs = SC.h_summary.as<char>();
+    if (compact) HIPCHK(ctx, hipMemcpyAsync(hs, SC.d_summary.p, sizeof(PlanSummary), hipMemcpyDeviceToHost, SC.stream));
+    HIPCHK(ctx, hipMemcpyAsync(hs + sizeof(PlanSummary), SC.d_totals.p, 16, hipMemcpyDeviceToHost, SC.stream));
+    HIPCHK(ctx, hipMemcpyAsync(hs + sizeof(PlanSummary) + 16, SC.d_overflow.p, P, hipMemcpyDeviceToHost, SC.stream));
+    SC.pf_pending.active = true;
+    SC.pf_pending.n_lists = n_lists;
+    SC.pf_pending.P = P;
+    SC.pf_pending.ev_base = ev_base;
     hc.lap("launch sweep 2 .. finalize");
     return MSFM_OK;
 }
@@ -818,18 +861,18 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
 // grown / overflowed pairs moved to the brute-force path in `force_exact`).
 int finish_prefilter(msfm_ctx* ctx, Batch& b, std::vector<char>& force_exact, bool* retry) {
     *retry = false;
-    msfm_ctx::PfPending& pe = ctx->pf_pending;
+    PfPending& pe = SC.pf_pending;
     if (!pe.active) return MSFM_OK;
     pe.active = false;
-    const char* hs = ctx->h_summary.as<char>();
+    const char* hs = SC.h_summary.as<char>();
     PlanSummary sm = {};
     unsigned long long totals[2] = {0, 0};
     std::memcpy(totals, hs + sizeof(PlanSummary), 16);
     float ms = 0.f;
     HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev_pool[pe.ev_base], ctx->ev_pool[pe.ev_base + 1]));
-    ctx->prof.approx_kernel_ms += ms;
+    SC.prof.approx_kernel_ms += ms;
     HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev_pool[pe.ev_base + 2], ctx->ev_pool[pe.ev_base + 3]));
-    ctx->prof.sweep2_ms += ms;
+    SC.prof.sweep2_ms += ms;
 #ifdef MSFM_SWEEP_PROBE
     for (int which = 0; which < 2; ++which) {   // diagnostic build: average cycles per tile and wave of the four loop segments
         unsigned long long pr[16][16];
@@ -855,7 +898,7 @@ int finish_prefilter(msfm_ctx* ctx, Batch& b, std::vector<char>& force_exact, bo
         PlanSummary d;
         std::memcpy(&d, hs, sizeof(PlanSummary));
         std::fprintf(stderr, "[msfm plan] ok %d, items %d, compacted rows %lld, candidate capacity %lld, swept descriptor pairs %lld; sweep 1 %.3f ms, sweep 2 %.3f ms\n",
-                     d.ok, d.n_items, d.cmp_rows, d.cand_elems, d.swept_desc_pairs, ctx->prof.approx_kernel_ms, ms);
+                     d.ok, d.n_items, d.cmp_rows, d.cand_elems, d.swept_desc_pairs, SC.prof.approx_kernel_ms, ms);
     }
     if (pe.compact) {
         std::memcpy(&sm, hs, sizeof(PlanSummary));
@@ -863,13 +906,13 @@ int finish_prefilter(msfm_ctx* ctx, Batch& b, std::vector<char>& force_exact, bo
         ctx->items_hint = sm.items_needed;
         ctx->cand_hint = sm.cand_elems;
         if (!sm.ok) {   // the prediction was too small: the buffers are sized from the need now
-            ctx->prof.plan_regrows += 1;
+            SC.prof.plan_regrows += 1;
             *retry = true;
             return MSFM_OK;
         }
-        ctx->prof.sweep2_descriptor_pairs += sm.swept_desc_pairs;
+        SC.prof.sweep2_descriptor_pairs += sm.swept_desc_pairs;
     } else {
-        ctx->prof.sweep2_descriptor_pairs += pe.dense_swept;
+        SC.prof.sweep2_descriptor_pairs += pe.dense_swept;
     }
     const unsigned char* ov = reinterpret_cast<const unsigned char*>(hs + sizeof(PlanSummary) + 16);
     int n_over = 0;
@@ -881,17 +924,17 @@ int finish_prefilter(msfm_ctx* ctx, Batch& b, std::vector<char>& force_exact, bo
         }
     }
     if (n_over > 0) {   // candidate-list overflow -> those pairs take the brute-force exact path in a second run
-        ctx->prof.fallback_pairs += n_over;
+        SC.prof.fallback_pairs += n_over;
         *retry = true;
         return MSFM_OK;
     }
-    ctx->prof.candidates += (int64_t)totals[0];
+    SC.prof.candidates += (int64_t)totals[0];
     for (size_t p = 0; p < pe.P; ++p)
         if (b.pairs[p].valid && b.pf[p].use) {
-            ctx->prof.prefilter_pairs += 1;
-            ctx->prof.prefilter_descriptor_pairs += (int64_t)b.pairs[p].n1 * b.pairs[p].n2;
+            SC.prof.prefilter_pairs += 1;
+            SC.prof.prefilter_descriptor_pairs += (int64_t)b.pairs[p].n1 * b.pairs[p].n2;
         }
-    if (pe.compact) ctx->prof.compacted_pairs += pe.compact_pairs;
+    if (pe.compact) SC.prof.compacted_pairs += pe.compact_pairs;
     return MSFM_OK;
 }
 
@@ -901,41 +944,41 @@ int run_exact(msfm_ctx* ctx, Batch& b, size_t ev_base) {
     assign_partials(b, 0, 4 * ctx->cu_count);
     build_items(b, 0);
     if (b.n_items == 0) return MSFM_OK;
-    HIPCHK(ctx, ctx->d_rp_s0.ensure(std::max<long long>(1, b.rp_elems) * 4));
-    HIPCHK(ctx, ctx->d_rp_i0.ensure(std::max<long long>(1, b.rp_elems) * 4));
-    HIPCHK(ctx, ctx->d_rp_s1.ensure(std::max<long long>(1, b.rp_elems) * 4));
-    HIPCHK(ctx, ctx->d_cp_s0.ensure(std::max<long long>(1, b.cp_elems) * 4));
-    HIPCHK(ctx, ctx->d_cp_i0.ensure(std::max<long long>(1, b.cp_elems) * 4));
-    HIPCHK(ctx, ctx->d_cp_s1.ensure(std::max<long long>(1, b.cp_elems) * 4));
+    HIPCHK(ctx, SC.d_rp_s0.ensure(std::max<long long>(1, b.rp_elems) * 4));
+    HIPCHK(ctx, SC.d_rp_i0.ensure(std::max<long long>(1, b.rp_elems) * 4));
+    HIPCHK(ctx, SC.d_rp_s1.ensure(std::max<long long>(1, b.rp_elems) * 4));
+    HIPCHK(ctx, SC.d_cp_s0.ensure(std::max<long long>(1, b.cp_elems) * 4));
+    HIPCHK(ctx, SC.d_cp_i0.ensure(std::max<long long>(1, b.cp_elems) * 4));
+    HIPCHK(ctx, SC.d_cp_s1.ensure(std::max<long long>(1, b.cp_elems) * 4));
     int rc = upload_pairs(ctx, b);
     if (rc != MSFM_OK) return rc;
     rc = upload_items(ctx, b, 0);
     if (rc != MSFM_OK) return rc;
     hipEvent_t e0 = get_event(ctx, ev_base), e1 = get_event(ctx, ev_base + 1);
     if (!e0 || !e1) return fail(ctx, MSFM_E_DEVICE, "hipEventCreate failed");
-    HIPCHK(ctx, hipEventRecord(e0, ctx->stream));
+    HIPCHK(ctx, hipEventRecord(e0, SC.stream));
     const dim3 grid((unsigned)b.n_items), block(kThreads);
     if (ctx->order == MSFM_ORDER_SSE4X4)
-        hipLaunchKernelGGL(dist_top2_kernel<0>, grid, block, kLdsBytes, ctx->stream,
-                           ctx->d_pairs.as<PairDesc>(), ctx->d_items.as<WorkItem>(),
-                           ctx->d_rp_s0.as<float>(), ctx->d_rp_i0.as<int>(), ctx->d_rp_s1.as<float>(),
-                           ctx->d_cp_s0.as<float>(), ctx->d_cp_i0.as<int>(), ctx->d_cp_s1.as<float>());
+        hipLaunchKernelGGL(dist_top2_kernel<0>, grid, block, kLdsBytes, SC.stream,
+                           SC.d_pairs.as<PairDesc>(), SC.d_items.as<WorkItem>(),
+                           SC.d_rp_s0.as<float>(), SC.d_rp_i0.as<int>(), SC.d_rp_s1.as<float>(),
+                           SC.d_cp_s0.as<float>(), SC.d_cp_i0.as<int>(), SC.d_cp_s1.as<float>());
     else
-        hipLaunchKernelGGL(dist_top2_kernel<1>, grid, block, kLdsBytes, ctx->stream,
-                           ctx->d_pairs.as<PairDesc>(), ctx->d_items.as<WorkItem>(),
-                           ctx->d_rp_s0.as<float>(), ctx->d_rp_i0.as<int>(), ctx->d_rp_s1.as<float>(),
-                           ctx->d_cp_s0.as<float>(), ctx->d_cp_i0.as<int>(), ctx->d_cp_s1.as<float>());
+        hipLaunchKernelGGL(dist_top2_kernel<1>, grid, block, kLdsBytes, SC.stream,
+                           SC.d_pairs.as<PairDesc>(), SC.d_items.as<WorkItem>(),
+                           SC.d_rp_s0.as<float>(), SC.d_rp_i0.as<int>(), SC.d_rp_s1.as<float>(),
+                           SC.d_cp_s0.as<float>(), SC.d_cp_i0.as<int>(), SC.d_cp_s1.as<float>());
     HIPCHK(ctx, hipGetLastError());
-    HIPCHK(ctx, hipEventRecord(e1, ctx->stream));
-    ctx->prof.dist_kernel_launches += 1;
+    HIPCHK(ctx, hipEventRecord(e1, SC.stream));
+    SC.prof.dist_kernel_launches += 1;
     for (auto& pd : b.pairs)
-        if (pd.valid && pd.path == 0) ctx->prof.exact_descriptor_pairs += (int64_t)pd.n1 * pd.n2;
+        if (pd.valid && pd.path == 0) SC.prof.exact_descriptor_pairs += (int64_t)pd.n1 * pd.n2;
     const dim3 mgrid((unsigned)((b.max_npad + 255) / 256), (unsigned)P);
-    hipLaunchKernelGGL(merge_knn_kernel, mgrid, dim3(256), 0, ctx->stream, ctx->d_pairs.as<PairDesc>(),
-                       ctx->d_rp_s0.as<float>(), ctx->d_rp_i0.as<int>(), ctx->d_rp_s1.as<float>(),
-                       ctx->d_cp_s0.as<float>(), ctx->d_cp_i0.as<int>(), ctx->d_cp_s1.as<float>(),
-                       ctx->d_k_i0.as<int>(), ctx->d_k_d0.as<float>(), ctx->d_k_d1.as<float>(),
-                       ctx->d_fix_count.as<int>(), ctx->d_fix_list.as<int4>(), ctx->fix_cap_eff);
+    hipLaunchKernelGGL(merge_knn_kernel, mgrid, dim3(256), 0, SC.stream, SC.d_pairs.as<PairDesc>(),
+                       SC.d_rp_s0.as<float>(), SC.d_rp_i0.as<int>(), SC.d_rp_s1.as<float>(),
+                       SC.d_cp_s0.as<float>(), SC.d_cp_i0.as<int>(), SC.d_cp_s1.as<float>(),
+                       SC.d_k_i0.as<int>(), SC.d_k_d0.as<float>(), SC.d_k_d1.as<float>(),
+                       SC.d_fix_count.as<int>(), SC.d_fix_list.as<int4>(), SC.fix_cap_eff);
     HIPCHK(ctx, hipGetLastError());
     return MSFM_OK;
 }
@@ -947,14 +990,14 @@ int run_exact(msfm_ctx* ctx, Batch& b, size_t ev_base) {
 //   index never reaches a list: the queue is not filled and nothing is re-scanned.
 int run_knn(msfm_ctx* ctx, Batch& b, size_t ev_base, bool* exact_launched, PruneParams prune, bool need_fix) {
     assign_common(b);
-    ctx->fix_cap_eff = need_fix ? ctx->fix_cap : 0;
+    SC.fix_cap_eff = need_fix ? ctx->fix_cap : 0;
     const long long kn = std::max<long long>(1, b.kf_elems + b.kr_elems);
-    HIPCHK(ctx, ctx->d_k_i0.ensure(kn * 4));
-    HIPCHK(ctx, ctx->d_k_d0.ensure(kn * 4));
-    HIPCHK(ctx, ctx->d_k_d1.ensure(kn * 4));
-    HIPCHK(ctx, ctx->d_fix_count.ensure(4));
-    HIPCHK(ctx, ctx->d_fix_list.ensure((size_t)ctx->fix_cap * sizeof(int4)));
-    HIPCHK(ctx, hipMemsetAsync(ctx->d_fix_count.p, 0, 4, ctx->stream));
+    HIPCHK(ctx, SC.d_k_i0.ensure(kn * 4));
+    HIPCHK(ctx, SC.d_k_d0.ensure(kn * 4));
+    HIPCHK(ctx, SC.d_k_d1.ensure(kn * 4));
+    HIPCHK(ctx, SC.d_fix_count.ensure(4));
+    HIPCHK(ctx, SC.d_fix_list.ensure((size_t)ctx->fix_cap * sizeof(int4)));
+    HIPCHK(ctx, hipMemsetAsync(SC.d_fix_count.p, 0, 4, SC.stream));
     bool any_pf = false, any_exact = false;
     for (auto& pd : b.pairs) any_pf |= (pd.valid && pd.path == 1);
     int rc;
@@ -974,33 +1017,44 @@ int run_knn(msfm_ctx* ctx, Batch& b, size_t ev_base, bool* exact_launched, Prune
     }
     if (any_pf || any_exact) {
         if (ctx->order == MSFM_ORDER_SSE4X4)
-            hipLaunchKernelGGL(tie_fixup_kernel<0>, dim3(256), dim3(64), 0, ctx->stream, ctx->d_pairs.as<PairDesc>(),
-                               ctx->d_fix_count.as<int>(), ctx->d_fix_list.as<int4>(), ctx->fix_cap_eff,
-                               ctx->d_k_i0.as<int>(), ctx->d_k_d0.as<float>());
+            hipLaunchKernelGGL(tie_fixup_kernel<0>, dim3(256), dim3(64), 0, SC.stream, SC.d_pairs.as<PairDesc>(),
+                               SC.d_fix_count.as<int>(), SC.d_fix_list.as<int4>(), SC.fix_cap_eff,
+                               SC.d_k_i0.as<int>(), SC.d_k_d0.as<float>());
         else
-            hipLaunchKernelGGL(tie_fixup_kernel<1>, dim3(256), dim3(64), 0, ctx->stream, ctx->d_pairs.as<PairDesc>(),
-                               ctx->d_fix_count.as<int>(), ctx->d_fix_list.as<int4>(), ctx->fix_cap_eff,
-                               ctx->d_k_i0.as<int>(), ctx->d_k_d0.as<float>());
+            hipLaunchKernelGGL(tie_fixup_kernel<1>, dim3(256), dim3(64), 0, SC.stream, SC.d_pairs.as<PairDesc>(),
+                               SC.d_fix_count.as<int>(), SC.d_fix_list.as<int4>(), SC.fix_cap_eff,
+                               SC.d_k_i0.as<int>(), SC.d_k_d0.as<float>());
         HIPCHK(ctx, hipGetLastError());
     }
     return MSFM_OK;
 }
 
-// Synchronises the stream.  *retry = true: more tied rows than the queue holds -- the queue has been grown to
-// fit, the caller re-runs the batch (rare: duplicate descriptors on the brute-force path with ratio > 1 or
+// The words the host reads at the end of a sub-batch -- tie-queue count, CSR offsets, certificate counts -- are copied
+// into PAGE-LOCKED memory (a copy into pageable memory would block the host until the whole sub-batch has run, and
+// with it the launch of the next sub-batch on the other stream).
+int queue_tail_copies(msfm_ctx* ctx, size_t P) {
+    HIPCHK(ctx, SC.h_tail.ensure(8 + (P + 1) * 8 + P * 4 + 64, 0));
+    char* h = SC.h_tail.as<char>();
+    HIPCHK(ctx, hipMemcpyAsync(h, SC.d_fix_count.p, 4, hipMemcpyDeviceToHost, SC.stream));
+    HIPCHK(ctx, hipMemcpyAsync(h + 8, SC.d_offsets.p, (P + 1) * 8, hipMemcpyDeviceToHost, SC.stream));
+    HIPCHK(ctx, hipMemcpyAsync(h + 8 + (P + 1) * 8, SC.d_sens.p, P * 4, hipMemcpyDeviceToHost, SC.stream));
+    return MSFM_OK;
+}
+
+// After the sub-batch's stream synchronisation.  *retry = true: more tied rows than the queue holds -- the queue has
+// been grown to fit, the caller re-runs the batch (rare: duplicate descriptors on the brute-force path with ratio > 1 or
 // through the knnMatch-level API).
 int check_fix_overflow(msfm_ctx* ctx, bool* retry) {
     int nfix = 0;
     *retry = false;
-    HIPCHK(ctx, hipMemcpyAsync(&nfix, ctx->d_fix_count.p, 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    if (ctx->fix_cap_eff > 0 && nfix > ctx->fix_cap_eff) {
+    std::memcpy(&nfix, SC.h_tail.as<char>(), 4);
+    if (SC.fix_cap_eff > 0 && nfix > SC.fix_cap_eff) {
         ctx->fix_cap = nfix + nfix / 8 + 1024;
-        ctx->prof.tie_queue_regrows += 1;
+        SC.prof.tie_queue_regrows += 1;
         *retry = true;
         return MSFM_OK;
     }
-    ctx->prof.tie_rows += nfix;
+    SC.prof.tie_rows += nfix;
     return MSFM_OK;
 }
 
@@ -1008,7 +1062,7 @@ int accumulate_kernel_time(msfm_ctx* ctx, size_t ev_base, bool launched) {
     if (!launched) return MSFM_OK;
     float ms = 0.f;
     HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev_pool[ev_base], ctx->ev_pool[ev_base + 1]));
-    ctx->prof.dist_kernel_ms += ms;
+    SC.prof.dist_kernel_ms += ms;
     return MSFM_OK;
 }
 
@@ -1020,6 +1074,8 @@ int accumulate_kernel_time(msfm_ctx* ctx, size_t ev_base, bool launched) {
 extern "C" {
 
 const char* msfm_version(void) { return "msfm-match 0.1 (gfx950)"; }
+
+static void destroy_streams(msfm_ctx* ctx);
 
 int msfm_create(int device_ordinal, msfm_ctx** out_ctx) {
     if (!out_ctx) return MSFM_E_INVALID;
@@ -1042,10 +1098,13 @@ int msfm_create(int device_ordinal, msfm_ctx** out_ctx) {
     ctx->cu_count = prop.multiProcessorCount;
     ctx->clock_mhz = prop.clockRate / 1000;
     std::snprintf(ctx->dev_name, sizeof(ctx->dev_name), "%s (%s)", prop.name, prop.gcnArchName);
-    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
-        delete ctx;
-        return MSFM_E_DEVICE;
-    }
+    for (Scratch& sc : ctx->sc)
+        if (hipStreamCreateWithFlags(&sc.stream, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&sc.sweep1_done, hipEventDisableTiming) != hipSuccess) {
+            destroy_streams(ctx);
+            delete ctx;
+            return MSFM_E_DEVICE;
+        }
     // the distance kernel needs 108 KiB of dynamic LDS
     hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void*>(dist_top2_kernel<0>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
@@ -1054,7 +1113,7 @@ int msfm_create(int device_ordinal, msfm_ctx** out_ctx) {
     if (e0 != hipSuccess || e1 != hipSuccess) {
         std::fprintf(stderr, "msfm_create: cannot reserve %d bytes of LDS: %s\n", kLdsBytes,
                      hipGetErrorString(e0 != hipSuccess ? e0 : e1));
-        (void)hipStreamDestroy(ctx->stream);
+        destroy_streams(ctx);
         delete ctx;
         return MSFM_E_DEVICE;
     }
@@ -1071,39 +1130,49 @@ int msfm_create(int device_ordinal, msfm_ctx** out_ctx) {
     if (e5 != hipSuccess || e6 != hipSuccess) e2 = e5 != hipSuccess ? e5 : e6;
     if (e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess) {
         std::fprintf(stderr, "msfm_create: cannot reserve %d bytes of LDS for the prefilter kernels\n", kPfLdsBytes);
-        (void)hipStreamDestroy(ctx->stream);
+        destroy_streams(ctx);
+        delete ctx;
+        return MSFM_E_DEVICE;
+    }
+    // the all-zero operand row the compacted sweep reads for rows without a source
+    if (ctx->d_zero_row.ensure(kPfRowBytes) != hipSuccess || hipMemset(ctx->d_zero_row.p, 0, kPfRowBytes) != hipSuccess) {
+        destroy_streams(ctx);
         delete ctx;
         return MSFM_E_DEVICE;
     }
     if (const char* e = std::getenv("MSFM_PREFILTER")) ctx->prefilter = e[0] == '2' ? 2 : (e[0] != '0');
     if (const char* e = std::getenv("MSFM_MAX_PAIRS_PER_BATCH"))
         if (std::atoi(e) > 0) ctx->max_pairs_per_batch = std::min(std::atoi(e), kMaxPairsPerBatchLimit);
+    if (const char* e = std::getenv("MSFM_PIPELINE"))
+        if (std::atoi(e) > 0) ctx->pipeline = std::min(std::atoi(e), 64);
     if (const char* e = std::getenv("MSFM_SCRATCH_MIB"))
         if (std::atoll(e) > 0) ctx->scratch_elems = std::atoll(e) * (1 << 20) / 4;
     *out_ctx = ctx;
     return MSFM_OK;
 }
 
+static void destroy_streams(msfm_ctx* ctx) {
+    for (Scratch& sc : ctx->sc) {
+        if (sc.sweep1_done) (void)hipEventDestroy(sc.sweep1_done);
+        if (sc.stream) (void)hipStreamDestroy(sc.stream);
+        sc.sweep1_done = nullptr;
+        sc.stream = nullptr;
+    }
+}
+
 void msfm_destroy(msfm_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    (void)hipStreamSynchronize(ctx->stream);
+    for (Scratch& sc : ctx->sc)
+        if (sc.stream) (void)hipStreamSynchronize(sc.stream);
     for (auto& im : ctx->images) free_image(im);
-    DevBuf* bufs[] = {&ctx->d_pairs, &ctx->d_items, &ctx->d_item_base, &ctx->d_stage, &ctx->d_rp_s0, &ctx->d_rp_i0, &ctx->d_rp_s1,
-                      &ctx->d_cp_s0, &ctx->d_cp_i0, &ctx->d_cp_s1, &ctx->d_k_i0, &ctx->d_k_d0, &ctx->d_k_d1,
-                      &ctx->d_st_qt, &ctx->d_st_d, &ctx->d_counts, &ctx->d_offsets, &ctx->d_sens, &ctx->d_out_qt,
-                      &ctx->d_out_d, &ctx->d_fix_count, &ctx->d_fix_list, &ctx->d_pf, &ctx->d_tu, &ctx->d_tv,
-                      &ctx->d_cand, &ctx->d_cand_s, &ctx->d_cand_count, &ctx->d_best, &ctx->d_second, &ctx->d_maxima,
-                      &ctx->d_zero_row, &ctx->d_cmp_tu, &ctx->d_live_idx, &ctx->d_vpairs, &ctx->d_vpf, &ctx->d_row_src, &ctx->d_colmask, &ctx->d_groups, &ctx->d_gmembers, &ctx->d_member_pair, &ctx->d_member_group, &ctx->d_gtot, &ctx->d_grow0, &ctx->d_ppair, &ctx->d_cnt, &ctx->d_mrow, &ctx->d_summary, &ctx->d_overflow, &ctx->d_totals,
-                      &ctx->d_vitems, &ctx->d_lists, &ctx->d_row_pair, &ctx->d_cand_pair, &ctx->d_vf_pairs, &ctx->d_vf_x1, &ctx->d_vf_y1,
-                      &ctx->d_vf_x2, &ctx->d_vf_y2, &ctx->d_vf_hyp, &ctx->d_vf_best_it, &ctx->d_vf_best_count,
-                      &ctx->d_vf_flags, &ctx->d_st2_qt, &ctx->d_st2_d, &ctx->d_counts2};
+    for (Scratch& sc : ctx->sc) sc.release_all();
+    DevBuf* bufs[] = {&ctx->d_stage, &ctx->d_maxima, &ctx->d_zero_row, &ctx->d_out_qt, &ctx->d_out_d};
     for (DevBuf* b : bufs) b->release();
     ctx->res_qt.release();
-    ctx->h_summary.release();
     ctx->res_dist.release();
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
-    (void)hipStreamDestroy(ctx->stream);
+    destroy_streams(ctx);
     delete ctx;
 }
 
@@ -1128,12 +1197,12 @@ int msfm_set_accum_order(msfm_ctx* ctx, int order) {
         if (im.n <= 0) continue;
         const int blocks = std::min(4096, im.nalloc * 16);
         if (order == MSFM_ORDER_SSE4X4)
-            hipLaunchKernelGGL((layout_kernel<0, float>), dim3(blocks), dim3(256), 0, ctx->stream, im.raw, (float*)nullptr, im.panel, im.n, im.nalloc);
+            hipLaunchKernelGGL((layout_kernel<0, float>), dim3(blocks), dim3(256), 0, SC.stream, im.raw, (float*)nullptr, im.panel, im.n, im.nalloc);
         else
-            hipLaunchKernelGGL((layout_kernel<1, float>), dim3(blocks), dim3(256), 0, ctx->stream, im.raw, (float*)nullptr, im.panel, im.n, im.nalloc);
+            hipLaunchKernelGGL((layout_kernel<1, float>), dim3(blocks), dim3(256), 0, SC.stream, im.raw, (float*)nullptr, im.panel, im.n, im.nalloc);
         HIPCHK(ctx, hipGetLastError());
     }
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(SC.stream));
     return MSFM_OK;
 }
 
@@ -1148,6 +1217,12 @@ int msfm_set_limits(msfm_ctx* ctx, int max_pairs_per_batch, int64_t scratch_byte
     // (the pair index of a sub-batch is gridDim.y of several kernels: at most 65535)
     ctx->max_pairs_per_batch = max_pairs_per_batch > 0 ? std::min(max_pairs_per_batch, kMaxPairsPerBatchLimit) : kDefaultMaxPairsPerBatch;
     ctx->scratch_elems = scratch_bytes > 0 ? std::max<long long>(1, scratch_bytes / 4) : kDefaultScratchElems;
+    return MSFM_OK;
+}
+
+int msfm_set_pipeline(msfm_ctx* ctx, int min_sub_batches) {
+    if (!ctx) return MSFM_E_INVALID;
+    ctx->pipeline = min_sub_batches > 0 ? std::min(min_sub_batches, 64) : kDefaultPipeline;
     return MSFM_OK;
 }
 
@@ -1178,14 +1253,14 @@ static int build_image(msfm_ctx* ctx, Image& im, const unsigned char* src8, bool
     const int blocks = std::min(4096, im.nalloc * 16);
     if (!src8) {
         if (ctx->order == MSFM_ORDER_SSE4X4)
-            hipLaunchKernelGGL((layout_kernel<0, float>), dim3(blocks), dim3(256), 0, ctx->stream, im.raw, (float*)nullptr, im.panel, n, im.nalloc);
+            hipLaunchKernelGGL((layout_kernel<0, float>), dim3(blocks), dim3(256), 0, SC.stream, im.raw, (float*)nullptr, im.panel, n, im.nalloc);
         else
-            hipLaunchKernelGGL((layout_kernel<1, float>), dim3(blocks), dim3(256), 0, ctx->stream, im.raw, (float*)nullptr, im.panel, n, im.nalloc);
+            hipLaunchKernelGGL((layout_kernel<1, float>), dim3(blocks), dim3(256), 0, SC.stream, im.raw, (float*)nullptr, im.panel, n, im.nalloc);
     } else {
         if (ctx->order == MSFM_ORDER_SSE4X4)
-            hipLaunchKernelGGL((layout_kernel<0, unsigned char>), dim3(blocks), dim3(256), 0, ctx->stream, src8, im.raw, im.panel, n, im.nalloc);
+            hipLaunchKernelGGL((layout_kernel<0, unsigned char>), dim3(blocks), dim3(256), 0, SC.stream, src8, im.raw, im.panel, n, im.nalloc);
         else
-            hipLaunchKernelGGL((layout_kernel<1, unsigned char>), dim3(blocks), dim3(256), 0, ctx->stream, src8, im.raw, im.panel, n, im.nalloc);
+            hipLaunchKernelGGL((layout_kernel<1, unsigned char>), dim3(blocks), dim3(256), 0, SC.stream, src8, im.raw, im.panel, n, im.nalloc);
     }
     HIPCHK(ctx, hipGetLastError());
     // prefilter operands (order-independent): fp16 swizzled blocks, norms, maxima
@@ -1193,21 +1268,21 @@ static int build_image(msfm_ctx* ctx, Image& im, const unsigned char* src8, bool
     HIPCHK(ctx, hipMalloc((void**)&im.h16, (size_t)npad * kPfRowBytes));
     HIPCHK(ctx, hipMalloc((void**)&im.nrm, (size_t)npad * 4));
     HIPCHK(ctx, ctx->d_maxima.ensure(16));
-    HIPCHK(ctx, hipMemsetAsync(ctx->d_maxima.p, 0, 16, ctx->stream));
-    hipLaunchKernelGGL(pf_prepare_kernel, dim3(std::min(2048, (npad * 16 + 255) / 256)), dim3(256), 0, ctx->stream,
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_maxima.p, 0, 16, SC.stream));
+    hipLaunchKernelGGL(pf_prepare_kernel, dim3(std::min(2048, (npad * 16 + 255) / 256)), dim3(256), 0, SC.stream,
                        im.raw, im.h16, im.nrm, ctx->d_maxima.as<unsigned>(), n, npad);
     HIPCHK(ctx, hipGetLastError());
     if (is_u8) {
         HIPCHK(ctx, hipMalloc((void**)&im.i8, (size_t)npad * kI8RowBytes));
         HIPCHK(ctx, hipMalloc((void**)&im.nrm_i8, (size_t)npad * 4));
-        hipLaunchKernelGGL(pf_prepare_i8_kernel, dim3(std::min(2048, (npad * 11 + 255) / 256)), dim3(256), 0, ctx->stream,
+        hipLaunchKernelGGL(pf_prepare_i8_kernel, dim3(std::min(2048, (npad * 11 + 255) / 256)), dim3(256), 0, SC.stream,
                            (const float*)im.raw, im.i8, im.nrm_i8, ctx->d_maxima.as<unsigned>(), n, npad);
         HIPCHK(ctx, hipGetLastError());
     }
     unsigned mx[4] = {0, 0, 0, 0};
-    HIPCHK(ctx, hipMemcpyAsync(mx, ctx->d_maxima.p, 16, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(mx, ctx->d_maxima.p, 16, hipMemcpyDeviceToHost, SC.stream));
     // the caller may free/reuse its buffer (and we reuse d_stage) as soon as we return
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(SC.stream));
     std::memcpy(&im.nrm_max, &mx[0], 4);
     std::memcpy(&im.abs_max, &mx[1], 4);
     std::memcpy(&im.nrm_i8_max, &mx[2], 4);
@@ -1220,10 +1295,10 @@ static int build_image(msfm_ctx* ctx, Image& im, const unsigned char* src8, bool
         const long long h0 = (hmin + hmax) / 2;
         if (hmin <= hmax && h0 - hmax >= kI8DigitLo && h0 - hmin <= kI8DigitHi) {
             im.h0_i8 = (int)h0;
-            hipLaunchKernelGGL(pf_digits_i8_kernel, dim3(std::min(1024, (n + 255) / 256)), dim3(256), 0, ctx->stream,
+            hipLaunchKernelGGL(pf_digits_i8_kernel, dim3(std::min(1024, (n + 255) / 256)), dim3(256), 0, SC.stream,
                                (const float*)im.nrm_i8, im.i8, n, im.h0_i8);
             HIPCHK(ctx, hipGetLastError());
-            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            HIPCHK(ctx, hipStreamSynchronize(SC.stream));
         } else {   // (an all-zero next to an all-128 descriptor: not SIFT) -- the image is served by the fp16 kernels
             (void)hipFree(im.i8);
             (void)hipFree(im.nrm_i8);
@@ -1242,9 +1317,9 @@ static int build_image(msfm_ctx* ctx, Image& im, const unsigned char* src8, bool
         if (k > 15) im.pf_safe = false;
         else {
             im.c = std::ldexp(1.f, k);
-            hipLaunchKernelGGL(pf_ext_kernel, dim3((npad + 255) / 256), dim3(256), 0, ctx->stream, im.nrm, im.h16, npad, im.c);
+            hipLaunchKernelGGL(pf_ext_kernel, dim3((npad + 255) / 256), dim3(256), 0, SC.stream, im.nrm, im.h16, npad, im.c);
             HIPCHK(ctx, hipGetLastError());
-            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            HIPCHK(ctx, hipStreamSynchronize(SC.stream));
         }
     }
     return MSFM_OK;
@@ -1262,11 +1337,11 @@ int msfm_upload_image(msfm_ctx* ctx, int image_id, const void* desc, int n, int 
     int rc = alloc_image(ctx, im, n);
     if (rc != MSFM_OK || n == 0) return rc;
     if (dtype == MSFM_DTYPE_F32) {
-        HIPCHK(ctx, hipMemcpyAsync(im.raw, desc, (size_t)n * kDim * 4, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(im.raw, desc, (size_t)n * kDim * 4, hipMemcpyHostToDevice, SC.stream));
         return build_image(ctx, im, nullptr, false);
     }
     HIPCHK(ctx, ctx->d_stage.ensure((size_t)n * kDim));
-    HIPCHK(ctx, hipMemcpyAsync(ctx->d_stage.p, desc, (size_t)n * kDim, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_stage.p, desc, (size_t)n * kDim, hipMemcpyHostToDevice, SC.stream));
     return build_image(ctx, im, ctx->d_stage.as<unsigned char>(), true);
 }
 
@@ -1291,8 +1366,8 @@ int msfm_subset_image(msfm_ctx* ctx, int src_image_id, int dst_image_id, const i
     int rc = alloc_image(ctx, im, count);
     if (rc != MSFM_OK || count == 0) return rc;
     HIPCHK(ctx, ctx->d_stage.ensure((size_t)count * 4));
-    HIPCHK(ctx, hipMemcpyAsync(ctx->d_stage.p, rows, (size_t)count * 4, hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(subset_rows_kernel, dim3(std::min(1024, (count * kDim + 255) / 256)), dim3(256), 0, ctx->stream,
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_stage.p, rows, (size_t)count * 4, hipMemcpyHostToDevice, SC.stream));
+    hipLaunchKernelGGL(subset_rows_kernel, dim3(std::min(1024, (count * kDim + 255) / 256)), dim3(256), 0, SC.stream,
                        (const float*)ctx->images[src_image_id].raw, (const int*)ctx->d_stage.as<int>(), im.raw, count);
     HIPCHK(ctx, hipGetLastError());
     return build_image(ctx, im, nullptr, ctx->images[src_image_id].is_u8);   // rows of a byte image are bytes
@@ -1309,7 +1384,7 @@ int msfm_image_rows(const msfm_ctx* ctx, int image_id, int* out_n) {
 int msfm_clear_images(msfm_ctx* ctx) {
     if (!ctx) return MSFM_E_INVALID;
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(SC.stream));
     for (auto& im : ctx->images) free_image(im);
     return MSFM_OK;
 }
@@ -1317,10 +1392,69 @@ int msfm_clear_images(msfm_ctx* ctx) {
 // An error return may leave launches of the failed batch in flight: drain the stream before handing control back, so
 // that the caller can free or reuse its buffers and a following call starts from an idle stream.
 static int drained(msfm_ctx* ctx, int rc) {
-    if (rc != MSFM_OK && ctx && ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (rc != MSFM_OK && ctx) {
+        for (Scratch& sc : ctx->sc)
+            if (sc.stream) (void)hipStreamSynchronize(sc.stream);
+        ctx->cur = &ctx->sc[0];
+    }
     return rc;
 }
 
+namespace {
+
+// host state of one sub-batch in flight (parallel to ctx->sc[slot])
+struct SubBatch {
+    bool active = false;
+    Batch b;
+    int begin = 0, end = 0;
+    size_t ev_base = 0;
+    bool exact_launched = false;
+};
+
+void add_profile(msfm_profile& to, const msfm_profile& d) {
+    to.dist_kernel_ms += d.dist_kernel_ms;
+    to.dist_kernel_launches += d.dist_kernel_launches;
+    to.descriptor_pairs += d.descriptor_pairs;
+    to.dist_algo_bytes += d.dist_algo_bytes;
+    to.approx_kernel_ms += d.approx_kernel_ms;
+    to.approx_kernel_launches += d.approx_kernel_launches;
+    to.prefilter_pairs += d.prefilter_pairs;
+    to.fallback_pairs += d.fallback_pairs;
+    to.candidates += d.candidates;
+    to.prefilter_descriptor_pairs += d.prefilter_descriptor_pairs;
+    to.exact_descriptor_pairs += d.exact_descriptor_pairs;
+    to.tie_rows += d.tie_rows;
+    to.sweep2_ms += d.sweep2_ms;
+    to.sweep2_launches += d.sweep2_launches;
+    to.compacted_pairs += d.compacted_pairs;
+    to.sweep2_descriptor_pairs += d.sweep2_descriptor_pairs;
+    to.verify_ms += d.verify_ms;
+    to.sub_batches += d.sub_batches;
+    to.tie_queue_regrows += d.tie_queue_regrows;
+    to.plan_regrows += d.plan_regrows;
+    to.sweep1_i8_launches += d.sweep1_i8_launches;
+    to.order_sensitive_rows += d.order_sensitive_rows;
+}
+
+int drain_streams(msfm_ctx* ctx) {
+    for (Scratch& s : ctx->sc) HIPCHK(ctx, hipStreamSynchronize(s.stream));
+    return MSFM_OK;
+}
+
+}  // namespace
+
+// msfm_match_pairs / msfm_match_pairs_verified.  The call is cut into device sub-batches (memory, pair count, and -- for
+// a large call -- at least ctx->pipeline of them); sub-batch k + 1 is LAUNCHED on the other stream / scratch set before
+// the host waits for sub-batch k, so that the bandwidth-bound tail of k runs under sweep 1 of k + 1:
+//
+//      issue(0)  issue(1) complete(0)  issue(2) complete(1)  issue(3) complete(2)  ...  complete(last)
+//
+// issue(k)    = every launch of the sub-batch (sweeps, plan, exact re-check, epilogue, [verification], CSR gather into the
+//               scratch set's own list buffer) + the copies of the words the host needs into page-locked memory;
+// complete(k) = wait for k's stream; a queue / plan buffer was too small -> drain everything, re-run k alone (grown by
+//               then), carry on behind it; else append k's lists to the call's lists (device-to-device for
+//               msfm_fetch_matches_device, device-to-host into the page-locked result buffers: asynchronous, on k's stream).
+// Results do not depend on the cut (tests force it every which way).
 static int match_pairs_impl(msfm_ctx* ctx, const int32_t* pairs, int n_pairs, const msfm_match_params* params,
                             const msfm_verify_params* verify, int64_t* out_offsets) {
     if (!ctx) return MSFM_E_INVALID;
@@ -1333,8 +1467,12 @@ static int match_pairs_impl(msfm_ctx* ctx, const int32_t* pairs, int n_pairs, co
     if (!(prm.ratio > 0.f) || !(prm.ratio <= 1.f)) prune.ratio = 0.f;  // outside (0, 1]: no ratio-based pruning
     if (!(prm.max_distance >= 0.0)) prune.max_distance = __builtin_huge_valf();  // NaN / negative: no distance-based pruning
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    ctx->cur = &ctx->sc[0];
     ctx->have_results = false;
-    ctx->pf_pending = msfm_ctx::PfPending{};
+    for (Scratch& s : ctx->sc) {
+        s.pf_pending = PfPending{};
+        s.sweep1_recorded = false;
+    }
     ctx->res_offsets.assign((size_t)n_pairs + 1, 0);
     ctx->res_sens.assign((size_t)n_pairs, 0);
     ctx->res_count = 0;
@@ -1342,23 +1480,34 @@ static int match_pairs_impl(msfm_ctx* ctx, const int32_t* pairs, int n_pairs, co
 
     hipEvent_t ev_begin = get_event(ctx, 0), ev_end = get_event(ctx, 1);
     if (!ev_begin || !ev_end) return fail(ctx, MSFM_E_DEVICE, "hipEventCreate failed");
-    HIPCHK(ctx, hipEventRecord(ev_begin, ctx->stream));
+    HIPCHK(ctx, hipEventRecord(ev_begin, ctx->sc[0].stream));
 
-    // sub-batches bounded by the partial-result scratch (12 B per partial entry) and a pair count
-    const long long kScratchElems = ctx->scratch_elems;
+    // ---- the cut: scratch memory per set, pair count, and a cost limit that gives a large call >= `pipeline` sub-batches
+    const long long kScratchElems = std::max<long long>(1, ctx->scratch_elems / 2);   // two scratch sets share the budget
     const int kMaxPairsPerBatch = ctx->max_pairs_per_batch;
+    long long cost_limit = 0;   // 0: none
+    if (ctx->pipeline > 1 && n_pairs > 1) {
+        long long total = 0;
+        for (int k = 0; k < n_pairs; ++k) {
+            const int i = pairs[2 * k], j = pairs[2 * k + 1];
+            if (i < 0 || i >= kSlots || j < 0 || j >= kSlots) return fail(ctx, MSFM_E_INVALID, "image id out of range");
+            const long long n1 = ctx->images[i].n, n2 = ctx->images[j].n;
+            if (n1 > 0 && n2 > 0) total += n1 * n2;
+        }
+        const long long n_sub = std::min<long long>(ctx->pipeline, total / kMinPipelineCost);
+        if (n_sub >= 2) cost_limit = (total + n_sub - 1) / n_sub;
+    }
     // a tie in sqrt space can only surface in a match list when a row with d0 == d1 can pass the ratio test
     const bool need_fix = !(prm.ratio <= 1.f);
-    size_t ev_next = 2;
-    int begin = 0;
-    while (begin < n_pairs) {
-      int end = begin;
-      std::vector<char> force_exact;   // pairs of this sub-batch whose candidate list overflowed: brute-force path in the re-run
-      msfm_profile prof_at_batch = ctx->prof;
-      for (int attempt = 0;; ++attempt) {   // a sub-batch is re-run when a queue / plan buffer was too small (grown by then)
-        Batch b;
-        long long est = 0;
-        end = begin;
+
+    SubBatch sb[2];
+    // pairs [begin, ...) -> sb.b (host tables); force_exact: pairs of this sub-batch whose candidate list overflowed in an
+    // earlier attempt take the brute-force path
+    auto build = [&](SubBatch& w, int begin, const std::vector<char>& force_exact) -> int {
+        w.b = Batch{};
+        w.begin = begin;
+        long long est = 0, cost = 0;
+        int end = begin;
         while (end < n_pairs && (end - begin) < kMaxPairsPerBatch) {
             PairDesc pd;
             PfPair pp;
@@ -1374,143 +1523,221 @@ static int match_pairs_impl(msfm_ctx* ctx, const int32_t* pairs, int n_pairs, co
             // partial-result scratch of the larger of the two paths (prefilter: 2x slots + candidates)
             const long long need = pd.valid ? ((long long)pd.n1pad + 2 * (long long)pd.a_blocks * pd.n2pad +
                                                3 * (8LL * (pd.n1 + pd.n2) + 1024)) : 0;
+            const long long c = pd.valid ? (long long)pd.n1 * pd.n2 : 0;
             if (end > begin && est + need > kScratchElems) break;
+            if (end > begin && cost_limit > 0 && cost + c > cost_limit) break;
             est += need;
-            const size_t k = b.pairs.size();
+            cost += c;
+            const size_t k = w.b.pairs.size();
             if (k < force_exact.size() && force_exact[k]) {
                 pp.use = 0;
                 pd.path = 0;
             }
-            b.pairs.push_back(pd);
-            b.pf.push_back(pp);
-            b.id1.push_back(pairs[2 * end]);
-            b.id2.push_back(pairs[2 * end + 1]);
+            w.b.pairs.push_back(pd);
+            w.b.pf.push_back(pp);
+            w.b.id1.push_back(pairs[2 * end]);
+            w.b.id2.push_back(pairs[2 * end + 1]);
             ++end;
         }
-        force_exact.resize(b.pairs.size(), 0);
-        const size_t P = b.pairs.size();
-        const size_t ev_base = ev_next;
-        if (attempt == 0) ev_next += 8;
-        if (attempt == 0) prof_at_batch = ctx->prof;
-        else {   // a re-run: times / launches / work of the dropped attempt do not count, the re-run counters do
-            msfm_profile keep = prof_at_batch;
-            keep.tie_queue_regrows = ctx->prof.tie_queue_regrows;
-            keep.plan_regrows = ctx->prof.plan_regrows;
-            keep.fallback_pairs = ctx->prof.fallback_pairs;
-            ctx->prof = keep;
-        }
-        bool exact_launched = false;
-        int rc = run_knn(ctx, b, ev_base, &exact_launched, prune, need_fix);
-        if (rc != MSFM_OK) return rc;
+        w.end = end;
+        return MSFM_OK;
+    };
 
-        HIPCHK(ctx, ctx->d_st_qt.ensure(std::max<long long>(1, b.out_elems) * sizeof(int2)));
-        HIPCHK(ctx, ctx->d_st_d.ensure(std::max<long long>(1, b.out_elems) * 4));
-        // the lists of the whole call stay on the device too (msfm_fetch_matches_device): this sub-batch appends
-        // at most out_elems matches behind the res_count already there
-        const size_t base = ctx->res_count;
-        HIPCHK(ctx, ctx->d_out_qt.ensure_keep((base + (size_t)std::max<long long>(1, b.out_elems)) * sizeof(int2), base * sizeof(int2), ctx->stream));
-        HIPCHK(ctx, ctx->d_out_d.ensure_keep((base + (size_t)std::max<long long>(1, b.out_elems)) * 4, base * 4, ctx->stream));
-        HIPCHK(ctx, ctx->d_counts.ensure(P * 4));
-        HIPCHK(ctx, ctx->d_sens.ensure(P * 4));
-        HIPCHK(ctx, ctx->d_offsets.ensure((P + 1) * 8));
+    // every launch of the sub-batch on the CURRENT scratch set (ctx->cur), nothing waits
+    auto issue = [&](SubBatch& w, size_t ev_base) -> int {
+        Batch& b = w.b;
+        const size_t P = b.pairs.size();
+        const int begin = w.begin;
+        w.ev_base = ev_base;
+        w.exact_launched = false;
+        SC.prof = msfm_profile{};
+        int rc = run_knn(ctx, b, ev_base, &w.exact_launched, prune, need_fix);
+        if (rc != MSFM_OK) return rc;
+        const long long oe = std::max<long long>(1, b.out_elems);
+        HIPCHK(ctx, SC.d_st_qt.ensure(oe * sizeof(int2)));
+        HIPCHK(ctx, SC.d_st_d.ensure(oe * 4));
+        HIPCHK(ctx, SC.d_sub_qt.ensure(oe * sizeof(int2)));
+        HIPCHK(ctx, SC.d_sub_d.ensure(oe * 4));
+        HIPCHK(ctx, SC.d_counts.ensure(P * 4));
+        HIPCHK(ctx, SC.d_sens.ensure(P * 4));
+        HIPCHK(ctx, SC.d_offsets.ensure((P + 1) * 8));
         EpiParams ep = {prm.ratio, prm.cross_check, prm.max_distance};
-        hipLaunchKernelGGL(epilogue_kernel, dim3((unsigned)P), dim3(256), 0, ctx->stream, ctx->d_pairs.as<PairDesc>(), ep,
-                           ctx->d_k_i0.as<int>(), ctx->d_k_d0.as<float>(), ctx->d_k_d1.as<float>(),
-                           ctx->d_st_qt.as<int2>(), ctx->d_st_d.as<float>(), ctx->d_counts.as<int>(), ctx->d_sens.as<int>());
+        hipLaunchKernelGGL(epilogue_kernel, dim3((unsigned)P), dim3(256), 0, SC.stream, SC.d_pairs.as<PairDesc>(), ep,
+                           SC.d_k_i0.as<int>(), SC.d_k_d0.as<float>(), SC.d_k_d1.as<float>(),
+                           SC.d_st_qt.as<int2>(), SC.d_st_d.as<float>(), SC.d_counts.as<int>(), SC.d_sens.as<int>());
         HIPCHK(ctx, hipGetLastError());
-        const int* d_counts = ctx->d_counts.as<int>();
-        const int2* d_st_qt = ctx->d_st_qt.as<int2>();
-        const float* d_st_d = ctx->d_st_d.as<float>();
+        const int* d_counts = SC.d_counts.as<int>();
+        const int2* d_st_qt = SC.d_st_qt.as<int2>();
+        const float* d_st_d = SC.d_st_d.as<float>();
         if (verify) {
             // FeatureUtils::FilterMatches on the staged lists: all hypotheses of all pairs at once
             VerifyParams vprm = {verify->threshold * verify->threshold, verify->confidence, verify->max_iters, 0, verify->seed};
-            const long long oe = std::max<long long>(1, b.out_elems);
             std::vector<VerifyPair> vpairs(P);
             for (size_t p = 0; p < P; ++p)
                 vpairs[p] = VerifyPair{ctx->images[pairs[2 * (begin + (int)p)]].kxy, ctx->images[pairs[2 * (begin + (int)p) + 1]].kxy};
-            HIPCHK(ctx, ctx->d_vf_pairs.ensure(P * sizeof(VerifyPair)));
-            HIPCHK(ctx, ctx->d_vf_x1.ensure(oe * 4));
-            HIPCHK(ctx, ctx->d_vf_y1.ensure(oe * 4));
-            HIPCHK(ctx, ctx->d_vf_x2.ensure(oe * 4));
-            HIPCHK(ctx, ctx->d_vf_y2.ensure(oe * 4));
-            HIPCHK(ctx, ctx->d_vf_flags.ensure(oe));
-            HIPCHK(ctx, ctx->d_vf_hyp.ensure(P * (size_t)vprm.max_iters * 4));
-            HIPCHK(ctx, ctx->d_vf_best_it.ensure(P * 4));
-            HIPCHK(ctx, ctx->d_vf_best_count.ensure(P * 4));
-            HIPCHK(ctx, ctx->d_st2_qt.ensure(oe * sizeof(int2)));
-            HIPCHK(ctx, ctx->d_st2_d.ensure(oe * 4));
-            HIPCHK(ctx, ctx->d_counts2.ensure(P * 4));
-            HIPCHK(ctx, hipMemcpyAsync(ctx->d_vf_pairs.p, vpairs.data(), P * sizeof(VerifyPair), hipMemcpyHostToDevice, ctx->stream));
+            HIPCHK(ctx, SC.d_vf_pairs.ensure(P * sizeof(VerifyPair)));
+            HIPCHK(ctx, SC.d_vf_x1.ensure(oe * 4));
+            HIPCHK(ctx, SC.d_vf_y1.ensure(oe * 4));
+            HIPCHK(ctx, SC.d_vf_x2.ensure(oe * 4));
+            HIPCHK(ctx, SC.d_vf_y2.ensure(oe * 4));
+            HIPCHK(ctx, SC.d_vf_flags.ensure(oe));
+            HIPCHK(ctx, SC.d_vf_hyp.ensure(P * (size_t)vprm.max_iters * 4));
+            HIPCHK(ctx, SC.d_vf_best_it.ensure(P * 4));
+            HIPCHK(ctx, SC.d_vf_best_count.ensure(P * 4));
+            HIPCHK(ctx, SC.d_st2_qt.ensure(oe * sizeof(int2)));
+            HIPCHK(ctx, SC.d_st2_d.ensure(oe * 4));
+            HIPCHK(ctx, SC.d_counts2.ensure(P * 4));
+            HIPCHK(ctx, hipMemcpyAsync(SC.d_vf_pairs.p, vpairs.data(), P * sizeof(VerifyPair), hipMemcpyHostToDevice, SC.stream));
             hipEvent_t v0 = get_event(ctx, ev_base + 6), v1 = get_event(ctx, ev_base + 7);
             if (!v0 || !v1) return fail(ctx, MSFM_E_DEVICE, "hipEventCreate failed");
-            HIPCHK(ctx, hipEventRecord(v0, ctx->stream));
-            const PairDesc* dp = ctx->d_pairs.as<PairDesc>();
-            float *x1 = ctx->d_vf_x1.as<float>(), *y1 = ctx->d_vf_y1.as<float>(), *x2 = ctx->d_vf_x2.as<float>(), *y2 = ctx->d_vf_y2.as<float>();
-            hipLaunchKernelGGL(vf_points_kernel, dim3((unsigned)P), dim3(256), 0, ctx->stream, dp, ctx->d_vf_pairs.as<VerifyPair>(),
+            HIPCHK(ctx, hipEventRecord(v0, SC.stream));
+            const PairDesc* dp = SC.d_pairs.as<PairDesc>();
+            float *x1 = SC.d_vf_x1.as<float>(), *y1 = SC.d_vf_y1.as<float>(), *x2 = SC.d_vf_x2.as<float>(), *y2 = SC.d_vf_y2.as<float>();
+            hipLaunchKernelGGL(vf_points_kernel, dim3((unsigned)P), dim3(256), 0, SC.stream, dp, SC.d_vf_pairs.as<VerifyPair>(),
                                d_counts, d_st_qt, x1, y1, x2, y2);
             HIPCHK(ctx, hipGetLastError());
-            hipLaunchKernelGGL(vf_hypotheses_kernel, dim3((unsigned)((vprm.max_iters + 255) / 256), (unsigned)P), dim3(256), 0, ctx->stream,
+            hipLaunchKernelGGL(vf_hypotheses_kernel, dim3((unsigned)((vprm.max_iters + 255) / 256), (unsigned)P), dim3(256), 0, SC.stream,
                                dp, d_counts, (const float*)x1, (const float*)y1, (const float*)x2, (const float*)y2,
-                               ctx->d_vf_hyp.as<int>(), vprm);
+                               SC.d_vf_hyp.as<int>(), vprm);
             HIPCHK(ctx, hipGetLastError());
-            hipLaunchKernelGGL(vf_select_kernel, dim3((unsigned)((P + 63) / 64)), dim3(64), 0, ctx->stream, d_counts,
-                               (const int*)ctx->d_vf_hyp.as<int>(), (int)P, vprm, ctx->d_vf_best_it.as<int>(), ctx->d_vf_best_count.as<int>());
+            hipLaunchKernelGGL(vf_select_kernel, dim3((unsigned)((P + 63) / 64)), dim3(64), 0, SC.stream, d_counts,
+                               (const int*)SC.d_vf_hyp.as<int>(), (int)P, vprm, SC.d_vf_best_it.as<int>(), SC.d_vf_best_count.as<int>());
             HIPCHK(ctx, hipGetLastError());
-            hipLaunchKernelGGL(vf_mask_compact_kernel, dim3((unsigned)P), dim3(256), 0, ctx->stream, dp, d_counts, d_st_qt, d_st_d,
+            hipLaunchKernelGGL(vf_mask_compact_kernel, dim3((unsigned)P), dim3(256), 0, SC.stream, dp, d_counts, d_st_qt, d_st_d,
                                (const float*)x1, (const float*)y1, (const float*)x2, (const float*)y2,
-                               (const int*)ctx->d_vf_best_it.as<int>(), (const int*)ctx->d_vf_best_count.as<int>(),
-                               ctx->d_vf_flags.as<unsigned char>(), vprm, ctx->d_st2_qt.as<int2>(), ctx->d_st2_d.as<float>(),
-                               ctx->d_counts2.as<int>());
+                               (const int*)SC.d_vf_best_it.as<int>(), (const int*)SC.d_vf_best_count.as<int>(),
+                               SC.d_vf_flags.as<unsigned char>(), vprm, SC.d_st2_qt.as<int2>(), SC.d_st2_d.as<float>(),
+                               SC.d_counts2.as<int>());
             HIPCHK(ctx, hipGetLastError());
-            HIPCHK(ctx, hipEventRecord(v1, ctx->stream));
-            d_counts = ctx->d_counts2.as<int>();
-            d_st_qt = ctx->d_st2_qt.as<int2>();
-            d_st_d = ctx->d_st2_d.as<float>();
+            HIPCHK(ctx, hipEventRecord(v1, SC.stream));
+            d_counts = SC.d_counts2.as<int>();
+            d_st_qt = SC.d_st2_qt.as<int2>();
+            d_st_d = SC.d_st2_d.as<float>();
         }
-        hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(256), 0, ctx->stream, d_counts,
-                           ctx->d_offsets.as<long long>(), (int)P);
+        hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(256), 0, SC.stream, d_counts,
+                           SC.d_offsets.as<long long>(), (int)P);
         HIPCHK(ctx, hipGetLastError());
-        hipLaunchKernelGGL(gather_kernel, dim3((unsigned)P), dim3(256), 0, ctx->stream, ctx->d_pairs.as<PairDesc>(),
-                           d_counts, ctx->d_offsets.as<long long>(), d_st_qt,
-                           d_st_d, ctx->d_out_qt.as<int2>() + base, ctx->d_out_d.as<float>() + base);
+        // CSR order, into this scratch set's own list buffer: where the lists go in the call's buffers is only known when
+        // the sub-batches before this one have been completed
+        hipLaunchKernelGGL(gather_kernel, dim3((unsigned)P), dim3(256), 0, SC.stream, SC.d_pairs.as<PairDesc>(),
+                           d_counts, SC.d_offsets.as<long long>(), d_st_qt,
+                           d_st_d, SC.d_sub_qt.as<int2>(), SC.d_sub_d.as<float>());
         HIPCHK(ctx, hipGetLastError());
+        rc = queue_tail_copies(ctx, P);
+        if (rc != MSFM_OK) return rc;
+        w.active = true;
+        return MSFM_OK;
+    };
 
-        std::vector<long long> offs(P + 1);
-        HIPCHK(ctx, hipMemcpyAsync(offs.data(), ctx->d_offsets.p, (P + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(ctx, hipMemcpyAsync(ctx->res_sens.data() + begin, ctx->d_sens.p, P * 4, hipMemcpyDeviceToHost, ctx->stream));
+    // wait for the sub-batch of the CURRENT scratch set; *retry: a queue / plan buffer was too small (grown by now)
+    auto complete = [&](SubBatch& w, std::vector<char>& force_exact, bool* retry_out) -> int {
+        Batch& b = w.b;
+        const size_t P = b.pairs.size();
+        w.active = false;
+        *retry_out = false;
+        HIPCHK(ctx, hipStreamSynchronize(SC.stream));
         bool retry = false, retry_pf = false;
-        rc = check_fix_overflow(ctx, &retry);  // synchronises the stream
+        force_exact.resize(P, 0);
+        int rc = check_fix_overflow(ctx, &retry);
         if (rc != MSFM_OK) return rc;
         rc = finish_prefilter(ctx, b, force_exact, &retry_pf);
         if (rc != MSFM_OK) return rc;
-        if ((retry || retry_pf) && attempt < 6) continue;
-        if (retry || retry_pf) return fail(ctx, MSFM_E_DEVICE, "batch kept overflowing its queues");
-        ctx->prof.descriptor_pairs += b.desc_pairs;
-        ctx->prof.dist_algo_bytes += b.algo_bytes;
-        const long long total = offs[P];
-        HIPCHK(ctx, ctx->res_qt.ensure((base + (size_t)total + 1) * 8, base * 8));
-        HIPCHK(ctx, ctx->res_dist.ensure((base + (size_t)total + 1) * 4, base * 4));
-        ctx->res_count = base + (size_t)total;
-        if (total > 0) {
-            HIPCHK(ctx, hipMemcpyAsync(ctx->res_qt.as<int32_t>() + 2 * base, ctx->d_out_qt.as<int2>() + base, (size_t)total * 8, hipMemcpyDeviceToHost, ctx->stream));
-            HIPCHK(ctx, hipMemcpyAsync(ctx->res_dist.as<float>() + base, ctx->d_out_d.as<float>() + base, (size_t)total * 4, hipMemcpyDeviceToHost, ctx->stream));
-            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        if (retry || retry_pf) {   // only the re-run counters of a dropped attempt count
+            ctx->prof.tie_queue_regrows += SC.prof.tie_queue_regrows;
+            ctx->prof.plan_regrows += SC.prof.plan_regrows;
+            ctx->prof.fallback_pairs += SC.prof.fallback_pairs;
+            *retry_out = true;
+            return MSFM_OK;
         }
-        for (size_t p = 0; p < P; ++p) ctx->res_offsets[(size_t)begin + p + 1] = (int64_t)base + offs[p + 1];
-        for (size_t p = 0; p < P; ++p) ctx->prof.order_sensitive_rows += ctx->res_sens[(size_t)begin + p];
-        rc = accumulate_kernel_time(ctx, ev_base, exact_launched);
+        SC.prof.fallback_pairs = 0;   // (counted when the attempt that found them was dropped)
+        const char* h = SC.h_tail.as<char>();
+        const long long* offs = reinterpret_cast<const long long*>(h + 8);
+        const int32_t* sens = reinterpret_cast<const int32_t*>(h + 8 + (P + 1) * 8);
+        const long long total = offs[P];
+        const size_t base = ctx->res_count;
+        // the call's lists: grown with the end of the call in mind (matches per pair so far x pairs to come), so that a call
+        // of a hundred sub-batches re-allocates -- and re-pins gigabytes of host memory -- once or twice, not a dozen times
+        const size_t need = base + (size_t)total + 1;
+        if (need * 8 > ctx->res_qt.cap || need * 4 > ctx->res_dist.cap || need * 8 > ctx->d_out_qt.cap || need * 4 > ctx->d_out_d.cap) {
+            rc = drain_streams(ctx);   // copies of earlier sub-batches may still be writing into the buffers that move
+            if (rc != MSFM_OK) return rc;
+            const double per_pair = (double)(base + (size_t)total) / (double)std::max(1, w.end);
+            const size_t hint = (size_t)(per_pair * (double)n_pairs * 1.08) + 4096;
+            HIPCHK(ctx, ctx->res_qt.ensure(need * 8, base * 8, hint * 8));
+            HIPCHK(ctx, ctx->res_dist.ensure(need * 4, base * 4, hint * 4));
+            HIPCHK(ctx, ctx->d_out_qt.ensure_keep(need * sizeof(int2), base * sizeof(int2), SC.stream, hint * sizeof(int2)));
+            HIPCHK(ctx, ctx->d_out_d.ensure_keep(need * 4, base * 4, SC.stream, hint * 4));
+        }
+        if (total > 0) {
+            HIPCHK(ctx, hipMemcpyAsync(ctx->res_qt.as<int32_t>() + 2 * base, SC.d_sub_qt.p, (size_t)total * 8, hipMemcpyDeviceToHost, SC.stream));
+            HIPCHK(ctx, hipMemcpyAsync(ctx->res_dist.as<float>() + base, SC.d_sub_d.p, (size_t)total * 4, hipMemcpyDeviceToHost, SC.stream));
+            HIPCHK(ctx, hipMemcpyAsync(ctx->d_out_qt.as<int2>() + base, SC.d_sub_qt.p, (size_t)total * 8, hipMemcpyDeviceToDevice, SC.stream));
+            HIPCHK(ctx, hipMemcpyAsync(ctx->d_out_d.as<float>() + base, SC.d_sub_d.p, (size_t)total * 4, hipMemcpyDeviceToDevice, SC.stream));
+        }
+        ctx->res_count = base + (size_t)total;
+        for (size_t p = 0; p < P; ++p) {
+            ctx->res_offsets[(size_t)w.begin + p + 1] = (int64_t)base + offs[p + 1];
+            ctx->res_sens[(size_t)w.begin + p] = sens[p];
+            SC.prof.order_sensitive_rows += sens[p];
+        }
+        SC.prof.descriptor_pairs += b.desc_pairs;
+        SC.prof.dist_algo_bytes += b.algo_bytes;
+        rc = accumulate_kernel_time(ctx, w.ev_base, w.exact_launched);
         if (rc != MSFM_OK) return rc;
         if (verify) {
             float vms = 0.f;
-            HIPCHK(ctx, hipEventElapsedTime(&vms, ctx->ev_pool[ev_base + 6], ctx->ev_pool[ev_base + 7]));
-            ctx->prof.verify_ms += vms;
+            HIPCHK(ctx, hipEventElapsedTime(&vms, ctx->ev_pool[w.ev_base + 6], ctx->ev_pool[w.ev_base + 7]));
+            SC.prof.verify_ms += vms;
         }
-        ctx->prof.sub_batches += 1;
-        break;
-      }
-      begin = end;
+        SC.prof.sub_batches += 1;
+        add_profile(ctx->prof, SC.prof);
+        return MSFM_OK;
+    };
+
+    const std::vector<char> no_force;
+    int next_begin = 0, slot = 0;
+    while (next_begin < n_pairs || sb[0].active || sb[1].active) {
+        if (next_begin < n_pairs && !sb[slot].active) {
+            ctx->cur = &ctx->sc[slot];
+            int rc = build(sb[slot], next_begin, no_force);
+            if (rc != MSFM_OK) return rc;
+            rc = issue(sb[slot], 2 + 8 * (size_t)slot);
+            if (rc != MSFM_OK) return rc;
+            next_begin = sb[slot].end;
+        }
+        const int other = slot ^ 1;
+        if (sb[other].active) {
+            ctx->cur = &ctx->sc[other];
+            std::vector<char> force_exact;
+            bool retry = false;
+            int rc = complete(sb[other], force_exact, &retry);
+            if (rc != MSFM_OK) return rc;
+            if (retry) {
+                // drop what is in flight behind it, re-run this sub-batch alone until it fits, carry on from its end
+                rc = drain_streams(ctx);
+                if (rc != MSFM_OK) return rc;
+                sb[slot].active = false;
+                ctx->sc[slot].pf_pending = PfPending{};
+                ctx->sc[slot].sweep1_recorded = false;
+                for (int attempt = 1;; ++attempt) {
+                    rc = build(sb[other], sb[other].begin, force_exact);
+                    if (rc != MSFM_OK) return rc;
+                    rc = issue(sb[other], 2 + 8 * (size_t)other);
+                    if (rc != MSFM_OK) return rc;
+                    rc = complete(sb[other], force_exact, &retry);
+                    if (rc != MSFM_OK) return rc;
+                    if (!retry) break;
+                    if (attempt >= 6) return fail(ctx, MSFM_E_DEVICE, "batch kept overflowing its queues");
+                }
+                next_begin = sb[other].end;
+            }
+        }
+        slot = other;
     }
-    HIPCHK(ctx, hipEventRecord(ev_end, ctx->stream));
+    int rc = drain_streams(ctx);
+    if (rc != MSFM_OK) return rc;
+    ctx->cur = &ctx->sc[0];
+    HIPCHK(ctx, hipEventRecord(ev_end, SC.stream));
     HIPCHK(ctx, hipEventSynchronize(ev_end));
     float ms = 0.f;
     HIPCHK(ctx, hipEventElapsedTime(&ms, ev_begin, ev_end));
@@ -1548,8 +1775,8 @@ int msfm_upload_keypoints(msfm_ctx* ctx, int image_id, const float* kpts, int n,
     std::vector<float2> xy((size_t)std::max(n, 1));
     for (int i = 0; i < n; ++i) xy[(size_t)i] = make_float2(kpts[(size_t)i * stride_floats], kpts[(size_t)i * stride_floats + 1]);
     HIPCHK(ctx, hipMalloc((void**)&im.kxy, xy.size() * sizeof(float2)));
-    HIPCHK(ctx, hipMemcpyAsync(im.kxy, xy.data(), xy.size() * sizeof(float2), hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(im.kxy, xy.data(), xy.size() * sizeof(float2), hipMemcpyHostToDevice, SC.stream));
+    HIPCHK(ctx, hipStreamSynchronize(SC.stream));
     im.nk = n;
     return MSFM_OK;
 }
@@ -1567,10 +1794,10 @@ int msfm_fetch_matches_device(msfm_ctx* ctx, int32_t* d_out_qt, float* d_out_dis
     if (!ctx->have_results) return fail(ctx, MSFM_E_STATE, "msfm_fetch_matches_device without a completed msfm_match_pairs");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     if (d_out_qt && ctx->res_count)
-        HIPCHK(ctx, hipMemcpyAsync(d_out_qt, ctx->d_out_qt.p, ctx->res_count * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(d_out_qt, ctx->d_out_qt.p, ctx->res_count * 8, hipMemcpyDeviceToDevice, SC.stream));
     if (d_out_dist && ctx->res_count)
-        HIPCHK(ctx, hipMemcpyAsync(d_out_dist, ctx->d_out_d.p, ctx->res_count * 4, hipMemcpyDeviceToDevice, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(d_out_dist, ctx->d_out_d.p, ctx->res_count * 4, hipMemcpyDeviceToDevice, SC.stream));
+    HIPCHK(ctx, hipStreamSynchronize(SC.stream));
     return MSFM_OK;
 }
 
@@ -1614,8 +1841,12 @@ int msfm_knn2_pair(msfm_ctx* ctx, int id1, int id2, int32_t* fwd_idx0, float* fw
 static int knn2_pair_impl(msfm_ctx* ctx, int id1, int id2, int32_t* fwd_idx0, float* fwd_d0, float* fwd_d1,
                           int32_t* rev_idx0, float* rev_d0, float* rev_d1) {
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    ctx->cur = &ctx->sc[0];
     ctx->prof = msfm_profile{};
-    ctx->pf_pending = msfm_ctx::PfPending{};   // (a failed earlier batch may have left its end-of-batch state behind)
+    for (Scratch& sc : ctx->sc) {   // (a failed earlier batch may have left its end-of-batch state behind)
+        sc.pf_pending = PfPending{};
+        sc.sweep1_recorded = false;
+    }
     Batch b;
     PairDesc pd;
     PfPair pp;
@@ -1633,9 +1864,12 @@ static int knn2_pair_impl(msfm_ctx* ctx, int id1, int id2, int32_t* fwd_idx0, fl
         b.rp_elems = b.cp_elems = b.kf_elems = b.kr_elems = b.out_elems = b.cand_elems = 0;
         b.desc_pairs = b.algo_bytes = 0;
         b.pairs[0].path = b.pf[0].use = force_exact[0] ? 0 : pp.use;
-        ctx->prof = msfm_profile{};
+        SC.prof = msfm_profile{};   // only the attempt that is kept counts
         rc = run_knn(ctx, b, 2, &exact_launched, PruneParams{0, 0.f, 0.f}, true);  // knnMatch twin: every row keeps its neighbours
         if (rc != MSFM_OK) return rc;
+        HIPCHK(ctx, SC.h_tail.ensure(64, 0));
+        HIPCHK(ctx, hipMemcpyAsync(SC.h_tail.p, SC.d_fix_count.p, 4, hipMemcpyDeviceToHost, SC.stream));
+        HIPCHK(ctx, hipStreamSynchronize(SC.stream));
         bool retry = false, retry_pf = false;
         rc = check_fix_overflow(ctx, &retry);
         if (rc != MSFM_OK) return rc;
@@ -1643,16 +1877,17 @@ static int knn2_pair_impl(msfm_ctx* ctx, int id1, int id2, int32_t* fwd_idx0, fl
         if (rc != MSFM_OK) return rc;
         if (!retry && !retry_pf) break;
         if (retry) ++regrows;
-        if (retry_pf) fallbacks += ctx->prof.fallback_pairs;
+        if (retry_pf) fallbacks += SC.prof.fallback_pairs;
         if (attempt >= 6) return fail(ctx, MSFM_E_DEVICE, "batch kept overflowing its queues");
     }
+    rc = accumulate_kernel_time(ctx, 2, exact_launched);
+    if (rc != MSFM_OK) return rc;
+    ctx->prof = SC.prof;
     ctx->prof.tie_queue_regrows = regrows;
     ctx->prof.fallback_pairs = fallbacks;
     ctx->prof.sub_batches = 1;
     ctx->prof.descriptor_pairs += b.desc_pairs;
     ctx->prof.dist_algo_bytes += b.algo_bytes;
-    rc = accumulate_kernel_time(ctx, 2, exact_launched);
-    if (rc != MSFM_OK) return rc;
     const PairDesc& q = b.pairs[0];
     const int n1 = ctx->images[id1].n, n2 = ctx->images[id2].n;
     if (!q.valid) {
@@ -1670,13 +1905,13 @@ static int knn2_pair_impl(msfm_ctx* ctx, int id1, int id2, int32_t* fwd_idx0, fl
         return MSFM_OK;
     }
     struct Cp { void* dst; const DevBuf* src; long long off; int n; };
-    const Cp cps[6] = {{fwd_idx0, &ctx->d_k_i0, q.kf_off, n1}, {fwd_d0, &ctx->d_k_d0, q.kf_off, n1},
-                       {fwd_d1, &ctx->d_k_d1, q.kf_off, n1},   {rev_idx0, &ctx->d_k_i0, q.kr_off, n2},
-                       {rev_d0, &ctx->d_k_d0, q.kr_off, n2},   {rev_d1, &ctx->d_k_d1, q.kr_off, n2}};
+    const Cp cps[6] = {{fwd_idx0, &SC.d_k_i0, q.kf_off, n1}, {fwd_d0, &SC.d_k_d0, q.kf_off, n1},
+                       {fwd_d1, &SC.d_k_d1, q.kf_off, n1},   {rev_idx0, &SC.d_k_i0, q.kr_off, n2},
+                       {rev_d0, &SC.d_k_d0, q.kr_off, n2},   {rev_d1, &SC.d_k_d1, q.kr_off, n2}};
     for (const Cp& c : cps)
         if (c.dst && c.n > 0)
-            HIPCHK(ctx, hipMemcpyAsync(c.dst, c.src->as<char>() + c.off * 4, (size_t)c.n * 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            HIPCHK(ctx, hipMemcpyAsync(c.dst, c.src->as<char>() + c.off * 4, (size_t)c.n * 4, hipMemcpyDeviceToHost, SC.stream));
+    HIPCHK(ctx, hipStreamSynchronize(SC.stream));
     return MSFM_OK;
 }
 

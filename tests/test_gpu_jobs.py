@@ -114,9 +114,19 @@ def test_config2_full_job_one_launch(gpu_ctx, oracle):
     for i, im in enumerate(imgs):
         gpu_ctx.upload_image(i, im)
     gpu_ctx.set_limits(0, 0)
-    offs, qt, d = gpu_ctx.match_pairs(pairs)
-    p = gpu_ctx.profile()
+    gpu_ctx.set_pipeline(1)
+    try:
+        offs, qt, d = gpu_ctx.match_pairs(pairs)
+        p = gpu_ctx.profile()
+    finally:
+        gpu_ctx.set_pipeline(0)
     assert p["sub_batches"] == 1 and p["approx_kernel_launches"] == 1      # ONE launch per sweep for the whole job
+    # the default: the job cut into 4 sub-batches on two streams (the tail of one under the next one's sweep 1) == the same lists
+    piped = gpu_ctx.match_pairs(pairs)
+    pp_ = gpu_ctx.profile()
+    assert pp_["sub_batches"] == 4 and pp_["approx_kernel_launches"] == 4 and pp_["prefilter_pairs"] == 8128
+    assert pp_["descriptor_pairs"] == p["descriptor_pairs"] and pp_["order_sensitive_rows"] == p["order_sensitive_rows"]
+    assert same_result((offs, qt, d), piped)
     assert p["prefilter_pairs"] == 8128 and p["fallback_pairs"] == 0 and p["compacted_pairs"] > 7000
     n = np.array([len(x) for x in imgs], np.int64)
     assert p["descriptor_pairs"] == int((n[pairs[:, 0]] * n[pairs[:, 1]]).sum())
@@ -148,11 +158,13 @@ def test_config2_full_job_one_launch(gpu_ctx, oracle):
         assert np.array_equal(a[1][a[0][k]:a[0][k + 1]], qt[s:e])
     # the job in 3 sub-batches == the job in one
     gpu_ctx.set_limits(3000, 0)
+    gpu_ctx.set_pipeline(1)
     try:
         split = gpu_ctx.match_pairs(pairs)
         assert gpu_ctx.profile()["sub_batches"] == 3
     finally:
         gpu_ctx.set_limits(0, 0)
+        gpu_ctx.set_pipeline(0)
     assert same_result((offs, qt, d), split)
 
 
@@ -168,19 +180,21 @@ def test_config3_330_images_in_one_call(gpu_ctx, oracle):
     offs, qt, d = offs.copy(), qt.copy(), d.copy()
     p = gpu_ctx.profile()
     assert p["sub_batches"] >= 4 and p["prefilter_pairs"] == 54285 and p["fallback_pairs"] == 0
-    # sampled pairs, biased towards the sub-batch boundaries (multiples of 16384 pairs)
+    # sampled pairs, incl. the former sub-batch boundaries (multiples of 16384 pairs)
     rng = np.random.default_rng(5)
     edge = np.array([0, 16383, 16384, 32767, 32768, 49151, 49152, 54284])
     sel = np.unique(np.concatenate([edge, rng.choice(len(pairs), 24, replace=False)]))
     check_pairs_vs_oracle(oracle, imgs, pairs, sel, offs, qt, d)
     # a different cut of the same job gives the same lists
     gpu_ctx.set_limits(20000, 0)
+    gpu_ctx.set_pipeline(1)
     try:
         again = gpu_ctx.match_pairs(pairs, fetch="view")
         assert gpu_ctx.profile()["sub_batches"] == 3
         assert same_result((offs, qt, d), again)
     finally:
         gpu_ctx.set_limits(0, 0)
+        gpu_ctx.set_pipeline(0)
     gpu_ctx.clear_images()
 
 

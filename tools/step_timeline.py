@@ -1,22 +1,31 @@
-"""One step of the bench job as a timeline: every kernel / device copy between two sweep-1 launches of a rocprofv3
---kernel-trace results database, with its duration and the gap before it.  Usage: python tools/step_timeline.py <results.db>"""
+"""One step of the bench job as a timeline: every kernel / device copy of one step (`launches` consecutive sweep-1
+launches: the step is cut into that many sub-batches on two streams) of a rocprofv3 --kernel-trace results database,
+with start / end relative to the step's first sweep 1, duration, and what else was running when it started.
+Usage: python tools/step_timeline.py <results.db> [sweep-1 launches per step, default 4]"""
 import sqlite3
 import sys
 
 db = sqlite3.connect(sys.argv[1])
+per_step = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 rows = db.execute("select name, start, end from kernels order by start").fetchall()
 idx = [i for i, r in enumerate(rows) if "sweep_kernel<1>" in r[0] and "i8" not in r[0]]
-i0, i1 = idx[-2], idx[-1]
-prev_end, tot_gap, tot = None, 0.0, 0.0
-print("# kernel (or runtime copy / fill kernel)            duration us   gap before us")
+i0, i1 = idx[-1 - per_step], idx[-1]
+t0 = rows[i0][1]
+print("# kernel (or runtime copy / fill kernel)             start ms     end ms   duration us   running at its start")
+busy_until = []
+tot = 0.0
+union_end, union = t0, 0.0
 for r in rows[i0:i1]:
-    name = r[0].split("(")[0]
-    name = name[-44:]
-    gap = (r[1] - prev_end) / 1e3 if prev_end else 0.0
-    tot_gap += max(gap, 0.0)
+    name = r[0].split("(")[0][-44:]
+    live = [n for n, e in busy_until if e > r[1]]
+    print("%-46s %10.3f %10.3f %12.1f   %s" % (name, (r[1] - t0) / 1e6, (r[2] - t0) / 1e6, (r[2] - r[1]) / 1e3,
+                                              ", ".join(sorted(set(x.split("<")[0].split("::")[-1] + ("<" + x.split("<")[1][:2] if "<" in x else "") for x in live))) or "-"))
+    busy_until.append((name, r[2]))
     tot += (r[2] - r[1]) / 1e3
-    print("%-46s %12.1f %12.1f" % (name, (r[2] - r[1]) / 1e3, gap))
-    prev_end = r[2]
-print("# sweep-1 launch to sweep-1 launch: %.3f ms; kernels %.3f ms; gaps %.3f ms (the two large ones at the end are the "
-      "device-to-host copy of the lists on the SDMA engine and the host's setup of the next call)" % (
-          (rows[i1][1] - rows[i0][1]) / 1e6, tot / 1e3, tot_gap / 1e3))
+    s = max(r[1], union_end)
+    if r[2] > s:
+        union += (r[2] - s) / 1e3
+        union_end = r[2]
+step = (rows[i1][1] - t0) / 1e6
+print("# first sweep-1 launch of the step to the first of the next: %.3f ms; sum of kernel durations %.3f ms; time with at "
+      "least one kernel running %.3f ms (overlap %.3f ms; idle %.3f ms)" % (step, tot / 1e3, union / 1e3, (tot - union) / 1e3, step - union / 1e3))
