@@ -65,6 +65,12 @@ template <> struct OrderTraits<1> {
     }
 };
 
+// The small kernels of a sub-batch's tail run on one stream while the persistent sweep 1 of the next sub-batch owns every CU
+// on the other.  At equal priority the SIMD arbiter keeps serving the (older) sweep waves: measured 8 x slower for the
+// thresholds kernel, 55 x for the single-workgroup plan kernel -- the whole tail then takes as long as the sweep it should
+// hide behind.  With the highest wave priority they get their issue slots and are gone in their stand-alone time.
+#define MSFM_TAIL_PRIO() __builtin_amdgcn_s_setprio(3)
+
 struct PairDesc {
     const float* a_panel;  // image id1 (query), panel layout
     const float* b_panel;  // image id2 (train)
@@ -426,6 +432,7 @@ __global__ void merge_knn_kernel(const PairDesc* __restrict__ pairs,
                                  const int* __restrict__ cp_i0, const float* __restrict__ cp_s1,
                                  int* __restrict__ k_i0, float* __restrict__ k_d0, float* __restrict__ k_d1,
                                  int* __restrict__ fix_count, int4* __restrict__ fix_list, int fix_cap) {
+    MSFM_TAIL_PRIO();
     const PairDesc pd = pairs[blockIdx.y];
     if (!pd.valid || pd.path != 0) return;
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -496,6 +503,7 @@ template <int ORDER>
 __global__ void tie_fixup_kernel(const PairDesc* __restrict__ pairs, const int* __restrict__ fix_count,
                                  const int4* __restrict__ fix_list, int fix_cap,
                                  int* __restrict__ k_i0, const float* __restrict__ k_d0) {
+    MSFM_TAIL_PRIO();
     const int nfix = min(*fix_count, fix_cap);
     for (int f = blockIdx.x; f < nfix; f += gridDim.x) {
         const int4 w = fix_list[f];
@@ -575,6 +583,7 @@ __global__ __launch_bounds__(256) void epilogue_kernel(const PairDesc* __restric
                                                        const float* __restrict__ k_d1,
                                                        int2* __restrict__ st_qt, float* __restrict__ st_d,
                                                        int* __restrict__ counts, int* __restrict__ sens_counts) {
+    MSFM_TAIL_PRIO();
     const PairDesc pd = pairs[blockIdx.x];
     __shared__ int wsum[4];
     __shared__ int running, n_sens;
@@ -641,6 +650,7 @@ __global__ __launch_bounds__(256) void epilogue_kernel(const PairDesc* __restric
 
 // exclusive scan of per-pair counts (single workgroup; P is at most a few thousand per batch)
 __global__ void scan_counts_kernel(const int* __restrict__ counts, long long* __restrict__ offsets, int n) {
+    MSFM_TAIL_PRIO();
     __shared__ long long carry;
     __shared__ long long wtot[4];
     if (threadIdx.x == 0) carry = 0;
@@ -672,6 +682,7 @@ __global__ void gather_kernel(const PairDesc* __restrict__ pairs, const int* __r
                               const long long* __restrict__ offsets, const int2* __restrict__ st_qt,
                               const float* __restrict__ st_d, int2* __restrict__ out_qt,
                               float* __restrict__ out_d) {
+    MSFM_TAIL_PRIO();
     const PairDesc pd = pairs[blockIdx.x];
     const int c = counts[blockIdx.x];
     const long long o = offsets[blockIdx.x];

@@ -306,6 +306,7 @@ void build_items(Batch& b, int path) {
 // one workgroup per pair: its items, in the order (range, A block), at their XCD-interleaved positions
 __global__ void build_items_kernel(const PairDesc* __restrict__ pairs, const int* __restrict__ item_base, int path, int per,
                                    WorkItem* __restrict__ items) {
+    MSFM_TAIL_PRIO();
     const int p = blockIdx.x;
     const int base = item_base[p];
     if (base < 0) return;
@@ -844,11 +845,7 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
                            SC.d_overflow.as<unsigned char>(), SC.d_totals.as<unsigned long long>());
         HIPCHK(ctx, hipGetLastError());
     }
-    HIPCHK(ctx, SC.h_summary.ensure(sizeof(PlanSummary) + 16 + P + 64, 0));
-    char* hs = SC.h_summary.as<char>();
-    if (compact) HIPCHK(ctx, hipMemcpyAsync(hs, SC.d_summary.p, sizeof(PlanSummary), hipMemcpyDeviceToHost, SC.stream));
-    HIPCHK(ctx, hipMemcpyAsync(hs + sizeof(PlanSummary), SC.d_totals.p, 16, hipMemcpyDeviceToHost, SC.stream));
-    HIPCHK(ctx, hipMemcpyAsync(hs + sizeof(PlanSummary) + 16, SC.d_overflow.p, P, hipMemcpyDeviceToHost, SC.stream));
+    // (summary / totals / overflow bytes travel to the host with the other end-of-batch words: queue_tail_copies)
     SC.pf_pending.active = true;
     SC.pf_pending.n_lists = n_lists;
     SC.pf_pending.P = P;
@@ -1029,15 +1026,49 @@ int run_knn(msfm_ctx* ctx, Batch& b, size_t ev_base, bool* exact_launched, Prune
     return MSFM_OK;
 }
 
-// The words the host reads at the end of a sub-batch -- tie-queue count, CSR offsets, certificate counts -- are copied
-// into PAGE-LOCKED memory (a copy into pageable memory would block the host until the whole sub-batch has run, and
-// with it the launch of the next sub-batch on the other stream).
+// The words the host reads at the end of a sub-batch -- tie-queue count, CSR offsets, certificate counts, and on the
+// prefilter path the plan summary, candidate totals and overflow bytes -- are WRITTEN INTO PAGE-LOCKED HOST MEMORY BY A
+// KERNEL.  A copy into pageable memory would block the host until the whole sub-batch has run (and with it the launch
+// of the next sub-batch on the other stream); and the runtime's own copy kernels for such small transfers have no wave
+// priority: under the other stream's persistent sweep one 16-byte copy was measured at 9.7 ms.
+struct ExportSeg {
+    const char* src;
+    char* dst;
+    unsigned bytes;
+};
+struct ExportSegs {
+    ExportSeg s[6];
+};
+
+__global__ void export_tail_kernel(ExportSegs segs) {
+    MSFM_TAIL_PRIO();
+    const unsigned tid = blockIdx.x * blockDim.x + threadIdx.x, nt = gridDim.x * blockDim.x;
+    for (int k = 0; k < 6; ++k) {
+        const ExportSeg e = segs.s[k];
+        const unsigned words = e.bytes >> 2;
+        for (unsigned i = tid; i < words; i += nt) reinterpret_cast<unsigned*>(e.dst)[i] = reinterpret_cast<const unsigned*>(e.src)[i];
+        for (unsigned i = (words << 2) + tid; i < e.bytes; i += nt) e.dst[i] = e.src[i];
+    }
+    __threadfence_system();
+}
+
 int queue_tail_copies(msfm_ctx* ctx, size_t P) {
     HIPCHK(ctx, SC.h_tail.ensure(8 + (P + 1) * 8 + P * 4 + 64, 0));
-    char* h = SC.h_tail.as<char>();
-    HIPCHK(ctx, hipMemcpyAsync(h, SC.d_fix_count.p, 4, hipMemcpyDeviceToHost, SC.stream));
-    HIPCHK(ctx, hipMemcpyAsync(h + 8, SC.d_offsets.p, (P + 1) * 8, hipMemcpyDeviceToHost, SC.stream));
-    HIPCHK(ctx, hipMemcpyAsync(h + 8 + (P + 1) * 8, SC.d_sens.p, P * 4, hipMemcpyDeviceToHost, SC.stream));
+    HIPCHK(ctx, SC.h_summary.ensure(sizeof(PlanSummary) + 16 + P + 64, 0));
+    char *h = nullptr, *hs = nullptr;
+    HIPCHK(ctx, hipHostGetDevicePointer((void**)&h, SC.h_tail.p, 0));
+    HIPCHK(ctx, hipHostGetDevicePointer((void**)&hs, SC.h_summary.p, 0));
+    ExportSegs segs = {};
+    segs.s[0] = ExportSeg{SC.d_fix_count.as<char>(), h, 4};
+    if (SC.d_offsets.p) segs.s[1] = ExportSeg{SC.d_offsets.as<char>(), h + 8, (unsigned)((P + 1) * 8)};
+    if (SC.d_sens.p) segs.s[2] = ExportSeg{SC.d_sens.as<char>(), h + 8 + (P + 1) * 8, (unsigned)(P * 4)};
+    if (SC.pf_pending.active) {
+        if (SC.pf_pending.compact) segs.s[3] = ExportSeg{SC.d_summary.as<char>(), hs, (unsigned)sizeof(PlanSummary)};
+        segs.s[4] = ExportSeg{SC.d_totals.as<char>(), hs + sizeof(PlanSummary), 16};
+        segs.s[5] = ExportSeg{SC.d_overflow.as<char>(), hs + sizeof(PlanSummary) + 16, (unsigned)P};
+    }
+    hipLaunchKernelGGL(export_tail_kernel, dim3(32), dim3(256), 0, SC.stream, segs);
+    HIPCHK(ctx, hipGetLastError());
     return MSFM_OK;
 }
 
@@ -1409,6 +1440,8 @@ struct SubBatch {
     int begin = 0, end = 0;
     size_t ev_base = 0;
     bool exact_launched = false;
+    int begin_of_cost = -1;       // the pair index cost_begin belongs to (a re-built sub-batch keeps its start cost)
+    long long cost_begin = 0;
 };
 
 void add_profile(msfm_profile& to, const msfm_profile& d) {
@@ -1495,8 +1528,9 @@ static int match_pairs_impl(msfm_ctx* ctx, const int32_t* pairs, int n_pairs, co
             if (n1 > 0 && n2 > 0) total += n1 * n2;
         }
         const long long n_sub = std::min<long long>(ctx->pipeline, total / kMinPipelineCost);
-        if (n_sub >= 2) cost_limit = (total + n_sub - 1) / n_sub;
+        if (n_sub >= 2) cost_limit = (total + n_sub - 1) / n_sub;   // part k ends where the running cost passes (k + 1) * cost_limit
     }
+    long long cost_done = 0;   // cost of the sub-batches built so far (a re-built sub-batch starts from its own begin: see build)
     // a tie in sqrt space can only surface in a match list when a row with d0 == d1 can pass the ratio test
     const bool need_fix = !(prm.ratio <= 1.f);
 
@@ -1506,6 +1540,13 @@ static int match_pairs_impl(msfm_ctx* ctx, const int32_t* pairs, int n_pairs, co
     auto build = [&](SubBatch& w, int begin, const std::vector<char>& force_exact) -> int {
         w.b = Batch{};
         w.begin = begin;
+        if (begin == 0) cost_done = 0;
+        const long long cost_begin = (begin == w.begin_of_cost) ? w.cost_begin : cost_done;
+        w.begin_of_cost = begin;
+        w.cost_begin = cost_begin;
+        // the first cumulative-cost mark behind this sub-batch's start
+        // (a part ends at the pair nearest to its mark, so its successor may start a little before or behind one)
+        const long long mark = cost_limit > 0 ? ((cost_begin + cost_limit / 2) / cost_limit + 1) * cost_limit : 0;
         long long est = 0, cost = 0;
         int end = begin;
         while (end < n_pairs && (end - begin) < kMaxPairsPerBatch) {
@@ -1525,7 +1566,7 @@ static int match_pairs_impl(msfm_ctx* ctx, const int32_t* pairs, int n_pairs, co
                                                3 * (8LL * (pd.n1 + pd.n2) + 1024)) : 0;
             const long long c = pd.valid ? (long long)pd.n1 * pd.n2 : 0;
             if (end > begin && est + need > kScratchElems) break;
-            if (end > begin && cost_limit > 0 && cost + c > cost_limit) break;
+            if (end > begin && cost_limit > 0 && cost_begin + cost + c / 2 > mark) break;
             est += need;
             cost += c;
             const size_t k = w.b.pairs.size();
@@ -1540,6 +1581,7 @@ static int match_pairs_impl(msfm_ctx* ctx, const int32_t* pairs, int n_pairs, co
             ++end;
         }
         w.end = end;
+        cost_done = cost_begin + cost;
         return MSFM_OK;
     };
 
@@ -1867,8 +1909,10 @@ static int knn2_pair_impl(msfm_ctx* ctx, int id1, int id2, int32_t* fwd_idx0, fl
         SC.prof = msfm_profile{};   // only the attempt that is kept counts
         rc = run_knn(ctx, b, 2, &exact_launched, PruneParams{0, 0.f, 0.f}, true);  // knnMatch twin: every row keeps its neighbours
         if (rc != MSFM_OK) return rc;
-        HIPCHK(ctx, SC.h_tail.ensure(64, 0));
-        HIPCHK(ctx, hipMemcpyAsync(SC.h_tail.p, SC.d_fix_count.p, 4, hipMemcpyDeviceToHost, SC.stream));
+        SC.d_offsets.release();   // (no CSR on this path: the export kernel skips absent segments)
+        SC.d_sens.release();
+        rc = queue_tail_copies(ctx, 1);
+        if (rc != MSFM_OK) return rc;
         HIPCHK(ctx, hipStreamSynchronize(SC.stream));
         bool retry = false, retry_pf = false;
         rc = check_fix_overflow(ctx, &retry);

@@ -90,6 +90,7 @@ __device__ __forceinline__ long long plan_block_exclusive_scan(long long v, long
 
 __global__ __launch_bounds__(kPlanThreads) void pf_plan_kernel(const PlanGroup* __restrict__ groups, int n_groups,
                                                          const int* __restrict__ gtot, PlanOut out) {
+    MSFM_TAIL_PRIO();
     const int tid = threadIdx.x, nt = blockDim.x;
     __shared__ long long s_base_rows, s_base_cand, s_base_items[8], s_base_rev[8];
     __shared__ int s_ok;
@@ -221,6 +222,7 @@ __global__ __launch_bounds__(kPlanThreads) void pf_plan_kernel(const PlanGroup* 
 // first compact row of every member: the group's first row + the rows of the members before it.  One wave per group.
 __global__ void pf_member_rows_kernel(const PlanGroup* __restrict__ groups, int n_groups, const int* __restrict__ gmembers,
                                       const int* __restrict__ cnt, const long long* __restrict__ grow0, long long* __restrict__ mrow) {
+    MSFM_TAIL_PRIO();
     const int g = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (g >= n_groups) return;
     const PlanGroup G = groups[g];
@@ -248,6 +250,7 @@ __global__ void pf_assign_kernel(const PairDesc* __restrict__ pairs, const PfPai
                                  int* __restrict__ live_idx, int* __restrict__ row_pair, float* __restrict__ cmp_tu,
                                  const _Float16** __restrict__ row_src, int row_halfs /* 136: fp16 rows, 72: byte rows */,
                                  unsigned long long* __restrict__ best, unsigned long long* __restrict__ second) {
+    MSFM_TAIL_PRIO();
     const int p = blockIdx.x >> 1, dir = blockIdx.x & 1;
     const PlanPair pl = pp_plan[p];
     if (pl.fwd_member < 0) return;
@@ -292,6 +295,7 @@ __global__ void pf_assign_kernel(const PairDesc* __restrict__ pairs, const PfPai
 __global__ void pf_overflow_kernel(const CandList* __restrict__ lists, int n_lists, const unsigned long long* __restrict__ cand_count,
                                    const PlanGroup* __restrict__ groups, const int* __restrict__ gmembers, const int* __restrict__ member_pair,
                                    unsigned char* __restrict__ overflow_pair, unsigned long long* __restrict__ totals /* [0] candidates, [1] overflowed lists */) {
+    MSFM_TAIL_PRIO();
     for (int l = blockIdx.x * blockDim.x + threadIdx.x; l < n_lists; l += gridDim.x * blockDim.x) {
         const CandList L = lists[l];
         if (L.cap == 0) continue;

@@ -217,6 +217,7 @@ __global__ void pf_thresholds_kernel(const PairDesc* __restrict__ pairs, const P
                                      const float* __restrict__ rp_s0, const float* __restrict__ rp_s1,
                                      const float* __restrict__ cp_s0, unsigned* __restrict__ colmask,
                                      float* __restrict__ tu, float* __restrict__ tv, PruneParams pr, PlanCounts plan) {
+    MSFM_TAIL_PRIO();
     const PairDesc pd = pairs[blockIdx.y];
     const PfPair pp = pf[blockIdx.y];
     if (!pd.valid || !pp.use) return;
@@ -342,6 +343,7 @@ __global__ void pf_exact_candidates_kernel(const PairDesc* __restrict__ pairs, c
                                            const unsigned long long* __restrict__ cand_count, int2* __restrict__ cand,
                                            float* __restrict__ cand_s, int* __restrict__ cand_pair,
                                            unsigned long long* __restrict__ best /* reduce phase A rides along */, int n_lists) {
+    MSFM_TAIL_PRIO();
   for (int lid = blockIdx.y; lid < n_lists; lid += gridDim.y) {   // (more lists than gridDim.y allows: stride)
     const CandList L = lists[lid];
     if (L.cap == 0) continue;
@@ -416,6 +418,7 @@ __global__ void pf_reduce_second_kernel(const PairDesc* __restrict__ pairs, cons
                                         const int2* __restrict__ cand, const float* __restrict__ cand_s,
                                         const int* __restrict__ cand_pair, const unsigned long long* __restrict__ best,
                                         unsigned long long* __restrict__ second, int n_lists) {
+    MSFM_TAIL_PRIO();
   for (int lid = blockIdx.y; lid < n_lists; lid += gridDim.y) {
     const CandList L = lists[lid];
     if (L.cap == 0) continue;
@@ -440,6 +443,7 @@ __global__ void pf_finalize_kernel(const PairDesc* __restrict__ pairs, const PfP
                                    const unsigned long long* __restrict__ best, const unsigned long long* __restrict__ second,
                                    int* __restrict__ k_i0, float* __restrict__ k_d0, float* __restrict__ k_d1,
                                    int* __restrict__ fix_count, int4* __restrict__ fix_list, int fix_cap) {
+    MSFM_TAIL_PRIO();
     const PairDesc pd = pairs[blockIdx.y];
     const PfPair pp = pf[blockIdx.y];
     if (!pd.valid || !pp.use) return;

@@ -37,6 +37,7 @@ constexpr int kVfChunk = 2048;  // matches staged in LDS at a time (4 float arra
 __global__ void vf_points_kernel(const PairDesc* __restrict__ pairs, const VerifyPair* __restrict__ vp,
                                  const int* __restrict__ counts, const int2* __restrict__ st_qt,
                                  float* __restrict__ x1, float* __restrict__ y1, float* __restrict__ x2, float* __restrict__ y2) {
+    MSFM_TAIL_PRIO();
     const PairDesc pd = pairs[blockIdx.x];
     const VerifyPair v = vp[blockIdx.x];
     const int n = counts[blockIdx.x];
@@ -55,6 +56,7 @@ __global__ __launch_bounds__(256) void vf_hypotheses_kernel(const PairDesc* __re
                                                             const float* __restrict__ x1, const float* __restrict__ y1,
                                                             const float* __restrict__ x2, const float* __restrict__ y2,
                                                             int* __restrict__ hyp_counts, VerifyParams prm) {
+    MSFM_TAIL_PRIO();
     __shared__ float sx1[kVfChunk], sy1[kVfChunk], sx2[kVfChunk], sy2[kVfChunk];
     const int p = blockIdx.y;
     const int n = counts[p];
@@ -85,6 +87,7 @@ __global__ __launch_bounds__(256) void vf_hypotheses_kernel(const PairDesc* __re
 // the sequential loop's adaptive stopping rule, replayed: one thread per pair
 __global__ void vf_select_kernel(const int* __restrict__ counts, const int* __restrict__ hyp_counts, int n_pairs,
                                  VerifyParams prm, int* __restrict__ best_it, int* __restrict__ best_count) {
+    MSFM_TAIL_PRIO();
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n_pairs) return;
     const int n = counts[p];
@@ -106,6 +109,7 @@ __global__ __launch_bounds__(256) void vf_mask_compact_kernel(
     const float* __restrict__ x2, const float* __restrict__ y2, const int* __restrict__ best_it,
     const int* __restrict__ best_count, unsigned char* __restrict__ flags /* scratch, staged layout */,
     VerifyParams prm, int2* __restrict__ out_qt, float* __restrict__ out_d, int* __restrict__ out_counts) {
+    MSFM_TAIL_PRIO();
     __shared__ double sF[9];
     __shared__ int s_ok, s_count, s_base, wsum[4];
     const int p = blockIdx.x;
