@@ -682,7 +682,8 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
         for (const PlanGroup& g : cp.groups) max_ranges = std::max<long long>(max_ranges, g.ranges);
         const long long slack = (long long)kPfWgRows * (long long)G + kPfWgRows;
         const long long rows_cap = std::max<long long>(ctx->cmp_rows_hint + ctx->cmp_rows_hint / 2, cp.rows_ub / 4) + slack;
-        const long long cand_cap = std::max<long long>(8 * rows_cap + 1024LL * (long long)G, ctx->cand_hint);
+        // (per group: 8 entries per compacted row rounded up to 1024, + 1024 -- plan_group_cap_units)
+        const long long cand_cap = std::max<long long>(8 * rows_cap + 2048LL * (long long)G, ctx->cand_hint);
         // (the list holds 8 x the longest per-XCD sub-list: twice the balanced size leaves room for skew)
         const long long items_cap = std::max<long long>(2 * ((rows_cap / kPfWgRows + (long long)G) * max_ranges + 64) / 8 * 8, (ctx->items_hint + 64) / 8 * 8);
         HIPCHK(ctx, SC.d_groups.ensure(std::max<size_t>(1, G) * sizeof(PlanGroup)));
@@ -690,7 +691,7 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
         HIPCHK(ctx, SC.d_member_pair.ensure(std::max<size_t>(1, M) * 4));
         HIPCHK(ctx, SC.d_member_group.ensure(std::max<size_t>(1, M) * 4));
         HIPCHK(ctx, SC.d_gtot.ensure(std::max<size_t>(1, G) * 4));
-        HIPCHK(ctx, SC.d_grow0.ensure(std::max<size_t>(1, G) * 8));
+        HIPCHK(ctx, SC.d_grow0.ensure((4 * std::max<size_t>(1, G) + 8) * 8));   // grow0 | gpos[3] | fwd_items_x[8]
         HIPCHK(ctx, SC.d_ppair.ensure(P * sizeof(PlanPair)));
         HIPCHK(ctx, SC.d_cnt.ensure(std::max<size_t>(1, M) * 4));
         HIPCHK(ctx, SC.d_mrow.ensure(std::max<size_t>(1, M) * 8));
@@ -717,6 +718,10 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
         HIPCHK(ctx, hipMemcpyAsync(SC.d_ppair.p, cp.ppair.data(), P * sizeof(PlanPair), hipMemcpyHostToDevice, SC.stream));
         // (the uploads above come from pageable vectors that die with this function: hipMemcpyAsync has staged them when it returns)
         HIPCHK(ctx, hipMemsetAsync(SC.d_cnt.p, 0, std::max<size_t>(1, M) * 4, SC.stream));
+        // (pf_plan_write_kernel stores only the non-zero fields of the groups' descriptors)
+        HIPCHK(ctx, hipMemsetAsync(SC.d_vpairs.p, 0, std::max<size_t>(1, G) * sizeof(PairDesc), SC.stream));
+        HIPCHK(ctx, hipMemsetAsync(SC.d_vpf.p, 0, std::max<size_t>(1, G) * sizeof(PfPair), SC.stream));
+        HIPCHK(ctx, hipMemsetAsync(SC.d_lists.p, 0, std::max<size_t>(1, G) * sizeof(CandList), SC.stream));
         HIPCHK(ctx, hipMemsetAsync(SC.d_summary.p, 0, sizeof(PlanSummary), SC.stream));
         HIPCHK(ctx, hipMemsetAsync(SC.d_vitems.p, 0xff, (size_t)items_cap * sizeof(WorkItem), SC.stream));
         HIPCHK(ctx, hipMemsetAsync(SC.d_row_src.p, 0, (size_t)rows_cap * 8, SC.stream));
@@ -735,6 +740,8 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
         po.lists = SC.d_lists.as<CandList>();
         po.items = SC.d_vitems.as<WorkItem>();
         po.grow0 = SC.d_grow0.as<long long>();
+        po.gpos = SC.d_grow0.as<long long>() + std::max<size_t>(1, G);
+        po.fwd_items_x = SC.d_grow0.as<long long>() + 4 * std::max<size_t>(1, G);
         po.summary = SC.d_summary.as<PlanSummary>();
         po.row_src = SC.d_row_src.as<const _Float16*>();
         po.zero_row = ctx->d_zero_row.as<_Float16>();
@@ -743,10 +750,15 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
         po.rows_cap = rows_cap;
         po.cand_cap = cand_cap;
         po.items_cap = items_cap;
-        hipLaunchKernelGGL(pf_plan_kernel, dim3(1), dim3(kPlanThreads), 0, SC.stream, SC.d_groups.as<PlanGroup>(), (int)G,
+        hipLaunchKernelGGL(pf_plan_scan_kernel, dim3(1), dim3(64), 0, SC.stream, SC.d_groups.as<PlanGroup>(), (int)G,
                            (const int*)SC.d_gtot.as<int>(), po);
         HIPCHK(ctx, hipGetLastError());
-        DBGSYNC(ctx, "pf_plan_kernel");
+        DBGSYNC(ctx, "pf_plan_scan_kernel");
+        if (G > 0)
+            hipLaunchKernelGGL(pf_plan_write_kernel, dim3((unsigned)((G + 63) / 64)), dim3(64), 0, SC.stream, SC.d_groups.as<PlanGroup>(), (int)G,
+                               (const int*)SC.d_gtot.as<int>(), po);
+        HIPCHK(ctx, hipGetLastError());
+        DBGSYNC(ctx, "pf_plan_write_kernel");
         if (G > 0)
             hipLaunchKernelGGL(pf_member_rows_kernel, dim3((unsigned)((G + 3) / 4)), dim3(256), 0, SC.stream, SC.d_groups.as<PlanGroup>(), (int)G,
                                (const int*)SC.d_gmembers.as<int>(), (const int*)SC.d_cnt.as<int>(),
@@ -1012,7 +1024,9 @@ int run_knn(msfm_ctx* ctx, Batch& b, size_t ev_base, bool* exact_launched, Prune
         rc = upload_pairs(ctx, b);  // later kernels still read the (all-invalid) pair table
         if (rc != MSFM_OK) return rc;
     }
-    if (any_pf || any_exact) {
+    // (no queue -- match lists with ratio <= 1 -- no fix-up launch: the kernel's 86 registers would not fit next to the other
+    // stream's sweep and the tail would wait for that sweep's end)
+    if ((any_pf || any_exact) && SC.fix_cap_eff > 0) {
         if (ctx->order == MSFM_ORDER_SSE4X4)
             hipLaunchKernelGGL(tie_fixup_kernel<0>, dim3(256), dim3(64), 0, SC.stream, SC.d_pairs.as<PairDesc>(),
                                SC.d_fix_count.as<int>(), SC.d_fix_list.as<int4>(), SC.fix_cap_eff,

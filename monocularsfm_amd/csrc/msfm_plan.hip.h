@@ -49,15 +49,21 @@ struct PlanSummary {
     long long swept_desc_pairs;  // descriptor pairs the compacted sweep multiplies (padding included)
 };
 
-constexpr int kPlanThreads = 512;   // (1024 would halve the registers per thread: the per-XCD totals then spill)
-// One workgroup of kPlanThreads threads.  All loops are strided over groups / members; the two exclusive scans (rows and work
-// items / candidate capacity over groups) run as chunked scans through LDS.
+// The plan is made by two kernels that both FIT NEXT TO a sweep-1 workgroup of the other stream (two waves of 226
+// registers per SIMD leave 48 of the 512): a 170-register single-workgroup version waited for a CU until that persistent
+// sweep had ended -- measured 8.4 ms instead of 0.08 ms, and the whole tail of the sub-batch with it.
+//   pf_plan_scan_kernel   one workgroup, one pass: per group its first compact row, its candidate-list base and its position
+//                         among the forward / reverse work items of its XCD (prefix sums through LDS), the totals, the verdict;
+//   pf_plan_write_kernel  one thread per group: the sweep descriptors (field by field into zeroed arrays) and the work items.
 struct PlanOut {
-    PairDesc* vpairs;         // [n_groups] sweep descriptors
+    PairDesc* vpairs;         // [n_groups] sweep descriptors (zeroed by the host)
     PfPair* vpf;
     CandList* lists;          // [n_groups]
     WorkItem* items;          // [items_cap], pre-filled with pair = -1
     long long* grow0;         // [n_groups] first compact row of the group (-1: invalid plan); pf_member_rows_kernel -> mrow
+    long long* gpos;          // [n_groups][3] scan -> write: first compact row | candidate-list base | position among the
+                              //   forward (dir 0) / reverse (dir 1) items of XCD g & 7
+    long long* fwd_items_x;   // [8] forward items per XCD: the reverse items of an XCD sit behind them
     PlanSummary* summary;
     const _Float16* const* row_src;  // per compact row: its operand row (filled by pf_assign_kernel)
     const _Float16* zero_row;        // 272 zero bytes
@@ -66,155 +72,154 @@ struct PlanOut {
     long long rows_cap, cand_cap, items_cap;
 };
 
-__device__ __forceinline__ long long plan_block_exclusive_scan(long long v, long long* total) {
-    // exclusive scan of one value per thread over the workgroup (<= 1024 threads)
-    __shared__ long long wsum[16];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    long long inc = v;
-    for (int d = 1; d < 64; d <<= 1) {
-        const long long o = __shfl_up(inc, d);
-        if (lane >= d) inc += o;
-    }
-    __syncthreads();
-    if (lane == 63) wsum[w] = inc;
-    __syncthreads();
-    long long base = 0, tot = 0;
-    for (int k = 0; k < (int)(blockDim.x >> 6); ++k) {
-        if (k < w) base += wsum[k];
-        tot += wsum[k];
-    }
-    *total = tot;
-    __syncthreads();
-    return base + inc - v;
+// candidate-list capacity of a group in units of 1024 entries: 8 per compacted row, rounded up, + 1024; at most 2^30 entries
+__device__ __forceinline__ int plan_group_cap_units(long long rows) {
+    return rows > 0 ? (int)min((rows + 127) / 128 + 1, 1LL << 20) : 0;
 }
 
-__global__ __launch_bounds__(kPlanThreads) void pf_plan_kernel(const PlanGroup* __restrict__ groups, int n_groups,
-                                                         const int* __restrict__ gtot, PlanOut out) {
+// inclusive scan over the 64 lanes of the wave (32-bit: rows travel as 512-row blocks, capacities as 1024-entry units)
+__device__ __forceinline__ int plan_wave_scan(int v) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(v, d);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+
+// ONE WAVE.  Work items: all items of a group go to XCD (group & 7) -- they stream the same image through that XCD's L2 --
+// and item j of XCD x sits at list position 8 j + x (workgroup b runs on XCD b % 8 and strides over the list by a multiple
+// of 8).  Groups alternate between long forward sweeps and short reverse ones in creation order, so the residue classes
+// carry comparable work; a contiguous chunk of the list per XCD (as for the uniform sweep-1 items) would give some XCDs
+// all the long items.  Forward groups -- the long sweeps -- come first in every XCD's list: a group's position is its
+// rank among the forward (reverse) items of its XCD; pf_plan_write_kernel puts the reverse ones behind all forward ones.
+// Lane l serves the groups g = 64 c + l: its XCD class l & 7 never changes, so the per-class running sums live in the
+// lanes themselves and a class-wise prefix sum is three shuffle steps of stride 8.
+__global__ __launch_bounds__(64) void pf_plan_scan_kernel(const PlanGroup* __restrict__ groups, int n_groups,
+                                                        const int* __restrict__ gtot, PlanOut out) {
     MSFM_TAIL_PRIO();
-    const int tid = threadIdx.x, nt = blockDim.x;
-    __shared__ long long s_base_rows, s_base_cand, s_base_items[8], s_base_rev[8];
-    __shared__ int s_ok;
-    if (tid == 0) { s_base_rows = 0; s_base_cand = 0; s_ok = 1; }
-    if (tid < 8) s_base_items[tid] = 0;
-    __syncthreads();
-    // Work items: all items of a group go to XCD (group & 7) -- they stream the same image through that XCD's L2 -- and
-    // item j of XCD x sits at list position 8 j + x (workgroup b runs on XCD b % 8 and strides over the list by a
-    // multiple of 8).  Groups alternate between long forward sweeps and short reverse ones in creation order, so the
-    // residue classes carry comparable work; a contiguous chunk of the list per XCD (as for the uniform sweep-1 items)
-    // would give some XCDs all the long items.
-    // pass 0: totals (does the plan fit?)   pass 1: write it
-    long long tot_rows = 0, tot_cand = 0, tot_swept = 0, tot_items_x[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tot_fwd_x[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    long long n_items = 0;
-    for (int pass = 0; pass < 2; ++pass) {
-        if (pass == 1) {
-            for (int x = 0; x < 8; ++x) n_items = tot_items_x[x] > n_items ? tot_items_x[x] : n_items;
-            n_items *= 8;
-            __syncthreads();
-            if (tid == 0) {
-                s_ok = (tot_rows <= out.rows_cap && tot_cand <= out.cand_cap && n_items <= out.items_cap) ? 1 : 0;
-                s_base_rows = s_base_cand = 0;
-                PlanSummary sm;
-                sm.ok = s_ok;
-                sm.n_items = s_ok ? (int)n_items : 0;
-                sm.cmp_rows = tot_rows;
-                sm.cand_elems = tot_cand;
-                sm.items_needed = n_items;
-                sm.swept_desc_pairs = tot_swept;
-                *out.summary = sm;
-            }
-            if (tid < 8) { s_base_items[tid] = 0; s_base_rev[tid] = tot_fwd_x[tid]; }   // reverse items behind all forward ones
-            __syncthreads();
+    const int lane = threadIdx.x;
+    long long base_rows = 0, base_cand = 0, tot_swept = 0;   // 512-row blocks / 1024-entry units of the chunks before
+    int carry_f = 0, carry_r = 0;   // forward / reverse items of this lane's XCD class in the chunks before
+#pragma unroll 1
+    for (int g0 = 0; g0 < n_groups; g0 += 64) {
+        const int g = g0 + lane;
+        const bool in = g < n_groups;
+        const long long rows = in ? gtot[g] : 0;   // (summed by pf_thresholds_kernel)
+        const int dir = in ? groups[g].dir : 0, ranges = in ? groups[g].ranges : 0;
+        const long long rows512 = (rows + kPfWgRows - 1) / kPfWgRows * kPfWgRows;
+        const int items = (int)(rows512 / kPfWgRows) * ranges;
+        long long swept = 0;
+        if (in) {
+            const int n2 = groups[g].n2, bt0 = groups[g].bt_begin, bt1 = groups[g].bt_end;
+            swept = rows512 * (long long)min(n2 - min(n2, bt0 * kBN), (bt1 - bt0) * kBN);
         }
-        const int ok = s_ok;
-        for (int g0 = 0; g0 < n_groups; g0 += nt) {
-            const int g = g0 + tid;
-            long long rows = 0;
-            PlanGroup G = {};
-            if (g < n_groups) {
-                G = groups[g];
-                rows = gtot[g];   // (summed by pf_count_kernel: a serial loop over up to 127 members here was most of this kernel)
-            }
-            const long long rows512 = (rows + kPfWgRows - 1) / kPfWgRows * kPfWgRows;
-            const long long ablocks = rows512 / kPfWgRows;
-            const long long items = ablocks * (g < n_groups ? G.ranges : 0);
-            const long long cap = rows > 0 ? (8 * rows + 1024 < (1LL << 30) ? 8 * rows + 1024 : (1LL << 30)) : 0;
-            long long tr, tc, ti[8], ti_rev[8], item0 = 0;
-            const long long row0 = s_base_rows + plan_block_exclusive_scan(rows512, &tr);
-            const long long cand0 = s_base_cand + plan_block_exclusive_scan(cap, &tc);
-            // (forward groups -- the long sweeps -- come first in every XCD's list: they are fetched first)
-            for (int x = 0; x < 8; ++x) {
-                long long tf, tb;
-                const long long lf = plan_block_exclusive_scan(((g & 7) == x && G.dir == 0) ? items : 0, &tf);
-                const long long lb = plan_block_exclusive_scan(((g & 7) == x && G.dir == 1) ? items : 0, &tb);
-                ti[x] = tf;          // forward items of this stride
-                ti_rev[x] = tb;
-                if ((g & 7) == x) item0 = G.dir == 0 ? s_base_items[x] + lf : s_base_rev[x] + lb;
-            }
-            if (pass == 0) {
-                tot_rows += tr;
-                tot_cand += tc;
-                for (int x = 0; x < 8; ++x) { tot_items_x[x] += ti[x] + ti_rev[x]; tot_fwd_x[x] += ti[x]; }
-                long long swept = (g < n_groups) ? rows512 * (long long)min(G.n2 - min(G.n2, G.bt_begin * kBN), (G.bt_end - G.bt_begin) * kBN) : 0, ts;
-                (void)plan_block_exclusive_scan(swept, &ts);
-                tot_swept += ts;
-            } else if (g < n_groups) {
-                // the group's sweep descriptor: A = its compacted rows, B = the streamed image
-                PairDesc vd = {};
-                vd.n1 = ok ? (int)rows : 0;
-                vd.n2 = G.n2;
-                vd.a_blocks256 = ok ? (int)ablocks : 0;
-                vd.b_tiles = G.b_tiles;
-                vd.n1pad = ok ? (int)rows512 : 0;
-                vd.n2pad = G.n2pad;
-                vd.valid = 1;
-                vd.path = 1;
-                vd.ranges = G.ranges;
-                out.vpairs[g] = vd;
-                PfPair vp = {};
-                vp.a_h = out.zero_row;
-                vp.a_rows = out.row_src + row0;
-                vp.b_h = G.b_h;
-                vp.b_nrm = G.b_nrm;
-                vp.b_c = G.b_c;
-                vp.a_c = G.a_c;
-                vp.b_h0 = G.b_h0;
-                vp.tu_off = row0;
-                vp.cand_off = cand0;
-                vp.cand_cap = ok ? (int)cap : 0;
-                vp.use = (ok && rows > 0) ? 1 : 0;
-                out.vpf[g] = vp;
-                CandList L = {};
-                L.pair = -1;
-                L.mode = 1 + G.dir;
-                L.off = cand0;
-                L.cap = ok ? (int)cap : 0;
-                L.live_idx = out.live_idx + row0;
-                L.row_pair = out.row_pair + row0;
-                out.lists[g] = L;
-                out.grow0[g] = ok ? row0 : -1;
-                if (ok) {
-                    const int nblk = G.bt_end - G.bt_begin;
-                    long long k = item0;
-                    for (int rg = 0; rg < G.ranges; ++rg) {
-                        const int t0 = G.bt_begin + (int)((long long)nblk * rg / G.ranges), t1 = G.bt_begin + (int)((long long)nblk * (rg + 1) / G.ranges);
-                        for (int ab = 0; ab < (int)ablocks; ++ab, ++k) {
-                            WorkItem w = {};
-                            w.pair = g;
-                            w.a_blk = ab;
-                            w.bt_begin = t0;
-                            w.bt_end = t1;
-                            w.range = rg;
-                            out.items[k * 8 + (g & 7)] = w;
-                        }
-                    }
-                }
-            }
-            if (tid == 0) {
-                s_base_rows += tr;
-                s_base_cand += tc;
-            }
-            if (tid < 8) { s_base_items[tid] += ti[tid]; s_base_rev[tid] += ti_rev[tid]; }
-            __syncthreads();
+        const int capu = plan_group_cap_units(rows), ablocks = (int)(rows512 / kPfWgRows);
+        tot_swept += swept;   // (lane-local: reduced once, behind the loop)
+        const int ir = plan_wave_scan(ablocks), ic = plan_wave_scan(capu);
+        int vf = dir == 0 ? items : 0, vr = dir == 1 ? items : 0;
+        const int f0 = vf, r0 = vr;
+#pragma unroll
+        for (int d = 8; d < 64; d <<= 1) {   // inclusive scan within the residue class lane & 7
+            const int of = __shfl_up(vf, d), orv = __shfl_up(vr, d);
+            if (lane >= d) { vf += of; vr += orv; }
+        }
+        if (in) {   // (one array, three values per group: one address register pair)
+            out.gpos[3 * (long long)g] = (base_rows + (ir - ablocks)) * kPfWgRows;
+            out.gpos[3 * (long long)g + 1] = (base_cand + (ic - capu)) * 1024;
+            out.gpos[3 * (long long)g + 2] = dir == 0 ? (long long)(carry_f + vf - f0) : (long long)(carry_r + vr - r0);
+        }
+        base_rows += __shfl(ir, 63);
+        base_cand += __shfl(ic, 63);
+        carry_f += __shfl(vf, 56 + (lane & 7));   // the class total sits in the class's last lane
+        carry_r += __shfl(vr, 56 + (lane & 7));
+    }
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) tot_swept += __shfl_xor(tot_swept, d);
+    // lanes 0..7 hold the totals of XCD 0..7 (group g = lane in chunk 0: class lane & 7)
+    int n_items = carry_f + carry_r;
+#pragma unroll
+    for (int d = 1; d < 8; d <<= 1) n_items = max(n_items, __shfl_xor(n_items, d));
+    if (lane < 8) out.fwd_items_x[lane] = carry_f;
+    if (lane == 0) {
+        const long long n8 = 8LL * n_items;
+        PlanSummary sm;
+        sm.ok = (base_rows * kPfWgRows <= out.rows_cap && base_cand * 1024 <= out.cand_cap && n8 <= out.items_cap) ? 1 : 0;
+        sm.n_items = sm.ok ? (int)n8 : 0;
+        sm.cmp_rows = base_rows * kPfWgRows;
+        sm.cand_elems = base_cand * 1024;
+        sm.items_needed = n8;
+        sm.swept_desc_pairs = tot_swept;
+        *out.summary = sm;
+    }
+}
+
+// one thread per group: its sweep descriptor (A = its compacted rows, B = the streamed image), candidate list and work
+// items.  The descriptor arrays arrive zeroed: only the fields that are not zero are stored, one at a time (few registers).
+__global__ void pf_plan_write_kernel(const PlanGroup* __restrict__ groups, int n_groups, const int* __restrict__ gtot, PlanOut out) {
+    MSFM_TAIL_PRIO();
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_groups) return;
+    const int ok = out.summary->ok;
+    const long long rows = gtot[g];
+    const long long rows512 = (rows + kPfWgRows - 1) / kPfWgRows * kPfWgRows;
+    const int ablocks = (int)(rows512 / kPfWgRows);
+    const long long row0 = out.gpos[3 * (long long)g], cand0 = out.gpos[3 * (long long)g + 1];
+    const int cap = ok ? plan_group_cap_units(rows) * 1024 : 0;
+    const PlanGroup* G = groups + g;
+#define MSFM_PLAN_FENCE() asm volatile("" ::: "memory")   /* loads stay next to their stores: few live registers */
+    PairDesc* vd = out.vpairs + g;
+    vd->n1 = ok ? (int)rows : 0;
+    vd->n2 = G->n2;
+    vd->a_blocks256 = ok ? ablocks : 0;
+    MSFM_PLAN_FENCE();
+    vd->b_tiles = G->b_tiles;
+    vd->n1pad = ok ? (int)rows512 : 0;
+    vd->n2pad = G->n2pad;
+    MSFM_PLAN_FENCE();
+    vd->valid = 1;
+    vd->path = 1;
+    vd->ranges = G->ranges;
+    MSFM_PLAN_FENCE();
+    PfPair* vp = out.vpf + g;
+    vp->a_h = out.zero_row;
+    vp->a_rows = out.row_src + row0;
+    MSFM_PLAN_FENCE();
+    vp->b_h = G->b_h;
+    vp->b_nrm = G->b_nrm;
+    MSFM_PLAN_FENCE();
+    vp->b_c = G->b_c;
+    vp->a_c = G->a_c;
+    vp->b_h0 = G->b_h0;
+    MSFM_PLAN_FENCE();
+    vp->tu_off = row0;
+    vp->cand_off = cand0;
+    vp->cand_cap = cap;
+    vp->use = (ok && rows > 0) ? 1 : 0;
+    MSFM_PLAN_FENCE();
+    CandList* L = out.lists + g;
+    L->pair = -1;
+    L->mode = 1 + G->dir;
+    L->off = cand0;
+    L->cap = cap;
+    MSFM_PLAN_FENCE();
+    L->live_idx = out.live_idx + row0;
+    L->row_pair = out.row_pair + row0;
+    MSFM_PLAN_FENCE();
+    out.grow0[g] = ok ? row0 : -1;   // (-1: pf_member_rows_kernel / pf_assign_kernel see an invalid plan, nothing is assigned)
+    if (!ok) return;
+    const int nblk = G->bt_end - G->bt_begin, ranges = G->ranges, bt0 = G->bt_begin;
+    long long k = out.gpos[3 * (long long)g + 2] + (G->dir == 1 ? out.fwd_items_x[g & 7] : 0);   // reverse items behind all forward ones
+    for (int rg = 0; rg < ranges; ++rg) {
+        const int t0 = bt0 + (int)((long long)nblk * rg / ranges), t1 = bt0 + (int)((long long)nblk * (rg + 1) / ranges);
+        for (int ab = 0; ab < ablocks; ++ab, ++k) {
+            WorkItem* w = out.items + (k * 8 + (g & 7));
+            w->pair = g;
+            w->a_blk = ab;
+            w->bt_begin = t0;
+            w->bt_end = t1;
+            w->range = rg;
         }
     }
 }

@@ -186,7 +186,10 @@ __global__ __launch_bounds__(kPfThreads, 2) void sweep_kernel(
 
     // A fragments: rows a_blk*512 + wave*64 + rb*32 + lcol, granule 2*ks + lhalf;
     // ninth k-step: [-c, -c, x_hi, x_lo, 0...] in the lhalf == 0 lanes (k = 128..135), zeros in the others
-    h8 af[kPfRB][9];
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    h8 af[kPfRB][8];
+    h4 ae[kPfRB];     // the ninth k-step's A side: k = 128..131 (lhalf == 0 lanes), two registers -- an h8 would cost four more
+                      // VGPRs, and at 226 the kernel leaves 48 of a SIMD's 512 to the tail kernels of the other stream, at <= 224 64
     const float inv_c = 1.f / pp.b_c;
 #pragma unroll
     for (int rb = 0; rb < kPfRB; ++rb) {
@@ -209,16 +212,16 @@ __global__ __launch_bounds__(kPfThreads, 2) void sweep_kernel(
         const _Float16 hi = (_Float16)xs;
         const float rest = xs - (float)hi;
         const _Float16 lo = (rest == rest && fabsf(rest) < 3.0e38f) ? (_Float16)rest : (_Float16)0.f;
-        h8 e;
+        h4 e;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) e[j] = (_Float16)0.f;
+        for (int j = 0; j < 4; ++j) e[j] = (_Float16)0.f;
         if (lhalf == 0) {
             e[0] = (_Float16)(-pp.b_c);
             e[1] = (_Float16)(-pp.b_c);
             e[2] = hi;
             e[3] = lo;
         }
-        af[rb][8] = e;
+        ae[rb] = e;
     }
 
     // this lane's 32 result rows: (rb, r) -> row = a_blk*512 + wave*64 + rb*32 + (r&3) + 8*(r>>2) + 4*lhalf
@@ -241,9 +244,11 @@ __global__ __launch_bounds__(kPfThreads, 2) void sweep_kernel(
     // still holds them as pending at the first MFMA and it drains vmcnt(0) INSIDE the loop, which would serialise
     // the DMA ring.
 #pragma unroll
-    for (int rb = 0; rb < kPfRB; ++rb)
+    for (int rb = 0; rb < kPfRB; ++rb) {
 #pragma unroll
-        for (int ks = 0; ks < 9; ++ks) asm volatile("" ::"v"(af[rb][ks]));
+        for (int ks = 0; ks < 8; ++ks) asm volatile("" ::"v"(af[rb][ks]));
+        asm volatile("" ::"v"(ae[rb]));
+    }
     wait_vmcnt<0>();  // prologue loads and the first three DMA groups are done: counted waits start clean
     MSFM_PROBE_SEG(9)
 
@@ -271,7 +276,6 @@ __global__ __launch_bounds__(kPfThreads, 2) void sweep_kernel(
     // (k 132..135) in the others.  The quadruple only fills k = 0..3 of its k-step, so the K = 8 instruction (lane l:
     // k = 4 (l >> 5) .. +3) carries it with half the operand registers; it occupies the pipe as long as a K = 16 one
     // (32 cycles, tools/ubench_clock.hip), i.e. the norm k-step is 4 of a tile's 36 MFMA slots.
-    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
     const int lane_row_off = lcol * kPfRowBytes + lhalf * 16;
     const int lane_ext_off = lcol * kPfRowBytes + 2 * kDim + lhalf * 8;
     auto load_bf = [&](int sl, h8 (&bf)[8], h4 (&be)[2]) {
@@ -293,7 +297,7 @@ __global__ __launch_bounds__(kPfThreads, 2) void sweep_kernel(
             for (int rb = 0; rb < kPfRB; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[rb][ks], bf[ks], acc[rb], 0, 0, 0);
 #pragma unroll
         for (int rb = 0; rb < kPfRB; ++rb)
-            acc[rb] = __builtin_amdgcn_mfma_f32_32x32x8f16(__builtin_shufflevector(af[rb][8], af[rb][8], 0, 1, 2, 3), be, acc[rb], 0, 0, 0);
+            acc[rb] = __builtin_amdgcn_mfma_f32_32x32x8f16(ae[rb], be, acc[rb], 0, 0, 0);
     };
     // Column block 0 of the tile in slot sl on the fragments already in `bf`; as soon as the two MFMAs of a k-step have
     // been issued its registers take the fragment of column block 1 (the read lands 16 MFMAs before it is needed).
@@ -312,7 +316,7 @@ __global__ __launch_bounds__(kPfThreads, 2) void sweep_kernel(
         }
 #pragma unroll
         for (int rb = 0; rb < kPfRB; ++rb)
-            acc[rb] = __builtin_amdgcn_mfma_f32_32x32x8f16(__builtin_shufflevector(af[rb][8], af[rb][8], 0, 1, 2, 3), be, acc[rb], 0, 0, 0);
+            acc[rb] = __builtin_amdgcn_mfma_f32_32x32x8f16(ae[rb], be, acc[rb], 0, 0, 0);
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
             __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);   // 2 MFMA
