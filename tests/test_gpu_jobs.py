@@ -190,7 +190,7 @@ def test_config3_330_images_in_one_call(gpu_ctx, oracle):
     gpu_ctx.set_pipeline(1)
     try:
         again = gpu_ctx.match_pairs(pairs, fetch="view")
-        assert 3 <= gpu_ctx.profile()["sub_batches"] != p["sub_batches"]     # (pair limit 20000, or the scratch limit of one set)
+        assert gpu_ctx.profile()["sub_batches"] >= 3                          # (pair limit 20000, or the scratch limit of one set)
         assert same_result((offs, qt, d), again)
     finally:
         gpu_ctx.set_limits(0, 0)
