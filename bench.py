@@ -274,7 +274,8 @@ def main():
     main_kw = {"max_distance": 1e9} if args.workload == "synthetic-u8" else {}
     acc = {k: 0 for k in ("dist_kernel_ms", "dist_kernel_launches", "approx_kernel_ms", "approx_kernel_launches",
                           "prefilter_descriptor_pairs", "exact_descriptor_pairs", "candidates", "fallback_pairs", "sweep2_ms",
-                          "sweep2_launches", "sweep2_descriptor_pairs", "compacted_pairs", "total_device_ms", "sub_batches")}
+                          "sweep2_launches", "sweep2_descriptor_pairs", "compacted_pairs", "total_device_ms", "sub_batches",
+                          "sweep1b_ms", "sweep1b_launches", "sweep1b_descriptor_pairs", "sweep1_q8_launches")}
     last_prof = {}
 
     def collect(p):
@@ -338,8 +339,9 @@ def main():
         algo_bytes_step = last_prof.get("dist_algo_bytes", 0)
         rows_work = float((n_rows[pairs[:, 0]] + n_rows[pairs[:, 1]]).sum()) * args.steps / max(world, 1)
         out["roofline"] = {
-            "kernel": "sweep 1 of the MFMA prefilter (%s); sweep 2 and the exact fp32 re-check only touch survivors"
-                      % ("v_mfma_i32_32x32x32_i8" if i8 else "v_mfma_f32_32x32x16_f16"),
+            "kernel": "sweep 1 of the MFMA prefilter (%s%s); sweep 2 and the exact fp32 re-check only touch survivors"
+                      % ("v_mfma_i32_32x32x32_i8" if i8 else "v_mfma_f32_32x32x16_f16",
+                         ", on the byte twins of the float store: route Q" if acc["sweep1_q8_launches"] else ""),
             "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TOP/s" if i8 else "TFLOP/s",
             "frac": achieved / peak,
             "traffic": tr["bytes_per_launch"] if tr else None, "traffic_unit": "HBM bytes/launch (PMC)", "traffic_detail": tr,
@@ -351,6 +353,9 @@ def main():
             "sweep2": {"ms_per_step": acc["sweep2_ms"] / args.steps, "launches": acc["sweep2_launches"],
                        "compacted_image_pairs": acc["compacted_pairs"] // max(1, args.steps),
                        "work_fraction_of_sweep1": acc["sweep2_descriptor_pairs"] / max(1, pf_pairs_work)},
+            # route Q (float store, byte twins): sweep 1 above runs on the twins; sweep 1' is the fp16 sweep of the rows it left alive
+            "route_q": {"twin_sweep_launches": acc["sweep1_q8_launches"], "sweep1b_ms_per_step": acc["sweep1b_ms"] / args.steps,
+                        "sweep1b_work_fraction_of_sweep1": acc["sweep1b_descriptor_pairs"] / max(1, pf_pairs_work)},
             "sweep1_ms_per_step": pf_ms / args.steps,
             "step_over_sweep1": (dt / args.steps * 1e3) / max(1e-9, pf_ms / args.steps),
             "candidates_per_row": acc["candidates"] / max(1.0, rows_work),

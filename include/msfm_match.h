@@ -85,6 +85,11 @@ typedef struct msfm_profile {
     int tie_queue_regrows;     /* sub-batches re-run because the sqrt-space tie queue had to grow */
     int plan_regrows;          /* sub-batches re-run because the device-side sweep-2 plan outgrew its predicted buffers */
     int sweep1_i8_launches;     /* sweep-1 launches on the integer matrix cores (byte stores, msfm_sweep_i8.hip.h) */
+    /* route Q: float images with byte twins (all values in [0, 1]) -- sweep 1 on the twins, on the integer matrix cores */
+    int sweep1_q8_launches;     /* sweep-1 launches on byte TWINS of float images (counted in sweep1_i8_launches too) */
+    int sweep1b_launches;       /* fp16 sweep 1' launches: the S~ top-2 of the rows the twins' sweep left alive (sweep_kernel<4>) */
+    double sweep1b_ms;
+    int64_t sweep1b_descriptor_pairs; /* descriptor pairs sweep 1' multiplied (padded compacted rows included) */
     int64_t order_sensitive_rows; /* rows / columns of the call WITHOUT an order-invariance certificate (see
                                      msfm_fetch_order_certificate); 0 => the stored (queryIdx, trainIdx) rows are the same
                                      under any conforming fp32 evaluation order of hal::normL2Sqr_ */
@@ -98,8 +103,11 @@ const char* msfm_last_error(const msfm_ctx* ctx);
 int msfm_device_info(const msfm_ctx* ctx, char* name, int name_cap, int* cu_count, int* clock_mhz);
 int msfm_set_accum_order(msfm_ctx* ctx, int order);
 /* 1 (default): MFMA prefilter + exact re-check where safe -- byte images (MSFM_DTYPE_U8 uploads) on the integer matrix
- * cores (v_mfma_i32_32x32x32_i8), everything else on the fp16 ones; 2: fp16 matrix cores for every image; 0: always the
- * brute-force exact kernel.  Results are bit-identical in all three.  Env: MSFM_PREFILTER=0|1|2. */
+ * cores (v_mfma_i32_32x32x32_i8); float images whose values all lie in [0, 1] (RootSIFT) get a byte twin at upload and
+ * their FIRST sweep on the integer cores too, followed by an fp16 sweep of the ~6 % of rows it leaves alive (route Q,
+ * MSFM_Q8=0 in the environment at msfm_create: off); everything else on the fp16 cores; 2: fp16 matrix cores for every
+ * image; 0: always the brute-force exact kernel.  Results are bit-identical in all.
+ * Env: MSFM_PREFILTER=0|1|2. */
 int msfm_set_prefilter(msfm_ctx* ctx, int enable);
 int msfm_get_profile(const msfm_ctx* ctx, msfm_profile* out);
 /* msfm_match_pairs cuts a call into device sub-batches of at most `max_pairs_per_batch` image pairs and

@@ -112,6 +112,13 @@ struct Image {
     float* nrm_i8 = nullptr;
     float nrm_i8_max = 0.f;
     int h0_i8 = 0;            // centre of the rows' h = floor(|x - 128|^2 / 2): the digit k-step carries H0 - h
+    // route Q (msfm_q8.hip.h): the byte twin q = rint(255 x) of a FLOAT image whose values all lie in [0, 1] -- operand rows,
+    // norms 2h and centre as for a byte image, plus the rows' quantisation error norms and their maximum
+    signed char* q8 = nullptr;
+    float* nrm_q8 = nullptr;
+    float* err_q8 = nullptr;
+    float err_q8_max = 0.f;
+    int h0_q8 = 0;
     // keypoint coordinates (x, y) for the geometric verification; nk = -1: not uploaded
     float2* kxy = nullptr;
     int nk = -1;
@@ -124,6 +131,9 @@ void free_image(Image& im) {
     if (im.nrm) (void)hipFree(im.nrm);
     if (im.i8) (void)hipFree(im.i8);
     if (im.nrm_i8) (void)hipFree(im.nrm_i8);
+    if (im.q8) (void)hipFree(im.q8);
+    if (im.nrm_q8) (void)hipFree(im.nrm_q8);
+    if (im.err_q8) (void)hipFree(im.err_q8);
     if (im.kxy) (void)hipFree(im.kxy);
     im = Image{};
 }
@@ -146,7 +156,7 @@ constexpr long long kMinPipelineCost = 15000000000LL;
 // tail of sub-batch k (thresholds, plan, sweep 2, exact re-check, epilogue, copy-out) runs on one stream, sweep 1 of
 // sub-batch k + 1 already owns the matrix pipes on the other (match_pairs_impl).
 struct PfPending {                // what the end-of-batch synchronisation has to look at
-    bool active = false, compact = false, i8 = false;
+    bool active = false, compact = false, i8 = false, q8 = false;
     size_t n_lists = 0, P = 0;
     long long rows_cap = 0, cand_cap = 0, items_cap = 0;
     int compact_pairs = 0;
@@ -166,6 +176,7 @@ struct Scratch {
     // prefilter path
     DevBuf d_pf, d_tu, d_tv, d_cand, d_cand_s, d_cand_count, d_best, d_second;
     DevBuf d_cmp_tu, d_live_idx, d_row_pair, d_row_src, d_cand_pair, d_vpairs, d_vpf, d_vitems, d_lists;
+    DevBuf d_pfq, d_cmp_s0, d_cmp_s1, d_summary_a;   // route Q: twin pair table, sweep 1' row results, summary of plan A
     // device-side plan of the compacted sweep 2 (msfm_plan.hip.h)
     DevBuf d_colmask, d_groups, d_gmembers, d_member_pair, d_member_group, d_gtot, d_grow0, d_ppair, d_cnt, d_mrow, d_summary, d_overflow, d_totals;
     PfPending pf_pending;
@@ -184,7 +195,7 @@ struct Scratch {
                           &d_cand_pair, &d_vpairs, &d_vpf, &d_vitems, &d_lists, &d_colmask, &d_groups, &d_gmembers, &d_member_pair,
                           &d_member_group, &d_gtot, &d_grow0, &d_ppair, &d_cnt, &d_mrow, &d_summary, &d_overflow, &d_totals, &d_vf_pairs,
                           &d_vf_x1, &d_vf_y1, &d_vf_x2, &d_vf_y2, &d_vf_hyp, &d_vf_best_it, &d_vf_best_count, &d_vf_flags, &d_st2_qt,
-                          &d_st2_d, &d_counts2};
+                          &d_st2_d, &d_counts2, &d_pfq, &d_cmp_s0, &d_cmp_s1, &d_summary_a};
         for (DevBuf* b : bufs) b->release();
         h_summary.release();
         h_tail.release();
@@ -209,6 +220,7 @@ struct msfm_ctx {
     long long scratch_elems = kDefaultScratchElems;
     int pipeline = kDefaultPipeline;  // sub-batches a large call is cut into at least, so that tails overlap sweeps (1: off)
     int prefilter = 1;                // 0: brute force only; 1: MFMA prefilter, integer matrix cores for byte stores; 2: fp16 MFMA only
+    int q8_route = 1;                 // float images in [0, 1] get byte twins and their first sweep on the integer cores (MSFM_Q8=0: off)
     long long cmp_rows_hint = 0;      // compacted rows the previous batch needed (sizes the next batch's buffers)
     long long items_hint = 0, cand_hint = 0;   // likewise: work items, candidate-list capacity
 
@@ -445,13 +457,14 @@ struct CompactPlan {
     std::vector<int> member_pair;   // member -> pair of the batch
     std::vector<PlanPair> ppair;    // per pair
     long long rows_ub = 0;          // compacted rows if every row were alive (each live column counted once)
+    long long rows_ub_all_bits = 0; // ... each column once per block group (plan A of route Q)
     int pairs = 0;
 };
 
 // Which groups exist and which (pair, direction[, block bit]) members they consist of: a function of the pair list
 // alone.  O(pairs + members): counting sort over dense image indices, no maps (this runs on the host while the GPU
 // is busy with sweep 1).
-void build_compact_plan(msfm_ctx* ctx, const Batch& b, CompactPlan& cp) {
+void build_compact_plan(msfm_ctx* ctx, const Batch& b, CompactPlan& cp, bool no_ranges) {
     const size_t P = b.pairs.size();
     cp.ppair.assign(P, PlanPair{-1, 0, 0, 0});
     static thread_local std::vector<int> dense;   // store slot -> dense image index of this batch (-1: absent)
@@ -528,6 +541,7 @@ void build_compact_plan(msfm_ctx* ctx, const Batch& b, CompactPlan& cp) {
             member_group.push_back(rev_group0_of_img[(size_t)di] + bit);
         }
         cp.rows_ub += pd.n2;
+        cp.rows_ub_all_bits += (long long)pd.n1 + (long long)pd.n2 * bits;
     }
     // counting sort of the members by group
     const size_t G = cp.groups.size(), M = cp.member_pair.size();
@@ -544,13 +558,17 @@ void build_compact_plan(msfm_ctx* ctx, const Batch& b, CompactPlan& cp) {
         cp.gmembers[(size_t)(g.first + g.count++)] = (int)m;
     }
     // a small batch would leave most CUs idle with one work item per 512 compacted rows: split the streamed ranges
+    // (route Q keeps whole streamed ranges: sweep 1' writes one row result per compacted row)
     const long long target = 4LL * ctx->cu_count;
-    if ((long long)G < target)
+    if ((long long)G < target && !no_ranges)
         for (PlanGroup& g : cp.groups) {
             const long long r = (target + (long long)G - 1) / (long long)G;
             g.ranges = (int)std::max<long long>(1, std::min<long long>(r, g.bt_end - g.bt_begin));
         }
 }
+
+// layout of Scratch::h_summary: PlanSummary (plan B, the one sweep 2 ran on) | PlanSummary (plan A of route Q) | totals[2] | overflow bytes
+constexpr size_t kHsTotals = 2 * sizeof(PlanSummary), kHsOverflow = kHsTotals + 16;
 
 // MFMA prefilter + exact re-check for the pairs on path 1, WITHOUT a host synchronisation: the caller looks at
 // SC.pf_pending at the end of the batch (finish_prefilter) and re-runs the batch if a capacity was exceeded or a
@@ -591,6 +609,41 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
             pp.b_h0 = ib.h0_i8;
         }
     SC.pf_pending.i8 = i8;
+    // Route Q (msfm_q8.hip.h): float images with byte twins -- sweep 1 on the twins (integer matrix cores), an fp16 sweep 1'
+    // on the rows that survive.  Every prefiltered pair of the batch must join two images with twins.
+    bool q8 = compact && !i8 && ctx->prefilter == 1 && ctx->q8_route;
+    long long q8_rows = 0, q8_pairs = 0;
+    for (size_t p = 0; p < P && q8; ++p)
+        if (b.pairs[p].valid && b.pf[p].use) {
+            q8 = ctx->images[b.id1[p]].q8 != nullptr && ctx->images[b.id2[p]].q8 != nullptr;
+            q8_rows += b.pairs[p].n1 + b.pairs[p].n2;
+            q8_pairs += 1;
+        }
+    // (two plans and three sweeps only pay on real images: batches of small ones -- the pre-emptive filter's 100-row
+    // subsets -- keep the fp16 route; MSFM_Q8=2 lifts the limit, for the tests)
+    if (q8 && ctx->q8_route < 2 && (q8_pairs == 0 || q8_rows < 2 * 1024 * q8_pairs)) q8 = false;
+    std::vector<PfPair> pfq;
+    if (q8) {
+        pfq = b.pf;
+        for (size_t p = 0; p < P; ++p) {
+            if (!b.pairs[p].valid || !b.pf[p].use) continue;
+            const Image& ia = ctx->images[b.id1[p]];
+            const Image& ib = ctx->images[b.id2[p]];
+            PfPair& pp = pfq[p];
+            pp.i8 = 1;
+            pp.a_h = reinterpret_cast<const _Float16*>(ia.q8);
+            pp.b_h = reinterpret_cast<const _Float16*>(ib.q8);
+            pp.a_nrm = ia.nrm_q8;
+            pp.b_nrm = ib.nrm_q8;
+            pp.a_c = ia.err_q8_max;     // (the twin pair carries the images' largest quantisation errors here)
+            pp.b_c = ib.err_q8_max;
+            pp.a_h0 = ia.h0_q8;
+            pp.b_h0 = ib.h0_q8;
+            pp.a_err = ia.err_q8;
+            pp.b_err = ib.err_q8;
+        }
+    }
+    SC.pf_pending.q8 = q8;
     long long dense_cand = 0;
     for (size_t p = 0; p < P; ++p) {
         b.pf[p].tu_off = b.pairs[p].kf_off;
@@ -603,6 +656,10 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
             dense_cand += b.pf[p].cand_cap;
             SC.pf_pending.dense_swept += (long long)b.pairs[p].n1pad * b.pairs[p].n2;
         }
+    }
+    for (size_t p = 0; p < P && q8; ++p) {
+        pfq[p].tu_off = b.pf[p].tu_off;
+        pfq[p].tv_off = b.pf[p].tv_off;
     }
     build_items(b, 1);
     if (b.n_items == 0) return MSFM_OK;
@@ -619,6 +676,10 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
     if (rc != MSFM_OK) return rc;
     rc = upload_items(ctx, b, 1);
     if (rc != MSFM_OK) return rc;
+    if (q8) {
+        HIPCHK(ctx, SC.d_pfq.ensure(P * sizeof(PfPair)));
+        HIPCHK(ctx, hipMemcpyAsync(SC.d_pfq.p, pfq.data(), P * sizeof(PfPair), hipMemcpyHostToDevice, SC.stream));
+    }
     if (!compact) {   // (compacted sweep 2: pf_assign_kernel initialises the live slots only)
         HIPCHK(ctx, hipMemsetAsync(SC.d_best.p, 0xff, kn * 8, SC.stream));
         HIPCHK(ctx, hipMemsetAsync(SC.d_second.p, 0xff, kn * 8, SC.stream));
@@ -645,8 +706,9 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
         if (other.sweep1_recorded) HIPCHK(ctx, hipStreamWaitEvent(SC.stream, other.sweep1_done, 0));
     }
     HIPCHK(ctx, hipEventRecord(e0, SC.stream));
-    if (i8)
-        hipLaunchKernelGGL(sweep_i8_kernel<1>, dim3(std::min<unsigned>(sweep_grid, (unsigned)b.n_items)), dim3(kI8Threads), kI8LdsBytes, SC.stream, dp, dpf,
+    if (i8 || q8)
+        hipLaunchKernelGGL(sweep_i8_kernel<1>, dim3(std::min<unsigned>(sweep_grid, (unsigned)b.n_items)), dim3(kI8Threads), kI8LdsBytes, SC.stream, dp,
+                           q8 ? (const PfPair*)SC.d_pfq.as<PfPair>() : dpf,
                            SC.d_items.as<WorkItem>(), SC.d_rp_s0.as<float>(), SC.d_rp_s1.as<float>(), SC.d_cp_s0.as<float>(),
                            (const float*)nullptr, (int2*)nullptr, (unsigned long long*)nullptr, (const int*)nullptr, (int)b.n_items, (int*)nullptr);
     else
@@ -660,11 +722,12 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
     HIPCHK(ctx, hipEventRecord(SC.sweep1_done, SC.stream));
     SC.sweep1_recorded = true;
     SC.prof.approx_kernel_launches += 1;
-    if (i8) SC.prof.sweep1_i8_launches += 1;
+    if (i8 || q8) SC.prof.sweep1_i8_launches += 1;
+    if (q8) SC.prof.sweep1_q8_launches += 1;
     const dim3 mgrid((unsigned)((b.max_npad + 255) / 256), (unsigned)P);
     if (!compact) {
         hipLaunchKernelGGL(pf_thresholds_kernel, mgrid, dim3(256), 0, SC.stream, dp, dpf, SC.d_rp_s0.as<float>(),
-                           SC.d_rp_s1.as<float>(), SC.d_cp_s0.as<float>(), (unsigned*)nullptr, tuv, tuv, prune, PlanCounts{});
+                           SC.d_rp_s1.as<float>(), SC.d_cp_s0.as<float>(), (unsigned*)nullptr, tuv, tuv, prune, PlanCounts{}, 0);
         HIPCHK(ctx, hipGetLastError());
         DBGSYNC(ctx, "pf_thresholds_kernel");
     }
@@ -675,13 +738,14 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
     if (compact) {
         // ---- static plan tables (the GPU is busy with sweep 1 meanwhile), buffers from the prediction ----------
         CompactPlan cp;
-        build_compact_plan(ctx, b, cp);
+        build_compact_plan(ctx, b, cp, q8);
         const size_t G = cp.groups.size(), M = cp.member_pair.size();
         n_lists = G;
         long long max_ranges = 1;
         for (const PlanGroup& g : cp.groups) max_ranges = std::max<long long>(max_ranges, g.ranges);
         const long long slack = (long long)kPfWgRows * (long long)G + kPfWgRows;
-        const long long rows_cap = std::max<long long>(ctx->cmp_rows_hint + ctx->cmp_rows_hint / 2, cp.rows_ub / 4) + slack;
+        // (route Q: plan A holds every live column once per 512-row block group of the other image)
+        const long long rows_cap = std::max<long long>(ctx->cmp_rows_hint + ctx->cmp_rows_hint / 2, (q8 ? cp.rows_ub_all_bits / 8 : cp.rows_ub / 4)) + slack;
         // (per group: 8 entries per compacted row rounded up to 1024, + 1024 -- plan_group_cap_units)
         const long long cand_cap = std::max<long long>(8 * rows_cap + 2048LL * (long long)G, ctx->cand_hint);
         // (the list holds 8 x the longest per-XCD sub-list: twice the balanced size leaves room for skew)
@@ -728,12 +792,8 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
         HIPCHK(ctx, hipMemsetAsync(SC.d_cand_count.p, 0, std::max<size_t>(1, G) * 8, SC.stream));
         hc.lap("plan tables + uploads");
         const PlanPair* dpp = SC.d_ppair.as<PlanPair>();
-        // thresholds + live counts per member / group (the plan tables above are uploaded by now; sweep 1 is still running)
         PlanCounts pc = {dpp, (const int*)SC.d_member_group.as<int>(), SC.d_cnt.as<int>(), SC.d_gtot.as<int>()};
-        hipLaunchKernelGGL(pf_thresholds_kernel, mgrid, dim3(256), 0, SC.stream, dp, dpf, SC.d_rp_s0.as<float>(),
-                           SC.d_rp_s1.as<float>(), SC.d_cp_s0.as<float>(), colmask, tuv, tuv, prune, pc);
-        HIPCHK(ctx, hipGetLastError());
-        DBGSYNC(ctx, "pf_thresholds_kernel");
+        HIPCHK(ctx, SC.d_summary_a.ensure(sizeof(PlanSummary)));
         PlanOut po = {};
         po.vpairs = SC.d_vpairs.as<PairDesc>();
         po.vpf = SC.d_vpf.as<PfPair>();
@@ -750,28 +810,83 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
         po.rows_cap = rows_cap;
         po.cand_cap = cand_cap;
         po.items_cap = items_cap;
-        hipLaunchKernelGGL(pf_plan_scan_kernel, dim3(1), dim3(64), 0, SC.stream, SC.d_groups.as<PlanGroup>(), (int)G,
-                           (const int*)SC.d_gtot.as<int>(), po);
-        HIPCHK(ctx, hipGetLastError());
-        DBGSYNC(ctx, "pf_plan_scan_kernel");
-        if (G > 0)
-            hipLaunchKernelGGL(pf_plan_write_kernel, dim3((unsigned)((G + 63) / 64)), dim3(64), 0, SC.stream, SC.d_groups.as<PlanGroup>(), (int)G,
+        // the plan from the live counts in d_cnt / d_gtot: scan, descriptors + work items, member rows, slot assignment
+        auto launch_plan = [&](PlanSummary* summary, int norms_only) -> int {
+            po.summary = summary;
+            hipLaunchKernelGGL(pf_plan_scan_kernel, dim3(1), dim3(64), 0, SC.stream, SC.d_groups.as<PlanGroup>(), (int)G,
                                (const int*)SC.d_gtot.as<int>(), po);
+            HIPCHK(ctx, hipGetLastError());
+            DBGSYNC(ctx, "pf_plan_scan_kernel");
+            if (G > 0)
+                hipLaunchKernelGGL(pf_plan_write_kernel, dim3((unsigned)((G + 63) / 64)), dim3(64), 0, SC.stream, SC.d_groups.as<PlanGroup>(), (int)G,
+                                   (const int*)SC.d_gtot.as<int>(), po);
+            HIPCHK(ctx, hipGetLastError());
+            DBGSYNC(ctx, "pf_plan_write_kernel");
+            if (G > 0)
+                hipLaunchKernelGGL(pf_member_rows_kernel, dim3((unsigned)((G + 3) / 4)), dim3(256), 0, SC.stream, SC.d_groups.as<PlanGroup>(), (int)G,
+                                   (const int*)SC.d_gmembers.as<int>(), (const int*)SC.d_cnt.as<int>(),
+                                   (const long long*)SC.d_grow0.as<long long>(), SC.d_mrow.as<long long>());
+            HIPCHK(ctx, hipGetLastError());
+            DBGSYNC(ctx, "pf_member_rows_kernel");
+            hipLaunchKernelGGL(pf_assign_kernel, dim3((unsigned)(2 * P)), dim3(256), 0, SC.stream, dp, dpf, dpp, (const float*)tuv,
+                               (const unsigned*)colmask, (const long long*)SC.d_mrow.as<long long>(),
+                               SC.d_live_idx.as<int>(), SC.d_row_pair.as<int>(), SC.d_cmp_tu.as<float>(),
+                               SC.d_row_src.as<const _Float16*>(), i8 ? kI8RowBytes / 2 : kPfRowHalfs,
+                               SC.d_best.as<unsigned long long>(), SC.d_second.as<unsigned long long>(), norms_only);
+            HIPCHK(ctx, hipGetLastError());
+            DBGSYNC(ctx, "pf_assign_kernel");
+            return MSFM_OK;
+        };
+        if (q8) {
+            // ---- route Q: live / dead from the twins' sweep, plan A, fp16 sweep 1' on the live rows, scatter ------------------
+            hipLaunchKernelGGL(pf_prune_q8_kernel, mgrid, dim3(256), 0, SC.stream, dp, dpf, (const PfPair*)SC.d_pfq.as<PfPair>(),
+                               (const float*)SC.d_rp_s0.as<float>(), (const float*)SC.d_rp_s1.as<float>(), (const float*)SC.d_cp_s0.as<float>(),
+                               colmask, tuv, prune, pc);
+            HIPCHK(ctx, hipGetLastError());
+            DBGSYNC(ctx, "pf_prune_q8_kernel");
+            HIPCHK(ctx, hipMemsetAsync(SC.d_summary_a.p, 0, sizeof(PlanSummary), SC.stream));
+            rc = launch_plan(SC.d_summary_a.as<PlanSummary>(), 1);
+            if (rc != MSFM_OK) return rc;
+            HIPCHK(ctx, SC.d_cmp_s0.ensure((size_t)rows_cap * 4));
+            HIPCHK(ctx, SC.d_cmp_s1.ensure((size_t)rows_cap * 4));
+            hipEvent_t e4 = get_event(ctx, ev_base + 6), e5 = get_event(ctx, ev_base + 7);
+            if (!e4 || !e5) return fail(ctx, MSFM_E_DEVICE, "hipEventCreate failed");
+            HIPCHK(ctx, hipEventRecord(e4, SC.stream));
+            hipLaunchKernelGGL(sweep_kernel<4>, dim3(sweep_grid), block, kPfLdsBytes, SC.stream,
+                               (const PairDesc*)SC.d_vpairs.as<PairDesc>(), (const PfPair*)SC.d_vpf.as<PfPair>(),
+                               (const WorkItem*)SC.d_vitems.as<WorkItem>(), SC.d_cmp_s0.as<float>(), SC.d_cmp_s1.as<float>(), (float*)nullptr,
+                               (float*)nullptr, (const float*)SC.d_cmp_tu.as<float>(), (const float*)nullptr, (int2*)nullptr,
+                               (unsigned long long*)nullptr, (const int*)&SC.d_summary_a.as<PlanSummary>()->n_items, 0,
+                               SC.d_totals.as<int>() + 8);
+            HIPCHK(ctx, hipGetLastError());
+            DBGSYNC(ctx, "sweep_kernel<4>");
+            HIPCHK(ctx, hipEventRecord(e5, SC.stream));
+            SC.prof.sweep1b_launches += 1;
+            if (G > 0)
+                hipLaunchKernelGGL(q8_scatter_kernel, dim3(16, (unsigned)std::min<size_t>(G, 65535)), dim3(256), 0, SC.stream, dp,
+                                   (const PairDesc*)SC.d_vpairs.as<PairDesc>(), (const CandList*)SC.d_lists.as<CandList>(),
+                                   (const PlanGroup*)SC.d_groups.as<PlanGroup>(), (int)G, (const long long*)SC.d_grow0.as<long long>(),
+                                   (const float*)SC.d_cmp_s0.as<float>(), (const float*)SC.d_cmp_s1.as<float>(),
+                                   SC.d_rp_s0.as<float>(), SC.d_rp_s1.as<float>(), SC.d_cp_s0.as<float>());
+            HIPCHK(ctx, hipGetLastError());
+            DBGSYNC(ctx, "q8_scatter_kernel");
+            // plan B starts from clean counters, work items, row sources and item cursors
+            HIPCHK(ctx, hipMemsetAsync(SC.d_gtot.p, 0, std::max<size_t>(1, G) * 4, SC.stream));
+            HIPCHK(ctx, hipMemsetAsync(SC.d_cnt.p, 0, std::max<size_t>(1, M) * 4, SC.stream));
+            HIPCHK(ctx, hipMemsetAsync(SC.d_vpairs.p, 0, std::max<size_t>(1, G) * sizeof(PairDesc), SC.stream));
+            HIPCHK(ctx, hipMemsetAsync(SC.d_vpf.p, 0, std::max<size_t>(1, G) * sizeof(PfPair), SC.stream));
+            HIPCHK(ctx, hipMemsetAsync(SC.d_lists.p, 0, std::max<size_t>(1, G) * sizeof(CandList), SC.stream));
+            HIPCHK(ctx, hipMemsetAsync(SC.d_vitems.p, 0xff, (size_t)items_cap * sizeof(WorkItem), SC.stream));
+            HIPCHK(ctx, hipMemsetAsync(SC.d_row_src.p, 0, (size_t)rows_cap * 8, SC.stream));
+            HIPCHK(ctx, hipMemsetAsync(SC.d_totals.p, 0, 64, SC.stream));
+        }
+        // thresholds + live counts per member / group (the plan tables above are uploaded by now; sweep 1 is still running)
+        hipLaunchKernelGGL(pf_thresholds_kernel, mgrid, dim3(256), 0, SC.stream, dp, dpf, SC.d_rp_s0.as<float>(),
+                           SC.d_rp_s1.as<float>(), SC.d_cp_s0.as<float>(), colmask, tuv, tuv, prune, pc, q8 ? 1 : 0);
         HIPCHK(ctx, hipGetLastError());
-        DBGSYNC(ctx, "pf_plan_write_kernel");
-        if (G > 0)
-            hipLaunchKernelGGL(pf_member_rows_kernel, dim3((unsigned)((G + 3) / 4)), dim3(256), 0, SC.stream, SC.d_groups.as<PlanGroup>(), (int)G,
-                               (const int*)SC.d_gmembers.as<int>(), (const int*)SC.d_cnt.as<int>(),
-                               (const long long*)SC.d_grow0.as<long long>(), SC.d_mrow.as<long long>());
-        HIPCHK(ctx, hipGetLastError());
-        DBGSYNC(ctx, "pf_member_rows_kernel");
-        hipLaunchKernelGGL(pf_assign_kernel, dim3((unsigned)(2 * P)), dim3(256), 0, SC.stream, dp, dpf, dpp, (const float*)tuv,
-                           (const unsigned*)colmask, (const long long*)SC.d_mrow.as<long long>(),
-                           SC.d_live_idx.as<int>(), SC.d_row_pair.as<int>(), SC.d_cmp_tu.as<float>(),
-                           SC.d_row_src.as<const _Float16*>(), i8 ? kI8RowBytes / 2 : kPfRowHalfs,
-                           SC.d_best.as<unsigned long long>(), SC.d_second.as<unsigned long long>());
-        HIPCHK(ctx, hipGetLastError());
-        DBGSYNC(ctx, "pf_assign_kernel");
+        DBGSYNC(ctx, "pf_thresholds_kernel");
+        rc = launch_plan(SC.d_summary.as<PlanSummary>(), 0);
+        if (rc != MSFM_OK) return rc;
         HIPCHK(ctx, hipEventRecord(e2, SC.stream));
         if (i8)
             hipLaunchKernelGGL(sweep_i8_kernel<3>, dim3(sweep_grid), dim3(kI8Threads), kI8LdsBytes, SC.stream,
@@ -876,7 +991,7 @@ int finish_prefilter(msfm_ctx* ctx, Batch& b, std::vector<char>& force_exact, bo
     const char* hs = SC.h_summary.as<char>();
     PlanSummary sm = {};
     unsigned long long totals[2] = {0, 0};
-    std::memcpy(totals, hs + sizeof(PlanSummary), 16);
+    std::memcpy(totals, hs + kHsTotals, 16);
     float ms = 0.f;
     HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev_pool[pe.ev_base], ctx->ev_pool[pe.ev_base + 1]));
     SC.prof.approx_kernel_ms += ms;
@@ -914,6 +1029,18 @@ int finish_prefilter(msfm_ctx* ctx, Batch& b, std::vector<char>& force_exact, bo
         ctx->cmp_rows_hint = sm.cmp_rows;
         ctx->items_hint = sm.items_needed;
         ctx->cand_hint = sm.cand_elems;
+        if (pe.q8) {   // plan A (every live column in every block group) is the larger one
+            PlanSummary sa;
+            std::memcpy(&sa, hs + sizeof(PlanSummary), sizeof(PlanSummary));
+            ctx->cmp_rows_hint = std::max(ctx->cmp_rows_hint, sa.cmp_rows);
+            ctx->items_hint = std::max(ctx->items_hint, sa.items_needed);
+            ctx->cand_hint = std::max(ctx->cand_hint, sa.cand_elems);
+            if (!sa.ok) sm.ok = 0;
+            float ms1b = 0.f;
+            HIPCHK(ctx, hipEventElapsedTime(&ms1b, ctx->ev_pool[pe.ev_base + 6], ctx->ev_pool[pe.ev_base + 7]));
+            SC.prof.sweep1b_ms += ms1b;
+            SC.prof.sweep1b_descriptor_pairs += sa.swept_desc_pairs;
+        }
         if (!sm.ok) {   // the prediction was too small: the buffers are sized from the need now
             SC.prof.plan_regrows += 1;
             *retry = true;
@@ -923,7 +1050,7 @@ int finish_prefilter(msfm_ctx* ctx, Batch& b, std::vector<char>& force_exact, bo
     } else {
         SC.prof.sweep2_descriptor_pairs += pe.dense_swept;
     }
-    const unsigned char* ov = reinterpret_cast<const unsigned char*>(hs + sizeof(PlanSummary) + 16);
+    const unsigned char* ov = reinterpret_cast<const unsigned char*>(hs + kHsOverflow);
     int n_over = 0;
     for (size_t p = 0; p < pe.P; ++p) {
         if (!b.pairs[p].valid || !b.pf[p].use) continue;
@@ -1051,13 +1178,13 @@ struct ExportSeg {
     unsigned bytes;
 };
 struct ExportSegs {
-    ExportSeg s[6];
+    ExportSeg s[8];
 };
 
 __global__ void export_tail_kernel(ExportSegs segs) {
     MSFM_TAIL_PRIO();
     const unsigned tid = blockIdx.x * blockDim.x + threadIdx.x, nt = gridDim.x * blockDim.x;
-    for (int k = 0; k < 6; ++k) {
+    for (int k = 0; k < 8; ++k) {
         const ExportSeg e = segs.s[k];
         const unsigned words = e.bytes >> 2;
         for (unsigned i = tid; i < words; i += nt) reinterpret_cast<unsigned*>(e.dst)[i] = reinterpret_cast<const unsigned*>(e.src)[i];
@@ -1068,7 +1195,7 @@ __global__ void export_tail_kernel(ExportSegs segs) {
 
 int queue_tail_copies(msfm_ctx* ctx, size_t P) {
     HIPCHK(ctx, SC.h_tail.ensure(8 + (P + 1) * 8 + P * 4 + 64, 0));
-    HIPCHK(ctx, SC.h_summary.ensure(sizeof(PlanSummary) + 16 + P + 64, 0));
+    HIPCHK(ctx, SC.h_summary.ensure(kHsOverflow + P + 64, 0));
     char *h = nullptr, *hs = nullptr;
     HIPCHK(ctx, hipHostGetDevicePointer((void**)&h, SC.h_tail.p, 0));
     HIPCHK(ctx, hipHostGetDevicePointer((void**)&hs, SC.h_summary.p, 0));
@@ -1078,8 +1205,9 @@ int queue_tail_copies(msfm_ctx* ctx, size_t P) {
     if (SC.d_sens.p) segs.s[2] = ExportSeg{SC.d_sens.as<char>(), h + 8 + (P + 1) * 8, (unsigned)(P * 4)};
     if (SC.pf_pending.active) {
         if (SC.pf_pending.compact) segs.s[3] = ExportSeg{SC.d_summary.as<char>(), hs, (unsigned)sizeof(PlanSummary)};
-        segs.s[4] = ExportSeg{SC.d_totals.as<char>(), hs + sizeof(PlanSummary), 16};
-        segs.s[5] = ExportSeg{SC.d_overflow.as<char>(), hs + sizeof(PlanSummary) + 16, (unsigned)P};
+        if (SC.pf_pending.q8) segs.s[6] = ExportSeg{SC.d_summary_a.as<char>(), hs + sizeof(PlanSummary), (unsigned)sizeof(PlanSummary)};
+        segs.s[4] = ExportSeg{SC.d_totals.as<char>(), hs + kHsTotals, 16};
+        segs.s[5] = ExportSeg{SC.d_overflow.as<char>(), hs + kHsOverflow, (unsigned)P};
     }
     hipLaunchKernelGGL(export_tail_kernel, dim3(32), dim3(256), 0, SC.stream, segs);
     HIPCHK(ctx, hipGetLastError());
@@ -1168,6 +1296,8 @@ int msfm_create(int device_ordinal, msfm_ctx** out_ctx) {
                                         hipFuncAttributeMaxDynamicSharedMemorySize, kPfLdsBytes);
     hipError_t e4 = hipFuncSetAttribute(reinterpret_cast<const void*>(sweep_kernel<3>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, kPfLdsBytes);
+    if (e4 == hipSuccess)
+        e4 = hipFuncSetAttribute(reinterpret_cast<const void*>(sweep_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, kPfLdsBytes);
     hipError_t e5 = hipFuncSetAttribute(reinterpret_cast<const void*>(sweep_i8_kernel<1>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, kI8LdsBytes);
     hipError_t e6 = hipFuncSetAttribute(reinterpret_cast<const void*>(sweep_i8_kernel<3>),
@@ -1188,6 +1318,7 @@ int msfm_create(int device_ordinal, msfm_ctx** out_ctx) {
     if (const char* e = std::getenv("MSFM_PREFILTER")) ctx->prefilter = e[0] == '2' ? 2 : (e[0] != '0');
     if (const char* e = std::getenv("MSFM_MAX_PAIRS_PER_BATCH"))
         if (std::atoi(e) > 0) ctx->max_pairs_per_batch = std::min(std::atoi(e), kMaxPairsPerBatchLimit);
+    if (const char* e = std::getenv("MSFM_Q8")) ctx->q8_route = e[0] == '2' ? 2 : (e[0] != '0');
     if (const char* e = std::getenv("MSFM_PIPELINE"))
         if (std::atoi(e) > 0) ctx->pipeline = std::min(std::atoi(e), 64);
     if (const char* e = std::getenv("MSFM_SCRATCH_MIB"))
@@ -1289,6 +1420,51 @@ static int alloc_image(msfm_ctx* ctx, Image& im, int n) {
     return MSFM_OK;
 }
 
+// route Q: byte twin of a float image with values in [0, 1] (msfm_q8.hip.h); no twin (nothing allocated) when a value
+// is negative / not finite or the rows' norms spread beyond the digit range
+static int build_q8_twin(msfm_ctx* ctx, Image& im) {
+    const int n = im.n, npad = im.nalloc * kBM;
+    HIPCHK(ctx, ctx->d_stage.ensure((size_t)n * kDim * 4));
+    HIPCHK(ctx, ctx->d_maxima.ensure(32));
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_maxima.p, 0, 32, SC.stream));
+    HIPCHK(ctx, hipMalloc((void**)&im.err_q8, (size_t)std::max(n, 1) * 4));
+    unsigned* mx_d = ctx->d_maxima.as<unsigned>();
+    hipLaunchKernelGGL(pf_quantise_q8_kernel, dim3(std::min(2048, (n + 3) / 4)), dim3(256), 0, SC.stream, (const float*)im.raw,
+                       ctx->d_stage.as<float>(), im.err_q8, mx_d + 4, mx_d + 5, n);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipMalloc((void**)&im.q8, (size_t)npad * kI8RowBytes));
+    HIPCHK(ctx, hipMalloc((void**)&im.nrm_q8, (size_t)npad * 4));
+    hipLaunchKernelGGL(pf_prepare_i8_kernel, dim3(std::min(2048, (npad * 11 + 255) / 256)), dim3(256), 0, SC.stream,
+                       (const float*)ctx->d_stage.as<float>(), im.q8, im.nrm_q8, mx_d, n, npad);
+    HIPCHK(ctx, hipGetLastError());
+    unsigned mx[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    HIPCHK(ctx, hipMemcpyAsync(mx, ctx->d_maxima.p, 32, hipMemcpyDeviceToHost, SC.stream));
+    HIPCHK(ctx, hipStreamSynchronize(SC.stream));
+    float nmax = 0.f, nmin = 0.f;
+    const unsigned min_bits = ~mx[3];
+    std::memcpy(&nmax, &mx[2], 4);
+    std::memcpy(&nmin, &min_bits, 4);
+    std::memcpy(&im.err_q8_max, &mx[5], 4);
+    const long long hmax = (long long)(0.5f * nmax), hmin = (long long)(0.5f * nmin);
+    const long long h0 = (hmin + hmax) / 2;
+    const bool ok = mx[4] == 0 && hmin <= hmax && h0 - hmax >= kI8DigitLo && h0 - hmin <= kI8DigitHi;
+    if (!ok) {
+        (void)hipFree(im.q8);
+        (void)hipFree(im.nrm_q8);
+        (void)hipFree(im.err_q8);
+        im.q8 = nullptr;
+        im.nrm_q8 = nullptr;
+        im.err_q8 = nullptr;
+        return MSFM_OK;
+    }
+    im.h0_q8 = (int)h0;
+    hipLaunchKernelGGL(pf_digits_i8_kernel, dim3(std::min(1024, (n + 255) / 256)), dim3(256), 0, SC.stream,
+                       (const float*)im.nrm_q8, im.q8, n, im.h0_q8);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipStreamSynchronize(SC.stream));
+    return MSFM_OK;
+}
+
 // everything derived from the row-major fp32 copy `im.raw` (src8 != nullptr: u8 rows still to be widened
 // into im.raw by the layout kernel): panels in accumulation order, prefilter operands
 static int build_image(msfm_ctx* ctx, Image& im, const unsigned char* src8, bool is_u8) {
@@ -1351,6 +1527,10 @@ static int build_image(msfm_ctx* ctx, Image& im, const unsigned char* src8, bool
             im.nrm_i8 = nullptr;
             im.is_u8 = false;
         }
+    }
+    if (!is_u8 && ctx->q8_route && im.abs_max <= 1.f) {
+        int rc = build_q8_twin(ctx, im);
+        if (rc != MSFM_OK) return rc;
     }
     im.pf_safe = (im.abs_max <= kF16Safe) && (im.nrm_max < 3.0e38f);  // NaN/inf compare false
     if (im.pf_safe) {
@@ -1481,6 +1661,10 @@ void add_profile(msfm_profile& to, const msfm_profile& d) {
     to.plan_regrows += d.plan_regrows;
     to.sweep1_i8_launches += d.sweep1_i8_launches;
     to.order_sensitive_rows += d.order_sensitive_rows;
+    to.sweep1_q8_launches += d.sweep1_q8_launches;
+    to.sweep1b_launches += d.sweep1b_launches;
+    to.sweep1b_ms += d.sweep1b_ms;
+    to.sweep1b_descriptor_pairs += d.sweep1b_descriptor_pairs;
 }
 
 int drain_streams(msfm_ctx* ctx) {
@@ -1757,7 +1941,7 @@ static int match_pairs_impl(msfm_ctx* ctx, const int32_t* pairs, int n_pairs, co
             ctx->cur = &ctx->sc[slot];
             int rc = build(sb[slot], next_begin, no_force);
             if (rc != MSFM_OK) return rc;
-            rc = issue(sb[slot], 2 + 8 * (size_t)slot);
+            rc = issue(sb[slot], 2 + 12 * (size_t)slot);
             if (rc != MSFM_OK) return rc;
             next_begin = sb[slot].end;
         }
@@ -1778,7 +1962,7 @@ static int match_pairs_impl(msfm_ctx* ctx, const int32_t* pairs, int n_pairs, co
                 for (int attempt = 1;; ++attempt) {
                     rc = build(sb[other], sb[other].begin, force_exact);
                     if (rc != MSFM_OK) return rc;
-                    rc = issue(sb[other], 2 + 8 * (size_t)other);
+                    rc = issue(sb[other], 2 + 12 * (size_t)other);
                     if (rc != MSFM_OK) return rc;
                     rc = complete(sb[other], force_exact, &retry);
                     if (rc != MSFM_OK) return rc;

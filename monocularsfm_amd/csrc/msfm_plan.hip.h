@@ -181,6 +181,7 @@ __global__ void pf_plan_write_kernel(const PlanGroup* __restrict__ groups, int n
     vd->valid = 1;
     vd->path = 1;
     vd->ranges = G->ranges;
+    vd->rp_off = row0;   // (sweep 1' of route Q writes its row results per compacted row)
     MSFM_PLAN_FENCE();
     PfPair* vp = out.vpf + g;
     vp->a_h = out.zero_row;
@@ -254,7 +255,8 @@ __global__ void pf_assign_kernel(const PairDesc* __restrict__ pairs, const PfPai
                                  const float* __restrict__ tuv, const unsigned* __restrict__ colmask, const long long* __restrict__ mrow,
                                  int* __restrict__ live_idx, int* __restrict__ row_pair, float* __restrict__ cmp_tu,
                                  const _Float16** __restrict__ row_src, int row_halfs /* 136: fp16 rows, 72: byte rows */,
-                                 unsigned long long* __restrict__ best, unsigned long long* __restrict__ second) {
+                                 unsigned long long* __restrict__ best, unsigned long long* __restrict__ second,
+                                 int norms_only /* plan A of route Q: the sweep wants -|a|^2 (accumulator = -S~/2), not T - |a|^2 */) {
     MSFM_TAIL_PRIO();
     const int p = blockIdx.x >> 1, dir = blockIdx.x & 1;
     const PlanPair pl = pp_plan[p];
@@ -289,7 +291,7 @@ __global__ void pf_assign_kernel(const PairDesc* __restrict__ pairs, const PfPai
             const long long k = r0 + atomicAdd(&cursor[b], 1);
             live_idx[k] = e;
             row_pair[k] = p;
-            cmp_tu[k] = t - nrm[e];
+            cmp_tu[k] = norms_only ? -nrm[e] : t - nrm[e];
             row_src[k] = src + (size_t)e * row_halfs;
         }
     }

@@ -95,6 +95,8 @@ struct PfPair {            // per-pair extras of the prefilter path (parallel to
                            //    (msfm_sweep_i8.hip.h), eps = 2
     int a_h0, b_h0;        // i8: the images' centres H0 (the digit k-step of a row carries H0 - h)
     int pad;
+    const float* a_err;    // route Q (msfm_q8.hip.h), twin pairs only: per-row quantisation error norms of the byte twins;
+    const float* b_err;    //   the images' maxima of them travel in a_c / b_c
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -216,7 +218,8 @@ struct PlanCounts {
 __global__ void pf_thresholds_kernel(const PairDesc* __restrict__ pairs, const PfPair* __restrict__ pf,
                                      const float* __restrict__ rp_s0, const float* __restrict__ rp_s1,
                                      const float* __restrict__ cp_s0, unsigned* __restrict__ colmask,
-                                     float* __restrict__ tu, float* __restrict__ tv, PruneParams pr, PlanCounts plan) {
+                                     float* __restrict__ tu, float* __restrict__ tv, PruneParams pr, PlanCounts plan,
+                                     int marked /* route Q: tu / tv arrive holding -inf for what pf_prune_q8_kernel found dead: skipped */) {
     MSFM_TAIL_PRIO();
     const PairDesc pd = pairs[blockIdx.y];
     const PfPair pp = pf[blockIdx.y];
@@ -225,7 +228,7 @@ __global__ void pf_thresholds_kernel(const PairDesc* __restrict__ pairs, const P
     bool row_live = false;       // for the plan counts below
     unsigned col_bits = 0;
     const float eps_norm = 4.8828125e-4f * fmaxf(pp.a_c, pp.b_c);  // 2^-11 c: fp16 subnormal flush of the norm quadruples
-    if (e < pd.n1pad) {
+    if (e < pd.n1pad && !(marked && tu[pp.tu_off + e] == -f_inf())) {
         float s0 = f_inf(), s1 = f_inf();
         for (int p = 0; p < pd.ranges; ++p) {
             const long long o = pd.rp_off + (long long)p * pd.n1pad + e;
@@ -240,7 +243,9 @@ __global__ void pf_thresholds_kernel(const PairDesc* __restrict__ pairs, const P
         tu[pp.tu_off + e] = live ? s1 + slack : -f_inf();
         row_live = live;
     }
-    if (e < pd.n2pad) {
+    if (e < pd.n2pad && marked && tv[pp.tv_off + e] == -f_inf()) {
+        if (colmask) colmask[pp.tv_off + e] = 0;
+    } else if (e < pd.n2pad) {
         // column partials of sweep 1: per 512-row A block the two largest of the accumulator maxima (-S~/2) over four
         // disjoint row classes; the second smallest S~ over all of them is an upper bound of the column's second-smallest.
         // Up to 16 blocks (8192 rows) the blocks' minima stay in registers for the mask below.
@@ -436,6 +441,7 @@ __global__ void pf_reduce_second_kernel(const PairDesc* __restrict__ pairs, cons
 }
 
 #include "msfm_plan.hip.h"
+#include "msfm_q8.hip.h"
 
 // finalize: the same outputs as merge_knn_kernel (idx0, d0, d1, tie queue)
 __global__ void pf_finalize_kernel(const PairDesc* __restrict__ pairs, const PfPair* __restrict__ pf,

@@ -1,0 +1,172 @@
+// msfm_q8.hip.h -- route Q: the first sweep of a FLOAT store on the INTEGER matrix cores (included by msfm_prefilter.hip.h).
+//
+// v_mfma_i32_32x32x32_i8 sustains ~2.0 POP/s on this part against ~1.25 PFLOP/s for the fp16 instruction: the integer
+// sweep of msfm_sweep_i8.hip.h does the same 128-term products in 0.62 of the time.  RootSIFT rows are bounded ([0, 1],
+// unit L2 norm: FeatureExtraction's L1-root normalisation, src/Feature/FeatureExtraction.cpp:260-270 of the reference),
+// so every image with all values in [0, 1] gets a BYTE TWIN  q = rint(255 x)  next to its fp16 operand rows, stored
+// exactly like a byte image (signed rows of 176 B with the norm digits).  The integer sweep on the twins yields, per
+// row, the exact integer S^ = |q_a - q_b|^2 of the two nearest twins (up to the parity bits: eps = 2, msfm_sweep_i8).
+//
+// What the twins prove.  With a^ = q_a / 255, e_a = |a - a^|_2 (computed per row at upload, rounded up) and d^ = |a^ - b^|:
+//        | |a - b| - d^ |  <=  e_a + e_b                         (triangle inequality, real arithmetic)
+// so per row q of image 1, with E_2 = max_t e_t:
+//        d0  >=  L0 = sqrt(S^min) / 255 - (e_q + E_2)            (S^min = smallest S^: S~ <= S^ <= S~ + 2)
+//        d1  <=  U1 = sqrt(S^(2) + 2) / 255 + (e_q + E_2)        (S^(2): an upper bound of the second smallest)
+// If L0 >= ratio * U1 the Lowe test fails whatever the exact bits are, if L0 > max_distance the distance cut removes
+// the row: it is DEAD, exactly as for the fp16 bounds of pf_thresholds_kernel (the pinned fp32 order is within 4e-6
+// relative of the real distance, msfm_kernels.hip.h: a factor 1 +- 1e-5 covers it).  On the bench data the same 6 % of the
+// rows stay alive as under the fp16 bound (tools/int8_prefilter_study.py) -- but the twin thresholds are too loose to
+// collect candidates with (28 per live row instead of 2.5).  So the live rows alone get an fp16 sweep 1:
+//
+//   sweep 1     sweep_i8_kernel<1> on the twins, every descriptor pair of the batch               (the dominant kernel)
+//   prune       pf_prune_q8_kernel: live / dead per row and column, live counts for plan A
+//   plan A      the compacted-sweep plan (msfm_plan.hip.h) with every live column in EVERY 512-row block group
+//   sweep 1'    sweep_kernel<4>: fp16 S~ top-2 of every compacted live row over its group's tiles  (~13 % of sweep 1's work)
+//   scatter     q8_scatter_kernel: those top-2 into the partial arrays pf_thresholds_kernel reads (rows: one range;
+//               columns: one entry per block group = the per-block minima the block mask needs)
+//   thresholds  pf_thresholds_kernel, unchanged but for skipping what the prune kernel marked dead
+//   plan B, sweep 2, exact re-check, ...   as on the fp16 route.
+// The candidate sets, and with them every bit of the result, are those of the fp16 route restricted to rows that are
+// provably dead anyway.
+#pragma once
+// (included inside namespace msfm)
+
+constexpr float kQ8Scale = 255.f;
+
+// byte twin of a float image: qf = rint(255 x) as floats (the input format of pf_prepare_i8_kernel), err[row] >= |x - q/255|_2
+// flags[0] |= 1 when a value is outside [0, 1] or not finite: no twin.  maxima[0] = max err (float bits).
+__global__ void pf_quantise_q8_kernel(const float* __restrict__ raw, float* __restrict__ qf, float* __restrict__ err,
+                                      unsigned* __restrict__ flags, unsigned* __restrict__ err_max, int n) {
+    const int lane = threadIdx.x & 63;
+    for (int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; row < n; row += (gridDim.x * blockDim.x) >> 6) {
+        float s = 0.f;
+        bool bad = false;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const float x = raw[(size_t)row * kDim + lane + 64 * k];
+            if (!(x >= 0.f && x <= 1.f)) bad = true;
+            const float q = fminf(fmaxf(rintf(x * kQ8Scale), 0.f), 255.f);
+            qf[(size_t)row * kDim + lane + 64 * k] = q;
+            const float d = x - q * (1.f / kQ8Scale);
+            s = fmaf(d, d, s);
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
+        if (__ballot(bad) != 0ull) {
+            if (lane == 0) atomicOr(&flags[0], 1u);
+        }
+        if (lane == 0) {
+            // rounded up: 130 fp32 roundings of non-negative terms (< 1e-5 relative), the division by 255 and the sqrt
+            const float e = sqrtf(s) * (1.f + 2e-5f) + 1e-7f;
+            err[row] = e;
+            atomicMax(err_max, __float_as_uint(e));
+        }
+    }
+}
+
+// live / dead from the integer sweep on the twins.  Rows: rp_s0 / rp_s1 hold S~min and an upper bound of the second
+// smallest S~ (floats holding integers); columns: per 512-row block the two largest accumulator maxima (-S~/2).
+// Live rows / columns get the marker +inf in tu / tv (dead: -inf), every live column carries ALL block bits.
+// grid = (ceil(max_npad/256), n_pairs), like pf_thresholds_kernel, whose member counting this kernel repeats.
+__global__ void pf_prune_q8_kernel(const PairDesc* __restrict__ pairs, const PfPair* __restrict__ pf, const PfPair* __restrict__ pfq,
+                                   const float* __restrict__ rp_s0, const float* __restrict__ rp_s1, const float* __restrict__ cp_s0,
+                                   unsigned* __restrict__ colmask, float* __restrict__ tuv, PruneParams pr, PlanCounts plan) {
+    MSFM_TAIL_PRIO();
+    const PairDesc pd = pairs[blockIdx.y];
+    const PfPair pp = pf[blockIdx.y];
+    if (!pd.valid || !pp.use) return;
+    const PfPair pq = pfq[blockIdx.y];
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    bool row_live = false;
+    unsigned col_bits = 0;
+    const float inv = 1.f / kQ8Scale;
+    auto dead = [&](float s0, float s1, float err) -> bool {
+        // S~ <= S^ <= S~ + 2;  sqrtf and the products below are rounded: the factors (1 -+ 1e-6) keep the bounds one-sided
+        const float l0 = fmaxf(sqrtf(fmaxf(s0, 0.f)) * inv * (1.f - 1e-6f) - err, 0.f);
+        const float u1 = sqrtf(s1 + 2.f) * inv * (1.f + 1e-6f) + err;
+        const bool ratio_fails = pr.ratio > 0.f && l0 * (1.f - 1e-5f) >= pr.ratio * u1 * (1.f + 1e-5f);
+        const bool too_far = l0 * (1.f - 1e-5f) > pr.max_distance * (1.f + 1e-5f);
+        return ratio_fails || too_far;
+    };
+    if (e < pd.n1pad) {
+        float s0 = f_inf(), s1 = f_inf();
+        for (int p = 0; p < pd.ranges; ++p) {
+            const long long o = pd.rp_off + (long long)p * pd.n1pad + e;
+            v2_merge(s0, s1, rp_s0[o], rp_s1[o]);
+        }
+        bool live = e < pd.n1;
+        if (live) live = !dead(s0, s1, (pq.a_err[e] + pq.b_c) * (1.f + 1e-6f));   // (b_c of the twin pair: E of image 2)
+        tuv[pp.tu_off + e] = live ? f_inf() : -f_inf();
+        row_live = live;
+    }
+    if (e < pd.n2pad) {
+        float s0 = f_inf(), s1 = f_inf();
+        const float2* cp2 = reinterpret_cast<const float2*>(cp_s0);
+        const int nb = pd.a_blocks256;
+        for (int p = 0; p < nb; ++p) {
+            const float2 m = cp2[pd.cp_off + (long long)p * pd.n2pad + e];
+            v2_merge(s0, s1, -2.f * m.x, -2.f * m.y);
+        }
+        bool live = e < pd.n2;
+        if (live) live = !dead(s0, s1, (pq.b_err[e] + pq.a_c) * (1.f + 1e-6f));
+        tuv[pp.tv_off + e] = live ? f_inf() : -f_inf();
+        // sweep 1' visits every 512-row block group of image 1 for a live column: one bit per group (see pf_thresholds_kernel)
+        const int g = (nb + 31) / 32, bits = (nb + g - 1) / g;
+        col_bits = live ? (bits >= 32 ? 0xffffffffu : ((1u << bits) - 1u)) : 0u;
+        colmask[pp.tv_off + e] = col_bits;
+    }
+    if (plan.pp_plan) {
+        const PlanPair pl = plan.pp_plan[blockIdx.y];
+        if (pl.fwd_member < 0) return;   // (block-uniform)
+        __shared__ int hist[33];
+        if (threadIdx.x < 33) hist[threadIdx.x] = 0;
+        __syncthreads();
+        const unsigned long long rl = __ballot(row_live);
+        if ((threadIdx.x & 63) == 0 && rl) atomicAdd(&hist[32], __popcll(rl));
+        const unsigned long long cl = __ballot(col_bits != 0u);
+        if ((threadIdx.x & 63) == 0 && cl) atomicAdd(&hist[0], __popcll(cl));   // every live column carries every bit
+        __syncthreads();
+        if (threadIdx.x == 0 && hist[32]) {
+            atomicAdd(&plan.cnt[pl.fwd_member], hist[32]);
+            atomicAdd(&plan.gtot[plan.member_group[pl.fwd_member]], hist[32]);
+        }
+        if ((int)threadIdx.x < pl.rev_bits && hist[0]) {
+            atomicAdd(&plan.cnt[pl.rev_member0 + threadIdx.x], hist[0]);
+            atomicAdd(&plan.gtot[plan.member_group[pl.rev_member0 + threadIdx.x]], hist[0]);
+        }
+    }
+}
+
+// sweep 1' results -> the partial arrays pf_thresholds_kernel reads.  One thread per compacted row k of plan A:
+// forward group: rp_s0 / rp_s1 of (pair, row) -- range 0 (the other ranges of a split pair get +inf);
+// reverse group (image, block bit b): the float2 column partial of the bit's FIRST 512-row block, -inf in the bit's others.
+__global__ void q8_scatter_kernel(const PairDesc* __restrict__ pairs, const PairDesc* __restrict__ vpairs, const CandList* __restrict__ lists,
+                                  const PlanGroup* __restrict__ groups, int n_groups, const long long* __restrict__ grow0,
+                                  const float* __restrict__ cmp_s0, const float* __restrict__ cmp_s1,
+                                  float* __restrict__ rp_s0, float* __restrict__ rp_s1, float* __restrict__ cp_s0) {
+    MSFM_TAIL_PRIO();
+    const int g = blockIdx.y;
+    if (g >= n_groups) return;
+    const long long row0 = grow0[g];
+    if (row0 < 0) return;
+    const int rows = vpairs[g].n1;
+    const CandList L = lists[g];
+    const PlanGroup G = groups[g];
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < rows; k += gridDim.x * blockDim.x) {
+        const int e = L.live_idx[k];
+        const PairDesc pd = pairs[L.row_pair[k]];
+        const float s0 = cmp_s0[row0 + k], s1 = cmp_s1[row0 + k];
+        if (G.dir == 0) {
+            for (int p = 0; p < pd.ranges; ++p) {
+                rp_s0[pd.rp_off + (long long)p * pd.n1pad + e] = p == 0 ? s0 : f_inf();
+                rp_s1[pd.rp_off + (long long)p * pd.n1pad + e] = p == 0 ? s1 : f_inf();
+            }
+        } else {
+            // the group's tile range [bt_begin, bt_end) in 128-row blocks = the 512-row blocks [bt_begin / 4, ceil(bt_end / 4))
+            const int p0 = G.bt_begin / (kPfWgRows / kBM), p1 = (G.bt_end + kPfWgRows / kBM - 1) / (kPfWgRows / kBM);
+            float2* cp2 = reinterpret_cast<float2*>(cp_s0);
+            for (int p = p0; p < p1 && p < pd.a_blocks256; ++p)
+                cp2[pd.cp_off + (long long)p * pd.n2pad + e] = p == p0 ? make_float2(-0.5f * s0, -0.5f * s1) : make_float2(-f_inf(), -f_inf());
+        }
+    }
+}

@@ -43,6 +43,9 @@
 // PASS 2: accumulator = -S~/2; append (q, t) where S~ <= T_row[q] or S~ <= T_col[t]   (dense sweep 2).
 // PASS 3: A = compacted live rows, accumulator = -(S~ - T_row)/2; append (k, t) where it is >= 0.
 //         PASS 2 / 3 first reduce a block to "any hit?" with v_max3 and only then build the bit mask.
+// PASS 4: A = compacted live rows (as PASS 3), accumulator = -S~/2, ROW results only (as PASS 1): the two smallest S~ of
+//         every compacted row over the streamed tile range.  The fp16-accurate sweep 1 of the rows an int8-quantised
+//         first sweep left alive (msfm_match.hip, route Q).
 #pragma once
 // (included inside namespace msfm)
 
@@ -55,14 +58,14 @@ __device__ unsigned long long g_sweep_probe3[16][16];   // the compacted sweep 2
 #define MSFM_PROBE(k) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); pb_acc[k] += n_ - pb_t; pb_t = n_; }
 #define MSFM_PROBE_ITEM_BEGIN const unsigned long long pb_item0 = __builtin_amdgcn_s_memtime(); unsigned long long pb_it = pb_item0;
 // item-level segments: 8 descriptor fetch | 9 A loads + first DMA (vmcnt 0) | 10 barrier + pre-read + offset | 11 loop | 12 drain | 13 row merge
-#define MSFM_PROBE_SEG(k) if (PASS != 2 && lane == 0) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); atomicAdd(&(PASS == 1 ? g_sweep_probe : g_sweep_probe3)[wave][k], n_ - pb_it); pb_it = n_; }
+#define MSFM_PROBE_SEG(k) if ((PASS == 1 || PASS == 3) && lane == 0) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); atomicAdd(&(PASS == 1 ? g_sweep_probe : g_sweep_probe3)[wave][k], n_ - pb_it); pb_it = n_; }
 #define MSFM_PROBE_ITEM_END                                                                                \
-    if (PASS != 2 && lane == 0) {                                                                          \
+    if ((PASS == 1 || PASS == 3) && lane == 0) {                                                           \
         unsigned long long (*pi_)[16] = PASS == 1 ? g_sweep_probe : g_sweep_probe3;                         \
         atomicAdd(&pi_[wave][6], (unsigned long long)(__builtin_amdgcn_s_memtime() - pb_item0));          \
     }
 #define MSFM_PROBE_END                                                                                     \
-    if (PASS != 2 && lane == 0) {                                                                          \
+    if ((PASS == 1 || PASS == 3) && lane == 0) {                                                           \
         unsigned long long (*pr_)[16] = PASS == 1 ? g_sweep_probe : g_sweep_probe3;                         \
         for (int k_ = 0; k_ < 4; ++k_) atomicAdd(&pr_[wave][k_], pb_acc[k_]);                              \
         atomicAdd(&pr_[wave][4], (unsigned long long)(t_end - t_begin));                                   \
@@ -197,7 +200,7 @@ __global__ __launch_bounds__(kPfThreads, 2) void sweep_kernel(
         // 272-byte rows: 17 aligned granules.  Compacted sweep: the A rows are live rows of many images, named by a
         // pointer table (a row without a source -- the tail of a group -- reads the image-independent zero row)
         const _Float16* arow = pp.a_h + (size_t)frow * kPfRowHalfs;
-        if (PASS == 3) {
+        if (PASS >= 3) {
             const _Float16* r = pp.a_rows[frow];
             arow = r ? r : pp.a_h;
         }
@@ -206,7 +209,7 @@ __global__ __launch_bounds__(kPfThreads, 2) void sweep_kernel(
         for (int ks = 0; ks < 8; ++ks) af[rb][ks] = ga[2 * ks + lhalf];
         // padding rows: X = -inf -> accumulator -inf, never a maximum, never a hit
         float X;
-        if (PASS == 3) X = frow < pd.n1 ? 0.5f * g_tu[pp.tu_off + frow] : -f_inf();
+        if (PASS >= 3) X = frow < pd.n1 ? 0.5f * g_tu[pp.tu_off + frow] : -f_inf();   // (PASS 4: the table holds -|a|^2)
         else X = frow < pd.n1 ? -0.5f * g_anrm[frow] : -f_inf();
         const float xs = X * inv_c;
         const _Float16 hi = (_Float16)xs;
@@ -478,8 +481,8 @@ __global__ __launch_bounds__(kPfThreads, 2) void sweep_kernel(
         if (PASS == 1 && grp == 0 && t > t_begin && wave == ((t - t_begin) & 3)) store_columns(t - 1);
         dma_tile(t + 3);   // into the slot of tile t-1, dead since the barrier before last
         if (wave_active) {
-            if (PASS == 1) {
-                fold_columns(column_max(accA), column_max(accB), (t - t_begin) & 1);   // block 1: columns 32..63 = +128 B
+            if (PASS == 1 || PASS == 4) {
+                if (PASS == 1) fold_columns(column_max(accA), column_max(accB), (t - t_begin) & 1);   // block 1: columns 32..63 = +128 B
 #pragma unroll
                 for (int rb = 0; rb < kPfRB; ++rb)
 #pragma unroll
@@ -501,10 +504,10 @@ __global__ __launch_bounds__(kPfThreads, 2) void sweep_kernel(
     MSFM_PROBE_END
     MSFM_PROBE_SEG(11)
     if (grp == 0) lds_barrier();   // the odd half's last EPI phase
-    if (PASS >= 2) flush_candidates();
+    if (PASS == 2 || PASS == 3) flush_candidates();
     if (PASS == 1 && wave == 0) store_columns(t_end - 1);
 
-    if (PASS == 1) {
+    if (PASS == 1 || PASS == 4) {
         wait_vmcnt<0>();   // the tail's DMA groups (re-fetches of the last tile) still write into the ring ...
         lds_barrier();     // ... everybody's have landed: the ring is scratch now
         MSFM_PROBE_SEG(12)
