@@ -1,5 +1,6 @@
-"""The three routes of the matcher on the BASELINE configs, one table (profiles/rNN_configs.txt):
-   integer matrix cores (v_mfma_i32_32x32x32_i8, byte stores only) | fp16 matrix cores | VALU brute force (exact order).
+"""The routes of the matcher on the BASELINE configs, one table (profiles/rNN_configs.txt):
+   integer matrix cores (v_mfma_i32_32x32x32_i8: byte stores directly; float stores in [0, 1] through their byte twins + an
+   fp16 sweep of the surviving rows = route Q) | fp16 matrix cores only | VALU brute force (exact order).
 Every route returns the same bits (asserted here on each job).  Large configs are timed on a seeded subset with the full
 per-image size.  Usage: python tools/configs_table.py [--quick] > gpurun_out/configs.txt"""
 import sys
@@ -10,7 +11,7 @@ import numpy as np
 sys.path.insert(0, ".")
 from monocularsfm_amd import _lib, synth  # noqa: E402
 
-MODES = [(1, "MFMA i8 "), (2, "MFMA f16"), (0, "VALU f32")]
+MODES = [(1, "MFMA i8 "), (2, "MFMA f16"), (0, "VALU f32")]   # (1 on a float store: route Q when every image has a byte twin)
 
 
 def run(ctx, pairs, mode, steps, **kw):
@@ -18,7 +19,7 @@ def run(ctx, pairs, mode, steps, **kw):
     ctx.match_pairs(pairs, fetch="view", **kw)   # warm-up (buffer growth, capacity hints)
     ctx.match_pairs(pairs, fetch="view", **kw)
     acc = {"approx_kernel_ms": 0.0, "sweep2_ms": 0.0, "candidates": 0, "dist_kernel_ms": 0.0, "sweep1_i8_launches": 0,
-           "prefilter_descriptor_pairs": 0}
+           "prefilter_descriptor_pairs": 0, "sweep1b_ms": 0.0}
     t0 = time.perf_counter()
     for _ in range(steps):
         offs, qt, d = ctx.match_pairs(pairs, fetch="view", **kw)
@@ -40,18 +41,21 @@ def job(name, imgs, pairs, steps, byte_store, **kw):
     print("%s: %d images, %d pairs, %.3g descriptor pairs per job" % (name, len(imgs), len(pairs), total))
     ref = None
     for mode, label in MODES:
-        if mode == 1 and not byte_store:
-            print("    %s  -- (float store: the integer cores need byte descriptors)" % label)
-            continue
         dt, a, res = run(ctx, pairs, mode, steps if mode else 1, **kw)
+        if mode == 1 and not byte_store:
+            if not a["sweep1_i8_launches"]:
+                print("    %s  -- (float store without byte twins -- values outside [0, 1]: the integer cores are not used)" % label)
+                continue
+            label = "route Q "
         if ref is None:
             ref = res
         same = all(np.array_equal(x, y) for x, y in zip(ref, res))
         if mode:
             ops = 256.0 * a["prefilter_descriptor_pairs"] / max(1e-9, a["approx_kernel_ms"] * 1e-3) / 1e12
             peak = 5000.0 if a["sweep1_i8_launches"] else 2500.0
-            detail = "sweep 1 %7.2f ms (%.0f T%s/s = %.3f of the dense peak) | sweep 2 %6.2f ms | %.2f candidates per row" % (
-                a["approx_kernel_ms"], ops, "OP" if a["sweep1_i8_launches"] else "FLOP", ops / peak, a["sweep2_ms"], a["candidates"] / n_rows)
+            detail = "sweep 1 %7.2f ms (%.0f T%s/s = %.3f of the dense peak)%s | sweep 2 %6.2f ms | %.2f candidates per row" % (
+                a["approx_kernel_ms"], ops, "OP" if a["sweep1_i8_launches"] else "FLOP", ops / peak,
+                (" | fp16 sweep 1' %6.2f ms" % a["sweep1b_ms"]) if a["sweep1b_ms"] else "", a["sweep2_ms"], a["candidates"] / n_rows)
         else:
             detail = "exact kernel %8.2f ms (%.1f TFLOP/s of 384 unfusable flop per pair)" % (
                 a["dist_kernel_ms"], 384.0 * total / max(1e-9, a["dist_kernel_ms"] * 1e-3) / 1e12)

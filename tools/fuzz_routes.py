@@ -1,6 +1,7 @@
-"""Long seeded fuzz: the prefilter routes (fp16 matrix cores; integer matrix cores for byte uploads) against the brute-force
-route (match lists and knnMatch-level arrays) over random sizes, value types, scales, duplicates, NaNs, parameters and
-orders.  Usage: python tools/fuzz_routes.py [seed] [cases]"""
+"""Long seeded fuzz: the prefilter routes (fp16 matrix cores; integer matrix cores for byte uploads; route Q = byte twins of
+float images in [0, 1] -- run with MSFM_Q8=2 in the environment so that the small images of the fuzz take it too) against
+the brute-force route (match lists and knnMatch-level arrays) over random sizes, value types, scales, duplicates, NaNs,
+parameters and orders.  Usage: [MSFM_Q8=2] python tools/fuzz_routes.py [seed] [cases]"""
 import sys, numpy as np
 sys.path.insert(0, '.')
 from monocularsfm_amd import _lib, synth
@@ -10,6 +11,7 @@ ctx = _lib.Context(0)
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 7)
 bad = 0
 n_i8 = 0
+n_q8 = 0
 for case in range(int(sys.argv[2]) if len(sys.argv) > 2 else 1500):
     n_img = int(rng.integers(2, 6))
     sizes = [int(rng.choice([1, 2, 3, 7, 31, 60, 64, 65, 130, 255, 256, 257, 600, 1100, 1700, 2600])) for _ in range(n_img)]
@@ -45,7 +47,8 @@ for case in range(int(sys.argv[2]) if len(sys.argv) > 2 else 1500):
     pairs = np.array([(i, j) for i in range(n_img) for j in range(n_img) if i != j or rng.random() < 0.2], np.int32)
     got = ctx.match_pairs(pairs, ratio, cc, md)
     n_i8 += ctx.profile()["sweep1_i8_launches"]
-    if kind == "bytes":     # and the fp16 cores on the same bytes
+    n_q8 += ctx.profile()["sweep1_q8_launches"]
+    if kind == "bytes" or ctx.profile()["sweep1_q8_launches"]:     # and the fp16 cores on the same data
         ctx.set_prefilter(2)
         got2 = ctx.match_pairs(pairs, ratio, cc, md)
         ctx.set_prefilter(True)
@@ -65,4 +68,4 @@ for case in range(int(sys.argv[2]) if len(sys.argv) > 2 else 1500):
     if not ok:
         bad += 1
         print("MISMATCH", case, kind, sizes, order, ratio, cc, md, flush=True)
-print("cases done, mismatches:", bad, "| integer-core sweep-1 launches:", n_i8)
+print("cases done, mismatches:", bad, "| integer-core sweep-1 launches:", n_i8, "| of them on byte twins of float images (route Q):", n_q8)
