@@ -95,14 +95,16 @@ def test_twins_only_for_values_in_the_unit_interval(gpu_ctx):
         assert p["sweep1_q8_launches"] == 0 and p["prefilter_pairs"] == len(pairs)     # mixed batch: the fp16 route
         gpu_ctx.set_prefilter(0)
         assert same(got, gpu_ctx.match_pairs(pairs))
-        # twice the values: outside the unit interval -> fp16 route, and (exact scaling by 2) the same index lists with doubled distances
+        # eight times the values: outside the unit interval -> fp16 route, and (exact scaling by a power of two) the same index
+        # lists with eightfold distances
         gpu_ctx.set_prefilter(1)
+        assert max(float(im.max()) for im in imgs) * 8.0 > 1.0
         for i, im in enumerate(imgs):
-            gpu_ctx.upload_image(i, (2.0 * im).astype(F32))
-        dbl = gpu_ctx.match_pairs(pairs, max_distance=1.4)
+            gpu_ctx.upload_image(i, (8.0 * im).astype(F32))
+        big = gpu_ctx.match_pairs(pairs, max_distance=5.6)
         assert gpu_ctx.profile()["sweep1_q8_launches"] == 0
-        assert np.array_equal(dbl[0], ref[0]) and np.array_equal(dbl[1], ref[1])
-        assert np.array_equal(b(dbl[2]), b((2.0 * ref[2]).astype(F32)))
+        assert np.array_equal(big[0], ref[0]) and np.array_equal(big[1], ref[1])
+        assert np.array_equal(b(big[2]), b((8.0 * ref[2]).astype(F32)))
     finally:
         gpu_ctx.set_prefilter(True)
 
