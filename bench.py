@@ -41,17 +41,20 @@ PEAK_F16_MFMA_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16/f16 MFMA peak
 PEAK_I8_MFMA_TOPS = 5000.0      # dense int8 MFMA (2 x K of fp16)
 
 
-def pmc_traffic():
+def pmc_traffic(i8):
     """HBM bytes per sweep-1 launch from the committed rocprofv3 PMC passes of this same command (separate --pmc
-    FETCH_SIZE / WRITE_SIZE runs; newest profiles/r*_pmc_traffic_approx.json): KB -> bytes, FETCH_SIZE doubled
-    (gfx950 counts 128-byte requests as 64 B, MI355X_MICROARCH.md).  None if absent."""
+    FETCH_SIZE / WRITE_SIZE runs of `bench.py --u8-images 0`; newest profiles/r*_pmc_traffic_approx.json): KB -> bytes,
+    FETCH_SIZE doubled (gfx950 counts 128-byte requests as 64 B, MI355X_MICROARCH.md).  The dominant kernel is
+    sweep_i8_kernel<1> when sweep 1 ran on the integer cores (byte stores, byte twins of float stores), else
+    sweep_kernel<1>.  None if absent."""
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic_approx.json")), reverse=True):
         try:
             d = json.load(open(path))
             per = {n: 2.0 * k["FETCH_SIZE"]["per_launch_KB_mean"] * 1024 + k["WRITE_SIZE"]["per_launch_KB_mean"] * 1024
                    for n, k in d.items()}
-            name = [n for n in per if n.startswith(("approx_kernel<1>", "sweep1", "sweep_kernel<1>"))][0]
-            return {"bytes_per_launch": per[name], "source": os.path.relpath(path, ROOT), "per_kernel_bytes": per}
+            want = ("sweep_i8_kernel<1>",) if i8 else ("approx_kernel<1>", "sweep1", "sweep_kernel<1>")
+            name = [n for n in per if n.startswith(want)][0]
+            return {"bytes_per_launch": per[name], "kernel": name, "source": os.path.relpath(path, ROOT), "per_kernel_bytes": per}
         except (OSError, KeyError, ValueError, IndexError):
             continue
     return None
@@ -335,7 +338,7 @@ def main():
         avg_ms = pf_ms / pf_launches
         flops = 256.0 * pf_pairs_work   # GEMM form: 128 x (mul, add) per descriptor pair
         achieved = flops / (pf_ms * 1e-3) / 1e12
-        tr = pmc_traffic()
+        tr = pmc_traffic(i8)
         algo_bytes_step = last_prof.get("dist_algo_bytes", 0)
         rows_work = float((n_rows[pairs[:, 0]] + n_rows[pairs[:, 1]]).sum()) * args.steps / max(world, 1)
         out["roofline"] = {

@@ -45,7 +45,9 @@ enum { MSFM_DTYPE_F32 = 0, MSFM_DTYPE_U8 = 1 };
  * the bits are identical to.  Integer-valued descriptors give identical bits under all. */
 enum {
     MSFM_ORDER_SSE4X4 = 0,   /* OpenCV 4.x SSE baseline: 16 lane partials, mul and add rounded apart */
-    MSFM_ORDER_AVX2_FMA = 1  /* OpenCV 4.x AVX2+FMA3 baseline: 32 lane partials, fused */
+    MSFM_ORDER_AVX2_FMA = 1, /* OpenCV 4.x AVX2+FMA3 baseline: 32 lane partials, fused */
+    MSFM_ORDER_AVX512_FMA = 3 /* AVX-512+FMA3 build of the same loop: 64 lane partials, fused (a third named order: the
+                                 cross-check of the order-invariance certificate, msfm_fetch_order_certificate) */
 };
 
 typedef struct msfm_ctx msfm_ctx;

@@ -15,7 +15,7 @@ if os.environ.get("MSFM_LIBRARY"):   # development hook: an alternative build of
 
 OK, E_INVALID, E_DEVICE, E_NOIMAGE, E_CAPACITY, E_STATE = range(6)
 DTYPE_F32, DTYPE_U8 = 0, 1
-ORDER_SSE4X4, ORDER_AVX2_FMA = 0, 1
+ORDER_SSE4X4, ORDER_AVX2_FMA, ORDER_AVX512_FMA = 0, 1, 3
 MAX_IMAGES = 10000
 DIM = 128
 

@@ -71,6 +71,21 @@ template <> struct OrderTraits<1> {
 // hide behind.  With the highest wave priority they get their issue slots and are gone in their stand-alone time.
 #define MSFM_TAIL_PRIO() __builtin_amdgcn_s_setprio(3)
 
+// AVX-512 + FMA3 (the third named order, MSFM_ORDER_AVX512_FMA = 3): lanes l = 0..15 x accumulators v = 0..3, 2 iterations,
+// fused, ((d0+d1)+d2)+d3 per lane, then y_l = (s_l + s_{l+8}) + (s_{l+4} + s_{l+12}) and (y0 + y2) + (y1 + y3): a balanced
+// in-order tree over the lanes processed as 0,8,4,12, 2,10,6,14, 1,9,5,13, 3,11,7,15.
+template <> struct OrderTraits<3> {
+    static constexpr int kGroups = 16, kIters = 2, kGroupPos = 8;
+    static constexpr bool kFused = true;
+    __host__ __device__ static int pos_to_k(int pos) {
+        const int g = pos >> 3, v = (pos >> 1) & 3, it = pos & 1;
+        // g = 4 a + b: lane = (a's quarter: 0, 2, 1, 3) + (b's step: 0, 8, 4, 12)
+        const int a = g >> 2, b = g & 3;
+        const int lane = ((a == 0) ? 0 : (a == 1) ? 2 : (a == 2) ? 1 : 3) + ((b == 0) ? 0 : (b == 1) ? 8 : (b == 2) ? 4 : 12);
+        return 64 * it + 16 * v + lane;
+    }
+};
+
 struct PairDesc {
     const float* a_panel;  // image id1 (query), panel layout
     const float* b_panel;  // image id2 (train)
@@ -320,6 +335,21 @@ __global__ __launch_bounds__(kThreads) void dist_top2_kernel(
                 else if (c == 1) { MSFM_FOREACH(lvl1[i][j] = lvl0[i][j] + s[i][j]) }
                 else { MSFM_FOREACH(lvl1[i][j] = lvl1[i][j] + (lvl0[i][j] + s[i][j])) }
             }
+        } else if (OT::kGroups == 16) {  // four groups per chunk: q_c = (g0+g1)+(g2+g3), result (q0+q1)+(q2+q3) -> lvl2
+#pragma unroll 1
+            for (int c = 0; c < kChunks; ++c) {
+                begin_chunk(c, sa, sb);
+                v2f s[4][kTN], q[4][kTN];
+                group_chains<ORDER>(sa, sb, lvl0);
+                group_chains<ORDER>(sa + OT::kGroupPos * kBM, sb + OT::kGroupPos * kWaveCols, s);
+                MSFM_FOREACH(q[i][j] = lvl0[i][j] + s[i][j])
+                group_chains<ORDER>(sa + 2 * OT::kGroupPos * kBM, sb + 2 * OT::kGroupPos * kWaveCols, lvl0);
+                group_chains<ORDER>(sa + 3 * OT::kGroupPos * kBM, sb + 3 * OT::kGroupPos * kWaveCols, s);
+                MSFM_FOREACH(q[i][j] = q[i][j] + (lvl0[i][j] + s[i][j]))
+                if (c == 0 || c == 2) { MSFM_FOREACH(lvl1[i][j] = q[i][j]) }
+                else if (c == 1) { MSFM_FOREACH(lvl2[i][j] = lvl1[i][j] + q[i][j]) }
+                else { MSFM_FOREACH(lvl2[i][j] = lvl2[i][j] + (lvl1[i][j] + q[i][j])) }
+            }
         } else {  // two groups per chunk: (((g0+g1)+(g2+g3)) + ((g4+g5)+(g6+g7))) -> lvl2
 #pragma unroll 1
             for (int c = 0; c < kChunks; ++c) {
@@ -472,8 +502,7 @@ __global__ void merge_knn_kernel(const PairDesc* __restrict__ pairs,
 template <int ORDER>
 __device__ float l2sqr_rowmajor(const float* __restrict__ a, const float* __restrict__ b) {
     using OT = OrderTraits<ORDER>;
-    float lvl[3] = {0.f, 0.f, 0.f};
-    float fin = 0.f;
+    float lvl[5] = {0.f, 0.f, 0.f, 0.f, 0.f};   // binary-counter stack: the balanced in-order tree over the groups
     for (int g = 0; g < OT::kGroups; ++g) {
         float s = 0.f;
         for (int v = 0; v < 4; ++v) {
@@ -487,15 +516,11 @@ __device__ float l2sqr_rowmajor(const float* __restrict__ a, const float* __rest
             }
             s = (v == 0) ? p : s + p;
         }
-        if ((g & 1) == 0) lvl[0] = s;
-        else if ((g & 2) == 0) lvl[1] = lvl[0] + s;
-        else if (OT::kGroups == 4 || (g & 4) != 0) {
-            float r = lvl[1] + (lvl[0] + s);
-            if (OT::kGroups == 8) r = lvl[2] + r;
-            fin = r;
-        } else lvl[2] = lvl[1] + (lvl[0] + s);
+        int j = 0;
+        for (int gg = g; gg & 1; gg >>= 1, ++j) s = lvl[j] + s;   // (the earlier subtree is the left operand)
+        lvl[j] = s;
     }
-    return fin;
+    return lvl[OT::kGroups == 4 ? 2 : (OT::kGroups == 8 ? 3 : 4)];
 }
 
 // one 64-lane workgroup per queued row: lowest index whose sqrtf(S) equals d0

@@ -941,14 +941,13 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
     if (n_lists > 0) {
         const dim3 cgrid(64, (unsigned)std::min<size_t>(n_lists, 65535));   // (the kernels stride over the lists in y)
         const unsigned long long* dcount = SC.d_cand_count.as<unsigned long long>();
-        if (ctx->order == MSFM_ORDER_SSE4X4)
-            hipLaunchKernelGGL(pf_exact_candidates_kernel<0>, cgrid, dim3(256), 0, SC.stream, dp, dl, dcount,
-                               SC.d_cand.as<int2>(), SC.d_cand_s.as<float>(), SC.d_cand_pair.as<int>(),
-                               SC.d_best.as<unsigned long long>(), (int)n_lists);
-        else
-            hipLaunchKernelGGL(pf_exact_candidates_kernel<1>, cgrid, dim3(256), 0, SC.stream, dp, dl, dcount,
-                               SC.d_cand.as<int2>(), SC.d_cand_s.as<float>(), SC.d_cand_pair.as<int>(),
-                               SC.d_best.as<unsigned long long>(), (int)n_lists);
+#define MSFM_LAUNCH_EXACT(O)                                                                                             \
+    hipLaunchKernelGGL(pf_exact_candidates_kernel<O>, cgrid, dim3(256), 0, SC.stream, dp, dl, dcount, SC.d_cand.as<int2>(), \
+                       SC.d_cand_s.as<float>(), SC.d_cand_pair.as<int>(), SC.d_best.as<unsigned long long>(), (int)n_lists)
+        if (ctx->order == MSFM_ORDER_SSE4X4) MSFM_LAUNCH_EXACT(0);
+        else if (ctx->order == MSFM_ORDER_AVX2_FMA) MSFM_LAUNCH_EXACT(1);
+        else MSFM_LAUNCH_EXACT(3);
+#undef MSFM_LAUNCH_EXACT
         HIPCHK(ctx, hipGetLastError());
         DBGSYNC(ctx, "pf_exact_candidates_kernel");
         const dim3 rgrid(16, (unsigned)std::min<size_t>(n_lists, 65535));
@@ -1094,16 +1093,14 @@ int run_exact(msfm_ctx* ctx, Batch& b, size_t ev_base) {
     if (!e0 || !e1) return fail(ctx, MSFM_E_DEVICE, "hipEventCreate failed");
     HIPCHK(ctx, hipEventRecord(e0, SC.stream));
     const dim3 grid((unsigned)b.n_items), block(kThreads);
-    if (ctx->order == MSFM_ORDER_SSE4X4)
-        hipLaunchKernelGGL(dist_top2_kernel<0>, grid, block, kLdsBytes, SC.stream,
-                           SC.d_pairs.as<PairDesc>(), SC.d_items.as<WorkItem>(),
-                           SC.d_rp_s0.as<float>(), SC.d_rp_i0.as<int>(), SC.d_rp_s1.as<float>(),
-                           SC.d_cp_s0.as<float>(), SC.d_cp_i0.as<int>(), SC.d_cp_s1.as<float>());
-    else
-        hipLaunchKernelGGL(dist_top2_kernel<1>, grid, block, kLdsBytes, SC.stream,
-                           SC.d_pairs.as<PairDesc>(), SC.d_items.as<WorkItem>(),
-                           SC.d_rp_s0.as<float>(), SC.d_rp_i0.as<int>(), SC.d_rp_s1.as<float>(),
-                           SC.d_cp_s0.as<float>(), SC.d_cp_i0.as<int>(), SC.d_cp_s1.as<float>());
+#define MSFM_LAUNCH_DIST(O)                                                                                               \
+    hipLaunchKernelGGL(dist_top2_kernel<O>, grid, block, kLdsBytes, SC.stream, SC.d_pairs.as<PairDesc>(), SC.d_items.as<WorkItem>(), \
+                       SC.d_rp_s0.as<float>(), SC.d_rp_i0.as<int>(), SC.d_rp_s1.as<float>(), SC.d_cp_s0.as<float>(),             \
+                       SC.d_cp_i0.as<int>(), SC.d_cp_s1.as<float>())
+    if (ctx->order == MSFM_ORDER_SSE4X4) MSFM_LAUNCH_DIST(0);
+    else if (ctx->order == MSFM_ORDER_AVX2_FMA) MSFM_LAUNCH_DIST(1);
+    else MSFM_LAUNCH_DIST(3);
+#undef MSFM_LAUNCH_DIST
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipEventRecord(e1, SC.stream));
     SC.prof.dist_kernel_launches += 1;
@@ -1154,14 +1151,13 @@ int run_knn(msfm_ctx* ctx, Batch& b, size_t ev_base, bool* exact_launched, Prune
     // (no queue -- match lists with ratio <= 1 -- no fix-up launch: the kernel's 86 registers would not fit next to the other
     // stream's sweep and the tail would wait for that sweep's end)
     if ((any_pf || any_exact) && SC.fix_cap_eff > 0) {
-        if (ctx->order == MSFM_ORDER_SSE4X4)
-            hipLaunchKernelGGL(tie_fixup_kernel<0>, dim3(256), dim3(64), 0, SC.stream, SC.d_pairs.as<PairDesc>(),
-                               SC.d_fix_count.as<int>(), SC.d_fix_list.as<int4>(), SC.fix_cap_eff,
-                               SC.d_k_i0.as<int>(), SC.d_k_d0.as<float>());
-        else
-            hipLaunchKernelGGL(tie_fixup_kernel<1>, dim3(256), dim3(64), 0, SC.stream, SC.d_pairs.as<PairDesc>(),
-                               SC.d_fix_count.as<int>(), SC.d_fix_list.as<int4>(), SC.fix_cap_eff,
-                               SC.d_k_i0.as<int>(), SC.d_k_d0.as<float>());
+#define MSFM_LAUNCH_FIX(O)                                                                                          \
+    hipLaunchKernelGGL(tie_fixup_kernel<O>, dim3(256), dim3(64), 0, SC.stream, SC.d_pairs.as<PairDesc>(),               \
+                       SC.d_fix_count.as<int>(), SC.d_fix_list.as<int4>(), SC.fix_cap_eff, SC.d_k_i0.as<int>(), SC.d_k_d0.as<float>())
+        if (ctx->order == MSFM_ORDER_SSE4X4) MSFM_LAUNCH_FIX(0);
+        else if (ctx->order == MSFM_ORDER_AVX2_FMA) MSFM_LAUNCH_FIX(1);
+        else MSFM_LAUNCH_FIX(3);
+#undef MSFM_LAUNCH_FIX
         HIPCHK(ctx, hipGetLastError());
     }
     return MSFM_OK;
@@ -1283,6 +1279,8 @@ int msfm_create(int device_ordinal, msfm_ctx** out_ctx) {
                                         hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
     hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(dist_top2_kernel<1>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+    if (e1 == hipSuccess)
+        e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(dist_top2_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
     if (e0 != hipSuccess || e1 != hipSuccess) {
         std::fprintf(stderr, "msfm_create: cannot reserve %d bytes of LDS: %s\n", kLdsBytes,
                      hipGetErrorString(e0 != hipSuccess ? e0 : e1));
@@ -1364,7 +1362,8 @@ int msfm_device_info(const msfm_ctx* ctx, char* name, int name_cap, int* cu_coun
 
 int msfm_set_accum_order(msfm_ctx* ctx, int order) {
     if (!ctx) return MSFM_E_INVALID;
-    if (order != MSFM_ORDER_SSE4X4 && order != MSFM_ORDER_AVX2_FMA) return fail(ctx, MSFM_E_INVALID, "unknown accumulation order");
+    if (order != MSFM_ORDER_SSE4X4 && order != MSFM_ORDER_AVX2_FMA && order != MSFM_ORDER_AVX512_FMA)
+        return fail(ctx, MSFM_E_INVALID, "unknown accumulation order");
     if (order == ctx->order) return MSFM_OK;
     // the panel layout stores dimensions in accumulation order: re-lay every resident image
     HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -1374,8 +1373,10 @@ int msfm_set_accum_order(msfm_ctx* ctx, int order) {
         const int blocks = std::min(4096, im.nalloc * 16);
         if (order == MSFM_ORDER_SSE4X4)
             hipLaunchKernelGGL((layout_kernel<0, float>), dim3(blocks), dim3(256), 0, SC.stream, im.raw, (float*)nullptr, im.panel, im.n, im.nalloc);
-        else
+        else if (order == MSFM_ORDER_AVX2_FMA)
             hipLaunchKernelGGL((layout_kernel<1, float>), dim3(blocks), dim3(256), 0, SC.stream, im.raw, (float*)nullptr, im.panel, im.n, im.nalloc);
+        else
+            hipLaunchKernelGGL((layout_kernel<3, float>), dim3(blocks), dim3(256), 0, SC.stream, im.raw, (float*)nullptr, im.panel, im.n, im.nalloc);
         HIPCHK(ctx, hipGetLastError());
     }
     HIPCHK(ctx, hipStreamSynchronize(SC.stream));
@@ -1475,13 +1476,17 @@ static int build_image(msfm_ctx* ctx, Image& im, const unsigned char* src8, bool
     if (!src8) {
         if (ctx->order == MSFM_ORDER_SSE4X4)
             hipLaunchKernelGGL((layout_kernel<0, float>), dim3(blocks), dim3(256), 0, SC.stream, im.raw, (float*)nullptr, im.panel, n, im.nalloc);
-        else
+        else if (ctx->order == MSFM_ORDER_AVX2_FMA)
             hipLaunchKernelGGL((layout_kernel<1, float>), dim3(blocks), dim3(256), 0, SC.stream, im.raw, (float*)nullptr, im.panel, n, im.nalloc);
+        else
+            hipLaunchKernelGGL((layout_kernel<3, float>), dim3(blocks), dim3(256), 0, SC.stream, im.raw, (float*)nullptr, im.panel, n, im.nalloc);
     } else {
         if (ctx->order == MSFM_ORDER_SSE4X4)
             hipLaunchKernelGGL((layout_kernel<0, unsigned char>), dim3(blocks), dim3(256), 0, SC.stream, src8, im.raw, im.panel, n, im.nalloc);
-        else
+        else if (ctx->order == MSFM_ORDER_AVX2_FMA)
             hipLaunchKernelGGL((layout_kernel<1, unsigned char>), dim3(blocks), dim3(256), 0, SC.stream, src8, im.raw, im.panel, n, im.nalloc);
+        else
+            hipLaunchKernelGGL((layout_kernel<3, unsigned char>), dim3(blocks), dim3(256), 0, SC.stream, src8, im.raw, im.panel, n, im.nalloc);
     }
     HIPCHK(ctx, hipGetLastError());
     // prefilter operands (order-independent): fp16 swizzled blocks, norms, maxima

@@ -380,6 +380,22 @@ __global__ void pf_exact_candidates_kernel(const PairDesc* __restrict__ pairs, c
             const float s0 = __shfl(s, (threadIdx.x & ~15) | 0, 64), s1 = __shfl(s, (threadIdx.x & ~15) | 1, 64);
             const float s2 = __shfl(s, (threadIdx.x & ~15) | 2, 64), s3 = __shfl(s, (threadIdx.x & ~15) | 3, 64);
             res = (s0 + s2) + (s1 + s3);
+        } else if (ORDER == 3) {
+            // AVX-512 order: 64 partials p[16 v + L]; lane `sub` owns L = sub: four accumulators x two iterations, fused
+            float s = 0.f;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const float t0 = a[16 * v + sub] - b[16 * v + sub];
+                const float t1 = a[64 + 16 * v + sub] - b[64 + 16 * v + sub];
+                const float p = __builtin_fmaf(t1, t1, t0 * t0);
+                s = (v == 0) ? p : s + p;
+            }
+            // y_l = (s_l + s_{l+8}) + (s_{l+4} + s_{l+12}), result (y0 + y2) + (y1 + y3): butterflies (a + b == b + a bitwise)
+            const int base = threadIdx.x & ~15;
+            const float x = s + __shfl(s, base | (sub ^ 8), 64);
+            const float y = x + __shfl(x, base | (sub ^ 4), 64);
+            const float z = y + __shfl(y, base | (sub ^ 2), 64);
+            res = z + __shfl(z, base | (sub ^ 1), 64);
         } else {
             // 32 partials: lane `sub` owns L = sub and L = sub + 16
             float pa = 0.f, pb = 0.f;

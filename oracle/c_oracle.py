@@ -11,6 +11,7 @@ _SO = os.path.join(_HERE, "libmsfm_oracle.so")
 ORDER_SSE4X4 = 0
 ORDER_AVX2_FMA = 1
 ORDER_SCALAR = 2
+ORDER_AVX512_FMA = 3
 ORDER_SSE4X4_PLAINC = 100  # test hook: plain-C statement of the SSE order
 
 

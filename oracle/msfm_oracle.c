@@ -84,6 +84,29 @@ static float l2sqr_avx2_fma(const float* a, const float* b)
     return ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
 }
 
+/* AVX-512 + FMA3 build of the same universal-intrinsics loop (CV_SIMD512: 16 lanes, four accumulators, two iterations,
+ * v_muladd fused), restated from memory like the others: lane partials p[16 v + L], s[L] = ((p0+p1)+p2)+p3
+ * per lane, then v_reduce_sum(v_float32x16): low + high 256-bit halves, low + high 128-bit halves, and the four-lane sum of
+ * the SSE order:  y_l = (s_l + s_{l+8}) + (s_{l+4} + s_{l+12}),  result = (y0 + y2) + (y1 + y3).
+ * A THIRD named order: its purpose is the cross-check of the order-invariance certificate (include/msfm_match.h), not a
+ * claim about a particular OpenCV binary. */
+static float l2sqr_avx512_fma(const float* a, const float* b)
+{
+    float p[64];
+    for (int L = 0; L < 64; ++L) p[L] = 0.0f;
+    for (int it = 0; it < 2; ++it)
+        for (int L = 0; L < 64; ++L) {
+            float t = a[64 * it + L] - b[64 * it + L];
+            p[L] = fmaf(t, t, p[L]);
+        }
+    float s[16], y[4];
+    for (int l = 0; l < 16; ++l)
+        s[l] = ((p[l] + p[16 + l]) + p[32 + l]) + p[48 + l];
+    for (int l = 0; l < 4; ++l)
+        y[l] = (s[l] + s[8 + l]) + (s[4 + l] + s[12 + l]);
+    return (y[0] + y[2]) + (y[1] + y[3]);
+}
+
 static float l2sqr_scalar(const float* a, const float* b)
 {
     float d = 0.0f;
@@ -101,6 +124,7 @@ float orc_l2sqr(const float* a, const float* b, int order)
     case MSFM_ORC_ORDER_SSE4X4: return l2sqr_sse4x4(a, b);
     case MSFM_ORC_ORDER_AVX2_FMA: return l2sqr_avx2_fma(a, b);
     case MSFM_ORC_ORDER_SCALAR: return l2sqr_scalar(a, b);
+    case MSFM_ORC_ORDER_AVX512_FMA: return l2sqr_avx512_fma(a, b);
     case 100: return l2sqr_sse4x4_scalar(a, b); /* test hook: plain-C SSE order */
     default: return NAN;
     }

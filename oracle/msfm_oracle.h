@@ -43,7 +43,10 @@ enum {
      * the AVX2 v_reduce_sum tree ((l0+l1)+(l2+l3))+((l4+l5)+(l6+l7)). */
     MSFM_ORC_ORDER_AVX2_FMA = 1,
     /* plain scalar loop d += t*t, c ascending, no FMA (OpenCV built without SIMD) */
-    MSFM_ORC_ORDER_SCALAR = 2
+    MSFM_ORC_ORDER_SCALAR = 2,
+    /* AVX-512 + FMA3 build of the universal-intrinsics loop: 4 accumulators x 16 lanes, 64 floats / iteration, fused,
+     * ((d0+d1)+d2)+d3 lane-wise, then halves / halves / the four-lane sum of the SSE order (msfm_oracle.c) */
+    MSFM_ORC_ORDER_AVX512_FMA = 3
 };
 
 /* S(a,b) in the given order (never sqrt'ed). */

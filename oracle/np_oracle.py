@@ -12,6 +12,7 @@ import numpy as np
 ORDER_SSE4X4 = 0
 ORDER_AVX2_FMA = 1
 ORDER_SCALAR = 2
+ORDER_AVX512_FMA = 3
 F32 = np.float32
 
 
@@ -42,6 +43,14 @@ def l2sqr_matrix(A, B, order=ORDER_SSE4X4):
             p = (T64[:, :, it, :] * T64[:, :, it, :] + p.astype(np.float64)).astype(F32)
         s = ((p[..., 0:8] + p[..., 8:16]) + p[..., 16:24]) + p[..., 24:32]
         return ((s[..., 0] + s[..., 1]) + (s[..., 2] + s[..., 3])) + ((s[..., 4] + s[..., 5]) + (s[..., 6] + s[..., 7]))
+    if order == ORDER_AVX512_FMA:
+        T64 = T.astype(np.float64).reshape(n1, n2, 2, 64)
+        p = np.zeros((n1, n2, 64), F32)
+        for it in range(2):   # (a float32 product of float32 values is exact in float64: one rounding, like fmaf)
+            p = (T64[:, :, it, :] * T64[:, :, it, :] + p.astype(np.float64)).astype(F32)
+        s = ((p[..., 0:16] + p[..., 16:32]) + p[..., 32:48]) + p[..., 48:64]
+        y = (s[..., 0:4] + s[..., 8:12]) + (s[..., 4:8] + s[..., 12:16])
+        return (y[..., 0] + y[..., 2]) + (y[..., 1] + y[..., 3])
     raise ValueError(order)
 
 

@@ -77,3 +77,23 @@ def test_product_package_does_not_import_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp", ".hpp")):
                 txt = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "import oracle" not in txt and "from oracle" not in txt and "msfm_oracle" not in txt, f
+
+
+def test_diagnostic_probes_are_compiled_out_of_the_shipped_code_object(built_lib, tmp_path):
+    """-DMSFM_SWEEP_PROBE (tools/gpu_probe.sh) adds s_memtime reads and atomics to the sweep kernels; the library that ships
+    must not contain any (VERDICT r02 hygiene item): disassemble the gfx950 code object of the built .so and look."""
+    import shutil
+    import subprocess
+    from monocularsfm_amd import _lib
+    llvm = "/opt/rocm/lib/llvm/bin"
+    if not os.path.exists(os.path.join(llvm, "llvm-objdump")):
+        pytest.skip("no llvm-objdump")
+    lib = str(tmp_path / "lib.so")
+    shutil.copy(_lib.LIB_PATH, lib)
+    subprocess.run([os.path.join(llvm, "llvm-objdump"), "--offloading", lib], check=True, capture_output=True, cwd=str(tmp_path))
+    co = [f for f in os.listdir(str(tmp_path)) if "gfx950" in f]
+    assert co, "no gfx950 code object in the library"
+    asm = subprocess.run([os.path.join(llvm, "llvm-objdump"), "-d", os.path.join(str(tmp_path), co[0])], check=True,
+                         capture_output=True, text=True).stdout
+    assert "v_mfma_i32_32x32x32_i8" in asm and "v_mfma_f32_32x32x16_f16" in asm      # (the disassembly is the real thing)
+    assert "s_memtime" not in asm and "s_memrealtime" not in asm

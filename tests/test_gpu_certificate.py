@@ -63,19 +63,21 @@ def test_certificate_is_clean_on_rootsift_data_and_the_orders_agree(gpu_ctx):
         assert np.array_equal(gpu_ctx.order_certificate(40), cert[:40])
     finally:
         gpu_ctx.set_prefilter(True)
-    # certificate == 0 on a pair  =>  the other named order returns the same index list for it
-    with _lib.Context(0, order=_lib.ORDER_AVX2_FMA) as other:
-        for i, im in enumerate(imgs):
-            other.upload_image(i, im)
-        offs2, qt2, d2 = other.match_pairs(pairs)
-    differing_distances = 0
-    for p in range(len(pairs)):
-        a, b_ = qt[offs[p]:offs[p + 1]], qt2[offs2[p]:offs2[p + 1]]
-        if cert[p] == 0:
-            assert np.array_equal(a, b_), p
-            differing_distances += int((d[offs[p]:offs[p + 1]].view(np.int32) != d2[offs2[p]:offs2[p + 1]].view(np.int32)).sum())
+    # certificate == 0 on a pair  =>  the other named orders (AVX2+FMA, AVX-512+FMA) return the same index list for it
     assert (cert == 0).sum() > 0.9 * len(pairs)       # unit-norm RootSIFT data: margins are orders of magnitude above 1e-5
-    assert differing_distances > 0                     # ... although the two orders do differ in the low bits of the distances
+    for other_order in (_lib.ORDER_AVX2_FMA, _lib.ORDER_AVX512_FMA):
+        with _lib.Context(0, order=other_order) as other:
+            for i, im in enumerate(imgs):
+                other.upload_image(i, im)
+            offs2, qt2, d2 = other.match_pairs(pairs)
+            assert np.array_equal(other.order_certificate(len(pairs)) == 0, cert == 0)    # (the certificate itself is stable)
+        differing_distances = 0
+        for p in range(len(pairs)):
+            a, b_ = qt[offs[p]:offs[p + 1]], qt2[offs2[p]:offs2[p + 1]]
+            if cert[p] == 0:
+                assert np.array_equal(a, b_), (other_order, p)
+                differing_distances += int((d[offs[p]:offs[p + 1]].view(np.int32) != d2[offs2[p]:offs2[p + 1]].view(np.int32)).sum())
+        assert differing_distances > 0                 # ... although the orders do differ in the low bits of the distances
 
 
 def planted():

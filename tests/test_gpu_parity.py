@@ -68,7 +68,7 @@ def test_u8_upload_equals_float_upload(gpu_ctx):
 SHAPES = [(600, 500), (129, 257), (128, 128), (127, 1), (1, 127), (2, 2), (1000, 77), (384, 2049), (3000, 2900)]
 
 
-@pytest.mark.parametrize("order", [0, 1])
+@pytest.mark.parametrize("order", [0, 1, 3])
 @pytest.mark.parametrize("shape", SHAPES, ids=["%dx%d" % s for s in SHAPES])
 def test_knn2_and_matches_vs_oracle(gpu_ctx, oracle, shape, order):
     n1, n2 = shape
@@ -134,14 +134,14 @@ def test_exact_duplicates_and_sqrt_space_ties(gpu_ctx, oracle):
 def test_integer_descriptors_identical_under_both_orders(gpu_ctx, oracle):
     u = synth.u8_images(2, [900, 850], seed=31)
     res = {}
-    for order in (0, 1):
+    for order in (0, 1, 3):
         gpu_ctx.set_accum_order(order)
         upload_pair(gpu_ctx, u[0].astype(np.uint8), u[1].astype(np.uint8))
         res[order] = gpu_ctx.knn2_pair(0, 1)
     gpu_ctx.set_accum_order(0)
     for d in (0, 1):
         for k in range(3):
-            assert np.array_equal(b(res[0][d][k]), b(res[1][d][k]))
+            assert np.array_equal(b(res[0][d][k]), b(res[1][d][k])) and np.array_equal(b(res[0][d][k]), b(res[3][d][k]))
     oi0, od0, _, od1 = oracle.knn2(u[0], u[1], 2, 8)   # plain scalar order: same bits for integers
     assert_knn_equal(res[0][0], oi0, od0, od1)
     q, t, d = gpu_ctx.match_pair(0, 1, 0.8, True, 1e9)

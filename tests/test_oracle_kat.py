@@ -29,10 +29,10 @@ def test_l2sqr_hand_values(oracle):
     a = np.zeros(128, F32)
     b = np.zeros(128, F32)
     a[0], a[1], b[0] = 3, 4, 1
-    for order in (0, 1, 2, 100):
+    for order in (0, 1, 2, 3, 100):
         assert oracle.l2sqr(a, b, order) == 2 * 2 + 4 * 4
     # all ones vs zeros: 128 exactly in every order
-    for order in (0, 1, 2):
+    for order in (0, 1, 2, 3):
         assert oracle.l2sqr(np.ones(128, F32), np.zeros(128, F32), order) == 128.0
 
 
@@ -70,7 +70,7 @@ def test_sse_order_is_not_fused(oracle):
     assert got == unfused
 
 
-@pytest.mark.parametrize("order", [0, 1, 2])
+@pytest.mark.parametrize("order", [0, 1, 2, 3])
 def test_c_oracle_matches_numpy_oracle(oracle, order):
     rng = np.random.default_rng(10 + order)
     A = rng.random((150, 128), dtype=F32)
