@@ -286,3 +286,51 @@ def test_tie_queue_grows_instead_of_failing(built_lib, oracle):
             assert np.array_equal(q, oq) and np.array_equal(t, ot) and np.array_equal(b(d), b(od))
             q, t, d = ctx.match_pair(0, 1, 0.8, True, 1e9)       # ratio <= 1: no fix-up needed, none queued
             assert ctx.profile()["tie_queue_regrows"] == 0 and len(q) == 0
+
+
+# ---- (e) the re-run path of the two-sub-batches-in-flight loop -----------------------------------------------------
+
+@pytest.mark.parametrize("twins", [True, False])
+def test_plan_regrow_with_sub_batches_in_flight(oracle, twins):
+    """A fresh context sizes the sweep-2 plan from a guess (a quarter of the rows).  Data on which most rows stay alive
+    (half of every image is a shared set of rows, ratio 0.95) outgrows it: the sub-batch is dropped while its successor is
+    already in flight on the other stream, everything is drained, it is re-run alone and the loop carries on behind it.
+    Same lists as the brute-force route; the profile counts the re-runs."""
+    from monocularsfm_amd import _lib
+    rng = np.random.default_rng(3)
+    sizes = [1500, 1400, 1600, 1300, 1550, 1450]
+    imgs = synth.rootsift_images(len(sizes), sizes, seed=91, n_proto=4000)
+    shared = imgs[0][:700].copy()
+    for k, im in enumerate(imgs):
+        rows = rng.choice(len(im), 700, replace=False)
+        v = np.abs(shared * (1 + 0.01 * rng.standard_normal(shared.shape).astype(F32)))
+        im[rows] = (v / np.linalg.norm(v, axis=1, keepdims=True)).astype(F32)
+        if not twins:
+            im *= F32(4.0)          # values beyond 1: no byte twins, the fp16 route
+    pairs = synth.all_pairs(len(sizes))
+    kw = {"ratio": 0.95, "cross_check": True, "max_distance": 10.0}
+    import os
+    old = os.environ.get("MSFM_Q8")
+    os.environ["MSFM_Q8"] = "2"
+    try:
+        with _lib.Context(0) as ctx:
+            for i, im in enumerate(imgs):
+                ctx.upload_image(i, im)
+            ctx.set_limits(4, 0)                         # 15 pairs -> 4 sub-batches, two in flight
+            got = ctx.match_pairs(pairs, **kw)
+            p = ctx.profile()
+            assert p["sub_batches"] == 4 and p["prefilter_pairs"] == len(pairs)
+            assert p["plan_regrows"] >= 1, "the test data no longer outgrows the first plan"
+            assert (p["sweep1_q8_launches"] > 0) == twins
+            again = ctx.match_pairs(pairs, **kw)         # the hints fit now
+            assert ctx.profile()["plan_regrows"] == 0 and same_result(got, again)
+            ctx.set_prefilter(0)
+            ctx.set_limits(0, 0)
+            assert same_result(got, ctx.match_pairs(pairs, **kw))
+    finally:
+        if old is None:
+            os.environ.pop("MSFM_Q8", None)
+        else:
+            os.environ["MSFM_Q8"] = old
+    assert got[0][-1] > 3000
+    check_pairs_vs_oracle(oracle, imgs, pairs, np.arange(len(pairs)), *got, nthreads=8, **kw)
