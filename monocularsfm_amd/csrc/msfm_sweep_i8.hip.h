@@ -7,17 +7,23 @@
 //
 //        acc = a'.b' - h_a - h_b        ->   S~ = -2 acc = S - (n'_a & 1) - (n'_b & 1),   |S~ - S| <= 2 =: eps
 //
-// is built WITHOUT a VALU instruction (every VALU instruction is SIMD time here):
-//   * -h_a (sweep 1) or floor((T_row - 2 h_a) / 2) (compacted sweep 2: a hit is acc >= 0  <=>  S~ <= T_row), minus the
-//     streamed image's centre H0_b, sits in 16 registers per lane for the whole work item and is the C OPERAND of the
-//     tile's first MFMA;
-//   * -(h_b - H0_b) rides in a FIFTH k-step: the B row carries 32 signed digits d behind its 128 operand bytes, the A
-//     side of that step is the constant vector c = [1, -128, -128, ...]: sum c_k d_k = d_0 - 128 (d_1 + ... + d_31)
-//     represents every integer in [-504 064, 507 903] -- an image whose h values spread further than that around their
-//     centre H0 (they cannot all be SIFT descriptors) is not a byte image for this path and takes the fp16 kernels.
-// Rows are 176 B = 11 granules (128 operand bytes, 32 digits, 16 B of padding: the same odd-granule bank swizzle as the
-// fp16 rows); the float "norm" array of the path holds 2h.  Padding COLUMNS carry zero digits, i.e. they look like a
-// real column: the image's last tile masks them in its epilogue (padding ROWS hold the "-inf" kI8Pad in their constant).
+// is built WITHOUT a VALU instruction (every VALU instruction is SIMD time here): both norms ride in a
+// FIFTH k-step of 32 slots.  Every row carries, behind its 128 operand bytes, 16 signed DIGITS d of V = H0 - h (H0 = its
+// image's centre of h) and the 16 CONSTANTS c = [1, -128 x 15]:  sum c_k d_k = d_0 - 128 (d_1 + ... + d_15) represents
+// every integer in [-243 968, 245 759] -- an image whose h values spread further than that around their centre (they
+// cannot all be SIFT descriptors) is not a byte image for this path and takes the fp16 kernels.
+//   * slots 0..15:  A side the constants, B side the streamed row's digits            ->  + (H0_b - h_b);
+//   * slots 16..31: sweep 1: A side the A ROW'S OWN digits, B side the constants      ->  + (H0_a - h_a)
+//     so the accumulator is  a'.b' - h_a - h_b + K,  K = H0_a + H0_b  uniform over the work item: the row / column maxima
+//     are taken on it as they are and K is subtracted where they leave the kernel.  No register holds a row constant:
+//     112 VGPRs instead of 127 -- four waves per SIMD then leave 64 of the 512 registers to the tail kernels of the
+//     OTHER stream's sub-batch, which run beside this sweep instead of behind it;
+//   * compacted sweep 2: slots 16..31 of the A side are zero and the row's hit level floor((T_row - 2 h_a) / 2) - H0_b (a
+//     hit is acc >= 0  <=>  S~ <= T_row; too wide for 16 digits) is the C OPERAND of the tile's first MFMA, as before.
+// Rows are 176 B = 11 granules (128 operand bytes, 16 digits, 16 constants, 16 B of padding: the same odd-granule bank
+// swizzle as the fp16 rows); the float "norm" array of the path holds 2h.  Padding COLUMNS carry zero digits, i.e. they look like a
+// real column: the image's last tile masks them in its epilogue; padding ROWS (zero digits as well) exist in one wave of
+// an image's last 512-row block only, which masks their accumulators the same way.
 // Everything downstream (thresholds, plan, exact re-check in the pinned fp32 order, reduce) is the float pipeline
 // unchanged: the results leave this kernel as floats (exact: |acc| < 2^23).  On byte data the pinned fp32 order is itself
 // exact integer arithmetic (every partial sum is an integer below 2^24; oracle/int_oracle.py pins that), so eps = 2
@@ -29,9 +35,9 @@
 #pragma once
 // (included inside namespace msfm)
 
-constexpr int kI8RowBytes = 176;                        // 128 operand bytes + 32 digits of -(h - H0) + 16 B padding
+constexpr int kI8RowBytes = 176;                        // 128 operand bytes + 16 digits of H0 - h + the 16 constants + 16 B padding
 constexpr int kI8TileBytes = kPfBT * kI8RowBytes;       // 11264 B = 11 DMA pieces
-constexpr int kI8DigitLo = -504064, kI8DigitHi = 507903;   // representable H0 - h (see pf_digits_i8_kernel)
+constexpr int kI8DigitLo = -243968, kI8DigitHi = 245759;   // representable H0 - h (see pf_digits_i8_kernel)
 // SIXTEEN waves of 32 rows (four per SIMD): on the integer cores a tile's matrix phase is 16 x 34 cycles per SIMD, and one
 // wave issues a VALU instruction every 8 cycles at best -- with two 64-row waves per SIMD the ~130 VALU instructions per
 // tile and wave set the pace (profiles/r02_i8_sweep_ablation.txt); four 32-row waves give the epilogue twice the issue slots
@@ -88,28 +94,28 @@ __global__ void pf_prepare_i8_kernel(const float* __restrict__ raw, signed char*
     }
 }
 
-// the 32 digits of V = H0 - h behind every real row's operand bytes: V = d_0 - 128 (d_1 + ... + d_31), d_0 in [-128, -1],
-// the rest filled greedily (the host has checked that every row of the image is inside [kI8DigitLo, kI8DigitHi])
+// the 16 digits of V = H0 - h behind every real row's operand bytes: V = d_0 - 128 (d_1 + ... + d_15), d_0 in [-128, -1],
+// the rest filled greedily (the host has checked that every row of the image is inside [kI8DigitLo, kI8DigitHi]); behind
+// them the 16 constants [1, -128 x 15] the OTHER side's digits are multiplied with
 __global__ void pf_digits_i8_kernel(const float* __restrict__ nrm2h, signed char* __restrict__ rows, int n, int h0) {
     for (int row = blockIdx.x * blockDim.x + threadIdx.x; row < n; row += gridDim.x * blockDim.x) {
         const int h = (int)(0.5f * nrm2h[row]);
         const int V = h0 - h;
         const int Wp = (V + 128) >> 7;          // floor((V + 128) / 128)
-        signed char d[32];
+        signed char d[16];
         d[0] = (signed char)(V - (Wp << 7));    // [-128, -1]
-        int R = -Wp;                            // d_1 + ... + d_31
+        int R = -Wp;                            // d_1 + ... + d_15
 #pragma unroll
-        for (int k = 1; k < 32; ++k) {
+        for (int k = 1; k < 16; ++k) {
             const int x = R < -128 ? -128 : (R > 127 ? 127 : R);
             d[k] = (signed char)x;
             R -= x;
         }
-        i4v lo, hi;
+        i4v lo;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
+        for (int w = 0; w < 4; ++w)
             lo[w] = (d[4 * w] & 255) | ((d[4 * w + 1] & 255) << 8) | ((d[4 * w + 2] & 255) << 16) | ((d[4 * w + 3] & 255) << 24);
-            hi[w] = (d[16 + 4 * w] & 255) | ((d[17 + 4 * w] & 255) << 8) | ((d[18 + 4 * w] & 255) << 16) | ((d[19 + 4 * w] & 255) << 24);
-        }
+        const i4v hi = {(int)0x80808001u, (int)0x80808080u, (int)0x80808080u, (int)0x80808080u};
         *reinterpret_cast<i4v*>(rows + (size_t)row * kI8RowBytes + kDim) = lo;
         *reinterpret_cast<i4v*>(rows + (size_t)row * kI8RowBytes + kDim + 16) = hi;
     }
@@ -180,7 +186,7 @@ __global__ __launch_bounds__(kI8Threads) void sweep_i8_kernel(
     if (PASS == 1 && tid < 2 * kPfBT * kPfColClasses) sCol[tid] = (int)0x80000000;
 
     // A fragments: row a_blk*512 + wave*32 + lcol, k-step ks = bytes 32 ks + 16 lhalf .. + 15
-    i4v af[4];
+    i4v af[4], a_digit;
     {
         const int frow = item.a_blk * kPfWgRows + wave * kI8WaveRows + lcol;
         const char* arow = reinterpret_cast<const char*>(pp.a_h) + (size_t)frow * kI8RowBytes;
@@ -191,40 +197,51 @@ __global__ __launch_bounds__(kI8Threads) void sweep_i8_kernel(
         const gi4_p ga = (gi4_p)arow;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) af[ks] = ga[2 * ks + lhalf];
+        // the A side of the digit k-step (this lane: slots 16 lhalf .. + 15): the constants in the lower half; in the upper
+        // half the row's own digits (sweep 1) or zeros (sweep 2: its rows keep their hit level in the C operand)
+        const i4v cdig = {(int)0x80808001u, (int)0x80808080u, (int)0x80808080u, (int)0x80808080u};
+        if (PASS == 1) {
+            a_digit = ga[8];
+            if (lhalf == 0) a_digit = cdig;
+        } else {
+            a_digit = lhalf == 0 ? cdig : i4v(0);
+        }
     }
     // this lane's 16 result rows: r -> row = a_blk*512 + wave*32 + (r&3) + 8*(r>>2) + 4*lhalf; their constants
     const int arow_base = item.a_blk * kPfWgRows + wave * kI8WaveRows + 4 * lhalf;
-    // The lane's 16 row constants = the C operand of the tile's first MFMA.  PASS 1: -h_a (the norm array holds 2 h_a, +inf
-    // on padding rows).  PASS 3: floor((T - 2 h_a) / 2), T = +inf -> everything hits.  Both minus the streamed image's
-    // centre H0_b (the digit k-step adds H0_b - h_b).  The loads are unconditional (both arrays cover the padded rows) and
-    // pinned by a register use: hipcc otherwise sinks each of them into its `rr < n1` branch and waits for it there -- 16
-    // round trips instead of 16 loads in flight.
-    i16v rowc;
-    {
+    // PASS 3: the lane's 16 row hit levels floor((T - 2 h_a) / 2) - H0_b (T = +inf -> everything hits) = the C operand of the
+    // tile's first MFMA.  The loads are unconditional (the array covers the padded rows) and pinned by a register use: hipcc
+    // otherwise sinks each of them into its `rr < n1` branch and waits for it there -- 16 round trips instead of 16 loads in
+    // flight.  PASS 1 has no row constants (header): its C operand is zero.
+    i16v rowc = i16v(0);
+    if (PASS == 3) {
         float xs[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int rr = arow_base + (r & 3) + 8 * (r >> 2);
-            xs[r] = PASS == 3 ? g_tu[pp.tu_off + rr] : g_anrm[rr];
+            xs[r] = g_tu[pp.tu_off + rr];
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(xs[r]));
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int rr = arow_base + (r & 3) + 8 * (r >> 2);
-            const float x = PASS == 3 ? 0.5f * xs[r] : -0.5f * xs[r];
-            rowc[r] = rr < pd.n1 ? (int)floorf(fminf(fmaxf(x, -5.0e8f), 5.0e8f)) - pp.b_h0 : kI8Pad;
+            rowc[r] = rr < pd.n1 ? (int)floorf(fminf(fmaxf(0.5f * xs[r], -5.0e8f), 5.0e8f)) - pp.b_h0 : kI8Pad;
         }
     }
-    // the A side of the digit k-step: c = [1, -128 x 31] (this lane: k = 16 lhalf .. + 15)
-    const i4v a_digit = {lhalf == 0 ? (int)0x80808001u : (int)0x80808080u, (int)0x80808080u, (int)0x80808080u, (int)0x80808080u};
+    const int item_k = PASS == 1 ? pp.a_h0 + pp.b_h0 : 0;   // sweep 1: every accumulator of the item is K = H0_a + H0_b too large
+    // sweep 1: the one wave of an image's last block that holds real AND padding rows masks the padding rows' accumulators
+    // (their operand bytes and digits are zero: they would look like a row with h = H0_a)
+    const bool wave_partial = PASS == 1 && item.a_blk * kPfWgRows + wave * kI8WaveRows < pd.n1 &&
+                              item.a_blk * kPfWgRows + (wave + 1) * kI8WaveRows > pd.n1;   // wave-uniform
     int rs0[16];   // PASS 1: running row maximum of the accumulator
 #pragma unroll
     for (int r = 0; r < 16; ++r) rs0[r] = (int)0x80000000;
     // pin the prologue loads before the loop (see sweep_kernel)
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) asm volatile("" ::"v"(af[ks]));
-    asm volatile("" ::"v"(rowc));
+    asm volatile("" ::"v"(a_digit));
+    if (PASS == 3) asm volatile("" ::"v"(rowc));
     wait_vmcnt<0>();
 
     int2* cbuf = reinterpret_cast<int2*>(sCand) + wave * kPfCandBuf;
@@ -300,11 +317,16 @@ __global__ __launch_bounds__(kI8Threads) void sweep_i8_kernel(
         const unsigned a = col_lds + (unsigned)cs * (kPfBT * kPfColClasses * 4);
         asm volatile("ds_max_i32 %0, %1\n\tds_max_i32 %0, %2 offset:128" ::"v"(a), "v"(mA), "v"(mB) : "memory");
     };
-    const unsigned colrow_lds = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)sCol + (unsigned)lane * 4u;
     auto store_columns = [&](int tt) {
-        const unsigned a = colrow_lds + (unsigned)((tt - t_begin) & 1) * (kPfBT * kPfColClasses * 4);
+        // (address and constants are rebuilt per call -- every fourth tile per wave -- instead of living in registers for the
+        // whole kernel: at <= 112 VGPRs four waves per SIMD leave 64 registers to the other stream's tail kernels)
+        unsigned lane_op = (unsigned)lane;
+        asm volatile("" : "+v"(lane_op));
+        const unsigned a = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)sCol + lane_op * 4u +
+                           (unsigned)((tt - t_begin) & 1) * (kPfBT * kPfColClasses * 4);
         i4v v;
-        const int reset = (int)0x80000000;
+        int reset = (int)0x80000000;
+        asm volatile("" : "+v"(reset));
         asm volatile("ds_read_b32 %0, %4\n\tds_read_b32 %1, %4 offset:256\n\tds_read_b32 %2, %4 offset:512\n\tds_read_b32 %3, %4 offset:768\n\t"
                      "s_waitcnt lgkmcnt(0)\n\t"
                      "ds_write_b32 %4, %5\n\tds_write_b32 %4, %5 offset:256\n\tds_write_b32 %4, %5 offset:512\n\tds_write_b32 %4, %5 offset:768"
@@ -314,9 +336,10 @@ __global__ __launch_bounds__(kI8Threads) void sweep_i8_kernel(
         const int m01 = max(v.x, v.y), n01 = min(v.x, v.y), m23 = max(v.z, v.w), n23 = min(v.z, v.w);
         const int hi = max(m01, m23), lo = max(min(m01, m23), max(n01, n23));
         v2f o;
-        o.x = hi > kI8PadTest ? (float)hi : -f_inf();
-        o.y = lo > kI8PadTest ? (float)lo : -f_inf();
-        reinterpret_cast<v2f*>(cp_s0)[pd.cp_off + (long long)item.a_blk * pd.n2pad + tt * kPfBT + lane] = o;
+        o.x = hi > kI8PadTest ? (float)(hi - item_k) : -f_inf();
+        o.y = lo > kI8PadTest ? (float)(lo - item_k) : -f_inf();
+        v2f* colbase = reinterpret_cast<v2f*>(cp_s0) + (pd.cp_off + (long long)item.a_blk * pd.n2pad);   // (uniform base + 32-bit lane offset)
+        colbase[(unsigned)(tt * kPfBT) + lane_op] = o;
     };
 
     lds_barrier();
@@ -333,8 +356,13 @@ __global__ __launch_bounds__(kI8Threads) void sweep_i8_kernel(
         if (wave_active) {
             __builtin_amdgcn_s_setprio(1);
             const char* pb2 = sB + sl * kI8TileBytes + lane_row_off + 2 * 32;
-            accA = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[0], bf[0][0], rowc, 0, 0, 0);   // C = the row constants: no init
-            accB = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[0], bf[0][1], rowc, 0, 0, 0);
+            if (PASS == 1) {   // C = 0 (an inline constant: no register, no init)
+                accA = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[0], bf[0][0], i16v(0), 0, 0, 0);
+                accB = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[0], bf[0][1], i16v(0), 0, 0, 0);
+            } else {           // C = the rows' hit levels
+                accA = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[0], bf[0][0], rowc, 0, 0, 0);
+                accB = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[0], bf[0][1], rowc, 0, 0, 0);
+            }
             bf[0][0] = *reinterpret_cast<const i4v*>(pb2);                          // k-step 2 into the registers of k-step 0
             bf[0][1] = *reinterpret_cast<const i4v*>(pb2 + 32 * kI8RowBytes);
             accA = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[1], bf[1][0], accA, 0, 0, 0);
@@ -347,7 +375,7 @@ __global__ __launch_bounds__(kI8Threads) void sweep_i8_kernel(
             bf[0][1] = *reinterpret_cast<const i4v*>(pb2 + 32 * kI8RowBytes + 64);
             accA = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[3], bf[1][0], accA, 0, 0, 0);
             accB = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[3], bf[1][1], accB, 0, 0, 0);
-            accA = __builtin_amdgcn_mfma_i32_32x32x32_i8(a_digit, bf[0][0], accA, 0, 0, 0);   // + H0_b - h_b
+            accA = __builtin_amdgcn_mfma_i32_32x32x32_i8(a_digit, bf[0][0], accA, 0, 0, 0);   // + (H0_b - h_b) [+ (H0_a - h_a)]
             accB = __builtin_amdgcn_mfma_i32_32x32x32_i8(a_digit, bf[0][1], accB, 0, 0, 0);
             __builtin_amdgcn_s_setprio(0);
         }
@@ -367,6 +395,19 @@ __global__ __launch_bounds__(kI8Threads) void sweep_i8_kernel(
                 for (int r = 0; r < 16; ++r) {
                     accA[r] = v0 ? accA[r] : kI8Pad;
                     accB[r] = v1 ? accB[r] : kI8Pad;
+                }
+            }
+            if (wave_partial) {
+                // (the limit is made opaque per tile: hipcc otherwise hoists the sixteen loop-invariant compares out of the
+                // tile loop and keeps their masks alive for every wave of every work item -- 16 registers for a branch that
+                // one wave per image takes)
+                int row_lim = pd.n1 - arow_base;
+                asm volatile("" : "+v"(row_lim));
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const bool real_row = (r & 3) + 8 * (r >> 2) < row_lim;
+                    accA[r] = real_row ? accA[r] : kI8Pad;
+                    accB[r] = real_row ? accB[r] : kI8Pad;
                 }
             }
             if (PASS == 3 && last_tile) {       // (sign bit set = no hit)
@@ -411,8 +452,8 @@ __global__ __launch_bounds__(kI8Threads) void sweep_i8_kernel(
             }
             // S~ = -2 * accumulator as a float (exact); padding -> +inf
             const long long o = pd.rp_off + (long long)item.range * pd.n1pad + item.a_blk * kPfWgRows + wave * kI8WaveRows + lane;
-            rp_s0[o] = m0 > kI8PadTest ? (float)(-2 * m0) : f_inf();
-            rp_s1[o] = m1 > kI8PadTest ? (float)(-2 * m1) : f_inf();
+            rp_s0[o] = m0 > kI8PadTest ? (float)(-2 * (m0 - item_k)) : f_inf();
+            rp_s1[o] = m1 > kI8PadTest ? (float)(-2 * (m1 - item_k)) : f_inf();
         }
     }
     }   // item loop
