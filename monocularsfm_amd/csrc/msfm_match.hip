@@ -147,6 +147,9 @@ constexpr int kMaxPairsPerBatchLimit = 65535;   // gridDim.y
 // exact re-check, epilogue, copy-out) runs under the next one's sweep 1; every sub-batch keeps >= kMinPipelineCost
 // descriptor pairs (a few ms of sweep 1) so that the fixed costs of a sub-batch stay small.
 constexpr int kDefaultPipeline = 4;
+// Sub-batches in flight (streams / scratch sets).  With three, the sweeps 1 of consecutive sub-batches run back to back
+// while the tails of the two before them run beside them; what cannot overlap a sweep is another sweep.
+constexpr int kInFlight = 3;
 constexpr long long kMinPipelineCost = 15000000000LL;
 
 }  // namespace
@@ -210,14 +213,16 @@ struct msfm_ctx {
     std::vector<Image> images;
     std::string err;
 
-    Scratch sc[2];
+    Scratch sc[kInFlight];
     Scratch* cur = &sc[0];            // the scratch set (and stream) the batch functions work on
+    Scratch* last_sweep1 = nullptr;   // the set whose sweep 1 was launched last in this call: the next sweep 1 waits for it
     DevBuf d_stage, d_maxima, d_zero_row;   // upload staging, upload-time maxima, the all-zero operand row
     DevBuf d_out_qt, d_out_d;         // the match lists of the whole call (msfm_fetch_matches_device)
     int fix_cap = 1 << 16;            // entries of the sqrt-space tie queue; grows on overflow (the sub-batch is re-run)
     // sub-batch limits of msfm_match_pairs (msfm_set_limits / MSFM_MAX_PAIRS_PER_BATCH / MSFM_SCRATCH_MIB)
     int max_pairs_per_batch = kDefaultMaxPairsPerBatch;
     long long scratch_elems = kDefaultScratchElems;
+    int in_flight = kInFlight;        // scratch sets used (MSFM_IN_FLIGHT=1|2|3 at msfm_create: fewer for A/B measurements)
     int pipeline = kDefaultPipeline;  // sub-batches a large call is cut into at least, so that tails overlap sweeps (1: off)
     int prefilter = 1;                // 0: brute force only; 1: MFMA prefilter, integer matrix cores for byte stores; 2: fp16 MFMA only
     int q8_route = 1;                 // float images in [0, 1] get byte twins and their first sweep on the integer cores (MSFM_Q8=0: off)
@@ -701,10 +706,8 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
     // Sweeps 1 of consecutive sub-batches are persistent one-workgroup-per-CU kernels: two of them cannot share the chip, and
     // a launch that merely queues behind the other stream's sweep would be timed (events) with its wait.  So this one
     // starts when the other stream's sweep 1 is done; what DOES overlap with it is that stream's tail.
-    {
-        Scratch& other = ctx->sc[ctx->cur == &ctx->sc[0] ? 1 : 0];
-        if (other.sweep1_recorded) HIPCHK(ctx, hipStreamWaitEvent(SC.stream, other.sweep1_done, 0));
-    }
+    if (ctx->last_sweep1 && ctx->last_sweep1 != ctx->cur)
+        HIPCHK(ctx, hipStreamWaitEvent(SC.stream, ctx->last_sweep1->sweep1_done, 0));
     HIPCHK(ctx, hipEventRecord(e0, SC.stream));
     if (i8 || q8)
         hipLaunchKernelGGL(sweep_i8_kernel<1>, dim3(std::min<unsigned>(sweep_grid, (unsigned)b.n_items)), dim3(kI8Threads), kI8LdsBytes, SC.stream, dp,
@@ -721,6 +724,7 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
     HIPCHK(ctx, hipEventRecord(e1, SC.stream));
     HIPCHK(ctx, hipEventRecord(SC.sweep1_done, SC.stream));
     SC.sweep1_recorded = true;
+    ctx->last_sweep1 = ctx->cur;
     SC.prof.approx_kernel_launches += 1;
     if (i8 || q8) SC.prof.sweep1_i8_launches += 1;
     if (q8) SC.prof.sweep1_q8_launches += 1;
@@ -1317,6 +1321,8 @@ int msfm_create(int device_ordinal, msfm_ctx** out_ctx) {
     if (const char* e = std::getenv("MSFM_MAX_PAIRS_PER_BATCH"))
         if (std::atoi(e) > 0) ctx->max_pairs_per_batch = std::min(std::atoi(e), kMaxPairsPerBatchLimit);
     if (const char* e = std::getenv("MSFM_Q8")) ctx->q8_route = e[0] == '2' ? 2 : (e[0] != '0');
+    if (const char* e = std::getenv("MSFM_IN_FLIGHT"))
+        if (std::atoi(e) >= 1 && std::atoi(e) <= kInFlight) ctx->in_flight = std::atoi(e);
     if (const char* e = std::getenv("MSFM_PIPELINE"))
         if (std::atoi(e) > 0) ctx->pipeline = std::min(std::atoi(e), 64);
     if (const char* e = std::getenv("MSFM_SCRATCH_MIB"))
@@ -1709,6 +1715,7 @@ static int match_pairs_impl(msfm_ctx* ctx, const int32_t* pairs, int n_pairs, co
         s.pf_pending = PfPending{};
         s.sweep1_recorded = false;
     }
+    ctx->last_sweep1 = nullptr;
     ctx->res_offsets.assign((size_t)n_pairs + 1, 0);
     ctx->res_sens.assign((size_t)n_pairs, 0);
     ctx->res_count = 0;
@@ -1719,7 +1726,8 @@ static int match_pairs_impl(msfm_ctx* ctx, const int32_t* pairs, int n_pairs, co
     HIPCHK(ctx, hipEventRecord(ev_begin, ctx->sc[0].stream));
 
     // ---- the cut: scratch memory per set, pair count, and a cost limit that gives a large call >= `pipeline` sub-batches
-    const long long kScratchElems = std::max<long long>(1, ctx->scratch_elems / 2);   // two scratch sets share the budget
+    const int kSets = ctx->in_flight;
+    const long long kScratchElems = std::max<long long>(1, ctx->scratch_elems / kSets);   // the scratch sets share the budget
     const int kMaxPairsPerBatch = ctx->max_pairs_per_batch;
     long long cost_limit = 0;   // 0: none
     if (ctx->pipeline > 1 && n_pairs > 1) {
@@ -1737,7 +1745,7 @@ static int match_pairs_impl(msfm_ctx* ctx, const int32_t* pairs, int n_pairs, co
     // a tie in sqrt space can only surface in a match list when a row with d0 == d1 can pass the ratio test
     const bool need_fix = !(prm.ratio <= 1.f);
 
-    SubBatch sb[2];
+    SubBatch sb[kInFlight];
     // pairs [begin, ...) -> sb.b (host tables); force_exact: pairs of this sub-batch whose candidate list overflowed in an
     // earlier attempt take the brute-force path
     auto build = [&](SubBatch& w, int begin, const std::vector<char>& force_exact) -> int {
@@ -1940,44 +1948,52 @@ static int match_pairs_impl(msfm_ctx* ctx, const int32_t* pairs, int n_pairs, co
     };
 
     const std::vector<char> no_force;
-    int next_begin = 0, slot = 0;
-    while (next_begin < n_pairs || sb[0].active || sb[1].active) {
-        if (next_begin < n_pairs && !sb[slot].active) {
+    int next_begin = 0;
+    long long issued = 0, completed = 0;   // sub-batch k lives in slot k % kSets
+    while (completed < issued || next_begin < n_pairs) {
+        // launch ahead: as many sub-batches as there are free scratch sets
+        while (next_begin < n_pairs && issued - completed < kSets) {
+            const int slot = (int)(issued % kSets);
             ctx->cur = &ctx->sc[slot];
             int rc = build(sb[slot], next_begin, no_force);
             if (rc != MSFM_OK) return rc;
             rc = issue(sb[slot], 2 + 12 * (size_t)slot);
             if (rc != MSFM_OK) return rc;
             next_begin = sb[slot].end;
+            ++issued;
         }
-        const int other = slot ^ 1;
-        if (sb[other].active) {
-            ctx->cur = &ctx->sc[other];
-            std::vector<char> force_exact;
-            bool retry = false;
-            int rc = complete(sb[other], force_exact, &retry);
+        // wait for the oldest one
+        const int slot = (int)(completed % kSets);
+        ctx->cur = &ctx->sc[slot];
+        std::vector<char> force_exact;
+        bool retry = false;
+        int rc = complete(sb[slot], force_exact, &retry);
+        if (rc != MSFM_OK) return rc;
+        if (retry) {
+            // drop what is in flight behind it, re-run this sub-batch alone until it fits, carry on from its end
+            rc = drain_streams(ctx);
             if (rc != MSFM_OK) return rc;
-            if (retry) {
-                // drop what is in flight behind it, re-run this sub-batch alone until it fits, carry on from its end
-                rc = drain_streams(ctx);
-                if (rc != MSFM_OK) return rc;
-                sb[slot].active = false;
-                ctx->sc[slot].pf_pending = PfPending{};
-                ctx->sc[slot].sweep1_recorded = false;
-                for (int attempt = 1;; ++attempt) {
-                    rc = build(sb[other], sb[other].begin, force_exact);
-                    if (rc != MSFM_OK) return rc;
-                    rc = issue(sb[other], 2 + 12 * (size_t)other);
-                    if (rc != MSFM_OK) return rc;
-                    rc = complete(sb[other], force_exact, &retry);
-                    if (rc != MSFM_OK) return rc;
-                    if (!retry) break;
-                    if (attempt >= 6) return fail(ctx, MSFM_E_DEVICE, "batch kept overflowing its queues");
+            for (int k = 0; k < kSets; ++k)
+                if (k != slot) {
+                    sb[k].active = false;
+                    ctx->sc[k].pf_pending = PfPending{};
+                    ctx->sc[k].sweep1_recorded = false;
                 }
-                next_begin = sb[other].end;
+            ctx->last_sweep1 = nullptr;
+            for (int attempt = 1;; ++attempt) {
+                rc = build(sb[slot], sb[slot].begin, force_exact);
+                if (rc != MSFM_OK) return rc;
+                rc = issue(sb[slot], 2 + 12 * (size_t)slot);
+                if (rc != MSFM_OK) return rc;
+                rc = complete(sb[slot], force_exact, &retry);
+                if (rc != MSFM_OK) return rc;
+                if (!retry) break;
+                if (attempt >= 6) return fail(ctx, MSFM_E_DEVICE, "batch kept overflowing its queues");
             }
+            next_begin = sb[slot].end;
+            issued = completed + 1;
         }
-        slot = other;
+        ++completed;
     }
     int rc = drain_streams(ctx);
     if (rc != MSFM_OK) return rc;
@@ -2092,6 +2108,7 @@ static int knn2_pair_impl(msfm_ctx* ctx, int id1, int id2, int32_t* fwd_idx0, fl
         sc.pf_pending = PfPending{};
         sc.sweep1_recorded = false;
     }
+    ctx->last_sweep1 = nullptr;
     Batch b;
     PairDesc pd;
     PfPair pp;
