@@ -147,9 +147,11 @@ constexpr int kMaxPairsPerBatchLimit = 65535;   // gridDim.y
 // exact re-check, epilogue, copy-out) runs under the next one's sweep 1; every sub-batch keeps >= kMinPipelineCost
 // descriptor pairs (a few ms of sweep 1) so that the fixed costs of a sub-batch stay small.
 constexpr int kDefaultPipeline = 4;
-// Sub-batches in flight (streams / scratch sets).  With three, the sweeps 1 of consecutive sub-batches run back to back
-// while the tails of the two before them run beside them; what cannot overlap a sweep is another sweep.
-constexpr int kInFlight = 3;
+// Sub-batches in flight (streams / scratch sets).  The loop below works for any number; THREE were measured and not kept
+// (profiles/r03_inflight_ab.txt): the bench job 43.1 ms against 41.9 ms with two, config 4 in full 9.70 s against 9.33 s --
+// the extra tail kernels running beside the sweeps cost them what the deeper overlap wins, and the scratch budget is cut
+// into smaller sub-batches.
+constexpr int kInFlight = 2;
 constexpr long long kMinPipelineCost = 15000000000LL;
 
 }  // namespace
@@ -222,7 +224,7 @@ struct msfm_ctx {
     // sub-batch limits of msfm_match_pairs (msfm_set_limits / MSFM_MAX_PAIRS_PER_BATCH / MSFM_SCRATCH_MIB)
     int max_pairs_per_batch = kDefaultMaxPairsPerBatch;
     long long scratch_elems = kDefaultScratchElems;
-    int in_flight = kInFlight;        // scratch sets used (MSFM_IN_FLIGHT=1|2|3 at msfm_create: fewer for A/B measurements)
+    int in_flight = kInFlight;        // scratch sets used (MSFM_IN_FLIGHT=1 at msfm_create: no sub-batch overlap, for A/B measurements)
     int pipeline = kDefaultPipeline;  // sub-batches a large call is cut into at least, so that tails overlap sweeps (1: off)
     int prefilter = 1;                // 0: brute force only; 1: MFMA prefilter, integer matrix cores for byte stores; 2: fp16 MFMA only
     int q8_route = 1;                 // float images in [0, 1] get byte twins and their first sweep on the integer cores (MSFM_Q8=0: off)

@@ -30,7 +30,7 @@ def mem_info():
     return free.value, total.value
 
 
-def predicted_sub_batches(n_rows, pairs, max_pairs=16384, scratch_elems=4 << 30):   # per scratch set: a third of the 48 GiB default
+def predicted_sub_batches(n_rows, pairs, max_pairs=16384, scratch_elems=6 << 30):   # per scratch set: half of the 48 GiB default
     """The cut of match_pairs_impl (csrc/msfm_match.hip): pairs are taken until the pair limit or the scratch estimate."""
     bounds = [0]
     est, cnt = 0, 0
