@@ -353,6 +353,8 @@ def main():
             "avg_launch_ms": avg_ms, "launches": pf_launches, "flops_per_desc_pair": 256.0,
             "descriptor_pairs_per_launch": pf_pairs_work / pf_launches,
             "algorithmic_bytes_per_launch": algo_bytes_step * args.steps / pf_launches,
+            # (event spans: with two sub-batches in flight a sweep-2 / sweep-1' launch waits for the other stream's sweep 1 --
+            # that wait is inside its span; profiles/rNN_route_q_kernel_stats_pipeline1.txt has the unpipelined kernel times)
             "sweep2": {"ms_per_step": acc["sweep2_ms"] / args.steps, "launches": acc["sweep2_launches"],
                        "compacted_image_pairs": acc["compacted_pairs"] // max(1, args.steps),
                        "work_fraction_of_sweep1": acc["sweep2_descriptor_pairs"] / max(1, pf_pairs_work)},

@@ -1097,6 +1097,9 @@ int run_exact(msfm_ctx* ctx, Batch& b, size_t ev_base) {
     if (rc != MSFM_OK) return rc;
     hipEvent_t e0 = get_event(ctx, ev_base), e1 = get_event(ctx, ev_base + 1);
     if (!e0 || !e1) return fail(ctx, MSFM_E_DEVICE, "hipEventCreate failed");
+    // (like sweep 1: the brute-force kernels of two sub-batches in flight take turns, so that the event span is the kernel's)
+    if (ctx->last_sweep1 && ctx->last_sweep1 != ctx->cur)
+        HIPCHK(ctx, hipStreamWaitEvent(SC.stream, ctx->last_sweep1->sweep1_done, 0));
     HIPCHK(ctx, hipEventRecord(e0, SC.stream));
     const dim3 grid((unsigned)b.n_items), block(kThreads);
 #define MSFM_LAUNCH_DIST(O)                                                                                               \
@@ -1109,6 +1112,9 @@ int run_exact(msfm_ctx* ctx, Batch& b, size_t ev_base) {
 #undef MSFM_LAUNCH_DIST
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipEventRecord(e1, SC.stream));
+    HIPCHK(ctx, hipEventRecord(SC.sweep1_done, SC.stream));
+    SC.sweep1_recorded = true;
+    ctx->last_sweep1 = ctx->cur;
     SC.prof.dist_kernel_launches += 1;
     for (auto& pd : b.pairs)
         if (pd.valid && pd.path == 0) SC.prof.exact_descriptor_pairs += (int64_t)pd.n1 * pd.n2;
