@@ -104,8 +104,9 @@ const char* msfm_last_error(const msfm_ctx* ctx);
 /* device name + CU count of the context's GPU (for bench reports); name_cap >= 64 */
 int msfm_device_info(const msfm_ctx* ctx, char* name, int name_cap, int* cu_count, int* clock_mhz);
 int msfm_set_accum_order(msfm_ctx* ctx, int order);
-/* 1 (default): MFMA prefilter + exact re-check where safe -- byte images (MSFM_DTYPE_U8 uploads) on the integer matrix
- * cores (v_mfma_i32_32x32x32_i8); float images whose values all lie in [0, 1] (RootSIFT) get a byte twin at upload and
+/* 1 (default): MFMA prefilter + exact re-check where safe -- byte images (MSFM_DTYPE_U8 uploads, and MSFM_DTYPE_F32
+ * uploads whose every value is an integer in [0, 255]: raw OpenCV SIFT stored as CV_32F, recognised on the device at
+ * upload; MSFM_BYTE_DETECT=0 at msfm_create: off) on the integer matrix cores (v_mfma_i32_32x32x32_i8); float images whose values all lie in [0, 1] (RootSIFT) get a byte twin at upload and
  * their FIRST sweep on the integer cores too, followed by an fp16 sweep of the ~6 % of rows it leaves alive (route Q,
  * MSFM_Q8=0 in the environment at msfm_create: off); everything else on the fp16 cores; 2: fp16 matrix cores for every
  * image; 0: always the brute-force exact kernel.  Results are bit-identical in all.

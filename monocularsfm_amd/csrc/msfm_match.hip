@@ -227,6 +227,7 @@ struct msfm_ctx {
     int in_flight = kInFlight;        // scratch sets used (MSFM_IN_FLIGHT=1 at msfm_create: no sub-batch overlap, for A/B measurements)
     int pipeline = kDefaultPipeline;  // sub-batches a large call is cut into at least, so that tails overlap sweeps (1: off)
     int prefilter = 1;                // 0: brute force only; 1: MFMA prefilter, integer matrix cores for byte stores; 2: fp16 MFMA only
+    int byte_detect = 1;              // a float upload holding only integers in [0, 255] is a byte store (MSFM_BYTE_DETECT=0: off)
     int q8_route = 1;                 // float images in [0, 1] get byte twins and their first sweep on the integer cores (MSFM_Q8=0: off)
     long long cmp_rows_hint = 0;      // compacted rows the previous batch needed (sizes the next batch's buffers)
     long long items_hint = 0, cand_hint = 0;   // likewise: work items, candidate-list capacity
@@ -1328,6 +1329,7 @@ int msfm_create(int device_ordinal, msfm_ctx** out_ctx) {
     if (const char* e = std::getenv("MSFM_PREFILTER")) ctx->prefilter = e[0] == '2' ? 2 : (e[0] != '0');
     if (const char* e = std::getenv("MSFM_MAX_PAIRS_PER_BATCH"))
         if (std::atoi(e) > 0) ctx->max_pairs_per_batch = std::min(std::atoi(e), kMaxPairsPerBatchLimit);
+    if (const char* e = std::getenv("MSFM_BYTE_DETECT")) ctx->byte_detect = e[0] != '0';
     if (const char* e = std::getenv("MSFM_Q8")) ctx->q8_route = e[0] == '2' ? 2 : (e[0] != '0');
     if (const char* e = std::getenv("MSFM_IN_FLIGHT"))
         if (std::atoi(e) >= 1 && std::atoi(e) <= kInFlight) ctx->in_flight = std::atoi(e);
@@ -1507,22 +1509,40 @@ static int build_image(msfm_ctx* ctx, Image& im, const unsigned char* src8, bool
     const int npad = im.nalloc * kBM;
     HIPCHK(ctx, hipMalloc((void**)&im.h16, (size_t)npad * kPfRowBytes));
     HIPCHK(ctx, hipMalloc((void**)&im.nrm, (size_t)npad * 4));
-    HIPCHK(ctx, ctx->d_maxima.ensure(16));
-    HIPCHK(ctx, hipMemsetAsync(ctx->d_maxima.p, 0, 16, SC.stream));
+    HIPCHK(ctx, ctx->d_maxima.ensure(32));
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_maxima.p, 0, 32, SC.stream));
     hipLaunchKernelGGL(pf_prepare_kernel, dim3(std::min(2048, (npad * 16 + 255) / 256)), dim3(256), 0, SC.stream,
                        im.raw, im.h16, im.nrm, ctx->d_maxima.as<unsigned>(), n, npad);
     HIPCHK(ctx, hipGetLastError());
-    if (is_u8) {
+    unsigned mx[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    bool detected = false;
+    auto prepare_bytes = [&]() -> int {
         HIPCHK(ctx, hipMalloc((void**)&im.i8, (size_t)npad * kI8RowBytes));
         HIPCHK(ctx, hipMalloc((void**)&im.nrm_i8, (size_t)npad * 4));
         hipLaunchKernelGGL(pf_prepare_i8_kernel, dim3(std::min(2048, (npad * 11 + 255) / 256)), dim3(256), 0, SC.stream,
                            (const float*)im.raw, im.i8, im.nrm_i8, ctx->d_maxima.as<unsigned>(), n, npad);
         HIPCHK(ctx, hipGetLastError());
+        return MSFM_OK;
+    };
+    if (is_u8) {
+        const int rc = prepare_bytes();
+        if (rc != MSFM_OK) return rc;
     }
-    unsigned mx[4] = {0, 0, 0, 0};
-    HIPCHK(ctx, hipMemcpyAsync(mx, ctx->d_maxima.p, 16, hipMemcpyDeviceToHost, SC.stream));
+    HIPCHK(ctx, hipMemcpyAsync(mx, ctx->d_maxima.p, 32, hipMemcpyDeviceToHost, SC.stream));
     // the caller may free/reuse its buffer (and we reuse d_stage) as soon as we return
     HIPCHK(ctx, hipStreamSynchronize(SC.stream));
+    if (!is_u8 && ctx->byte_detect && mx[6] == 0 && n > 0) {
+        // A FLOAT upload whose every value is an integer in [0, 255] (raw OpenCV SIFT stored as CV_32F, the reference's
+        // Database::WriteDescriptors format before RootSIFT): the same store as a byte upload.  Every partial sum of
+        // (a - b)^2 stays below 2^24, so S is an exact integer under any accumulation order and the image rides the
+        // integer matrix cores.
+        is_u8 = detected = true;
+        im.is_u8 = im.from_u8 = true;
+        const int rc = prepare_bytes();
+        if (rc != MSFM_OK) return rc;
+        HIPCHK(ctx, hipMemcpyAsync(mx, ctx->d_maxima.p, 32, hipMemcpyDeviceToHost, SC.stream));
+        HIPCHK(ctx, hipStreamSynchronize(SC.stream));
+    }
     std::memcpy(&im.nrm_max, &mx[0], 4);
     std::memcpy(&im.abs_max, &mx[1], 4);
     std::memcpy(&im.nrm_i8_max, &mx[2], 4);
@@ -1547,7 +1567,7 @@ static int build_image(msfm_ctx* ctx, Image& im, const unsigned char* src8, bool
             im.is_u8 = false;
         }
     }
-    if (!is_u8 && ctx->q8_route && im.abs_max <= 1.f) {
+    if ((!is_u8 || detected) && ctx->q8_route && im.abs_max <= 1.f) {   // (a float image of 0 / 1 entries is both)
         int rc = build_q8_twin(ctx, im);
         if (rc != MSFM_OK) return rc;
     }

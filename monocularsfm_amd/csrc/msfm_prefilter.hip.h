@@ -103,7 +103,8 @@ struct PfPair {            // per-pair extras of the prefilter path (parallel to
 // upload-time preparation: fp16 operand rows (272 B each, see kPfRowBytes), row norms, maxima
 // ---------------------------------------------------------------------------------------------
 __global__ void pf_prepare_kernel(const float* __restrict__ raw, _Float16* __restrict__ h, float* __restrict__ nrm,
-                                  unsigned* __restrict__ maxima /* [0]=nrm_max bits, [1]=abs_max bits */,
+                                  unsigned* __restrict__ maxima /* [0]=nrm_max bits, [1]=abs_max bits,
+                                                                   [6]=1 if a value is not an integer in [0, 255] */,
                                   int n, int npad) {
     const long long total = (long long)npad * 16;
     for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
@@ -111,15 +112,18 @@ __global__ void pf_prepare_kernel(const float* __restrict__ raw, _Float16* __res
         const int row = (int)(e >> 4), g = (int)(e & 15);
         h8 v;
         float amax = 0.f;
+        bool bytes = true;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const float x = row < n ? raw[(size_t)row * kDim + g * 8 + k] : 0.f;
             v[k] = (_Float16)x;
             amax = fmaxf(amax, fabsf(x));
             if (!(fabsf(x) <= 3.0e38f)) amax = f_inf();  // NaN / inf
+            bytes = bytes && x >= 0.f && x <= 255.f && x == __builtin_rintf(x);
         }
         *reinterpret_cast<h8*>(h + (size_t)row * kPfRowHalfs + g * 8) = v;
         if (amax > 0.f) atomicMax(&maxima[1], __float_as_uint(amax));
+        if (!bytes) maxima[6] = 1u;
     }
     for (int row = blockIdx.x * blockDim.x + threadIdx.x; row < npad; row += gridDim.x * blockDim.x) {
         float s = f_inf();

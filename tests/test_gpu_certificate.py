@@ -129,9 +129,14 @@ def test_byte_images_are_exact_under_every_order(gpu_ctx):
     offs, _, _ = gpu_ctx.match_pairs(pairs, max_distance=1e9)
     assert offs[-1] > 100 and gpu_ctx.profile()["order_sensitive_rows"] == 0
     assert not gpu_ctx.order_certificate(len(pairs)).any()
-    # the same values uploaded as floats carry no such guarantee by type: the predicate runs (and may or may not fire)
+    # the same values uploaded as floats are recognised as a byte store (every value is checked at upload): still exact
     for i, x in enumerate(u):
         gpu_ctx.upload_image(i, x.astype(F32))
+    gpu_ctx.match_pairs(pairs, max_distance=1e9)
+    assert gpu_ctx.profile()["order_sensitive_rows"] == 0 and not gpu_ctx.order_certificate(len(pairs)).any()
+    # ... half-integers are not: the predicate runs (and may or may not fire)
+    for i, x in enumerate(u):
+        gpu_ctx.upload_image(i, x.astype(F32) + F32(0.5))
     gpu_ctx.match_pairs(pairs, max_distance=1e9)
     cert = gpu_ctx.order_certificate(len(pairs))
     for p in range(len(pairs)):

@@ -91,21 +91,73 @@ def test_candidate_sets_are_tighter_on_the_integer_cores(gpu_ctx):
 
 
 def test_mixed_batch_takes_the_fp16_kernels(gpu_ctx, oracle):
-    """A batch that joins a byte image with a float image cannot use the integer cores; a float upload of byte VALUES
-    is a float image.  The result does not depend on it."""
+    """A batch that joins a byte image with a float image (half-integers here: exact in fp32, not bytes) cannot use the
+    integer cores.  The result does not depend on it."""
     u = synth.u8_images(3, [800, 900, 700], seed=5, as_float=False)
+    imgs = [u[0].astype(F32), u[1].astype(F32) + F32(0.5), u[2].astype(F32)]
     gpu_ctx.upload_image(0, u[0])
-    gpu_ctx.upload_image(1, u[1].astype(F32))
+    gpu_ctx.upload_image(1, imgs[1])
     gpu_ctx.upload_image(2, u[2])
     kw = {"ratio": 0.8, "cross_check": True, "max_distance": 1e9}
     pairs = synth.all_pairs(3)
     mixed = gpu_ctx.match_pairs(pairs, **kw)
-    assert gpu_ctx.profile()["sweep1_i8_launches"] == 0
-    check_vs_int_reference(u, pairs, mixed, **kw)
+    assert gpu_ctx.profile()["sweep1_i8_launches"] == 0 and gpu_ctx.profile()["prefilter_pairs"] == len(pairs)
+    o_offs, oq, ot, od = oracle.match_pairs(imgs, pairs, nthreads=8, **kw)
+    assert np.array_equal(mixed[0], o_offs) and np.array_equal(mixed[1][:, 0], oq) and np.array_equal(mixed[1][:, 1], ot)
+    assert np.array_equal(b(mixed[2]), b(od)) and o_offs[-1] > 50
     only_bytes = gpu_ctx.match_pairs(np.array([[2, 0]], np.int32), **kw)
     assert gpu_ctx.profile()["sweep1_i8_launches"] == 1
     check_vs_int_reference(u, [(2, 0)], only_bytes, **kw)
     gpu_ctx.clear_images()
+
+
+def test_float_upload_of_byte_values_is_a_byte_store(gpu_ctx, monkeypatch):
+    """The reference's store is CV_32F throughout (Database::WriteDescriptors, /root/reference/src/Database/Database.cpp:249-262);
+    raw OpenCV SIFT rows in it are integers 0..255.  Such an upload is recognised (every value checked on the device at
+    upload) and served by the integer cores: same bits as the MSFM_DTYPE_U8 upload, the fp16 route and brute force; one
+    non-integer value anywhere keeps the image a float image; MSFM_BYTE_DETECT=0 switches the recognition off."""
+    from monocularsfm_amd import _lib
+    sizes = [1100, 64, 513, 900, 1]
+    u = synth.u8_images(len(sizes), sizes, seed=2718, dup_frac=0.2, as_float=False)
+    pairs = synth.all_pairs(len(sizes))
+    kw = {"ratio": 0.8, "cross_check": True, "max_distance": 1e9}
+    for i, x in enumerate(u):
+        gpu_ctx.upload_image(i, x)
+    ref = gpu_ctx.match_pairs(pairs, **kw)
+    assert gpu_ctx.profile()["sweep1_i8_launches"] == 1 and ref[0][-1] > 100
+    for i, x in enumerate(u):
+        gpu_ctx.upload_image(i, x.astype(F32))
+    out = run_modes(gpu_ctx, pairs, **kw)
+    assert out[I8, "i8"] == 1 and out[F16, "i8"] == 0 and out[BRUTE, "i8"] == 0
+    for mode in (I8, F16, BRUTE):
+        assert same_result(out[mode], ref), mode
+    assert gpu_ctx.profile()["order_sensitive_rows"] == 0          # exact integers under every accumulation order
+    check_vs_int_reference(u, pairs, out[I8], **kw)
+    # subsets of a recognised image are recognised as well
+    gpu_ctx.subset_image(0, 10, np.arange(0, 1100, 3, dtype=np.int32))
+    gpu_ctx.subset_image(3, 11, np.arange(0, 900, 2, dtype=np.int32))
+    sub = gpu_ctx.match_pairs(np.array([[10, 11]], np.int32), **kw)
+    assert gpu_ctx.profile()["sweep1_i8_launches"] == 1
+    check_vs_int_reference({10: np.ascontiguousarray(u[0][::3]), 11: np.ascontiguousarray(u[3][::2])}, [(10, 11)], sub, **kw)
+    # one value off the integer grid / outside [0, 255] / negative zero is fine: float image or not
+    for value, is_bytes in ((17.5, False), (256.0, False), (-1.0, False), (-0.0, True)):
+        x = u[0].astype(F32)
+        x[1099, 127] = value
+        gpu_ctx.upload_image(0, x)
+        got = gpu_ctx.match_pairs(np.array([[0, 3]], np.int32), **kw)
+        assert gpu_ctx.profile()["sweep1_i8_launches"] == (1 if is_bytes else 0), value
+        gpu_ctx.set_prefilter(0)
+        try:
+            assert same_result(got, gpu_ctx.match_pairs(np.array([[0, 3]], np.int32), **kw)), value
+        finally:
+            gpu_ctx.set_prefilter(True)
+    gpu_ctx.clear_images()
+    monkeypatch.setenv("MSFM_BYTE_DETECT", "0")
+    with _lib.Context(0) as ctx:
+        for i, x in enumerate(u):
+            ctx.upload_image(i, x.astype(F32))
+        off = ctx.match_pairs(pairs, **kw)
+        assert ctx.profile()["sweep1_i8_launches"] == 0 and same_result(off, ref)
 
 
 def test_subsets_of_byte_images_stay_bytes(gpu_ctx):

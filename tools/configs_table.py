@@ -28,7 +28,7 @@ def run(ctx, pairs, mode, steps, **kw):
     ctx.set_pipeline(0)
     ctx.match_pairs(pairs, fetch="view", **kw)
     acc = {"approx_kernel_ms": 0.0, "sweep2_ms": 0.0, "candidates": 0, "dist_kernel_ms": 0.0, "sweep1_i8_launches": 0,
-           "prefilter_descriptor_pairs": 0, "sweep1b_ms": 0.0}
+           "sweep1_q8_launches": 0, "prefilter_descriptor_pairs": 0, "sweep1b_ms": 0.0}
     t0 = time.perf_counter()
     for _ in range(steps):
         offs, qt, d = ctx.match_pairs(pairs, fetch="view", **kw)
@@ -58,7 +58,8 @@ def job(name, imgs, pairs, steps, byte_store, **kw):
             if not a["sweep1_i8_launches"]:
                 print("    %s  -- (float store without byte twins -- values outside [0, 1]: the integer cores are not used)" % label)
                 continue
-            label = "route Q "
+            if a["sweep1_q8_launches"]:
+                label = "route Q "
         if ref is None:
             ref = res
         same = all(np.array_equal(x, y) for x, y in zip(ref, res))
@@ -86,9 +87,9 @@ def main():
     n5 = 8 if quick else 24
     imgs, pairs, name = synth.job("synthetic-u8", n5, 16384, seed=4096)
     job("config 5 subset (" + name + ", %d of 4096 images)" % n5, imgs, pairs, 3, True, max_distance=1e9)
-    # the same byte values uploaded as floats: what a store without the u8 side table costs
+    # the same byte values uploaded as floats (the reference's CV_32F store holding raw SIFT): recognised at upload, same route
     imgs, pairs, name = synth.job("synthetic-u8", n4, 8192, seed=1329)
-    job("config 4 subset, byte values stored as float32", [x.astype(np.float32) for x in imgs], pairs, 3, False, max_distance=1e9)
+    job("config 4 subset, byte values stored as float32 (recognised as a byte store at upload)", [x.astype(np.float32) for x in imgs], pairs, 3, False, max_distance=1e9)
 
 
 if __name__ == "__main__":
