@@ -270,6 +270,25 @@ def main():
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 sustained = float(t.cpu()[0])
         run_job.sustained = sustained
+        # after everything timed: the sweeps ALONE (one sub-batch per step, nothing in flight beside them) -- in the timed
+        # region the other sub-batches' bandwidth-bound tails run beside a sweep and stretch its event span
+        run_job.solo = None
+        if collect is not None and not args.no_prefilter and os.environ.get("MSFM_PIPELINE") is None:
+            ctx.set_pipeline(1)
+            solo = {"approx_kernel_ms": 0.0, "approx_kernel_launches": 0, "sweep2_ms": 0.0, "prefilter_descriptor_pairs": 0, "wall_ms": 0.0}
+            try:
+                step()
+                for _ in range(3):
+                    t2 = time.perf_counter()
+                    step()
+                    solo["wall_ms"] += (time.perf_counter() - t2) * 1e3 / 3
+                    p = ctx.profile()
+                    for k in ("approx_kernel_ms", "approx_kernel_launches", "sweep2_ms", "prefilter_descriptor_pairs"):
+                        solo[k] += p[k]
+            finally:
+                ctx.set_pipeline(0)
+            barrier()
+            run_job.solo = solo
         return dt, result, upload_s, per_rank, n_rows
 
     # ---- main workload -----------------------------------------------------------------------------------------
@@ -288,6 +307,7 @@ def main():
 
     dt, result, upload_s, per_rank, n_rows = run_job(imgs, pairs, args.steps, args.warmup, collect, args.sustained_steps, **main_kw)
     sustained = run_job.sustained
+    solo = run_job.solo
     total_desc_pairs = int((n_rows[pairs[:, 0]] * n_rows[pairs[:, 1]]).sum())
     offs = result[0]
     n_matches = int(offs[-1])
@@ -324,8 +344,8 @@ def main():
         # 0 => the index lists are the same under any conforming fp32 order of OpenCV's normL2Sqr_
         "order_sensitive_rows": int(last_prof.get("order_sensitive_rows", -1)),
         "sub_batches_per_step": acc["sub_batches"] // max(1, args.steps),
-        # the step is cut into sub-batches launched alternately on two streams: the bandwidth-bound tail of one runs
-        # under the next one's sweep 1 (msfm_set_pipeline / MSFM_PIPELINE; 1 = one launch per sweep, no overlap)
+        # the step is cut into shrinking sub-batches launched round-robin on three streams: the bandwidth-bound tail of one runs
+        # beside the sweeps of the next ones (msfm_set_pipeline / MSFM_PIPELINE; 1 = one launch per sweep, no overlap)
         "pipeline_env": os.environ.get("MSFM_PIPELINE"),
     }
     pf_ms, pf_launches = acc["approx_kernel_ms"], acc["approx_kernel_launches"]
@@ -361,6 +381,12 @@ def main():
             # route Q (float store, byte twins): sweep 1 above runs on the twins; sweep 1' is the fp16 sweep of the rows it left alive
             "route_q": {"twin_sweep_launches": acc["sweep1_q8_launches"], "sweep1b_ms_per_step": acc["sweep1b_ms"] / args.steps,
                         "sweep1b_work_fraction_of_sweep1": acc["sweep1b_descriptor_pairs"] / max(1, pf_pairs_work)},
+            # the same kernel with nothing beside it: 3 further steps with the pipeline off (one launch per sweep), after the timed region
+            "solo": None if not solo or not solo["approx_kernel_launches"] else {
+                "avg_launch_ms": solo["approx_kernel_ms"] / solo["approx_kernel_launches"], "launches": solo["approx_kernel_launches"],
+                "achieved": 256.0 * solo["prefilter_descriptor_pairs"] / (solo["approx_kernel_ms"] * 1e-3) / 1e12,
+                "frac": 256.0 * solo["prefilter_descriptor_pairs"] / (solo["approx_kernel_ms"] * 1e-3) / 1e12 / peak,
+                "sweep2_ms_per_step": solo["sweep2_ms"] / 3, "ms_per_step_unpipelined": solo["wall_ms"]},
             "sweep1_ms_per_step": pf_ms / args.steps,
             "step_over_sweep1": (dt / args.steps * 1e3) / max(1e-9, pf_ms / args.steps),
             "candidates_per_row": acc["candidates"] / max(1.0, rows_work),
@@ -397,6 +423,7 @@ def main():
 
         # u8 distances are hundreds, not fractions of a unit-norm descriptor: no distance cut (reference default 0.7 is for RootSIFT)
         u_dt, u_res, _, u_per_rank, u_rows = run_job(u_imgs, u_pairs, args.u8_steps, 1, u_collect, max_distance=1e9)
+        u_solo = run_job.solo
         u_total = int((u_rows[u_pairs[:, 0]] * u_rows[u_pairs[:, 1]]).sum())
         i8 = u_acc["sweep1_i8_launches"] > 0
         u_ach = 256.0 * u_acc["prefilter_descriptor_pairs"] / max(1e-9, u_acc["approx_kernel_ms"] * 1e-3) / 1e12
@@ -406,7 +433,10 @@ def main():
             "steps": args.u8_steps, "image_pairs": int(len(u_pairs)), "matches_per_step": int(u_res[0][-1]),
             "per_rank_ms": [{"compute": c, "exchange": e} for c, e in u_per_rank],
             "sweep1": {"instruction": "v_mfma_i32_32x32x32_i8" if i8 else "v_mfma_f32_32x32x16_f16", "achieved": u_ach,
-                       "frac": u_ach / (PEAK_I8_MFMA_TOPS if i8 else PEAK_F16_MFMA_TFLOPS)},
+                       "frac": u_ach / (PEAK_I8_MFMA_TOPS if i8 else PEAK_F16_MFMA_TFLOPS),
+                       # the kernel with nothing beside it (pipeline off, after the timed steps)
+                       "solo_frac": None if not u_solo or not u_solo["approx_kernel_ms"] else
+                       256.0 * u_solo["prefilter_descriptor_pairs"] / (u_solo["approx_kernel_ms"] * 1e-3) / 1e12 / (PEAK_I8_MFMA_TOPS if i8 else PEAK_F16_MFMA_TFLOPS)},
             "full_config_seconds_at_this_rate": 882456 * 8192.0 * 8192.0 / (u_total * args.u8_steps / u_dt),
         }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -114,15 +114,17 @@ int msfm_set_accum_order(msfm_ctx* ctx, int order);
 int msfm_set_prefilter(msfm_ctx* ctx, int enable);
 int msfm_get_profile(const msfm_ctx* ctx, msfm_profile* out);
 /* msfm_match_pairs cuts a call into device sub-batches of at most `max_pairs_per_batch` image pairs and
- * `scratch_bytes` of partial-result scratch (defaults 16384 pairs / 48 GiB -- shared by the two scratch sets of the pipeline; also MSFM_MAX_PAIRS_PER_BATCH and
+ * `scratch_bytes` of partial-result scratch (defaults 16384 pairs / 48 GiB -- 24 GiB for each of the pipeline's scratch sets; also MSFM_MAX_PAIRS_PER_BATCH and
  * MSFM_SCRATCH_MIB in the environment at msfm_create).  Results do not depend on the cut (tests force small limits
  * to cross it); a value <= 0 restores that default.  The reference's counterpart is the 100-pair flush of
  * BruteFeatureMatcher::RunMatching (src/Feature/FeatureMatching.cpp:118-139, max_pairs_size_). */
 int msfm_set_limits(msfm_ctx* ctx, int max_pairs_per_batch, int64_t scratch_bytes);
-/* A call of enough work (>= 1.5e10 descriptor pairs per part) is cut into at least `min_sub_batches` sub-batches, launched
- * alternately on two streams / scratch sets: the bandwidth-bound tail of one (thresholds, sweep-2 plan, exact re-check,
- * epilogue, copy-out) runs while the next one's sweep 1 owns the matrix cores.  Default 4; 1 = one sub-batch where memory
- * allows (no overlap); <= 0 restores the default.  Env: MSFM_PIPELINE.  Results do not depend on it. */
+/* A call of enough work (>= 1.5e10 descriptor pairs per part) is cut into at least `min_sub_batches` sub-batches of shrinking
+ * size (the last one 0.3 of the average: what follows the call's last sweep has nothing to hide behind), launched round-robin
+ * on three streams / scratch sets: the bandwidth-bound tail of one (thresholds, sweep-2 plan, exact re-check, epilogue,
+ * copy-out) runs while the sweeps of the next ones own the matrix cores.  Default 6; 1 = one sub-batch where memory allows
+ * (no overlap); <= 0 restores the default.  Env: MSFM_PIPELINE, MSFM_PIPELINE_TAPER, MSFM_IN_FLIGHT.  Results do not depend
+ * on any of it. */
 int msfm_set_pipeline(msfm_ctx* ctx, int min_sub_batches);
 
 /* ---- descriptor store -------------------------------------------------------------------

@@ -169,8 +169,8 @@ class Context:
         self._chk(self._L.msfm_set_limits(self._h, int(max_pairs_per_batch), int(scratch_bytes)))
 
     def set_pipeline(self, min_sub_batches=0):
-        """A large call is cut into at least this many sub-batches whose tails overlap the next one's sweep 1 (<= 0:
-        default 4; 1: off).  Results do not depend on it."""
+        """A large call is cut into at least this many (shrinking) sub-batches whose tails overlap the next ones' sweeps (<= 0:
+        default 6; 1: off).  Results do not depend on it."""
         self._chk(self._L.msfm_set_pipeline(self._h, int(min_sub_batches)))
 
     def profile(self):

@@ -119,6 +119,7 @@ struct Image {
     float* err_q8 = nullptr;
     float err_q8_max = 0.f;
     int h0_q8 = 0;
+    float q8_level = 0.f;     // the context's twin level m (scale 255 / m) this twin was built with
     // keypoint coordinates (x, y) for the geometric verification; nk = -1: not uploaded
     float2* kxy = nullptr;
     int nk = -1;
@@ -146,12 +147,13 @@ constexpr int kMaxPairsPerBatchLimit = 65535;   // gridDim.y
 // A call large enough is cut into at least this many sub-batches so that the bandwidth-bound tail of one (thresholds, plan,
 // exact re-check, epilogue, copy-out) runs under the next one's sweep 1; every sub-batch keeps >= kMinPipelineCost
 // descriptor pairs (a few ms of sweep 1) so that the fixed costs of a sub-batch stay small.
-constexpr int kDefaultPipeline = 4;
-// Sub-batches in flight (streams / scratch sets).  The loop below works for any number; THREE were measured and not kept
-// (profiles/r03_inflight_ab.txt): the bench job 43.1 ms against 41.9 ms with two, config 4 in full 9.70 s against 9.33 s --
-// the extra tail kernels running beside the sweeps cost them what the deeper overlap wins, and the scratch budget is cut
-// into smaller sub-batches.
-constexpr int kInFlight = 2;
+constexpr int kDefaultPipeline = 6;
+// Sub-batches in flight (streams / scratch sets).  With three, sweep 1 of sub-batch k + 2 is ordered behind sweep 2 of sub-batch k
+// (Scratch::sweep2_done): the matrix pipes see S1(k+1) S2(k) S1(k+2) S2(k+1) ... and every bandwidth-bound tail has a sweep to run
+// beside.  Measured on the bench job (profiles/r03_inflight_ab.txt): 2 sets x 4 equal parts 40.7 ms, 3 sets x 6 tapered parts 39.6 ms;
+// what the overlap can win is bounded -- the part draws its full power budget under a sweep alone, a tail kernel beside it
+// slows the sweep by about what it would have cost alone (section 5.1.7 of DESIGN.md).
+constexpr int kInFlight = 3;
 constexpr long long kMinPipelineCost = 15000000000LL;
 
 }  // namespace
@@ -193,6 +195,9 @@ struct Scratch {
     msfm_profile prof = {};           // this sub-batch's share; joins the call's profile when the sub-batch is accepted
     hipEvent_t sweep1_done = nullptr; // recorded behind sweep 1: the other stream's next sweep 1 waits for it
     bool sweep1_recorded = false;
+    hipEvent_t sweep2_done = nullptr; // recorded behind sweep 2: the sweep 1 two sub-batches later waits for it (three sets in flight)
+    bool sweep2_recorded = false;
+    long long seq = 0;                // number of the sub-batch this set works on (msfm_ctx::issue_seq)
     void release_all() {
         DevBuf* bufs[] = {&d_pairs, &d_items, &d_item_base, &d_rp_s0, &d_rp_i0, &d_rp_s1, &d_cp_s0, &d_cp_i0, &d_cp_s1, &d_k_i0, &d_k_d0,
                           &d_k_d1, &d_st_qt, &d_st_d, &d_counts, &d_offsets, &d_sens, &d_sub_qt, &d_sub_d, &d_fix_count, &d_fix_list, &d_pf, &d_tu,
@@ -224,10 +229,14 @@ struct msfm_ctx {
     // sub-batch limits of msfm_match_pairs (msfm_set_limits / MSFM_MAX_PAIRS_PER_BATCH / MSFM_SCRATCH_MIB)
     int max_pairs_per_batch = kDefaultMaxPairsPerBatch;
     long long scratch_elems = kDefaultScratchElems;
+    long long issue_seq = 0;          // sub-batches issued so far
+    double pipeline_taper = 0.3;      // size of a call's last part relative to the average part (MSFM_PIPELINE_TAPER; 1: equal parts)
     int in_flight = kInFlight;        // scratch sets used (MSFM_IN_FLIGHT=1 at msfm_create: no sub-batch overlap, for A/B measurements)
     int pipeline = kDefaultPipeline;  // sub-batches a large call is cut into at least, so that tails overlap sweeps (1: off)
     int prefilter = 1;                // 0: brute force only; 1: MFMA prefilter, integer matrix cores for byte stores; 2: fp16 MFMA only
     int byte_detect = 1;              // a float upload holding only integers in [0, 255] is a byte store (MSFM_BYTE_DETECT=0: off)
+    float q8_level = 0.f;             // m: largest value of the twinned images so far, rounded up to a multiple of 1/16 (msfm_q8.hip.h)
+    int q8_direct = 1;                // thresholds for sweep 2 straight from the twins' sweep when they are fine enough (MSFM_Q8_DIRECT=0: never, 2: always)
     int q8_route = 1;                 // float images in [0, 1] get byte twins and their first sweep on the integer cores (MSFM_Q8=0: off)
     long long cmp_rows_hint = 0;      // compacted rows the previous batch needed (sizes the next batch's buffers)
     long long items_hint = 0, cand_hint = 0;   // likewise: work items, candidate-list capacity
@@ -651,7 +660,11 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
             pp.b_err = ib.err_q8;
         }
     }
-    SC.pf_pending.q8 = q8;
+    // fine twins: their sweep's bounds are the thresholds of sweep 2; coarse ones (a store with values near 1): an fp16 sweep 1'
+    // of the live rows refines them first
+    const bool q8_direct = q8 && (ctx->q8_direct == 2 || (ctx->q8_direct == 1 && ctx->q8_level <= kQ8DirectMaxLevel));
+    const bool q8_refine = q8 && !q8_direct;
+    SC.pf_pending.q8 = q8_refine;   // (a plan A and a sweep 1' to account for at the end of the batch)
     long long dense_cand = 0;
     for (size_t p = 0; p < P; ++p) {
         b.pf[p].tu_off = b.pairs[p].kf_off;
@@ -711,6 +724,11 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
     // starts when the other stream's sweep 1 is done; what DOES overlap with it is that stream's tail.
     if (ctx->last_sweep1 && ctx->last_sweep1 != ctx->cur)
         HIPCHK(ctx, hipStreamWaitEvent(SC.stream, ctx->last_sweep1->sweep1_done, 0));
+    // ... and, with three sub-batches in flight, behind sweep 2 of the one before that: the matrix pipes see
+    // S1(k+1) S2(k) S1(k+2) S2(k+1) ..., every bandwidth-bound tail runs beside a sweep, and two persistent kernels never split the CUs
+    for (Scratch& other : ctx->sc)
+        if (&other != ctx->cur && other.sweep2_recorded && other.seq + 2 <= SC.seq)
+            HIPCHK(ctx, hipStreamWaitEvent(SC.stream, other.sweep2_done, 0));
     HIPCHK(ctx, hipEventRecord(e0, SC.stream));
     if (i8 || q8)
         hipLaunchKernelGGL(sweep_i8_kernel<1>, dim3(std::min<unsigned>(sweep_grid, (unsigned)b.n_items)), dim3(kI8Threads), kI8LdsBytes, SC.stream, dp,
@@ -745,14 +763,14 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
     if (compact) {
         // ---- static plan tables (the GPU is busy with sweep 1 meanwhile), buffers from the prediction ----------
         CompactPlan cp;
-        build_compact_plan(ctx, b, cp, q8);
+        build_compact_plan(ctx, b, cp, q8_refine);
         const size_t G = cp.groups.size(), M = cp.member_pair.size();
         n_lists = G;
         long long max_ranges = 1;
         for (const PlanGroup& g : cp.groups) max_ranges = std::max<long long>(max_ranges, g.ranges);
         const long long slack = (long long)kPfWgRows * (long long)G + kPfWgRows;
         // (route Q: plan A holds every live column once per 512-row block group of the other image)
-        const long long rows_cap = std::max<long long>(ctx->cmp_rows_hint + ctx->cmp_rows_hint / 2, (q8 ? cp.rows_ub_all_bits / 8 : cp.rows_ub / 4)) + slack;
+        const long long rows_cap = std::max<long long>(ctx->cmp_rows_hint + ctx->cmp_rows_hint / 2, (q8_refine ? cp.rows_ub_all_bits / 8 : cp.rows_ub / 4)) + slack;
         // (per group: 8 entries per compacted row rounded up to 1024, + 1024 -- plan_group_cap_units)
         const long long cand_cap = std::max<long long>(8 * rows_cap + 2048LL * (long long)G, ctx->cand_hint);
         // (the list holds 8 x the longest per-XCD sub-list: twice the balanced size leaves room for skew)
@@ -845,12 +863,15 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
             return MSFM_OK;
         };
         if (q8) {
-            // ---- route Q: live / dead from the twins' sweep, plan A, fp16 sweep 1' on the live rows, scatter ------------------
+            // ---- route Q: live / dead (fine twins: and the thresholds, the block masks, the counts of the plan) from the twins' sweep
             hipLaunchKernelGGL(pf_prune_q8_kernel, mgrid, dim3(256), 0, SC.stream, dp, dpf, (const PfPair*)SC.d_pfq.as<PfPair>(),
                                (const float*)SC.d_rp_s0.as<float>(), (const float*)SC.d_rp_s1.as<float>(), (const float*)SC.d_cp_s0.as<float>(),
-                               colmask, tuv, prune, pc);
+                               colmask, tuv, prune, pc, ctx->q8_level / 255.f, q8_direct ? 1 : 0);
             HIPCHK(ctx, hipGetLastError());
             DBGSYNC(ctx, "pf_prune_q8_kernel");
+        }
+        if (q8_refine) {
+            // ---- coarse twins: plan A, fp16 sweep 1' on the live rows, scatter ------------------------------------------------
             HIPCHK(ctx, hipMemsetAsync(SC.d_summary_a.p, 0, sizeof(PlanSummary), SC.stream));
             rc = launch_plan(SC.d_summary_a.as<PlanSummary>(), 1);
             if (rc != MSFM_OK) return rc;
@@ -888,8 +909,9 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
             HIPCHK(ctx, hipMemsetAsync(SC.d_totals.p, 0, 64, SC.stream));
         }
         // thresholds + live counts per member / group (the plan tables above are uploaded by now; sweep 1 is still running)
-        hipLaunchKernelGGL(pf_thresholds_kernel, mgrid, dim3(256), 0, SC.stream, dp, dpf, SC.d_rp_s0.as<float>(),
-                           SC.d_rp_s1.as<float>(), SC.d_cp_s0.as<float>(), colmask, tuv, tuv, prune, pc, q8 ? 1 : 0);
+        if (!q8_direct)
+            hipLaunchKernelGGL(pf_thresholds_kernel, mgrid, dim3(256), 0, SC.stream, dp, dpf, SC.d_rp_s0.as<float>(),
+                               SC.d_rp_s1.as<float>(), SC.d_cp_s0.as<float>(), colmask, tuv, tuv, prune, pc, q8 ? 1 : 0);
         HIPCHK(ctx, hipGetLastError());
         DBGSYNC(ctx, "pf_thresholds_kernel");
         rc = launch_plan(SC.d_summary.as<PlanSummary>(), 0);
@@ -913,6 +935,8 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
         DBGSYNC(ctx, "sweep_kernel<3>");
         SC.prof.sweep2_launches += 1;
         HIPCHK(ctx, hipEventRecord(e3, SC.stream));
+        HIPCHK(ctx, hipEventRecord(SC.sweep2_done, SC.stream));
+        SC.sweep2_recorded = true;
         dl = SC.d_lists.as<CandList>();
         SC.pf_pending.compact = true;
         SC.pf_pending.rows_cap = rows_cap;
@@ -942,6 +966,8 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
         DBGSYNC(ctx, "sweep_kernel<2>");
         SC.prof.sweep2_launches += 1;
         HIPCHK(ctx, hipEventRecord(e3, SC.stream));
+        HIPCHK(ctx, hipEventRecord(SC.sweep2_done, SC.stream));
+        SC.sweep2_recorded = true;
         dl = SC.d_lists.as<CandList>();
     }
 
@@ -1282,7 +1308,8 @@ int msfm_create(int device_ordinal, msfm_ctx** out_ctx) {
     std::snprintf(ctx->dev_name, sizeof(ctx->dev_name), "%s (%s)", prop.name, prop.gcnArchName);
     for (Scratch& sc : ctx->sc)
         if (hipStreamCreateWithFlags(&sc.stream, hipStreamNonBlocking) != hipSuccess ||
-            hipEventCreateWithFlags(&sc.sweep1_done, hipEventDisableTiming) != hipSuccess) {
+            hipEventCreateWithFlags(&sc.sweep1_done, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&sc.sweep2_done, hipEventDisableTiming) != hipSuccess) {
             destroy_streams(ctx);
             delete ctx;
             return MSFM_E_DEVICE;
@@ -1329,7 +1356,12 @@ int msfm_create(int device_ordinal, msfm_ctx** out_ctx) {
     if (const char* e = std::getenv("MSFM_PREFILTER")) ctx->prefilter = e[0] == '2' ? 2 : (e[0] != '0');
     if (const char* e = std::getenv("MSFM_MAX_PAIRS_PER_BATCH"))
         if (std::atoi(e) > 0) ctx->max_pairs_per_batch = std::min(std::atoi(e), kMaxPairsPerBatchLimit);
+    if (const char* e = std::getenv("MSFM_PIPELINE_TAPER")) {
+        const double t = std::atof(e);
+        if (t >= 0.05 && t <= 1.0) ctx->pipeline_taper = t;
+    }
     if (const char* e = std::getenv("MSFM_BYTE_DETECT")) ctx->byte_detect = e[0] != '0';
+    if (const char* e = std::getenv("MSFM_Q8_DIRECT")) ctx->q8_direct = e[0] == '2' ? 2 : (e[0] != '0');
     if (const char* e = std::getenv("MSFM_Q8")) ctx->q8_route = e[0] == '2' ? 2 : (e[0] != '0');
     if (const char* e = std::getenv("MSFM_IN_FLIGHT"))
         if (std::atoi(e) >= 1 && std::atoi(e) <= kInFlight) ctx->in_flight = std::atoi(e);
@@ -1344,6 +1376,8 @@ int msfm_create(int device_ordinal, msfm_ctx** out_ctx) {
 static void destroy_streams(msfm_ctx* ctx) {
     for (Scratch& sc : ctx->sc) {
         if (sc.sweep1_done) (void)hipEventDestroy(sc.sweep1_done);
+        if (sc.sweep2_done) (void)hipEventDestroy(sc.sweep2_done);
+        sc.sweep2_done = nullptr;
         if (sc.stream) (void)hipStreamDestroy(sc.stream);
         sc.sweep1_done = nullptr;
         sc.stream = nullptr;
@@ -1439,15 +1473,28 @@ static int alloc_image(msfm_ctx* ctx, Image& im, int n) {
 
 // route Q: byte twin of a float image with values in [0, 1] (msfm_q8.hip.h); no twin (nothing allocated) when a value
 // is negative / not finite or the rows' norms spread beyond the digit range
+static void free_q8_twin(Image& im) {
+    if (im.q8) (void)hipFree(im.q8);
+    if (im.nrm_q8) (void)hipFree(im.nrm_q8);
+    if (im.err_q8) (void)hipFree(im.err_q8);
+    im.q8 = nullptr;
+    im.nrm_q8 = nullptr;
+    im.err_q8 = nullptr;
+}
+
+// (the image's values lie in [0, ctx->q8_level]: the caller has raised the level)
 static int build_q8_twin(msfm_ctx* ctx, Image& im) {
     const int n = im.n, npad = im.nalloc * kBM;
+    free_q8_twin(im);
+    im.q8_level = ctx->q8_level;
+    const float scale = 255.f / ctx->q8_level, inv = ctx->q8_level / 255.f;
     HIPCHK(ctx, ctx->d_stage.ensure((size_t)n * kDim * 4));
     HIPCHK(ctx, ctx->d_maxima.ensure(32));
     HIPCHK(ctx, hipMemsetAsync(ctx->d_maxima.p, 0, 32, SC.stream));
     HIPCHK(ctx, hipMalloc((void**)&im.err_q8, (size_t)std::max(n, 1) * 4));
     unsigned* mx_d = ctx->d_maxima.as<unsigned>();
     hipLaunchKernelGGL(pf_quantise_q8_kernel, dim3(std::min(2048, (n + 3) / 4)), dim3(256), 0, SC.stream, (const float*)im.raw,
-                       ctx->d_stage.as<float>(), im.err_q8, mx_d + 4, mx_d + 5, n);
+                       ctx->d_stage.as<float>(), im.err_q8, mx_d + 4, mx_d + 5, n, scale, inv);
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipMalloc((void**)&im.q8, (size_t)npad * kI8RowBytes));
     HIPCHK(ctx, hipMalloc((void**)&im.nrm_q8, (size_t)npad * 4));
@@ -1466,12 +1513,7 @@ static int build_q8_twin(msfm_ctx* ctx, Image& im) {
     const long long h0 = (hmin + hmax) / 2;
     const bool ok = mx[4] == 0 && hmin <= hmax && h0 - hmax >= kI8DigitLo && h0 - hmin <= kI8DigitHi;
     if (!ok) {
-        (void)hipFree(im.q8);
-        (void)hipFree(im.nrm_q8);
-        (void)hipFree(im.err_q8);
-        im.q8 = nullptr;
-        im.nrm_q8 = nullptr;
-        im.err_q8 = nullptr;
+        free_q8_twin(im);
         return MSFM_OK;
     }
     im.h0_q8 = (int)h0;
@@ -1568,6 +1610,7 @@ static int build_image(msfm_ctx* ctx, Image& im, const unsigned char* src8, bool
         }
     }
     if ((!is_u8 || detected) && ctx->q8_route && im.abs_max <= 1.f) {   // (a float image of 0 / 1 entries is both)
+        ctx->q8_level = std::max(ctx->q8_level, std::max(kQ8LevelStep, std::ceil(im.abs_max / kQ8LevelStep) * kQ8LevelStep));
         int rc = build_q8_twin(ctx, im);
         if (rc != MSFM_OK) return rc;
     }
@@ -1650,6 +1693,7 @@ int msfm_clear_images(msfm_ctx* ctx) {
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipStreamSynchronize(SC.stream));
     for (auto& im : ctx->images) free_image(im);
+    ctx->q8_level = 0.f;
     return MSFM_OK;
 }
 
@@ -1742,8 +1786,20 @@ static int match_pairs_impl(msfm_ctx* ctx, const int32_t* pairs, int n_pairs, co
     for (Scratch& s : ctx->sc) {
         s.pf_pending = PfPending{};
         s.sweep1_recorded = false;
+        s.sweep2_recorded = false;
     }
     ctx->last_sweep1 = nullptr;
+    // twins built before a later upload raised the context's level (msfm_q8.hip.h): rebuilt here, nothing is in flight
+    if (ctx->q8_route && ctx->prefilter == 1)
+        for (int k = 0; k < 2 * n_pairs; ++k) {
+            const int id = pairs[k];
+            if (id < 0 || id >= kSlots) continue;
+            Image& im = ctx->images[id];
+            if (im.q8 && im.q8_level != ctx->q8_level) {
+                const int rc = build_q8_twin(ctx, im);
+                if (rc != MSFM_OK) return rc;
+            }
+        }
     ctx->res_offsets.assign((size_t)n_pairs + 1, 0);
     ctx->res_sens.assign((size_t)n_pairs, 0);
     ctx->res_count = 0;
@@ -1755,9 +1811,12 @@ static int match_pairs_impl(msfm_ctx* ctx, const int32_t* pairs, int n_pairs, co
 
     // ---- the cut: scratch memory per set, pair count, and a cost limit that gives a large call >= `pipeline` sub-batches
     const int kSets = ctx->in_flight;
-    const long long kScratchElems = std::max<long long>(1, ctx->scratch_elems / kSets);   // the scratch sets share the budget
+    const long long kScratchElems = std::max<long long>(1, ctx->scratch_elems / std::min(kSets, 2));   // the scratch sets share the budget (a third set: +50 %)
     const int kMaxPairsPerBatch = ctx->max_pairs_per_batch;
-    long long cost_limit = 0;   // 0: none
+    // cumulative-cost marks of the parts (empty: no cost cut).  The parts shrink linearly towards the end of the call, the last
+    // one to `pipeline_taper` of the average: what follows the LAST sweep 1 of a call -- that part's thresholds, plan, sweep 2,
+    // exact re-check, epilogue -- has nothing left to hide behind, and it is proportional to the part's size.
+    std::vector<long long> marks;
     if (ctx->pipeline > 1 && n_pairs > 1) {
         long long total = 0;
         for (int k = 0; k < n_pairs; ++k) {
@@ -1767,7 +1826,15 @@ static int match_pairs_impl(msfm_ctx* ctx, const int32_t* pairs, int n_pairs, co
             if (n1 > 0 && n2 > 0) total += n1 * n2;
         }
         const long long n_sub = std::min<long long>(ctx->pipeline, total / kMinPipelineCost);
-        if (n_sub >= 2) cost_limit = (total + n_sub - 1) / n_sub;   // part k ends where the running cost passes (k + 1) * cost_limit
+        if (n_sub >= 2) {
+            const double last = ctx->pipeline_taper, first = 2.0 - last;
+            double acc = 0.0;
+            marks.push_back(0);
+            for (long long k = 0; k < n_sub; ++k) {
+                acc += first - (first - last) * (double)k / (double)(n_sub - 1);
+                marks.push_back(k + 1 == n_sub ? total : (long long)((double)total * acc / (double)n_sub));
+            }
+        }
     }
     long long cost_done = 0;   // cost of the sub-batches built so far (a re-built sub-batch starts from its own begin: see build)
     // a tie in sqrt space can only surface in a match list when a row with d0 == d1 can pass the ratio test
@@ -1785,7 +1852,12 @@ static int match_pairs_impl(msfm_ctx* ctx, const int32_t* pairs, int n_pairs, co
         w.cost_begin = cost_begin;
         // the first cumulative-cost mark behind this sub-batch's start
         // (a part ends at the pair nearest to its mark, so its successor may start a little before or behind one)
-        const long long mark = cost_limit > 0 ? ((cost_begin + cost_limit / 2) / cost_limit + 1) * cost_limit : 0;
+        long long mark = 0;
+        if (!marks.empty()) {
+            size_t i = 0;
+            while (i + 2 < marks.size() && cost_begin >= (marks[i] + marks[i + 1]) / 2) ++i;
+            mark = marks[i + 1];
+        }
         long long est = 0, cost = 0;
         int end = begin;
         while (end < n_pairs && (end - begin) < kMaxPairsPerBatch) {
@@ -1805,7 +1877,7 @@ static int match_pairs_impl(msfm_ctx* ctx, const int32_t* pairs, int n_pairs, co
                                                3 * (8LL * (pd.n1 + pd.n2) + 1024)) : 0;
             const long long c = pd.valid ? (long long)pd.n1 * pd.n2 : 0;
             if (end > begin && est + need > kScratchElems) break;
-            if (end > begin && cost_limit > 0 && cost_begin + cost + c / 2 > mark) break;
+            if (end > begin && !marks.empty() && cost_begin + cost + c / 2 > mark) break;
             est += need;
             cost += c;
             const size_t k = w.b.pairs.size();
@@ -1832,6 +1904,8 @@ static int match_pairs_impl(msfm_ctx* ctx, const int32_t* pairs, int n_pairs, co
         w.ev_base = ev_base;
         w.exact_launched = false;
         SC.prof = msfm_profile{};
+        SC.seq = ctx->issue_seq++;
+        SC.sweep2_recorded = false;
         int rc = run_knn(ctx, b, ev_base, &w.exact_launched, prune, need_fix);
         if (rc != MSFM_OK) return rc;
         const long long oe = std::max<long long>(1, b.out_elems);
@@ -2006,6 +2080,7 @@ static int match_pairs_impl(msfm_ctx* ctx, const int32_t* pairs, int n_pairs, co
                     sb[k].active = false;
                     ctx->sc[k].pf_pending = PfPending{};
                     ctx->sc[k].sweep1_recorded = false;
+                    ctx->sc[k].sweep2_recorded = false;
                 }
             ctx->last_sweep1 = nullptr;
             for (int attempt = 1;; ++attempt) {
@@ -2135,6 +2210,7 @@ static int knn2_pair_impl(msfm_ctx* ctx, int id1, int id2, int32_t* fwd_idx0, fl
     for (Scratch& sc : ctx->sc) {   // (a failed earlier batch may have left its end-of-batch state behind)
         sc.pf_pending = PfPending{};
         sc.sweep1_recorded = false;
+        sc.sweep2_recorded = false;
     }
     ctx->last_sweep1 = nullptr;
     Batch b;

@@ -31,12 +31,19 @@
 #pragma once
 // (included inside namespace msfm)
 
-constexpr float kQ8Scale = 255.f;
+// The twins' scale.  A context quantises with ONE scale s = 255 / m, m = the largest value of its twinned images rounded up to
+// a multiple of 1/16 (RootSIFT values rarely exceed 0.45: s ~ 580, error norms ~0.0056 instead of 0.0128 at s = 255); a
+// twin built under a smaller m is rebuilt at the start of the next matching call (msfm_match.hip: refresh_twins).  The
+// real number the bounds are stated with is the float `inv` ~ 1 / s itself: the twin is a^ = q * inv EXACTLY.
+constexpr float kQ8LevelStep = 1.f / 16.f;
+// with twins at least this fine the twins' sweep yields thresholds tight enough to collect candidates with directly
+// (~4.5 per live row on RootSIFT-like data against 2.5 after an fp16 sweep 1'; 12 at m = 1): no sweep 1'
+constexpr float kQ8DirectMaxLevel = 0.625f;
 
-// byte twin of a float image: qf = rint(255 x) as floats (the input format of pf_prepare_i8_kernel), err[row] >= |x - q/255|_2
+// byte twin of a float image: qf = rint(x * scale) as floats (the input format of pf_prepare_i8_kernel), err[row] >= |x - q inv|_2
 // flags[0] |= 1 when a value is outside [0, 1] or not finite: no twin.  maxima[0] = max err (float bits).
 __global__ void pf_quantise_q8_kernel(const float* __restrict__ raw, float* __restrict__ qf, float* __restrict__ err,
-                                      unsigned* __restrict__ flags, unsigned* __restrict__ err_max, int n) {
+                                      unsigned* __restrict__ flags, unsigned* __restrict__ err_max, int n, float scale, float inv) {
     const int lane = threadIdx.x & 63;
     for (int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; row < n; row += (gridDim.x * blockDim.x) >> 6) {
         float s = 0.f;
@@ -45,9 +52,9 @@ __global__ void pf_quantise_q8_kernel(const float* __restrict__ raw, float* __re
         for (int k = 0; k < 2; ++k) {
             const float x = raw[(size_t)row * kDim + lane + 64 * k];
             if (!(x >= 0.f && x <= 1.f)) bad = true;
-            const float q = fminf(fmaxf(rintf(x * kQ8Scale), 0.f), 255.f);
+            const float q = fminf(fmaxf(rintf(x * scale), 0.f), 255.f);
             qf[(size_t)row * kDim + lane + 64 * k] = q;
-            const float d = x - q * (1.f / kQ8Scale);
+            const float d = fmaf(-q, inv, x);   // x - q inv, rounded once
             s = fmaf(d, d, s);
         }
 #pragma unroll
@@ -56,7 +63,7 @@ __global__ void pf_quantise_q8_kernel(const float* __restrict__ raw, float* __re
             if (lane == 0) atomicOr(&flags[0], 1u);
         }
         if (lane == 0) {
-            // rounded up: 130 fp32 roundings of non-negative terms (< 1e-5 relative), the division by 255 and the sqrt
+            // rounded up: the differences (one rounding each), 130 fp32 roundings of non-negative terms (< 1e-5 relative), the sqrt
             const float e = sqrtf(s) * (1.f + 2e-5f) + 1e-7f;
             err[row] = e;
             atomicMax(err_max, __float_as_uint(e));
@@ -70,7 +77,8 @@ __global__ void pf_quantise_q8_kernel(const float* __restrict__ raw, float* __re
 // grid = (ceil(max_npad/256), n_pairs), like pf_thresholds_kernel, whose member counting this kernel repeats.
 __global__ void pf_prune_q8_kernel(const PairDesc* __restrict__ pairs, const PfPair* __restrict__ pf, const PfPair* __restrict__ pfq,
                                    const float* __restrict__ rp_s0, const float* __restrict__ rp_s1, const float* __restrict__ cp_s0,
-                                   unsigned* __restrict__ colmask, float* __restrict__ tuv, PruneParams pr, PlanCounts plan) {
+                                   unsigned* __restrict__ colmask, float* __restrict__ tuv, PruneParams pr, PlanCounts plan,
+                                   float inv, int direct) {
     MSFM_TAIL_PRIO();
     const PairDesc pd = pairs[blockIdx.y];
     const PfPair pp = pf[blockIdx.y];
@@ -79,14 +87,24 @@ __global__ void pf_prune_q8_kernel(const PairDesc* __restrict__ pairs, const PfP
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     bool row_live = false;
     unsigned col_bits = 0;
-    const float inv = 1.f / kQ8Scale;
+    // S~ <= S^ <= S~ + 2;  sqrtf and the products below are rounded: the factors (1 -+ 1e-6) keep the bounds one-sided
+    auto lower = [&](float s0, float err) -> float { return fmaxf(sqrtf(fmaxf(s0, 0.f)) * inv * (1.f - 1e-6f) - err, 0.f); };
+    auto upper = [&](float s1, float err) -> float { return sqrtf(s1 + 2.f) * inv * (1.f + 1e-6f) + err; };
     auto dead = [&](float s0, float s1, float err) -> bool {
-        // S~ <= S^ <= S~ + 2;  sqrtf and the products below are rounded: the factors (1 -+ 1e-6) keep the bounds one-sided
-        const float l0 = fmaxf(sqrtf(fmaxf(s0, 0.f)) * inv * (1.f - 1e-6f) - err, 0.f);
-        const float u1 = sqrtf(s1 + 2.f) * inv * (1.f + 1e-6f) + err;
+        const float l0 = lower(s0, err), u1 = upper(s1, err);
         const bool ratio_fails = pr.ratio > 0.f && l0 * (1.f - 1e-5f) >= pr.ratio * u1 * (1.f + 1e-5f);
         const bool too_far = l0 * (1.f - 1e-5f) > pr.max_distance * (1.f + 1e-5f);
         return ratio_fails || too_far;
+    };
+    // direct mode: the threshold sweep 2 (fp16) collects candidates with.  Every column that can be the first or second
+    // neighbour of the row under the pinned fp32 order has a real S <= U1^2 (1 + 2.1e-5) (U1 bounds the real second distance,
+    // the pinned order is within 1e-5 relative of real arithmetic), hence an fp16 S~ <= that + eps; + the roundings here
+    // and in sweep 2's test, as in pf_thresholds_kernel
+    const float eps_norm = 4.8828125e-4f * fmaxf(pp.a_c, pp.b_c);
+    auto threshold = [&](float u1, float nrm, float other_max) -> float {
+        const float eps = kEpsRel * (nrm + other_max) + kEpsAbs * (sqrtf(nrm) + sqrtf(other_max)) + eps_norm;
+        const float u2 = u1 * u1;
+        return u2 * (1.f + 3e-5f) + eps + 1e-5f * (u2 + nrm + other_max);
     };
     if (e < pd.n1pad) {
         float s0 = f_inf(), s1 = f_inf();
@@ -95,8 +113,11 @@ __global__ void pf_prune_q8_kernel(const PairDesc* __restrict__ pairs, const PfP
             v2_merge(s0, s1, rp_s0[o], rp_s1[o]);
         }
         bool live = e < pd.n1;
-        if (live) live = !dead(s0, s1, (pq.a_err[e] + pq.b_c) * (1.f + 1e-6f));   // (b_c of the twin pair: E of image 2)
-        tuv[pp.tu_off + e] = live ? f_inf() : -f_inf();
+        const float err = live ? (pq.a_err[e] + pq.b_c) * (1.f + 1e-6f) : 0.f;   // (b_c of the twin pair: E of image 2)
+        if (live) live = !dead(s0, s1, err);
+        float T = live ? f_inf() : -f_inf();
+        if (live && direct) T = threshold(upper(s1, err), pp.a_nrm[e], pp.b_nrm_max);
+        tuv[pp.tu_off + e] = T;
         row_live = live;
     }
     if (e < pd.n2pad) {
@@ -108,11 +129,24 @@ __global__ void pf_prune_q8_kernel(const PairDesc* __restrict__ pairs, const PfP
             v2_merge(s0, s1, -2.f * m.x, -2.f * m.y);
         }
         bool live = e < pd.n2;
-        if (live) live = !dead(s0, s1, (pq.b_err[e] + pq.a_c) * (1.f + 1e-6f));
-        tuv[pp.tv_off + e] = live ? f_inf() : -f_inf();
-        // sweep 1' visits every 512-row block group of image 1 for a live column: one bit per group (see pf_thresholds_kernel)
+        const float err = live ? (pq.b_err[e] + pq.a_c) * (1.f + 1e-6f) : 0.f;
+        if (live) live = !dead(s0, s1, err);
         const int g = (nb + 31) / 32, bits = (nb + g - 1) / g;
-        col_bits = live ? (bits >= 32 ? 0xffffffffu : ((1u << bits) - 1u)) : 0u;
+        if (!direct) {
+            tuv[pp.tv_off + e] = live ? f_inf() : -f_inf();
+            // sweep 1' visits every 512-row block group of image 1 for a live column: one bit per group (see pf_thresholds_kernel)
+            col_bits = live ? (bits >= 32 ? 0xffffffffu : ((1u << bits) - 1u)) : 0u;
+        } else {
+            // the blocks of image 1 that can hold a candidate of this column: the block's nearest row may be as close as
+            // lower(block minimum), a candidate is at most U1 away
+            const float u1 = live ? upper(s1, err) : 0.f;
+            tuv[pp.tv_off + e] = live ? threshold(u1, pp.b_nrm[e], pp.a_nrm_max) : -f_inf();
+            if (live)
+                for (int p = 0; p < nb; ++p) {
+                    const float smin = -2.f * cp2[pd.cp_off + (long long)p * pd.n2pad + e].x;
+                    if (lower(smin, err) * (1.f - 1e-5f) <= u1 * (1.f + 1e-5f)) col_bits |= 1u << (p / g);
+                }
+        }
         colmask[pp.tv_off + e] = col_bits;
     }
     if (plan.pp_plan) {
@@ -123,16 +157,25 @@ __global__ void pf_prune_q8_kernel(const PairDesc* __restrict__ pairs, const PfP
         __syncthreads();
         const unsigned long long rl = __ballot(row_live);
         if ((threadIdx.x & 63) == 0 && rl) atomicAdd(&hist[32], __popcll(rl));
-        const unsigned long long cl = __ballot(col_bits != 0u);
-        if ((threadIdx.x & 63) == 0 && cl) atomicAdd(&hist[0], __popcll(cl));   // every live column carries every bit
+        if (!direct) {
+            const unsigned long long cl = __ballot(col_bits != 0u);
+            if ((threadIdx.x & 63) == 0 && cl) atomicAdd(&hist[0], __popcll(cl));   // every live column carries every bit
+        } else {
+            while (col_bits) {
+                const int bit = __builtin_ctz(col_bits);
+                col_bits &= col_bits - 1;
+                atomicAdd(&hist[bit], 1);
+            }
+        }
         __syncthreads();
         if (threadIdx.x == 0 && hist[32]) {
             atomicAdd(&plan.cnt[pl.fwd_member], hist[32]);
             atomicAdd(&plan.gtot[plan.member_group[pl.fwd_member]], hist[32]);
         }
-        if ((int)threadIdx.x < pl.rev_bits && hist[0]) {
-            atomicAdd(&plan.cnt[pl.rev_member0 + threadIdx.x], hist[0]);
-            atomicAdd(&plan.gtot[plan.member_group[pl.rev_member0 + threadIdx.x]], hist[0]);
+        const int mine = direct ? hist[threadIdx.x < 33 ? threadIdx.x : 0] : hist[0];
+        if ((int)threadIdx.x < pl.rev_bits && mine) {
+            atomicAdd(&plan.cnt[pl.rev_member0 + threadIdx.x], mine);
+            atomicAdd(&plan.gtot[plan.member_group[pl.rev_member0 + threadIdx.x]], mine);
         }
     }
 }

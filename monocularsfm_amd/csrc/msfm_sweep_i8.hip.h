@@ -48,7 +48,7 @@ constexpr int kI8WaveRows = kPfWgRows / kI8Waves;       // 32: one MFMA row bloc
 // Ring of EIGHT 11-KiB tiles, DMA seven tiles ahead: a phase is ~600 cycles here, so the three-tile lead of the fp16
 // kernel (1.6 us there) would be 0.75 us -- less than an L2 miss.
 constexpr int kI8Ring = 8;
-constexpr int kI8LdsBytes = kI8Ring * kI8TileBytes + kI8Waves * kPfCandBuf * 8 + 2 * kPfBT * kPfColClasses * 4;
+constexpr int kI8LdsBytes = kI8Ring * kI8TileBytes + kI8Waves * kPfCandBuf * 8 + 4 * kPfBT * kPfColClasses * 4;
 static_assert(kI8WaveRows == 32, "one 32-row block per wave");
 constexpr int kI8Pad = -(1 << 29);                      // "-inf" of a padding row / column (two of them still fit an int32)
 constexpr int kI8PadTest = -(1 << 27);                  // anything below is padding
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(kI8Threads) void sweep_i8_kernel(
     extern __shared__ __attribute__((aligned(16))) char pf_smem[];
     char* sB = pf_smem;                                                   // [ring slot][64 rows x 176 B]
     char* sCand = pf_smem + kI8Ring * kI8TileBytes;                       // [wave][kPfCandBuf] int2 (PASS 3)
-    int* sCol = reinterpret_cast<int*>(sCand + kI8Waves * kPfCandBuf * 8);  // [2 tiles][4 classes][64 columns] (PASS 1)
+    int* sCol = reinterpret_cast<int*>(sCand + kI8Waves * kPfCandBuf * 8);  // [4 tiles][4 classes][64 columns] (PASS 1)
 
     const int n_items = n_items_dev ? *n_items_dev : n_items_host;
     __shared__ int s_next_item;
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(kI8Threads) void sweep_i8_kernel(
 
 #pragma unroll
     for (int k = 0; k < kI8Ring - 1; ++k) dma_tile(t_begin + k);
-    if (PASS == 1 && tid < 2 * kPfBT * kPfColClasses) sCol[tid] = (int)0x80000000;
+    if (PASS == 1 && tid < 4 * kPfBT * kPfColClasses) sCol[tid] = (int)0x80000000;
 
     // A fragments: row a_blk*512 + wave*32 + lcol, k-step ks = bytes 32 ks + 16 lhalf .. + 15
     i4v af[4], a_digit;
@@ -323,7 +323,7 @@ __global__ __launch_bounds__(kI8Threads) void sweep_i8_kernel(
         unsigned lane_op = (unsigned)lane;
         asm volatile("" : "+v"(lane_op));
         const unsigned a = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)sCol + lane_op * 4u +
-                           (unsigned)((tt - t_begin) & 1) * (kPfBT * kPfColClasses * 4);
+                           (unsigned)((tt - t_begin) & 3) * (kPfBT * kPfColClasses * 4);
         i4v v;
         int reset = (int)0x80000000;
         asm volatile("" : "+v"(reset));
@@ -343,101 +343,119 @@ __global__ __launch_bounds__(kI8Threads) void sweep_i8_kernel(
     };
 
     lds_barrier();
+    dma_tile(t_begin + kI8Ring - 1);   // the first interval's DMA group
     i4v bf[2][2];
     if (wave_active) preread(0, bf);
-    if (grp == 1) lds_barrier();
 
     i16v accA, accB;
+    // the matrix half of a tile: 10 MFMA, k-steps 2, 3 and the digits read from LDS behind the MFMA pairs that free their registers
+    auto matrix_half = [&](int t) {
+        const int sl = (t - t_begin) & (kI8Ring - 1);
+        __builtin_amdgcn_s_setprio(1);
+        const char* pb2 = sB + sl * kI8TileBytes + lane_row_off + 2 * 32;
+        if (PASS == 1) {   // C = 0 (an inline constant: no register, no init)
+            accA = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[0], bf[0][0], i16v(0), 0, 0, 0);
+            accB = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[0], bf[0][1], i16v(0), 0, 0, 0);
+        } else {           // C = the rows' hit levels
+            accA = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[0], bf[0][0], rowc, 0, 0, 0);
+            accB = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[0], bf[0][1], rowc, 0, 0, 0);
+        }
+        bf[0][0] = *reinterpret_cast<const i4v*>(pb2);                          // k-step 2 into the registers of k-step 0
+        bf[0][1] = *reinterpret_cast<const i4v*>(pb2 + 32 * kI8RowBytes);
+        accA = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[1], bf[1][0], accA, 0, 0, 0);
+        accB = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[1], bf[1][1], accB, 0, 0, 0);
+        bf[1][0] = *reinterpret_cast<const i4v*>(pb2 + 32);                     // k-step 3 into those of k-step 1
+        bf[1][1] = *reinterpret_cast<const i4v*>(pb2 + 32 * kI8RowBytes + 32);
+        accA = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[2], bf[0][0], accA, 0, 0, 0);
+        accB = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[2], bf[0][1], accB, 0, 0, 0);
+        bf[0][0] = *reinterpret_cast<const i4v*>(pb2 + 64);                     // the digits (bytes 128 + 16 lhalf ..)
+        bf[0][1] = *reinterpret_cast<const i4v*>(pb2 + 32 * kI8RowBytes + 64);
+        accA = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[3], bf[1][0], accA, 0, 0, 0);
+        accB = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[3], bf[1][1], accB, 0, 0, 0);
+        accA = __builtin_amdgcn_mfma_i32_32x32x32_i8(a_digit, bf[0][0], accA, 0, 0, 0);   // + (H0_b - h_b) [+ (H0_a - h_a)]
+        accB = __builtin_amdgcn_mfma_i32_32x32x32_i8(a_digit, bf[0][1], accB, 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    // the epilogue half of tile t (its accumulators are in accA / accB)
+    auto epilogue_half = [&](int t) {
+        // the image's last tile: columns >= n2 carry zero digits (they look like a column with h = H0): mask them
+        const bool last_tile = (t + 1) * kPfBT > pd.n2;   // wave-uniform
+        if (PASS == 1 && last_tile) {
+            const bool v0 = t * kPfBT + lcol < pd.n2, v1 = t * kPfBT + 32 + lcol < pd.n2;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                accA[r] = v0 ? accA[r] : kI8Pad;
+                accB[r] = v1 ? accB[r] : kI8Pad;
+            }
+        }
+        if (wave_partial) {
+            // (the limit is made opaque per tile: hipcc otherwise hoists the sixteen loop-invariant compares out of the
+            // tile loop and keeps their masks alive for every wave of every work item -- 16 registers for a branch that
+            // one wave per image takes)
+            int row_lim = pd.n1 - arow_base;
+            asm volatile("" : "+v"(row_lim));
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const bool real_row = (r & 3) + 8 * (r >> 2) < row_lim;
+                accA[r] = real_row ? accA[r] : kI8Pad;
+                accB[r] = real_row ? accB[r] : kI8Pad;
+            }
+        }
+        if (PASS == 3 && last_tile) {       // (sign bit set = no hit)
+            if (!(t * kPfBT + lcol < pd.n2)) accA = i16v(-1);
+            if (!(t * kPfBT + 32 + lcol < pd.n2)) accB = i16v(-1);
+        }
+        if (PASS == 1) {
+            fold_columns(column_max(accA), column_max(accB), (t - t_begin) & 3);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) rs0[r] = max3i(rs0[r], accA[r], accB[r]);
+        } else {
+            scan_hits3(accA, accB, t * kPfBT + lcol);
+        }
+    };
+
+    // ONE barrier per tile.  Every wave runs matrix(u), epilogue(u), matrix(u + 1), ...; the even group passes its barrier behind
+    // the epilogues, the odd group behind the matrix halves: in interval v (between barriers B_{v-1} and B_v) the even group does
+    // matrix(v), epilogue(v) and the odd group epilogue(v - 1), matrix(v).  On every SIMD two waves issue MFMA while the other two
+    // issue the VALU work of an epilogue -- they co-issue, profiles/r03_ubench_coissue.txt -- and a wave that finishes its first
+    // half early goes on with its second instead of waiting for the slowest wave of the workgroup at a mid-tile barrier (round 2:
+    // two barriers per tile, the halves in lock-step).
+    //   ring: B_v guarantees that tiles <= v + 2 have landed (the even group pre-reads tile v + 2's first fragments at the end of
+    //   interval v + 1); the DMA waves have issued the groups up to v + kI8Ring - 1 by then: "at most kI8Ring - 3 outstanding" (loads
+    //   retire in order).  The group issued at the start of interval v overwrites the slot of tile v - 1, whose last readers (both
+    //   groups' matrix(v - 1)) finished before B_{v-1}.
+    //   column classes: tile t is folded by the even group in interval t and by the odd one in interval t + 1, stored (and reset)
+    //   at the start of interval t + 2 by one wave: four slots.
+    auto next_interval = [&](int v) {
+        wait_older_group();
+        lds_barrier();
+        dma_tile(v + kI8Ring - 1);
+        if (PASS == 1 && v - 2 >= t_begin && wave == ((v - t_begin) & 3)) store_columns(v - 2);
+    };
     MSFM_PROBE_BEGIN
 #pragma unroll 1
-    for (int t = t_begin; t < t_end; ++t) {
-        const int sl = (t - t_begin) & (kI8Ring - 1);
-        // ---- MFMA phase ----------------------------------------------------------------------------------------
-        if (wave_active) {
-            __builtin_amdgcn_s_setprio(1);
-            const char* pb2 = sB + sl * kI8TileBytes + lane_row_off + 2 * 32;
-            if (PASS == 1) {   // C = 0 (an inline constant: no register, no init)
-                accA = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[0], bf[0][0], i16v(0), 0, 0, 0);
-                accB = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[0], bf[0][1], i16v(0), 0, 0, 0);
-            } else {           // C = the rows' hit levels
-                accA = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[0], bf[0][0], rowc, 0, 0, 0);
-                accB = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[0], bf[0][1], rowc, 0, 0, 0);
-            }
-            bf[0][0] = *reinterpret_cast<const i4v*>(pb2);                          // k-step 2 into the registers of k-step 0
-            bf[0][1] = *reinterpret_cast<const i4v*>(pb2 + 32 * kI8RowBytes);
-            accA = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[1], bf[1][0], accA, 0, 0, 0);
-            accB = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[1], bf[1][1], accB, 0, 0, 0);
-            bf[1][0] = *reinterpret_cast<const i4v*>(pb2 + 32);                     // k-step 3 into those of k-step 1
-            bf[1][1] = *reinterpret_cast<const i4v*>(pb2 + 32 * kI8RowBytes + 32);
-            accA = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[2], bf[0][0], accA, 0, 0, 0);
-            accB = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[2], bf[0][1], accB, 0, 0, 0);
-            bf[0][0] = *reinterpret_cast<const i4v*>(pb2 + 64);                     // the digits (bytes 128 + 16 lhalf ..)
-            bf[0][1] = *reinterpret_cast<const i4v*>(pb2 + 32 * kI8RowBytes + 64);
-            accA = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[3], bf[1][0], accA, 0, 0, 0);
-            accB = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[3], bf[1][1], accB, 0, 0, 0);
-            accA = __builtin_amdgcn_mfma_i32_32x32x32_i8(a_digit, bf[0][0], accA, 0, 0, 0);   // + (H0_b - h_b) [+ (H0_a - h_a)]
-            accB = __builtin_amdgcn_mfma_i32_32x32x32_i8(a_digit, bf[0][1], accB, 0, 0, 0);
-            __builtin_amdgcn_s_setprio(0);
-        }
+    for (int u = t_begin; u < t_end; ++u) {
+        if (wave_active) matrix_half(u);
         MSFM_PROBE(0)
-        if (grp == 0) wait_older_group();
-        lds_barrier();
+        if (grp == 1) next_interval(u + 1);
         MSFM_PROBE(1)
-        // ---- EPI phase -----------------------------------------------------------------------------------------
-        if (PASS == 1 && grp == 0 && t > t_begin && wave == ((t - t_begin) & 3)) store_columns(t - 1);
-        dma_tile(t + kI8Ring - 1);
         if (wave_active) {
-            // the image's last tile: columns >= n2 carry zero digits (they look like a column with h = H0): mask them
-            const bool last_tile = (t + 1) * kPfBT > pd.n2;   // wave-uniform
-            if (PASS == 1 && last_tile) {
-                const bool v0 = t * kPfBT + lcol < pd.n2, v1 = t * kPfBT + 32 + lcol < pd.n2;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    accA[r] = v0 ? accA[r] : kI8Pad;
-                    accB[r] = v1 ? accB[r] : kI8Pad;
-                }
-            }
-            if (wave_partial) {
-                // (the limit is made opaque per tile: hipcc otherwise hoists the sixteen loop-invariant compares out of the
-                // tile loop and keeps their masks alive for every wave of every work item -- 16 registers for a branch that
-                // one wave per image takes)
-                int row_lim = pd.n1 - arow_base;
-                asm volatile("" : "+v"(row_lim));
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const bool real_row = (r & 3) + 8 * (r >> 2) < row_lim;
-                    accA[r] = real_row ? accA[r] : kI8Pad;
-                    accB[r] = real_row ? accB[r] : kI8Pad;
-                }
-            }
-            if (PASS == 3 && last_tile) {       // (sign bit set = no hit)
-                if (!(t * kPfBT + lcol < pd.n2)) accA = i16v(-1);
-                if (!(t * kPfBT + 32 + lcol < pd.n2)) accB = i16v(-1);
-            }
-            if (PASS == 1) {
-                fold_columns(column_max(accA), column_max(accB), (t - t_begin) & 1);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) rs0[r] = max3i(rs0[r], accA[r], accB[r]);
-            } else {
-                scan_hits3(accA, accB, t * kPfBT + lcol);
-            }
+            epilogue_half(u);
+            if (u + 1 < t_end) preread((u + 1 - t_begin) & (kI8Ring - 1), bf);
         }
-        if (wave_active && t + 1 < t_end) preread((sl + 1) & (kI8Ring - 1), bf);
         MSFM_PROBE(2)
-        if (grp == 1) wait_older_group();
-        lds_barrier();
+        if (grp == 0) next_interval(u + 1);
         MSFM_PROBE(3)
     }
     MSFM_PROBE_END
-    if (grp == 0) lds_barrier();
     if (PASS == 3) flush_candidates();
-    if (PASS == 1 && wave == 0) store_columns(t_end - 1);
 
     if (PASS == 1) {
         // rows: the two largest of a row's 32 lane maxima, transposed through the wave's share of the idle ring
         // ([32 rows][32 lanes + 1] ints; see sweep_kernel): lane l < 32 reduces row l of the wave
         wait_vmcnt<0>();   // the tail's DMA groups still write into the ring ...
-        lds_barrier();     // ... everybody's have landed
+        lds_barrier();     // ... everybody's have landed, and the odd group's last epilogue has folded its columns
+        if (wave == 0) store_columns(t_end - 1);
         int* tr = reinterpret_cast<int*>(sB) + wave * (kI8WaveRows * 33);
         static_assert(kI8Waves * kI8WaveRows * 33 * 4 <= kI8Ring * kI8TileBytes, "the transposition fits the ring");
 #pragma unroll

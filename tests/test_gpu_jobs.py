@@ -121,10 +121,10 @@ def test_config2_full_job_one_launch(gpu_ctx, oracle):
     finally:
         gpu_ctx.set_pipeline(0)
     assert p["sub_batches"] == 1 and p["approx_kernel_launches"] == 1      # ONE launch per sweep for the whole job
-    # the default: the job cut into 4 sub-batches on two streams (the tail of one under the next one's sweep 1) == the same lists
+    # the default: the job cut into 6 shrinking sub-batches, three in flight (tails under the other sub-batches' sweeps) == the same lists
     piped = gpu_ctx.match_pairs(pairs)
     pp_ = gpu_ctx.profile()
-    assert pp_["sub_batches"] == 4 and pp_["approx_kernel_launches"] == 4 and pp_["prefilter_pairs"] == 8128
+    assert pp_["sub_batches"] == 6 and pp_["approx_kernel_launches"] == 6 and pp_["prefilter_pairs"] == 8128
     assert pp_["descriptor_pairs"] == p["descriptor_pairs"] and pp_["order_sensitive_rows"] == p["order_sensitive_rows"]
     assert same_result((offs, qt, d), piped)
     assert p["prefilter_pairs"] == 8128 and p["fallback_pairs"] == 0 and p["compacted_pairs"] > 7000
@@ -316,7 +316,7 @@ def test_plan_regrow_with_sub_batches_in_flight(oracle, twins):
         with _lib.Context(0) as ctx:
             for i, im in enumerate(imgs):
                 ctx.upload_image(i, im)
-            ctx.set_limits(4, 0)                         # 15 pairs -> 4 sub-batches, two in flight
+            ctx.set_limits(4, 0)                         # 15 pairs -> 4 sub-batches, three in flight
             got = ctx.match_pairs(pairs, **kw)
             p = ctx.profile()
             assert p["sub_batches"] == 4 and p["prefilter_pairs"] == len(pairs)

@@ -1,6 +1,7 @@
 """Route Q: float stores whose values lie in [0, 1] (RootSIFT) get byte twins, their FIRST sweep runs on the integer matrix
-cores, an fp16 sweep 1' refines the ~6 % of rows that survive (csrc/msfm_q8.hip.h).  It must return the same bits as
-the fp16 route, the brute-force route and the oracle -- the reference computes every pair with cv::BFMatcher
+cores (csrc/msfm_q8.hip.h).  Fine twins (values up to 0.625: scale >= 408) give the thresholds of sweep 2 directly; coarse
+ones get an fp16 sweep 1' of the ~6 % of rows that survive first.  Either way it must return the same bits as the fp16
+route, the brute-force route and the oracle -- the reference computes every pair with cv::BFMatcher
 (/root/reference/src/Feature/FeatureUtils.cpp:141-174), there is no approximation to hide behind."""
 import numpy as np
 import pytest
@@ -32,17 +33,19 @@ def check_vs_oracle(oracle, imgs, pairs, sel, res, **kw):
     return int(o_offs[-1])
 
 
-def test_route_q_equals_the_fp16_route_brute_force_and_the_oracle(gpu_ctx, oracle):
+def test_route_q_equals_the_fp16_route_brute_force_and_the_oracle(gpu_ctx, oracle, monkeypatch):
     imgs, pairs, _ = synth.job("south-building", 20, seed=77)         # 190 pairs of ~5000-row images: route Q by default
+    gpu_ctx.clear_images()                                             # (the session's context: start from an empty store, level 0)
     for i, im in enumerate(imgs):
         gpu_ctx.upload_image(i, im)
     try:
         gpu_ctx.set_prefilter(1)
         q = gpu_ctx.match_pairs(pairs)
         pq = gpu_ctx.profile()
-        assert pq["sweep1_q8_launches"] >= 1 and pq["sweep1b_launches"] == pq["sweep1_q8_launches"] == pq["sweep1_i8_launches"]
+        # values up to ~0.42 -> level 0.4375, scale 583: thresholds straight from the twins' sweep, no sweep 1'
+        assert pq["sweep1_q8_launches"] >= 1 and pq["sweep1b_launches"] == 0 and pq["sweep1_q8_launches"] == pq["sweep1_i8_launches"]
         assert pq["prefilter_pairs"] == len(pairs) and pq["fallback_pairs"] == 0
-        assert 0 < pq["sweep1b_descriptor_pairs"] < 0.4 * pq["prefilter_descriptor_pairs"]      # only survivors see fp16
+        assert 0 < pq["sweep2_descriptor_pairs"] < 0.4 * pq["prefilter_descriptor_pairs"]       # only survivors see fp16
         assert q[0][-1] > 20000
         gpu_ctx.set_prefilter(2)                                           # fp16 matrix cores for every image
         f = gpu_ctx.match_pairs(pairs)
@@ -75,6 +78,58 @@ def test_route_q_equals_the_fp16_route_brute_force_and_the_oracle(gpu_ctx, oracl
         gpu_ctx.set_pipeline(0)
     sel = np.sort(np.random.default_rng(9).choice(len(pairs), 24, replace=False))
     assert check_vs_oracle(oracle, imgs, pairs, sel, q) > 24 * 50
+    # the same job with the refinement sweep forced (what a store with values near 1 takes): same bits
+    monkeypatch.setenv("MSFM_Q8_DIRECT", "0")
+    with _lib.Context(0) as ctx:
+        for i, im in enumerate(imgs):
+            ctx.upload_image(i, im)
+        r = ctx.match_pairs(pairs)
+        pr = ctx.profile()
+        assert pr["sweep1_q8_launches"] >= 1 and pr["sweep1b_launches"] == pr["sweep1_q8_launches"]
+        assert 0 < pr["sweep1b_descriptor_pairs"] < 0.4 * pr["prefilter_descriptor_pairs"]
+        assert same(q, r)
+        assert pr["candidates"] < pq["candidates"]             # (the refined thresholds are the tighter ones)
+
+
+def test_twin_level_follows_the_store(gpu_ctx):
+    """The context quantises with one scale 255 / m, m = the largest twinned value so far rounded up to 1/16.  An upload that
+    raises m makes the older twins stale: they are rebuilt at the next matching call (and past m = 0.625 the batch goes
+    through the refinement sweep).  Same bits throughout; msfm_clear_images starts over."""
+    imgs = synth.rootsift_images(5, [2600, 2300, 2500, 2400, 2200], seed=15, n_proto=6000)
+    pairs = synth.all_pairs(5)
+    gpu_ctx.clear_images()
+    try:
+        gpu_ctx.set_prefilter(2)
+        for i, im in enumerate(imgs):
+            gpu_ctx.upload_image(i, im)
+        ref = gpu_ctx.match_pairs(pairs)
+        gpu_ctx.set_prefilter(1)
+        got = gpu_ctx.match_pairs(pairs)
+        p = gpu_ctx.profile()
+        assert p["sweep1_q8_launches"] >= 1 and p["sweep1b_launches"] == 0 and same(got, ref)
+        # image 4 again with one large value (a legal RootSIFT row: the rest of that row shrinks): level 0.9375
+        big = imgs[4].copy()
+        big[7] *= F32(0.35)
+        big[7, 3] = F32(0.93)
+        gpu_ctx.upload_image(4, big)
+        gpu_ctx.set_prefilter(2)
+        ref2 = gpu_ctx.match_pairs(pairs)
+        gpu_ctx.set_prefilter(1)
+        got2 = gpu_ctx.match_pairs(pairs)               # twins 0..3 are rebuilt at the new level here
+        p = gpu_ctx.profile()
+        assert p["sweep1_q8_launches"] >= 1 and p["sweep1b_launches"] == p["sweep1_q8_launches"] and same(got2, ref2)
+        sub = pairs[:3]                                   # pairs of the old images only: still the store's (coarse) level
+        got3 = gpu_ctx.match_pairs(sub)
+        assert gpu_ctx.profile()["sweep1b_launches"] >= 1
+        assert np.array_equal(got3[1], ref[1][:ref[0][3]])
+        gpu_ctx.clear_images()
+        for i, im in enumerate(imgs):
+            gpu_ctx.upload_image(i, im)
+        got4 = gpu_ctx.match_pairs(pairs)
+        assert gpu_ctx.profile()["sweep1b_launches"] == 0 and same(got4, ref)
+    finally:
+        gpu_ctx.set_prefilter(True)
+        gpu_ctx.clear_images()
 
 
 def test_twins_only_for_values_in_the_unit_interval(gpu_ctx):
@@ -109,10 +164,13 @@ def test_twins_only_for_values_in_the_unit_interval(gpu_ctx):
         gpu_ctx.set_prefilter(True)
 
 
-def test_route_q_on_small_ragged_and_degenerate_images(oracle, monkeypatch):
+@pytest.mark.parametrize("direct", ["1", "2"])
+def test_route_q_on_small_ragged_and_degenerate_images(oracle, monkeypatch, direct):
     """MSFM_Q8=2 lifts the 'real images only' limit: images below one wave, one 512-row block, ragged sizes, near-duplicate
-    swarms (tight thresholds), rows of exact zeros and ones (quantise without error)."""
+    swarms (tight thresholds), rows of exact zeros and ones (quantise without error; level 1: the refinement sweep unless
+    MSFM_Q8_DIRECT=2 forces the direct thresholds onto the coarse twins)."""
     monkeypatch.setenv("MSFM_Q8", "2")
+    monkeypatch.setenv("MSFM_Q8_DIRECT", direct)
     rng = np.random.default_rng(11)
     sizes = [3, 64, 65, 511, 512, 513, 700, 1300, 40, 2]
     imgs = synth.rootsift_images(len(sizes), sizes, seed=31, n_proto=900)
@@ -135,7 +193,7 @@ def test_route_q_on_small_ragged_and_degenerate_images(oracle, monkeypatch):
             ctx.upload_image(i, im)
         q = ctx.match_pairs(pairs)
         p = ctx.profile()
-        assert p["sweep1_q8_launches"] >= 1 and p["sweep1b_launches"] >= 1
+        assert p["sweep1_q8_launches"] >= 1 and (p["sweep1b_launches"] >= 1) == (direct == "1")
         ctx.set_prefilter(2)
         f = ctx.match_pairs(pairs)
         assert ctx.profile()["sweep1_q8_launches"] == 0

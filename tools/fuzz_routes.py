@@ -1,5 +1,6 @@
 """Long seeded fuzz: the prefilter routes (fp16 matrix cores; integer matrix cores for byte uploads; route Q = byte twins of
-float images in [0, 1] -- run with MSFM_Q8=2 in the environment so that the small images of the fuzz take it too) against
+float images in [0, 1] -- run with MSFM_Q8=2 in the environment so that the small images of the fuzz take it too; fine twins
+give sweep 2 its thresholds directly, coarse ones go through the fp16 sweep 1', MSFM_Q8_DIRECT=2 / =0 forces one of them) against
 the brute-force route (match lists and knnMatch-level arrays) over random sizes, value types, scales, duplicates, NaNs,
 parameters and orders.  Usage: [MSFM_Q8=2] python tools/fuzz_routes.py [seed] [cases]"""
 import sys, numpy as np
@@ -12,6 +13,7 @@ rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 7)
 bad = 0
 n_i8 = 0
 n_q8 = 0
+n_direct = 0
 for case in range(int(sys.argv[2]) if len(sys.argv) > 2 else 1500):
     n_img = int(rng.integers(2, 6))
     sizes = [int(rng.choice([1, 2, 3, 7, 31, 60, 64, 65, 130, 255, 256, 257, 600, 1100, 1700, 2600])) for _ in range(n_img)]
@@ -43,11 +45,13 @@ for case in range(int(sys.argv[2]) if len(sys.argv) > 2 else 1500):
     if kind in ("u8", "bytes"):
         md = float(rng.choice([150.0, 400.0, 1e4, np.inf]))
     ctx.set_accum_order(order)
+    ctx.clear_images()          # (the twins' level follows the store: every case starts from an empty one)
     for i, im in enumerate(imgs): ctx.upload_image(i, im)
     pairs = np.array([(i, j) for i in range(n_img) for j in range(n_img) if i != j or rng.random() < 0.2], np.int32)
     got = ctx.match_pairs(pairs, ratio, cc, md)
     n_i8 += ctx.profile()["sweep1_i8_launches"]
     n_q8 += ctx.profile()["sweep1_q8_launches"]
+    n_direct += ctx.profile()["sweep1_q8_launches"] - ctx.profile()["sweep1b_launches"]
     if kind == "bytes" or ctx.profile()["sweep1_q8_launches"]:     # and the fp16 cores on the same data
         ctx.set_prefilter(2)
         got2 = ctx.match_pairs(pairs, ratio, cc, md)
@@ -68,4 +72,5 @@ for case in range(int(sys.argv[2]) if len(sys.argv) > 2 else 1500):
     if not ok:
         bad += 1
         print("MISMATCH", case, kind, sizes, order, ratio, cc, md, flush=True)
-print("cases done, mismatches:", bad, "| integer-core sweep-1 launches:", n_i8, "| of them on byte twins of float images (route Q):", n_q8)
+print("cases done, mismatches:", bad, "| integer-core sweep-1 launches:", n_i8, "| of them on byte twins of float images (route Q):", n_q8,
+      "| of those with direct thresholds (no sweep 1'):", n_direct)

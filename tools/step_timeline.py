@@ -8,10 +8,13 @@ import sys
 db = sqlite3.connect(sys.argv[1])
 per_step = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 rows = db.execute("select name, start, end from kernels order by start").fetchall()
-# sweep 1 of the main (float) job: sweep_kernel<1> on the fp16 route, sweep_i8_kernel<1> followed by sweep_kernel<4> on route Q
+# sweep 1 of the main (float) job: sweep_kernel<1> on the fp16 route, sweep_i8_kernel<1> on route Q (followed by sweep_kernel<4>
+# when the twins are coarse).  Run the bench with --u8-images 0: the byte job's sweeps have the same name.
 idx = [i for i, r in enumerate(rows) if "sweep_kernel<1>" in r[0] and "i8" not in r[0]]
 if len(idx) <= per_step:
     idx = [i for i, r in enumerate(rows) if "sweep_i8_kernel<1>" in r[0] and any("sweep_kernel<4>" in rows[j][0] for j in range(i, min(i + 150, len(rows))))]
+if len(idx) <= per_step:
+    idx = [i for i, r in enumerate(rows) if "sweep_i8_kernel<1>" in r[0]]
 i0, i1 = idx[-1 - per_step], idx[-1]
 t0 = rows[i0][1]
 print("# kernel (or runtime copy / fill kernel)             start ms     end ms   duration us   running at its start")
