@@ -275,24 +275,35 @@ __global__ void pf_assign_kernel(const PairDesc* __restrict__ pairs, const PfPai
         base[threadIdx.x] = (int)threadIdx.x < bits ? mrow[(dir ? pl.rev_member0 : pl.fwd_member) + threadIdx.x] : -1;
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < n; e += blockDim.x) {
-        const float t = tuv[off + e];
-        if (t == -f_inf()) continue;
-        // the reduce kernels only ever touch the slots of live rows / columns (and pf_finalize_kernel reads no others):
-        // "no candidate yet" is written here, for the 6 % that are alive, instead of a memset over every slot of the batch
-        best[off + e] = ~0ull;
-        second[off + e] = ~0ull;
-        unsigned m = dir ? colmask[off + e] : 1u;
-        while (m) {
-            const int b = __builtin_ctz(m);
-            m &= m - 1;
-            const long long r0 = base[b];
-            if (r0 < 0) continue;   // invalid plan
-            const long long k = r0 + atomicAdd(&cursor[b], 1);
-            live_idx[k] = e;
-            row_pair[k] = p;
-            cmp_tu[k] = norms_only ? -nrm[e] : t - nrm[e];
-            row_src[k] = src + (size_t)e * row_halfs;
+    // (four independent threshold loads in flight per thread: ~94 % of the slots are dead and need nothing else)
+    for (int e0 = threadIdx.x; e0 < n; e0 += 4 * blockDim.x) {
+        float t4[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int e = e0 + j * blockDim.x;
+            t4[j] = e < n ? tuv[off + e] : -f_inf();
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int e = e0 + j * blockDim.x;
+            const float t = t4[j];
+            if (t == -f_inf()) continue;
+            // the reduce kernels only ever touch the slots of live rows / columns (and pf_finalize_kernel reads no others):
+            // "no candidate yet" is written here, for the 6 % that are alive, instead of a memset over every slot of the batch
+            best[off + e] = ~0ull;
+            second[off + e] = ~0ull;
+            unsigned m = dir ? colmask[off + e] : 1u;
+            while (m) {
+                const int b = __builtin_ctz(m);
+                m &= m - 1;
+                const long long r0 = base[b];
+                if (r0 < 0) continue;   // invalid plan
+                const long long k = r0 + atomicAdd(&cursor[b], 1);
+                live_idx[k] = e;
+                row_pair[k] = p;
+                cmp_tu[k] = norms_only ? -nrm[e] : t - nrm[e];
+                row_src[k] = src + (size_t)e * row_halfs;
+            }
         }
     }
 }

@@ -124,9 +124,21 @@ __global__ void pf_prune_q8_kernel(const PairDesc* __restrict__ pairs, const PfP
         float s0 = f_inf(), s1 = f_inf();
         const float2* cp2 = reinterpret_cast<const float2*>(cp_s0);
         const int nb = pd.a_blocks256;
-        for (int p = 0; p < nb; ++p) {
-            const float2 m = cp2[pd.cp_off + (long long)p * pd.n2pad + e];
-            v2_merge(s0, s1, -2.f * m.x, -2.f * m.y);
+        // up to 16 blocks (8192 rows) the blocks' minima stay in registers for the mask below: sixteen independent loads in flight
+        float bmin[16];
+        if (nb <= 16) {
+#pragma unroll
+            for (int p = 0; p < 16; ++p) {
+                float2 m = make_float2(-f_inf(), -f_inf());
+                if (p < nb) m = cp2[pd.cp_off + (long long)p * pd.n2pad + e];
+                bmin[p] = -2.f * m.x;
+                v2_merge(s0, s1, -2.f * m.x, -2.f * m.y);
+            }
+        } else {
+            for (int p = 0; p < nb; ++p) {
+                const float2 m = cp2[pd.cp_off + (long long)p * pd.n2pad + e];
+                v2_merge(s0, s1, -2.f * m.x, -2.f * m.y);
+            }
         }
         bool live = e < pd.n2;
         const float err = live ? (pq.b_err[e] + pq.a_c) * (1.f + 1e-6f) : 0.f;
@@ -141,11 +153,18 @@ __global__ void pf_prune_q8_kernel(const PairDesc* __restrict__ pairs, const PfP
             // lower(block minimum), a candidate is at most U1 away
             const float u1 = live ? upper(s1, err) : 0.f;
             tuv[pp.tv_off + e] = live ? threshold(u1, pp.b_nrm[e], pp.a_nrm_max) : -f_inf();
-            if (live)
-                for (int p = 0; p < nb; ++p) {
-                    const float smin = -2.f * cp2[pd.cp_off + (long long)p * pd.n2pad + e].x;
-                    if (lower(smin, err) * (1.f - 1e-5f) <= u1 * (1.f + 1e-5f)) col_bits |= 1u << (p / g);
+            if (live) {
+                if (nb <= 16) {
+#pragma unroll
+                    for (int p = 0; p < 16; ++p)
+                        if (p < nb && lower(bmin[p], err) * (1.f - 1e-5f) <= u1 * (1.f + 1e-5f)) col_bits |= 1u << p;   // (g = 1)
+                } else {
+                    for (int p = 0; p < nb; ++p) {
+                        const float smin = -2.f * cp2[pd.cp_off + (long long)p * pd.n2pad + e].x;
+                        if (lower(smin, err) * (1.f - 1e-5f) <= u1 * (1.f + 1e-5f)) col_bits |= 1u << (p / g);
+                    }
                 }
+            }
         }
         colmask[pp.tv_off + e] = col_bits;
     }

@@ -171,9 +171,15 @@ __global__ __launch_bounds__(kI8Threads) void sweep_i8_kernel(
         if (!dma_wave) return;
         const int tc = tt < t_end ? tt : t_end - 1;
         const int sl = (tt - t_begin) & (kI8Ring - 1);
-        const unsigned off = (unsigned)tc * (unsigned)kI8TileBytes + lane_off;
-        char* l = sB + sl * kI8TileBytes + wave * 1024;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gB + off), (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+        // the tile's offset goes into the SCALAR base, the lane's 32-bit offset is the same register for the whole item: no VALU
+        // instruction per tile (hipcc's own lowering of the builtin adds the two in a VGPR pair).  M0 = the wave's LDS destination.
+        const unsigned long long tile = (unsigned long long)gB + (unsigned long long)(unsigned)tc * (unsigned long long)kI8TileBytes;
+        const unsigned dst = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)(sB + sl * kI8TileBytes + wave * 1024);
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"   // (m0 is a reserved register: naming it as a clobber is the point)
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                     :: "v"(lane_off), "s"(tile), "s"(dst) : "memory", "m0");
+#pragma clang diagnostic pop
     };
     // One load per group and DMA wave.  At either wait the wave has issued the groups up to tile u + kI8Ring - 3 and needs
     // tile u: "at most kI8Ring - 3 outstanding" = tile u has landed (loads retire in order; see sweep_kernel).
@@ -258,7 +264,9 @@ __global__ __launch_bounds__(kI8Threads) void sweep_i8_kernel(
         n_buf = 0;
     };
 
-    const bool wave_active = item.a_blk * kPfWgRows + wave * kI8WaveRows < pd.n1;
+    // (readfirstlane: the compiler otherwise carries this wave-uniform flag as a lane mask and spends two VALU instructions per
+    // tile on rebuilding it -- under a busy matrix pipe a VALU instruction costs ~8 ns of SIMD time)
+    const bool wave_active = __builtin_amdgcn_readfirstlane((int)(item.a_blk * kPfWgRows + wave * kI8WaveRows < pd.n1)) != 0;
 
     // B fragments.  The two column blocks of a tile are two independent accumulator chains (a single dependent MFMA
     // chain runs at 3/4 of the rate, profiles/r01_ubench_mfma_chains.txt), so a k-step needs BOTH blocks' fragments:
