@@ -176,6 +176,8 @@ def main():
     ap.add_argument("--sustained-steps", type=int, default=200,
                     help="extra untimed-for-`value` run of this many steps after the K timed ones -> sustained_ms_per_step "
                          "(the part's clock is set by a power budget: a 1 s burst and a 10 s run differ); 0 = skip")
+    ap.add_argument("--no-solo", action="store_true",
+                    help="skip the 4 extra steps with the pipeline off that measure the sweeps alone (roofline.solo); for kernel traces")
     args = ap.parse_args()
 
     import torch
@@ -273,7 +275,7 @@ def main():
         # after everything timed: the sweeps ALONE (one sub-batch per step, nothing in flight beside them) -- in the timed
         # region the other sub-batches' bandwidth-bound tails run beside a sweep and stretch its event span
         run_job.solo = None
-        if collect is not None and not args.no_prefilter and os.environ.get("MSFM_PIPELINE") is None:
+        if collect is not None and not args.no_prefilter and not args.no_solo and os.environ.get("MSFM_PIPELINE") is None:
             ctx.set_pipeline(1)
             solo = {"approx_kernel_ms": 0.0, "approx_kernel_launches": 0, "sweep2_ms": 0.0, "prefilter_descriptor_pairs": 0, "wall_ms": 0.0}
             try:

@@ -271,7 +271,8 @@ __global__ __launch_bounds__(kPfThreads, 2) void sweep_kernel(
         n_buf = 0;
     };
 
-    const bool wave_active = item.a_blk * kPfWgRows + wave * kPfWaveRows < pd.n1;  // wave-uniform
+    // (wave-uniform; readfirstlane keeps it in a scalar register -- as a lane mask it costs two VALU instructions per tile)
+    const bool wave_active = __builtin_amdgcn_readfirstlane((int)(item.a_blk * kPfWgRows + wave * kPfWaveRows < pd.n1)) != 0;
 
     // B fragments of the tile in ring slot sl: the 8 data k-steps of column block 0 (row lcol of the slot, granule
     // 2 ks + lhalf: a constant offset from the lane's row address), and the ninth k-step of BOTH column blocks -- the first

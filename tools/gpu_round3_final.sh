@@ -3,12 +3,17 @@
 set -u
 ROOT=$(pwd); OUT=$ROOT/gpurun_out; mkdir -p $OUT
 timeout 1200 python -m pytest tests -m gpu -q > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -4 $OUT/pytest_gpu.log
+MSFM_Q8=2 timeout 600 python tools/fuzz_routes.py 601 1000 > $OUT/fuzz_q8.txt 2>&1; echo "fuzz q8 rc=$?"; tail -1 $OUT/fuzz_q8.txt
+MSFM_Q8=2 MSFM_Q8_DIRECT=2 timeout 600 python tools/fuzz_routes.py 602 600 > $OUT/fuzz_q8_direct.txt 2>&1; echo "fuzz q8 direct rc=$?"; tail -1 $OUT/fuzz_q8_direct.txt
+MSFM_Q8=2 MSFM_Q8_DIRECT=0 timeout 600 python tools/fuzz_routes.py 603 400 > $OUT/fuzz_q8_refine.txt 2>&1; echo "fuzz q8 refine rc=$?"; tail -1 $OUT/fuzz_q8_refine.txt
+timeout 600 python tools/fuzz_routes.py 604 1000 > $OUT/fuzz_default.txt 2>&1; echo "fuzz rc=$?"; tail -1 $OUT/fuzz_default.txt
+timeout 600 python tools/fuzz_oracle.py 605 300 > $OUT/fuzz_oracle.txt 2>&1; echo "fuzz oracle rc=$?"; tail -1 $OUT/fuzz_oracle.txt
 timeout 300 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"; tail -c 300 $OUT/bench.json
 MSFM_Q8_DIRECT=0 timeout 300 python bench.py --no-cpu-baseline --sustained-steps 0 --u8-images 0 > $OUT/bench_refine.json 2> $OUT/bench_refine.err; echo "bench refine rc=$?"
 MSFM_Q8=0 timeout 300 python bench.py --no-cpu-baseline --sustained-steps 0 --u8-images 0 > $OUT/bench_fp16_route.json 2> $OUT/bench_fp16.err; echo "bench fp16 rc=$?"
 export TMPDIR=/tmp
-BENCH="python $ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline --sustained-steps 0 --u8-images 0"
-FULL="python $ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline --sustained-steps 0"
+BENCH="python $ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline --sustained-steps 0 --u8-images 0 --no-solo"
+FULL="python $ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline --sustained-steps 0 --no-solo"
 cd /tmp
 rm -rf $OUT/prof_stats $OUT/prof_stats_p1 $OUT/prof_stats_full $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq
 timeout 400 rocprofv3 --kernel-trace --stats -d $OUT/prof_stats -- $BENCH > $OUT/prof_stats.log 2>&1; echo "stats rc=$?"
