@@ -112,7 +112,7 @@ struct Image {
     float* nrm_i8 = nullptr;
     float nrm_i8_max = 0.f;
     int h0_i8 = 0;            // centre of the rows' h = floor(|x - 128|^2 / 2): the digit k-step carries H0 - h
-    // route Q (msfm_q8.hip.h): the byte twin q = rint(255 x) of a FLOAT image whose values all lie in [0, 1] -- operand rows,
+    // route Q (msfm_q8.hip.h): the byte twin q = rint(x 255 / m) of a FLOAT image whose values all lie in [0, 1] -- operand rows,
     // norms 2h and centre as for a byte image, plus the rows' quantisation error norms and their maximum
     signed char* q8 = nullptr;
     float* nrm_q8 = nullptr;

@@ -3,31 +3,38 @@
 // v_mfma_i32_32x32x32_i8 sustains ~2.0 POP/s on this part against ~1.25 PFLOP/s for the fp16 instruction: the integer
 // sweep of msfm_sweep_i8.hip.h does the same 128-term products in 0.62 of the time.  RootSIFT rows are bounded ([0, 1],
 // unit L2 norm: FeatureExtraction's L1-root normalisation, src/Feature/FeatureExtraction.cpp:260-270 of the reference),
-// so every image with all values in [0, 1] gets a BYTE TWIN  q = rint(255 x)  next to its fp16 operand rows, stored
-// exactly like a byte image (signed rows of 176 B with the norm digits).  The integer sweep on the twins yields, per
-// row, the exact integer S^ = |q_a - q_b|^2 of the two nearest twins (up to the parity bits: eps = 2, msfm_sweep_i8).
+// so every image with all values in [0, 1] gets a BYTE TWIN  q = rint(s x),  s = 255 / m (m: the largest value of the context's
+// twinned images, rounded up to 1/16 -- below), next to its fp16 operand rows, stored exactly like a byte image (signed rows of
+// 176 B with the norm digits).  The integer sweep on the twins yields, per row, the exact integer S^ = |q_a - q_b|^2 of the two
+// nearest twins (up to the parity bits: eps = 2, msfm_sweep_i8).
 //
-// What the twins prove.  With a^ = q_a / 255, e_a = |a - a^|_2 (computed per row at upload, rounded up) and d^ = |a^ - b^|:
+// What the twins prove.  With a^ = q_a inv (inv ~ 1 / s: the float itself), e_a = |a - a^|_2 (computed per row at upload, rounded
+// up) and d^ = |a^ - b^|:
 //        | |a - b| - d^ |  <=  e_a + e_b                         (triangle inequality, real arithmetic)
 // so per row q of image 1, with E_2 = max_t e_t:
-//        d0  >=  L0 = sqrt(S^min) / 255 - (e_q + E_2)            (S^min = smallest S^: S~ <= S^ <= S~ + 2)
-//        d1  <=  U1 = sqrt(S^(2) + 2) / 255 + (e_q + E_2)        (S^(2): an upper bound of the second smallest)
+//        d0  >=  L0 = sqrt(S^min) inv - (e_q + E_2)              (S^min = smallest S^: S~ <= S^ <= S~ + 2)
+//        d1  <=  U1 = sqrt(S^(2) + 2) inv + (e_q + E_2)          (S^(2): an upper bound of the second smallest)
 // If L0 >= ratio * U1 the Lowe test fails whatever the exact bits are, if L0 > max_distance the distance cut removes
 // the row: it is DEAD, exactly as for the fp16 bounds of pf_thresholds_kernel (the pinned fp32 order is within 4e-6
 // relative of the real distance, msfm_kernels.hip.h: a factor 1 +- 1e-5 covers it).  On the bench data the same 6 % of the
-// rows stay alive as under the fp16 bound (tools/int8_prefilter_study.py) -- but the twin thresholds are too loose to
-// collect candidates with (28 per live row instead of 2.5).  So the live rows alone get an fp16 sweep 1:
+// rows stay alive as under the fp16 bound (tools/int8_prefilter_study.py).
 //
+// FINE twins (m <= 0.625, i.e. RootSIFT: s ~ 580, e ~ 0.0056) -- the thresholds of sweep 2 come straight from the twins:
 //   sweep 1     sweep_i8_kernel<1> on the twins, every descriptor pair of the batch               (the dominant kernel)
-//   prune       pf_prune_q8_kernel: live / dead per row and column, live counts for plan A
+//   prune       pf_prune_q8_kernel(direct): live / dead, T = U1^2 + eps_fp16 per live row / column, the block masks of the
+//               reverse direction from the twins' per-block column minima, the live counts of the plan
+//   plan, sweep 2 (fp16), exact re-check, ...   as on the fp16 route.  4.9 candidates per live row instead of 2.5, mask density
+//               0.50 instead of 0.24 -- and no sweep 1' (12 candidates per live row at s = 255: hence the adaptive scale).
+// COARSE twins (values beyond 0.625; MSFM_Q8_DIRECT=0 forces it) -- the live rows get an fp16 sweep 1 of their own first:
+//   sweep 1, prune (live / dead only)
 //   plan A      the compacted-sweep plan (msfm_plan.hip.h) with every live column in EVERY 512-row block group
 //   sweep 1'    sweep_kernel<4>: fp16 S~ top-2 of every compacted live row over its group's tiles  (~13 % of sweep 1's work)
 //   scatter     q8_scatter_kernel: those top-2 into the partial arrays pf_thresholds_kernel reads (rows: one range;
 //               columns: one entry per block group = the per-block minima the block mask needs)
 //   thresholds  pf_thresholds_kernel, unchanged but for skipping what the prune kernel marked dead
 //   plan B, sweep 2, exact re-check, ...   as on the fp16 route.
-// The candidate sets, and with them every bit of the result, are those of the fp16 route restricted to rows that are
-// provably dead anyway.
+// The candidate sets contain those of the fp16 route restricted to rows that are provably dead anyway: every bit of the result
+// is the same.
 #pragma once
 // (included inside namespace msfm)
 
