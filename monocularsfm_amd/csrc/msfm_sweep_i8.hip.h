@@ -1,5 +1,6 @@
 // msfm_sweep_i8.hip.h -- the sweeps of the prefilter path on the INTEGER matrix cores, for stores whose descriptors are
-// bytes (`descriptors_u8` side table / MSFM_DTYPE_U8 uploads).  Included by msfm_prefilter.hip.h after msfm_sweep.hip.h.
+// bytes (`descriptors_u8` side table / MSFM_DTYPE_U8 uploads / float uploads holding only integers 0..255) and, sweep 1 only,
+// for the byte twins of float stores (msfm_q8.hip.h).  Included by msfm_prefilter.hip.h after msfm_sweep.hip.h.
 //
 // A byte descriptor x (0..255) is stored as the signed byte x' = x - 128 (= x ^ 0x80): the distance is shift invariant,
 // |a - b|^2 = |a' - b'|^2 = n'_a + n'_b - 2 a'.b' with n' = |x'|^2 <= 2^21, and v_mfma_i32_32x32x32_i8 computes a'.b'
@@ -7,7 +8,8 @@
 //
 //        acc = a'.b' - h_a - h_b        ->   S~ = -2 acc = S - (n'_a & 1) - (n'_b & 1),   |S~ - S| <= 2 =: eps
 //
-// is built WITHOUT a VALU instruction (every VALU instruction is SIMD time here): both norms ride in a
+// is built WITHOUT a VALU instruction (a VALU instruction beside busy matrix pipes costs ~8 ns of SIMD time, DESIGN.md 5.1.3:
+// profiles/r03_ubench_coissue.txt): both norms ride in a
 // FIFTH k-step of 32 slots.  Every row carries, behind its 128 operand bytes, 16 signed DIGITS d of V = H0 - h (H0 = its
 // image's centre of h) and the 16 CONSTANTS c = [1, -128 x 15]:  sum c_k d_k = d_0 - 128 (d_1 + ... + d_15) represents
 // every integer in [-243 968, 245 759] -- an image whose h values spread further than that around their centre (they
@@ -29,9 +31,10 @@
 // exact integer arithmetic (every partial sum is an integer below 2^24; oracle/int_oracle.py pins that), so eps = 2
 // instead of ~1.5e-3 (n_a + n_b) ~ 1000: fewer candidates, and half the matrix time.
 //
-// Same program as sweep_kernel (msfm_sweep.hip.h): MFMA / EPI ping-pong between waves of a SIMD, LDS ring filled by
-// LDS-DMA, counted vmcnt waits, persistent workgroups.  PASS 1 and PASS 3 only: the dense sweep 2 (kNN-level API,
-// ratio > 0.95) stays on the fp16 kernel.
+// Same ingredients as sweep_kernel (msfm_sweep.hip.h): matrix halves and epilogue halves of different waves of a SIMD side by
+// side, LDS ring filled by LDS-DMA, counted vmcnt waits, persistent workgroups -- but ONE workgroup barrier per tile (round 3;
+// the tile loop below says how the two groups of waves are skewed around it).  PASS 1 and PASS 3 only: the dense sweep 2
+// (kNN-level API, ratio > 0.95) stays on the fp16 kernel.
 #pragma once
 // (included inside namespace msfm)
 
@@ -41,12 +44,12 @@ constexpr int kI8DigitLo = -243968, kI8DigitHi = 245759;   // representable H0 -
 // SIXTEEN waves of 32 rows (four per SIMD): on the integer cores a tile's matrix phase is 16 x 34 cycles per SIMD, and one
 // wave issues a VALU instruction every 8 cycles at best -- with two 64-row waves per SIMD the ~130 VALU instructions per
 // tile and wave set the pace (profiles/r02_i8_sweep_ablation.txt); four 32-row waves give the epilogue twice the issue slots
-// per matrix slot.  Waves w, w+4, w+8, w+12 share a SIMD; the ping-pong halves are (w >> 2) & 1.
+// per matrix slot.  Waves w, w+4, w+8, w+12 share a SIMD; the two groups of the tile loop are (w >> 2) & 1.
 constexpr int kI8Waves = 16;
 constexpr int kI8Threads = 64 * kI8Waves;
 constexpr int kI8WaveRows = kPfWgRows / kI8Waves;       // 32: one MFMA row block per wave
-// Ring of EIGHT 11-KiB tiles, DMA seven tiles ahead: a phase is ~600 cycles here, so the three-tile lead of the fp16
-// kernel (1.6 us there) would be 0.75 us -- less than an L2 miss.
+// Ring of EIGHT 11-KiB tiles, DMA seven tiles ahead: a tile takes ~1 us here, so the three-tile lead of the fp16
+// kernel (1.6 us per tile there) would leave little more than an L2 miss.
 constexpr int kI8Ring = 8;
 constexpr int kI8LdsBytes = kI8Ring * kI8TileBytes + kI8Waves * kPfCandBuf * 8 + 4 * kPfBT * kPfColClasses * 4;
 static_assert(kI8WaveRows == 32, "one 32-row block per wave");
