@@ -198,6 +198,39 @@ def test_config3_330_images_in_one_call(gpu_ctx, oracle):
     gpu_ctx.clear_images()
 
 
+@pytest.mark.parametrize("in_flight,parts,taper", [("1", "4", "1.0"), ("2", "4", "0.1"), ("3", "3", "1.0"), ("3", "8", "0.05")])
+def test_results_do_not_depend_on_sets_in_flight_parts_or_taper(gpu_ctx, monkeypatch, in_flight, parts, taper):
+    """The cost cut of a large call (msfm_set_pipeline / MSFM_PIPELINE parts, shrinking by MSFM_PIPELINE_TAPER) and the
+    number of scratch sets in flight (MSFM_IN_FLIGHT; with three, sweep 1 of sub-batch k + 2 is ordered behind sweep 2 of k)
+    are scheduling only: same offsets, same rows, same distance bits as the default context -- also with the pair limit
+    forcing further cuts inside the parts, and on the fp16 route."""
+    from monocularsfm_amd import _lib
+    imgs, pairs, _ = synth.job("south-building", 72, seed=4321)        # 2556 pairs, 6.5e10 descriptor pairs: up to 4 parts
+    gpu_ctx.clear_images()
+    for i, im in enumerate(imgs):
+        gpu_ctx.upload_image(i, im)
+    ref = gpu_ctx.match_pairs(pairs)
+    p0 = gpu_ctx.profile()
+    assert p0["sub_batches"] == 4 and p0["prefilter_pairs"] == len(pairs) and ref[0][-1] > 100000
+    gpu_ctx.clear_images()
+    monkeypatch.setenv("MSFM_IN_FLIGHT", in_flight)
+    monkeypatch.setenv("MSFM_PIPELINE", parts)
+    monkeypatch.setenv("MSFM_PIPELINE_TAPER", taper)
+    with _lib.Context(0) as ctx:
+        for i, im in enumerate(imgs):
+            ctx.upload_image(i, im)
+        got = ctx.match_pairs(pairs)
+        p = ctx.profile()
+        assert same_result(ref, got)
+        assert p["sub_batches"] == min(int(parts), 4) and p["order_sensitive_rows"] == p0["order_sensitive_rows"]
+        ctx.set_limits(300, 0)                                         # the pair limit cuts inside the parts
+        got = ctx.match_pairs(pairs)
+        assert same_result(ref, got) and ctx.profile()["sub_batches"] >= 9
+        ctx.set_limits(0, 0)
+        ctx.set_prefilter(2)                                           # fp16 route, same schedule
+        assert same_result(ref, ctx.match_pairs(pairs))
+
+
 # ---- (d) integer descriptors vs the exact-integer reference -----------------------------------------------------
 
 @pytest.mark.parametrize("prefilter", [True, False])
