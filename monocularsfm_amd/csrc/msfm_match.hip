@@ -1034,7 +1034,8 @@ int finish_prefilter(msfm_ctx* ctx, Batch& b, std::vector<char>& force_exact, bo
         unsigned long long pr[16][16];
         if (which == 0) HIPCHK(ctx, hipMemcpyFromSymbol(pr, HIP_SYMBOL(g_sweep_probe), sizeof(pr)));
         else HIPCHK(ctx, hipMemcpyFromSymbol(pr, HIP_SYMBOL(g_sweep_probe3), sizeof(pr)));
-        for (int w = 0; w < (pe.i8 ? 16 : kPfWaves); w += (pe.i8 ? 1 : 3)) {
+        const bool sixteen = pr[8][5] != 0;   // (the integer-core kernels run sixteen waves)
+        for (int w = 0; w < (sixteen ? 16 : kPfWaves); w += (sixteen ? 1 : 3)) {
             const double n = (double)std::max<unsigned long long>(1, pr[w][4]);
             const double it_n = (double)std::max<unsigned long long>(1, pr[w][5]);
             std::fprintf(stderr, "[sweep %d probe] wave %d: MFMA %.0f | wait+barrier %.0f | EPI %.0f | wait+barrier %.0f cycles per tile (%.0f tiles, %llu items); per item: %.0f cycles in the loop, %.0f outside it (descriptor fetch, A loads, first DMA, row merge)\n",

@@ -151,6 +151,7 @@ __global__ __launch_bounds__(kI8Threads) void sweep_i8_kernel(
         it = s_next_item * 8 + (int)(blockIdx.x & 7);
     }
     if (it >= n_items) break;
+    MSFM_PROBE_ITEM_BEGIN
     const WorkItem item = items[it];
     if (item.pair < 0) continue;
     const PfPair pp = pf[item.pair];
@@ -159,6 +160,7 @@ __global__ __launch_bounds__(kI8Threads) void sweep_i8_kernel(
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    MSFM_PROBE_SEG(8)
     const int grp = (wave >> 2) & 1;    // 0: MFMA in the even phases, 1: in the odd ones; two waves of each on every SIMD
     const int lcol = lane & 31, lhalf = lane >> 5;
 
@@ -172,7 +174,11 @@ __global__ __launch_bounds__(kI8Threads) void sweep_i8_kernel(
     const unsigned lane_off = (unsigned)(wave * 1024 + lane * 16);
     auto dma_tile = [&](int tt) {
         if (!dma_wave) return;
+#ifdef MSFM_EXPERIMENT_SAME_TILE   // timing experiment only (wrong results): every DMA group re-reads the item's first tile
+        const int tc = t_begin;
+#else
         const int tc = tt < t_end ? tt : t_end - 1;
+#endif
         const int sl = (tt - t_begin) & (kI8Ring - 1);
         // the tile's offset goes into the SCALAR base, the lane's 32-bit offset is the same register for the whole item: no VALU
         // instruction per tile (hipcc's own lowering of the builtin adds the two in a VGPR pair).  M0 = the wave's LDS destination.
@@ -252,6 +258,7 @@ __global__ __launch_bounds__(kI8Threads) void sweep_i8_kernel(
     asm volatile("" ::"v"(a_digit));
     if (PASS == 3) asm volatile("" ::"v"(rowc));
     wait_vmcnt<0>();
+    MSFM_PROBE_SEG(9)
 
     int2* cbuf = reinterpret_cast<int2*>(sCand) + wave * kPfCandBuf;
     const unsigned cbuf_lds = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)cbuf;
@@ -357,6 +364,7 @@ __global__ __launch_bounds__(kI8Threads) void sweep_i8_kernel(
     dma_tile(t_begin + kI8Ring - 1);   // the first interval's DMA group
     i4v bf[2][2];
     if (wave_active) preread(0, bf);
+    MSFM_PROBE_SEG(10)
 
     i16v accA, accB;
     // the matrix half of a tile: 10 MFMA, k-steps 2, 3 and the digits read from LDS behind the MFMA pairs that free their registers
@@ -439,7 +447,11 @@ __global__ __launch_bounds__(kI8Threads) void sweep_i8_kernel(
     //   at the start of interval t + 2 by one wave: four slots.
     auto next_interval = [&](int v) {
         wait_older_group();
+#ifdef MSFM_EXPERIMENT_NO_BARRIER   // timing experiment only (races: wrong results): what do the per-tile barriers cost?
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#else
         lds_barrier();
+#endif
         dma_tile(v + kI8Ring - 1);
         if (PASS == 1 && v - 2 >= t_begin && wave == ((v - t_begin) & 3)) store_columns(v - 2);
     };
@@ -459,6 +471,7 @@ __global__ __launch_bounds__(kI8Threads) void sweep_i8_kernel(
         MSFM_PROBE(3)
     }
     MSFM_PROBE_END
+    MSFM_PROBE_SEG(11)
     if (PASS == 3) flush_candidates();
 
     if (PASS == 1) {
@@ -485,5 +498,7 @@ __global__ __launch_bounds__(kI8Threads) void sweep_i8_kernel(
             rp_s1[o] = m1 > kI8PadTest ? (float)(-2 * (m1 - item_k)) : f_inf();
         }
     }
+    MSFM_PROBE_SEG(13)
+    MSFM_PROBE_ITEM_END
     }   // item loop
 }
