@@ -375,12 +375,12 @@ def main():
             "avg_launch_ms": avg_ms, "launches": pf_launches, "flops_per_desc_pair": 256.0,
             "descriptor_pairs_per_launch": pf_pairs_work / pf_launches,
             "algorithmic_bytes_per_launch": algo_bytes_step * args.steps / pf_launches,
-            # (event spans: with two sub-batches in flight a sweep-2 / sweep-1' launch waits for the other stream's sweep 1 --
+            # (event spans: with sub-batches in flight a sweep-2 launch waits for another stream's sweep 1 --
             # that wait is inside its span; profiles/rNN_route_q_kernel_stats_pipeline1.txt has the unpipelined kernel times)
             "sweep2": {"ms_per_step": acc["sweep2_ms"] / args.steps, "launches": acc["sweep2_launches"],
                        "compacted_image_pairs": acc["compacted_pairs"] // max(1, args.steps),
                        "work_fraction_of_sweep1": acc["sweep2_descriptor_pairs"] / max(1, pf_pairs_work)},
-            # route Q (float store, byte twins): sweep 1 above runs on the twins; sweep 1' is the fp16 sweep of the rows it left alive
+            # route Q (float store, byte twins): sweep 1 above runs on the twins; sweep 1' (coarse twins only) is the fp16 sweep of the rows it left alive
             "route_q": {"twin_sweep_launches": acc["sweep1_q8_launches"], "sweep1b_ms_per_step": acc["sweep1b_ms"] / args.steps,
                         "sweep1b_work_fraction_of_sweep1": acc["sweep1b_descriptor_pairs"] / max(1, pf_pairs_work)},
             # the same kernel with nothing beside it: 3 further steps with the pipeline off (one launch per sweep), after the timed region

@@ -89,7 +89,8 @@ typedef struct msfm_profile {
     int sweep1_i8_launches;     /* sweep-1 launches on the integer matrix cores (byte stores, msfm_sweep_i8.hip.h) */
     /* route Q: float images with byte twins (all values in [0, 1]) -- sweep 1 on the twins, on the integer matrix cores */
     int sweep1_q8_launches;     /* sweep-1 launches on byte TWINS of float images (counted in sweep1_i8_launches too) */
-    int sweep1b_launches;       /* fp16 sweep 1' launches: the S~ top-2 of the rows the twins' sweep left alive (sweep_kernel<4>) */
+    int sweep1b_launches;       /* fp16 sweep 1' launches (coarse twins only -- values beyond 0.625, or MSFM_Q8_DIRECT=0: the S~ top-2 of the
+                                   rows the twins' sweep left alive, sweep_kernel<4>); 0 when the twins give sweep 2 its thresholds directly */
     double sweep1b_ms;
     int64_t sweep1b_descriptor_pairs; /* descriptor pairs sweep 1' multiplied (padded compacted rows included) */
     int64_t order_sensitive_rows; /* rows / columns of the call WITHOUT an order-invariance certificate (see
@@ -107,8 +108,9 @@ int msfm_set_accum_order(msfm_ctx* ctx, int order);
 /* 1 (default): MFMA prefilter + exact re-check where safe -- byte images (MSFM_DTYPE_U8 uploads, and MSFM_DTYPE_F32
  * uploads whose every value is an integer in [0, 255]: raw OpenCV SIFT stored as CV_32F, recognised on the device at
  * upload; MSFM_BYTE_DETECT=0 at msfm_create: off) on the integer matrix cores (v_mfma_i32_32x32x32_i8); float images whose values all lie in [0, 1] (RootSIFT) get a byte twin at upload and
- * their FIRST sweep on the integer cores too, followed by an fp16 sweep of the ~6 % of rows it leaves alive (route Q,
- * MSFM_Q8=0 in the environment at msfm_create: off); everything else on the fp16 cores; 2: fp16 matrix cores for every
+ * their FIRST sweep on the integer cores too; fine twins (the store's values stay below 0.625) hand the second sweep its thresholds
+ * directly, coarse ones are refined by an fp16 sweep of the ~6 % of rows left alive first (route Q; MSFM_Q8=0 in the environment
+ * at msfm_create: off, MSFM_Q8_DIRECT=0: always refine); everything else on the fp16 cores; 2: fp16 matrix cores for every
  * image; 0: always the brute-force exact kernel.  Results are bit-identical in all.
  * Env: MSFM_PREFILTER=0|1|2. */
 int msfm_set_prefilter(msfm_ctx* ctx, int enable);
