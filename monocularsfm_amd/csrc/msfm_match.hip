@@ -1042,7 +1042,7 @@ int finish_prefilter(msfm_ctx* ctx, Batch& b, std::vector<char>& force_exact, bo
                          which == 0 ? 1 : 3, w, pr[w][0] / n, pr[w][1] / n, pr[w][2] / n, pr[w][3] / n, n, pr[w][5],
                          (double)(pr[w][0] + pr[w][1] + pr[w][2] + pr[w][3]) / it_n,
                          ((double)pr[w][6] - (double)(pr[w][0] + pr[w][1] + pr[w][2] + pr[w][3])) / it_n);
-            if (which == 0)
+            if (which == 0 || !sixteen)
                 std::fprintf(stderr, "    item segments (cycles): descriptor fetch %.0f | A loads + first DMA %.0f | barrier + pre-read %.0f | loop %.0f | drain %.0f | row merge + stores %.0f\n",
                              pr[w][8] / it_n, pr[w][9] / it_n, pr[w][10] / it_n, pr[w][11] / it_n, pr[w][12] / it_n, pr[w][13] / it_n);
         }

@@ -370,7 +370,8 @@ __global__ __launch_bounds__(kI8Threads) void sweep_i8_kernel(
     // the matrix half of a tile: 10 MFMA, k-steps 2, 3 and the digits read from LDS behind the MFMA pairs that free their registers
     auto matrix_half = [&](int t) {
         const int sl = (t - t_begin) & (kI8Ring - 1);
-        __builtin_amdgcn_s_setprio(1);
+        // (no s_setprio: with one barrier per tile the waves of a SIMD interleave well on their own -- priority for the matrix
+        // halves measured 0.7 % slower, for the epilogue halves 2 % slower, profiles/r03_i8_sync_experiments.txt)
         const char* pb2 = sB + sl * kI8TileBytes + lane_row_off + 2 * 32;
         if (PASS == 1) {   // C = 0 (an inline constant: no register, no init)
             accA = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[0], bf[0][0], i16v(0), 0, 0, 0);
@@ -393,7 +394,6 @@ __global__ __launch_bounds__(kI8Threads) void sweep_i8_kernel(
         accB = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[3], bf[1][1], accB, 0, 0, 0);
         accA = __builtin_amdgcn_mfma_i32_32x32x32_i8(a_digit, bf[0][0], accA, 0, 0, 0);   // + (H0_b - h_b) [+ (H0_a - h_a)]
         accB = __builtin_amdgcn_mfma_i32_32x32x32_i8(a_digit, bf[0][1], accB, 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
     };
     // the epilogue half of tile t (its accumulators are in accA / accB)
     auto epilogue_half = [&](int t) {
