@@ -181,8 +181,8 @@ struct Scratch {
     DevBuf d_fix_count, d_fix_list;
     int fix_cap_eff = 0;              // capacity handed to the kernels of the current batch (0: ties need no fix-up)
     // prefilter path
-    DevBuf d_pf, d_tu, d_tv, d_cand, d_cand_s, d_cand_count, d_best, d_second;
-    DevBuf d_cmp_tu, d_live_idx, d_row_pair, d_row_src, d_cand_pair, d_vpairs, d_vpf, d_vitems, d_lists;
+    DevBuf d_pf, d_tu, d_tv, d_cand, d_cand_count, d_best, d_second;
+    DevBuf d_cmp_tu, d_live_idx, d_row_pair, d_row_src, d_vpairs, d_vpf, d_vitems, d_lists;
     DevBuf d_pfq, d_cmp_s0, d_cmp_s1, d_summary_a;   // route Q: twin pair table, sweep 1' row results, summary of plan A
     // device-side plan of the compacted sweep 2 (msfm_plan.hip.h)
     DevBuf d_colmask, d_groups, d_gmembers, d_member_pair, d_member_group, d_gtot, d_grow0, d_ppair, d_cnt, d_mrow, d_summary, d_overflow, d_totals;
@@ -201,8 +201,8 @@ struct Scratch {
     void release_all() {
         DevBuf* bufs[] = {&d_pairs, &d_items, &d_item_base, &d_rp_s0, &d_rp_i0, &d_rp_s1, &d_cp_s0, &d_cp_i0, &d_cp_s1, &d_k_i0, &d_k_d0,
                           &d_k_d1, &d_st_qt, &d_st_d, &d_counts, &d_offsets, &d_sens, &d_sub_qt, &d_sub_d, &d_fix_count, &d_fix_list, &d_pf, &d_tu,
-                          &d_tv, &d_cand, &d_cand_s, &d_cand_count, &d_best, &d_second, &d_cmp_tu, &d_live_idx, &d_row_pair, &d_row_src,
-                          &d_cand_pair, &d_vpairs, &d_vpf, &d_vitems, &d_lists, &d_colmask, &d_groups, &d_gmembers, &d_member_pair,
+                          &d_tv, &d_cand, &d_cand_count, &d_best, &d_second, &d_cmp_tu, &d_live_idx, &d_row_pair, &d_row_src,
+                          &d_vpairs, &d_vpf, &d_vitems, &d_lists, &d_colmask, &d_groups, &d_gmembers, &d_member_pair,
                           &d_member_group, &d_gtot, &d_grow0, &d_ppair, &d_cnt, &d_mrow, &d_summary, &d_overflow, &d_totals, &d_vf_pairs,
                           &d_vf_x1, &d_vf_y1, &d_vf_x2, &d_vf_y2, &d_vf_hyp, &d_vf_best_it, &d_vf_best_count, &d_vf_flags, &d_st2_qt,
                           &d_st2_d, &d_counts2, &d_pfq, &d_cmp_s0, &d_cmp_s1, &d_summary_a};
@@ -794,8 +794,6 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
         HIPCHK(ctx, SC.d_row_pair.ensure((size_t)rows_cap * 4));
         HIPCHK(ctx, SC.d_row_src.ensure((size_t)rows_cap * 8));
         HIPCHK(ctx, SC.d_cand.ensure((size_t)cand_cap * sizeof(int2)));
-        HIPCHK(ctx, SC.d_cand_s.ensure((size_t)cand_cap * 4));
-        HIPCHK(ctx, SC.d_cand_pair.ensure((size_t)cand_cap * 4));
         HIPCHK(ctx, SC.d_cand_count.ensure(std::max<size_t>(1, G) * 8));
         if (G > 0) {
             HIPCHK(ctx, hipMemcpyAsync(SC.d_groups.p, cp.groups.data(), G * sizeof(PlanGroup), hipMemcpyHostToDevice, SC.stream));
@@ -950,8 +948,6 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
         for (size_t p = 0; p < P; ++p)
             lists[p] = CandList{(int)p, 0, b.pf[p].cand_off, b.pf[p].cand_cap, 0, nullptr, nullptr};
         HIPCHK(ctx, SC.d_cand.ensure(std::max<long long>(1, dense_cand) * sizeof(int2)));
-        HIPCHK(ctx, SC.d_cand_s.ensure(std::max<long long>(1, dense_cand) * 4));
-        HIPCHK(ctx, SC.d_cand_pair.ensure(std::max<long long>(1, dense_cand) * 4));
         HIPCHK(ctx, SC.d_cand_count.ensure(P * 8));
         HIPCHK(ctx, SC.d_lists.ensure(P * sizeof(CandList)));
         HIPCHK(ctx, hipMemsetAsync(SC.d_cand_count.p, 0, P * 8, SC.stream));
@@ -975,20 +971,15 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
         const dim3 cgrid(64, (unsigned)std::min<size_t>(n_lists, 65535));   // (the kernels stride over the lists in y)
         const unsigned long long* dcount = SC.d_cand_count.as<unsigned long long>();
 #define MSFM_LAUNCH_EXACT(O)                                                                                             \
-    hipLaunchKernelGGL(pf_exact_candidates_kernel<O>, cgrid, dim3(256), 0, SC.stream, dp, dl, dcount, SC.d_cand.as<int2>(), \
-                       SC.d_cand_s.as<float>(), SC.d_cand_pair.as<int>(), SC.d_best.as<unsigned long long>(), (int)n_lists)
+    hipLaunchKernelGGL(pf_exact_candidates_kernel<O>, cgrid, dim3(256), 0, SC.stream, dp, dl, dcount,                      \
+                       (const int2*)SC.d_cand.as<int2>(), SC.d_best.as<unsigned long long>(), SC.d_second.as<unsigned long long>(), \
+                       (int)n_lists)
         if (ctx->order == MSFM_ORDER_SSE4X4) MSFM_LAUNCH_EXACT(0);
         else if (ctx->order == MSFM_ORDER_AVX2_FMA) MSFM_LAUNCH_EXACT(1);
         else MSFM_LAUNCH_EXACT(3);
 #undef MSFM_LAUNCH_EXACT
         HIPCHK(ctx, hipGetLastError());
         DBGSYNC(ctx, "pf_exact_candidates_kernel");
-        const dim3 rgrid(16, (unsigned)std::min<size_t>(n_lists, 65535));
-        hipLaunchKernelGGL(pf_reduce_second_kernel, rgrid, dim3(256), 0, SC.stream, dp, dl, dcount,
-                           SC.d_cand.as<int2>(), SC.d_cand_s.as<float>(), (const int*)SC.d_cand_pair.as<int>(),
-                           SC.d_best.as<unsigned long long>(), SC.d_second.as<unsigned long long>(), (int)n_lists);
-        HIPCHK(ctx, hipGetLastError());
-        DBGSYNC(ctx, "pf_reduce_second_kernel");
     }
     hipLaunchKernelGGL(pf_finalize_kernel, mgrid, dim3(256), 0, SC.stream, dp, dpf, (const float*)tuv, SC.d_best.as<unsigned long long>(),
                        SC.d_second.as<unsigned long long>(), SC.d_k_i0.as<int>(), SC.d_k_d0.as<float>(),

@@ -349,9 +349,9 @@ __device__ __forceinline__ unsigned long long pf_key(float s, int idx) {
 // Records are rewritten in place as real (q, t).   grid = (x, n_lists)
 template <int ORDER>
 __global__ void pf_exact_candidates_kernel(const PairDesc* __restrict__ pairs, const CandList* __restrict__ lists,
-                                           const unsigned long long* __restrict__ cand_count, int2* __restrict__ cand,
-                                           float* __restrict__ cand_s, int* __restrict__ cand_pair,
-                                           unsigned long long* __restrict__ best /* reduce phase A rides along */, int n_lists) {
+                                           const unsigned long long* __restrict__ cand_count, const int2* __restrict__ cand,
+                                           unsigned long long* __restrict__ best, unsigned long long* __restrict__ second /* the reduction rides along */,
+                                           int n_lists) {
     MSFM_TAIL_PRIO();
   for (int lid = blockIdx.y; lid < n_lists; lid += gridDim.y) {   // (more lists than gridDim.y allows: stride)
     const CandList L = lists[lid];
@@ -421,15 +421,22 @@ __global__ void pf_exact_candidates_kernel(const PairDesc* __restrict__ pairs, c
             res = ((sv[0] + sv[1]) + (sv[2] + sv[3])) + ((sv[4] + sv[5]) + (sv[6] + sv[7]));
         }
         if (live && sub == 0) {
-            cand[L.off + c] = qt;
-            cand_s[L.off + c] = res;
-            cand_pair[L.off + c] = pair;
-            // reduce phase A: best (S, idx) per row and per column among the candidates (64-bit atomicMin).  A mode-1 list
-            // only serves the row direction, a mode-2 list only the column direction: the live rows of the OTHER
+            // The reduction rides along: best AND second (S, idx) per row and per column among the candidates, two 64-bit
+            // atomicMin per entry and direction.  atomicMin(best) returns the old best: the LOSER of that update -- the old best
+            // if the new key displaced it, else the new key -- goes into `second`.  Every key except the final minimum is a
+            // loser exactly once, the final minimum never: second ends as the second smallest key (a key arriving twice would
+            // meet itself as the old best: skipped).  Round 2 re-read the whole candidate list in a second kernel for this.
+            // A mode-1 list only serves the row direction, a mode-2 list only the column direction: the live rows of the OTHER
             // direction get their complete candidate sets from their own list.
             if (res < f_inf()) {   // batchDistance never inserts a distance >= FLT_MAX
-                if (L.mode != 2) atomicMin(&best[pairs[pair].kf_off + qt.x], pf_key(res, qt.y));
-                if (L.mode != 1) atomicMin(&best[pairs[pair].kr_off + qt.y], pf_key(res, qt.x));
+                auto fold = [&](long long slot, unsigned long long key) {
+                    const unsigned long long old = atomicMin(&best[slot], key);
+                    if (old == key) return;
+                    const unsigned long long loser = old > key ? old : key;
+                    if (loser != ~0ull) atomicMin(&second[slot], loser);
+                };
+                if (L.mode != 2) fold(pairs[pair].kf_off + qt.x, pf_key(res, qt.y));
+                if (L.mode != 1) fold(pairs[pair].kr_off + qt.y, pf_key(res, qt.x));
             }
         }
     }
@@ -437,28 +444,6 @@ __global__ void pf_exact_candidates_kernel(const PairDesc* __restrict__ pairs, c
 }
 
 
-// reduce phase B: second best = min over the candidates that are not the best one
-__global__ void pf_reduce_second_kernel(const PairDesc* __restrict__ pairs, const CandList* __restrict__ lists,
-                                        const unsigned long long* __restrict__ cand_count,
-                                        const int2* __restrict__ cand, const float* __restrict__ cand_s,
-                                        const int* __restrict__ cand_pair, const unsigned long long* __restrict__ best,
-                                        unsigned long long* __restrict__ second, int n_lists) {
-    MSFM_TAIL_PRIO();
-  for (int lid = blockIdx.y; lid < n_lists; lid += gridDim.y) {
-    const CandList L = lists[lid];
-    if (L.cap == 0) continue;
-    const int n = (int)(cand_count[lid] < (unsigned long long)L.cap ? cand_count[lid] : (unsigned long long)L.cap);
-    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < n; c += gridDim.x * blockDim.x) {
-        const int2 qt = cand[L.off + c];
-        const float s = cand_s[L.off + c];
-        if (!(s < f_inf())) continue;
-        const long long kfo = pairs[cand_pair[L.off + c]].kf_off, kro = pairs[cand_pair[L.off + c]].kr_off;
-        const unsigned long long kf = pf_key(s, qt.y), kr = pf_key(s, qt.x);
-        if (L.mode != 2 && kf != best[kfo + qt.x]) atomicMin(&second[kfo + qt.x], kf);
-        if (L.mode != 1 && kr != best[kro + qt.y]) atomicMin(&second[kro + qt.y], kr);
-    }
-  }
-}
 
 #include "msfm_plan.hip.h"
 #include "msfm_q8.hip.h"
