@@ -166,7 +166,6 @@ __global__ __launch_bounds__(kI8Threads) void sweep_i8_kernel(
 
     const int t_begin = item.bt_begin * 2, t_end = min(item.bt_end * 2, max(item.bt_begin * 2 + 1, (pd.n2 + kPfBT - 1) / kPfBT));
     const char* gB = reinterpret_cast<const char*>(pp.b_h);
-    const gfloat_p g_anrm = (gfloat_p)pp.a_nrm;
     const gfloat_p g_tu = (gfloat_p)tu;
 
     // DMA group of tile tt: the tile's 11 pieces go to waves 0..10, one each
