@@ -255,6 +255,8 @@ __global__ void pf_thresholds_kernel(const PairDesc* __restrict__ pairs, const P
         // Up to 16 blocks (8192 rows) the blocks' minima stay in registers for the mask below.
         float s0 = f_inf(), s1 = f_inf();
         const float2* cp2 = reinterpret_cast<const float2*>(cp_s0);
+        const int* cpk = reinterpret_cast<const int*>(cp_s0);   // (the integer sweeps write 4-byte packed partials: i8_cp_pack)
+        auto partial = [&](long long i) -> float2 { return pp.i8 ? i8_cp_unpack(cpk[i]) : cp2[i]; };
         const int nb = pd.a_blocks256;
         float bmin[16];
         if (nb <= 16) {
@@ -262,14 +264,14 @@ __global__ void pf_thresholds_kernel(const PairDesc* __restrict__ pairs, const P
             for (int p = 0; p < 16; ++p) {
                 bmin[p] = f_inf();
                 if (p < nb) {
-                    const float2 m = cp2[pd.cp_off + (long long)p * pd.n2pad + e];
+                    const float2 m = partial(pd.cp_off + (long long)p * pd.n2pad + e);
                     bmin[p] = -2.f * m.x;
                     v2_merge(s0, s1, -2.f * m.x, -2.f * m.y);
                 }
             }
         } else {
             for (int p = 0; p < nb; ++p) {
-                const float2 m = cp2[pd.cp_off + (long long)p * pd.n2pad + e];
+                const float2 m = partial(pd.cp_off + (long long)p * pd.n2pad + e);
                 v2_merge(s0, s1, -2.f * m.x, -2.f * m.y);
             }
         }
@@ -292,7 +294,7 @@ __global__ void pf_thresholds_kernel(const PairDesc* __restrict__ pairs, const P
                         if (p < nb && bmin[p] <= T) mask |= 1u << p;   // (g = 1)
                 } else {
                     for (int p = 0; p < nb; ++p) {
-                        const float smin = -2.f * cp2[pd.cp_off + (long long)p * pd.n2pad + e].x;
+                        const float smin = -2.f * partial(pd.cp_off + (long long)p * pd.n2pad + e).x;
                         if (smin <= T) mask |= 1u << (p / g);
                     }
                 }

@@ -129,7 +129,7 @@ __global__ void pf_prune_q8_kernel(const PairDesc* __restrict__ pairs, const PfP
     }
     if (e < pd.n2pad) {
         float s0 = f_inf(), s1 = f_inf();
-        const float2* cp2 = reinterpret_cast<const float2*>(cp_s0);
+        const int* cpk = reinterpret_cast<const int*>(cp_s0);   // packed partials of the integer sweep (i8_cp_pack)
         const int nb = pd.a_blocks256;
         // up to 16 blocks (8192 rows) the blocks' minima stay in registers for the mask below: sixteen independent loads in flight
         float bmin[16];
@@ -137,13 +137,13 @@ __global__ void pf_prune_q8_kernel(const PairDesc* __restrict__ pairs, const PfP
 #pragma unroll
             for (int p = 0; p < 16; ++p) {
                 float2 m = make_float2(-f_inf(), -f_inf());
-                if (p < nb) m = cp2[pd.cp_off + (long long)p * pd.n2pad + e];
+                if (p < nb) m = i8_cp_unpack(cpk[pd.cp_off + (long long)p * pd.n2pad + e]);
                 bmin[p] = -2.f * m.x;
                 v2_merge(s0, s1, -2.f * m.x, -2.f * m.y);
             }
         } else {
             for (int p = 0; p < nb; ++p) {
-                const float2 m = cp2[pd.cp_off + (long long)p * pd.n2pad + e];
+                const float2 m = i8_cp_unpack(cpk[pd.cp_off + (long long)p * pd.n2pad + e]);
                 v2_merge(s0, s1, -2.f * m.x, -2.f * m.y);
             }
         }
@@ -167,7 +167,7 @@ __global__ void pf_prune_q8_kernel(const PairDesc* __restrict__ pairs, const PfP
                         if (p < nb && lower(bmin[p], err) * (1.f - 1e-5f) <= u1 * (1.f + 1e-5f)) col_bits |= 1u << p;   // (g = 1)
                 } else {
                     for (int p = 0; p < nb; ++p) {
-                        const float smin = -2.f * cp2[pd.cp_off + (long long)p * pd.n2pad + e].x;
+                        const float smin = -2.f * i8_cp_unpack(cpk[pd.cp_off + (long long)p * pd.n2pad + e]).x;
                         if (lower(smin, err) * (1.f - 1e-5f) <= u1 * (1.f + 1e-5f)) col_bits |= 1u << (p / g);
                     }
                 }
