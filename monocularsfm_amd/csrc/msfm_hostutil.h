@@ -1,0 +1,52 @@
+// msfm_hostutil.h -- small pure functions shared by device and host code, compilable on their own (tests/test_hostutil.py builds a
+// g++ driver around them): the 4-byte packing of the integer sweeps' column partials, the cost marks of a call's sub-batches.
+#pragma once
+#include <vector>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define MSFM_HD __host__ __device__ inline __attribute__((always_inline))
+#else
+#define MSFM_HD inline
+#endif
+
+// Column partial of the integer sweeps -- per column and 512-row block the two largest accumulators (relative to the item's K:
+// -S~/2, <= 1, > -2^23) -- in FOUR bytes instead of the float pipeline's float2: the largest exactly (24 bits; -2^23 = "no real
+// row"), and an 8-bit code of how far below it the second largest is, rounded UP: code c stands for
+// ((16 + (c & 15)) << (c >> 4)) - 16 (exact up to 15, then 1/16 steps; 255 = "no second").  The second value is only ever used as
+// an upper bound of the column's second-smallest S^ -- a smaller accumulator is a larger S^ -- so rounding the gap up keeps every
+// bound valid; it halves what sweep 1 writes and the thresholds / prune kernels read (3.3 GB -> 1.65 GB per 8128-pair job).
+MSFM_HD int msfm_cp_pack(int hi, bool hi_valid, int lo, bool lo_valid) {
+    unsigned c = 255u;
+    if (lo_valid) {
+        const unsigned x = (unsigned)(hi - lo) + 16u;          // gap + 16 >= 16
+        int e = 27 - __builtin_clz(x);                         // floor(log2 x) - 4 >= 0
+        unsigned m = (x + (1u << e) - 1u) >> e;                // 16 .. 32, rounded up
+        e += (int)(m >> 5);                                    // (m == 32 -> 16 at the next exponent)
+        m = (m >> 5) ? 16u : m;
+        const unsigned code = ((unsigned)e << 4) | (m - 16u);
+        c = code >= 255u ? 255u : code;                        // (e > 15 lands here as well)
+    }
+    return hi_valid ? (int)(((unsigned)hi << 8) | c) : (int)0x80000000;
+}
+constexpr int kCpNone = -(1 << 23);                                           // the "no real row" value of the 24-bit field
+MSFM_HD int msfm_cp_hi(int code) { return code >> 8; }                        // kCpNone: no real row
+MSFM_HD bool msfm_cp_has_second(int code) { return (code & 255) != 255; }
+MSFM_HD int msfm_cp_gap(int code) { const int c = code & 255; return ((16 + (c & 15)) << (c >> 4)) - 16; }
+
+// Cumulative-cost marks of the parts a large call is cut into (msfm_set_pipeline): n_sub parts whose size shrinks linearly towards
+// the end of the call, the last one to `taper` of the average -- what follows the LAST sweep 1 of a call (that part's thresholds,
+// plan, sweep 2, exact re-check, epilogue) has nothing left to hide behind, and it is proportional to the part's size.
+// -> marks[0] = 0 < marks[1] < ... < marks[n_sub] = total.
+inline std::vector<long long> msfm_pipeline_marks(long long total, long long n_sub, double taper) {
+    std::vector<long long> marks;
+    if (n_sub < 2) return marks;
+    const double last = taper, first = 2.0 - last;
+    double acc = 0.0;
+    marks.push_back(0);
+    for (long long k = 0; k < n_sub; ++k) {
+        acc += first - (first - last) * (double)k / (double)(n_sub - 1);
+        marks.push_back(k + 1 == n_sub ? total : (long long)((double)total * acc / (double)n_sub));
+    }
+    return marks;
+}

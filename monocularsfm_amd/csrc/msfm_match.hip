@@ -7,6 +7,7 @@
 // descriptor re-read.  No CPU fallback: every entry point that needs the GPU fails loudly
 // when there is none.
 #include "msfm_match.h"
+#include "msfm_hostutil.h"
 #include "msfm_kernels.hip.h"
 #include "msfm_prefilter.hip.h"
 #include "msfm_verify.hip.h"
@@ -1805,9 +1806,7 @@ static int match_pairs_impl(msfm_ctx* ctx, const int32_t* pairs, int n_pairs, co
     const int kSets = ctx->in_flight;
     const long long kScratchElems = std::max<long long>(1, ctx->scratch_elems / std::min(kSets, 2));   // the scratch sets share the budget (a third set: +50 %)
     const int kMaxPairsPerBatch = ctx->max_pairs_per_batch;
-    // cumulative-cost marks of the parts (empty: no cost cut).  The parts shrink linearly towards the end of the call, the last
-    // one to `pipeline_taper` of the average: what follows the LAST sweep 1 of a call -- that part's thresholds, plan, sweep 2,
-    // exact re-check, epilogue -- has nothing left to hide behind, and it is proportional to the part's size.
+    // cumulative-cost marks of the parts (empty: no cost cut): msfm_pipeline_marks (msfm_hostutil.h) -- shrinking parts
     std::vector<long long> marks;
     if (ctx->pipeline > 1 && n_pairs > 1) {
         long long total = 0;
@@ -1817,16 +1816,7 @@ static int match_pairs_impl(msfm_ctx* ctx, const int32_t* pairs, int n_pairs, co
             const long long n1 = ctx->images[i].n, n2 = ctx->images[j].n;
             if (n1 > 0 && n2 > 0) total += n1 * n2;
         }
-        const long long n_sub = std::min<long long>(ctx->pipeline, total / kMinPipelineCost);
-        if (n_sub >= 2) {
-            const double last = ctx->pipeline_taper, first = 2.0 - last;
-            double acc = 0.0;
-            marks.push_back(0);
-            for (long long k = 0; k < n_sub; ++k) {
-                acc += first - (first - last) * (double)k / (double)(n_sub - 1);
-                marks.push_back(k + 1 == n_sub ? total : (long long)((double)total * acc / (double)n_sub));
-            }
-        }
+        marks = msfm_pipeline_marks(total, std::min<long long>(ctx->pipeline, total / kMinPipelineCost), ctx->pipeline_taper);
     }
     long long cost_done = 0;   // cost of the sub-batches built so far (a re-built sub-batch starts from its own begin: see build)
     // a tie in sqrt space can only surface in a match list when a row with d0 == d1 can pass the ratio test

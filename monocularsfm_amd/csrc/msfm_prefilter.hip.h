@@ -255,7 +255,7 @@ __global__ void pf_thresholds_kernel(const PairDesc* __restrict__ pairs, const P
         // Up to 16 blocks (8192 rows) the blocks' minima stay in registers for the mask below.
         float s0 = f_inf(), s1 = f_inf();
         const float2* cp2 = reinterpret_cast<const float2*>(cp_s0);
-        const int* cpk = reinterpret_cast<const int*>(cp_s0);   // (the integer sweeps write 4-byte packed partials: i8_cp_pack)
+        const int* cpk = reinterpret_cast<const int*>(cp_s0);   // (the integer sweeps write 4-byte packed partials: msfm_cp_pack)
         auto partial = [&](long long i) -> float2 { return pp.i8 ? i8_cp_unpack(cpk[i]) : cp2[i]; };
         const int nb = pd.a_blocks256;
         float bmin[16];

@@ -129,7 +129,7 @@ __global__ void pf_prune_q8_kernel(const PairDesc* __restrict__ pairs, const PfP
     }
     if (e < pd.n2pad) {
         float s0 = f_inf(), s1 = f_inf();
-        const int* cpk = reinterpret_cast<const int*>(cp_s0);   // packed partials of the integer sweep (i8_cp_pack)
+        const int* cpk = reinterpret_cast<const int*>(cp_s0);   // packed partials of the integer sweep (msfm_cp_pack)
         const int nb = pd.a_blocks256;
         // up to 16 blocks (8192 rows) the blocks' minima stay in registers for the mask below: sixteen independent loads in flight
         float bmin[16];

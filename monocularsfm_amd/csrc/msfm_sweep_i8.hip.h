@@ -63,30 +63,11 @@ typedef int i16v __attribute__((ext_vector_type(16)));
 
 __device__ __forceinline__ int max3i(int a, int b, int c) { return max(max(a, b), c); }  // folds to v_max3_i32
 
-// Column partial of the integer sweeps -- per column and 512-row block the two largest accumulators (relative to the item's K:
-// -S~/2, <= 1, > -2^23) -- in FOUR bytes instead of the float pipeline's float2: the largest exactly (24 bits; -2^23 = "no real
-// row"), and an 8-bit code of how far below it the second largest is, rounded UP: code c stands for
-// ((16 + (c & 15)) << (c >> 4)) - 16 (exact up to 15, then 1/16 steps; 255 = "no second").  The second value is only ever used as
-// an upper bound of the column's second-smallest S^ -- a smaller accumulator is a larger S^ -- so rounding the gap up keeps every
-// bound valid; it halves what sweep 1 writes and the thresholds / prune kernels read (3.3 GB -> 1.65 GB per 8128-pair job).
-__device__ __forceinline__ int i8_cp_pack(int hi, bool hi_valid, int lo, bool lo_valid) {
-    unsigned c = 255u;
-    if (lo_valid) {
-        const unsigned x = (unsigned)(hi - lo) + 16u;          // gap + 16 >= 16
-        int e = 27 - __builtin_clz(x);                         // floor(log2 x) - 4 >= 0
-        unsigned m = (x + (1u << e) - 1u) >> e;                // 16 .. 32, rounded up
-        e += (int)(m >> 5);                                    // (m == 32 -> 16 at the next exponent)
-        m = (m >> 5) ? 16u : m;
-        const unsigned code = ((unsigned)e << 4) | (m - 16u);
-        c = code >= 255u ? 255u : code;                        // (e > 15 lands here as well)
-    }
-    return hi_valid ? (int)(((unsigned)hi << 8) | c) : (int)0x80000000;
-}
+// Column partials of the integer sweeps: one packed 32-bit word (msfm_hostutil.h: msfm_cp_pack) instead of the float pipeline's float2
 __device__ __forceinline__ float2 i8_cp_unpack(int code) {   // -> the float pipeline's (largest, second largest), -inf for none
-    const int hi = code >> 8, c = code & 255;
-    if (hi == -(1 << 23)) return make_float2(-f_inf(), -f_inf());
-    const int gap = ((16 + (c & 15)) << (c >> 4)) - 16;
-    return make_float2((float)hi, c == 255 ? -f_inf() : (float)(hi - gap));
+    const int hi = msfm_cp_hi(code);
+    if (hi == kCpNone) return make_float2(-f_inf(), -f_inf());
+    return make_float2((float)hi, msfm_cp_has_second(code) ? (float)(hi - msfm_cp_gap(code)) : -f_inf());
 }
 
 // upload-time preparation of a byte image: signed operand rows (digits zero until pf_digits_i8_kernel), the float "norms"
@@ -374,10 +355,10 @@ __global__ __launch_bounds__(kI8Threads) void sweep_i8_kernel(
                      "s_waitcnt lgkmcnt(0)\n\t"
                      "ds_write_b32 %4, %5\n\tds_write_b32 %4, %5 offset:256\n\tds_write_b32 %4, %5 offset:512\n\tds_write_b32 %4, %5 offset:768"
                      : "=&v"(v.x), "=&v"(v.y), "=&v"(v.z), "=&v"(v.w) : "v"(a), "v"(reset) : "memory");
-        // the two largest of the four class maxima of the accumulator (-S~/2), packed (i8_cp_pack); none where a class saw no real row
+        // the two largest of the four class maxima of the accumulator (-S~/2), packed (msfm_cp_pack); none where a class saw no real row
         const int m01 = max(v.x, v.y), n01 = min(v.x, v.y), m23 = max(v.z, v.w), n23 = min(v.z, v.w);
         const int hi = max(m01, m23), lo = max(min(m01, m23), max(n01, n23));
-        const int o = i8_cp_pack(hi - item_k, hi > kI8PadTest, lo - item_k, lo > kI8PadTest);
+        const int o = msfm_cp_pack(hi - item_k, hi > kI8PadTest, lo - item_k, lo > kI8PadTest);
         int* colbase = reinterpret_cast<int*>(cp_s0) + (pd.cp_off + (long long)item.a_blk * pd.n2pad);   // (uniform base + 32-bit lane offset)
         colbase[(unsigned)(tt * kPfBT) + lane_op] = o;
     };

@@ -1,0 +1,87 @@
+"""Pure host-testable pieces of the library (monocularsfm_amd/csrc/msfm_hostutil.h), compiled here with g++:
+
+  * the 4-byte packing of the integer sweeps' column partials: the largest accumulator must survive exactly, the decoded second
+    largest may only be SMALLER than the true one (it is used as an upper bound of the column's second-smallest distance: every
+    pruning / threshold bound of the prefilter stays valid) and by at most 1/16 of the gap;
+  * the cost marks of a large call's sub-batches (msfm_set_pipeline): increasing, ending at the total, parts shrinking towards the
+    end, the last one `taper` of the average.
+The reference's counterpart of the second is the fixed 100-pair flush of BruteFeatureMatcher::RunMatching
+(/root/reference/src/Feature/FeatureMatching.cpp:118-139)."""
+import os
+import subprocess
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "..", "monocularsfm_amd", "csrc")
+
+DRIVER = r"""
+#include "msfm_hostutil.h"
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+int main() {
+    std::mt19937_64 rng(12345);
+    long long checked = 0;
+    auto check = [&](int hi, int lo) -> bool {
+        const int code = msfm_cp_pack(hi, true, lo, true);
+        if (msfm_cp_hi(code) != hi) { std::printf("hi lost: %d -> %d\n", hi, msfm_cp_hi(code)); return false; }
+        const int gap = hi - lo;
+        if (!msfm_cp_has_second(code)) return gap > 1000000 - 64 || gap >= ((31 << 15) - 16 - (1 << 15));   // only huge gaps may drop the second
+        const int dec = msfm_cp_gap(code);
+        if (dec < gap) { std::printf("gap rounded DOWN: %d -> %d\n", gap, dec); return false; }
+        if (gap < 16 && dec != gap) { std::printf("small gap not exact: %d -> %d\n", gap, dec); return false; }
+        if ((long long)dec * 16 > (long long)(gap + 16) * 17) { std::printf("gap too coarse: %d -> %d\n", gap, dec); return false; }
+        ++checked;
+        return true;
+    };
+    for (int gap = 0; gap < 70000; ++gap)
+        if (!check(-12345, -12345 - gap)) return 1;
+    for (int k = 0; k < 2000000; ++k) {
+        const int hi = 1 - (int)(rng() % 4200000ull);
+        const int gap = (int)(rng() % (k & 1 ? 3000ull : 5000000ull));
+        if (!check(hi, hi - gap)) return 1;
+    }
+    for (int e = 0; e < 23; ++e)
+        for (int d = -2; d <= 2; ++d) {
+            const int gap = (1 << e) + d;
+            if (gap >= 0 && !check(0, -gap)) return 1;
+        }
+    // markers
+    if (msfm_cp_hi(msfm_cp_pack(-5, false, -7, true)) != kCpNone) { std::printf("no-row marker\n"); return 1; }
+    if (msfm_cp_has_second(msfm_cp_pack(-5, true, -7, false))) { std::printf("no-second marker\n"); return 1; }
+    if (msfm_cp_hi(msfm_cp_pack(-4200000, true, -4200001, true)) != -4200000 || msfm_cp_hi(msfm_cp_pack(1, true, 0, true)) != 1) { std::printf("range\n"); return 1; }
+    // marks
+    const long long totals[] = {30000000001LL, 206310000000LL, 59220619689984LL};
+    const double tapers[] = {0.05, 0.3, 1.0};
+    for (long long total : totals)
+        for (long long n = 2; n <= 9; ++n)
+            for (double taper : tapers) {
+                const std::vector<long long> m = msfm_pipeline_marks(total, n, taper);
+                if ((long long)m.size() != n + 1 || m.front() != 0 || m.back() != total) { std::printf("marks ends\n"); return 1; }
+                long long prev_part = -1;
+                for (long long k = 0; k < n; ++k) {
+                    const long long part = m[k + 1] - m[k];
+                    if (part <= 0) { std::printf("marks not increasing\n"); return 1; }
+                    if (prev_part >= 0 && part > prev_part + 2) { std::printf("parts grow: %lld after %lld\n", part, prev_part); return 1; }
+                    prev_part = part;
+                }
+                const double avg = (double)total / (double)n, last = (double)(m[n] - m[n - 1]);
+                if (last < taper * avg * 0.999 - 2 || last > taper * avg * 1.001 + 2) { std::printf("last part %.0f vs %.0f\n", last, taper * avg); return 1; }
+            }
+    if (!msfm_pipeline_marks(1000, 1, 0.3).empty() || !msfm_pipeline_marks(1000, 0, 0.3).empty()) { std::printf("marks for one part\n"); return 1; }
+    std::printf("ok %lld\n", checked);
+    return 0;
+}
+"""
+
+
+def test_packed_column_partials_and_pipeline_marks(tmp_path):
+    src = tmp_path / "driver.cpp"
+    src.write_text(DRIVER)
+    exe = tmp_path / "driver"
+    cc = subprocess.run(["g++", "-O2", "-std=c++17", "-I", CSRC, "-o", str(exe), str(src)], capture_output=True, text=True)
+    assert cc.returncode == 0, cc.stderr
+    run = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert run.returncode == 0, run.stdout + run.stderr
+    assert run.stdout.startswith("ok ") and int(run.stdout.split()[1]) > 1000000   # (gaps beyond ~1e6 drop the second: not counted)
