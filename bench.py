@@ -2,7 +2,9 @@
 """bench.py -- ComputeMatches hot path on MI355X: descriptor-pairs/s (and image-pairs/s).
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+  (N > 1: either under python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ..., or plain
+   `python bench.py --gpus N`: without WORLD_SIZE in the environment the script launches that command itself, one rank per
+   GPU, passes rank 0's JSON line through and returns the job's exit code)
 
 Workload (BASELINE.json configs[1]): South-Building-shaped job -- 128 images, ~5k 128-D float32 RootSIFT-like
 descriptors each (seeded synthetic), brute-force all pairs (8128 image pairs, pre-emptive filter
@@ -12,10 +14,11 @@ rank at the end (N > 1: per-pair counts all-reduced, the lists sent over RCCL fr
 Descriptors are resident in HBM before the timed region.
 
 STRONG scaling: the SAME job at every N (the N = 1 line is the BENCH line); the pair list is cut into N contiguous
-cost-balanced ranges, the store is replicated.  `strong_u8` in the same JSON line is a second strong-scaling
-measurement on a seeded subset of BASELINE configs[3] (the 1329 x 8192 u8 job north_star names): `--u8-images`
-images (default 192) of the 1329, full per-image size -- large enough that per-rank work at N = 8 is tens of ms.
-`--workload synthetic-u8 --images 1329 --desc 8192` runs that job in full as the main workload.
+cost-balanced ranges, the store is replicated.  `strong_u8` in the same JSON line is the strong-scaling measurement
+north_star's >= 6x target is stated on: BASELINE configs[3] IN FULL (1329 images x 8192 u8 descriptors, 882 456 pairs,
+5.92e13 descriptor pairs; ~9 s per step on one GPU), one warm-up step + `--u8-steps` (default 1) timed steps at every N --
+strong_u8.value at N = 8 over the value at N = 1 IS that measurement.  `--u8-images M` (< 1329) runs a seeded M-image subset
+instead (tests), 0 skips the job.  `--workload synthetic-u8 --images 1329 --desc 8192` runs it as the main workload.
 
 Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel (sweep 1 of the MFMA prefilter), timed with
 HIP events on the library's own stream inside the timed region; `cpu_baseline` is the CPU oracle ("port": a
@@ -50,11 +53,18 @@ def pmc_traffic(i8):
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic_approx.json")), reverse=True):
         try:
             d = json.load(open(path))
+            # steps of the profiled command (`--steps 3 --warmup 2` = 5 in every committed pass; "_meta" since round 4)
+            pmc_steps = float(d.get("_meta", {}).get("steps", 5))
+            d = {n: k for n, k in d.items() if not n.startswith("_")}
             per = {n: 2.0 * k["FETCH_SIZE"]["per_launch_KB_mean"] * 1024 + k["WRITE_SIZE"]["per_launch_KB_mean"] * 1024
                    for n, k in d.items()}
             want = ("sweep_i8_kernel<1>",) if i8 else ("approx_kernel<1>", "sweep1", "sweep_kernel<1>")
             name = [n for n in per if n.startswith(want)][0]
-            return {"bytes_per_launch": per[name], "kernel": name, "source": os.path.relpath(path, ROOT), "per_kernel_bytes": per}
+            # the profiled command may cut a step into another number of launches than this run: bytes per STEP are comparable
+            launches = float(d[name]["FETCH_SIZE"].get("launches", pmc_steps))
+            return {"bytes_per_step": per[name] * launches / pmc_steps, "pmc_launches_per_step": launches / pmc_steps,
+                    "bytes_per_pmc_launch": per[name], "kernel": name, "source": os.path.relpath(path, ROOT),
+                    "per_kernel_bytes_per_pmc_launch": per}
         except (OSError, KeyError, ValueError, IndexError):
             continue
     return None
@@ -170,15 +180,33 @@ def main():
                     help="brute-force exact-order kernel for every pair (same results, ~20x slower)")
     ap.add_argument("--f16-only", action="store_true", help="byte stores on the fp16 matrix cores too (default: integer matrix cores)")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
-    ap.add_argument("--u8-images", type=int, default=192,
-                    help="images of the secondary strong-scaling job (subset of the 1329 x 8192 u8 config); 0 = skip")
-    ap.add_argument("--u8-steps", type=int, default=2)
+    ap.add_argument("--u8-images", type=int, default=1329,
+                    help="images of the strong-scaling job on the 1329 x 8192 u8 config (default: the config in full; fewer = "
+                         "a seeded subset); 0 = skip")
+    ap.add_argument("--u8-steps", type=int, default=None, help="timed steps of that job (default 1 for the full config, else 2)")
     ap.add_argument("--sustained-steps", type=int, default=200,
                     help="extra untimed-for-`value` run of this many steps after the K timed ones -> sustained_ms_per_step "
                          "(the part's clock is set by a power budget: a 1 s burst and a 10 s run differ); 0 = skip")
     ap.add_argument("--no-solo", action="store_true",
                     help="skip the 4 extra steps with the pipeline off that measure the sweeps alone (roofline.solo); for kernel traces")
     args = ap.parse_args()
+    if args.u8_steps is None:
+        args.u8_steps = 1 if args.u8_images >= 1329 else 2
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher -- one rank per GPU under torch.distributed.run, rank 0's JSON line
+        # (the only thing the ranks print on stdout) passes through, the job's exit code is ours
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", "2")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd, env=env))
 
     import torch
     import torch.distributed as dist
@@ -188,10 +216,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
-        args.gpus = world
+    args.gpus = world   # (under a launcher the process group is what counts)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; no GPU visible (there is no CPU fallback)")
     if args.share_gpu:
@@ -219,7 +244,7 @@ def main():
     elif args.f16_only:
         ctx.set_prefilter(2)
 
-    def run_job(imgs, pairs, steps, warmup, collect=None, sustained_steps=0, **match_kw):
+    def run_job(imgs, pairs, steps, warmup, collect=None, sustained_steps=0, solo_pass=True, **match_kw):
         """Upload, W untimed + K timed steps; -> (seconds of the K steps: max over ranks, result of the last step,
         upload seconds, per-rank [compute_ms, exchange_ms] means)."""
         n_rows = np.array([len(x) for x in imgs], np.int64)
@@ -275,7 +300,7 @@ def main():
         # after everything timed: the sweeps ALONE (one sub-batch per step, nothing in flight beside them) -- in the timed
         # region the other sub-batches' bandwidth-bound tails run beside a sweep and stretch its event span
         run_job.solo = None
-        if collect is not None and not args.no_prefilter and not args.no_solo and os.environ.get("MSFM_PIPELINE") is None:
+        if collect is not None and solo_pass and not args.no_prefilter and not args.no_solo and os.environ.get("MSFM_PIPELINE") is None:
             ctx.set_pipeline(1)
             solo = {"approx_kernel_ms": 0.0, "approx_kernel_launches": 0, "sweep2_ms": 0.0, "prefilter_descriptor_pairs": 0, "wall_ms": 0.0}
             try:
@@ -363,18 +388,34 @@ def main():
         tr = pmc_traffic(i8)
         algo_bytes_step = last_prof.get("dist_algo_bytes", 0)
         rows_work = float((n_rows[pairs[:, 0]] + n_rows[pairs[:, 1]]).sum()) * args.steps / max(world, 1)
+        # ONE launch unit for `traffic`, `algorithmic_bytes_per_launch` and `achieved`: this run's average sweep-1 launch
+        # (the step is cut into `launches_per_step` of them).  The PMC passes are separate runs of the same command -- counters
+        # cannot be collected inside the timed process -- so their bytes per STEP are divided by this run's launches per step.
+        launches_per_step = pf_launches / float(args.steps)
+        traffic = tr["bytes_per_step"] / launches_per_step if tr else None
+        algo_launch = algo_bytes_step / launches_per_step
+        # what the sweep itself reads when nothing is re-used: both images' operand rows once per image pair -- 176-byte byte-twin
+        # rows on the integer cores (128 operand bytes + digits + constants), 272-byte fp16 rows otherwise
+        row_bytes = 176.0 if i8 else 272.0
+        algo_rows_launch = float((n_rows[pairs[:, 0]] + n_rows[pairs[:, 1]]).sum()) / max(world, 1) * row_bytes / launches_per_step
         out["roofline"] = {
             "kernel": "sweep 1 of the MFMA prefilter (%s%s); sweep 2 and the exact fp32 re-check only touch survivors"
                       % ("v_mfma_i32_32x32x32_i8" if i8 else "v_mfma_f32_32x32x16_f16",
                          ", on the byte twins of the float store: route Q" if acc["sweep1_q8_launches"] else ""),
             "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TOP/s" if i8 else "TFLOP/s",
             "frac": achieved / peak,
-            "traffic": tr["bytes_per_launch"] if tr else None, "traffic_unit": "HBM bytes/launch (PMC)", "traffic_detail": tr,
+            "traffic": traffic, "traffic_unit": "HBM bytes per launch of THIS run (PMC bytes per step / launches per step)",
+            "traffic_detail": tr,
             # not measured by THIS run: rocprofv3 --pmc passes cannot run inside the timed process
             "traffic_source": ("committed PMC pass of this command: " + tr["source"]) if tr else None,
-            "avg_launch_ms": avg_ms, "launches": pf_launches, "flops_per_desc_pair": 256.0,
+            "avg_launch_ms": avg_ms, "launches": pf_launches, "launches_per_step": launches_per_step, "flops_per_desc_pair": 256.0,
             "descriptor_pairs_per_launch": pf_pairs_work / pf_launches,
-            "algorithmic_bytes_per_launch": algo_bytes_step * args.steps / pf_launches,
+            # (n1 + n2) x 128 x 4 B + the kNN lists per image pair, no cross-pair reuse -- per launch, like `traffic`
+            "algorithmic_bytes_per_launch": algo_launch,
+            "traffic_over_algorithmic": (traffic / algo_launch) if (traffic is not None and algo_launch > 0) else None,
+            "algorithmic_bytes_per_launch_operand_rows": algo_rows_launch,
+            "traffic_over_algorithmic_operand_rows": (traffic / algo_rows_launch) if (traffic is not None and algo_rows_launch > 0) else None,
+            "traffic_per_step": tr["bytes_per_step"] if tr else None, "algorithmic_bytes_per_step": algo_bytes_step,
             # (event spans: with sub-batches in flight a sweep-2 launch waits for another stream's sweep 1 --
             # that wait is inside its span; profiles/rNN_route_q_kernel_stats_pipeline1.txt has the unpipelined kernel times)
             "sweep2": {"ms_per_step": acc["sweep2_ms"] / args.steps, "launches": acc["sweep2_launches"],
@@ -414,33 +455,60 @@ def main():
         else:
             out["roofline"] = exact
 
-    # ---- secondary strong-scaling job: a subset of the 1329 x 8192 u8 config -------------------------------------
-    if args.u8_images > 1 and args.workload == "south-building" and not args.no_prefilter:
-        u_imgs, u_pairs, u_name = synth.job("synthetic-u8", args.u8_images, 8192, seed=1329)
-        u_acc = {"approx_kernel_ms": 0.0, "prefilter_descriptor_pairs": 0, "sweep1_i8_launches": 0}
+    # ---- the strong-scaling job of north_star's >= 6x target: BASELINE configs[3] (1329 x 8192 u8), in full by default --------
+    def u8_job():
+        full = args.u8_images >= 1329
+        n_img = min(args.u8_images, 1329)
+        t_gen = time.perf_counter()
+        u_imgs, u_pairs, u_name = synth.job("synthetic-u8", n_img, 8192, seed=1329)
+        gen_s = time.perf_counter() - t_gen
+        u_acc = {"approx_kernel_ms": 0.0, "prefilter_descriptor_pairs": 0, "sweep1_i8_launches": 0, "sub_batches": 0,
+                 "approx_kernel_launches": 0, "order_sensitive_rows": 0, "candidates": 0}
 
         def u_collect(p):
             for k in u_acc:
                 u_acc[k] += p.get(k, 0)
 
-        # u8 distances are hundreds, not fractions of a unit-norm descriptor: no distance cut (reference default 0.7 is for RootSIFT)
-        u_dt, u_res, _, u_per_rank, u_rows = run_job(u_imgs, u_pairs, args.u8_steps, 1, u_collect, max_distance=1e9)
+        # u8 distances are hundreds, not fractions of a unit-norm descriptor: no distance cut (reference default 0.7 is for RootSIFT).
+        # One warm-up step (buffers sized, plan hints learnt), then the timed ones; the sweeps-alone pass only on small subsets
+        # (three more steps of the full job would be half a minute)
+        u_dt, u_res, u_upload_s, u_per_rank, u_rows = run_job(u_imgs, u_pairs, args.u8_steps, 1, u_collect, solo_pass=n_img <= 256,
+                                                              max_distance=1e9)
         u_solo = run_job.solo
         u_total = int((u_rows[u_pairs[:, 0]] * u_rows[u_pairs[:, 1]]).sum())
         i8 = u_acc["sweep1_i8_launches"] > 0
+        u_peak = PEAK_I8_MFMA_TOPS if i8 else PEAK_F16_MFMA_TFLOPS
         u_ach = 256.0 * u_acc["prefilter_descriptor_pairs"] / max(1e-9, u_acc["approx_kernel_ms"] * 1e-3) / 1e12
-        out["strong_u8"] = {
-            "workload": u_name + " (seeded subset of BASELINE configs[3]: %d of 1329 images, full per-image size)" % args.u8_images,
-            "value": u_total * args.u8_steps / u_dt, "unit": "descriptor-pairs/s", "ms_per_step": u_dt / args.u8_steps * 1e3,
-            "steps": args.u8_steps, "image_pairs": int(len(u_pairs)), "matches_per_step": int(u_res[0][-1]),
+        u_val = u_total * args.u8_steps / u_dt
+        return {
+            "workload": u_name + (" -- BASELINE configs[3] IN FULL" if full else
+                                  " (seeded subset of BASELINE configs[3]: %d of 1329 images, full per-image size)" % n_img),
+            "full_config": full,
+            "value": u_val, "unit": "descriptor-pairs/s", "ms_per_step": u_dt / args.u8_steps * 1e3,
+            "seconds_per_step": u_dt / args.u8_steps, "image_pairs_per_s": len(u_pairs) * args.u8_steps / u_dt,
+            "steps": args.u8_steps, "warmup": 1, "image_pairs": int(len(u_pairs)), "descriptor_pairs_per_step": u_total,
+            "matches_per_step": int(u_res[0][-1]), "n_gpus": world, "scaling": "strong",
             "per_rank_ms": [{"compute": c, "exchange": e} for c, e in u_per_rank],
+            "sub_batches_per_step_rank0": u_acc["sub_batches"] // max(1, args.u8_steps),
+            "order_sensitive_rows_rank0": int(u_acc["order_sensitive_rows"]) // max(1, args.u8_steps),
             "sweep1": {"instruction": "v_mfma_i32_32x32x32_i8" if i8 else "v_mfma_f32_32x32x16_f16", "achieved": u_ach,
-                       "frac": u_ach / (PEAK_I8_MFMA_TOPS if i8 else PEAK_F16_MFMA_TFLOPS),
-                       # the kernel with nothing beside it (pipeline off, after the timed steps)
+                       "frac": u_ach / u_peak, "ms_per_step_rank0": u_acc["approx_kernel_ms"] / args.u8_steps,
+                       "step_over_sweep1_rank0": (u_dt / args.u8_steps * 1e3) / max(1e-9, u_acc["approx_kernel_ms"] / args.u8_steps),
+                       # the kernel with nothing beside it (pipeline off, after the timed steps; subsets only)
                        "solo_frac": None if not u_solo or not u_solo["approx_kernel_ms"] else
-                       256.0 * u_solo["prefilter_descriptor_pairs"] / (u_solo["approx_kernel_ms"] * 1e-3) / 1e12 / (PEAK_I8_MFMA_TOPS if i8 else PEAK_F16_MFMA_TFLOPS)},
-            "full_config_seconds_at_this_rate": 882456 * 8192.0 * 8192.0 / (u_total * args.u8_steps / u_dt),
+                       256.0 * u_solo["prefilter_descriptor_pairs"] / (u_solo["approx_kernel_ms"] * 1e-3) / 1e12 / u_peak},
+            "setup": {"generate_s": gen_s, "upload_s": u_upload_s, "store_bytes": int(sum(x.nbytes for x in u_imgs))},
+            "full_config_seconds_at_this_rate": 882456 * 8192.0 * 8192.0 / u_val,
         }
+
+    if args.u8_images > 1 and args.workload == "south-building" and not args.no_prefilter:
+        if world == 1:
+            try:   # (a failure of the second job must not take the headline line with it)
+                out["strong_u8"] = u8_job()
+            except Exception as e:  # noqa: BLE001
+                out["strong_u8"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        else:
+            out["strong_u8"] = u8_job()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(imgs, pairs, budget_s=args.cpu_budget)
         out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]

@@ -115,11 +115,15 @@ int msfm_set_accum_order(msfm_ctx* ctx, int order);
  * Env: MSFM_PREFILTER=0|1|2. */
 int msfm_set_prefilter(msfm_ctx* ctx, int enable);
 int msfm_get_profile(const msfm_ctx* ctx, msfm_profile* out);
-/* msfm_match_pairs cuts a call into device sub-batches of at most `max_pairs_per_batch` image pairs and
- * `scratch_bytes` of partial-result scratch (defaults 16384 pairs / 48 GiB -- 24 GiB for each of the pipeline's scratch sets; also MSFM_MAX_PAIRS_PER_BATCH and
- * MSFM_SCRATCH_MIB in the environment at msfm_create).  Results do not depend on the cut (tests force small limits
- * to cross it); a value <= 0 restores that default.  The reference's counterpart is the 100-pair flush of
- * BruteFeatureMatcher::RunMatching (src/Feature/FeatureMatching.cpp:118-139, max_pairs_size_). */
+/* msfm_match_pairs cuts a call into device sub-batches of at most `max_pairs_per_batch` image pairs (default 16384) and of
+ * at most `scratch_bytes` of device scratch for ALL sub-batches in flight TOGETHER (three scratch sets share it, a third each;
+ * what a pair needs: msfm_pair_scratch_bytes in csrc/msfm_hostutil.h -- on the matrix-core route ~2 MB per pair of 8192-row
+ * images).  scratch_bytes <= 0 (default): 64 GiB, but never more than a quarter of what the device has free when the call starts
+ * (hipMemGetInfo + what the sets already hold); an explicit value is honoured up to three quarters of that.  The call's result
+ * lists (12 bytes per match, device + page-locked host) and the descriptor store are NOT part of this budget.  Also
+ * MSFM_MAX_PAIRS_PER_BATCH and MSFM_SCRATCH_MIB in the environment at msfm_create.  Results do not depend on the cut (tests force
+ * small limits to cross it).  The reference's counterpart is the 100-pair flush of BruteFeatureMatcher::RunMatching
+ * (src/Feature/FeatureMatching.cpp:118-139, max_pairs_size_). */
 int msfm_set_limits(msfm_ctx* ctx, int max_pairs_per_batch, int64_t scratch_bytes);
 /* A call of enough work (>= 1.5e10 descriptor pairs per part) is cut into at least `min_sub_batches` sub-batches of shrinking
  * size (the last one 0.3 of the average: what follows the call's last sweep has nothing to hide behind), launched round-robin
@@ -169,7 +173,15 @@ int msfm_fetch_matches(msfm_ctx* ctx, int32_t* out_qt, float* out_dist);
  * of squares (relative 1e-5 on a distance, derivation in csrc/msfm_kernels.hip.h).  The reference delegates S(q,t) to an
  * unpinned OpenCV (cv::BFMatcher::knnMatch, src/Feature/FeatureUtils.cpp:146-149) whose accumulation order depends on the
  * build; a pair with 0 sensitive rows has the same (queryIdx, trainIdx) list under ANY such build.  Pairs of byte images
- * are exact integers under every order (always 0).  out_sensitive_rows: n_pairs int32. */
+ * are exact integers under every order (always 0).  out_sensitive_rows: n_pairs int32.
+ * The TIE RULE, the other thing SURVEY App. C restates from memory (batchDistance keeps the lower train index among equal
+ * distances): with ratio <= 1 the match LISTS do not depend on it either.  A row whose two smallest distances are equal
+ * (d0 == d1, which is when the rule decides the first neighbour) fails `d0 < ratio * d1` under either index order, in both
+ * directions, so its index never reaches a list; a tie for the SECOND place leaves the value d1 unchanged.  So a job with 0
+ * order-sensitive rows and ratio <= 1 stores the same rows under any conforming accumulation order AND either tie order
+ * (tests/test_gpu_certificate.py::test_match_lists_do_not_depend_on_the_tie_rule flips the rule in the integer reference on
+ * the planted-tie fixture; only the knnMatch-level API msfm_knn2_pair and ratio > 1 see the rule, and implement the lower
+ * index: tie_fixup_kernel). */
 int msfm_fetch_order_certificate(msfm_ctx* ctx, int32_t* out_sensitive_rows);
 /* The same lists without the copy: pointers into the context's page-locked result buffers
  * (2 * count int32, count float), valid until the next matching call on this context or msfm_destroy. */

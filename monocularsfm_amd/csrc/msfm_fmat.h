@@ -17,10 +17,10 @@
 #pragma once
 
 #if defined(__HIPCC__)
-#define MSFM_HD __host__ __device__ inline
+#define MSFM_FHD __host__ __device__ inline
 #define MSFM_UNROLL _Pragma("unroll")
 #else
-#define MSFM_HD inline
+#define MSFM_FHD inline
 #define MSFM_UNROLL
 #endif
 
@@ -34,7 +34,7 @@ struct Norm2D {
 
 // centroid + mean-distance sqrt(2) scaling (Hartley) of the points x[idx[i]], y[idx[i]]
 template <typename IndexFn>
-MSFM_HD Norm2D normalizer(const float* x, const float* y, int n, IndexFn at) {
+MSFM_FHD Norm2D normalizer(const float* x, const float* y, int n, IndexFn at) {
     Norm2D t{0.0, 0.0, 1.0};
     for (int i = 0; i < n; ++i) {
         t.cx += (double)x[at(i)];
@@ -53,9 +53,9 @@ MSFM_HD Norm2D normalizer(const float* x, const float* y, int n, IndexFn at) {
 }
 
 // packed upper triangle of a symmetric 9 x 9 matrix: element (a, b), a <= b
-MSFM_HD constexpr int tri(int a, int b) { return a * 9 - a * (a - 1) / 2 + (b - a); }
+MSFM_FHD constexpr int tri(int a, int b) { return a * 9 - a * (a - 1) / 2 + (b - a); }
 
-MSFM_HD void moment_add(double M[45], const Norm2D& t1, const Norm2D& t2, float px1, float py1, float px2, float py2) {
+MSFM_FHD void moment_add(double M[45], const Norm2D& t1, const Norm2D& t2, float px1, float py1, float px2, float py2) {
     const double x1 = ((double)px1 - t1.cx) * t1.s, y1 = ((double)py1 - t1.cy) * t1.s;
     const double x2 = ((double)px2 - t2.cx) * t2.s, y2 = ((double)py2 - t2.cy) * t2.s;
     const double r[9] = {x2 * x1, x2 * y1, x2, y2 * x1, y2 * y1, y2, x1, y1, 1.0};
@@ -66,7 +66,7 @@ MSFM_UNROLL
 }
 
 // one Jacobi rotation of the symmetric 3 x 3 matrix (a00..a22 by reference) in the (p, q) plane
-MSFM_HD void jacobi_rot(double& app, double& aqq, double& apq, double& apr, double& aqr, double& vp0, double& vp1,
+MSFM_FHD void jacobi_rot(double& app, double& aqq, double& apq, double& apr, double& aqr, double& vp0, double& vp1,
                         double& vp2, double& vq0, double& vq1, double& vq2) {
     if (!(apq > 1e-300 || apq < -1e-300)) return;
     const double theta = (aqq - app) / (2.0 * apq);
@@ -91,7 +91,7 @@ MSFM_HD void jacobi_rot(double& app, double& aqq, double& apq, double& apr, doub
 // F (row-major 3 x 3, unit Frobenius norm, x2^T F x1 = 0) from the moment matrix of normalised points.
 // M is destroyed.  `steps` inverse-iteration steps: 2 for an 8-point sample (exact null space), more for a
 // least-squares refit whose smallest eigenvalue is the residual.  Returns false for degenerate input.
-MSFM_HD bool solve(double M[45], const Norm2D& t1, const Norm2D& t2, double F[9], int steps) {
+MSFM_FHD bool solve(double M[45], const Norm2D& t1, const Norm2D& t2, double F[9], int steps) {
     double trace = 0.0;
 MSFM_UNROLL
     for (int a = 0; a < 9; ++a) trace += M[tri(a, a)];
@@ -196,7 +196,7 @@ MSFM_UNROLL
 }
 
 // max of the squared distances of x2 to the line F x1 and of x1 to the line F^T x2 (findFundamentalMat's error)
-MSFM_HD double epipolar_error(const double F[9], float ax, float ay, float bx, float by) {
+MSFM_FHD double epipolar_error(const double F[9], float ax, float ay, float bx, float by) {
     const double x1 = ax, y1 = ay, x2 = bx, y2 = by;
     double l0 = F[0] * x1 + F[1] * y1 + F[2], l1 = F[3] * x1 + F[4] * y1 + F[5], l2 = F[6] * x1 + F[7] * y1 + F[8];
     const double d2 = x2 * l0 + y2 * l1 + l2;
@@ -211,13 +211,13 @@ MSFM_HD double epipolar_error(const double F[9], float ax, float ay, float bx, f
 }
 
 // counter-based sampling: the 8 distinct match indices of hypothesis `it` (n >= 8)
-MSFM_HD unsigned long long mix64(unsigned long long z) {
+MSFM_FHD unsigned long long mix64(unsigned long long z) {
     z += 0x9e3779b97f4a7c15ULL;
     z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL;
     z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
     return z ^ (z >> 31);
 }
-MSFM_HD void sample8(unsigned long long seed, int it, int n, int idx[8]) {
+MSFM_FHD void sample8(unsigned long long seed, int it, int n, int idx[8]) {
 MSFM_UNROLL
     for (int k = 0; k < 8; ++k) idx[k] = -1;
 MSFM_UNROLL
@@ -236,7 +236,7 @@ MSFM_UNROLL
 }
 
 // hypothesis `it`: F from its 8 sampled matches; x1/y1/x2/y2 are the pair's aligned match coordinates
-MSFM_HD bool hypothesis(const float* x1, const float* y1, const float* x2, const float* y2, int n,
+MSFM_FHD bool hypothesis(const float* x1, const float* y1, const float* x2, const float* y2, int n,
                         unsigned long long seed, int it, double F[9]) {
     int idx[8];
     sample8(seed, it, n, idx);
@@ -265,7 +265,7 @@ MSFM_UNROLL
 // and libm's log and the device library's log are different functions.  x > 0, finite, normal.
 // x = m 2^e with m in [sqrt(1/2), sqrt(2)); log m = 2 atanh(y), y = (m - 1) / (m + 1), |y| < 0.172: 20 odd terms reach
 // 1e-32 relative -- far below the double rounding of the sum.
-MSFM_HD double det_log(double x) {
+MSFM_FHD double det_log(double x) {
     unsigned long long bits;
     static_assert(sizeof(bits) == sizeof(x), "64-bit double");
     __builtin_memcpy(&bits, &x, 8);
@@ -287,7 +287,7 @@ MSFM_HD double det_log(double x) {
 }
 
 template <typename CountFn>
-MSFM_HD int replay_adaptive(int n, int max_iters, double confidence, CountFn count_at, int* best_count_out) {
+MSFM_FHD int replay_adaptive(int n, int max_iters, double confidence, CountFn count_at, int* best_count_out) {
     int best = 0, best_it = -1, iters = max_iters;
     for (int it = 0; it < iters; ++it) {
         const int c = count_at(it);

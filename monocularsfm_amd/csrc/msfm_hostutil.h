@@ -1,5 +1,6 @@
 // msfm_hostutil.h -- small pure functions shared by device and host code, compilable on their own (tests/test_hostutil.py builds a
-// g++ driver around them): the 4-byte packing of the integer sweeps' column partials, the cost marks of a call's sub-batches.
+// g++ driver around them): the 4-byte packing of the integer sweeps' column partials, the cost marks of a call's sub-batches, the
+// scratch memory one image pair of a sub-batch needs.
 #pragma once
 #include <vector>
 
@@ -49,4 +50,27 @@ inline std::vector<long long> msfm_pipeline_marks(long long total, long long n_s
         marks.push_back(k + 1 == n_sub ? total : (long long)((double)total * acc / (double)n_sub));
     }
     return marks;
+}
+
+// Device scratch ONE image pair adds to a sub-batch, in bytes -- what match_pairs_impl (msfm_match.hip) cuts a call by, and
+// what the buffers of a scratch set really hold (round 3 charged 2 x a_blocks128 x n2pad 4-byte units per pair whatever the
+// route: 2.6 - 3.4 x what the matrix-core route allocates, so a "48 GiB" budget produced 200 sub-batches of config 4 on a
+// 58 GiB footprint).  n1pad / n2pad: rows padded to 512; blocks128 / blocks512: 128- / 512-row blocks of image 1.
+//   route 1, matrix cores, match lists with ratio <= 0.95 (compacted sweep 2): row partials 2 x 4 B x n1pad | column partials
+//     8 B (fp16 route: float2; the integer routes use 4 of them) per 512-row block and column | thresholds, block masks, best /
+//     second keys, final kNN arrays: 36 B per padded row and column | staged + compact match lists 24 B per row | the plan of
+//     sweep 2 and its candidate lists for ONE SIXTEENTH of the rows alive (measured: 1 - 3.3 %; buffers that turn out too small are
+//     re-grown and the sub-batch re-run, this is only the cut): 20 B + 8 candidates x 8 B per compacted row, a column once per
+//     512-row block group (at most 32);
+//   route 2, matrix cores, dense sweep 2 (kNN-level API, ratio > 0.95): candidate lists of 16 entries per row and column instead;
+//   route 0, brute force: three 4-byte row partials per padded row, three per 128-row block and column.
+inline long long msfm_pair_scratch_bytes(int n1, int n2, int n1pad, int n2pad, int blocks128, int blocks512, int route) {
+    if (n1 <= 0 || n2 <= 0) return 0;
+    const long long common = 36LL * ((long long)n1pad + n2pad) + 24LL * n1 + 1024;
+    if (route == 0) return common + 12LL * n1pad + 12LL * (long long)blocks128 * n2pad;
+    const long long partials = 8LL * n1pad + 8LL * (long long)blocks512 * n2pad;
+    if (route == 2) return common + partials + 128LL * ((long long)n1 + n2) + 16384;
+    const long long bits = blocks512 < 32 ? blocks512 : 32;
+    const long long cmp_rows = ((long long)n1 + (long long)n2 * bits) / 16 + 1024;
+    return common + partials + 84LL * cmp_rows;
 }

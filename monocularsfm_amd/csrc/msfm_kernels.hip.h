@@ -41,6 +41,8 @@ constexpr int kLdsB = kPanelFloats;
 constexpr int kLdsFloats = kLdsB + 8 * 2 * kWaveSlotFloats;
 constexpr int kLdsBytes = kLdsFloats * 4;
 
+// the sixteen-group order (AVX-512) parks the rows' running argmin indices in LDS between tile epilogues (dist_top2_kernel)
+constexpr int kLdsBytesIdxStash = kLdsBytes + kTM * kThreads * 4;
 template <int ORDER> struct OrderTraits;
 // OpenCV 4.x SSE baseline: lanes l=0..3 x accumulators v=0..3, 8 iterations, no FMA,
 // ((d0+d1)+d2)+d3 per lane then (l0+l2)+(l1+l3): groups are processed in lane order 0,2,1,3
@@ -205,13 +207,27 @@ __device__ __forceinline__ void group_chains(const float* __restrict__ sa, const
             const float bj[kTN] = {bb.x, bb.y, bb.z, bb.w};
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                if (h == 1 && pos + 1 < kPos) {
+                // (the sixteen-group order keeps five partial-sum sets of the tree alive: its operands of the next position are
+                // fetched after this one is consumed instead -- twelve registers less, no spills; it is the cross-check order)
+                if (OT::kGroups != 16 && h == 1 && pos + 1 < kPos) {
                     // next position's LDS reads go out between the two half blocks: the wait for THIS
                     // position's operands (hipcc emits lgkmcnt(0)) then never covers a just-issued read
                     __builtin_amdgcn_sched_barrier(0);
                     a_lo = *reinterpret_cast<const v4f*>(sa + (pos + 1) * kBM);
                     a_hi = *reinterpret_cast<const v4f*>(sa + (pos + 1) * kBM + 64);
                     bb = *reinterpret_cast<const v4f*>(sb + (pos + 1) * kWaveCols);
+                }
+                if (OT::kGroups == 16) {   // (one row pair at a time: four difference registers alive instead of sixteen)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        v2f u[kTN];
+#pragma unroll
+                        for (int j = 0; j < kTN; ++j) u[j] = ap[2 * h + i] - (v2f)(bj[j]);
+#pragma unroll
+                        for (int j = 0; j < kTN; ++j)
+                            p[2 * h + i][j] = (it == 0) ? u[j] * u[j] : __builtin_elementwise_fma(u[j], u[j], p[2 * h + i][j]);
+                    }
+                    continue;
                 }
                 v2f t[2][kTN];
 #pragma unroll
@@ -240,6 +256,12 @@ __device__ __forceinline__ void group_chains(const float* __restrict__ sa, const
             // keep the scheduler from hoisting later positions' LDS reads over this block (it
             // otherwise runs out of VGPRs and spills)
             __builtin_amdgcn_sched_barrier(0);
+            if (OT::kGroups == 16 && pos + 1 < kPos) {
+                a_lo = *reinterpret_cast<const v4f*>(sa + (pos + 1) * kBM);
+                a_hi = *reinterpret_cast<const v4f*>(sa + (pos + 1) * kBM + 64);
+                bb = *reinterpret_cast<const v4f*>(sb + (pos + 1) * kWaveCols);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -303,6 +325,15 @@ __global__ __launch_bounds__(kThreads) void dist_top2_kernel(
     int r_i0[kTM];
 #pragma unroll
     for (int i = 0; i < kTM; ++i) { r_s0[i] = f_inf(); r_s1[i] = f_inf(); r_i0[i] = -1; }
+    // Sixteen groups: five partial-sum sets of the balanced tree are alive inside the fourth chunk (160 registers) next to the
+    // 32 chain accumulators -- the eight running argmin indices wait in LDS ([i][thread]: conflict-free) while the sums are
+    // formed and are only in registers during a tile's epilogue (256 VGPRs, no spill; the other orders keep them in registers).
+    constexpr bool kStashIdx = OT::kGroups == 16;
+    int* sIdx = reinterpret_cast<int*>(smem + kLdsFloats);
+    if (kStashIdx) {
+#pragma unroll
+        for (int i = 0; i < kTM; ++i) sIdx[i * kThreads + tid] = -1;
+    }
 
     v2f lvl0[4][kTN], lvl1[4][kTN], lvl2[4][kTN];  // [row pair][column]
     (void)lvl2;
@@ -383,10 +414,18 @@ __global__ __launch_bounds__(kThreads) void dist_top2_kernel(
                     if (arow0 + (i & 3) + (i >> 2) * 64 >= pd.n1 || col0 + j >= pd.n2) fin[i][j] = f_inf();
         }
         // rows: this lane's 4 train indices, ascending
+        if (kStashIdx) {
+#pragma unroll
+            for (int i = 0; i < kTM; ++i) r_i0[i] = sIdx[i * kThreads + tid];
+        }
 #pragma unroll
         for (int i = 0; i < kTM; ++i)
 #pragma unroll
             for (int j = 0; j < kTN; ++j) top2_push(r_s0[i], r_i0[i], r_s1[i], fin[i][j], col0 + j);
+        if (kStashIdx) {
+#pragma unroll
+            for (int i = 0; i < kTM; ++i) sIdx[i * kThreads + tid] = r_i0[i];
+        }
         // columns: this lane's 8 query indices (ascending), then the 16 ty lanes of the wave
 #pragma unroll
         for (int j = 0; j < kTN; ++j) {
@@ -412,6 +451,10 @@ __global__ __launch_bounds__(kThreads) void dist_top2_kernel(
     }
 
     // ---- rows: merge the 4 tx lane groups of the wave, then the 8 waves through LDS ----------
+    if (kStashIdx) {
+#pragma unroll
+        for (int i = 0; i < kTM; ++i) r_i0[i] = sIdx[i * kThreads + tid];
+    }
 #pragma unroll
     for (int i = 0; i < kTM; ++i) {
 #pragma unroll

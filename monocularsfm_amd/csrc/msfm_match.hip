@@ -92,6 +92,51 @@ struct PinnedBuf {
     template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
 };
 
+// a table inside an upload arena (Scratch::d_up): not owned, set by UploadPlan::place
+struct Ref {
+    void* p = nullptr;
+    template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+// The host tables a sub-batch uploads, packed: every table is written into ONE page-locked staging buffer and travels in ONE
+// hipMemcpyAsync into a device arena of the same layout (round 3: nine pageable copies per sub-batch, each a 5 us link of
+// the launch chain at the head of the sub-batch, from vectors that died with the issuing function -- ADVICE r03).  The
+// staging buffer belongs to the scratch set and is rewritten only after the set's previous sub-batch has been completed.
+struct UploadPlan {
+    struct Item { Ref* dst; const void* src; size_t bytes, off; };
+    std::vector<Item> items;
+    size_t total = 0;
+    void add(Ref& dst, const void* src, size_t bytes) {
+        items.push_back(Item{&dst, src, bytes, total});
+        total += (bytes + 255) & ~(size_t)255;
+    }
+    hipError_t place_and_copy(DevBuf& arena, PinnedBuf& staging, hipStream_t stream) {
+        const size_t need = std::max<size_t>(total, 256);
+        hipError_t e = arena.ensure(need);
+        if (e != hipSuccess) return e;
+        e = staging.ensure(need, 0);
+        if (e != hipSuccess) return e;
+        for (const Item& it : items) {
+            it.dst->p = static_cast<char*>(arena.p) + it.off;
+            if (it.bytes) std::memcpy(static_cast<char*>(staging.p) + it.off, it.src, it.bytes);
+        }
+        return total ? hipMemcpyAsync(arena.p, staging.p, total, hipMemcpyHostToDevice, stream) : hipSuccess;
+    }
+};
+
+// Every table a sub-batch clears before its kernels run, in ONE launch (round 3: ~27 hipMemsetAsync per sub-batch = 27 runtime
+// fill kernels of ~5 us each, without wave priority: they starved under the other stream's sweep).
+struct FillSeg {
+    void* p;
+    unsigned long long bytes;
+    unsigned value;   // the byte, replicated
+};
+constexpr int kFillSegs = 12;
+struct FillSegs {
+    FillSeg s[kFillSegs];
+    int n;
+};
+
 struct Image {
     int n = -1;  // -1: not uploaded
     int nblk = 0;    // 128-row blocks holding data
@@ -141,8 +186,12 @@ void free_image(Image& im) {
 }
 
 constexpr int kSlots = 2 * MSFM_MAX_IMAGES + 2;  // ids >= MSFM_MAX_IMAGES: auxiliary (top-scale subsets, two operator-level scratch slots)
-// sub-batches of msfm_match_pairs are bounded by the partial-result scratch (4-byte units: ~48 GiB of the 288 GB) and a pair count
-constexpr long long kDefaultScratchElems = (long long)12 << 30;
+// Sub-batches of msfm_match_pairs are bounded by a pair count and by the device scratch of ALL scratch sets in flight together
+// (msfm_pair_scratch_bytes per pair, msfm_hostutil.h): at most kDefaultScratchBytes, and never more than a quarter of what the
+// device has free when the call starts (hipMemGetInfo + what the sets already hold) -- a 9-second job gains ~2.5 % from 7
+// instead of 19 sub-batches per 80 000 pairs, but every GiB of scratch costs ~10 ms the first time it is allocated
+// (profiles/r04_scratch_ab.txt).
+constexpr long long kDefaultScratchBytes = (long long)64 << 30;
 constexpr int kDefaultMaxPairsPerBatch = 16384;
 constexpr int kMaxPairsPerBatchLimit = 65535;   // gridDim.y
 // A call large enough is cut into at least this many sub-batches so that the bandwidth-bound tail of one (thresholds, plan,
@@ -174,7 +223,13 @@ struct PfPending {                // what the end-of-batch synchronisation has t
 
 struct Scratch {
     hipStream_t stream = nullptr;
-    DevBuf d_pairs, d_items, d_item_base;
+    // upload arenas + their page-locked staging: [0] pair tables of the matrix-core route, [1] plan tables of sweep 2, [2] pair tables
+    // of the brute-force route (a sub-batch may run both routes: the first route's copy may still be in flight)
+    DevBuf d_up[3];
+    PinnedBuf h_up[3];
+    Ref d_pairs, d_pf, d_pfq, d_item_base;                                   // in d_up[0] / d_up[2]
+    Ref d_groups, d_gmembers, d_member_pair, d_member_group, d_ppair;       // in d_up[1]
+    DevBuf d_items;
     DevBuf d_rp_s0, d_rp_i0, d_rp_s1, d_cp_s0, d_cp_i0, d_cp_s1;
     DevBuf d_k_i0, d_k_d0, d_k_d1;
     DevBuf d_st_qt, d_st_d, d_counts, d_offsets, d_sens;
@@ -182,11 +237,11 @@ struct Scratch {
     DevBuf d_fix_count, d_fix_list;
     int fix_cap_eff = 0;              // capacity handed to the kernels of the current batch (0: ties need no fix-up)
     // prefilter path
-    DevBuf d_pf, d_tu, d_tv, d_cand, d_cand_count, d_best, d_second;
+    DevBuf d_tu, d_tv, d_cand, d_cand_count, d_best, d_second;
     DevBuf d_cmp_tu, d_live_idx, d_row_pair, d_row_src, d_vpairs, d_vpf, d_vitems, d_lists;
-    DevBuf d_pfq, d_cmp_s0, d_cmp_s1, d_summary_a;   // route Q: twin pair table, sweep 1' row results, summary of plan A
+    DevBuf d_cmp_s0, d_cmp_s1, d_summary_a;   // route Q: sweep 1' row results, summary of plan A
     // device-side plan of the compacted sweep 2 (msfm_plan.hip.h)
-    DevBuf d_colmask, d_groups, d_gmembers, d_member_pair, d_member_group, d_gtot, d_grow0, d_ppair, d_cnt, d_mrow, d_summary, d_overflow, d_totals;
+    DevBuf d_colmask, d_gtot, d_grow0, d_cnt, d_mrow, d_summary, d_overflow, d_totals;
     PfPending pf_pending;
     PinnedBuf h_summary;              // PlanSummary | totals[2] | overflow bytes
     PinnedBuf h_tail;                 // tie-queue count | CSR offsets [P + 1] | certificate counts [P]: read at the end of the sub-batch
@@ -199,15 +254,24 @@ struct Scratch {
     hipEvent_t sweep2_done = nullptr; // recorded behind sweep 2: the sweep 1 two sub-batches later waits for it (three sets in flight)
     bool sweep2_recorded = false;
     long long seq = 0;                // number of the sub-batch this set works on (msfm_ctx::issue_seq)
-    void release_all() {
-        DevBuf* bufs[] = {&d_pairs, &d_items, &d_item_base, &d_rp_s0, &d_rp_i0, &d_rp_s1, &d_cp_s0, &d_cp_i0, &d_cp_s1, &d_k_i0, &d_k_d0,
-                          &d_k_d1, &d_st_qt, &d_st_d, &d_counts, &d_offsets, &d_sens, &d_sub_qt, &d_sub_d, &d_fix_count, &d_fix_list, &d_pf, &d_tu,
+    void for_each_buf(void (*fn)(DevBuf&, void*), void* arg) {
+        DevBuf* bufs[] = {&d_up[0], &d_up[1], &d_up[2], &d_items, &d_rp_s0, &d_rp_i0, &d_rp_s1, &d_cp_s0, &d_cp_i0, &d_cp_s1, &d_k_i0, &d_k_d0,
+                          &d_k_d1, &d_st_qt, &d_st_d, &d_counts, &d_offsets, &d_sens, &d_sub_qt, &d_sub_d, &d_fix_count, &d_fix_list, &d_tu,
                           &d_tv, &d_cand, &d_cand_count, &d_best, &d_second, &d_cmp_tu, &d_live_idx, &d_row_pair, &d_row_src,
-                          &d_vpairs, &d_vpf, &d_vitems, &d_lists, &d_colmask, &d_groups, &d_gmembers, &d_member_pair,
-                          &d_member_group, &d_gtot, &d_grow0, &d_ppair, &d_cnt, &d_mrow, &d_summary, &d_overflow, &d_totals, &d_vf_pairs,
+                          &d_vpairs, &d_vpf, &d_vitems, &d_lists, &d_colmask, &d_gtot, &d_grow0, &d_cnt, &d_mrow, &d_summary, &d_overflow,
+                          &d_totals, &d_vf_pairs,
                           &d_vf_x1, &d_vf_y1, &d_vf_x2, &d_vf_y2, &d_vf_hyp, &d_vf_best_it, &d_vf_best_count, &d_vf_flags, &d_st2_qt,
-                          &d_st2_d, &d_counts2, &d_pfq, &d_cmp_s0, &d_cmp_s1, &d_summary_a};
-        for (DevBuf* b : bufs) b->release();
+                          &d_st2_d, &d_counts2, &d_cmp_s0, &d_cmp_s1, &d_summary_a};
+        for (DevBuf* b : bufs) fn(*b, arg);
+    }
+    long long device_bytes() {
+        long long sum = 0;
+        for_each_buf([](DevBuf& b, void* a) { *static_cast<long long*>(a) += (long long)b.cap; }, &sum);
+        return sum;
+    }
+    void release_all() {
+        for_each_buf([](DevBuf& b, void*) { b.release(); }, nullptr);
+        for (PinnedBuf& h : h_up) h.release();
         h_summary.release();
         h_tail.release();
     }
@@ -229,7 +293,7 @@ struct msfm_ctx {
     int fix_cap = 1 << 16;            // entries of the sqrt-space tie queue; grows on overflow (the sub-batch is re-run)
     // sub-batch limits of msfm_match_pairs (msfm_set_limits / MSFM_MAX_PAIRS_PER_BATCH / MSFM_SCRATCH_MIB)
     int max_pairs_per_batch = kDefaultMaxPairsPerBatch;
-    long long scratch_elems = kDefaultScratchElems;
+    long long scratch_bytes = 0;      // msfm_set_limits / MSFM_SCRATCH_MIB: total for the scratch sets in flight; 0 = automatic (above)
     long long issue_seq = 0;          // sub-batches issued so far
     double pipeline_taper = 0.3;      // size of a call's last part relative to the average part (MSFM_PIPELINE_TAPER; 1: equal parts)
     int in_flight = kInFlight;        // scratch sets used (MSFM_IN_FLIGHT=1 at msfm_create: no sub-batch overlap, for A/B measurements)
@@ -305,6 +369,9 @@ struct Batch {
     int max_npad = 0;
     int64_t desc_pairs = 0;
     int64_t algo_bytes = 0;
+    // host tables of copies that are still in flight when the issuing function returns (they live as long as the sub-batch)
+    std::vector<CandList> dense_lists;
+    std::vector<VerifyPair> verify_pairs;
 };
 
 // Work items of the pairs whose `path` matches: only their NUMBERING is made on the host -- per pair the index of its
@@ -445,22 +512,61 @@ hipEvent_t get_event(msfm_ctx* ctx, size_t i) {
     return ctx->ev_pool[i];
 }
 
-int upload_pairs(msfm_ctx* ctx, Batch& b) {
-    const size_t P = b.pairs.size();
-    HIPCHK(ctx, SC.d_pairs.ensure(P * sizeof(PairDesc)));
-    HIPCHK(ctx, SC.d_pf.ensure(P * sizeof(PfPair)));
-    HIPCHK(ctx, hipMemcpyAsync(SC.d_pairs.p, b.pairs.data(), P * sizeof(PairDesc), hipMemcpyHostToDevice, SC.stream));
-    HIPCHK(ctx, hipMemcpyAsync(SC.d_pf.p, b.pf.data(), P * sizeof(PfPair), hipMemcpyHostToDevice, SC.stream));
-    return MSFM_OK;
+__global__ void fill_segs_kernel(FillSegs segs) {
+    MSFM_TAIL_PRIO();
+    const unsigned long long tid = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x, nt = (unsigned long long)gridDim.x * blockDim.x;
+    for (int k = 0; k < segs.n; ++k) {
+        const FillSeg e = segs.s[k];
+        const unsigned w = e.value * 0x01010101u;
+        // (device allocations and arena offsets are 256-byte aligned: 16-byte stores, then the tail)
+        const unsigned long long n16 = e.bytes >> 4;
+        uint4* p16 = reinterpret_cast<uint4*>(e.p);
+        for (unsigned long long i = tid; i < n16; i += nt) p16[i] = make_uint4(w, w, w, w);
+        for (unsigned long long i = (n16 << 4) + tid; i < e.bytes; i += nt) reinterpret_cast<unsigned char*>(e.p)[i] = (unsigned char)e.value;
+    }
 }
 
-int upload_items(msfm_ctx* ctx, Batch& b, int path) {
+struct FillBatch {
+    FillSegs segs = {};
+    unsigned long long bytes = 0;
+    std::vector<FillSegs> full;
+    void add(void* p, size_t n, unsigned value) {
+        if (!p || n == 0) return;
+        if (segs.n == kFillSegs) {
+            full.push_back(segs);
+            segs = FillSegs{};
+        }
+        segs.s[segs.n++] = FillSeg{p, (unsigned long long)n, value & 255u};
+        bytes += n;
+    }
+    hipError_t launch(hipStream_t stream) {
+        if (segs.n) full.push_back(segs);
+        // one wave per SIMD and CU at most: small enough to run beside a resident sweep workgroup, enough stores in flight for the
+        // tens of MB the row-source table of a sub-batch takes
+        const unsigned grid = (unsigned)std::max<unsigned long long>(1, std::min<unsigned long long>(256, (bytes + 65535) / 65536));
+        for (const FillSegs& f : full) hipLaunchKernelGGL(fill_segs_kernel, dim3(grid), dim3(256), 0, stream, f);
+        full.clear();
+        segs = FillSegs{};
+        bytes = 0;
+        return hipGetLastError();
+    }
+};
+
+// The pair tables of one route of the sub-batch (slot 0: matrix-core route, 2: brute-force route) in ONE copy, the work-item list
+// cleared (pair = -1: padding item) together with `more` in ONE fill launch, the items written by build_items_kernel.
+int upload_pair_tables(msfm_ctx* ctx, Batch& b, int path, const std::vector<PfPair>* pfq, FillBatch& fills) {
     const size_t P = b.pairs.size();
+    const int slot = path == 1 ? 0 : 2;
+    UploadPlan up;
+    up.add(SC.d_pairs, b.pairs.data(), P * sizeof(PairDesc));
+    up.add(SC.d_pf, b.pf.data(), P * sizeof(PfPair));
+    if (pfq) up.add(SC.d_pfq, pfq->data(), P * sizeof(PfPair));
+    up.add(SC.d_item_base, b.item_base.data(), b.item_base.size() * 4);
+    HIPCHK(ctx, up.place_and_copy(SC.d_up[slot], SC.h_up[slot], SC.stream));
     HIPCHK(ctx, SC.d_items.ensure(std::max<size_t>(1, b.n_items) * sizeof(WorkItem)));
+    fills.add(SC.d_items.p, b.n_items * sizeof(WorkItem), 0xff);
+    HIPCHK(ctx, fills.launch(SC.stream));
     if (b.n_items == 0) return MSFM_OK;
-    HIPCHK(ctx, SC.d_item_base.ensure(P * 4));
-    HIPCHK(ctx, hipMemsetAsync(SC.d_items.p, 0xff, b.n_items * sizeof(WorkItem), SC.stream));   // pair = -1: padding item
-    HIPCHK(ctx, hipMemcpyAsync(SC.d_item_base.p, b.item_base.data(), P * 4, hipMemcpyHostToDevice, SC.stream));
     hipLaunchKernelGGL(build_items_kernel, dim3((unsigned)P), dim3(64), 0, SC.stream, (const PairDesc*)SC.d_pairs.as<PairDesc>(),
                        (const int*)SC.d_item_base.as<int>(), path, (int)b.items_per_xcd, SC.d_items.as<WorkItem>());
     HIPCHK(ctx, hipGetLastError());
@@ -694,21 +800,17 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
     HIPCHK(ctx, SC.d_colmask.ensure(kn * 4));
     HIPCHK(ctx, SC.d_best.ensure(kn * 8));
     HIPCHK(ctx, SC.d_second.ensure(kn * 8));
-    int rc = upload_pairs(ctx, b);
-    if (rc != MSFM_OK) return rc;
-    rc = upload_items(ctx, b, 1);
-    if (rc != MSFM_OK) return rc;
-    if (q8) {
-        HIPCHK(ctx, SC.d_pfq.ensure(P * sizeof(PfPair)));
-        HIPCHK(ctx, hipMemcpyAsync(SC.d_pfq.p, pfq.data(), P * sizeof(PfPair), hipMemcpyHostToDevice, SC.stream));
-    }
-    if (!compact) {   // (compacted sweep 2: pf_assign_kernel initialises the live slots only)
-        HIPCHK(ctx, hipMemsetAsync(SC.d_best.p, 0xff, kn * 8, SC.stream));
-        HIPCHK(ctx, hipMemsetAsync(SC.d_second.p, 0xff, kn * 8, SC.stream));
-    }
     HIPCHK(ctx, SC.d_overflow.ensure(P));
     HIPCHK(ctx, SC.d_totals.ensure(64));   // [0..1] candidate / overflow totals (64-bit), ints [8..15]: per-XCD item cursors of sweep 2
-    HIPCHK(ctx, hipMemsetAsync(SC.d_totals.p, 0, 64, SC.stream));
+    FillBatch fills;
+    if (!compact) {   // (compacted sweep 2: pf_assign_kernel initialises the live slots only)
+        fills.add(SC.d_best.p, (size_t)kn * 8, 0xff);
+        fills.add(SC.d_second.p, (size_t)kn * 8, 0xff);
+    }
+    fills.add(SC.d_totals.p, 64, 0);
+    fills.add(SC.d_overflow.p, P, 0);   // (which pairs own an overflowed list: pf_overflow_kernel at the end of the chain)
+    int rc = upload_pair_tables(ctx, b, 1, q8 ? &pfq : nullptr, fills);
+    if (rc != MSFM_OK) return rc;
 
     hipEvent_t e0 = get_event(ctx, ev_base), e1 = get_event(ctx, ev_base + 1);
     hipEvent_t e2 = get_event(ctx, ev_base + 2), e3 = get_event(ctx, ev_base + 3);
@@ -776,13 +878,8 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
         const long long cand_cap = std::max<long long>(8 * rows_cap + 2048LL * (long long)G, ctx->cand_hint);
         // (the list holds 8 x the longest per-XCD sub-list: twice the balanced size leaves room for skew)
         const long long items_cap = std::max<long long>(2 * ((rows_cap / kPfWgRows + (long long)G) * max_ranges + 64) / 8 * 8, (ctx->items_hint + 64) / 8 * 8);
-        HIPCHK(ctx, SC.d_groups.ensure(std::max<size_t>(1, G) * sizeof(PlanGroup)));
-        HIPCHK(ctx, SC.d_gmembers.ensure(std::max<size_t>(1, M) * 4));
-        HIPCHK(ctx, SC.d_member_pair.ensure(std::max<size_t>(1, M) * 4));
-        HIPCHK(ctx, SC.d_member_group.ensure(std::max<size_t>(1, M) * 4));
         HIPCHK(ctx, SC.d_gtot.ensure(std::max<size_t>(1, G) * 4));
         HIPCHK(ctx, SC.d_grow0.ensure((4 * std::max<size_t>(1, G) + 8) * 8));   // grow0 | gpos[3] | fwd_items_x[8]
-        HIPCHK(ctx, SC.d_ppair.ensure(P * sizeof(PlanPair)));
         HIPCHK(ctx, SC.d_cnt.ensure(std::max<size_t>(1, M) * 4));
         HIPCHK(ctx, SC.d_mrow.ensure(std::max<size_t>(1, M) * 8));
         HIPCHK(ctx, SC.d_summary.ensure(sizeof(PlanSummary)));
@@ -796,24 +893,27 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
         HIPCHK(ctx, SC.d_row_src.ensure((size_t)rows_cap * 8));
         HIPCHK(ctx, SC.d_cand.ensure((size_t)cand_cap * sizeof(int2)));
         HIPCHK(ctx, SC.d_cand_count.ensure(std::max<size_t>(1, G) * 8));
-        if (G > 0) {
-            HIPCHK(ctx, hipMemcpyAsync(SC.d_groups.p, cp.groups.data(), G * sizeof(PlanGroup), hipMemcpyHostToDevice, SC.stream));
-            HIPCHK(ctx, hipMemcpyAsync(SC.d_gmembers.p, cp.gmembers.data(), M * 4, hipMemcpyHostToDevice, SC.stream));
-            HIPCHK(ctx, hipMemcpyAsync(SC.d_member_pair.p, cp.member_pair.data(), M * 4, hipMemcpyHostToDevice, SC.stream));
-            HIPCHK(ctx, hipMemcpyAsync(SC.d_member_group.p, cp.member_group.data(), M * 4, hipMemcpyHostToDevice, SC.stream));
+        {   // the plan's static tables in one copy (page-locked staging of this scratch set), everything it clears in one launch
+            UploadPlan up;
+            up.add(SC.d_groups, cp.groups.data(), G * sizeof(PlanGroup));
+            up.add(SC.d_gmembers, cp.gmembers.data(), M * 4);
+            up.add(SC.d_member_pair, cp.member_pair.data(), M * 4);
+            up.add(SC.d_member_group, cp.member_group.data(), M * 4);
+            up.add(SC.d_ppair, cp.ppair.data(), P * sizeof(PlanPair));
+            HIPCHK(ctx, up.place_and_copy(SC.d_up[1], SC.h_up[1], SC.stream));
+            FillBatch fb;
+            fb.add(SC.d_gtot.p, std::max<size_t>(1, G) * 4, 0);
+            fb.add(SC.d_cnt.p, std::max<size_t>(1, M) * 4, 0);
+            // (pf_plan_write_kernel stores only the non-zero fields of the groups' descriptors)
+            fb.add(SC.d_vpairs.p, std::max<size_t>(1, G) * sizeof(PairDesc), 0);
+            fb.add(SC.d_vpf.p, std::max<size_t>(1, G) * sizeof(PfPair), 0);
+            fb.add(SC.d_lists.p, std::max<size_t>(1, G) * sizeof(CandList), 0);
+            fb.add(SC.d_summary.p, sizeof(PlanSummary), 0);
+            fb.add(SC.d_vitems.p, (size_t)items_cap * sizeof(WorkItem), 0xff);
+            fb.add(SC.d_row_src.p, (size_t)rows_cap * 8, 0);
+            fb.add(SC.d_cand_count.p, std::max<size_t>(1, G) * 8, 0);
+            HIPCHK(ctx, fb.launch(SC.stream));
         }
-        HIPCHK(ctx, hipMemsetAsync(SC.d_gtot.p, 0, std::max<size_t>(1, G) * 4, SC.stream));
-        HIPCHK(ctx, hipMemcpyAsync(SC.d_ppair.p, cp.ppair.data(), P * sizeof(PlanPair), hipMemcpyHostToDevice, SC.stream));
-        // (the uploads above come from pageable vectors that die with this function: hipMemcpyAsync has staged them when it returns)
-        HIPCHK(ctx, hipMemsetAsync(SC.d_cnt.p, 0, std::max<size_t>(1, M) * 4, SC.stream));
-        // (pf_plan_write_kernel stores only the non-zero fields of the groups' descriptors)
-        HIPCHK(ctx, hipMemsetAsync(SC.d_vpairs.p, 0, std::max<size_t>(1, G) * sizeof(PairDesc), SC.stream));
-        HIPCHK(ctx, hipMemsetAsync(SC.d_vpf.p, 0, std::max<size_t>(1, G) * sizeof(PfPair), SC.stream));
-        HIPCHK(ctx, hipMemsetAsync(SC.d_lists.p, 0, std::max<size_t>(1, G) * sizeof(CandList), SC.stream));
-        HIPCHK(ctx, hipMemsetAsync(SC.d_summary.p, 0, sizeof(PlanSummary), SC.stream));
-        HIPCHK(ctx, hipMemsetAsync(SC.d_vitems.p, 0xff, (size_t)items_cap * sizeof(WorkItem), SC.stream));
-        HIPCHK(ctx, hipMemsetAsync(SC.d_row_src.p, 0, (size_t)rows_cap * 8, SC.stream));
-        HIPCHK(ctx, hipMemsetAsync(SC.d_cand_count.p, 0, std::max<size_t>(1, G) * 8, SC.stream));
         hc.lap("plan tables + uploads");
         const PlanPair* dpp = SC.d_ppair.as<PlanPair>();
         PlanCounts pc = {dpp, (const int*)SC.d_member_group.as<int>(), SC.d_cnt.as<int>(), SC.d_gtot.as<int>()};
@@ -898,14 +998,16 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
             HIPCHK(ctx, hipGetLastError());
             DBGSYNC(ctx, "q8_scatter_kernel");
             // plan B starts from clean counters, work items, row sources and item cursors
-            HIPCHK(ctx, hipMemsetAsync(SC.d_gtot.p, 0, std::max<size_t>(1, G) * 4, SC.stream));
-            HIPCHK(ctx, hipMemsetAsync(SC.d_cnt.p, 0, std::max<size_t>(1, M) * 4, SC.stream));
-            HIPCHK(ctx, hipMemsetAsync(SC.d_vpairs.p, 0, std::max<size_t>(1, G) * sizeof(PairDesc), SC.stream));
-            HIPCHK(ctx, hipMemsetAsync(SC.d_vpf.p, 0, std::max<size_t>(1, G) * sizeof(PfPair), SC.stream));
-            HIPCHK(ctx, hipMemsetAsync(SC.d_lists.p, 0, std::max<size_t>(1, G) * sizeof(CandList), SC.stream));
-            HIPCHK(ctx, hipMemsetAsync(SC.d_vitems.p, 0xff, (size_t)items_cap * sizeof(WorkItem), SC.stream));
-            HIPCHK(ctx, hipMemsetAsync(SC.d_row_src.p, 0, (size_t)rows_cap * 8, SC.stream));
-            HIPCHK(ctx, hipMemsetAsync(SC.d_totals.p, 0, 64, SC.stream));
+            FillBatch fb;
+            fb.add(SC.d_gtot.p, std::max<size_t>(1, G) * 4, 0);
+            fb.add(SC.d_cnt.p, std::max<size_t>(1, M) * 4, 0);
+            fb.add(SC.d_vpairs.p, std::max<size_t>(1, G) * sizeof(PairDesc), 0);
+            fb.add(SC.d_vpf.p, std::max<size_t>(1, G) * sizeof(PfPair), 0);
+            fb.add(SC.d_lists.p, std::max<size_t>(1, G) * sizeof(CandList), 0);
+            fb.add(SC.d_vitems.p, (size_t)items_cap * sizeof(WorkItem), 0xff);
+            fb.add(SC.d_row_src.p, (size_t)rows_cap * 8, 0);
+            fb.add(SC.d_totals.p, 64, 0);
+            HIPCHK(ctx, fb.launch(SC.stream));
         }
         // thresholds + live counts per member / group (the plan tables above are uploaded by now; sweep 1 is still running)
         if (!q8_direct)
@@ -945,7 +1047,8 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
     } else {
         // ---- dense sweep 2: the pairs' own lists, the sweep-1 items again ----------------------------------------
         n_lists = P;
-        std::vector<CandList> lists(P);
+        std::vector<CandList>& lists = b.dense_lists;   // (lives as long as the sub-batch: the copy below may still be in flight)
+        lists.resize(P);
         for (size_t p = 0; p < P; ++p)
             lists[p] = CandList{(int)p, 0, b.pf[p].cand_off, b.pf[p].cand_cap, 0, nullptr, nullptr};
         HIPCHK(ctx, SC.d_cand.ensure(std::max<long long>(1, dense_cand) * sizeof(int2)));
@@ -953,7 +1056,6 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
         HIPCHK(ctx, SC.d_lists.ensure(P * sizeof(CandList)));
         HIPCHK(ctx, hipMemsetAsync(SC.d_cand_count.p, 0, P * 8, SC.stream));
         HIPCHK(ctx, hipMemcpyAsync(SC.d_lists.p, lists.data(), P * sizeof(CandList), hipMemcpyHostToDevice, SC.stream));
-        HIPCHK(ctx, hipMemcpyAsync(SC.d_pf.p, b.pf.data(), P * sizeof(PfPair), hipMemcpyHostToDevice, SC.stream));  // cand_off / cap
         HIPCHK(ctx, hipEventRecord(e2, SC.stream));
         hipLaunchKernelGGL(sweep_kernel<2>, dim3(std::min<unsigned>(sweep_grid, (unsigned)b.n_items)), block, kPfLdsBytes, SC.stream, dp, dpf,
                            SC.d_items.as<WorkItem>(), (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr,
@@ -969,12 +1071,15 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
     }
 
     if (n_lists > 0) {
-        const dim3 cgrid(64, (unsigned)std::min<size_t>(n_lists, 65535));   // (the kernels stride over the lists in y)
+        // list l on XCD l mod 8, by that XCD's workgroups in spans of consecutive candidates (see the kernel): 8 workgroups of
+        // 4 waves per CU when it has the chip to itself, one per CU fits next to a resident sweep workgroup
+        const int wgs_per_xcd = std::max(1, ctx->cu_count / 8) * 8;
+        const dim3 cgrid((unsigned)(8 * wgs_per_xcd));
         const unsigned long long* dcount = SC.d_cand_count.as<unsigned long long>();
 #define MSFM_LAUNCH_EXACT(O)                                                                                             \
     hipLaunchKernelGGL(pf_exact_candidates_kernel<O>, cgrid, dim3(256), 0, SC.stream, dp, dl, dcount,                      \
                        (const int2*)SC.d_cand.as<int2>(), SC.d_best.as<unsigned long long>(), SC.d_second.as<unsigned long long>(), \
-                       (int)n_lists)
+                       (int)n_lists, wgs_per_xcd)
         if (ctx->order == MSFM_ORDER_SSE4X4) MSFM_LAUNCH_EXACT(0);
         else if (ctx->order == MSFM_ORDER_AVX2_FMA) MSFM_LAUNCH_EXACT(1);
         else MSFM_LAUNCH_EXACT(3);
@@ -988,7 +1093,6 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
     HIPCHK(ctx, hipGetLastError());
     DBGSYNC(ctx, "pf_finalize_kernel");
     // which pairs own an overflowed list, how many candidates were evaluated: read at the end of the batch
-    HIPCHK(ctx, hipMemsetAsync(SC.d_overflow.p, 0, P, SC.stream));
     if (n_lists > 0) {
         hipLaunchKernelGGL(pf_overflow_kernel, dim3((unsigned)((n_lists + 255) / 256)), dim3(256), 0, SC.stream, dl, (int)n_lists,
                            (const unsigned long long*)SC.d_cand_count.as<unsigned long long>(), (const PlanGroup*)SC.d_groups.as<PlanGroup>(),
@@ -1111,9 +1215,8 @@ int run_exact(msfm_ctx* ctx, Batch& b, size_t ev_base) {
     HIPCHK(ctx, SC.d_cp_s0.ensure(std::max<long long>(1, b.cp_elems) * 4));
     HIPCHK(ctx, SC.d_cp_i0.ensure(std::max<long long>(1, b.cp_elems) * 4));
     HIPCHK(ctx, SC.d_cp_s1.ensure(std::max<long long>(1, b.cp_elems) * 4));
-    int rc = upload_pairs(ctx, b);
-    if (rc != MSFM_OK) return rc;
-    rc = upload_items(ctx, b, 0);
+    FillBatch fills;
+    int rc = upload_pair_tables(ctx, b, 0, nullptr, fills);
     if (rc != MSFM_OK) return rc;
     hipEvent_t e0 = get_event(ctx, ev_base), e1 = get_event(ctx, ev_base + 1);
     if (!e0 || !e1) return fail(ctx, MSFM_E_DEVICE, "hipEventCreate failed");
@@ -1123,7 +1226,7 @@ int run_exact(msfm_ctx* ctx, Batch& b, size_t ev_base) {
     HIPCHK(ctx, hipEventRecord(e0, SC.stream));
     const dim3 grid((unsigned)b.n_items), block(kThreads);
 #define MSFM_LAUNCH_DIST(O)                                                                                               \
-    hipLaunchKernelGGL(dist_top2_kernel<O>, grid, block, kLdsBytes, SC.stream, SC.d_pairs.as<PairDesc>(), SC.d_items.as<WorkItem>(), \
+    hipLaunchKernelGGL(dist_top2_kernel<O>, grid, block, (O) == 3 ? kLdsBytesIdxStash : kLdsBytes, SC.stream, SC.d_pairs.as<PairDesc>(), SC.d_items.as<WorkItem>(), \
                        SC.d_rp_s0.as<float>(), SC.d_rp_i0.as<int>(), SC.d_rp_s1.as<float>(), SC.d_cp_s0.as<float>(),             \
                        SC.d_cp_i0.as<int>(), SC.d_cp_s1.as<float>())
     if (ctx->order == MSFM_ORDER_SSE4X4) MSFM_LAUNCH_DIST(0);
@@ -1177,7 +1280,10 @@ int run_knn(msfm_ctx* ctx, Batch& b, size_t ev_base, bool* exact_launched, Prune
         if (rc != MSFM_OK) return rc;
         *exact_launched = b.n_items != 0;
     } else if (!any_pf) {
-        rc = upload_pairs(ctx, b);  // later kernels still read the (all-invalid) pair table
+        b.item_base.assign(b.pairs.size(), -1);
+        b.n_items = 0;
+        FillBatch fills;
+        rc = upload_pair_tables(ctx, b, 0, nullptr, fills);  // later kernels still read the (all-invalid) pair table
         if (rc != MSFM_OK) return rc;
     }
     // (no queue -- match lists with ratio <= 1 -- no fix-up launch: the kernel's 86 registers would not fit next to the other
@@ -1313,7 +1419,7 @@ int msfm_create(int device_ordinal, msfm_ctx** out_ctx) {
     hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(dist_top2_kernel<1>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
     if (e1 == hipSuccess)
-        e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(dist_top2_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+        e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(dist_top2_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytesIdxStash);
     if (e0 != hipSuccess || e1 != hipSuccess) {
         std::fprintf(stderr, "msfm_create: cannot reserve %d bytes of LDS: %s\n", kLdsBytes,
                      hipGetErrorString(e0 != hipSuccess ? e0 : e1));
@@ -1361,7 +1467,7 @@ int msfm_create(int device_ordinal, msfm_ctx** out_ctx) {
     if (const char* e = std::getenv("MSFM_PIPELINE"))
         if (std::atoi(e) > 0) ctx->pipeline = std::min(std::atoi(e), 64);
     if (const char* e = std::getenv("MSFM_SCRATCH_MIB"))
-        if (std::atoll(e) > 0) ctx->scratch_elems = std::atoll(e) * (1 << 20) / 4;
+        if (std::atoll(e) > 0) ctx->scratch_bytes = std::atoll(e) * (1LL << 20);
     *out_ctx = ctx;
     return MSFM_OK;
 }
@@ -1436,7 +1542,7 @@ int msfm_set_limits(msfm_ctx* ctx, int max_pairs_per_batch, int64_t scratch_byte
     if (!ctx) return MSFM_E_INVALID;
     // (the pair index of a sub-batch is gridDim.y of several kernels: at most 65535)
     ctx->max_pairs_per_batch = max_pairs_per_batch > 0 ? std::min(max_pairs_per_batch, kMaxPairsPerBatchLimit) : kDefaultMaxPairsPerBatch;
-    ctx->scratch_elems = scratch_bytes > 0 ? std::max<long long>(1, scratch_bytes / 4) : kDefaultScratchElems;
+    ctx->scratch_bytes = scratch_bytes > 0 ? scratch_bytes : 0;
     return MSFM_OK;
 }
 
@@ -1804,7 +1910,20 @@ static int match_pairs_impl(msfm_ctx* ctx, const int32_t* pairs, int n_pairs, co
 
     // ---- the cut: scratch memory per set, pair count, and a cost limit that gives a large call >= `pipeline` sub-batches
     const int kSets = ctx->in_flight;
-    const long long kScratchElems = std::max<long long>(1, ctx->scratch_elems / std::min(kSets, 2));   // the scratch sets share the budget (a third set: +50 %)
+    // the scratch sets in flight SHARE the budget (three sets at half of it each were 1.5 x the documented limit)
+    long long budget = ctx->scratch_bytes > 0 ? ctx->scratch_bytes : kDefaultScratchBytes;
+    {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            long long held = 0;   // what the scratch sets hold already is theirs to use
+            for (Scratch& sc : ctx->sc) held += sc.device_bytes();
+            const long long avail = (long long)free_b + held;
+            budget = std::min(budget, ctx->scratch_bytes > 0 ? avail * 3 / 4 : avail / 4);
+        }
+    }
+    const long long kScratchBytes = std::max<long long>(1, budget / kSets);
+    // which buffers a pair needs (msfm_pair_scratch_bytes): 0 brute force, 1 matrix cores + compacted sweep 2, 2 + dense sweep 2
+    const int scratch_route = !ctx->prefilter ? 0 : ((prune.ratio > 0.f && prune.ratio <= 0.95f) ? 1 : 2);
     const int kMaxPairsPerBatch = ctx->max_pairs_per_batch;
     // cumulative-cost marks of the parts (empty: no cost cut): msfm_pipeline_marks (msfm_hostutil.h) -- shrinking parts
     std::vector<long long> marks;
@@ -1854,11 +1973,10 @@ static int match_pairs_impl(msfm_ctx* ctx, const int32_t* pairs, int n_pairs, co
                     return fail(ctx, MSFM_E_STATE, "geometric verification needs msfm_upload_keypoints for image " +
                                                        std::to_string(ia.nk < ia.n ? pairs[2 * end] : pairs[2 * end + 1]));
             }
-            // partial-result scratch of the larger of the two paths (prefilter: 2x slots + candidates)
-            const long long need = pd.valid ? ((long long)pd.n1pad + 2 * (long long)pd.a_blocks * pd.n2pad +
-                                               3 * (8LL * (pd.n1 + pd.n2) + 1024)) : 0;
+            const long long need = pd.valid ? msfm_pair_scratch_bytes(pd.n1, pd.n2, pd.n1pad, pd.n2pad, pd.a_blocks, pd.a_blocks256,
+                                                                     pp.use ? scratch_route : 0) : 0;
             const long long c = pd.valid ? (long long)pd.n1 * pd.n2 : 0;
-            if (end > begin && est + need > kScratchElems) break;
+            if (end > begin && est + need > kScratchBytes) break;
             if (end > begin && !marks.empty() && cost_begin + cost + c / 2 > mark) break;
             est += need;
             cost += c;
@@ -1909,7 +2027,8 @@ static int match_pairs_impl(msfm_ctx* ctx, const int32_t* pairs, int n_pairs, co
         if (verify) {
             // FeatureUtils::FilterMatches on the staged lists: all hypotheses of all pairs at once
             VerifyParams vprm = {verify->threshold * verify->threshold, verify->confidence, verify->max_iters, 0, verify->seed};
-            std::vector<VerifyPair> vpairs(P);
+            std::vector<VerifyPair>& vpairs = b.verify_pairs;   // (lives as long as the sub-batch: the copy below may still be in flight)
+            vpairs.resize(P);
             for (size_t p = 0; p < P; ++p)
                 vpairs[p] = VerifyPair{ctx->images[pairs[2 * (begin + (int)p)]].kxy, ctx->images[pairs[2 * (begin + (int)p) + 1]].kxy};
             HIPCHK(ctx, SC.d_vf_pairs.ensure(P * sizeof(VerifyPair)));

@@ -348,20 +348,35 @@ __device__ __forceinline__ unsigned long long pf_key(float s, int idx) {
 
 // exact pinned-order S for every candidate: 16 lanes per candidate (SSE order: lane L owns the
 // lane partial k = L mod 16; AVX2 order: 32 partials -> 2 per lane), coalesced 64-B row reads.
-// Records are rewritten in place as real (q, t).   grid = (x, n_lists)
+//
+// WHERE a candidate is evaluated decides what the kernel costs: it is a gather of two 512-byte rows per candidate, and round 3
+// dealt 16-candidate windows of every list round-robin over all workgroups -- i.e. over the eight XCDs and their separate L2
+// caches -- so that 25 M candidates fetched 21 GB from memory (PMC) although they name only ~5 M distinct compacted rows and a
+// few hundred streamed images.  A list (= one group of sweep 2) has two kinds of locality:
+//   * its candidates arrive in chunks of <= 256 written by ONE wave of sweep 2 (flush_candidates): 64 compacted rows against the
+//     few tiles that wave swept since its last flush -- ~5 candidates per compacted row sit close together in the list;
+//   * every candidate of the list names a row of the SAME streamed image (or 512-row block group of it): <= 2.5 MB at 5000 rows.
+// So: list l is evaluated on XCD l mod 8 only (a workgroup's XCD is blockIdx.x mod 8: hardware round-robin), by the
+// `wgs_per_xcd` workgroups of that XCD in spans of kExSpan consecutive candidates -- the streamed image stays in that XCD's 4 MB
+// L2 while its list is worked off, a compacted row's second to fifth use hits the workgroup's L1 / the L2.
+// grid = 8 * wgs_per_xcd.
+constexpr int kExSpan = 256;
 template <int ORDER>
 __global__ void pf_exact_candidates_kernel(const PairDesc* __restrict__ pairs, const CandList* __restrict__ lists,
                                            const unsigned long long* __restrict__ cand_count, const int2* __restrict__ cand,
                                            unsigned long long* __restrict__ best, unsigned long long* __restrict__ second /* the reduction rides along */,
-                                           int n_lists) {
+                                           int n_lists, int wgs_per_xcd) {
     MSFM_TAIL_PRIO();
-  for (int lid = blockIdx.y; lid < n_lists; lid += gridDim.y) {   // (more lists than gridDim.y allows: stride)
+    const int xcd = blockIdx.x & 7, wg = blockIdx.x >> 3;
+  for (int lid = xcd; lid < n_lists; lid += 8) {
     const CandList L = lists[lid];
     if (L.cap == 0) continue;
     const int n = (int)(cand_count[lid] < (unsigned long long)L.cap ? cand_count[lid] : (unsigned long long)L.cap);
     const int sub = threadIdx.x & 15;
-    for (int c = (blockIdx.x * blockDim.x + threadIdx.x) >> 4; c < ((n + 3) & ~3); c += (gridDim.x * blockDim.x) >> 4) {
-        const bool live = c < n;
+   for (int c0 = wg * kExSpan; c0 < n; c0 += wgs_per_xcd * kExSpan) {
+    const int c1 = min(n, c0 + kExSpan), c_end = c0 + ((c1 - c0 + 3) & ~3);   // (whole waves take part in the shuffles)
+    for (int c = c0 + (threadIdx.x >> 4); c < c_end; c += blockDim.x >> 4) {
+        const bool live = c < c1;
         int2 qt = live ? cand[L.off + c] : make_int2(0, 0);
         int pair = L.mode == 0 ? L.pair : L.row_pair[live ? qt.x : 0];
         if (!live && L.mode != 0) pair = L.row_pair[0], qt = make_int2(0, 0);
@@ -442,6 +457,7 @@ __global__ void pf_exact_candidates_kernel(const PairDesc* __restrict__ pairs, c
             }
         }
     }
+   }
   }
 }
 

@@ -44,9 +44,12 @@ def s_matrix(A, B, rows=None):
     return S
 
 
-def knn2(A, B, rows=None, block=512):
+def knn2(A, B, rows=None, block=512, tie="lowest"):
     """-> idx0, d0, idx1, d1 like BFMatcher(NORM_L2).knnMatch(A[rows], B, k=2): per query the two smallest
-    sqrtf(S) under (distance ascending, train index ascending); -1 / FLT_MAX where fewer neighbours exist."""
+    sqrtf(S) under (distance ascending, train index ascending); -1 / FLT_MAX where fewer neighbours exist.
+    tie="highest" flips the tie rule (equal distances: the HIGHER train index first) -- not what batchDistance does
+    (SURVEY App. C restates its rule from memory); it exists so that the tests can show which results do NOT depend on it."""
+    assert tie in ("lowest", "highest")
     Ai, Bi = _as_int(A), _as_int(B)
     if rows is not None:
         Ai = Ai[np.asarray(rows)]
@@ -62,7 +65,10 @@ def knn2(A, B, rows=None, block=512):
         D = np.sqrt(S.astype(F32))      # S < 2^24: the conversion is exact; IEEE sqrt is correctly rounded
         # batchDistance compares the distance BIT PATTERNS (non-negative floats: same order) and keeps the lower
         # train index on ties: a stable sort on D is that rule
-        order = np.argsort(D.view(np.int32), axis=1, kind="stable")[:, :2]
+        if tie == "lowest":
+            order = np.argsort(D.view(np.int32), axis=1, kind="stable")[:, :2]
+        else:
+            order = n2 - 1 - np.argsort(D.view(np.int32)[:, ::-1], axis=1, kind="stable")[:, :2]
         r = np.arange(D.shape[0])
         idx0[s:s + block] = order[:, 0]
         d0[s:s + block] = D[r, order[:, 0]]
@@ -72,29 +78,29 @@ def knn2(A, B, rows=None, block=512):
     return idx0, d0, idx1, d1
 
 
-def compute_matches(A, B, ratio=0.8):
+def compute_matches(A, B, ratio=0.8, tie="lowest"):
     """FeatureUtils::ComputeMatches: keep (q, idx0) iff d0 < fl32(ratio * d1), strict; train < 2 rows -> none."""
     n1, n2 = len(A), len(B)
     if n1 == 0 or n2 < 2:
         z = np.zeros(0, np.int32)
         return z, z.copy(), np.zeros(0, F32)
-    i0, d0, _, d1 = knn2(A, B)
+    i0, d0, _, d1 = knn2(A, B, tie=tie)
     thr = (F32(ratio) * d1).astype(F32)       # one fp32 multiply, single rounding
     keep = d0 < thr
     q = np.nonzero(keep)[0].astype(np.int32)
     return q, i0[keep].astype(np.int32), d0[keep]
 
 
-def match_pair(A, B, ratio=0.8, cross_check=True, max_distance=0.7):
+def match_pair(A, B, ratio=0.8, cross_check=True, max_distance=0.7, tie="lowest"):
     """ComputeCrossMatches / ComputeMatches + FilterMatchesByDistance, as MatchImagePairs chains them."""
     if cross_check and (len(A) < 2 or len(B) < 2):
         # one direction has a train set of < 2 rows: undefined in the reference (FeatureUtils.cpp:152 indexes the 2nd
         # neighbour unconditionally); build-defined as "no matches" (include/msfm_match.h, msfm_oracle.c)
         z = np.zeros(0, np.int32)
         return z, z.copy(), np.zeros(0, F32)
-    q, t, d = compute_matches(A, B, ratio)
+    q, t, d = compute_matches(A, B, ratio, tie)
     if cross_check:
-        rq, rt, _ = compute_matches(B, A, ratio)
+        rq, rt, _ = compute_matches(B, A, ratio, tie)
         # vis[reverse query] = reverse train; a missing key reads as 0 (unordered_map::operator[], FeatureUtils.cpp:302)
         vis = {int(a): int(b) for a, b in zip(rq, rt)}
         keep = np.array([vis.get(int(tt), 0) == int(qq) for qq, tt in zip(q, t)], bool) if len(q) else np.zeros(0, bool)

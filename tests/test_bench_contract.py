@@ -35,6 +35,19 @@ def test_bench_line_contract():
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in rf, k
     assert rf["bound"] in ("hbm", "mfma", "valu") and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
+    # `traffic`, `algorithmic_bytes_per_launch` and `achieved` refer to ONE launch unit: this run's average sweep-1 launch
+    lps = rf["launches_per_step"]
+    assert abs(lps - rf["launches"] / d["steps"]) < 1e-9
+    assert abs(rf["algorithmic_bytes_per_launch"] * lps - rf["algorithmic_bytes_per_step"]) < 1e-6 * rf["algorithmic_bytes_per_step"]
+    assert abs(rf["descriptor_pairs_per_launch"] * lps - d["config"]["descriptor_pairs_per_step"]) < 1e-6 * d["config"]["descriptor_pairs_per_step"]
+    assert rf["algorithmic_bytes_per_launch_operand_rows"] < rf["algorithmic_bytes_per_launch"]
+    if rf["traffic"] is not None:
+        assert "per launch of THIS run" in rf["traffic_unit"]
+        assert abs(rf["traffic"] * lps - rf["traffic_per_step"]) < 1e-6 * rf["traffic_per_step"]
+        assert abs(rf["traffic_over_algorithmic"] - rf["traffic"] / rf["algorithmic_bytes_per_launch"]) < 1e-9
+        assert abs(rf["traffic_over_algorithmic"] - rf["traffic_per_step"] / rf["algorithmic_bytes_per_step"]) < 1e-6
+    su = d["strong_u8"]
+    assert su["full_config"] is False and su["n_gpus"] == 1 and su["scaling"] == "strong" and su["sweep1"]["frac"] > 0
     cb = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in cb, k
@@ -62,3 +75,26 @@ def test_bench_two_ranks_sharing_the_gpu():
     assert r1.returncode == 0, r1.stderr[-2000:]
     d1 = json.loads([l for l in r1.stdout.splitlines() if l.startswith("{")][0])
     assert d1["config"]["matches_per_step"] == d["config"]["matches_per_step"]
+
+
+def test_bench_gpus_2_launches_itself():
+    """`python bench.py --gpus 2` WITHOUT torchrun in the command (the form of the driver's BENCH command with N changed): the
+    script becomes the launcher, rank 0's JSON line is the only line on stdout, the exit code is the job's."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--images", "20", "--u8-images", "5", "--backend", "gloo", "--share-gpu"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and len(d["per_rank_ms"]) == 2
+    assert d["config"]["image_pairs"] == 190 and d["config"]["matches_per_step"] > 0
+    su = d["strong_u8"]
+    assert su["n_gpus"] == 2 and su["image_pairs"] == 10 and len(su["per_rank_ms"]) == 2 and su["value"] > 0
+    # a failing job's exit code comes back through the launcher (more ranks than this box has GPUs, RCCL, no --share-gpu)
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                          "--images", "8", "--u8-images", "0"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    import torch
+    if torch.cuda.device_count() < 2:
+        assert bad.returncode != 0 and not [l for l in bad.stdout.splitlines() if l.startswith("{")]

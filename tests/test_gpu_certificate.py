@@ -141,3 +141,34 @@ def test_byte_images_are_exact_under_every_order(gpu_ctx):
     cert = gpu_ctx.order_certificate(len(pairs))
     for p in range(len(pairs)):
         assert cert[p] == expected_count(gpu_ctx, *pairs[p], max_distance=1e9)
+
+
+def test_match_lists_do_not_depend_on_the_tie_rule(gpu_ctx):
+    """The other half of SURVEY App. C: batchDistance's tie rule (lower train index among equal distances) is restated from
+    memory like the accumulation order.  On the planted-tie fixture the device lists equal the integer reference with the rule
+    FLIPPED (highest index first) for every ratio <= 1 -- a job with 0 order-sensitive rows is independent of both
+    (/root/reference/src/Feature/FeatureUtils.cpp:146-156; include/msfm_match.h next to msfm_fetch_order_certificate)."""
+    import os
+    from oracle import int_oracle
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "u8_ties_150x161.npz"))
+    A, B = g["desc1"], g["desc2"]
+    lo, hi = int_oracle.knn2(A, B), int_oracle.knn2(A, B, tie="highest")
+    assert (lo[0] != hi[0]).any()                                    # the fixture does contain first-place ties
+    for as_bytes in (True, False):                                   # byte upload / the same values in the CV_32F table
+        gpu_ctx.upload_image(0, A.astype(np.uint8) if as_bytes else A.astype(F32))
+        gpu_ctx.upload_image(1, B.astype(np.uint8) if as_bytes else B.astype(F32))
+        for prefilter in (1, 2, 0):                                  # integer cores / fp16 cores + exact re-check / brute force
+            gpu_ctx.set_prefilter(prefilter)
+            try:
+                for ratio in (0.8, 1.0):
+                    for cc in (True, False):
+                        q, t, d = gpu_ctx.match_pair(0, 1, ratio, cc, 1e9)
+                        rq, rt, rd = int_oracle.match_pair(A, B, ratio, cc, 1e9, tie="highest")
+                        assert len(rq) > 0 and np.array_equal(q, rq) and np.array_equal(t, rt), (as_bytes, prefilter, ratio, cc)
+                        assert np.array_equal(d.view(np.int32), np.asarray(rd, F32).view(np.int32))
+                assert gpu_ctx.profile()["order_sensitive_rows"] == 0       # byte values: exact under every order
+            finally:
+                gpu_ctx.set_prefilter(True)
+    # the knnMatch-level API does see the rule, and implements the LOWER index
+    (fi, fd0, fd1), _ = gpu_ctx.knn2_pair(0, 1)
+    assert np.array_equal(fi, lo[0]) and not np.array_equal(fi, hi[0])

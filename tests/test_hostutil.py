@@ -4,7 +4,8 @@
     largest may only be SMALLER than the true one (it is used as an upper bound of the column's second-smallest distance: every
     pruning / threshold bound of the prefilter stays valid) and by at most 1/16 of the gap;
   * the cost marks of a large call's sub-batches (msfm_set_pipeline): increasing, ending at the total, parts shrinking towards the
-    end, the last one `taper` of the average.
+    end, the last one `taper` of the average;
+  * the device scratch one image pair adds to a sub-batch (what a call is cut by), and its Python twin in tools/config4_full.py.
 The reference's counterpart of the second is the fixed 100-pair flush of BruteFeatureMatcher::RunMatching
 (/root/reference/src/Feature/FeatureMatching.cpp:118-139)."""
 import os
@@ -70,6 +71,18 @@ int main() {
                 if (last < taper * avg * 0.999 - 2 || last > taper * avg * 1.001 + 2) { std::printf("last part %.0f vs %.0f\n", last, taper * avg); return 1; }
             }
     if (!msfm_pipeline_marks(1000, 1, 0.3).empty() || !msfm_pipeline_marks(1000, 0, 0.3).empty()) { std::printf("marks for one part\n"); return 1; }
+    // scratch per pair: monotone in the sizes, the three routes differ, printed for the Python twin in tools/config4_full.py
+    const int sizes[][2] = {{8192, 8192}, {16384, 16384}, {5038, 4711}, {100, 100}, {1, 700}};
+    for (auto& z : sizes) {
+        const int n1 = z[0], n2 = z[1], n1pad = (n1 + 511) / 512 * 512, n2pad = (n2 + 511) / 512 * 512;
+        const long long r1 = msfm_pair_scratch_bytes(n1, n2, n1pad, n2pad, (n1 + 127) / 128, n1pad / 512, 1);
+        const long long r0 = msfm_pair_scratch_bytes(n1, n2, n1pad, n2pad, (n1 + 127) / 128, n1pad / 512, 0);
+        const long long r2 = msfm_pair_scratch_bytes(n1, n2, n1pad, n2pad, (n1 + 127) / 128, n1pad / 512, 2);
+        if (r0 <= 0 || r1 <= 0 || r2 <= r1 - 84LL * (((long long)n1 + (long long)n2 * 32) / 16 + 1024)) { std::printf("scratch routes\n"); return 1; }
+        if (msfm_pair_scratch_bytes(n1 + 512, n2, n1pad + 512, n2pad, (n1 + 639) / 128, n1pad / 512 + 1, 1) <= r1) { std::printf("scratch not monotone\n"); return 1; }
+        std::printf("scratch %d %d %lld\n", n1, n2, r1);
+    }
+    if (msfm_pair_scratch_bytes(0, 700, 0, 1024, 0, 0, 1) != 0) { std::printf("empty side\n"); return 1; }
     std::printf("ok %lld\n", checked);
     return 0;
 }
@@ -84,4 +97,16 @@ def test_packed_column_partials_and_pipeline_marks(tmp_path):
     assert cc.returncode == 0, cc.stderr
     run = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
     assert run.returncode == 0, run.stdout + run.stderr
-    assert run.stdout.startswith("ok ") and int(run.stdout.split()[1]) > 1000000   # (gaps beyond ~1e6 drop the second: not counted)
+    lines = run.stdout.splitlines()
+    assert lines[-1].startswith("ok ") and int(lines[-1].split()[1]) > 1000000   # (gaps beyond ~1e6 drop the second: not counted)
+    # the sub-batch cut predicted by tools/config4_full.py uses a Python twin of msfm_pair_scratch_bytes: same numbers
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("config4_full", os.path.join(HERE, "..", "tools", "config4_full.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    twins = [l.split() for l in lines if l.startswith("scratch ")]
+    assert len(twins) == 5
+    for _, n1, n2, want in twins:
+        assert mod.pair_scratch_bytes(int(n1), int(n2)) == int(want), (n1, n2)
+    # config 4: ~2 MB per pair -> the default 64 GiB / 3 sets holds ~8 000 pairs per sub-batch (round 3: 4 400 in "48 GiB")
+    assert 1.5e6 < mod.pair_scratch_bytes(8192, 8192) < 3.0e6

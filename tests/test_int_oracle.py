@@ -110,6 +110,27 @@ def test_integer_reference_reproduces_the_u8_fixtures(path):
         assert np.array_equal(np.sort(S, 1)[:, 0], g["int_fwd_s0"]) and np.array_equal(np.sort(S, 1)[:, 1], g["int_fwd_s1"])
 
 
+def test_match_lists_do_not_depend_on_the_tie_rule():
+    """ratio <= 1: a row with d0 == d1 fails `d0 < ratio * d1` whichever tied index comes first, so flipping the tie rule
+    (highest train index first) changes knnMatch's idx0 on the planted ties but not one entry of the match lists
+    (FeatureUtils.cpp:146-156; the header states it next to msfm_fetch_order_certificate)."""
+    g = np.load(os.path.join(HERE, "golden", "u8_ties_150x161.npz"))
+    A, B = g["desc1"], g["desc2"]
+    lo, hi = io.knn2(A, B), io.knn2(A, B, tie="highest")
+    assert np.array_equal(b(lo[1]), b(hi[1])) and np.array_equal(b(lo[3]), b(hi[3]))     # the distance VALUES never depend on it
+    flipped = np.nonzero(lo[0] != hi[0])[0]
+    assert len(flipped) >= 1 and (lo[1][flipped] == lo[3][flipped]).all()                  # idx0 differs exactly on d0 == d1 rows
+    for ratio in (0.8, 0.95, 1.0):
+        for cc in (True, False):
+            ref = io.match_pair(A, B, ratio, cc, 1e9)
+            alt = io.match_pair(A, B, ratio, cc, 1e9, tie="highest")
+            assert len(ref[0]) > 0 and all(np.array_equal(b(x), b(y)) for x, y in zip(ref, alt)), (ratio, cc)
+    # ... and with ratio > 1 it DOES matter (which is why the library runs the tie fix-up there)
+    ref = io.match_pair(A, B, 1.5, False, 1e9)
+    alt = io.match_pair(A, B, 1.5, False, 1e9, tie="highest")
+    assert not np.array_equal(ref[1], alt[1])
+
+
 def test_rejects_non_integer_input():
     with pytest.raises(ValueError):
         io.knn2(np.full((2, 128), 0.5, np.float32), np.zeros((2, 128), np.float32))
