@@ -206,7 +206,13 @@ def main():
         env.setdefault("OMP_NUM_THREADS", "2")
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
                "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-        raise SystemExit(subprocess.call(cmd, env=env))
+        # (the ranks print one thing on stdout -- rank 0's JSON line -- but libraries under them may not keep to that: gloo
+        # announces its connections there; anything that is not the line goes to stderr)
+        proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+        for line in proc.stdout:
+            (sys.stdout if line.startswith("{") else sys.stderr).write(line)
+            sys.stdout.flush()
+        raise SystemExit(proc.wait())
 
     import torch
     import torch.distributed as dist

@@ -237,7 +237,7 @@ struct Scratch {
     DevBuf d_fix_count, d_fix_list;
     int fix_cap_eff = 0;              // capacity handed to the kernels of the current batch (0: ties need no fix-up)
     // prefilter path
-    DevBuf d_tu, d_tv, d_cand, d_cand_count, d_best, d_second;
+    DevBuf d_tu, d_tv, d_cand, d_cand_ps, d_cand_count, d_best, d_second;
     DevBuf d_cmp_tu, d_live_idx, d_row_pair, d_row_src, d_vpairs, d_vpf, d_vitems, d_lists;
     DevBuf d_cmp_s0, d_cmp_s1, d_summary_a;   // route Q: sweep 1' row results, summary of plan A
     // device-side plan of the compacted sweep 2 (msfm_plan.hip.h)
@@ -257,7 +257,7 @@ struct Scratch {
     void for_each_buf(void (*fn)(DevBuf&, void*), void* arg) {
         DevBuf* bufs[] = {&d_up[0], &d_up[1], &d_up[2], &d_items, &d_rp_s0, &d_rp_i0, &d_rp_s1, &d_cp_s0, &d_cp_i0, &d_cp_s1, &d_k_i0, &d_k_d0,
                           &d_k_d1, &d_st_qt, &d_st_d, &d_counts, &d_offsets, &d_sens, &d_sub_qt, &d_sub_d, &d_fix_count, &d_fix_list, &d_tu,
-                          &d_tv, &d_cand, &d_cand_count, &d_best, &d_second, &d_cmp_tu, &d_live_idx, &d_row_pair, &d_row_src,
+                          &d_tv, &d_cand, &d_cand_ps, &d_cand_count, &d_best, &d_second, &d_cmp_tu, &d_live_idx, &d_row_pair, &d_row_src,
                           &d_vpairs, &d_vpf, &d_vitems, &d_lists, &d_colmask, &d_gtot, &d_grow0, &d_cnt, &d_mrow, &d_summary, &d_overflow,
                           &d_totals, &d_vf_pairs,
                           &d_vf_x1, &d_vf_y1, &d_vf_x2, &d_vf_y2, &d_vf_hyp, &d_vf_best_it, &d_vf_best_count, &d_vf_flags, &d_st2_qt,
@@ -892,6 +892,7 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
         HIPCHK(ctx, SC.d_row_pair.ensure((size_t)rows_cap * 4));
         HIPCHK(ctx, SC.d_row_src.ensure((size_t)rows_cap * 8));
         HIPCHK(ctx, SC.d_cand.ensure((size_t)cand_cap * sizeof(int2)));
+        HIPCHK(ctx, SC.d_cand_ps.ensure((size_t)cand_cap * sizeof(int2)));
         HIPCHK(ctx, SC.d_cand_count.ensure(std::max<size_t>(1, G) * 8));
         {   // the plan's static tables in one copy (page-locked staging of this scratch set), everything it clears in one launch
             UploadPlan up;
@@ -1052,6 +1053,7 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
         for (size_t p = 0; p < P; ++p)
             lists[p] = CandList{(int)p, 0, b.pf[p].cand_off, b.pf[p].cand_cap, 0, nullptr, nullptr};
         HIPCHK(ctx, SC.d_cand.ensure(std::max<long long>(1, dense_cand) * sizeof(int2)));
+        HIPCHK(ctx, SC.d_cand_ps.ensure(std::max<long long>(1, dense_cand) * sizeof(int2)));
         HIPCHK(ctx, SC.d_cand_count.ensure(P * 8));
         HIPCHK(ctx, SC.d_lists.ensure(P * sizeof(CandList)));
         HIPCHK(ctx, hipMemsetAsync(SC.d_cand_count.p, 0, P * 8, SC.stream));
@@ -1073,19 +1075,26 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
     if (n_lists > 0) {
         // list l on XCD l mod 8, by that XCD's workgroups in spans of consecutive candidates (see the kernel): 8 workgroups of
         // 4 waves per CU when it has the chip to itself, one per CU fits next to a resident sweep workgroup
-        const int wgs_per_xcd = std::max(1, ctx->cu_count / 8) * 8;
+#ifndef MSFM_EX_WGMULT
+#define MSFM_EX_WGMULT 8
+#endif
+        const int wgs_per_xcd = std::max(1, ctx->cu_count / 8) * MSFM_EX_WGMULT;
         const dim3 cgrid((unsigned)(8 * wgs_per_xcd));
         const unsigned long long* dcount = SC.d_cand_count.as<unsigned long long>();
 #define MSFM_LAUNCH_EXACT(O)                                                                                             \
     hipLaunchKernelGGL(pf_exact_candidates_kernel<O>, cgrid, dim3(256), 0, SC.stream, dp, dl, dcount,                      \
-                       (const int2*)SC.d_cand.as<int2>(), SC.d_best.as<unsigned long long>(), SC.d_second.as<unsigned long long>(), \
-                       (int)n_lists, wgs_per_xcd)
+                       SC.d_cand.as<int2>(), SC.d_cand_ps.as<int2>(), SC.d_best.as<unsigned long long>(), (int)n_lists, wgs_per_xcd)
         if (ctx->order == MSFM_ORDER_SSE4X4) MSFM_LAUNCH_EXACT(0);
         else if (ctx->order == MSFM_ORDER_AVX2_FMA) MSFM_LAUNCH_EXACT(1);
         else MSFM_LAUNCH_EXACT(3);
 #undef MSFM_LAUNCH_EXACT
         HIPCHK(ctx, hipGetLastError());
         DBGSYNC(ctx, "pf_exact_candidates_kernel");
+        hipLaunchKernelGGL(pf_second_kernel, dim3(32, (unsigned)std::min<size_t>(n_lists, 65535)), dim3(256), 0, SC.stream, dp, dl, dcount,
+                           (const int2*)SC.d_cand.as<int2>(), (const int2*)SC.d_cand_ps.as<int2>(),
+                           (const unsigned long long*)SC.d_best.as<unsigned long long>(), SC.d_second.as<unsigned long long>(), (int)n_lists);
+        HIPCHK(ctx, hipGetLastError());
+        DBGSYNC(ctx, "pf_second_kernel");
     }
     hipLaunchKernelGGL(pf_finalize_kernel, mgrid, dim3(256), 0, SC.stream, dp, dpf, (const float*)tuv, SC.d_best.as<unsigned long long>(),
                        SC.d_second.as<unsigned long long>(), SC.d_k_i0.as<int>(), SC.d_k_d0.as<float>(),

@@ -356,24 +356,82 @@ __device__ __forceinline__ unsigned long long pf_key(float s, int idx) {
 //   * its candidates arrive in chunks of <= 256 written by ONE wave of sweep 2 (flush_candidates): 64 compacted rows against the
 //     few tiles that wave swept since its last flush -- ~5 candidates per compacted row sit close together in the list;
 //   * every candidate of the list names a row of the SAME streamed image (or 512-row block group of it): <= 2.5 MB at 5000 rows.
-// So: list l is evaluated on XCD l mod 8 only (a workgroup's XCD is blockIdx.x mod 8: hardware round-robin), by the
-// `wgs_per_xcd` workgroups of that XCD in spans of kExSpan consecutive candidates -- the streamed image stays in that XCD's 4 MB
-// L2 while its list is worked off, a compacted row's second to fifth use hits the workgroup's L1 / the L2.
-// grid = 8 * wgs_per_xcd.
-constexpr int kExSpan = 256;
+// So: list l is evaluated on XCD l mod 8 only (a workgroup's XCD is blockIdx.x mod 8: hardware round-robin), in spans of kExSpan
+// consecutive candidates dealt round-robin over the `wgs_per_xcd` workgroups of that XCD ACROSS the XCD's lists (span g of the
+// XCD's concatenated lists -> workgroup g mod wgs_per_xcd: a per-list deal would hand the first workgroups every short list
+// -- measured 2.5 x slower).  Every workgroup builds the prefix sums of its XCD's span counts in LDS (one gather of the list
+// lengths + a block scan, ~4 us) and finds the list of a span by binary search there.  The streamed image stays in the XCD's
+// 4 MB L2 while its list is worked off, a compacted row's second to fifth use hits the L1 / L2.   grid = 8 * wgs_per_xcd.
+#ifndef MSFM_EX_SPAN
+#define MSFM_EX_SPAN 256
+#endif
+#ifndef MSFM_EX_GLOBAL      // experiment switch: 1 = spans dealt over ALL workgroups, whatever their XCD
+#define MSFM_EX_GLOBAL 0
+#endif
+constexpr int kExSpan = MSFM_EX_SPAN;
+constexpr int kExLists = 1024;   // lists per XCD and round of the prefix table (4 per thread)
 template <int ORDER>
-__global__ void pf_exact_candidates_kernel(const PairDesc* __restrict__ pairs, const CandList* __restrict__ lists,
-                                           const unsigned long long* __restrict__ cand_count, const int2* __restrict__ cand,
-                                           unsigned long long* __restrict__ best, unsigned long long* __restrict__ second /* the reduction rides along */,
-                                           int n_lists, int wgs_per_xcd) {
+__global__ __launch_bounds__(256) void pf_exact_candidates_kernel(
+    const PairDesc* __restrict__ pairs, const CandList* __restrict__ lists, const unsigned long long* __restrict__ cand_count,
+    int2* __restrict__ cand /* in: the sweep's records; out: the real (q, t) */, int2* __restrict__ cand_ps /* out: (pair, S bits) */,
+    unsigned long long* __restrict__ best, int n_lists, int wgs_per_xcd) {
     MSFM_TAIL_PRIO();
-    const int xcd = blockIdx.x & 7, wg = blockIdx.x >> 3;
-  for (int lid = xcd; lid < n_lists; lid += 8) {
-    const CandList L = lists[lid];
-    if (L.cap == 0) continue;
-    const int n = (int)(cand_count[lid] < (unsigned long long)L.cap ? cand_count[lid] : (unsigned long long)L.cap);
+    __shared__ int s_base[kExLists + 1];   // s_base[i] = spans of the XCD's lists before list i of the round
+    __shared__ int s_part[256];
+    const int lstride = MSFM_EX_GLOBAL ? 1 : 8;
+    const int xcd = MSFM_EX_GLOBAL ? 0 : (int)(blockIdx.x & 7), wg = MSFM_EX_GLOBAL ? (int)blockIdx.x : (int)(blockIdx.x >> 3);
+    if (MSFM_EX_GLOBAL) wgs_per_xcd = (int)gridDim.x;
+    const int my_lists = n_lists > xcd ? (n_lists - xcd + lstride - 1) / lstride : 0;
     const int sub = threadIdx.x & 15;
-   for (int c0 = wg * kExSpan; c0 < n; c0 += wgs_per_xcd * kExSpan) {
+    int rot = 0;   // spans dealt in earlier rounds, mod wgs_per_xcd: the deal goes on where it stopped
+  for (int l0 = 0; l0 < my_lists; l0 += kExLists) {
+    const int nl = min(kExLists, my_lists - l0);
+    // ---- span counts of this round's lists -> exclusive prefix sums in s_base ----
+    int cnt4[4], mine = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int i = 4 * threadIdx.x + j;
+        int ns = 0;
+        if (i < nl) {
+            const int lid = xcd + lstride * (l0 + i);
+            const int cap = lists[lid].cap;
+            const unsigned long long cc = cand_count[lid];
+            const int n = (int)(cc < (unsigned long long)cap ? cc : (unsigned long long)cap);
+            ns = (n + kExSpan - 1) / kExSpan;
+        }
+        cnt4[j] = ns;
+        mine += ns;
+    }
+    __syncthreads();   // (the previous round's readers of s_base are done)
+    s_part[threadIdx.x] = mine;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {
+        const int v = (int)threadIdx.x >= d ? s_part[threadIdx.x - d] : 0;
+        __syncthreads();
+        s_part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    int run = s_part[threadIdx.x] - mine;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        s_base[4 * threadIdx.x + j] = run;
+        run += cnt4[j];
+    }
+    if (threadIdx.x == 255) s_base[kExLists] = run;
+    __syncthreads();
+    const int total = s_base[kExLists];
+    const int first = (wg - rot % wgs_per_xcd + wgs_per_xcd) % wgs_per_xcd;
+   for (int g = first; g < total; g += wgs_per_xcd) {
+    // the list of span g: the last i with s_base[i] <= g (lists without spans repeat their successor's base: skipped by "last")
+    int lo = 0, hi = kExLists;   // invariant: s_base[lo] <= g < s_base[hi]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (s_base[mid] <= g) lo = mid; else hi = mid;
+    }
+    const int lid = xcd + lstride * (l0 + lo);
+    const CandList L = lists[lid];
+    const int n = (int)(cand_count[lid] < (unsigned long long)L.cap ? cand_count[lid] : (unsigned long long)L.cap);
+    const int c0 = (g - s_base[lo]) * kExSpan;
     const int c1 = min(n, c0 + kExSpan), c_end = c0 + ((c1 - c0 + 3) & ~3);   // (whole waves take part in the shuffles)
     for (int c = c0 + (threadIdx.x >> 4); c < c_end; c += blockDim.x >> 4) {
         const bool live = c < c1;
@@ -438,30 +496,67 @@ __global__ void pf_exact_candidates_kernel(const PairDesc* __restrict__ pairs, c
             res = ((sv[0] + sv[1]) + (sv[2] + sv[3])) + ((sv[4] + sv[5]) + (sv[6] + sv[7]));
         }
         if (live && sub == 0) {
-            // The reduction rides along: best AND second (S, idx) per row and per column among the candidates, two 64-bit
-            // atomicMin per entry and direction.  atomicMin(best) returns the old best: the LOSER of that update -- the old best
-            // if the new key displaced it, else the new key -- goes into `second`.  Every key except the final minimum is a
-            // loser exactly once, the final minimum never: second ends as the second smallest key (a key arriving twice would
-            // meet itself as the old best: skipped).  Round 2 re-read the whole candidate list in a second kernel for this.
+            // The BEST key per row / column rides along as a fire-and-forget 64-bit atomicMin (no return value: the wave does not
+            // wait for it).  Round 3 took the old value back and pushed the loser of every update into `second` right here: two
+            // DEPENDENT returning atomics behind every candidate -- with a row's ~5 candidates now evaluated back to back by one
+            // workgroup they queued up on the same address and the kernel got 60 % SLOWER although it fetched 37 % less (profiles/
+            // r04_exact_xcd_local_ab.txt).  The second-best key is pf_second_kernel's, from the records written here: the real
+            // (q, t) in place of the sweep's record, (pair, S bits) beside it; S = +inf: batchDistance never inserts it.
             // A mode-1 list only serves the row direction, a mode-2 list only the column direction: the live rows of the OTHER
             // direction get their complete candidate sets from their own list.
-            if (res < f_inf()) {   // batchDistance never inserts a distance >= FLT_MAX
-                auto fold = [&](long long slot, unsigned long long key) {
-                    const unsigned long long old = atomicMin(&best[slot], key);
-                    if (old == key) return;
-                    const unsigned long long loser = old > key ? old : key;
-                    if (loser != ~0ull) atomicMin(&second[slot], loser);
-                };
-                if (L.mode != 2) fold(pairs[pair].kf_off + qt.x, pf_key(res, qt.y));
-                if (L.mode != 1) fold(pairs[pair].kr_off + qt.y, pf_key(res, qt.x));
+            const bool ins = res < f_inf();
+#ifndef MSFM_EX_NOSTORE   // (timing experiments only: wrong results)
+            cand[L.off + c] = qt;
+            cand_ps[L.off + c] = make_int2(pair, ins ? __float_as_int(res) : 0x7f800000);
+#endif
+#ifndef MSFM_EX_NOATOMIC
+            if (ins) {
+                if (L.mode != 2) atomicMin(&best[pairs[pair].kf_off + qt.x], pf_key(res, qt.y));
+                if (L.mode != 1) atomicMin(&best[pairs[pair].kr_off + qt.y], pf_key(res, qt.x));
             }
+#else
+            if (res == 12345.f) best[0] = 0;
+#endif
         }
     }
    }
+    rot = (rot + total) % wgs_per_xcd;
   }
 }
 
 
+
+// The second-best key per row / column among the candidates: every key that is not its slot's final best (complete when
+// pf_exact_candidates_kernel has run) is a candidate for `second`; a duplicate of the best key meets itself and is skipped,
+// duplicates of other keys are idempotent under min.  Streaming: 16 bytes per candidate + one 8-byte look at `best`.
+// grid = (x, lists; the kernel strides over more lists than gridDim.y allows)
+__global__ void pf_second_kernel(const PairDesc* __restrict__ pairs, const CandList* __restrict__ lists,
+                                 const unsigned long long* __restrict__ cand_count, const int2* __restrict__ cand,
+                                 const int2* __restrict__ cand_ps, const unsigned long long* __restrict__ best,
+                                 unsigned long long* __restrict__ second, int n_lists) {
+    MSFM_TAIL_PRIO();
+    for (int lid = blockIdx.y; lid < n_lists; lid += gridDim.y) {
+        const CandList L = lists[lid];
+        if (L.cap == 0) continue;
+        const int n = (int)(cand_count[lid] < (unsigned long long)L.cap ? cand_count[lid] : (unsigned long long)L.cap);
+        for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < n; c += gridDim.x * blockDim.x) {
+            const int2 ps = cand_ps[L.off + c];
+            if (ps.y == 0x7f800000) continue;
+            const int2 qt = cand[L.off + c];
+            const float sv = __int_as_float(ps.y);
+            if (L.mode != 2) {
+                const long long slot = pairs[ps.x].kf_off + qt.x;
+                const unsigned long long key = pf_key(sv, qt.y);
+                if (best[slot] != key) atomicMin(&second[slot], key);
+            }
+            if (L.mode != 1) {
+                const long long slot = pairs[ps.x].kr_off + qt.y;
+                const unsigned long long key = pf_key(sv, qt.x);
+                if (best[slot] != key) atomicMin(&second[slot], key);
+            }
+        }
+    }
+}
 
 #include "msfm_plan.hip.h"
 #include "msfm_q8.hip.h"
