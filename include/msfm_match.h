@@ -234,6 +234,9 @@ int msfm_pair_from_id(int32_t pair_id, int* out_id1, int* out_id2);
 int msfm_swap_image_pair(int id1, int id2);
 
 const char* msfm_version(void);
+/* gfx950 devices this process can open with msfm_create (ordinals 0 .. n-1); 0 without a GPU.  The reference is single-device;
+ * the drop-in's node-level fan-out (MSFM_DEVICES=all in host/FeatureMatching.cpp) asks it how many contexts to create. */
+int msfm_device_count(void);
 
 #ifdef __cplusplus
 }

@@ -25,7 +25,7 @@ EXPORTS = [
     "msfm_match_pair", "msfm_match_pairs", "msfm_fetch_matches", "msfm_knn2_pair",
     "msfm_topscale_select", "msfm_pair_id", "msfm_pair_from_id", "msfm_swap_image_pair",
     "msfm_version", "msfm_upload_keypoints", "msfm_match_pairs_verified", "msfm_subset_image", "msfm_view_matches", "msfm_set_limits", "msfm_fetch_matches_device",
-    "msfm_fetch_order_certificate", "msfm_set_pipeline",
+    "msfm_fetch_order_certificate", "msfm_set_pipeline", "msfm_device_count",
 ]
 
 
@@ -101,6 +101,8 @@ def load():
     L.msfm_pair_from_id.argtypes = [C.c_int32, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.msfm_swap_image_pair.argtypes = [C.c_int, C.c_int]
     L.msfm_version.restype = C.c_char_p
+    L.msfm_device_count.argtypes = []
+    L.msfm_device_count.restype = C.c_int
     for name in EXPORTS:
         getattr(L, name)  # raises AttributeError if the library lacks a declared symbol
     _lib = L
@@ -295,6 +297,11 @@ class Context:
         self._chk(self._L.msfm_knn2_pair(self._h, int(id1), int(id2), _ip(f_i), _fp(f_d0), _fp(f_d1),
                                          _ip(r_i), _fp(r_d0), _fp(r_d1)))
         return (f_i[:n1], f_d0[:n1], f_d1[:n1]), (r_i[:n2], r_d0[:n2], r_d1[:n2])
+
+
+def device_count():
+    """gfx950 devices msfm_create can open (0 without a GPU)."""
+    return int(load().msfm_device_count())
 
 
 def topscale_select(kpts, k):

@@ -237,7 +237,7 @@ struct Scratch {
     DevBuf d_fix_count, d_fix_list;
     int fix_cap_eff = 0;              // capacity handed to the kernels of the current batch (0: ties need no fix-up)
     // prefilter path
-    DevBuf d_tu, d_tv, d_cand, d_cand_ps, d_cand_count, d_best, d_second;
+    DevBuf d_tu, d_tv, d_cand, d_cand_count, d_best, d_second;
     DevBuf d_cmp_tu, d_live_idx, d_row_pair, d_row_src, d_vpairs, d_vpf, d_vitems, d_lists;
     DevBuf d_cmp_s0, d_cmp_s1, d_summary_a;   // route Q: sweep 1' row results, summary of plan A
     // device-side plan of the compacted sweep 2 (msfm_plan.hip.h)
@@ -257,7 +257,7 @@ struct Scratch {
     void for_each_buf(void (*fn)(DevBuf&, void*), void* arg) {
         DevBuf* bufs[] = {&d_up[0], &d_up[1], &d_up[2], &d_items, &d_rp_s0, &d_rp_i0, &d_rp_s1, &d_cp_s0, &d_cp_i0, &d_cp_s1, &d_k_i0, &d_k_d0,
                           &d_k_d1, &d_st_qt, &d_st_d, &d_counts, &d_offsets, &d_sens, &d_sub_qt, &d_sub_d, &d_fix_count, &d_fix_list, &d_tu,
-                          &d_tv, &d_cand, &d_cand_ps, &d_cand_count, &d_best, &d_second, &d_cmp_tu, &d_live_idx, &d_row_pair, &d_row_src,
+                          &d_tv, &d_cand, &d_cand_count, &d_best, &d_second, &d_cmp_tu, &d_live_idx, &d_row_pair, &d_row_src,
                           &d_vpairs, &d_vpf, &d_vitems, &d_lists, &d_colmask, &d_gtot, &d_grow0, &d_cnt, &d_mrow, &d_summary, &d_overflow,
                           &d_totals, &d_vf_pairs,
                           &d_vf_x1, &d_vf_y1, &d_vf_x2, &d_vf_y2, &d_vf_hyp, &d_vf_best_it, &d_vf_best_count, &d_vf_flags, &d_st2_qt,
@@ -801,13 +801,15 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
     HIPCHK(ctx, SC.d_best.ensure(kn * 8));
     HIPCHK(ctx, SC.d_second.ensure(kn * 8));
     HIPCHK(ctx, SC.d_overflow.ensure(P));
-    HIPCHK(ctx, SC.d_totals.ensure(64));   // [0..1] candidate / overflow totals (64-bit), ints [8..15]: per-XCD item cursors of sweep 2
+    // [0..1] candidate / overflow totals (64-bit), ints [8..15]: per-XCD item cursors of sweep 2, ints [16..23]: per-XCD span cursors
+    // of the exact re-check
+    HIPCHK(ctx, SC.d_totals.ensure(128));
     FillBatch fills;
     if (!compact) {   // (compacted sweep 2: pf_assign_kernel initialises the live slots only)
         fills.add(SC.d_best.p, (size_t)kn * 8, 0xff);
         fills.add(SC.d_second.p, (size_t)kn * 8, 0xff);
     }
-    fills.add(SC.d_totals.p, 64, 0);
+    fills.add(SC.d_totals.p, 128, 0);
     fills.add(SC.d_overflow.p, P, 0);   // (which pairs own an overflowed list: pf_overflow_kernel at the end of the chain)
     int rc = upload_pair_tables(ctx, b, 1, q8 ? &pfq : nullptr, fills);
     if (rc != MSFM_OK) return rc;
@@ -892,7 +894,6 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
         HIPCHK(ctx, SC.d_row_pair.ensure((size_t)rows_cap * 4));
         HIPCHK(ctx, SC.d_row_src.ensure((size_t)rows_cap * 8));
         HIPCHK(ctx, SC.d_cand.ensure((size_t)cand_cap * sizeof(int2)));
-        HIPCHK(ctx, SC.d_cand_ps.ensure((size_t)cand_cap * sizeof(int2)));
         HIPCHK(ctx, SC.d_cand_count.ensure(std::max<size_t>(1, G) * 8));
         {   // the plan's static tables in one copy (page-locked staging of this scratch set), everything it clears in one launch
             UploadPlan up;
@@ -1053,7 +1054,6 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
         for (size_t p = 0; p < P; ++p)
             lists[p] = CandList{(int)p, 0, b.pf[p].cand_off, b.pf[p].cand_cap, 0, nullptr, nullptr};
         HIPCHK(ctx, SC.d_cand.ensure(std::max<long long>(1, dense_cand) * sizeof(int2)));
-        HIPCHK(ctx, SC.d_cand_ps.ensure(std::max<long long>(1, dense_cand) * sizeof(int2)));
         HIPCHK(ctx, SC.d_cand_count.ensure(P * 8));
         HIPCHK(ctx, SC.d_lists.ensure(P * sizeof(CandList)));
         HIPCHK(ctx, hipMemsetAsync(SC.d_cand_count.p, 0, P * 8, SC.stream));
@@ -1073,28 +1073,21 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
     }
 
     if (n_lists > 0) {
-        // list l on XCD l mod 8, by that XCD's workgroups in spans of consecutive candidates (see the kernel): 8 workgroups of
-        // 4 waves per CU when it has the chip to itself, one per CU fits next to a resident sweep workgroup
-#ifndef MSFM_EX_WGMULT
-#define MSFM_EX_WGMULT 8
-#endif
-        const int wgs_per_xcd = std::max(1, ctx->cu_count / 8) * MSFM_EX_WGMULT;
+        // list l on XCD l mod 8, its spans of 256 candidates handed out by a per-XCD cursor to that XCD's persistent workgroups
+        // (see the kernel): 8 workgroups of 4 waves per CU when it has the chip to itself, one per CU fits next to a sweep workgroup
+        const int wgs_per_xcd = std::max(1, ctx->cu_count / 8) * 8;
         const dim3 cgrid((unsigned)(8 * wgs_per_xcd));
         const unsigned long long* dcount = SC.d_cand_count.as<unsigned long long>();
 #define MSFM_LAUNCH_EXACT(O)                                                                                             \
-    hipLaunchKernelGGL(pf_exact_candidates_kernel<O>, cgrid, dim3(256), 0, SC.stream, dp, dl, dcount,                      \
-                       SC.d_cand.as<int2>(), SC.d_cand_ps.as<int2>(), SC.d_best.as<unsigned long long>(), (int)n_lists, wgs_per_xcd)
+    hipLaunchKernelGGL(pf_exact_candidates_kernel<O>, cgrid, dim3(kExSpan), 0, SC.stream, dp, dl, dcount,                  \
+                       (const int2*)SC.d_cand.as<int2>(), SC.d_best.as<unsigned long long>(), SC.d_second.as<unsigned long long>(), \
+                       (int)n_lists, SC.d_totals.as<int>() + 16)
         if (ctx->order == MSFM_ORDER_SSE4X4) MSFM_LAUNCH_EXACT(0);
         else if (ctx->order == MSFM_ORDER_AVX2_FMA) MSFM_LAUNCH_EXACT(1);
         else MSFM_LAUNCH_EXACT(3);
 #undef MSFM_LAUNCH_EXACT
         HIPCHK(ctx, hipGetLastError());
         DBGSYNC(ctx, "pf_exact_candidates_kernel");
-        hipLaunchKernelGGL(pf_second_kernel, dim3(32, (unsigned)std::min<size_t>(n_lists, 65535)), dim3(256), 0, SC.stream, dp, dl, dcount,
-                           (const int2*)SC.d_cand.as<int2>(), (const int2*)SC.d_cand_ps.as<int2>(),
-                           (const unsigned long long*)SC.d_best.as<unsigned long long>(), SC.d_second.as<unsigned long long>(), (int)n_lists);
-        HIPCHK(ctx, hipGetLastError());
-        DBGSYNC(ctx, "pf_second_kernel");
     }
     hipLaunchKernelGGL(pf_finalize_kernel, mgrid, dim3(256), 0, SC.stream, dp, dpf, (const float*)tuv, SC.d_best.as<unsigned long long>(),
                        SC.d_second.as<unsigned long long>(), SC.d_k_i0.as<int>(), SC.d_k_d0.as<float>(),
@@ -1390,6 +1383,18 @@ int accumulate_kernel_time(msfm_ctx* ctx, size_t ev_base, bool launched) {
 extern "C" {
 
 const char* msfm_version(void) { return "msfm-match 0.1 (gfx950)"; }
+
+int msfm_device_count(void) {
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return 0;
+    int usable = 0;
+    for (int d = 0; d < count; ++d) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, d) != hipSuccess || std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) break;
+        ++usable;   // (ordinals are contiguous: the count of leading gfx950 devices)
+    }
+    return usable;
+}
 
 static void destroy_streams(msfm_ctx* ctx);
 

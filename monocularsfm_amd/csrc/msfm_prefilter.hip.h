@@ -346,54 +346,131 @@ __device__ __forceinline__ unsigned long long pf_key(float s, int idx) {
     return ((unsigned long long)__float_as_uint(s) << 32) | (unsigned)idx;  // s >= 0: uint order == float order
 }
 
-// exact pinned-order S for every candidate: 16 lanes per candidate (SSE order: lane L owns the
-// lane partial k = L mod 16; AVX2 order: 32 partials -> 2 per lane), coalesced 64-B row reads.
+// ---------------------------------------------------------------------------------------------------------------------------
+// Exact pinned-order S for every candidate, and the best / second-best (S, index) per row and column among them.
 //
-// WHERE a candidate is evaluated decides what the kernel costs: it is a gather of two 512-byte rows per candidate, and round 3
-// dealt 16-candidate windows of every list round-robin over all workgroups -- i.e. over the eight XCDs and their separate L2
-// caches -- so that 25 M candidates fetched 21 GB from memory (PMC) although they name only ~5 M distinct compacted rows and a
-// few hundred streamed images.  A list (= one group of sweep 2) has two kinds of locality:
-//   * its candidates arrive in chunks of <= 256 written by ONE wave of sweep 2 (flush_candidates): 64 compacted rows against the
-//     few tiles that wave swept since its last flush -- ~5 candidates per compacted row sit close together in the list;
-//   * every candidate of the list names a row of the SAME streamed image (or 512-row block group of it): <= 2.5 MB at 5000 rows.
-// So: list l is evaluated on XCD l mod 8 only (a workgroup's XCD is blockIdx.x mod 8: hardware round-robin), in spans of kExSpan
-// consecutive candidates dealt round-robin over the `wgs_per_xcd` workgroups of that XCD ACROSS the XCD's lists (span g of the
-// XCD's concatenated lists -> workgroup g mod wgs_per_xcd: a per-list deal would hand the first workgroups every short list
-// -- measured 2.5 x slower).  Every workgroup builds the prefix sums of its XCD's span counts in LDS (one gather of the list
-// lengths + a block scan, ~4 us) and finds the list of a span by binary search there.  The streamed image stays in the XCD's
-// 4 MB L2 while its list is worked off, a compacted row's second to fifth use hits the L1 / L2.   grid = 8 * wgs_per_xcd.
-#ifndef MSFM_EX_SPAN
-#define MSFM_EX_SPAN 256
-#endif
-#ifndef MSFM_EX_GLOBAL      // experiment switch: 1 = spans dealt over ALL workgroups, whatever their XCD
-#define MSFM_EX_GLOBAL 0
-#endif
-constexpr int kExSpan = MSFM_EX_SPAN;
+// What this kernel costs is decided by three things that round 3's version (16-candidate windows of every list dealt round-robin over
+// all workgroups, two returning 64-bit atomics behind every candidate) got wrong -- measured, profiles/r04_exact_recheck.txt:
+//  (1) ATOMICS, not bytes, were its limit: ~60 M device-scope 64-bit atomics per 25 M candidates at the ~19 G/s the part sustains
+//      = the kernel's 3.6 ms, whatever the gather did (fetching 37 % less changed nothing).  Now every candidate first LOOKS at
+//      its slots with plain loads (issued together with the metadata, long before they are needed): a key that does not beat the
+//      slot's current best can only be a candidate for `second`, and only if it beats the current second -- most candidates of a row
+//      are neither (a row has ~5; the running minimum of a random sequence changes ~2 times) and issue NO atomic.  A stale look is
+//      harmless: the slots only ever decrease, so "not smaller than what I saw" implies "not smaller than what is there".
+//  (2) The dependent chain record -> row tables -> pair table -> rows was walked once per candidate and wave, four round trips in a
+//      row with nothing else in flight.  Now a workgroup STAGES a span of 256 consecutive candidates: thread t resolves candidate t
+//      (three round trips, 256 candidates at once), leaves the two row addresses in LDS, and the 16-lane groups then stream through
+//      the span with one round trip per candidate, two candidates in flight per group.
+//  (3) WHERE a candidate is evaluated: a list (= one group of sweep 2) names rows of ONE streamed image (<= 2.5 MB at 5000 rows) and
+//      arrives in chunks of <= 256 written by one wave of sweep 2 (64 compacted rows, each ~2-3 times per chunk).  List l is
+//      evaluated on XCD l mod 8 only (a workgroup's XCD is blockIdx.x mod 8: hardware round-robin), its spans handed out by a
+//      per-XCD cursor (a static deal left 40 % of the time to the slowest workgroup): the streamed image stays in that XCD's 4 MB L2,
+//      a compacted row's repeats hit.  Memory fetches 21 GB -> 13 GB per 25 M candidates.
+// 16 lanes per candidate (SSE order: lane L owns the lane partial k = L mod 16; AVX2 order: 32 partials -> 2 per lane; AVX-512: 64
+// -> 4 per lane): in every order lane L needs the elements 16 j + L, j = 0..7, of both rows -- coalesced 64-byte reads.
+// grid = 8 * workgroups per XCD (persistent), block = kExSpan threads.
+constexpr int kExSpan = 256;
 constexpr int kExLists = 1024;   // lists per XCD and round of the prefix table (4 per thread)
+
 template <int ORDER>
-__global__ __launch_bounds__(256) void pf_exact_candidates_kernel(
+__device__ __forceinline__ float pf_exact_combine(const float (&av)[8], const float (&bv)[8], int sub) {
+    const int base = threadIdx.x & 63 & ~15;
+    if (ORDER == 0) {
+        float p = 0.f;
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const float t = av[it] - bv[it];
+            p = (it == 0) ? t * t : p + t * t;
+        }
+        // s[l] = ((p[l] + p[4+l]) + p[8+l]) + p[12+l]; result = (s0+s2)+(s1+s3)
+        const float p4 = __shfl(p, base | ((sub & 3) + 4), 64);
+        const float p8 = __shfl(p, base | ((sub & 3) + 8), 64);
+        const float p12 = __shfl(p, base | ((sub & 3) + 12), 64);
+        const float p0 = __shfl(p, base | (sub & 3), 64);
+        const float s = ((p0 + p4) + p8) + p12;  // valid in every lane for l = sub & 3
+        const float s0 = __shfl(s, base | 0, 64), s1 = __shfl(s, base | 1, 64);
+        const float s2 = __shfl(s, base | 2, 64), s3 = __shfl(s, base | 3, 64);
+        return (s0 + s2) + (s1 + s3);
+    } else if (ORDER == 3) {
+        // AVX-512 order: 64 partials p[16 v + L]; lane `sub` owns L = sub: four accumulators x two iterations, fused
+        float s = 0.f;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const float t0 = av[v] - bv[v];
+            const float t1 = av[4 + v] - bv[4 + v];
+            const float p = __builtin_fmaf(t1, t1, t0 * t0);
+            s = (v == 0) ? p : s + p;
+        }
+        // y_l = (s_l + s_{l+8}) + (s_{l+4} + s_{l+12}), result (y0 + y2) + (y1 + y3): butterflies (a + b == b + a bitwise)
+        const float x = s + __shfl(s, base | (sub ^ 8), 64);
+        const float y = x + __shfl(x, base | (sub ^ 4), 64);
+        const float z = y + __shfl(y, base | (sub ^ 2), 64);
+        return z + __shfl(z, base | (sub ^ 1), 64);
+    } else {
+        // 32 partials: lane `sub` owns L = sub (elements 32 it + sub) and L = sub + 16 (elements 32 it + sub + 16)
+        float pa = 0.f, pb = 0.f;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const float ta = av[2 * it] - bv[2 * it];
+            const float tb = av[2 * it + 1] - bv[2 * it + 1];
+            pa = (it == 0) ? ta * ta : __builtin_fmaf(ta, ta, pa);
+            pb = (it == 0) ? tb * tb : __builtin_fmaf(tb, tb, pb);
+        }
+        // s[l] = ((p[l]+p[8+l])+p[16+l])+p[24+l], l = 0..7: p[l]=pa(l), p[8+l]=pa(8+l), p[16+l]=pb(l), p[24+l]=pb(8+l)
+        const int l = sub & 7;
+        const float q0 = __shfl(pa, base | l, 64), q1 = __shfl(pa, base | (8 + l), 64);
+        const float q2 = __shfl(pb, base | l, 64), q3 = __shfl(pb, base | (8 + l), 64);
+        const float s = ((q0 + q1) + q2) + q3;
+        float sv[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) sv[k] = __shfl(s, base | k, 64);
+        return ((sv[0] + sv[1]) + (sv[2] + sv[3])) + ((sv[4] + sv[5]) + (sv[6] + sv[7]));
+    }
+}
+
+// One key into a slot's (best, second): best ends as the smallest key the slot ever saw, second as the second smallest -- every key
+// but the final minimum loses exactly once against `best` (when it arrives, or when it is displaced) and is then offered to
+// `second`; a key arriving twice meets itself and is dropped.  sb / ss: what a plain load saw in the slot some time ago (>= what
+// is there now): they only ever let a key skip an atomic that could not have changed anything.
+__device__ __forceinline__ void pf_fold(unsigned long long* __restrict__ best, unsigned long long* __restrict__ second, long long slot,
+                                        unsigned long long key, unsigned long long sb, unsigned long long ss) {
+    if (key == sb) return;
+    unsigned long long loser = key;
+    if (key < sb) {
+        const unsigned long long old = atomicMin(&best[slot], key);
+        if (old == key) return;
+        loser = old > key ? old : key;
+        if (loser == ~0ull) return;
+    }
+    if (loser < ss) atomicMin(&second[slot], loser);
+}
+
+template <int ORDER>
+__global__ __launch_bounds__(kExSpan) void pf_exact_candidates_kernel(
     const PairDesc* __restrict__ pairs, const CandList* __restrict__ lists, const unsigned long long* __restrict__ cand_count,
-    int2* __restrict__ cand /* in: the sweep's records; out: the real (q, t) */, int2* __restrict__ cand_ps /* out: (pair, S bits) */,
-    unsigned long long* __restrict__ best, int n_lists, int wgs_per_xcd) {
+    const int2* __restrict__ cand, unsigned long long* __restrict__ best, unsigned long long* __restrict__ second, int n_lists,
+    int* __restrict__ cursors /* [8], zero: spans handed out per XCD */) {
     MSFM_TAIL_PRIO();
     __shared__ int s_base[kExLists + 1];   // s_base[i] = spans of the XCD's lists before list i of the round
-    __shared__ int s_part[256];
-    const int lstride = MSFM_EX_GLOBAL ? 1 : 8;
-    const int xcd = MSFM_EX_GLOBAL ? 0 : (int)(blockIdx.x & 7), wg = MSFM_EX_GLOBAL ? (int)blockIdx.x : (int)(blockIdx.x >> 3);
-    if (MSFM_EX_GLOBAL) wgs_per_xcd = (int)gridDim.x;
-    const int my_lists = n_lists > xcd ? (n_lists - xcd + lstride - 1) / lstride : 0;
-    const int sub = threadIdx.x & 15;
-    int rot = 0;   // spans dealt in earlier rounds, mod wgs_per_xcd: the deal goes on where it stopped
+    __shared__ int s_part[kExSpan];
+    __shared__ const float* s_a[kExSpan];
+    __shared__ const float* s_b[kExSpan];
+    __shared__ float s_res[kExSpan];
+    __shared__ int s_g;
+    const int xcd = blockIdx.x & 7, tid = threadIdx.x, sub = tid & 15, grp = tid >> 4;
+    const int my_lists = n_lists > xcd ? (n_lists - xcd + 7) / 8 : 0;
+    if (tid == 0) s_g = atomicAdd(&cursors[xcd], 1);
+    int round_base = 0;   // spans of the XCD's earlier rounds
   for (int l0 = 0; l0 < my_lists; l0 += kExLists) {
     const int nl = min(kExLists, my_lists - l0);
     // ---- span counts of this round's lists -> exclusive prefix sums in s_base ----
     int cnt4[4], mine = 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const int i = 4 * threadIdx.x + j;
+        const int i = 4 * tid + j;
         int ns = 0;
         if (i < nl) {
-            const int lid = xcd + lstride * (l0 + i);
+            const int lid = xcd + 8 * (l0 + i);
             const int cap = lists[lid].cap;
             const unsigned long long cc = cand_count[lid];
             const int n = (int)(cc < (unsigned long long)cap ? cc : (unsigned long long)cap);
@@ -402,160 +479,90 @@ __global__ __launch_bounds__(256) void pf_exact_candidates_kernel(
         cnt4[j] = ns;
         mine += ns;
     }
-    __syncthreads();   // (the previous round's readers of s_base are done)
-    s_part[threadIdx.x] = mine;
+    __syncthreads();   // (the previous round's readers of s_base are done; thread 0's first s_g is visible)
+    s_part[tid] = mine;
     __syncthreads();
-    for (int d = 1; d < 256; d <<= 1) {
-        const int v = (int)threadIdx.x >= d ? s_part[threadIdx.x - d] : 0;
+    for (int d = 1; d < kExSpan; d <<= 1) {
+        const int v = tid >= d ? s_part[tid - d] : 0;
         __syncthreads();
-        s_part[threadIdx.x] += v;
+        s_part[tid] += v;
         __syncthreads();
     }
-    int run = s_part[threadIdx.x] - mine;
+    int run = s_part[tid] - mine;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        s_base[4 * threadIdx.x + j] = run;
+        s_base[4 * tid + j] = run;
         run += cnt4[j];
     }
-    if (threadIdx.x == 255) s_base[kExLists] = run;
+    if (tid == kExSpan - 1) s_base[kExLists] = run;
     __syncthreads();
     const int total = s_base[kExLists];
-    const int first = (wg - rot % wgs_per_xcd + wgs_per_xcd) % wgs_per_xcd;
-   for (int g = first; g < total; g += wgs_per_xcd) {
-    // the list of span g: the last i with s_base[i] <= g (lists without spans repeat their successor's base: skipped by "last")
-    int lo = 0, hi = kExLists;   // invariant: s_base[lo] <= g < s_base[hi]
+   for (;;) {
+    const int g = s_g - round_base;      // this workgroup's span of the round (uniform)
+    if (g >= total) break;               // the rest belongs to the next round, if any (s_g is kept)
+    // the list of span g: the last i with s_base[i] <= g (lists without spans share their successor's base: "last" skips them)
+    int lo = 0, hi = kExLists;           // invariant: s_base[lo] <= g < s_base[hi]
     while (hi - lo > 1) {
         const int mid = (lo + hi) >> 1;
         if (s_base[mid] <= g) lo = mid; else hi = mid;
     }
-    const int lid = xcd + lstride * (l0 + lo);
+    const int lid = xcd + 8 * (l0 + lo);
     const CandList L = lists[lid];
     const int n = (int)(cand_count[lid] < (unsigned long long)L.cap ? cand_count[lid] : (unsigned long long)L.cap);
-    const int c0 = (g - s_base[lo]) * kExSpan;
-    const int c1 = min(n, c0 + kExSpan), c_end = c0 + ((c1 - c0 + 3) & ~3);   // (whole waves take part in the shuffles)
-    for (int c = c0 + (threadIdx.x >> 4); c < c_end; c += blockDim.x >> 4) {
-        const bool live = c < c1;
-        int2 qt = live ? cand[L.off + c] : make_int2(0, 0);
-        int pair = L.mode == 0 ? L.pair : L.row_pair[live ? qt.x : 0];
-        if (!live && L.mode != 0) pair = L.row_pair[0], qt = make_int2(0, 0);
-        if (live && L.mode == 1) qt.x = L.live_idx[qt.x];
-        if (live && L.mode == 2) qt = make_int2(qt.y, L.live_idx[qt.x]);
-        const float* a = pairs[pair].a_raw + (size_t)qt.x * kDim;
-        const float* b = pairs[pair].b_raw + (size_t)qt.y * kDim;
-        float res;
-        if (ORDER == 0) {
-            float p = 0.f;
+    const int c0 = (g - s_base[lo]) * kExSpan, c1 = min(n, c0 + kExSpan);
+    // ---- phase 1: thread t resolves candidate t of the span (the tail's threads resolve the span's first one again: valid
+    //      addresses for the whole-wave shuffles of phase 2) and looks at its slots
+    const bool live = c0 + tid < c1;
+    int2 qt = cand[L.off + (live ? c0 + tid : c0)];
+    const int pair = L.mode == 0 ? L.pair : L.row_pair[qt.x];
+    if (L.mode == 1) qt.x = L.live_idx[qt.x];
+    if (L.mode == 2) qt = make_int2(qt.y, L.live_idx[qt.x]);
+    const PairDesc* pd = pairs + pair;
+    s_a[tid] = pd->a_raw + (size_t)qt.x * kDim;
+    s_b[tid] = pd->b_raw + (size_t)qt.y * kDim;
+    // A mode-1 list only serves the row direction, a mode-2 list only the column direction: the live rows of the OTHER
+    // direction get their complete candidate sets from their own list.
+    const long long slot_r = pd->kf_off + qt.x, slot_c = pd->kr_off + qt.y;
+    unsigned long long sb_r = ~0ull, ss_r = ~0ull, sb_c = ~0ull, ss_c = ~0ull;
+    if (live && L.mode != 2) sb_r = best[slot_r], ss_r = second[slot_r];
+    if (live && L.mode != 1) sb_c = best[slot_c], ss_c = second[slot_c];
+    __syncthreads();
+    // the next span's number: fetched now (everybody has read this span's: that read is above the barrier), in flight during phase 2
+    int g_next = 0;
+    if (tid == 0) g_next = atomicAdd(&cursors[xcd], 1);
+    // ---- phase 2: the 16-lane groups stream through the span, two candidates in flight per group
+    const int n4 = (c1 - c0 + 3) & ~3;   // (whole waves take part in the shuffles)
+    for (int k0 = grp; k0 < n4; k0 += 32) {
+        const int k1 = k0 + 16 < n4 ? k0 + 16 : k0;   // (uniform per wave: a wave's four groups are four consecutive candidates)
+        const float* a0 = s_a[k0];
+        const float* b0 = s_b[k0];
+        const float* a1 = s_a[k1];
+        const float* b1 = s_b[k1];
+        float av0[8], bv0[8], av1[8], bv1[8];
 #pragma unroll
-            for (int it = 0; it < 8; ++it) {
-                const float t = a[16 * it + sub] - b[16 * it + sub];
-                p = (it == 0) ? t * t : p + t * t;
-            }
-            // s[l] = ((p[l] + p[4+l]) + p[8+l]) + p[12+l]; result = (s0+s2)+(s1+s3)
-            const float p4 = __shfl(p, (threadIdx.x & ~15) | ((sub & 3) + 4), 64);
-            const float p8 = __shfl(p, (threadIdx.x & ~15) | ((sub & 3) + 8), 64);
-            const float p12 = __shfl(p, (threadIdx.x & ~15) | ((sub & 3) + 12), 64);
-            const float p0 = __shfl(p, (threadIdx.x & ~15) | (sub & 3), 64);
-            const float s = ((p0 + p4) + p8) + p12;  // valid in every lane for l = sub & 3
-            const float s0 = __shfl(s, (threadIdx.x & ~15) | 0, 64), s1 = __shfl(s, (threadIdx.x & ~15) | 1, 64);
-            const float s2 = __shfl(s, (threadIdx.x & ~15) | 2, 64), s3 = __shfl(s, (threadIdx.x & ~15) | 3, 64);
-            res = (s0 + s2) + (s1 + s3);
-        } else if (ORDER == 3) {
-            // AVX-512 order: 64 partials p[16 v + L]; lane `sub` owns L = sub: four accumulators x two iterations, fused
-            float s = 0.f;
+        for (int j = 0; j < 8; ++j) av0[j] = a0[16 * j + sub], bv0[j] = b0[16 * j + sub];
 #pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                const float t0 = a[16 * v + sub] - b[16 * v + sub];
-                const float t1 = a[64 + 16 * v + sub] - b[64 + 16 * v + sub];
-                const float p = __builtin_fmaf(t1, t1, t0 * t0);
-                s = (v == 0) ? p : s + p;
-            }
-            // y_l = (s_l + s_{l+8}) + (s_{l+4} + s_{l+12}), result (y0 + y2) + (y1 + y3): butterflies (a + b == b + a bitwise)
-            const int base = threadIdx.x & ~15;
-            const float x = s + __shfl(s, base | (sub ^ 8), 64);
-            const float y = x + __shfl(x, base | (sub ^ 4), 64);
-            const float z = y + __shfl(y, base | (sub ^ 2), 64);
-            res = z + __shfl(z, base | (sub ^ 1), 64);
-        } else {
-            // 32 partials: lane `sub` owns L = sub and L = sub + 16
-            float pa = 0.f, pb = 0.f;
-#pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                const float ta = a[32 * it + sub] - b[32 * it + sub];
-                const float tb = a[32 * it + sub + 16] - b[32 * it + sub + 16];
-                pa = (it == 0) ? ta * ta : __builtin_fmaf(ta, ta, pa);
-                pb = (it == 0) ? tb * tb : __builtin_fmaf(tb, tb, pb);
-            }
-            // s[l] = ((p[l]+p[8+l])+p[16+l])+p[24+l], l = 0..7: p[l]=pa(l), p[8+l]=pa(8+l), p[16+l]=pb(l), p[24+l]=pb(8+l)
-            const int l = sub & 7, base = threadIdx.x & ~15;
-            const float q0 = __shfl(pa, base | l, 64), q1 = __shfl(pa, base | (8 + l), 64);
-            const float q2 = __shfl(pb, base | l, 64), q3 = __shfl(pb, base | (8 + l), 64);
-            const float s = ((q0 + q1) + q2) + q3;
-            float sv[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) sv[k] = __shfl(s, base | k, 64);
-            res = ((sv[0] + sv[1]) + (sv[2] + sv[3])) + ((sv[4] + sv[5]) + (sv[6] + sv[7]));
+        for (int j = 0; j < 8; ++j) av1[j] = a1[16 * j + sub], bv1[j] = b1[16 * j + sub];
+        const float r0 = pf_exact_combine<ORDER>(av0, bv0, sub);
+        const float r1 = pf_exact_combine<ORDER>(av1, bv1, sub);
+        if (sub == 0) {
+            s_res[k0] = r0;
+            s_res[k1] = r1;
         }
-        if (live && sub == 0) {
-            // The BEST key per row / column rides along as a fire-and-forget 64-bit atomicMin (no return value: the wave does not
-            // wait for it).  Round 3 took the old value back and pushed the loser of every update into `second` right here: two
-            // DEPENDENT returning atomics behind every candidate -- with a row's ~5 candidates now evaluated back to back by one
-            // workgroup they queued up on the same address and the kernel got 60 % SLOWER although it fetched 37 % less (profiles/
-            // r04_exact_xcd_local_ab.txt).  The second-best key is pf_second_kernel's, from the records written here: the real
-            // (q, t) in place of the sweep's record, (pair, S bits) beside it; S = +inf: batchDistance never inserts it.
-            // A mode-1 list only serves the row direction, a mode-2 list only the column direction: the live rows of the OTHER
-            // direction get their complete candidate sets from their own list.
-            const bool ins = res < f_inf();
-#ifndef MSFM_EX_NOSTORE   // (timing experiments only: wrong results)
-            cand[L.off + c] = qt;
-            cand_ps[L.off + c] = make_int2(pair, ins ? __float_as_int(res) : 0x7f800000);
-#endif
-#ifndef MSFM_EX_NOATOMIC
-            if (ins) {
-                if (L.mode != 2) atomicMin(&best[pairs[pair].kf_off + qt.x], pf_key(res, qt.y));
-                if (L.mode != 1) atomicMin(&best[pairs[pair].kr_off + qt.y], pf_key(res, qt.x));
-            }
-#else
-            if (res == 12345.f) best[0] = 0;
-#endif
+    }
+    if (tid == 0) s_g = g_next;
+    __syncthreads();
+    // ---- phase 3: thread t folds candidate t into its slots
+    if (live) {
+        const float res = s_res[tid];
+        if (res < f_inf()) {   // batchDistance never inserts a distance >= FLT_MAX
+            if (L.mode != 2) pf_fold(best, second, slot_r, pf_key(res, qt.y), sb_r, ss_r);
+            if (L.mode != 1) pf_fold(best, second, slot_c, pf_key(res, qt.x), sb_c, ss_c);
         }
     }
    }
-    rot = (rot + total) % wgs_per_xcd;
+    round_base += total;
   }
-}
-
-
-
-// The second-best key per row / column among the candidates: every key that is not its slot's final best (complete when
-// pf_exact_candidates_kernel has run) is a candidate for `second`; a duplicate of the best key meets itself and is skipped,
-// duplicates of other keys are idempotent under min.  Streaming: 16 bytes per candidate + one 8-byte look at `best`.
-// grid = (x, lists; the kernel strides over more lists than gridDim.y allows)
-__global__ void pf_second_kernel(const PairDesc* __restrict__ pairs, const CandList* __restrict__ lists,
-                                 const unsigned long long* __restrict__ cand_count, const int2* __restrict__ cand,
-                                 const int2* __restrict__ cand_ps, const unsigned long long* __restrict__ best,
-                                 unsigned long long* __restrict__ second, int n_lists) {
-    MSFM_TAIL_PRIO();
-    for (int lid = blockIdx.y; lid < n_lists; lid += gridDim.y) {
-        const CandList L = lists[lid];
-        if (L.cap == 0) continue;
-        const int n = (int)(cand_count[lid] < (unsigned long long)L.cap ? cand_count[lid] : (unsigned long long)L.cap);
-        for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < n; c += gridDim.x * blockDim.x) {
-            const int2 ps = cand_ps[L.off + c];
-            if (ps.y == 0x7f800000) continue;
-            const int2 qt = cand[L.off + c];
-            const float sv = __int_as_float(ps.y);
-            if (L.mode != 2) {
-                const long long slot = pairs[ps.x].kf_off + qt.x;
-                const unsigned long long key = pf_key(sv, qt.y);
-                if (best[slot] != key) atomicMin(&second[slot], key);
-            }
-            if (L.mode != 1) {
-                const long long slot = pairs[ps.x].kr_off + qt.y;
-                const unsigned long long key = pf_key(sv, qt.x);
-                if (best[slot] != key) atomicMin(&second[slot], key);
-            }
-        }
-    }
 }
 
 #include "msfm_plan.hip.h"

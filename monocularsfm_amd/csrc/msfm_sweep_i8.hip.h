@@ -147,25 +147,11 @@ __global__ __launch_bounds__(kI8Threads) void sweep_i8_kernel(
 
     const int n_items = n_items_dev ? *n_items_dev : n_items_host;
     __shared__ int s_next_item;
-    // Sweep 1 walks its items with a fixed stride: the NEXT item's record is known when this one starts.  The last wave (it
-    // issues no tile DMA, nobody counts its vmcnt) fetches it by LDS-DMA -- no register, no wait -- and the next item starts
-    // from an LDS read instead of a ~2 us miss at the head of its dependent chain record -> pair tables -> A rows / first tiles
-    // (an item's record is read once, by one workgroup: never in a cache).  Two buffers: the one being filled is never the one
-    // being read; s_pre_it[b] says whose record buffer b holds; the parity lives in LDS (s_pre_it[2], toggled by one thread
-    // behind the item's first barrier) -- the kernel has no scalar register to spare: one more and hipcc keeps uniform values in
-    // VGPRs, 113 of them, and four waves per SIMD no longer leave 64 registers to the other stream's tail kernels.
-    __shared__ __attribute__((aligned(16))) int s_pre_item[2][64];
-    __shared__ int s_pre_it[3];
-    static_assert(sizeof(WorkItem) == 32, "the record travels as eight dwords");
-    if (PASS == 1) {
-        if (threadIdx.x < 3) s_pre_it[threadIdx.x] = threadIdx.x < 2 ? -1 : 0;
-        lds_barrier();
-    }
+    bool first_item = true;
 #pragma unroll 1
     for (int it = blockIdx.x;; it += gridDim.x) {
-    const bool was_first = PASS == 1 && it == (int)blockIdx.x;   // (sweep 2 fetches its items from the cursors: a barrier anyway)
-    if (!was_first || dyn_next) lds_barrier();
-    const int par = PASS == 1 ? __builtin_amdgcn_readfirstlane(s_pre_it[2]) : 0;
+    if (!first_item || dyn_next) lds_barrier();
+    first_item = false;
     if (dyn_next) {
         if (threadIdx.x == 0) s_next_item = atomicAdd(&dyn_next[blockIdx.x & 7], 1);
         lds_barrier();
@@ -173,45 +159,14 @@ __global__ __launch_bounds__(kI8Threads) void sweep_i8_kernel(
     }
     if (it >= n_items) break;
     MSFM_PROBE_ITEM_BEGIN
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const unsigned lane_off = (unsigned)(wave * 1024 + lane * 16);   // (the tile DMA's lane offset: alive through the whole item loop)
-    if (PASS == 1 && wave == kI8Waves - 1) {
-        const int nit = it + (int)gridDim.x;
-        if (nit < n_items) {
-            // all 64 lanes, lane l fetching dword l mod 8 of the record (eight copies in the 256-byte buffer), its offset derived
-            // from lane_off through an opaque copy: no exec-mask juggling, no new loop-invariant value -- the kernel has neither a
-            // scalar nor a vector register to spare (113 VGPRs: four waves per SIMD no longer leave 64 to the other stream's tails)
-            unsigned lo16 = lane_off;
-            asm volatile("" : "+v"(lo16));
-            const unsigned long long src = (unsigned long long)(items + nit);
-            const unsigned dst = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)s_pre_item[par ^ 1];
-#pragma clang diagnostic push
-#pragma clang diagnostic ignored "-Winline-asm"
-            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1"
-                         :: "v"((lo16 >> 2) & 28u), "s"(src), "s"(dst) : "memory", "m0");
-#pragma clang diagnostic pop
-            s_pre_it[par ^ 1] = nit;   // (every lane, the same value)
-        }
-    }
-    WorkItem item;
-    if (PASS == 1 && !was_first && __builtin_amdgcn_readfirstlane(s_pre_it[par]) == it) {
-        // (landed: every wave drained its vmcnt before the barrier that ended the previous item)
-        const i4v lo = *reinterpret_cast<const i4v*>(s_pre_item[par]);
-        const int rg = s_pre_item[par][4];
-        item.pair = __builtin_amdgcn_readfirstlane(lo.x);
-        item.a_blk = __builtin_amdgcn_readfirstlane(lo.y);
-        item.bt_begin = __builtin_amdgcn_readfirstlane(lo.z);
-        item.bt_end = __builtin_amdgcn_readfirstlane(lo.w);
-        item.range = __builtin_amdgcn_readfirstlane(rg);
-    } else {
-        item = items[it];
-    }
+    const WorkItem item = items[it];
     if (item.pair < 0) continue;
     const PfPair pp = pf[item.pair];
     if (!pp.use) continue;
     const PairDesc pd = pairs[item.pair];
 
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     MSFM_PROBE_SEG(8)
     const int grp = (wave >> 2) & 1;    // 0: MFMA in the even phases, 1: in the odd ones; two waves of each on every SIMD
     const int lcol = lane & 31, lhalf = lane >> 5;
@@ -222,6 +177,7 @@ __global__ __launch_bounds__(kI8Threads) void sweep_i8_kernel(
 
     // DMA group of tile tt: the tile's 11 pieces go to waves 0..10, one each
     const bool dma_wave = wave < kI8TileBytes / 1024;   // wave-uniform
+    const unsigned lane_off = (unsigned)(wave * 1024 + lane * 16);
     auto dma_tile = [&](int tt) {
         if (!dma_wave) return;
 #ifdef MSFM_EXPERIMENT_SAME_TILE   // timing experiment only (wrong results): every DMA group re-reads the item's first tile
@@ -239,7 +195,7 @@ __global__ __launch_bounds__(kI8Threads) void sweep_i8_kernel(
         asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
                      :: "v"(lane_off), "s"(tile), "s"(dst) : "memory", "m0");
 #ifdef MSFM_EXPERIMENT_DMA_X4   // timing experiment only (same results): every piece travels L2 -> LDS four times -- what four 4-wave
-                                // workgroups per CU, each with a B ring of its own, would ask of the L2 (profiles/r04_i8_dma_x4.txt)
+                                // workgroups per CU, each with a B ring of its own, would ask of the L2 (profiles/r04_i8_structural_experiments.txt)
         asm volatile("global_load_lds_dwordx4 %0, %1\n\tglobal_load_lds_dwordx4 %0, %1\n\tglobal_load_lds_dwordx4 %0, %1"
                      :: "v"(lane_off), "s"(tile) : "memory");
 #endif
@@ -418,7 +374,6 @@ __global__ __launch_bounds__(kI8Threads) void sweep_i8_kernel(
 
     lds_barrier();
     dma_tile(t_begin + kI8Ring - 1);   // the first interval's DMA group
-    if (PASS == 1 && tid == 0) s_pre_it[2] = par ^ 1;   // (every wave has read the parity: it did so before the barrier above)
     i4v bf[2][2];
     if (wave_active) preread(0, bf);
     MSFM_PROBE_SEG(10)

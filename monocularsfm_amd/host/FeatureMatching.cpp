@@ -67,7 +67,11 @@ void FeatureMatcher::OpenDatabaseAndDevice() {
     database_->Open(database_path_);
     if (!ctx_) {
         std::vector<int> devs;
-        if (const char* list = std::getenv("MSFM_DEVICES")) {
+        const char* list = std::getenv("MSFM_DEVICES");
+        if (list && std::string(list) == "all") {   // every gfx950 device of the node: one context and one host thread each
+            const int n = msfm_device_count();
+            for (int d = 0; d < n; ++d) devs.push_back(d);
+        } else if (list) {
             for (const char* c = list; *c;) {
                 char* end = nullptr;
                 const long v = std::strtol(c, &end, 10);

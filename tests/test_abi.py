@@ -30,6 +30,9 @@ def test_library_exports_every_declared_symbol(built_lib):
         assert hasattr(built_lib, name), "libmsfm_match.so does not export %s" % name
     assert sorted(_lib.EXPORTS) == declared_functions()
     assert b"gfx950" in built_lib.msfm_version()
+    import torch
+    if not torch.cuda.is_available():
+        assert built_lib.msfm_device_count() == 0     # no GPU here: the count is a plain 0, not an error
 
 
 def test_no_torch_types_in_the_abi():

@@ -221,6 +221,32 @@ def test_multi_device_split_writes_the_same_rows(exe, dataset, tmp_path, gv):
     assert strip(outs[0]) == strip(outs[1])
 
 
+def test_multi_device_all_uses_every_gpu_of_the_box(exe, dataset, tmp_path):
+    """MSFM_DEVICES=all: one context and one host thread per gfx950 device the box has (msfm_device_count) -- one on the
+    test box, eight on a full node (never run there: DESIGN.md section 6 says so) -- and "every device twice" on top of it, so
+    that the split / merge code runs over 2 x count contexts wherever this test runs.  Same rows, same stdout."""
+    from monocularsfm_amd import _lib
+    n = _lib.device_count()
+    assert n >= 1
+    descs, kps = dataset
+    base = str(tmp_path / "one.db")
+    database.write_synthetic_database(base, descs, kps)
+    rows, outs = [], []
+    for tag in ("all", "twice"):
+        shutil.copy(base, str(tmp_path / (tag + ".db")))
+    for tag, env in (("one", {}), ("all", {"MSFM_DEVICES": "all"}), ("twice", {"MSFM_DEVICES": ",".join([str(d) for d in range(n)] * 2)})):
+        path = str(tmp_path / (tag + ".db"))
+        cfg = tmp_path / (tag + ".yaml")
+        cfg.write_text(YAML.format(db=path, mt=1))
+        outs.append(run_cli(exe, cfg, dict(env)))
+        d = database.Database(path)
+        rows.append(d.db.execute("SELECT pair_id, rows, cols, data FROM matches ORDER BY pair_id").fetchall())
+        d.Close()
+    assert len(rows[0]) > 5 and rows[0] == rows[1] == rows[2]
+    strip = lambda s: re.sub(r"Elapsed time: [0-9.]+", "Elapsed time: X", s)
+    assert strip(outs[0]) == strip(outs[1]) == strip(outs[2])
+
+
 @pytest.mark.parametrize("mt", [0, 1])
 def test_images_without_descriptors_and_tiny_images(exe, tmp_path, mt):
     """Images with 0, 1 and 2 descriptors next to normal ones: the reference would hit knnMatch's undefined cases
