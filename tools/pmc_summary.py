@@ -1,6 +1,7 @@
 """Aggregate rocprofv3 --pmc passes (run with --output-format csv) into the JSON committed under profiles/.
 
-Usage: python tools/pmc_summary.py <out.json> <kernel-substring>[,<kernel-substring>...] <dir-or-csv> [<dir-or-csv> ...]
+Usage: [PMC_STEPS=5] python tools/pmc_summary.py <out.json> <kernel-substring>[,<kernel-substring>...] <dir-or-csv> [<dir-or-csv> ...]
+PMC_STEPS = steps (timed + warm-up) of the profiled bench command: written as "_meta" so that bench.py can turn "per launch" into "per step".
 Every *_counter_collection.csv below the given paths is read; per kernel (matched by substring, reported under
 the substring) and per counter: the mean over dispatches of the counter value (FETCH_SIZE / WRITE_SIZE are KB).
 """
@@ -38,6 +39,8 @@ def main():
             vals = list(d.values())
             res[k][c] = {"per_launch_KB_mean" if c.endswith("_SIZE") else "per_launch_mean": sum(vals) / len(vals),
                          "launches": len(vals)}
+    if os.environ.get("PMC_STEPS"):
+        res["_meta"] = {"steps": int(os.environ["PMC_STEPS"])}
     json.dump(res, open(out_path, "w"), indent=1)
     print(json.dumps(res, indent=1))
 
