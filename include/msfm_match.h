@@ -96,6 +96,10 @@ typedef struct msfm_profile {
     int64_t order_sensitive_rows; /* rows / columns of the call WITHOUT an order-invariance certificate (see
                                      msfm_fetch_order_certificate); 0 => the stored (queryIdx, trainIdx) rows are the same
                                      under any conforming fp32 evaluation order of hal::normL2Sqr_ */
+    int demoted_pairs;            /* pairs of two byte images (or of two images with byte twins) whose first sweep ran on the fp16 cores
+                                     all the same, because their SUB-BATCH also held a pair that could not take the integer route (a
+                                     mixed store: the route is chosen per sub-batch).  Same results, ~1.6 x the sweep time; 0 on a
+                                     homogeneous store */
 } msfm_profile;
 
 /* ---- context ------------------------------------------------------------------------- */

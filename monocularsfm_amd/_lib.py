@@ -48,7 +48,8 @@ class Profile(C.Structure):
                 ("sweep2_descriptor_pairs", C.c_int64), ("verify_ms", C.c_double),
                 ("sub_batches", C.c_int), ("tie_queue_regrows", C.c_int), ("plan_regrows", C.c_int),
                 ("sweep1_i8_launches", C.c_int), ("sweep1_q8_launches", C.c_int), ("sweep1b_launches", C.c_int),
-                ("sweep1b_ms", C.c_double), ("sweep1b_descriptor_pairs", C.c_int64), ("order_sensitive_rows", C.c_int64)]
+                ("sweep1b_ms", C.c_double), ("sweep1b_descriptor_pairs", C.c_int64), ("order_sensitive_rows", C.c_int64),
+                ("demoted_pairs", C.c_int)]
 
 
 class MsfmError(RuntimeError):

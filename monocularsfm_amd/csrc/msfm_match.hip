@@ -150,7 +150,7 @@ struct Image {
     float c = 1.f;            // scale of the quadruples (power of two)
     float nrm_max = 0.f, abs_max = 0.f;
     bool pf_safe = false;
-    // byte stores (MSFM_DTYPE_U8 uploads and their subsets): signed operand rows of 144 B for the integer matrix cores
+    // byte stores (MSFM_DTYPE_U8 uploads and their subsets): signed operand rows of 176 B (kI8RowBytes: 128 operand bytes, 16 digits, 16 constants, padding) for the integer matrix cores
     // and the float "norms" 2 floor(|x - 128|^2 / 2) (msfm_sweep_i8.hip.h)
     bool is_u8 = false;
     bool from_u8 = false;     // uploaded as MSFM_DTYPE_U8 (or a subset of such an image): integer values 0..255
@@ -208,10 +208,13 @@ constexpr long long kMinPipelineCost = 15000000000LL;
 
 }  // namespace
 
-// Everything ONE device sub-batch in flight owns: its stream, the partial / plan / candidate / result scratch, the
-// page-locked words the host reads at the end of the sub-batch, its share of the profile.  A context has two: while the
-// tail of sub-batch k (thresholds, plan, sweep 2, exact re-check, epilogue, copy-out) runs on one stream, sweep 1 of
-// sub-batch k + 1 already owns the matrix pipes on the other (match_pairs_impl).
+// Everything ONE device sub-batch in flight owns: its stream, the partial / plan / candidate / result scratch, the upload arenas
+// with their page-locked staging, the page-locked words the host reads at the end of the sub-batch, its share of the profile.  A
+// context has kInFlight (three) of them: while the tail of sub-batch k (thresholds, plan, sweep 2, exact re-check, epilogue,
+// copy-out) runs on one stream, the sweeps of sub-batches k + 1 and k + 2 are already queued on the others (match_pairs_impl).
+// Buffers grow on demand (DevBuf::ensure = hipFree + hipMalloc, both of which synchronise the DEVICE: a growth inside issue()
+// serialises the pipeline once -- in the first call of a job shape, and whenever a later sub-batch is larger than any before --
+// and is also what makes re-using a buffer safe that kernels queued earlier still read; steady state allocates nothing).
 struct PfPending {                // what the end-of-batch synchronisation has to look at
     bool active = false, compact = false, i8 = false, q8 = false;
     size_t n_lists = 0, P = 0;
@@ -722,7 +725,7 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
             const Image& ib = ctx->images[b.id2[p]];
             PfPair& pp = b.pf[p];
             pp.i8 = 1;
-            pp.a_h = reinterpret_cast<const _Float16*>(ia.i8);   // 144-byte rows behind the same pointers
+            pp.a_h = reinterpret_cast<const _Float16*>(ia.i8);   // 176-byte rows behind the same pointers
             pp.b_h = reinterpret_cast<const _Float16*>(ib.i8);
             pp.a_nrm = ia.nrm_i8;
             pp.b_nrm = ib.nrm_i8;
@@ -767,6 +770,16 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
             pp.b_err = ib.err_q8;
         }
     }
+    // The route is chosen per sub-batch: one pair that cannot take an integer route sends all of them to the fp16 kernels (same
+    // results, ~1.6 x the sweep time).  Counted, so that a mixed store shows up in the profile instead of only in the clock.
+    if (compact && ctx->prefilter == 1 && !i8 && !q8)
+        for (size_t p = 0; p < P; ++p) {
+            if (!b.pairs[p].valid || !b.pf[p].use) continue;
+            const Image& ia = ctx->images[b.id1[p]];
+            const Image& ib = ctx->images[b.id2[p]];
+            const bool twins = ctx->q8_route && ia.q8 && ib.q8 && (ctx->q8_route == 2 || b.pairs[p].n1 + b.pairs[p].n2 >= 2048);
+            if ((ia.is_u8 && ib.is_u8) || twins) SC.prof.demoted_pairs += 1;
+        }
     // fine twins: their sweep's bounds are the thresholds of sweep 2; coarse ones (a store with values near 1): an fp16 sweep 1'
     // of the live rows refines them first
     const bool q8_direct = q8 && (ctx->q8_direct == 2 || (ctx->q8_direct == 1 && ctx->q8_level <= kQ8DirectMaxLevel));
@@ -1861,6 +1874,7 @@ void add_profile(msfm_profile& to, const msfm_profile& d) {
     to.sweep1b_launches += d.sweep1b_launches;
     to.sweep1b_ms += d.sweep1b_ms;
     to.sweep1b_descriptor_pairs += d.sweep1b_descriptor_pairs;
+    to.demoted_pairs += d.demoted_pairs;
 }
 
 int drain_streams(msfm_ctx* ctx) {

@@ -102,11 +102,13 @@ def test_mixed_batch_takes_the_fp16_kernels(gpu_ctx, oracle):
     pairs = synth.all_pairs(3)
     mixed = gpu_ctx.match_pairs(pairs, **kw)
     assert gpu_ctx.profile()["sweep1_i8_launches"] == 0 and gpu_ctx.profile()["prefilter_pairs"] == len(pairs)
+    # ... but it is counted: pair (2, 0) joins two byte images and lost the integer route to its sub-batch's company
+    assert gpu_ctx.profile()["demoted_pairs"] == 1
     o_offs, oq, ot, od = oracle.match_pairs(imgs, pairs, nthreads=8, **kw)
     assert np.array_equal(mixed[0], o_offs) and np.array_equal(mixed[1][:, 0], oq) and np.array_equal(mixed[1][:, 1], ot)
     assert np.array_equal(b(mixed[2]), b(od)) and o_offs[-1] > 50
     only_bytes = gpu_ctx.match_pairs(np.array([[2, 0]], np.int32), **kw)
-    assert gpu_ctx.profile()["sweep1_i8_launches"] == 1
+    assert gpu_ctx.profile()["sweep1_i8_launches"] == 1 and gpu_ctx.profile()["demoted_pairs"] == 0
     check_vs_int_reference(u, [(2, 0)], only_bytes, **kw)
     gpu_ctx.clear_images()
 
