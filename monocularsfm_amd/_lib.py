@@ -102,8 +102,11 @@ def load():
     L.msfm_pair_from_id.argtypes = [C.c_int32, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.msfm_swap_image_pair.argtypes = [C.c_int, C.c_int]
     L.msfm_version.restype = C.c_char_p
-    L.msfm_device_count.argtypes = []
-    L.msfm_device_count.restype = C.c_int
+    try:   # (the A/B tools also load older builds of the library: tools/ab_multi.py)
+        L.msfm_device_count.argtypes = []
+        L.msfm_device_count.restype = C.c_int
+    except AttributeError:
+        pass
     for name in EXPORTS:
         getattr(L, name)  # raises AttributeError if the library lacks a declared symbol
     _lib = L

@@ -645,10 +645,36 @@ __device__ __forceinline__ bool order_sensitive(int i0, float d0, float d1, floa
     return !certified;
 }
 
-__global__ __launch_bounds__(256) void epilogue_kernel(const PairDesc* __restrict__ pairs, EpiParams prm,
-                                                       const int* __restrict__ k_i0,
-                                                       const float* __restrict__ k_d0,
-                                                       const float* __restrict__ k_d1,
+// Where the epilogue takes a row's (idx0, d0, d1) from: the final kNN arrays (brute-force route, knnMatch-level API, tie fix-up), or --
+// matrix-core route, match lists -- straight from the reduce slots of the exact re-check: a row whose threshold is -inf was pruned
+// (it may own stray candidates of the other direction: "no neighbour"), a live one carries its best / second (S, index) keys.
+// The second form saves writing and re-reading 12 bytes for every one of a batch's ~83 M row / column slots, 94 % of them dead.
+struct KnnFromArrays {
+    const int* i0;
+    const float* d0;
+    const float* d1;
+    __device__ __forceinline__ void get(long long slot, int& i, float& a, float& b) const {
+        i = i0[slot];
+        a = d0[slot];
+        b = d1[slot];
+    }
+};
+struct KnnFromKeys {
+    const float* tuv;
+    const unsigned long long* best;
+    const unsigned long long* second;
+    __device__ __forceinline__ void get(long long slot, int& i, float& a, float& b) const {
+        i = -1;
+        a = b = 3.402823466e+38f;
+        if (tuv[slot] == -f_inf()) return;
+        const unsigned long long kb = best[slot], ks = second[slot];
+        if (kb != ~0ull) { i = (int)(unsigned)(kb & 0xffffffffu); a = sqrtf(__uint_as_float((unsigned)(kb >> 32))); }
+        if (ks != ~0ull) b = sqrtf(__uint_as_float((unsigned)(ks >> 32)));
+    }
+};
+
+template <class KNN>
+__global__ __launch_bounds__(256) void epilogue_kernel(const PairDesc* __restrict__ pairs, EpiParams prm, KNN knn,
                                                        int2* __restrict__ st_qt, float* __restrict__ st_d,
                                                        int* __restrict__ counts, int* __restrict__ sens_counts) {
     MSFM_TAIL_PRIO();
@@ -672,16 +698,15 @@ __global__ __launch_bounds__(256) void epilogue_kernel(const PairDesc* __restric
         int t = -1;
         float d0 = 0.f;
         if (q < pd.n1) {
-            t = k_i0[pd.kf_off + q];
-            d0 = k_d0[pd.kf_off + q];
-            const float d1 = k_d1[pd.kf_off + q];
+            float d1;
+            knn.get(pd.kf_off + q, t, d0, d1);
             // m[0].distance < distance_ratio * m[1].distance, fp32 product, strict
             keep = (t >= 0) && (d1 < 3.402823466e+38f) && (d0 < prm.ratio * d1);
             sens = certify && order_sensitive(t, d0, d1, prm.ratio, prm.max_distance, true);
             if (keep && prm.cross_check) {
-                const int rq = k_i0[pd.kr_off + t];
-                const float rd0 = k_d0[pd.kr_off + t];
-                const float rd1 = k_d1[pd.kr_off + t];
+                int rq;
+                float rd0, rd1;
+                knn.get(pd.kr_off + t, rq, rd0, rd1);
                 const bool rkeep = (rq >= 0) && (rd1 < 3.402823466e+38f) && (rd0 < prm.ratio * rd1);
                 const int vis = rkeep ? rq : 0;  // unordered_map::operator[] default-inserts 0
                 keep = (vis == q);
@@ -708,7 +733,10 @@ __global__ __launch_bounds__(256) void epilogue_kernel(const PairDesc* __restric
     if (certify && prm.cross_check)
         for (int t0 = 0; t0 < pd.n2; t0 += 256) {
             const int t = t0 + threadIdx.x;
-            const bool s = t < pd.n2 && order_sensitive(k_i0[pd.kr_off + t], k_d0[pd.kr_off + t], k_d1[pd.kr_off + t], prm.ratio, prm.max_distance, false);
+            int ri = -1;
+            float rd0 = 0.f, rd1 = 0.f;
+            if (t < pd.n2) knn.get(pd.kr_off + t, ri, rd0, rd1);
+            const bool s = t < pd.n2 && order_sensitive(ri, rd0, rd1, prm.ratio, prm.max_distance, false);
             const unsigned long long sb = __ballot(s);
             if (lane == 0 && sb) atomicAdd(&n_sens, __popcll(sb));
         }

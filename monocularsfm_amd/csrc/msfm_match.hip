@@ -239,6 +239,7 @@ struct Scratch {
     DevBuf d_sub_qt, d_sub_d;         // the sub-batch's match lists, compact (CSR order), before they join the call's lists
     DevBuf d_fix_count, d_fix_list;
     int fix_cap_eff = 0;              // capacity handed to the kernels of the current batch (0: ties need no fix-up)
+    bool keys_epilogue = false;       // the epilogue reads the reduce slots of the exact re-check itself: no pf_finalize_kernel, no kNN arrays
     // prefilter path
     DevBuf d_tu, d_tv, d_cand, d_cand_count, d_best, d_second;
     DevBuf d_cmp_tu, d_live_idx, d_row_pair, d_row_src, d_vpairs, d_vpf, d_vitems, d_lists;
@@ -1102,11 +1103,13 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
         HIPCHK(ctx, hipGetLastError());
         DBGSYNC(ctx, "pf_exact_candidates_kernel");
     }
-    hipLaunchKernelGGL(pf_finalize_kernel, mgrid, dim3(256), 0, SC.stream, dp, dpf, (const float*)tuv, SC.d_best.as<unsigned long long>(),
-                       SC.d_second.as<unsigned long long>(), SC.d_k_i0.as<int>(), SC.d_k_d0.as<float>(),
-                       SC.d_k_d1.as<float>(), SC.d_fix_count.as<int>(), SC.d_fix_list.as<int4>(), SC.fix_cap_eff);
-    HIPCHK(ctx, hipGetLastError());
-    DBGSYNC(ctx, "pf_finalize_kernel");
+    if (!SC.keys_epilogue) {
+        hipLaunchKernelGGL(pf_finalize_kernel, mgrid, dim3(256), 0, SC.stream, dp, dpf, (const float*)tuv, SC.d_best.as<unsigned long long>(),
+                           SC.d_second.as<unsigned long long>(), SC.d_k_i0.as<int>(), SC.d_k_d0.as<float>(),
+                           SC.d_k_d1.as<float>(), SC.d_fix_count.as<int>(), SC.d_fix_list.as<int4>(), SC.fix_cap_eff);
+        HIPCHK(ctx, hipGetLastError());
+        DBGSYNC(ctx, "pf_finalize_kernel");
+    }
     // which pairs own an overflowed list, how many candidates were evaluated: read at the end of the batch
     if (n_lists > 0) {
         hipLaunchKernelGGL(pf_overflow_kernel, dim3((unsigned)((n_lists + 255) / 256)), dim3(256), 0, SC.stream, dl, (int)n_lists,
@@ -1271,7 +1274,7 @@ int run_exact(msfm_ctx* ctx, Batch& b, size_t ev_base) {
 //   need_fix: the caller can observe WHICH index a sqrt-space tie resolves to (knnMatch-level API, ratio > 1).
 //   For match lists with ratio <= 1 a row with d0 == d1 fails `d0 < ratio * d1` in both directions, so its
 //   index never reaches a list: the queue is not filled and nothing is re-scanned.
-int run_knn(msfm_ctx* ctx, Batch& b, size_t ev_base, bool* exact_launched, PruneParams prune, bool need_fix) {
+int run_knn(msfm_ctx* ctx, Batch& b, size_t ev_base, bool* exact_launched, PruneParams prune, bool need_fix, bool lists_only) {
     assign_common(b);
     SC.fix_cap_eff = need_fix ? ctx->fix_cap : 0;
     const long long kn = std::max<long long>(1, b.kf_elems + b.kr_elems);
@@ -1283,12 +1286,15 @@ int run_knn(msfm_ctx* ctx, Batch& b, size_t ev_base, bool* exact_launched, Prune
     HIPCHK(ctx, hipMemsetAsync(SC.d_fix_count.p, 0, 4, SC.stream));
     bool any_pf = false, any_exact = false;
     for (auto& pd : b.pairs) any_pf |= (pd.valid && pd.path == 1);
+    for (auto& pd : b.pairs) any_exact |= (pd.valid && pd.path == 0);
+    // match lists of a batch that is on the matrix-core route throughout, no sqrt-space tie queue: the epilogue reads best / second
+    // keys directly (KnnFromKeys); the knnMatch-level API and mixed batches keep the kNN arrays
+    SC.keys_epilogue = lists_only && any_pf && !any_exact && SC.fix_cap_eff == 0;
     int rc;
     if (any_pf) {
         rc = run_prefilter(ctx, b, ev_base + 2, prune);  // events ev_base+2 .. ev_base+5
         if (rc != MSFM_OK) return rc;
     }
-    for (auto& pd : b.pairs) any_exact |= (pd.valid && pd.path == 0);
     *exact_launched = false;
     if (any_exact) {
         rc = run_exact(ctx, b, ev_base);
@@ -2034,7 +2040,7 @@ static int match_pairs_impl(msfm_ctx* ctx, const int32_t* pairs, int n_pairs, co
         SC.prof = msfm_profile{};
         SC.seq = ctx->issue_seq++;
         SC.sweep2_recorded = false;
-        int rc = run_knn(ctx, b, ev_base, &w.exact_launched, prune, need_fix);
+        int rc = run_knn(ctx, b, ev_base, &w.exact_launched, prune, need_fix, true);
         if (rc != MSFM_OK) return rc;
         const long long oe = std::max<long long>(1, b.out_elems);
         HIPCHK(ctx, SC.d_st_qt.ensure(oe * sizeof(int2)));
@@ -2045,9 +2051,14 @@ static int match_pairs_impl(msfm_ctx* ctx, const int32_t* pairs, int n_pairs, co
         HIPCHK(ctx, SC.d_sens.ensure(P * 4));
         HIPCHK(ctx, SC.d_offsets.ensure((P + 1) * 8));
         EpiParams ep = {prm.ratio, prm.cross_check, prm.max_distance};
-        hipLaunchKernelGGL(epilogue_kernel, dim3((unsigned)P), dim3(256), 0, SC.stream, SC.d_pairs.as<PairDesc>(), ep,
-                           SC.d_k_i0.as<int>(), SC.d_k_d0.as<float>(), SC.d_k_d1.as<float>(),
-                           SC.d_st_qt.as<int2>(), SC.d_st_d.as<float>(), SC.d_counts.as<int>(), SC.d_sens.as<int>());
+        if (SC.keys_epilogue)
+            hipLaunchKernelGGL(epilogue_kernel<KnnFromKeys>, dim3((unsigned)P), dim3(256), 0, SC.stream, SC.d_pairs.as<PairDesc>(), ep,
+                               KnnFromKeys{SC.d_tu.as<float>(), SC.d_best.as<unsigned long long>(), SC.d_second.as<unsigned long long>()},
+                               SC.d_st_qt.as<int2>(), SC.d_st_d.as<float>(), SC.d_counts.as<int>(), SC.d_sens.as<int>());
+        else
+            hipLaunchKernelGGL(epilogue_kernel<KnnFromArrays>, dim3((unsigned)P), dim3(256), 0, SC.stream, SC.d_pairs.as<PairDesc>(), ep,
+                               KnnFromArrays{SC.d_k_i0.as<int>(), SC.d_k_d0.as<float>(), SC.d_k_d1.as<float>()},
+                               SC.d_st_qt.as<int2>(), SC.d_st_d.as<float>(), SC.d_counts.as<int>(), SC.d_sens.as<int>());
         HIPCHK(ctx, hipGetLastError());
         const int* d_counts = SC.d_counts.as<int>();
         const int2* d_st_qt = SC.d_st_qt.as<int2>();
@@ -2360,7 +2371,7 @@ static int knn2_pair_impl(msfm_ctx* ctx, int id1, int id2, int32_t* fwd_idx0, fl
         b.desc_pairs = b.algo_bytes = 0;
         b.pairs[0].path = b.pf[0].use = force_exact[0] ? 0 : pp.use;
         SC.prof = msfm_profile{};   // only the attempt that is kept counts
-        rc = run_knn(ctx, b, 2, &exact_launched, PruneParams{0, 0.f, 0.f}, true);  // knnMatch twin: every row keeps its neighbours
+        rc = run_knn(ctx, b, 2, &exact_launched, PruneParams{0, 0.f, 0.f}, true, false);  // knnMatch twin: every row keeps its neighbours
         if (rc != MSFM_OK) return rc;
         SC.d_offsets.release();   // (no CSR on this path: the export kernel skips absent segments)
         SC.d_sens.release();

@@ -21,11 +21,15 @@ args = ap.parse_args()
 imgs, pairs, name = synth.job("synthetic-u8", args.images or 48, 8192, seed=1329) if args.u8 else synth.job("south-building", args.images or 128)
 kw = {"max_distance": 1e9} if args.u8 else {}
 tree = _lib.LIB_PATH
+all_exports = list(_lib.EXPORTS)
 ctxs = {}
 for spec in args.libs:
     nm, _, path = spec.partition("=")
     _lib._lib = None
     _lib.LIB_PATH = tree if (nm == "tree" and not path) else path
+    import ctypes
+    probe = ctypes.CDLL(_lib.LIB_PATH)
+    _lib.EXPORTS = [e for e in all_exports if hasattr(probe, e)]   # (an older build may lack the newest entry points)
     ctx = _lib.Context(0)
     for i, im in enumerate(imgs):
         ctx.upload_image(i, im)
