@@ -91,8 +91,10 @@ template <> struct OrderTraits<3> {
 struct PairDesc {
     const float* a_panel;  // image id1 (query), panel layout
     const float* b_panel;  // image id2 (train)
-    const float* a_raw;    // row-major copies (tie fix-up only)
+    const float* a_raw;    // row-major copies (tie fix-up)
     const float* b_raw;
+    const float* a_rawp;   // the same rows for the exact re-check: position 64 h + 4 L + c of a row holds its element 16 (4 h + c) + L
+    const float* b_rawp;   // (lane L of a 16-lane group needs the elements 16 j + L, j = 0..7, in every accumulation order: two 16-byte loads)
     int n1, n2;
     int a_blocks, b_tiles;
     int n1pad, n2pad;

@@ -143,6 +143,7 @@ struct Image {
     int nalloc = 0;  // allocated blocks (even: the prefilter walks 256-row A blocks); padding is zero-filled
     float* panel = nullptr;
     float* raw = nullptr;
+    float* rawp = nullptr;   // raw, every row permuted for the exact re-check (PairDesc::a_rawp)
     // prefilter operands: fp16 rows of 272 B (128 halfs + the norm quadruple of the ninth MFMA k-step), row norms
     // (+inf padded), maxima
     _Float16* h16 = nullptr;
@@ -174,6 +175,7 @@ struct Image {
 void free_image(Image& im) {
     if (im.panel) (void)hipFree(im.panel);
     if (im.raw) (void)hipFree(im.raw);
+    if (im.rawp) (void)hipFree(im.rawp);
     if (im.h16) (void)hipFree(im.h16);
     if (im.nrm) (void)hipFree(im.nrm);
     if (im.i8) (void)hipFree(im.i8);
@@ -437,6 +439,8 @@ int fill_pair(msfm_ctx* ctx, int id1, int id2, PairDesc& pd, PfPair& pp) {
     pd.b_panel = b.panel;
     pd.a_raw = a.raw;
     pd.b_raw = b.raw;
+    pd.a_rawp = a.rawp;
+    pd.b_rawp = b.rawp;
     pd.n1 = a.n;
     pd.n2 = b.n;
     pd.a_blocks = a.nblk;
@@ -968,8 +972,9 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
                                    (const long long*)SC.d_grow0.as<long long>(), SC.d_mrow.as<long long>());
             HIPCHK(ctx, hipGetLastError());
             DBGSYNC(ctx, "pf_member_rows_kernel");
-            hipLaunchKernelGGL(pf_assign_kernel, dim3((unsigned)(2 * P)), dim3(256), 0, SC.stream, dp, dpf, dpp, (const float*)tuv,
-                               (const unsigned*)colmask, (const long long*)SC.d_mrow.as<long long>(),
+            hipLaunchKernelGGL(pf_assign_kernel, dim3((unsigned)(2 * P), (unsigned)((b.max_npad + kAssignChunk - 1) / kAssignChunk)), dim3(256), 0,
+                               SC.stream, dp, dpf, dpp, (const float*)tuv,
+                               (const unsigned*)colmask, (const long long*)SC.d_mrow.as<long long>(), SC.d_cnt.as<int>(),
                                SC.d_live_idx.as<int>(), SC.d_row_pair.as<int>(), SC.d_cmp_tu.as<float>(),
                                SC.d_row_src.as<const _Float16*>(), i8 ? kI8RowBytes / 2 : kPfRowHalfs,
                                SC.d_best.as<unsigned long long>(), SC.d_second.as<unsigned long long>(), norms_only);
@@ -1600,6 +1605,7 @@ static int alloc_image(msfm_ctx* ctx, Image& im, int n) {
     if (n == 0) return MSFM_OK;
     HIPCHK(ctx, hipMalloc((void**)&im.panel, (size_t)im.nalloc * kPanelFloats * 4));
     HIPCHK(ctx, hipMalloc((void**)&im.raw, (size_t)n * kDim * 4));
+    HIPCHK(ctx, hipMalloc((void**)&im.rawp, (size_t)n * kDim * 4));
     return MSFM_OK;
 }
 
@@ -1656,6 +1662,17 @@ static int build_q8_twin(msfm_ctx* ctx, Image& im) {
     return MSFM_OK;
 }
 
+namespace {
+// rawp: position 64 h + 4 L + c of a row <- its element 16 (4 h + c) + L (the exact re-check's 16-lane groups, msfm_prefilter.hip.h:
+// lane L's float4 number h sits at float offset 64 h + 4 L -- the sixteen lanes of a group read 256 contiguous bytes per load)
+__global__ void permute_rows_kernel(const float* __restrict__ raw, float* __restrict__ rawp, int n) {
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < (long long)n * kDim; e += (long long)gridDim.x * blockDim.x) {
+        const int k = (int)(e & (kDim - 1)), h = k >> 6, L = (k >> 2) & 15, c = k & 3;
+        rawp[e] = raw[(e & ~(long long)(kDim - 1)) + 16 * (4 * h + c) + L];
+    }
+}
+}  // namespace
+
 // everything derived from the row-major fp32 copy `im.raw` (src8 != nullptr: u8 rows still to be widened
 // into im.raw by the layout kernel): panels in accumulation order, prefilter operands
 static int build_image(msfm_ctx* ctx, Image& im, const unsigned char* src8, bool is_u8) {
@@ -1678,6 +1695,8 @@ static int build_image(msfm_ctx* ctx, Image& im, const unsigned char* src8, bool
         else
             hipLaunchKernelGGL((layout_kernel<3, unsigned char>), dim3(blocks), dim3(256), 0, SC.stream, src8, im.raw, im.panel, n, im.nalloc);
     }
+    HIPCHK(ctx, hipGetLastError());
+    hipLaunchKernelGGL(permute_rows_kernel, dim3(std::min(2048, (n * kDim + 255) / 256)), dim3(256), 0, SC.stream, (const float*)im.raw, im.rawp, n);
     HIPCHK(ctx, hipGetLastError());
     // prefilter operands (order-independent): fp16 swizzled blocks, norms, maxima
     const int npad = im.nalloc * kBM;

@@ -249,61 +249,81 @@ __global__ void pf_member_rows_kernel(const PlanGroup* __restrict__ groups, int 
 }
 
 // every live row takes its slot(s) in the compacted row set: index, pair, threshold (sweep 2 folds (T - |a|^2)/2 into
-// the MFMA), and the address of its fp16 operand row.  Every member is filled by exactly one workgroup (the forward
-// member by (pair, 0), the reverse members by (pair, 1)), so the fill cursors live in LDS.
-__global__ void pf_assign_kernel(const PairDesc* __restrict__ pairs, const PfPair* __restrict__ pf, const PlanPair* __restrict__ pp_plan,
-                                 const float* __restrict__ tuv, const unsigned* __restrict__ colmask, const long long* __restrict__ mrow,
-                                 int* __restrict__ live_idx, int* __restrict__ row_pair, float* __restrict__ cmp_tu,
-                                 const _Float16** __restrict__ row_src, int row_halfs /* 136: fp16 rows, 72: byte rows */,
-                                 unsigned long long* __restrict__ best, unsigned long long* __restrict__ second,
-                                 int norms_only /* plan A of route Q: the sweep wants -|a|^2 (accumulator = -S~/2), not T - |a|^2 */) {
+// the MFMA), and the address of its fp16 operand row.
+// One workgroup per (pair, direction, chunk of 1024 rows): it counts its live rows per member (LDS), reserves that many slots of
+// every member with ONE atomicSub on the member's count -- the counts the thresholds / prune kernel left there are exactly the rows
+// this kernel finds, they tick down to zero -- and fills them.  Round 3 walked a whole (pair, direction) per workgroup with the fill
+// cursors in LDS: five chunks in a row, each a chain of dependent round trips -- 65 000 waves living 80 us each, 79 % of it in
+// SQ_WAIT_ANY, 1.3 TB/s.  Every load of a thread is issued before anything depends on one.   grid = (2 * pairs, chunks)
+constexpr int kAssignChunk = 1024;
+__global__ __launch_bounds__(256) void pf_assign_kernel(
+    const PairDesc* __restrict__ pairs, const PfPair* __restrict__ pf, const PlanPair* __restrict__ pp_plan,
+    const float* __restrict__ tuv, const unsigned* __restrict__ colmask, const long long* __restrict__ mrow, int* __restrict__ cnt,
+    int* __restrict__ live_idx, int* __restrict__ row_pair, float* __restrict__ cmp_tu,
+    const _Float16** __restrict__ row_src, int row_halfs /* 136: fp16 rows, 88: byte rows */,
+    unsigned long long* __restrict__ best, unsigned long long* __restrict__ second,
+    int norms_only /* plan A of route Q: the sweep wants -|a|^2 (accumulator = -S~/2), not T - |a|^2 */) {
     MSFM_TAIL_PRIO();
     const int p = blockIdx.x >> 1, dir = blockIdx.x & 1;
     const PlanPair pl = pp_plan[p];
     if (pl.fwd_member < 0) return;
     const PairDesc pd = pairs[p];
-    const PfPair pp = pf[p];
     const int n = dir ? pd.n2 : pd.n1;
+    const int e_begin = blockIdx.y * kAssignChunk;
+    if (e_begin >= n) return;
+    const PfPair pp = pf[p];
     const long long off = dir ? pp.tv_off : pp.tu_off;
     const float* nrm = dir ? pp.b_nrm : pp.a_nrm;
     const _Float16* src = dir ? pp.b_h : pp.a_h;
-    __shared__ int cursor[32];
+    const int bits = dir ? pl.rev_bits : 1, member0 = dir ? pl.rev_member0 : pl.fwd_member;
+    __shared__ int hist[32];
     __shared__ long long base[32];
-    if (threadIdx.x < 32) {
-        cursor[threadIdx.x] = 0;
-        const int bits = dir ? pl.rev_bits : 1;
-        base[threadIdx.x] = (int)threadIdx.x < bits ? mrow[(dir ? pl.rev_member0 : pl.fwd_member) + threadIdx.x] : -1;
+    // ---- all loads of the thread (clamped: the arrays cover the padded rows)
+    float t4[4], n4[4];
+    unsigned m4[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int e = e_begin + (int)threadIdx.x + j * 256, ec = e < n ? e : n - 1;
+        t4[j] = tuv[off + ec];
+        m4[j] = dir ? colmask[off + ec] : 1u;
+        n4[j] = nrm[ec];
+        if (e >= n) t4[j] = -f_inf();
+    }
+    long long my_row0 = -1;
+    if ((int)threadIdx.x < bits) my_row0 = mrow[member0 + threadIdx.x];
+    if (threadIdx.x < 32) hist[threadIdx.x] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (t4[j] == -f_inf()) continue;
+        for (unsigned m = m4[j]; m; m &= m - 1) atomicAdd(&hist[__builtin_ctz(m)], 1);
     }
     __syncthreads();
-    // (four independent threshold loads in flight per thread: ~94 % of the slots are dead and need nothing else)
-    for (int e0 = threadIdx.x; e0 < n; e0 += 4 * blockDim.x) {
-        float t4[4];
+    if ((int)threadIdx.x < bits) {
+        const int h = hist[threadIdx.x];
+        // (an invalid plan -- capacity exceeded, the batch is re-run -- has no rows to give out)
+        base[threadIdx.x] = (h > 0 && my_row0 >= 0) ? my_row0 + (long long)(atomicSub(&cnt[member0 + threadIdx.x], h) - h) : -1;
+        hist[threadIdx.x] = 0;
+    }
+    __syncthreads();
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int e = e0 + j * blockDim.x;
-            t4[j] = e < n ? tuv[off + e] : -f_inf();
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int e = e0 + j * blockDim.x;
-            const float t = t4[j];
-            if (t == -f_inf()) continue;
-            // the reduce kernels only ever touch the slots of live rows / columns (and pf_finalize_kernel reads no others):
-            // "no candidate yet" is written here, for the 6 % that are alive, instead of a memset over every slot of the batch
-            best[off + e] = ~0ull;
-            second[off + e] = ~0ull;
-            unsigned m = dir ? colmask[off + e] : 1u;
-            while (m) {
-                const int b = __builtin_ctz(m);
-                m &= m - 1;
-                const long long r0 = base[b];
-                if (r0 < 0) continue;   // invalid plan
-                const long long k = r0 + atomicAdd(&cursor[b], 1);
-                live_idx[k] = e;
-                row_pair[k] = p;
-                cmp_tu[k] = norms_only ? -nrm[e] : t - nrm[e];
-                row_src[k] = src + (size_t)e * row_halfs;
-            }
+    for (int j = 0; j < 4; ++j) {
+        const float t = t4[j];
+        if (t == -f_inf()) continue;
+        const int e = e_begin + (int)threadIdx.x + j * 256;
+        // the reduce kernels only ever touch the slots of live rows / columns: "no candidate yet" is written here, for the
+        // 6 % that are alive, instead of a memset over every slot of the batch
+        best[off + e] = ~0ull;
+        second[off + e] = ~0ull;
+        for (unsigned m = m4[j]; m; m &= m - 1) {
+            const int b = __builtin_ctz(m);
+            const long long r0 = base[b];
+            if (r0 < 0) continue;
+            const long long k = r0 + atomicAdd(&hist[b], 1);
+            live_idx[k] = e;
+            row_pair[k] = p;
+            cmp_tu[k] = norms_only ? -n4[j] : t - n4[j];
+            row_src[k] = src + (size_t)e * row_halfs;
         }
     }
 }

@@ -232,14 +232,32 @@ __global__ void pf_thresholds_kernel(const PairDesc* __restrict__ pairs, const P
     bool row_live = false;       // for the plan counts below
     unsigned col_bits = 0;
     const float eps_norm = 4.8828125e-4f * fmaxf(pp.a_c, pp.b_c);  // 2^-11 c: fp16 subnormal flush of the norm quadruples
-    if (e < pd.n1pad && !(marked && tu[pp.tu_off + e] == -f_inf())) {
+    // ---- every load of this thread first, at clamped (always valid) indices: one memory round trip per wave instead of a chain of
+    // them (rows, the columns' partials, their norms); see pf_prune_q8_kernel
+    const float2* cp2 = reinterpret_cast<const float2*>(cp_s0);
+    const int* cpk = reinterpret_cast<const int*>(cp_s0);   // (the integer sweeps write 4-byte packed partials: msfm_cp_pack)
+    const int nb = pd.a_blocks256;
+    const bool in_r = e < pd.n1pad, in_c = e < pd.n2pad;
+    const int er = in_r ? e : 0, ec = in_c ? e : 0;
+    const float ld_rs0 = rp_s0[pd.rp_off + er], ld_rs1 = rp_s1[pd.rp_off + er];
+    const float ld_anrm = pp.a_nrm[er], ld_bnrm = pp.b_nrm[ec];
+    const float ld_tu = marked ? tu[pp.tu_off + er] : 0.f, ld_tv = marked ? tv[pp.tv_off + ec] : 0.f;
+    float2 ld_cp[16];
+#pragma unroll
+    for (int p = 0; p < 16; ++p) {
+        const long long i = pd.cp_off + (long long)min(p, nb - 1) * pd.n2pad + ec;
+        ld_cp[p] = pp.i8 ? make_float2(__int_as_float(cpk[i]), 0.f) : cp2[i];
+    }
+    auto partial16 = [&](int p) -> float2 { return pp.i8 ? i8_cp_unpack(__float_as_int(ld_cp[p].x)) : ld_cp[p]; };
+    if (in_r && !(marked && ld_tu == -f_inf())) {
         float s0 = f_inf(), s1 = f_inf();
-        for (int p = 0; p < pd.ranges; ++p) {
+        v2_merge(s0, s1, ld_rs0, ld_rs1);
+        for (int p = 1; p < pd.ranges; ++p) {   // (a pair split into B ranges: small batches only)
             const long long o = pd.rp_off + (long long)p * pd.n1pad + e;
             v2_merge(s0, s1, rp_s0[o], rp_s1[o]);
         }
         // s1 = S~(2); eps_row = rel*(na + nb_max) + abs*(sqrt(na)+sqrt(nb_max)) + eps_norm; threshold in S-space
-        const float na = pp.a_nrm[e];
+        const float na = ld_anrm;
         const float eps = pp.i8 ? kI8Eps : kEpsRel * (na + pp.b_nrm_max) + kEpsAbs * (sqrtf(na) + sqrtf(pp.b_nrm_max)) + eps_norm;
         // + roundings here and in sweep 2's test (none on the integer path: S~, T and the test are exact integers)
         const float slack = pp.i8 ? 2.f * eps : 2.f * eps + 1e-5f * (fabsf(s1) + na + pp.b_nrm_max);
@@ -247,24 +265,21 @@ __global__ void pf_thresholds_kernel(const PairDesc* __restrict__ pairs, const P
         tu[pp.tu_off + e] = live ? s1 + slack : -f_inf();
         row_live = live;
     }
-    if (e < pd.n2pad && marked && tv[pp.tv_off + e] == -f_inf()) {
+    if (in_c && marked && ld_tv == -f_inf()) {
         if (colmask) colmask[pp.tv_off + e] = 0;
-    } else if (e < pd.n2pad) {
+    } else if (in_c) {
         // column partials of sweep 1: per 512-row A block the two largest of the accumulator maxima (-S~/2) over four
         // disjoint row classes; the second smallest S~ over all of them is an upper bound of the column's second-smallest.
         // Up to 16 blocks (8192 rows) the blocks' minima stay in registers for the mask below.
         float s0 = f_inf(), s1 = f_inf();
-        const float2* cp2 = reinterpret_cast<const float2*>(cp_s0);
-        const int* cpk = reinterpret_cast<const int*>(cp_s0);   // (the integer sweeps write 4-byte packed partials: msfm_cp_pack)
         auto partial = [&](long long i) -> float2 { return pp.i8 ? i8_cp_unpack(cpk[i]) : cp2[i]; };
-        const int nb = pd.a_blocks256;
         float bmin[16];
         if (nb <= 16) {
 #pragma unroll
             for (int p = 0; p < 16; ++p) {
                 bmin[p] = f_inf();
                 if (p < nb) {
-                    const float2 m = partial(pd.cp_off + (long long)p * pd.n2pad + e);
+                    const float2 m = partial16(p);
                     bmin[p] = -2.f * m.x;
                     v2_merge(s0, s1, -2.f * m.x, -2.f * m.y);
                 }
@@ -275,7 +290,7 @@ __global__ void pf_thresholds_kernel(const PairDesc* __restrict__ pairs, const P
                 v2_merge(s0, s1, -2.f * m.x, -2.f * m.y);
             }
         }
-        const float nb_ = pp.b_nrm[e];
+        const float nb_ = ld_bnrm;
         const float eps = pp.i8 ? kI8Eps : kEpsRel * (nb_ + pp.a_nrm_max) + kEpsAbs * (sqrtf(nb_) + sqrtf(pp.a_nrm_max)) + eps_norm;
         const float slack = pp.i8 ? 2.f * eps : 2.f * eps + 1e-5f * (fabsf(s1) + nb_ + pp.a_nrm_max);
         const bool live = (e < pd.n2) && !pf_dead(s0, s1, nb_, eps, pp.a_nrm_max, pr);
@@ -372,27 +387,32 @@ __device__ __forceinline__ unsigned long long pf_key(float s, int idx) {
 constexpr int kExSpan = 256;
 constexpr int kExLists = 1024;   // lists per XCD and round of the prefix table (4 per thread)
 
+// lane l of a 16-lane row <- lane l + N of the same row (0 beyond the row): a DPP row shift, a VALU modifier -- the reductions below
+// used eight LDS-crossbar shuffles (ds_bpermute) per candidate in round 3
+template <int N>
+__device__ __forceinline__ float pf_row_shl(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x100 + N, 0xf, 0xf, true));
+}
+
+// The named order's reduction of one candidate's 128 squared differences; av / bv: the lane's elements 16 j + sub, j = 0..7, of the two
+// rows.  The result is valid in lane 0 of the 16-lane group (sub == 0) -- the lane that stores it.
 template <int ORDER>
-__device__ __forceinline__ float pf_exact_combine(const float (&av)[8], const float (&bv)[8], int sub) {
-    const int base = threadIdx.x & 63 & ~15;
+__device__ __forceinline__ float pf_exact_combine(const float (&av)[8], const float (&bv)[8]) {
     if (ORDER == 0) {
+        // SSE: 16 lane partials p[L] = sum_j t(16 j + L)^2 (rounded product, rounded add, j ascending);
+        // s[l] = ((p[l] + p[4+l]) + p[8+l]) + p[12+l], l = 0..3; result (s0 + s2) + (s1 + s3)
         float p = 0.f;
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
             const float t = av[it] - bv[it];
             p = (it == 0) ? t * t : p + t * t;
         }
-        // s[l] = ((p[l] + p[4+l]) + p[8+l]) + p[12+l]; result = (s0+s2)+(s1+s3)
-        const float p4 = __shfl(p, base | ((sub & 3) + 4), 64);
-        const float p8 = __shfl(p, base | ((sub & 3) + 8), 64);
-        const float p12 = __shfl(p, base | ((sub & 3) + 12), 64);
-        const float p0 = __shfl(p, base | (sub & 3), 64);
-        const float s = ((p0 + p4) + p8) + p12;  // valid in every lane for l = sub & 3
-        const float s0 = __shfl(s, base | 0, 64), s1 = __shfl(s, base | 1, 64);
-        const float s2 = __shfl(s, base | 2, 64), s3 = __shfl(s, base | 3, 64);
-        return (s0 + s2) + (s1 + s3);
+        const float s = ((p + pf_row_shl<4>(p)) + pf_row_shl<8>(p)) + pf_row_shl<12>(p);   // lanes 0..3
+        const float u = s + pf_row_shl<2>(s);                                              // lane 0: s0 + s2, lane 1: s1 + s3
+        return u + pf_row_shl<1>(u);
     } else if (ORDER == 3) {
-        // AVX-512 order: 64 partials p[16 v + L]; lane `sub` owns L = sub: four accumulators x two iterations, fused
+        // AVX-512: 64 partials p[16 v + L]; lane L: four accumulators x two iterations, fused; y_l = (s_l + s_{l+8}) + (s_{l+4} + s_{l+12}),
+        // result (y0 + y2) + (y1 + y3)
         float s = 0.f;
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
@@ -401,13 +421,13 @@ __device__ __forceinline__ float pf_exact_combine(const float (&av)[8], const fl
             const float p = __builtin_fmaf(t1, t1, t0 * t0);
             s = (v == 0) ? p : s + p;
         }
-        // y_l = (s_l + s_{l+8}) + (s_{l+4} + s_{l+12}), result (y0 + y2) + (y1 + y3): butterflies (a + b == b + a bitwise)
-        const float x = s + __shfl(s, base | (sub ^ 8), 64);
-        const float y = x + __shfl(x, base | (sub ^ 4), 64);
-        const float z = y + __shfl(y, base | (sub ^ 2), 64);
-        return z + __shfl(z, base | (sub ^ 1), 64);
+        const float x = s + pf_row_shl<8>(s);   // lanes 0..7
+        const float y = x + pf_row_shl<4>(x);   // lanes 0..3
+        const float z = y + pf_row_shl<2>(y);   // lanes 0, 1
+        return z + pf_row_shl<1>(z);
     } else {
-        // 32 partials: lane `sub` owns L = sub (elements 32 it + sub) and L = sub + 16 (elements 32 it + sub + 16)
+        // AVX2: 32 partials; lane L owns L (elements 32 it + L) and L + 16 (elements 32 it + L + 16), fused;
+        // s[l] = ((p[l] + p[8+l]) + p[16+l]) + p[24+l], l = 0..7; result ((s0+s1)+(s2+s3)) + ((s4+s5)+(s6+s7))
         float pa = 0.f, pb = 0.f;
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
@@ -416,15 +436,10 @@ __device__ __forceinline__ float pf_exact_combine(const float (&av)[8], const fl
             pa = (it == 0) ? ta * ta : __builtin_fmaf(ta, ta, pa);
             pb = (it == 0) ? tb * tb : __builtin_fmaf(tb, tb, pb);
         }
-        // s[l] = ((p[l]+p[8+l])+p[16+l])+p[24+l], l = 0..7: p[l]=pa(l), p[8+l]=pa(8+l), p[16+l]=pb(l), p[24+l]=pb(8+l)
-        const int l = sub & 7;
-        const float q0 = __shfl(pa, base | l, 64), q1 = __shfl(pa, base | (8 + l), 64);
-        const float q2 = __shfl(pb, base | l, 64), q3 = __shfl(pb, base | (8 + l), 64);
-        const float s = ((q0 + q1) + q2) + q3;
-        float sv[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) sv[k] = __shfl(s, base | k, 64);
-        return ((sv[0] + sv[1]) + (sv[2] + sv[3])) + ((sv[4] + sv[5]) + (sv[6] + sv[7]));
+        const float s = ((pa + pf_row_shl<8>(pa)) + pb) + pf_row_shl<8>(pb);   // lanes 0..7
+        const float t = s + pf_row_shl<1>(s);                                  // lanes 0, 2, 4, 6
+        const float v = t + pf_row_shl<2>(t);                                  // lanes 0, 4
+        return v + pf_row_shl<4>(v);
     }
 }
 
@@ -518,8 +533,8 @@ __global__ __launch_bounds__(kExSpan) void pf_exact_candidates_kernel(
     if (L.mode == 1) qt.x = L.live_idx[qt.x];
     if (L.mode == 2) qt = make_int2(qt.y, L.live_idx[qt.x]);
     const PairDesc* pd = pairs + pair;
-    s_a[tid] = pd->a_raw + (size_t)qt.x * kDim;
-    s_b[tid] = pd->b_raw + (size_t)qt.y * kDim;
+    s_a[tid] = pd->a_rawp + (size_t)qt.x * kDim;
+    s_b[tid] = pd->b_rawp + (size_t)qt.y * kDim;
     // A mode-1 list only serves the row direction, a mode-2 list only the column direction: the live rows of the OTHER
     // direction get their complete candidate sets from their own list.
     const long long slot_r = pd->kf_off + qt.x, slot_c = pd->kr_off + qt.y;
@@ -538,13 +553,23 @@ __global__ __launch_bounds__(kExSpan) void pf_exact_candidates_kernel(
         const float* b0 = s_b[k0];
         const float* a1 = s_a[k1];
         const float* b1 = s_b[k1];
+        // (the permuted row copy: the lane's eight elements 16 j + sub are two float4, each load 256 contiguous bytes per group -- four
+        // wave-level loads per candidate instead of sixteen: 55 % of the kernel's wave cycles were SQ_WAIT_INST_ANY, vector-memory issue)
         float av0[8], bv0[8], av1[8], bv1[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) av0[j] = a0[16 * j + sub], bv0[j] = b0[16 * j + sub];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) av1[j] = a1[16 * j + sub], bv1[j] = b1[16 * j + sub];
-        const float r0 = pf_exact_combine<ORDER>(av0, bv0, sub);
-        const float r1 = pf_exact_combine<ORDER>(av1, bv1, sub);
+        {
+            const float4* pa0 = reinterpret_cast<const float4*>(a0) + sub;
+            const float4* pb0 = reinterpret_cast<const float4*>(b0) + sub;
+            const float4* pa1 = reinterpret_cast<const float4*>(a1) + sub;
+            const float4* pb1 = reinterpret_cast<const float4*>(b1) + sub;
+            const float4 x0 = pa0[0], x1 = pa0[16], y0 = pb0[0], y1 = pb0[16];
+            const float4 z0 = pa1[0], z1 = pa1[16], w0 = pb1[0], w1 = pb1[16];
+            av0[0] = x0.x, av0[1] = x0.y, av0[2] = x0.z, av0[3] = x0.w, av0[4] = x1.x, av0[5] = x1.y, av0[6] = x1.z, av0[7] = x1.w;
+            bv0[0] = y0.x, bv0[1] = y0.y, bv0[2] = y0.z, bv0[3] = y0.w, bv0[4] = y1.x, bv0[5] = y1.y, bv0[6] = y1.z, bv0[7] = y1.w;
+            av1[0] = z0.x, av1[1] = z0.y, av1[2] = z0.z, av1[3] = z0.w, av1[4] = z1.x, av1[5] = z1.y, av1[6] = z1.z, av1[7] = z1.w;
+            bv1[0] = w0.x, bv1[1] = w0.y, bv1[2] = w0.z, bv1[3] = w0.w, bv1[4] = w1.x, bv1[5] = w1.y, bv1[6] = w1.z, bv1[7] = w1.w;
+        }
+        const float r0 = pf_exact_combine<ORDER>(av0, bv0);
+        const float r1 = pf_exact_combine<ORDER>(av1, bv1);
         if (sub == 0) {
             s_res[k0] = r0;
             s_res[k1] = r1;

@@ -113,31 +113,43 @@ __global__ void pf_prune_q8_kernel(const PairDesc* __restrict__ pairs, const PfP
         const float u2 = u1 * u1;
         return u2 * (1.f + 3e-5f) + eps + 1e-5f * (u2 + nrm + other_max);
     };
-    if (e < pd.n1pad) {
+    // ---- every load of this thread first, at clamped (always valid) indices: the kernel is bookkeeping over ~83 M row / column
+    // slots per job and was five dependent memory round trips per wave (rows, their errors, the columns' sixteen partials, their
+    // errors, the norms of the live ones: 76 % of its wave cycles in SQ_WAIT_ANY at 2.4 TB/s); now it is one.
+    const int* cpk = reinterpret_cast<const int*>(cp_s0);   // packed partials of the integer sweep (msfm_cp_pack)
+    const int nb = pd.a_blocks256;
+    const bool in_r = e < pd.n1pad, in_c = e < pd.n2pad;
+    const int er = in_r ? e : 0, ec = in_c ? e : 0;
+    const float ld_rs0 = rp_s0[pd.rp_off + er], ld_rs1 = rp_s1[pd.rp_off + er];
+    const float ld_aerr = pq.a_err[min(er, pd.n1 - 1)], ld_anrm = pp.a_nrm[er];
+    const float ld_berr = pq.b_err[min(ec, pd.n2 - 1)], ld_bnrm = pp.b_nrm[ec];
+    int ld_cp[16];
+#pragma unroll
+    for (int p = 0; p < 16; ++p) ld_cp[p] = cpk[pd.cp_off + (long long)min(p, nb - 1) * pd.n2pad + ec];
+    if (in_r) {
         float s0 = f_inf(), s1 = f_inf();
-        for (int p = 0; p < pd.ranges; ++p) {
+        v2_merge(s0, s1, ld_rs0, ld_rs1);
+        for (int p = 1; p < pd.ranges; ++p) {   // (a pair split into B ranges: small batches only)
             const long long o = pd.rp_off + (long long)p * pd.n1pad + e;
             v2_merge(s0, s1, rp_s0[o], rp_s1[o]);
         }
         bool live = e < pd.n1;
-        const float err = live ? (pq.a_err[e] + pq.b_c) * (1.f + 1e-6f) : 0.f;   // (b_c of the twin pair: E of image 2)
+        const float err = live ? (ld_aerr + pq.b_c) * (1.f + 1e-6f) : 0.f;   // (b_c of the twin pair: E of image 2)
         if (live) live = !dead(s0, s1, err);
         float T = live ? f_inf() : -f_inf();
-        if (live && direct) T = threshold(upper(s1, err), pp.a_nrm[e], pp.b_nrm_max);
+        if (live && direct) T = threshold(upper(s1, err), ld_anrm, pp.b_nrm_max);
         tuv[pp.tu_off + e] = T;
         row_live = live;
     }
-    if (e < pd.n2pad) {
+    if (in_c) {
         float s0 = f_inf(), s1 = f_inf();
-        const int* cpk = reinterpret_cast<const int*>(cp_s0);   // packed partials of the integer sweep (msfm_cp_pack)
-        const int nb = pd.a_blocks256;
-        // up to 16 blocks (8192 rows) the blocks' minima stay in registers for the mask below: sixteen independent loads in flight
+        // up to 16 blocks (8192 rows) the blocks' minima stay in registers for the mask below
         float bmin[16];
         if (nb <= 16) {
 #pragma unroll
             for (int p = 0; p < 16; ++p) {
                 float2 m = make_float2(-f_inf(), -f_inf());
-                if (p < nb) m = i8_cp_unpack(cpk[pd.cp_off + (long long)p * pd.n2pad + e]);
+                if (p < nb) m = i8_cp_unpack(ld_cp[p]);
                 bmin[p] = -2.f * m.x;
                 v2_merge(s0, s1, -2.f * m.x, -2.f * m.y);
             }
@@ -148,7 +160,7 @@ __global__ void pf_prune_q8_kernel(const PairDesc* __restrict__ pairs, const PfP
             }
         }
         bool live = e < pd.n2;
-        const float err = live ? (pq.b_err[e] + pq.a_c) * (1.f + 1e-6f) : 0.f;
+        const float err = live ? (ld_berr + pq.a_c) * (1.f + 1e-6f) : 0.f;
         if (live) live = !dead(s0, s1, err);
         const int g = (nb + 31) / 32, bits = (nb + g - 1) / g;
         if (!direct) {
@@ -159,7 +171,7 @@ __global__ void pf_prune_q8_kernel(const PairDesc* __restrict__ pairs, const PfP
             // the blocks of image 1 that can hold a candidate of this column: the block's nearest row may be as close as
             // lower(block minimum), a candidate is at most U1 away
             const float u1 = live ? upper(s1, err) : 0.f;
-            tuv[pp.tv_off + e] = live ? threshold(u1, pp.b_nrm[e], pp.a_nrm_max) : -f_inf();
+            tuv[pp.tv_off + e] = live ? threshold(u1, ld_bnrm, pp.a_nrm_max) : -f_inf();
             if (live) {
                 if (nb <= 16) {
 #pragma unroll
