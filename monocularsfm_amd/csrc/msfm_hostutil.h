@@ -1,6 +1,6 @@
 // msfm_hostutil.h -- small pure functions shared by device and host code, compilable on their own (tests/test_hostutil.py builds a
 // g++ driver around them): the 4-byte packing of the integer sweeps' column partials, the cost marks of a call's sub-batches, the
-// scratch memory one image pair of a sub-batch needs.
+// scratch memory one image pair of a sub-batch needs, the fold of a candidate's key into a slot's (best, second).
 #pragma once
 #include <vector>
 
@@ -73,4 +73,24 @@ inline long long msfm_pair_scratch_bytes(int n1, int n2, int n1pad, int n2pad, i
     const long long bits = blocks512 < 32 ? blocks512 : 32;
     const long long cmp_rows = ((long long)n1 + (long long)n2 * bits) / 16 + 1024;
     return common + partials + 84LL * cmp_rows;
+}
+
+// One key into a slot's (best, second) -- the reduction of the exact re-check (pf_exact_candidates_kernel).  best ends as the
+// smallest key the slot ever saw, second as the second smallest DISTINCT key: every key but the final minimum loses exactly once
+// against `best` (when it arrives, or when a smaller one displaces it) and is then offered to `second`; a key arriving twice meets
+// itself and is dropped.  seen_best / seen_second: what a plain load saw in the two words some time BEFORE (any earlier state: the
+// words only ever decrease, so a stale look is >= the truth): a key that does not beat what was seen cannot change the word and
+// skips the atomic -- most candidates of a row do.  amin(word, key) = atomic minimum returning the old value.  ~0 = "nothing yet".
+template <class AtomicMin>
+MSFM_HD void msfm_fold_key(unsigned long long* best, unsigned long long* second, unsigned long long key, unsigned long long seen_best,
+                           unsigned long long seen_second, AtomicMin amin) {
+    if (key == seen_best) return;
+    unsigned long long loser = key;
+    if (key < seen_best) {
+        const unsigned long long old = amin(best, key);
+        if (old == key) return;
+        loser = old > key ? old : key;
+        if (loser == ~0ull) return;
+    }
+    if (loser < seen_second) (void)amin(second, loser);
 }

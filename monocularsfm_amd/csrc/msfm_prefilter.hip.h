@@ -443,21 +443,12 @@ __device__ __forceinline__ float pf_exact_combine(const float (&av)[8], const fl
     }
 }
 
-// One key into a slot's (best, second): best ends as the smallest key the slot ever saw, second as the second smallest -- every key
-// but the final minimum loses exactly once against `best` (when it arrives, or when it is displaced) and is then offered to
-// `second`; a key arriving twice meets itself and is dropped.  sb / ss: what a plain load saw in the slot some time ago (>= what
-// is there now): they only ever let a key skip an atomic that could not have changed anything.
+// One key into a slot's (best, second): msfm_fold_key (msfm_hostutil.h, where a g++-built test drives the same code through random
+// arrival orders and stale looks) with the device's 64-bit atomicMin.
 __device__ __forceinline__ void pf_fold(unsigned long long* __restrict__ best, unsigned long long* __restrict__ second, long long slot,
                                         unsigned long long key, unsigned long long sb, unsigned long long ss) {
-    if (key == sb) return;
-    unsigned long long loser = key;
-    if (key < sb) {
-        const unsigned long long old = atomicMin(&best[slot], key);
-        if (old == key) return;
-        loser = old > key ? old : key;
-        if (loser == ~0ull) return;
-    }
-    if (loser < ss) atomicMin(&second[slot], loser);
+    msfm_fold_key(best + slot, second + slot, key, sb, ss,
+                  [](unsigned long long* w, unsigned long long k) -> unsigned long long { return atomicMin(w, k); });
 }
 
 template <int ORDER>

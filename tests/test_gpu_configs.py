@@ -81,6 +81,55 @@ def test_config5_u8_16384(gpu_ctx, oracle):
     assert len(q) > 400 and (np.diff(q) > 0).all()
 
 
+def whole_result_properties(offs, qt, pairs, n_rows):
+    """size-independent properties of a job's result (tools/config4_full.py checks the same on the full configs)"""
+    assert (np.diff(offs) >= 0).all()
+    pair_of = np.repeat(np.arange(len(pairs)), np.diff(offs))
+    q, t = np.asarray(qt[:, 0]), np.asarray(qt[:, 1])
+    assert ((q >= 0) & (q < n_rows[pairs[pair_of, 0]]) & (t >= 0) & (t < n_rows[pairs[pair_of, 1]])).all()
+    same = pair_of[1:] == pair_of[:-1]
+    assert (np.diff(q.astype(np.int64))[same] > 0).all()                                       # ascending queryIdx inside a pair
+    assert (np.diff(np.sort(pair_of.astype(np.int64) * (1 << 20) + t)) != 0).all()            # cross-check: a train row at most once per pair
+
+
+@pytest.mark.parametrize("images, desc, seed, scratch_mib", [(96, 8192, 1329, 0), (40, 16384, 4096, 6144)])
+def test_config4_and_config5_jobs_beyond_a_toy_subset(gpu_ctx, oracle, images, desc, seed, scratch_mib):
+    """BASELINE configs[3] at 96 of its 1329 images (4560 pairs, 3.1e11 descriptor pairs) and configs[4] at 40 of its 4096 (780 pairs of
+    16384-row images -- 32 row blocks per image: the edge of the 32-bit block mask --, 2.1e11 descriptor pairs; its scratch budget
+    lowered so that the call is cut into several sub-batches in flight) as ONE msfm_match_pairs call each: the first and the last
+    pair and seeded random ones against the C oracle (on byte values its sums are exact integers -- tests/test_int_oracle.py pins it
+    to the int64 reference, which would take two minutes per pair at this size), the whole result through its size-independent
+    properties.  The full configs: tools/config4_full.py -> profiles/r04_config4_full.json,
+    r04_config5_512.json.  Replaces at this size: /root/reference/src/Feature/FeatureMatching.cpp:102-145."""
+    imgs, pairs, _ = synth.job("synthetic-u8", images, desc, seed=seed)
+    n_rows = np.array([len(x) for x in imgs], np.int64)
+    for i, im in enumerate(imgs):
+        gpu_ctx.upload_image(i, im)
+    gpu_ctx.set_limits(0, scratch_mib << 20)
+    try:
+        offs, qt, d = gpu_ctx.match_pairs(pairs, max_distance=1e9, fetch="view")
+        offs, qt, d = offs.copy(), qt.copy(), d.copy()
+        p = gpu_ctx.profile()
+    finally:
+        gpu_ctx.set_limits(0, 0)
+    assert p["sweep1_i8_launches"] == p["sub_batches"] and p["prefilter_pairs"] == len(pairs) and p["fallback_pairs"] == 0
+    assert p["order_sensitive_rows"] == 0 and p["demoted_pairs"] == 0
+    assert p["sub_batches"] >= (6 if scratch_mib == 0 else 8)
+    assert offs[-1] > 300 * len(pairs)                     # the planted 5 % near-duplicates match
+    whole_result_properties(offs, qt, pairs, n_rows)
+    rng = np.random.default_rng(seed)
+    sel = np.asarray(sorted(set([0, len(pairs) - 1] + rng.choice(len(pairs), 4, replace=False).tolist())), np.int64)
+    f32 = {int(i): imgs[int(i)].astype(F32) for i in np.unique(pairs[sel])}
+    o_offs, oq, ot, od = oracle.match_pairs(f32, pairs[sel], max_distance=1e9, nthreads=16)
+    assert o_offs[-1] > 300 * len(sel)
+    for k, pk in enumerate(sel):
+        s, e = int(offs[pk]), int(offs[pk + 1])
+        os_, oe = int(o_offs[k]), int(o_offs[k + 1])
+        assert np.array_equal(qt[s:e, 0], oq[os_:oe]) and np.array_equal(qt[s:e, 1], ot[os_:oe]), pk
+        assert np.array_equal(b(d[s:e]), b(od[os_:oe])), pk
+    gpu_ctx.clear_images()
+
+
 @pytest.mark.parametrize("byte_store", [False, True])
 def test_very_tall_image_against_a_small_one(gpu_ctx, byte_store):
     """Edge of the size range: 140 005 rows (274 A blocks of 512 rows: the 32-bit block mask of the reverse plan covers

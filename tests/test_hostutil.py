@@ -5,7 +5,9 @@
     pruning / threshold bound of the prefilter stays valid) and by at most 1/16 of the gap;
   * the cost marks of a large call's sub-batches (msfm_set_pipeline): increasing, ending at the total, parts shrinking towards the
     end, the last one `taper` of the average;
-  * the device scratch one image pair adds to a sub-batch (what a call is cut by), and its Python twin in tools/config4_full.py.
+  * the device scratch one image pair adds to a sub-batch (what a call is cut by), and its Python twin in tools/config4_full.py;
+  * the fold of a candidate's key into a slot's (best, second) in the exact re-check -- the device kernel calls this very function
+    with atomicMin: 200 000 random arrival sequences with repeated keys, every arrival acting on a STALE look at the slot.
 The reference's counterpart of the second is the fixed 100-pair flush of BruteFeatureMatcher::RunMatching
 (/root/reference/src/Feature/FeatureMatching.cpp:118-139)."""
 import os
@@ -83,6 +85,25 @@ int main() {
         std::printf("scratch %d %d %lld\n", n1, n2, r1);
     }
     if (msfm_pair_scratch_bytes(0, 700, 0, 1024, 0, 0, 1) != 0) { std::printf("empty side\n"); return 1; }
+    // the fold of the exact re-check: random keys (with repeats) in random order, every arrival looking at an OLDER state of the slot
+    {
+        auto amin = [](unsigned long long* w, unsigned long long k) { const unsigned long long o = *w; if (k < o) *w = k; return o; };
+        for (int trial = 0; trial < 200000; ++trial) {
+            const int n = 1 + (int)(rng() % 9);
+            unsigned long long keys[16];
+            for (int i = 0; i < n; ++i) keys[i] = (i > 0 && rng() % 4 == 0) ? keys[rng() % i] : ((rng() % 50) << 32 | (rng() % 7));
+            unsigned long long best = ~0ull, second = ~0ull, hb[17], hs[17];
+            for (int i = 0; i < n; ++i) {
+                hb[i] = best; hs[i] = second;                       // the slot's history: state before arrival i
+                const int look = (int)(rng() % (i + 1));            // a look taken at any earlier (or the current) state
+                msfm_fold_key(&best, &second, keys[i], hb[look], hs[look], amin);
+            }
+            unsigned long long m0 = ~0ull, m1 = ~0ull;
+            for (int i = 0; i < n; ++i) if (keys[i] < m0) m0 = keys[i];
+            for (int i = 0; i < n; ++i) if (keys[i] != m0 && keys[i] < m1) m1 = keys[i];
+            if (best != m0 || second != m1) { std::printf("fold: best %llx second %llx, want %llx %llx (n = %d)\n", best, second, m0, m1, n); return 1; }
+        }
+    }
     std::printf("ok %lld\n", checked);
     return 0;
 }
