@@ -377,8 +377,8 @@ def main():
         # 0 => the index lists are the same under any conforming fp32 order of OpenCV's normL2Sqr_
         "order_sensitive_rows": int(last_prof.get("order_sensitive_rows", -1)),
         "sub_batches_per_step": acc["sub_batches"] // max(1, args.steps),
-        # the step is cut into shrinking sub-batches launched round-robin on three streams: the bandwidth-bound tail of one runs
-        # beside the sweeps of the next ones (msfm_set_pipeline / MSFM_PIPELINE; 1 = one launch per sweep, no overlap)
+        # the step is cut into sub-batches (two equal ones for this job) launched on separate streams: the bandwidth-bound tail of
+        # one runs beside the sweeps of the next (msfm_set_pipeline / MSFM_PIPELINE; 1 = one launch per sweep, no overlap)
         "pipeline_env": os.environ.get("MSFM_PIPELINE"),
     }
     pf_ms, pf_launches = acc["approx_kernel_ms"], acc["approx_kernel_launches"]

@@ -129,12 +129,12 @@ int msfm_get_profile(const msfm_ctx* ctx, msfm_profile* out);
  * small limits to cross it).  The reference's counterpart is the 100-pair flush of BruteFeatureMatcher::RunMatching
  * (src/Feature/FeatureMatching.cpp:118-139, max_pairs_size_). */
 int msfm_set_limits(msfm_ctx* ctx, int max_pairs_per_batch, int64_t scratch_bytes);
-/* A call of enough work (>= 1.5e10 descriptor pairs per part) is cut into at least `min_sub_batches` sub-batches of shrinking
- * size (the last one 0.3 of the average: what follows the call's last sweep has nothing to hide behind), launched round-robin
- * on three streams / scratch sets: the bandwidth-bound tail of one (thresholds, sweep-2 plan, exact re-check, epilogue,
- * copy-out) runs while the sweeps of the next ones own the matrix cores.  Default 6; 1 = one sub-batch where memory allows
- * (no overlap); <= 0 restores the default.  Env: MSFM_PIPELINE, MSFM_PIPELINE_TAPER, MSFM_IN_FLIGHT.  Results do not depend
- * on any of it. */
+/* A call of enough work (>= 1.5e10 descriptor pairs per part) is cut into at least `min_sub_batches` sub-batches, launched round-robin
+ * on three streams / scratch sets: the bandwidth-bound tail of one (thresholds, sweep-2 plan, exact re-check, epilogue, copy-out)
+ * runs while the sweeps of the next ones own the matrix cores.  Default 2 equal parts (round 3: 6 parts shrinking to 0.3 of the
+ * average; with round 4's smaller tails a further cut costs more than it hides); 1 = one sub-batch where memory allows (no overlap);
+ * <= 0 restores the default.  Env: MSFM_PIPELINE, MSFM_PIPELINE_TAPER (size of the last part relative to the average, default 1),
+ * MSFM_IN_FLIGHT.  Results do not depend on any of it. */
 int msfm_set_pipeline(msfm_ctx* ctx, int min_sub_batches);
 
 /* ---- descriptor store -------------------------------------------------------------------

@@ -176,7 +176,7 @@ class Context:
 
     def set_pipeline(self, min_sub_batches=0):
         """A large call is cut into at least this many (shrinking) sub-batches whose tails overlap the next ones' sweeps (<= 0:
-        default 6; 1: off).  Results do not depend on it."""
+        default 2; 1: off).  Results do not depend on it."""
         self._chk(self._L.msfm_set_pipeline(self._h, int(min_sub_batches)))
 
     def profile(self):

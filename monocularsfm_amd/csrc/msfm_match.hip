@@ -197,14 +197,17 @@ constexpr long long kDefaultScratchBytes = (long long)64 << 30;
 constexpr int kDefaultMaxPairsPerBatch = 16384;
 constexpr int kMaxPairsPerBatchLimit = 65535;   // gridDim.y
 // A call large enough is cut into at least this many sub-batches so that the bandwidth-bound tail of one (thresholds, plan,
-// exact re-check, epilogue, copy-out) runs under the next one's sweep 1; every sub-batch keeps >= kMinPipelineCost
-// descriptor pairs (a few ms of sweep 1) so that the fixed costs of a sub-batch stay small.
-constexpr int kDefaultPipeline = 6;
+// exact re-check, epilogue, copy-out) runs under the next one's sweep 1; every sub-batch keeps >= kMinPipelineCost descriptor pairs
+// (a few ms of sweep 1) so that the fixed costs of a sub-batch stay small.  TWO EQUAL parts since round 4: with ~5 ms of tail
+// kernels per 8128-pair job (7.3 in round 3, when six parts shrinking to 0.3 of the average were best) the first part's tail hides
+// under the second part's sweep and every further cut costs more -- another sub-batch's fill and drain, sweeps stretched by the
+// tails beside them -- than it hides: 39.5 -> 37.3 ms against six parts, 39.4 against one (profiles/r04_pipeline_ab.txt, one box,
+// alternated, twice).  Jobs cut by memory or by the pair limit anyway (config 3, config 4) are not affected.
+constexpr int kDefaultPipeline = 2;
+constexpr double kDefaultTaper = 1.0;   // size of a call's last part relative to the average part
 // Sub-batches in flight (streams / scratch sets).  With three, sweep 1 of sub-batch k + 2 is ordered behind sweep 2 of sub-batch k
 // (Scratch::sweep2_done): the matrix pipes see S1(k+1) S2(k) S1(k+2) S2(k+1) ... and every bandwidth-bound tail has a sweep to run
-// beside.  Measured on the bench job (profiles/r03_inflight_ab.txt): 2 sets x 4 equal parts 40.7 ms, 3 sets x 6 tapered parts 39.6 ms;
-// what the overlap can win is bounded -- the part draws its full power budget under a sweep alone, a tail kernel beside it
-// slows the sweep by about what it would have cost alone (section 5.1.7 of DESIGN.md).
+// beside -- what the many-sub-batch jobs (config 4: 105 of them) live on.
 constexpr int kInFlight = 3;
 constexpr long long kMinPipelineCost = 15000000000LL;
 
@@ -301,7 +304,7 @@ struct msfm_ctx {
     int max_pairs_per_batch = kDefaultMaxPairsPerBatch;
     long long scratch_bytes = 0;      // msfm_set_limits / MSFM_SCRATCH_MIB: total for the scratch sets in flight; 0 = automatic (above)
     long long issue_seq = 0;          // sub-batches issued so far
-    double pipeline_taper = 0.3;      // size of a call's last part relative to the average part (MSFM_PIPELINE_TAPER; 1: equal parts)
+    double pipeline_taper = kDefaultTaper;   // size of a call's last part relative to the average part (MSFM_PIPELINE_TAPER; 1: equal parts)
     int in_flight = kInFlight;        // scratch sets used (MSFM_IN_FLIGHT=1 at msfm_create: no sub-batch overlap, for A/B measurements)
     int pipeline = kDefaultPipeline;  // sub-batches a large call is cut into at least, so that tails overlap sweeps (1: off)
     int prefilter = 1;                // 0: brute force only; 1: MFMA prefilter, integer matrix cores for byte stores; 2: fp16 MFMA only

@@ -121,10 +121,17 @@ def test_config2_full_job_one_launch(gpu_ctx, oracle):
     finally:
         gpu_ctx.set_pipeline(0)
     assert p["sub_batches"] == 1 and p["approx_kernel_launches"] == 1      # ONE launch per sweep for the whole job
-    # the default: the job cut into 6 shrinking sub-batches, three in flight (tails under the other sub-batches' sweeps) == the same lists
+    # the default: the job cut into two equal sub-batches in flight (the first one's tail under the second one's sweep) == the same lists
     piped = gpu_ctx.match_pairs(pairs)
     pp_ = gpu_ctx.profile()
-    assert pp_["sub_batches"] == 6 and pp_["approx_kernel_launches"] == 6 and pp_["prefilter_pairs"] == 8128
+    assert pp_["sub_batches"] == 2 and pp_["approx_kernel_launches"] == 2 and pp_["prefilter_pairs"] == 8128
+    # ... and round 3's schedule (six parts shrinking to 0.3 of the average, three in flight) as well
+    gpu_ctx.set_pipeline(6)
+    try:
+        six = gpu_ctx.match_pairs(pairs)
+        assert gpu_ctx.profile()["sub_batches"] == 6 and same_result((offs, qt, d), six)
+    finally:
+        gpu_ctx.set_pipeline(0)
     assert pp_["descriptor_pairs"] == p["descriptor_pairs"] and pp_["order_sensitive_rows"] == p["order_sensitive_rows"]
     assert same_result((offs, qt, d), piped)
     assert p["prefilter_pairs"] == 8128 and p["fallback_pairs"] == 0 and p["compacted_pairs"] > 7000
@@ -205,13 +212,13 @@ def test_results_do_not_depend_on_sets_in_flight_parts_or_taper(gpu_ctx, monkeyp
     are scheduling only: same offsets, same rows, same distance bits as the default context -- also with the pair limit
     forcing further cuts inside the parts, and on the fp16 route."""
     from monocularsfm_amd import _lib
-    imgs, pairs, _ = synth.job("south-building", 72, seed=4321)        # 2556 pairs, 6.5e10 descriptor pairs: up to 4 parts
+    imgs, pairs, _ = synth.job("south-building", 72, seed=4321)        # 2556 pairs, 6.5e10 descriptor pairs: up to 4 parts (default: 2)
     gpu_ctx.clear_images()
     for i, im in enumerate(imgs):
         gpu_ctx.upload_image(i, im)
     ref = gpu_ctx.match_pairs(pairs)
     p0 = gpu_ctx.profile()
-    assert p0["sub_batches"] == 4 and p0["prefilter_pairs"] == len(pairs) and ref[0][-1] > 100000
+    assert p0["sub_batches"] == 2 and p0["prefilter_pairs"] == len(pairs) and ref[0][-1] > 100000
     gpu_ctx.clear_images()
     monkeypatch.setenv("MSFM_IN_FLIGHT", in_flight)
     monkeypatch.setenv("MSFM_PIPELINE", parts)
