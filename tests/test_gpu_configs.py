@@ -92,7 +92,7 @@ def whole_result_properties(offs, qt, pairs, n_rows):
     assert (np.diff(np.sort(pair_of.astype(np.int64) * (1 << 20) + t)) != 0).all()            # cross-check: a train row at most once per pair
 
 
-@pytest.mark.parametrize("images, desc, seed, scratch_mib", [(96, 8192, 1329, 4096), (40, 16384, 4096, 3072)])
+@pytest.mark.parametrize("images, desc, seed, scratch_mib", [(96, 8192, 1329, 4096), (40, 16384, 4096, 2048)])
 def test_config4_and_config5_jobs_beyond_a_toy_subset(gpu_ctx, oracle, images, desc, seed, scratch_mib):
     """BASELINE configs[3] at 96 of its 1329 images (4560 pairs, 3.1e11 descriptor pairs) and configs[4] at 40 of its 4096 (780 pairs of
     16384-row images -- 32 row blocks per image: the edge of the 32-bit block mask --, 2.1e11 descriptor pairs), their scratch budgets
