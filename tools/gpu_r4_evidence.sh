@@ -19,7 +19,7 @@ timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/prof_u8_p1 -- python $ROOT/
 cd $ROOT
 DB=$(ls -t $(find $OUT/prof_stats -name '*.db') | head -1)
 python tools/rocprof_summary.py "$DB" "$BENCH" > $OUT/bench_kernel_stats.txt 2>&1; head -8 $OUT/bench_kernel_stats.txt | cut -c1-60,150-215
-python tools/step_timeline.py "$DB" 6 > $OUT/step_timeline.txt 2>&1; tail -1 $OUT/step_timeline.txt | cut -c1-300
+python tools/step_timeline.py "$DB" 2 > $OUT/step_timeline.txt 2>&1; tail -1 $OUT/step_timeline.txt | cut -c1-300
 DB1=$(ls -t $(find $OUT/prof_stats_p1 -name '*.db') | head -1)
 python tools/rocprof_summary.py "$DB1" "MSFM_PIPELINE=1 $BENCH" > $OUT/bench_kernel_stats_pipeline1.txt 2>&1; head -12 $OUT/bench_kernel_stats_pipeline1.txt | cut -c1-60,150-215
 DBU=$(ls -t $(find $OUT/prof_u8_p1 -name '*.db') | head -1)
