@@ -400,12 +400,18 @@ __global__ __launch_bounds__(kI8Threads) void sweep_i8_kernel(
         bf[1][1] = *reinterpret_cast<const i4v*>(pb2 + 32 * kI8RowBytes + 32);
         accA = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[2], bf[0][0], accA, 0, 0, 0);
         accB = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[2], bf[0][1], accB, 0, 0, 0);
+#ifdef MSFM_EXPERIMENT_NO_DIGITS   // timing experiment only (wrong results): the sweep without its fifth k-step -- the ceiling of any
+                                   // norm-free formulation (profiles/r04_norm_free_twin_study.txt)
+        accA = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[3], bf[1][0], accA, 0, 0, 0);
+        accB = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[3], bf[1][1], accB, 0, 0, 0);
+#else
         bf[0][0] = *reinterpret_cast<const i4v*>(pb2 + 64);                     // the digits (bytes 128 + 16 lhalf ..)
         bf[0][1] = *reinterpret_cast<const i4v*>(pb2 + 32 * kI8RowBytes + 64);
         accA = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[3], bf[1][0], accA, 0, 0, 0);
         accB = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[3], bf[1][1], accB, 0, 0, 0);
         accA = __builtin_amdgcn_mfma_i32_32x32x32_i8(a_digit, bf[0][0], accA, 0, 0, 0);   // + (H0_b - h_b) [+ (H0_a - h_a)]
         accB = __builtin_amdgcn_mfma_i32_32x32x32_i8(a_digit, bf[0][1], accB, 0, 0, 0);
+#endif
     };
     // the epilogue half of tile t (its accumulators are in accA / accB)
     auto epilogue_half = [&](int t) {

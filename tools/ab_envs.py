@@ -41,7 +41,7 @@ for rnd in range(args.rounds):
         wall = (time.perf_counter() - t0) * 1e3
         p = ctx.profile()
         if rnd >= 2:
-            res[nm].append((p["approx_kernel_ms"], p["total_device_ms"], wall, p["sub_batches"]))
+            res[nm].append((p["approx_kernel_ms"], p["total_device_ms"], wall, p["sub_batches"], p["sweep2_ms"]))
         cur = (np.array(offs), np.array(qt), np.array(d).view(np.int32))
         if ref is None:
             ref = cur
@@ -49,5 +49,5 @@ for rnd in range(args.rounds):
 print("# %s, %d rounds" % (name, args.rounds - 2))
 for nm in ctxs:
     a = np.array(res[nm])
-    print("%-44s sub-batches %d | sweep1 med %.3f ms | device span min %.3f med %.3f ms | wall med %.3f ms" % (
-        nm, int(a[0, 3]), np.median(a[:, 0]), a[:, 1].min(), np.median(a[:, 1]), np.median(a[:, 2])), flush=True)
+    print("%-44s sub-batches %d | sweep1 med %.3f ms | sweep2 med %.3f ms | device span min %.3f med %.3f ms | wall med %.3f ms" % (
+        nm, int(a[0, 3]), np.median(a[:, 0]), np.median(a[:, 4]), a[:, 1].min(), np.median(a[:, 1]), np.median(a[:, 2])), flush=True)
