@@ -443,9 +443,16 @@ __global__ __launch_bounds__(kI8Threads) void sweep_i8_kernel(
             if (!(t * kPfBT + 32 + lcol < pd.n2)) accB = i16v(-1);
         }
         if (PASS == 1) {
+#ifdef MSFM_EXPERIMENT_FOLD_HALF   // timing experiment only (wrong results): half of the epilogue's VALU work -- what does a v_max3 cost here?
+            fold_columns(column_max(accA), column_max(accA), (t - t_begin) & 3);
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) rs0[r] = max3i(rs0[r], accA[r], accB[r + 1]);
+            asm volatile("" :: "v"(accB));
+#else
             fold_columns(column_max(accA), column_max(accB), (t - t_begin) & 3);
 #pragma unroll
             for (int r = 0; r < 16; ++r) rs0[r] = max3i(rs0[r], accA[r], accB[r]);
+#endif
         } else {
             scan_hits3(accA, accB, t * kPfBT + lcol);
         }
@@ -467,6 +474,9 @@ __global__ __launch_bounds__(kI8Threads) void sweep_i8_kernel(
         wait_older_group();
 #ifdef MSFM_EXPERIMENT_NO_BARRIER   // timing experiment only (races: wrong results): what do the per-tile barriers cost?
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#elif defined(MSFM_EXPERIMENT_HALF_BARRIER)   // timing experiment only (races): every second barrier -- what would one barrier per TWO tiles return?
+        if (v & 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        else lds_barrier();
 #else
         lds_barrier();
 #endif
