@@ -10,6 +10,8 @@
   (d) integer descriptors against the exact-integer reference (oracle/int_oracle.py), u8 upload path.
 The reference's counterpart of (a)-(c) is the pair loop of FeatureMatcher::MatchImagePairs and the 100-pair
 flush of BruteFeatureMatcher::RunMatching (/root/reference/src/Feature/FeatureMatching.cpp:14-49, 118-139)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -374,3 +376,18 @@ def test_plan_regrow_with_sub_batches_in_flight(oracle, twins):
             os.environ["MSFM_Q8"] = old
     assert got[0][-1] > 3000
     check_pairs_vs_oracle(oracle, imgs, pairs, np.arange(len(pairs)), *got, nthreads=8, **kw)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("q8", ["1", "2"])
+def test_job_fuzz_random_stores_under_random_cuts(built_lib, q8):
+    """tools/fuzz_jobs.py, a short run: whole calls on random stores (float / byte / mixed) under random cuts -- pairs per sub-batch,
+    scratch budget, pipeline parts -- equal the call under the defaults bit for bit and the C oracle on the whole pair list.
+    (3300 cases of it: profiles/r04_fuzz_jobs.txt.)"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MSFM_Q8=q8)
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_jobs.py"), "5", "30"], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "mismatches: 0" in r.stdout
