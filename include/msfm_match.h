@@ -98,8 +98,11 @@ typedef struct msfm_profile {
                                      under any conforming fp32 evaluation order of hal::normL2Sqr_ */
     int demoted_pairs;            /* pairs of two byte images (or of two images with byte twins) whose first sweep ran on the fp16 cores
                                      all the same, because their SUB-BATCH also held a pair that could not take the integer route (a
-                                     mixed store: the route is chosen per sub-batch).  Same results, ~1.6 x the sweep time; 0 on a
-                                     homogeneous store */
+                                     mixed store: byte stores and coarse twins choose the route per sub-batch; fine twins do not, see
+                                     mixed_route_sub_batches).  Same results, ~1.6 x the sweep time; 0 on a homogeneous store */
+    int mixed_route_sub_batches;  /* sub-batches that ran TWO first sweeps: the integer one on the pairs whose images both have fine byte
+                                     twins, the fp16 one on the rest (an image with a value beyond [0, 1] among twinned ones) -- the twins'
+                                     pairs are not demoted then.  Byte stores and coarse twins still choose one route per sub-batch */
 } msfm_profile;
 
 /* ---- context ------------------------------------------------------------------------- */

@@ -235,7 +235,7 @@ struct Scratch {
     // of the brute-force route (a sub-batch may run both routes: the first route's copy may still be in flight)
     DevBuf d_up[3];
     PinnedBuf h_up[3];
-    Ref d_pairs, d_pf, d_pfq, d_item_base;                                   // in d_up[0] / d_up[2]
+    Ref d_pairs, d_pf, d_pfq, d_pf16, d_item_base, d_item_base16;                                   // in d_up[0] / d_up[2]
     Ref d_groups, d_gmembers, d_member_pair, d_member_group, d_ppair;       // in d_up[1]
     DevBuf d_items;
     DevBuf d_rp_s0, d_rp_i0, d_rp_s1, d_cp_s0, d_cp_i0, d_cp_s1;
@@ -247,7 +247,7 @@ struct Scratch {
     bool keys_epilogue = false;       // the epilogue reads the reduce slots of the exact re-check itself: no pf_finalize_kernel, no kNN arrays
     // prefilter path
     DevBuf d_tu, d_tv, d_cand, d_cand_count, d_best, d_second;
-    DevBuf d_cmp_tu, d_live_idx, d_row_pair, d_row_src, d_vpairs, d_vpf, d_vitems, d_lists;
+    DevBuf d_cmp_tu, d_live_idx, d_row_pair, d_row_src, d_vpairs, d_vpf, d_vitems, d_lists, d_items16;
     DevBuf d_cmp_s0, d_cmp_s1, d_summary_a;   // route Q: sweep 1' row results, summary of plan A
     // device-side plan of the compacted sweep 2 (msfm_plan.hip.h)
     DevBuf d_colmask, d_gtot, d_grow0, d_cnt, d_mrow, d_summary, d_overflow, d_totals;
@@ -270,7 +270,7 @@ struct Scratch {
                           &d_vpairs, &d_vpf, &d_vitems, &d_lists, &d_colmask, &d_gtot, &d_grow0, &d_cnt, &d_mrow, &d_summary, &d_overflow,
                           &d_totals, &d_vf_pairs,
                           &d_vf_x1, &d_vf_y1, &d_vf_x2, &d_vf_y2, &d_vf_hyp, &d_vf_best_it, &d_vf_best_count, &d_vf_flags, &d_st2_qt,
-                          &d_st2_d, &d_counts2, &d_cmp_s0, &d_cmp_s1, &d_summary_a};
+                          &d_st2_d, &d_counts2, &d_cmp_s0, &d_cmp_s1, &d_summary_a, &d_items16};
         for (DevBuf* b : bufs) fn(*b, arg);
     }
     long long device_bytes() {
@@ -387,7 +387,8 @@ struct Batch {
 // first item in the linear list -- the list itself (85 000 items of 32 B for the bench job) is written by
 // build_items_kernel from the pair descriptors.  Items of one pair are contiguous; the linear list is cut into 8 chunks,
 // one per XCD (workgroup b runs on XCD b % 8): linear item k sits at position (k % per) * 8 + k / per.
-void build_items(Batch& b, int path) {
+// (`only`: a subset of the pairs -- the list of one route of a mixed sub-batch -- into the given outputs instead of the batch's own)
+void build_items(Batch& b, int path, const std::vector<char>* only = nullptr, std::vector<int>* base_out = nullptr, size_t* per_out = nullptr) {
     // Pairs in the order of their STREAMED image (id2): the 32 workgroups of an XCD walk 32 consecutive items of their
     // chunk at a time, and those then stream the same B image -- one image (1.4 MB at 5000 rows) stays in the XCD's 4 MB
     // L2 while ~30 workgroups read it, instead of three or four images evicting one another (pair order = id1-major:
@@ -396,14 +397,20 @@ void build_items(Batch& b, int path) {
     for (size_t p = 0; p < order.size(); ++p) order[p] = (int)p;
     if (b.id2.size() == b.pairs.size())
         std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return b.id2[(size_t)x] < b.id2[(size_t)y]; });
-    b.item_base.assign(b.pairs.size(), -1);
+    std::vector<int>& base = base_out ? *base_out : b.item_base;
+    base.assign(b.pairs.size(), -1);
     long long n = 0;
     for (size_t q = 0; q < order.size(); ++q) {
         const size_t p = (size_t)order[q];
         const PairDesc& pd = b.pairs[p];
         if (!pd.valid || pd.path != path) continue;
-        b.item_base[p] = (int)n;
+        if (only && !(*only)[p]) continue;
+        base[p] = (int)n;
         n += (long long)pd.ranges * (path == 1 ? pd.a_blocks256 : pd.a_blocks);
+    }
+    if (per_out) {
+        *per_out = (size_t)((n + 7) / 8);
+        return;
     }
     b.items_per_xcd = (size_t)((n + 7) / 8);
     b.n_items = b.items_per_xcd * 8;
@@ -565,22 +572,34 @@ struct FillBatch {
 
 // The pair tables of one route of the sub-batch (slot 0: matrix-core route, 2: brute-force route) in ONE copy, the work-item list
 // cleared (pair = -1: padding item) together with `more` in ONE fill launch, the items written by build_items_kernel.
-int upload_pair_tables(msfm_ctx* ctx, Batch& b, int path, const std::vector<PfPair>* pfq, FillBatch& fills) {
+int upload_pair_tables(msfm_ctx* ctx, Batch& b, int path, const std::vector<PfPair>* pfq, FillBatch& fills, const std::vector<PfPair>* pf16 = nullptr,
+                       const std::vector<int>* item_base16 = nullptr, size_t per16 = 0) {
     const size_t P = b.pairs.size();
     const int slot = path == 1 ? 0 : 2;
     UploadPlan up;
     up.add(SC.d_pairs, b.pairs.data(), P * sizeof(PairDesc));
     up.add(SC.d_pf, b.pf.data(), P * sizeof(PfPair));
     if (pfq) up.add(SC.d_pfq, pfq->data(), P * sizeof(PfPair));
+    if (pf16) up.add(SC.d_pf16, pf16->data(), P * sizeof(PfPair));
+    if (item_base16) up.add(SC.d_item_base16, item_base16->data(), item_base16->size() * 4);
     up.add(SC.d_item_base, b.item_base.data(), b.item_base.size() * 4);
     HIPCHK(ctx, up.place_and_copy(SC.d_up[slot], SC.h_up[slot], SC.stream));
     HIPCHK(ctx, SC.d_items.ensure(std::max<size_t>(1, b.n_items) * sizeof(WorkItem)));
     fills.add(SC.d_items.p, b.n_items * sizeof(WorkItem), 0xff);
+    if (item_base16 && per16) {
+        HIPCHK(ctx, SC.d_items16.ensure(per16 * 8 * sizeof(WorkItem)));
+        fills.add(SC.d_items16.p, per16 * 8 * sizeof(WorkItem), 0xff);
+    }
     HIPCHK(ctx, fills.launch(SC.stream));
     if (b.n_items == 0) return MSFM_OK;
     hipLaunchKernelGGL(build_items_kernel, dim3((unsigned)P), dim3(64), 0, SC.stream, (const PairDesc*)SC.d_pairs.as<PairDesc>(),
                        (const int*)SC.d_item_base.as<int>(), path, (int)b.items_per_xcd, SC.d_items.as<WorkItem>());
     HIPCHK(ctx, hipGetLastError());
+    if (item_base16 && per16) {   // the second route's own list: a kernel that walks the common list and skips pays ~17 us per skipped item
+        hipLaunchKernelGGL(build_items_kernel, dim3((unsigned)P), dim3(64), 0, SC.stream, (const PairDesc*)SC.d_pairs.as<PairDesc>(),
+                           (const int*)SC.d_item_base16.as<int>(), path, (int)per16, SC.d_items16.as<WorkItem>());
+        HIPCHK(ctx, hipGetLastError());
+    }
     return MSFM_OK;
 }
 
@@ -747,21 +766,40 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
     // Route Q (msfm_q8.hip.h): float images with byte twins -- sweep 1 on the twins (integer matrix cores), an fp16 sweep 1'
     // on the rows that survive.  Every prefiltered pair of the batch must join two images with twins.
     bool q8 = compact && !i8 && ctx->prefilter == 1 && ctx->q8_route;
-    long long q8_rows = 0, q8_pairs = 0;
-    for (size_t p = 0; p < P && q8; ++p)
-        if (b.pairs[p].valid && b.pf[p].use) {
-            q8 = ctx->images[b.id1[p]].q8 != nullptr && ctx->images[b.id2[p]].q8 != nullptr;
-            q8_rows += b.pairs[p].n1 + b.pairs[p].n2;
-            q8_pairs += 1;
-        }
+    long long q8_rows = 0, q8_pairs = 0, twin_pairs = 0, twin_rows = 0;
+    std::vector<char> twin;
+    if (q8) {
+        twin.assign(P, 0);
+        for (size_t p = 0; p < P; ++p)
+            if (b.pairs[p].valid && b.pf[p].use) {
+                q8_rows += b.pairs[p].n1 + b.pairs[p].n2;
+                q8_pairs += 1;
+                if (ctx->images[b.id1[p]].q8 != nullptr && ctx->images[b.id2[p]].q8 != nullptr) {
+                    twin[p] = 1;
+                    twin_pairs += 1;
+                    twin_rows += b.pairs[p].n1 + b.pairs[p].n2;
+                }
+            }
+    }
     // (two plans and three sweeps only pay on real images: batches of small ones -- the pre-emptive filter's 100-row
     // subsets -- keep the fp16 route; MSFM_Q8=2 lifts the limit, for the tests)
-    if (q8 && ctx->q8_route < 2 && (q8_pairs == 0 || q8_rows < 2 * 1024 * q8_pairs)) q8 = false;
-    std::vector<PfPair> pfq;
+    const bool fine_twins = ctx->q8_direct == 2 || (ctx->q8_direct == 1 && ctx->q8_level <= kQ8DirectMaxLevel);
+    bool q8_mixed = false;   // some pairs join images without twins: THEIR sweep 1 runs on the fp16 cores, the twins' on the integer cores
+    if (q8 && twin_pairs < q8_pairs) {
+        // (fine twins only: the coarse route's plan A / sweep 1' cover whole sub-batches; and only when a quarter of the work or more has twins)
+        q8_mixed = fine_twins && twin_pairs > 0 && 4 * twin_rows >= q8_rows;
+        if (!q8_mixed) q8 = false;
+    }
+    if (q8 && ctx->q8_route < 2 && (twin_pairs == 0 || twin_rows < 2 * 1024 * twin_pairs)) q8 = q8_mixed = false;
+    std::vector<PfPair> pfq, pf16;
     if (q8) {
         pfq = b.pf;
         for (size_t p = 0; p < P; ++p) {
             if (!b.pairs[p].valid || !b.pf[p].use) continue;
+            if (!twin[p]) {   // (mixed sub-batch: not a pair of the twins' sweep)
+                pfq[p].use = 0;
+                continue;
+            }
             const Image& ia = ctx->images[b.id1[p]];
             const Image& ib = ctx->images[b.id2[p]];
             PfPair& pp = pfq[p];
@@ -780,7 +818,7 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
     }
     // The route is chosen per sub-batch: one pair that cannot take an integer route sends all of them to the fp16 kernels (same
     // results, ~1.6 x the sweep time).  Counted, so that a mixed store shows up in the profile instead of only in the clock.
-    if (compact && ctx->prefilter == 1 && !i8 && !q8)
+    if (compact && ctx->prefilter == 1 && !i8 && !q8)   // (a mixed sub-batch of fine twins keeps the twins' pairs on the integer cores: q8_mixed)
         for (size_t p = 0; p < P; ++p) {
             if (!b.pairs[p].valid || !b.pf[p].use) continue;
             const Image& ia = ctx->images[b.id1[p]];
@@ -790,7 +828,7 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
         }
     // fine twins: their sweep's bounds are the thresholds of sweep 2; coarse ones (a store with values near 1): an fp16 sweep 1'
     // of the live rows refines them first
-    const bool q8_direct = q8 && (ctx->q8_direct == 2 || (ctx->q8_direct == 1 && ctx->q8_level <= kQ8DirectMaxLevel));
+    const bool q8_direct = q8 && fine_twins;
     const bool q8_refine = q8 && !q8_direct;
     SC.pf_pending.q8 = q8_refine;   // (a plan A and a sweep 1' to account for at the end of the batch)
     long long dense_cand = 0;
@@ -810,8 +848,26 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
         pfq[p].tu_off = b.pf[p].tu_off;
         pfq[p].tv_off = b.pf[p].tv_off;
     }
+    if (q8_mixed) {   // the table of the fp16 first sweep and its thresholds: the pairs WITHOUT twins (after the offsets above are final)
+        pf16 = b.pf;
+        for (size_t p = 0; p < P; ++p)
+            if (twin[p]) pf16[p].use = 0;
+        // The column partials share one buffer: the fp16 sweep stores 8-byte entries at ELEMENT cp_off, the integer sweep 4-byte entries
+        // at the same element numbers -- in a homogeneous sub-batch either is consistent, mixed they would overlap.  The twins' pairs
+        // count their offset in 4-byte entries of their own 8-byte region.  (Only the integer sweep and the prune kernel read it; the
+        // batch is rebuilt before a re-run.)
+        for (size_t p = 0; p < P; ++p)
+            if (twin[p]) b.pairs[p].cp_off *= 2;
+    }
+    std::vector<int> item_base16;
+    size_t per16 = 0;
     build_items(b, 1);
     if (b.n_items == 0) return MSFM_OK;
+    if (q8_mixed) {   // the fp16 first sweep's own item list: the pairs without twins
+        std::vector<char> only(P, 0);
+        for (size_t p = 0; p < P; ++p) only[p] = (b.pairs[p].valid && b.pf[p].use && !twin[p]) ? 1 : 0;
+        build_items(b, 1, &only, &item_base16, &per16);
+    }
     const long long kn = std::max<long long>(1, b.kf_elems + b.kr_elems);
     HIPCHK(ctx, SC.d_rp_s0.ensure(std::max<long long>(1, b.rp_elems) * 4));
     HIPCHK(ctx, SC.d_rp_s1.ensure(std::max<long long>(1, b.rp_elems) * 4));
@@ -832,7 +888,7 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
     }
     fills.add(SC.d_totals.p, 128, 0);
     fills.add(SC.d_overflow.p, P, 0);   // (which pairs own an overflowed list: pf_overflow_kernel at the end of the chain)
-    int rc = upload_pair_tables(ctx, b, 1, q8 ? &pfq : nullptr, fills);
+    int rc = upload_pair_tables(ctx, b, 1, q8 ? &pfq : nullptr, fills, q8_mixed ? &pf16 : nullptr, q8_mixed ? &item_base16 : nullptr, per16);
     if (rc != MSFM_OK) return rc;
 
     hipEvent_t e0 = get_event(ctx, ev_base), e1 = get_event(ctx, ev_base + 1);
@@ -867,6 +923,14 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
                            SC.d_cp_s0.as<float>(), (float*)nullptr, (const float*)nullptr, (const float*)nullptr,
                            (int2*)nullptr, (unsigned long long*)nullptr, (const int*)nullptr, (int)b.n_items, (int*)nullptr);
     HIPCHK(ctx, hipGetLastError());
+    if (q8_mixed && per16) {   // the pairs without twins: their own item list (the twins' sweep skipped them: not in use in ITS table)
+        hipLaunchKernelGGL(sweep_kernel<1>, dim3(std::min<unsigned>(sweep_grid, (unsigned)(per16 * 8))), block, kPfLdsBytes, SC.stream, dp,
+                           (const PfPair*)SC.d_pf16.as<PfPair>(), SC.d_items16.as<WorkItem>(), SC.d_rp_s0.as<float>(), SC.d_rp_s1.as<float>(),
+                           SC.d_cp_s0.as<float>(), (float*)nullptr, (const float*)nullptr, (const float*)nullptr,
+                           (int2*)nullptr, (unsigned long long*)nullptr, (const int*)nullptr, (int)(per16 * 8), (int*)nullptr);
+        HIPCHK(ctx, hipGetLastError());
+        SC.prof.mixed_route_sub_batches += 1;
+    }
     DBGSYNC(ctx, "sweep_kernel<1>");
     HIPCHK(ctx, hipEventRecord(e1, SC.stream));
     HIPCHK(ctx, hipEventRecord(SC.sweep1_done, SC.stream));
@@ -1037,6 +1101,9 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
         if (!q8_direct)
             hipLaunchKernelGGL(pf_thresholds_kernel, mgrid, dim3(256), 0, SC.stream, dp, dpf, SC.d_rp_s0.as<float>(),
                                SC.d_rp_s1.as<float>(), SC.d_cp_s0.as<float>(), colmask, tuv, tuv, prune, pc, q8 ? 1 : 0);
+        else if (q8_mixed)   // (the pairs of the fp16 sweep 1: thresholds and plan counts the usual way; the prune kernel did the twins')
+            hipLaunchKernelGGL(pf_thresholds_kernel, mgrid, dim3(256), 0, SC.stream, dp, (const PfPair*)SC.d_pf16.as<PfPair>(), SC.d_rp_s0.as<float>(),
+                               SC.d_rp_s1.as<float>(), SC.d_cp_s0.as<float>(), colmask, tuv, tuv, prune, pc, 0);
         HIPCHK(ctx, hipGetLastError());
         DBGSYNC(ctx, "pf_thresholds_kernel");
         rc = launch_plan(SC.d_summary.as<PlanSummary>(), 0);
@@ -1903,6 +1970,7 @@ void add_profile(msfm_profile& to, const msfm_profile& d) {
     to.sweep1b_ms += d.sweep1b_ms;
     to.sweep1b_descriptor_pairs += d.sweep1b_descriptor_pairs;
     to.demoted_pairs += d.demoted_pairs;
+    to.mixed_route_sub_batches += d.mixed_route_sub_batches;
 }
 
 int drain_streams(msfm_ctx* ctx) {

@@ -91,6 +91,7 @@ __global__ void pf_prune_q8_kernel(const PairDesc* __restrict__ pairs, const PfP
     const PfPair pp = pf[blockIdx.y];
     if (!pd.valid || !pp.use) return;
     const PfPair pq = pfq[blockIdx.y];
+    if (!pq.use) return;   // (a mixed sub-batch: this pair went through the fp16 sweep 1, pf_thresholds_kernel looks after it)
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     bool row_live = false;
     unsigned col_bits = 0;

@@ -141,15 +141,25 @@ def test_twins_only_for_values_in_the_unit_interval(gpu_ctx):
             gpu_ctx.upload_image(i, im)
         ref = gpu_ctx.match_pairs(pairs)
         assert gpu_ctx.profile()["sweep1_q8_launches"] >= 1
-        # one image with ONE value outside [0, 1]: no twin for it, and a batch that holds it keeps the fp16 route
+        # one image with ONE value outside [0, 1]: no twin for it.  Its three pairs take the fp16 first sweep, the other three stay on
+        # the integer cores (fine twins: a mixed sub-batch runs both sweeps; round 3 sent all six to the fp16 kernels)
         bad = imgs[2].copy()
         bad[0, int(np.argmin(bad[0]))] = -1e-3
         gpu_ctx.upload_image(2, bad)
         got = gpu_ctx.match_pairs(pairs)
         p = gpu_ctx.profile()
-        assert p["sweep1_q8_launches"] == 0 and p["prefilter_pairs"] == len(pairs)     # mixed batch: the fp16 route
+        assert p["prefilter_pairs"] == len(pairs) and p["fallback_pairs"] == 0
+        assert p["sweep1_q8_launches"] == 1 and p["mixed_route_sub_batches"] == 1 and p["demoted_pairs"] == 0
+        assert not same(got, ref)                                                     # (the edited row changed a list)
+        gpu_ctx.set_prefilter(2)                                                      # every pair on the fp16 cores
+        assert same(got, gpu_ctx.match_pairs(pairs)) and gpu_ctx.profile()["mixed_route_sub_batches"] == 0
         gpu_ctx.set_prefilter(0)
         assert same(got, gpu_ctx.match_pairs(pairs))
+        gpu_ctx.set_prefilter(1)
+        # the same under forced sub-batches: (0,1) alone is all twins, (0,2) alone all fp16, the rest mixed or not as they fall
+        gpu_ctx.set_limits(2, 0)
+        assert same(got, gpu_ctx.match_pairs(pairs))
+        gpu_ctx.set_limits(0, 0)
         # eight times the values: outside the unit interval -> fp16 route, and (exact scaling by a power of two) the same index
         # lists with eightfold distances
         gpu_ctx.set_prefilter(1)

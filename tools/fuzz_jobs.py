@@ -2,7 +2,7 @@
 budget, pipeline parts -- against (1) the same call under the library's defaults, bit for bit (offsets, (q, t) rows, distance bits:
 results do not depend on how a call is cut or overlapped), and (2) the C oracle on the whole pair list (small stores).
 tools/fuzz_routes.py covers the routes pair by pair; this one covers what sits above them: sub-batch cuts by count and by memory,
-the packed table uploads and batched fills, sets in flight, route decisions per sub-batch (mixed stores demote pairs), re-runs.
+the packed table uploads and batched fills, sets in flight, route decisions per sub-batch (mixed stores: both first sweeps in one sub-batch, or demoted pairs), re-runs.
 Usage: python tools/fuzz_jobs.py [seed] [cases]"""
 import sys
 
@@ -30,7 +30,7 @@ def main():
     rng = np.random.default_rng(seed)
     ctx = _lib.Context(0)
     bad = 0
-    n_sub = n_demoted = n_q8 = n_i8 = 0
+    n_sub = n_demoted = n_q8 = n_i8 = n_mixed = 0
     for case in range(cases):
         n_img = int(rng.integers(3, 20))
         big = rng.random() < 0.35
@@ -69,6 +69,7 @@ def main():
         n_q8 += pr["sweep1_q8_launches"]
         n_i8 += pr["sweep1_i8_launches"]
         n_demoted += pr["demoted_pairs"]
+        n_mixed += pr["mixed_route_sub_batches"]
         for _ in range(2):
             mp = int(rng.choice([1, 2, 3, 17, 100, 0]))
             sb = int(rng.choice([1 << 20, 8 << 20, 64 << 20, 1 << 30, 0]))
@@ -77,6 +78,7 @@ def main():
             ctx.set_pipeline(parts)
             got = ctx.match_pairs(pairs, ratio, cc, md)
             n_sub += ctx.profile()["sub_batches"]
+            n_mixed += ctx.profile()["mixed_route_sub_batches"]
             if not same(ref, got):
                 bad += 1
                 print("MISMATCH cut", case, kind, sizes, "max_pairs", mp, "scratch", sb, "parts", parts, flush=True)
@@ -88,8 +90,15 @@ def main():
             if not (np.array_equal(o[0], ref[0]) and np.array_equal(qt, ref[1]) and np.array_equal(bits(o[3]), bits(ref[2]))):
                 bad += 1
                 print("MISMATCH oracle", case, kind, sizes, ratio, cc, md, flush=True)
+                for k, (i, j) in enumerate(pairs):   # which pairs, and what their images look like (largest value: twins exist up to 1)
+                    a0, a1, b0, b1 = int(o[0][k]), int(o[0][k + 1]), int(ref[0][k]), int(ref[0][k + 1])
+                    if a1 - a0 != b1 - b0 or not np.array_equal(qt[a0:a1], ref[1][b0:b1]) or not np.array_equal(bits(o[3][a0:a1]), bits(ref[2][b0:b1])):
+                        print("   pair %d = (%d, %d): rows %d x %d, largest values %.4g / %.4g, oracle %d matches, device %d" % (
+                            k, i, j, sizes[i], sizes[j], float(np.max(imgs[i])), float(np.max(imgs[j])), a1 - a0, b1 - b0), flush=True)
+                print("   profile of the default call:", {x: pr[x] for x in ("sub_batches", "sweep1_q8_launches", "sweep1_i8_launches", "mixed_route_sub_batches",
+                                                                           "demoted_pairs", "fallback_pairs", "prefilter_pairs", "plan_regrows")}, flush=True)
     print("job cases done, mismatches:", bad, "| sub-batches under the random cuts:", n_sub, "| route Q / integer sweep-1 launches (defaults):", n_q8, "/", n_i8,
-          "| pairs demoted from the integer route in mixed sub-batches:", n_demoted)
+          "| sub-batches with BOTH first sweeps (twins + fp16):", n_mixed, "| pairs demoted from the integer route in mixed sub-batches:", n_demoted)
     return 1 if bad else 0
 
 
