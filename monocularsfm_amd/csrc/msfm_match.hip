@@ -763,8 +763,9 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
             pp.b_h0 = ib.h0_i8;
         }
     SC.pf_pending.i8 = i8;
-    // Route Q (msfm_q8.hip.h): float images with byte twins -- sweep 1 on the twins (integer matrix cores), an fp16 sweep 1'
-    // on the rows that survive.  Every prefiltered pair of the batch must join two images with twins.
+    // Route Q (msfm_q8.hip.h): float images with byte twins -- sweep 1 on the twins (integer matrix cores); coarse twins: an fp16
+    // sweep 1' on the rows that survive.  A pair takes it when both its images have twins; a sub-batch in which only SOME pairs do runs
+    // two first sweeps (fine twins: q8_mixed below) or keeps the fp16 route for all of them (coarse twins).
     bool q8 = compact && !i8 && ctx->prefilter == 1 && ctx->q8_route;
     long long q8_rows = 0, q8_pairs = 0, twin_pairs = 0, twin_rows = 0;
     std::vector<char> twin;
