@@ -1219,28 +1219,6 @@ int finish_prefilter(msfm_ctx* ctx, Batch& b, std::vector<char>& force_exact, bo
     SC.prof.approx_kernel_ms += ms;
     HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev_pool[pe.ev_base + 2], ctx->ev_pool[pe.ev_base + 3]));
     SC.prof.sweep2_ms += ms;
-#ifdef MSFM_SWEEP_PROBE
-    for (int which = 0; which < 2; ++which) {   // diagnostic build: average cycles per tile and wave of the four loop segments
-        unsigned long long pr[16][16];
-        if (which == 0) HIPCHK(ctx, hipMemcpyFromSymbol(pr, HIP_SYMBOL(g_sweep_probe), sizeof(pr)));
-        else HIPCHK(ctx, hipMemcpyFromSymbol(pr, HIP_SYMBOL(g_sweep_probe3), sizeof(pr)));
-        const bool sixteen = pr[8][5] != 0;   // (the integer-core kernels run sixteen waves)
-        for (int w = 0; w < (sixteen ? 16 : kPfWaves); w += (sixteen ? 1 : 3)) {
-            const double n = (double)std::max<unsigned long long>(1, pr[w][4]);
-            const double it_n = (double)std::max<unsigned long long>(1, pr[w][5]);
-            std::fprintf(stderr, "[sweep %d probe] wave %d: MFMA %.0f | wait+barrier %.0f | EPI %.0f | wait+barrier %.0f cycles per tile (%.0f tiles, %llu items); per item: %.0f cycles in the loop, %.0f outside it (descriptor fetch, A loads, first DMA, row merge)\n",
-                         which == 0 ? 1 : 3, w, pr[w][0] / n, pr[w][1] / n, pr[w][2] / n, pr[w][3] / n, n, pr[w][5],
-                         (double)(pr[w][0] + pr[w][1] + pr[w][2] + pr[w][3]) / it_n,
-                         ((double)pr[w][6] - (double)(pr[w][0] + pr[w][1] + pr[w][2] + pr[w][3])) / it_n);
-            if (which == 0 || !sixteen)
-                std::fprintf(stderr, "    item segments (cycles): descriptor fetch %.0f | A loads + first DMA %.0f | barrier + pre-read %.0f | loop %.0f | drain %.0f | row merge + stores %.0f\n",
-                             pr[w][8] / it_n, pr[w][9] / it_n, pr[w][10] / it_n, pr[w][11] / it_n, pr[w][12] / it_n, pr[w][13] / it_n);
-        }
-        std::memset(pr, 0, sizeof(pr));
-        if (which == 0) HIPCHK(ctx, hipMemcpyToSymbol(HIP_SYMBOL(g_sweep_probe), pr, sizeof(pr)));
-        else HIPCHK(ctx, hipMemcpyToSymbol(HIP_SYMBOL(g_sweep_probe3), pr, sizeof(pr)));
-    }
-#endif
     if (std::getenv("MSFM_DEBUG_TIMING") && pe.compact) {
         PlanSummary d;
         std::memcpy(&d, hs, sizeof(PlanSummary));

@@ -49,37 +49,6 @@
 #pragma once
 // (included inside namespace msfm)
 
-// Diagnostic build only (tools/gpu_probe.sh, -DMSFM_SWEEP_PROBE): per-wave cycle sums of the four segments of a tile
-// (MFMA phase, its wait + barrier, EPI phase, its wait + barrier), printed by the library after every sweep 1.
-#ifdef MSFM_SWEEP_PROBE
-__device__ unsigned long long g_sweep_probe[16][16];    // (16: the integer-core kernels run sixteen waves)
-__device__ unsigned long long g_sweep_probe3[16][16];   // the compacted sweep 2
-#define MSFM_PROBE_BEGIN unsigned long long pb_t = __builtin_amdgcn_s_memtime(), pb_acc[4] = {0, 0, 0, 0};
-#define MSFM_PROBE(k) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); pb_acc[k] += n_ - pb_t; pb_t = n_; }
-#define MSFM_PROBE_ITEM_BEGIN const unsigned long long pb_item0 = __builtin_amdgcn_s_memtime(); unsigned long long pb_it = pb_item0;
-// item-level segments: 8 descriptor fetch | 9 A loads + first DMA (vmcnt 0) | 10 barrier + pre-read + offset | 11 loop | 12 drain | 13 row merge
-#define MSFM_PROBE_SEG(k) if ((PASS == 1 || PASS == 3) && lane == 0) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); atomicAdd(&(PASS == 1 ? g_sweep_probe : g_sweep_probe3)[wave][k], n_ - pb_it); pb_it = n_; }
-#define MSFM_PROBE_ITEM_END                                                                                \
-    if ((PASS == 1 || PASS == 3) && lane == 0) {                                                           \
-        unsigned long long (*pi_)[16] = PASS == 1 ? g_sweep_probe : g_sweep_probe3;                         \
-        atomicAdd(&pi_[wave][6], (unsigned long long)(__builtin_amdgcn_s_memtime() - pb_item0));          \
-    }
-#define MSFM_PROBE_END                                                                                     \
-    if ((PASS == 1 || PASS == 3) && lane == 0) {                                                           \
-        unsigned long long (*pr_)[16] = PASS == 1 ? g_sweep_probe : g_sweep_probe3;                         \
-        for (int k_ = 0; k_ < 4; ++k_) atomicAdd(&pr_[wave][k_], pb_acc[k_]);                              \
-        atomicAdd(&pr_[wave][4], (unsigned long long)(t_end - t_begin));                                   \
-        atomicAdd(&pr_[wave][5], 1ull);                                                                    \
-    }
-#else
-#define MSFM_PROBE_BEGIN
-#define MSFM_PROBE(k)
-#define MSFM_PROBE_END
-#define MSFM_PROBE_ITEM_BEGIN
-#define MSFM_PROBE_ITEM_END
-#define MSFM_PROBE_SEG(k)
-#endif
-
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -136,7 +105,6 @@ __global__ __launch_bounds__(kPfThreads, 2) void sweep_kernel(
         it = s_next_item * 8 + (int)(blockIdx.x & 7);
     }
     if (it >= n_items) break;
-    MSFM_PROBE_ITEM_BEGIN
     const WorkItem item = items[it];
     if (item.pair < 0) continue;
     const PfPair pp = pf[item.pair];
@@ -145,7 +113,6 @@ __global__ __launch_bounds__(kPfThreads, 2) void sweep_kernel(
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    MSFM_PROBE_SEG(8)
     const int grp = wave >> 2;          // 0: MFMA in the even phases, 1: in the odd ones
     const int lcol = lane & 31, lhalf = lane >> 5;
 
@@ -253,7 +220,6 @@ __global__ __launch_bounds__(kPfThreads, 2) void sweep_kernel(
         asm volatile("" ::"v"(ae[rb]));
     }
     wait_vmcnt<0>();  // prologue loads and the first three DMA groups are done: counted waits start clean
-    MSFM_PROBE_SEG(9)
 
     // sweep 2: wave-private candidate buffer in LDS
     int2* cbuf = reinterpret_cast<int2*>(sCand) + wave * kPfCandBuf;
@@ -456,8 +422,6 @@ __global__ __launch_bounds__(kPfThreads, 2) void sweep_kernel(
     if (grp == 1) lds_barrier();                         // the odd half starts half a tile later
 
     f16v accA[kPfRB], accB[kPfRB];
-    MSFM_PROBE_SEG(10)
-    MSFM_PROBE_BEGIN
 #pragma unroll 1
     for (int t = t_begin; t < t_end; ++t) {
         const int sl = (t - t_begin) & (kPfRing - 1);
@@ -471,12 +435,10 @@ __global__ __launch_bounds__(kPfThreads, 2) void sweep_kernel(
             mfma_block(bf, be[1], accB);
             __builtin_amdgcn_s_setprio(0);
         }
-        MSFM_PROBE(0)
         // tile t+1 must be complete one phase before its first MFMA: this half waits here for its share (its DMA
         // group of tile t+2 may stay in flight), the other half at the end of its EPI phase
         if (grp == 0) wait_older_group();
         lds_barrier();
-        MSFM_PROBE(1)
         // ---- EPI phase: everything that is not matrix work ---------------------------------------------------
         // (the store comes before the DMA group: the counted wait then covers it together with the older group)
         if (PASS == 1 && grp == 0 && t > t_begin && wave == ((t - t_begin) & 3)) store_columns(t - 1);
@@ -497,13 +459,9 @@ __global__ __launch_bounds__(kPfThreads, 2) void sweep_kernel(
             }
         }
         if (kPreRead && wave_active && t + 1 < t_end) load_bf((sl + 1) & (kPfRing - 1), bf, be);   // the next MFMA phase starts on registers
-        MSFM_PROBE(2)
         if (grp == 1) wait_older_group();
         lds_barrier();
-        MSFM_PROBE(3)
     }
-    MSFM_PROBE_END
-    MSFM_PROBE_SEG(11)
     if (grp == 0) lds_barrier();   // the odd half's last EPI phase
     if (PASS == 2 || PASS == 3) flush_candidates();
     if (PASS == 1 && wave == 0) store_columns(t_end - 1);
@@ -511,7 +469,6 @@ __global__ __launch_bounds__(kPfThreads, 2) void sweep_kernel(
     if (PASS == 1 || PASS == 4) {
         wait_vmcnt<0>();   // the tail's DMA groups (re-fetches of the last tile) still write into the ring ...
         lds_barrier();     // ... everybody's have landed: the ring is scratch now
-        MSFM_PROBE_SEG(12)
         // rows: lane (lcol, lhalf) holds, for each of its 32 rows, the accumulator maximum over ITS columns; a row's result is
         // the two largest of its 32 lane values (S~ = -2 acc: the smallest S~ and an upper bound of the second smallest).
         // Transposed through the wave's share of the (now idle) B ring -- [64 rows][32 lanes + 1] floats -- so that lane l
@@ -534,7 +491,5 @@ __global__ __launch_bounds__(kPfThreads, 2) void sweep_kernel(
         rp_s0[o] = -2.f * m0;      // padding rows: -inf -> +inf
         rp_s1[o] = -2.f * m1;
     }
-    MSFM_PROBE_SEG(13)
-    MSFM_PROBE_ITEM_END
     }   // item loop
 }

@@ -158,7 +158,6 @@ __global__ __launch_bounds__(kI8Threads) void sweep_i8_kernel(
         it = s_next_item * 8 + (int)(blockIdx.x & 7);
     }
     if (it >= n_items) break;
-    MSFM_PROBE_ITEM_BEGIN
     const WorkItem item = items[it];
     if (item.pair < 0) continue;
     const PfPair pp = pf[item.pair];
@@ -167,7 +166,6 @@ __global__ __launch_bounds__(kI8Threads) void sweep_i8_kernel(
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    MSFM_PROBE_SEG(8)
     const int grp = (wave >> 2) & 1;    // 0: MFMA in the even phases, 1: in the odd ones; two waves of each on every SIMD
     const int lcol = lane & 31, lhalf = lane >> 5;
 
@@ -180,11 +178,7 @@ __global__ __launch_bounds__(kI8Threads) void sweep_i8_kernel(
     const unsigned lane_off = (unsigned)(wave * 1024 + lane * 16);
     auto dma_tile = [&](int tt) {
         if (!dma_wave) return;
-#ifdef MSFM_EXPERIMENT_SAME_TILE   // timing experiment only (wrong results): every DMA group re-reads the item's first tile
-        const int tc = t_begin;
-#else
         const int tc = tt < t_end ? tt : t_end - 1;
-#endif
         const int sl = (tt - t_begin) & (kI8Ring - 1);
         // the tile's offset goes into the SCALAR base, the lane's 32-bit offset is the same register for the whole item: no VALU
         // instruction per tile (hipcc's own lowering of the builtin adds the two in a VGPR pair).  M0 = the wave's LDS destination.
@@ -194,21 +188,12 @@ __global__ __launch_bounds__(kI8Threads) void sweep_i8_kernel(
 #pragma clang diagnostic ignored "-Winline-asm"   // (m0 is a reserved register: naming it as a clobber is the point)
         asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
                      :: "v"(lane_off), "s"(tile), "s"(dst) : "memory", "m0");
-#ifdef MSFM_EXPERIMENT_DMA_X4   // timing experiment only (same results): every piece travels L2 -> LDS four times -- what four 4-wave
-                                // workgroups per CU, each with a B ring of its own, would ask of the L2 (profiles/r04_i8_structural_experiments.txt)
-        asm volatile("global_load_lds_dwordx4 %0, %1\n\tglobal_load_lds_dwordx4 %0, %1\n\tglobal_load_lds_dwordx4 %0, %1"
-                     :: "v"(lane_off), "s"(tile) : "memory");
-#endif
 #pragma clang diagnostic pop
     };
     // One load per group and DMA wave.  At either wait the wave has issued the groups up to tile u + kI8Ring - 3 and needs
     // tile u: "at most kI8Ring - 3 outstanding" = tile u has landed (loads retire in order; see sweep_kernel).
     auto wait_older_group = [&]() {
-#ifdef MSFM_EXPERIMENT_DMA_X4
-        if (dma_wave) wait_vmcnt<4 * (kI8Ring - 3)>();
-#else
         if (dma_wave) wait_vmcnt<kI8Ring - 3>();
-#endif
     };
 
 #pragma unroll
@@ -273,7 +258,6 @@ __global__ __launch_bounds__(kI8Threads) void sweep_i8_kernel(
     asm volatile("" ::"v"(a_digit));
     if (PASS == 3) asm volatile("" ::"v"(rowc));
     wait_vmcnt<0>();
-    MSFM_PROBE_SEG(9)
 
     int2* cbuf = reinterpret_cast<int2*>(sCand) + wave * kPfCandBuf;
     const unsigned cbuf_lds = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)cbuf;
@@ -376,7 +360,6 @@ __global__ __launch_bounds__(kI8Threads) void sweep_i8_kernel(
     dma_tile(t_begin + kI8Ring - 1);   // the first interval's DMA group
     i4v bf[2][2];
     if (wave_active) preread(0, bf);
-    MSFM_PROBE_SEG(10)
 
     i16v accA, accB;
     // the matrix half of a tile: 10 MFMA, k-steps 2, 3 and the digits read from LDS behind the MFMA pairs that free their registers
@@ -400,18 +383,12 @@ __global__ __launch_bounds__(kI8Threads) void sweep_i8_kernel(
         bf[1][1] = *reinterpret_cast<const i4v*>(pb2 + 32 * kI8RowBytes + 32);
         accA = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[2], bf[0][0], accA, 0, 0, 0);
         accB = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[2], bf[0][1], accB, 0, 0, 0);
-#ifdef MSFM_EXPERIMENT_NO_DIGITS   // timing experiment only (wrong results): the sweep without its fifth k-step -- the ceiling of any
-                                   // norm-free formulation (profiles/r04_norm_free_twin_study.txt)
-        accA = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[3], bf[1][0], accA, 0, 0, 0);
-        accB = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[3], bf[1][1], accB, 0, 0, 0);
-#else
         bf[0][0] = *reinterpret_cast<const i4v*>(pb2 + 64);                     // the digits (bytes 128 + 16 lhalf ..)
         bf[0][1] = *reinterpret_cast<const i4v*>(pb2 + 32 * kI8RowBytes + 64);
         accA = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[3], bf[1][0], accA, 0, 0, 0);
         accB = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[3], bf[1][1], accB, 0, 0, 0);
         accA = __builtin_amdgcn_mfma_i32_32x32x32_i8(a_digit, bf[0][0], accA, 0, 0, 0);   // + (H0_b - h_b) [+ (H0_a - h_a)]
         accB = __builtin_amdgcn_mfma_i32_32x32x32_i8(a_digit, bf[0][1], accB, 0, 0, 0);
-#endif
     };
     // the epilogue half of tile t (its accumulators are in accA / accB)
     auto epilogue_half = [&](int t) {
@@ -443,16 +420,9 @@ __global__ __launch_bounds__(kI8Threads) void sweep_i8_kernel(
             if (!(t * kPfBT + 32 + lcol < pd.n2)) accB = i16v(-1);
         }
         if (PASS == 1) {
-#ifdef MSFM_EXPERIMENT_FOLD_HALF   // timing experiment only (wrong results): half of the epilogue's VALU work -- what does a v_max3 cost here?
-            fold_columns(column_max(accA), column_max(accA), (t - t_begin) & 3);
-#pragma unroll
-            for (int r = 0; r < 16; r += 2) rs0[r] = max3i(rs0[r], accA[r], accB[r + 1]);
-            asm volatile("" :: "v"(accB));
-#else
             fold_columns(column_max(accA), column_max(accB), (t - t_begin) & 3);
 #pragma unroll
             for (int r = 0; r < 16; ++r) rs0[r] = max3i(rs0[r], accA[r], accB[r]);
-#endif
         } else {
             scan_hits3(accA, accB, t * kPfBT + lcol);
         }
@@ -472,34 +442,20 @@ __global__ __launch_bounds__(kI8Threads) void sweep_i8_kernel(
     //   at the start of interval t + 2 by one wave: four slots.
     auto next_interval = [&](int v) {
         wait_older_group();
-#ifdef MSFM_EXPERIMENT_NO_BARRIER   // timing experiment only (races: wrong results): what do the per-tile barriers cost?
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#elif defined(MSFM_EXPERIMENT_HALF_BARRIER)   // timing experiment only (races): every second barrier -- what would one barrier per TWO tiles return?
-        if (v & 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        else lds_barrier();
-#else
         lds_barrier();
-#endif
         dma_tile(v + kI8Ring - 1);
         if (PASS == 1 && v - 2 >= t_begin && wave == ((v - t_begin) & 3)) store_columns(v - 2);
     };
-    MSFM_PROBE_BEGIN
 #pragma unroll 1
     for (int u = t_begin; u < t_end; ++u) {
         if (wave_active) matrix_half(u);
-        MSFM_PROBE(0)
         if (grp == 1) next_interval(u + 1);
-        MSFM_PROBE(1)
         if (wave_active) {
             epilogue_half(u);
             if (u + 1 < t_end) preread((u + 1 - t_begin) & (kI8Ring - 1), bf);
         }
-        MSFM_PROBE(2)
         if (grp == 0) next_interval(u + 1);
-        MSFM_PROBE(3)
     }
-    MSFM_PROBE_END
-    MSFM_PROBE_SEG(11)
     if (PASS == 3) flush_candidates();
 
     if (PASS == 1) {
@@ -526,7 +482,5 @@ __global__ __launch_bounds__(kI8Threads) void sweep_i8_kernel(
             rp_s1[o] = m1 > kI8PadTest ? (float)(-2 * (m1 - item_k)) : f_inf();
         }
     }
-    MSFM_PROBE_SEG(13)
-    MSFM_PROBE_ITEM_END
     }   // item loop
 }

@@ -61,7 +61,11 @@ def test_config4_u8_8192(gpu_ctx, oracle):
         gpu_ctx.upload_image(i, im)   # uint8 upload path
     A, B = u[0].astype(F32), u[1].astype(F32)
     fwd, rev = check_pair_sampled(gpu_ctx, oracle, A, B, seed=4)
-    assert np.array_equal(fwd[1] ** 2, np.rint(fwd[1] ** 2)) or True  # d^2 are integers (checked against the oracle above)
+    # the distances are sqrtf of INTEGERS (below 2^22 here, where rint(d^2) recovers S): d == fl32(sqrt(rint(d^2))) bit for bit
+    for dd in (fwd[1], fwd[2], rev[1], rev[2]):
+        dd = dd[dd < 3.0e38]
+        S = np.rint(dd.astype(np.float64) ** 2)
+        assert S.max() < 2 ** 22 and np.array_equal(np.sqrt(S).astype(F32).view(np.int32), dd.view(np.int32))
     q, t, d = gpu_ctx.match_pair(0, 1, 0.8, True, 1e9)
     assert len(q) > 200            # the planted near-duplicates match
     nz = q != 0
