@@ -157,6 +157,7 @@ struct Image {
     bool from_u8 = false;     // uploaded as MSFM_DTYPE_U8 (or a subset of such an image): integer values 0..255
     signed char* i8 = nullptr;
     float* nrm_i8 = nullptr;
+    int* n2_i8 = nullptr;     // n' = |x - 128|^2 per row, exactly (nrm_i8 holds 2 floor(n' / 2)): the exact S of a byte pair's candidates
     float nrm_i8_max = 0.f;
     int h0_i8 = 0;            // centre of the rows' h = floor(|x - 128|^2 / 2): the digit k-step carries H0 - h
     // route Q (msfm_q8.hip.h): the byte twin q = rint(x 255 / m) of a FLOAT image whose values all lie in [0, 1] -- operand rows,
@@ -180,6 +181,7 @@ void free_image(Image& im) {
     if (im.nrm) (void)hipFree(im.nrm);
     if (im.i8) (void)hipFree(im.i8);
     if (im.nrm_i8) (void)hipFree(im.nrm_i8);
+    if (im.n2_i8) (void)hipFree(im.n2_i8);
     if (im.q8) (void)hipFree(im.q8);
     if (im.nrm_q8) (void)hipFree(im.nrm_q8);
     if (im.err_q8) (void)hipFree(im.err_q8);
@@ -249,6 +251,7 @@ struct Scratch {
     DevBuf d_tu, d_tv, d_cand, d_cand_count, d_best, d_second;
     DevBuf d_cmp_tu, d_live_idx, d_row_pair, d_row_src, d_vpairs, d_vpf, d_vitems, d_lists, d_items16;
     DevBuf d_cmp_s0, d_cmp_s1, d_summary_a;   // route Q: sweep 1' row results, summary of plan A
+    DevBuf d_cand_val, d_cmp_n2;              // integer route: the candidates' accumulators (parallel to d_cand), n' per compacted row
     // device-side plan of the compacted sweep 2 (msfm_plan.hip.h)
     DevBuf d_colmask, d_gtot, d_grow0, d_cnt, d_mrow, d_summary, d_overflow, d_totals;
     PfPending pf_pending;
@@ -270,7 +273,7 @@ struct Scratch {
                           &d_vpairs, &d_vpf, &d_vitems, &d_lists, &d_colmask, &d_gtot, &d_grow0, &d_cnt, &d_mrow, &d_summary, &d_overflow,
                           &d_totals, &d_vf_pairs,
                           &d_vf_x1, &d_vf_y1, &d_vf_x2, &d_vf_y2, &d_vf_hyp, &d_vf_best_it, &d_vf_best_count, &d_vf_flags, &d_st2_qt,
-                          &d_st2_d, &d_counts2, &d_cmp_s0, &d_cmp_s1, &d_summary_a, &d_items16};
+                          &d_st2_d, &d_counts2, &d_cmp_s0, &d_cmp_s1, &d_summary_a, &d_items16, &d_cand_val, &d_cmp_n2};
         for (DevBuf* b : bufs) fn(*b, arg);
     }
     long long device_bytes() {
@@ -654,6 +657,7 @@ void build_compact_plan(msfm_ctx* ctx, const Batch& b, CompactPlan& cp, bool no_
             g.b_c = pp.b_c;
             g.a_c = pp.a_c;     // (per image: every image that meets image j in this batch has a compatible scale, see fill_pair)
             g.b_h0 = pp.b_h0;
+            g.b_n2 = pp.b_n2;
             g.dir = 0;
             g.bt_begin = 0;
             g.bt_end = pd.b_tiles;
@@ -678,6 +682,7 @@ void build_compact_plan(msfm_ctx* ctx, const Batch& b, CompactPlan& cp, bool no_
                 g.b_c = pp.a_c;
                 g.a_c = pp.b_c;
                 g.b_h0 = pp.a_h0;
+                g.b_n2 = pp.a_n2;
                 g.dir = 1;
                 g.bt_begin = std::min(pd.a_blocks, bit * gshift * (kPfWgRows / kBM));
                 g.bt_end = std::min(pd.a_blocks, (bit + 1) * gshift * (kPfWgRows / kBM));
@@ -761,6 +766,8 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
             pp.a_c = pp.b_c = 0.f;
             pp.a_h0 = ia.h0_i8;
             pp.b_h0 = ib.h0_i8;
+            pp.a_n2 = ia.n2_i8;
+            pp.b_n2 = ib.n2_i8;
         }
     SC.pf_pending.i8 = i8;
     // Route Q (msfm_q8.hip.h): float images with byte twins -- sweep 1 on the twins (integer matrix cores); coarse twins: an fp16
@@ -917,7 +924,8 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
         hipLaunchKernelGGL(sweep_i8_kernel<1>, dim3(std::min<unsigned>(sweep_grid, (unsigned)b.n_items)), dim3(kI8Threads), kI8LdsBytes, SC.stream, dp,
                            q8 ? (const PfPair*)SC.d_pfq.as<PfPair>() : dpf,
                            SC.d_items.as<WorkItem>(), SC.d_rp_s0.as<float>(), SC.d_rp_s1.as<float>(), SC.d_cp_s0.as<float>(),
-                           (const float*)nullptr, (int2*)nullptr, (unsigned long long*)nullptr, (const int*)nullptr, (int)b.n_items, (int*)nullptr);
+                           (const float*)nullptr, (int2*)nullptr, (unsigned long long*)nullptr, (const int*)nullptr, (int)b.n_items, (int*)nullptr,
+                           (int*)nullptr);
     else
         hipLaunchKernelGGL(sweep_kernel<1>, dim3(std::min<unsigned>(sweep_grid, (unsigned)b.n_items)), block, kPfLdsBytes, SC.stream, dp, dpf,
                            SC.d_items.as<WorkItem>(), SC.d_rp_s0.as<float>(), SC.d_rp_s1.as<float>(),
@@ -980,6 +988,10 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
         HIPCHK(ctx, SC.d_row_pair.ensure((size_t)rows_cap * 4));
         HIPCHK(ctx, SC.d_row_src.ensure((size_t)rows_cap * 8));
         HIPCHK(ctx, SC.d_cand.ensure((size_t)cand_cap * sizeof(int2)));
+        if (i8) {
+            HIPCHK(ctx, SC.d_cand_val.ensure((size_t)cand_cap * 4));
+            HIPCHK(ctx, SC.d_cmp_n2.ensure((size_t)rows_cap * 4));
+        }
         HIPCHK(ctx, SC.d_cand_count.ensure(std::max<size_t>(1, G) * 8));
         {   // the plan's static tables in one copy (page-locked staging of this scratch set), everything it clears in one launch
             UploadPlan up;
@@ -1022,6 +1034,8 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
         po.rows_cap = rows_cap;
         po.cand_cap = cand_cap;
         po.items_cap = items_cap;
+        po.cmp_tu = SC.d_cmp_tu.as<float>();
+        po.cmp_n2 = i8 ? SC.d_cmp_n2.as<int>() : nullptr;
         // the plan from the live counts in d_cnt / d_gtot: scan, descriptors + work items, member rows, slot assignment
         auto launch_plan = [&](PlanSummary* summary, int norms_only) -> int {
             po.summary = summary;
@@ -1045,7 +1059,8 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
                                (const unsigned*)colmask, (const long long*)SC.d_mrow.as<long long>(), SC.d_cnt.as<int>(),
                                SC.d_live_idx.as<int>(), SC.d_row_pair.as<int>(), SC.d_cmp_tu.as<float>(),
                                SC.d_row_src.as<const _Float16*>(), i8 ? kI8RowBytes / 2 : kPfRowHalfs,
-                               SC.d_best.as<unsigned long long>(), SC.d_second.as<unsigned long long>(), norms_only);
+                               SC.d_best.as<unsigned long long>(), SC.d_second.as<unsigned long long>(), norms_only,
+                               i8 ? SC.d_cmp_n2.as<int>() : (int*)nullptr);
             HIPCHK(ctx, hipGetLastError());
             DBGSYNC(ctx, "pf_assign_kernel");
             return MSFM_OK;
@@ -1111,12 +1126,12 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
         if (rc != MSFM_OK) return rc;
         HIPCHK(ctx, hipEventRecord(e2, SC.stream));
         if (i8)
-            hipLaunchKernelGGL(sweep_i8_kernel<3>, dim3(sweep_grid), dim3(kI8Threads), kI8LdsBytes, SC.stream,
+            hipLaunchKernelGGL(sweep_i8_kernel<3>, dim3(sweep_grid), dim3(kI8Threads), kI8LdsBytes3, SC.stream,
                                (const PairDesc*)SC.d_vpairs.as<PairDesc>(), (const PfPair*)SC.d_vpf.as<PfPair>(),
                                (const WorkItem*)SC.d_vitems.as<WorkItem>(), (float*)nullptr, (float*)nullptr, (float*)nullptr,
                                (const float*)SC.d_cmp_tu.as<float>(), SC.d_cand.as<int2>(),
                                SC.d_cand_count.as<unsigned long long>(), (const int*)&SC.d_summary.as<PlanSummary>()->n_items, 0,
-                               SC.d_totals.as<int>() + 8);
+                               SC.d_totals.as<int>() + 8, SC.d_cand_val.as<int>());
         else
             hipLaunchKernelGGL(sweep_kernel<3>, dim3(sweep_grid), block, kPfLdsBytes, SC.stream,
                                (const PairDesc*)SC.d_vpairs.as<PairDesc>(), (const PfPair*)SC.d_vpf.as<PfPair>(),
@@ -1171,8 +1186,10 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
 #define MSFM_LAUNCH_EXACT(O)                                                                                             \
     hipLaunchKernelGGL(pf_exact_candidates_kernel<O>, cgrid, dim3(kExSpan), 0, SC.stream, dp, dl, dcount,                  \
                        (const int2*)SC.d_cand.as<int2>(), SC.d_best.as<unsigned long long>(), SC.d_second.as<unsigned long long>(), \
-                       (int)n_lists, SC.d_totals.as<int>() + 16)
-        if (ctx->order == MSFM_ORDER_SSE4X4) MSFM_LAUNCH_EXACT(0);
+                       (int)n_lists, SC.d_totals.as<int>() + 16, (const int*)SC.d_cand_val.as<int>(), 0)
+        // byte pairs on the integer route: the sweep handed over exact integers -- no rows are read, the named order does not matter
+        if (i8 && compact) MSFM_LAUNCH_EXACT(4);
+        else if (ctx->order == MSFM_ORDER_SSE4X4) MSFM_LAUNCH_EXACT(0);
         else if (ctx->order == MSFM_ORDER_AVX2_FMA) MSFM_LAUNCH_EXACT(1);
         else MSFM_LAUNCH_EXACT(3);
 #undef MSFM_LAUNCH_EXACT
@@ -1525,7 +1542,7 @@ int msfm_create(int device_ordinal, msfm_ctx** out_ctx) {
     hipError_t e5 = hipFuncSetAttribute(reinterpret_cast<const void*>(sweep_i8_kernel<1>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, kI8LdsBytes);
     hipError_t e6 = hipFuncSetAttribute(reinterpret_cast<const void*>(sweep_i8_kernel<3>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, kI8LdsBytes);
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, kI8LdsBytes3);
     if (e5 != hipSuccess || e6 != hipSuccess) e2 = e5 != hipSuccess ? e5 : e6;
     if (e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess) {
         std::fprintf(stderr, "msfm_create: cannot reserve %d bytes of LDS for the prefilter kernels\n", kPfLdsBytes);
@@ -1686,7 +1703,7 @@ static int build_q8_twin(msfm_ctx* ctx, Image& im) {
     HIPCHK(ctx, hipMalloc((void**)&im.q8, (size_t)npad * kI8RowBytes));
     HIPCHK(ctx, hipMalloc((void**)&im.nrm_q8, (size_t)npad * 4));
     hipLaunchKernelGGL(pf_prepare_i8_kernel, dim3(std::min(2048, (npad * 11 + 255) / 256)), dim3(256), 0, SC.stream,
-                       (const float*)ctx->d_stage.as<float>(), im.q8, im.nrm_q8, mx_d, n, npad);
+                       (const float*)ctx->d_stage.as<float>(), im.q8, im.nrm_q8, mx_d, n, npad, (int*)nullptr);
     HIPCHK(ctx, hipGetLastError());
     unsigned mx[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     HIPCHK(ctx, hipMemcpyAsync(mx, ctx->d_maxima.p, 32, hipMemcpyDeviceToHost, SC.stream));
@@ -1761,8 +1778,9 @@ static int build_image(msfm_ctx* ctx, Image& im, const unsigned char* src8, bool
     auto prepare_bytes = [&]() -> int {
         HIPCHK(ctx, hipMalloc((void**)&im.i8, (size_t)npad * kI8RowBytes));
         HIPCHK(ctx, hipMalloc((void**)&im.nrm_i8, (size_t)npad * 4));
+        HIPCHK(ctx, hipMalloc((void**)&im.n2_i8, (size_t)npad * 4));
         hipLaunchKernelGGL(pf_prepare_i8_kernel, dim3(std::min(2048, (npad * 11 + 255) / 256)), dim3(256), 0, SC.stream,
-                           (const float*)im.raw, im.i8, im.nrm_i8, ctx->d_maxima.as<unsigned>(), n, npad);
+                           (const float*)im.raw, im.i8, im.nrm_i8, ctx->d_maxima.as<unsigned>(), n, npad, im.n2_i8);
         HIPCHK(ctx, hipGetLastError());
         return MSFM_OK;
     };
@@ -1804,8 +1822,10 @@ static int build_image(msfm_ctx* ctx, Image& im, const unsigned char* src8, bool
         } else {   // (an all-zero next to an all-128 descriptor: not SIFT) -- the image is served by the fp16 kernels
             (void)hipFree(im.i8);
             (void)hipFree(im.nrm_i8);
+            (void)hipFree(im.n2_i8);
             im.i8 = nullptr;
             im.nrm_i8 = nullptr;
+            im.n2_i8 = nullptr;
             im.is_u8 = false;
         }
     }

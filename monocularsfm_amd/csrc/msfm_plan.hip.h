@@ -38,6 +38,7 @@ struct PlanGroup {            // static description of one compacted sweep (host
     int first, count;         // members: gmembers[first .. first + count)
     int ranges;               // B-range split of its work items (1 unless the batch is small)
     int b_h0;                 // integer-core route: the streamed image's centre H0
+    const int* b_n2;          // integer-core route: the streamed image's exact row norms n' (CandList::b_n2)
 };
 
 struct PlanSummary {
@@ -70,6 +71,8 @@ struct PlanOut {
     int* live_idx;            // per compact row: row index in its image
     int* row_pair;            // per compact row: pair of the batch
     long long rows_cap, cand_cap, items_cap;
+    const float* cmp_tu;      // per compact row: T - |a|^2 (pf_assign_kernel); the integer route's exact-S fold reads it back
+    const int* cmp_n2;        // per compact row: n' (integer route; pf_assign_kernel)
 };
 
 // candidate-list capacity of a group in units of 1024 entries: 8 per compacted row, rounded up, + 1024; at most 2^30 entries
@@ -208,6 +211,10 @@ __global__ void pf_plan_write_kernel(const PlanGroup* __restrict__ groups, int n
     L->live_idx = out.live_idx + row0;
     L->row_pair = out.row_pair + row0;
     MSFM_PLAN_FENCE();
+    L->cmp_tu = out.cmp_tu + row0;
+    L->cmp_n2 = out.cmp_n2 ? out.cmp_n2 + row0 : nullptr;
+    L->b_n2 = G->b_n2;
+    MSFM_PLAN_FENCE();
     out.grow0[g] = ok ? row0 : -1;   // (-1: pf_member_rows_kernel / pf_assign_kernel see an invalid plan, nothing is assigned)
     if (!ok) return;
     const int nblk = G->bt_end - G->bt_begin, ranges = G->ranges, bt0 = G->bt_begin;
@@ -262,7 +269,8 @@ __global__ __launch_bounds__(256) void pf_assign_kernel(
     int* __restrict__ live_idx, int* __restrict__ row_pair, float* __restrict__ cmp_tu,
     const _Float16** __restrict__ row_src, int row_halfs /* 136: fp16 rows, 88: byte rows */,
     unsigned long long* __restrict__ best, unsigned long long* __restrict__ second,
-    int norms_only /* plan A of route Q: the sweep wants -|a|^2 (accumulator = -S~/2), not T - |a|^2 */) {
+    int norms_only /* plan A of route Q: the sweep wants -|a|^2 (accumulator = -S~/2), not T - |a|^2 */,
+    int* __restrict__ cmp_n2 /* integer route: n' per compact row (null otherwise) */) {
     MSFM_TAIL_PRIO();
     const int p = blockIdx.x >> 1, dir = blockIdx.x & 1;
     const PlanPair pl = pp_plan[p];
@@ -275,18 +283,22 @@ __global__ __launch_bounds__(256) void pf_assign_kernel(
     const long long off = dir ? pp.tv_off : pp.tu_off;
     const float* nrm = dir ? pp.b_nrm : pp.a_nrm;
     const _Float16* src = dir ? pp.b_h : pp.a_h;
+    const int* n2 = dir ? pp.b_n2 : pp.a_n2;
+    const bool with_n2 = cmp_n2 != nullptr && n2 != nullptr;
     const int bits = dir ? pl.rev_bits : 1, member0 = dir ? pl.rev_member0 : pl.fwd_member;
     __shared__ int hist[32];
     __shared__ long long base[32];
     // ---- all loads of the thread (clamped: the arrays cover the padded rows)
     float t4[4], n4[4];
     unsigned m4[4];
+    int x4[4] = {0, 0, 0, 0};
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int e = e_begin + (int)threadIdx.x + j * 256, ec = e < n ? e : n - 1;
         t4[j] = tuv[off + ec];
         m4[j] = dir ? colmask[off + ec] : 1u;
         n4[j] = nrm[ec];
+        if (with_n2) x4[j] = n2[ec];
         if (e >= n) t4[j] = -f_inf();
     }
     long long my_row0 = -1;
@@ -323,6 +335,7 @@ __global__ __launch_bounds__(256) void pf_assign_kernel(
             live_idx[k] = e;
             row_pair[k] = p;
             cmp_tu[k] = norms_only ? -n4[j] : t - n4[j];
+            if (with_n2) cmp_n2[k] = x4[j];
             row_src[k] = src + (size_t)e * row_halfs;
         }
     }

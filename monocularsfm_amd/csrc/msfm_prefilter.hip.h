@@ -97,6 +97,8 @@ struct PfPair {            // per-pair extras of the prefilter path (parallel to
     int pad;
     const float* a_err;    // route Q (msfm_q8.hip.h), twin pairs only: per-row quantisation error norms of the byte twins;
     const float* b_err;    //   the images' maxima of them travel in a_c / b_c
+    const int* a_n2;       // i8 (byte images, not twins): n' = |x - 128|^2 per row, exactly (norms hold 2 floor(n' / 2)): what turns a
+    const int* b_n2;       //   candidate's accumulator into the exact S (pf_exact_candidates_kernel<4>)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -355,6 +357,11 @@ struct CandList {
     int pad;
     const int* live_idx;
     const int* row_pair;
+    // integer-core route (byte pairs): what pf_exact_candidates_kernel<4> needs to turn a candidate's accumulator into the exact S --
+    // per compacted row its hit-level source T - 2 h_a and its n', per row of the streamed image its n'
+    const float* cmp_tu;
+    const int* cmp_n2;
+    const int* b_n2;
 };
 
 __device__ __forceinline__ unsigned long long pf_key(float s, int idx) {
@@ -451,11 +458,16 @@ __device__ __forceinline__ void pf_fold(unsigned long long* __restrict__ best, u
                   [](unsigned long long* w, unsigned long long k) -> unsigned long long { return atomicMin(w, k); });
 }
 
+// ORDER 4 (round 5) -- byte pairs on the integer-core route: NO row is read.  sweep_i8_kernel<3> hands over every candidate's accumulator
+// acc = a'.b' - h_b + C (C = the compacted row's hit level, the C operand of its tile's first MFMA), and S = n'_a + (n'_b & 1) - 2 (acc - C)
+// is the exact integer |a - b|^2 -- which on byte data IS the pinned fp32 order's result under every named order (every partial sum is an
+// integer below 2^24; oracle/int_oracle.py pins that).  Phase 2 -- the gather of two 512-byte rows per candidate, 39 % of a step's HBM
+// bytes on the float job -- does not exist here; the staging, the per-XCD span cursor and the look-before-atomic fold are shared.
 template <int ORDER>
 __global__ __launch_bounds__(kExSpan) void pf_exact_candidates_kernel(
     const PairDesc* __restrict__ pairs, const CandList* __restrict__ lists, const unsigned long long* __restrict__ cand_count,
     const int2* __restrict__ cand, unsigned long long* __restrict__ best, unsigned long long* __restrict__ second, int n_lists,
-    int* __restrict__ cursors /* [8], zero: spans handed out per XCD */) {
+    int* __restrict__ cursors /* [8], zero: spans handed out per XCD */, const int* __restrict__ cand_val /* ORDER 4 */, int b_h0_unused) {
     MSFM_TAIL_PRIO();
     __shared__ int s_base[kExLists + 1];   // s_base[i] = spans of the XCD's lists before list i of the round
     __shared__ int s_part[kExSpan];
@@ -520,12 +532,21 @@ __global__ __launch_bounds__(kExSpan) void pf_exact_candidates_kernel(
     //      addresses for the whole-wave shuffles of phase 2) and looks at its slots
     const bool live = c0 + tid < c1;
     int2 qt = cand[L.off + (live ? c0 + tid : c0)];
+    float s_int = 0.f;
+    if (ORDER == 4) {
+        // (compacted lists only: the integer route has no dense sweep 2)  C exactly as sweep_i8_kernel<3> forms its C operand
+        const int acc = cand_val[L.off + (live ? c0 + tid : c0)];
+        const int C = (int)floorf(fminf(fmaxf(0.5f * L.cmp_tu[qt.x], -5.0e8f), 5.0e8f));
+        s_int = (float)(L.cmp_n2[qt.x] + (L.b_n2[qt.y] & 1) - 2 * (acc - C));
+    }
     const int pair = L.mode == 0 ? L.pair : L.row_pair[qt.x];
     if (L.mode == 1) qt.x = L.live_idx[qt.x];
     if (L.mode == 2) qt = make_int2(qt.y, L.live_idx[qt.x]);
     const PairDesc* pd = pairs + pair;
-    s_a[tid] = pd->a_rawp + (size_t)qt.x * kDim;
-    s_b[tid] = pd->b_rawp + (size_t)qt.y * kDim;
+    if (ORDER != 4) {
+        s_a[tid] = pd->a_rawp + (size_t)qt.x * kDim;
+        s_b[tid] = pd->b_rawp + (size_t)qt.y * kDim;
+    }
     // A mode-1 list only serves the row direction, a mode-2 list only the column direction: the live rows of the OTHER
     // direction get their complete candidate sets from their own list.
     const long long slot_r = pd->kf_off + qt.x, slot_c = pd->kr_off + qt.y;
@@ -537,7 +558,7 @@ __global__ __launch_bounds__(kExSpan) void pf_exact_candidates_kernel(
     int g_next = 0;
     if (tid == 0) g_next = atomicAdd(&cursors[xcd], 1);
     // ---- phase 2: the 16-lane groups stream through the span, two candidates in flight per group
-    const int n4 = (c1 - c0 + 3) & ~3;   // (whole waves take part in the shuffles)
+    const int n4 = ORDER == 4 ? 0 : (c1 - c0 + 3) & ~3;   // (whole waves take part in the shuffles)
     for (int k0 = grp; k0 < n4; k0 += 32) {
         const int k1 = k0 + 16 < n4 ? k0 + 16 : k0;   // (uniform per wave: a wave's four groups are four consecutive candidates)
         const float* a0 = s_a[k0];
@@ -570,7 +591,7 @@ __global__ __launch_bounds__(kExSpan) void pf_exact_candidates_kernel(
     __syncthreads();
     // ---- phase 3: thread t folds candidate t into its slots
     if (live) {
-        const float res = s_res[tid];
+        const float res = ORDER == 4 ? s_int : s_res[tid];
         if (res < f_inf()) {   // batchDistance never inserts a distance >= FLT_MAX
             if (L.mode != 2) pf_fold(best, second, slot_r, pf_key(res, qt.y), sb_r, ss_r);
             if (L.mode != 1) pf_fold(best, second, slot_c, pf_key(res, qt.x), sb_c, ss_c);

@@ -51,7 +51,9 @@ constexpr int kI8WaveRows = kPfWgRows / kI8Waves;       // 32: one MFMA row bloc
 // Ring of EIGHT 11-KiB tiles, DMA seven tiles ahead: a tile takes ~1 us here, so the three-tile lead of the fp16
 // kernel (1.6 us per tile there) would leave little more than an L2 miss.
 constexpr int kI8Ring = 8;
+// ring | per-wave candidate buffers (q, t) (PASS 3) | column class maxima (PASS 1) | per-wave accumulator values of the candidates (PASS 3)
 constexpr int kI8LdsBytes = kI8Ring * kI8TileBytes + kI8Waves * kPfCandBuf * 8 + 4 * kPfBT * kPfColClasses * 4;
+constexpr int kI8LdsBytes3 = kI8LdsBytes + kI8Waves * kPfCandBuf * 4;
 static_assert(kI8WaveRows == 32, "one 32-row block per wave");
 constexpr int kI8Pad = -(1 << 29);                      // "-inf" of a padding row / column (two of them still fit an int32)
 constexpr int kI8PadTest = -(1 << 27);                  // anything below is padding
@@ -74,7 +76,7 @@ __device__ __forceinline__ float2 i8_cp_unpack(int code) {   // -> the float pip
 // 2h (+inf on padding rows).  `raw` holds the bytes widened to float (the store's row-major copy).
 // maxima[2] = max 2h, maxima[3] = ~(min 2h) (float bits).
 __global__ void pf_prepare_i8_kernel(const float* __restrict__ raw, signed char* __restrict__ rows, float* __restrict__ nrm2h,
-                                     unsigned* __restrict__ maxima, int n, int npad) {
+                                     unsigned* __restrict__ maxima, int n, int npad, int* __restrict__ n2 /* nullable: |x - 128|^2 exactly */) {
     const long long total = (long long)npad * 11;
     for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
         const int row = (int)(e / 11), g = (int)(e - (long long)row * 11);
@@ -99,6 +101,9 @@ __global__ void pf_prepare_i8_kernel(const float* __restrict__ raw, signed char*
             f = (float)(2 * (s >> 1));
             atomicMax(&maxima[2], __float_as_uint(f));
             atomicMax(&maxima[3], ~__float_as_uint(f));
+            if (n2) n2[row] = s;
+        } else if (n2) {
+            n2[row] = 0;
         }
         nrm2h[row] = f;
     }
@@ -136,7 +141,7 @@ __global__ __launch_bounds__(kI8Threads) void sweep_i8_kernel(
     const PairDesc* __restrict__ pairs, const PfPair* __restrict__ pf, const WorkItem* __restrict__ items,
     float* __restrict__ rp_s0, float* __restrict__ rp_s1, float* __restrict__ cp_s0, const float* __restrict__ tu,
     int2* __restrict__ cand, unsigned long long* __restrict__ cand_count, const int* __restrict__ n_items_dev, int n_items_host,
-    int* __restrict__ dyn_next) {
+    int* __restrict__ dyn_next, int* __restrict__ cand_val /* PASS 3: the accumulator of every candidate, parallel to `cand` */) {
     static_assert(PASS == 1 || PASS == 3, "sweep 1 and the compacted sweep 2");
     typedef const __attribute__((address_space(1))) float* gfloat_p;
     typedef const __attribute__((address_space(1))) i4v* gi4_p;
@@ -144,6 +149,7 @@ __global__ __launch_bounds__(kI8Threads) void sweep_i8_kernel(
     char* sB = pf_smem;                                                   // [ring slot][64 rows x 176 B]
     char* sCand = pf_smem + kI8Ring * kI8TileBytes;                       // [wave][kPfCandBuf] int2 (PASS 3)
     int* sCol = reinterpret_cast<int*>(sCand + kI8Waves * kPfCandBuf * 8);  // [4 tiles][4 classes][64 columns] (PASS 1)
+    int* sVal = sCol + 4 * kPfBT * kPfColClasses;                           // [wave][kPfCandBuf] (PASS 3; only kI8LdsBytes3 launches have it)
 
     const int n_items = n_items_dev ? *n_items_dev : n_items_host;
     __shared__ int s_next_item;
@@ -261,6 +267,8 @@ __global__ __launch_bounds__(kI8Threads) void sweep_i8_kernel(
 
     int2* cbuf = reinterpret_cast<int2*>(sCand) + wave * kPfCandBuf;
     const unsigned cbuf_lds = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)cbuf;
+    int* vbuf = sVal + wave * kPfCandBuf;
+    const unsigned vbuf_lds = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)vbuf;
     int n_buf = 0;
     auto flush_candidates = [&]() {
         if (n_buf == 0) return;
@@ -269,7 +277,10 @@ __global__ __launch_bounds__(kI8Threads) void sweep_i8_kernel(
         const int base = __builtin_amdgcn_readfirstlane((int)(base64 < (unsigned long long)pp.cand_cap ? base64 : (unsigned long long)pp.cand_cap));
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         for (int k = lane; k < n_buf; k += 64)
-            if (base + k < pp.cand_cap) cand[pp.cand_off + base + k] = cbuf[k];
+            if (base + k < pp.cand_cap) {
+                cand[pp.cand_off + base + k] = cbuf[k];
+                cand_val[pp.cand_off + base + k] = vbuf[k];
+            }
         n_buf = 0;
     };
 
@@ -302,6 +313,33 @@ __global__ __launch_bounds__(kI8Threads) void sweep_i8_kernel(
     };
     // compacted sweep: a hit is accumulator >= 0, sign bit clear (see scan_hits3 of sweep_kernel); 16 elements per lane
     // and column block: element r ends up at bit 15 - r of the block's mask
+    // With every hit travels its ACCUMULATOR (round 5): acc = a'.b' - h_b + C with C the row's hit level floor((T - 2 h_a) / 2) (the C
+    // operand; clamped, see rowc) -- the consumer (pf_exact_candidates_kernel<4>) turns it into the EXACT S = n'_a + (n'_b & 1) - 2 (acc - C):
+    // on byte data the pinned fp32 order is exact integer arithmetic (header), so the candidates of a byte pair need no second look at
+    // their rows.  acc[k] with a per-lane k: a select chain over the 16 accumulators (15 v_cmp + v_cndmask), paid once per hit -- about one
+    // per wave and tile on compacted rows.
+    auto pick16 = [&](const i16v& a, int k) -> int {   // (a chain, not a tree: one temporary -- the kernel sits at its register limit)
+        int v = a[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) v = k == r ? a[r] : v;
+        return v;
+    };
+    auto scan_block = [&](const i16v& a, unsigned nmask, int col) {
+        unsigned hm = ~nmask & 0xffffu;
+        for (unsigned long long mm = __ballot(hm != 0u); mm != 0ull; mm = __ballot(hm != 0u)) {
+            const bool hit = hm != 0u;
+            const int k = (__clz((int)hm) - 16) & 15;   // first remaining element of this lane (lanes without a hit: any valid index)
+            if (n_buf + 64 > kPfCandBuf) flush_candidates();
+            const int v = pick16(a, k);
+            if (hit) {
+                hm &= ~(0x8000u >> k);
+                const int slt = n_buf + __popcll(mm & ((1ull << lane) - 1ull));
+                const int2 e = make_int2(arow_base + (k & 3) + 8 * (k >> 2), col);
+                asm volatile("ds_write_b64 %0, %1\n\tds_write_b32 %2, %3" ::"v"(cbuf_lds + slt * 8), "v"(e), "v"(vbuf_lds + slt * 4), "v"(v) : "memory");
+            }
+            n_buf += __popcll(mm);
+        }
+    };
     auto scan_hits3 = [&](const i16v& a0, const i16v& a1, int col0) {
         unsigned nm[2] = {0u, 0u};
 #pragma unroll
@@ -309,23 +347,10 @@ __global__ __launch_bounds__(kI8Threads) void sweep_i8_kernel(
             nm[0] = __builtin_amdgcn_alignbit(nm[0], (unsigned)a0[r], 31);
             nm[1] = __builtin_amdgcn_alignbit(nm[1], (unsigned)a1[r], 31);
         }
-#pragma unroll 1
-        for (int blk = 0; blk < 2; ++blk) {
-            unsigned hm = ~(blk ? nm[1] : nm[0]) & 0xffffu;
-            const int col = col0 + blk * 32;
-            for (unsigned long long mm = __ballot(hm != 0u); mm != 0ull; mm = __ballot(hm != 0u)) {
-                const bool hit = hm != 0u;
-                const int k = __clz((int)hm) - 16;   // first remaining element of this lane
-                if (n_buf + 64 > kPfCandBuf) flush_candidates();
-                if (hit) {
-                    hm &= ~(0x8000u >> k);
-                    const int slt = n_buf + __popcll(mm & ((1ull << lane) - 1ull));
-                    const int2 e = make_int2(arow_base + (k & 3) + 8 * (k >> 2), col);
-                    asm volatile("ds_write_b64 %0, %1" ::"v"(cbuf_lds + slt * 8), "v"(e) : "memory");
-                }
-                n_buf += __popcll(mm);
-            }
-        }
+        // (the common case -- no hit in the wave's 64 x 32 elements -- leaves after one ballot)
+        if (__ballot(((~nm[0] | ~nm[1]) & 0xffffu) != 0u) == 0ull) return;
+        scan_block(a0, nm[0], col0);
+        scan_block(a1, nm[1], col0 + 32);
     };
     // sweep 1, columns: one LDS atomic per column block into the tile's class array (see sweep_kernel)
     const unsigned col_lds = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)sCol +

@@ -1,0 +1,23 @@
+#!/bin/bash
+# Round 5: the GPU calls of the round, one stage per `gpurun` call (each box is fresh; A/B comparisons happen inside one stage).
+#   /usr/local/graft/bin/gpurun --timeout 1500 -- 'bash tools/gpu_r5.sh <stage>'
+# Output: gpurun_out/r5/<stage>/ ; what is judged is copied to profiles/r05_* (index: profiles/r05_README.md).
+# tools/_ab/libmsfm_match_r04.so = the library of commit 73e894c (round 4's final build):
+#   git worktree add /tmp/w 73e894c && make -C /tmp/w/monocularsfm_amd/csrc && cp /tmp/w/monocularsfm_amd/csrc/libmsfm_match.so tools/_ab/libmsfm_match_r04.so
+set -u
+STAGE=${1:-probe}
+ROOT=$(pwd); OUT=$ROOT/gpurun_out/r5/$STAGE; rm -rf $OUT; mkdir -p $OUT; export TMPDIR=/tmp
+R04=tools/_ab/libmsfm_match_r04.so
+run() { local name=$1; shift; local t0=$(date +%s); timeout ${TMO:-600} "$@" > $OUT/$name.txt 2>&1; echo "$name rc=$? ($(( $(date +%s) - t0 )) s)"; }
+
+case $STAGE in
+probe)   # what an upload can cost, the block-scaled fp6 instruction, parity of the exact-S-in-sweep byte route + its A/B against round 4
+    run ubench_upload tools/ubench_upload; cat $OUT/ubench_upload.txt
+    run ubench_fp6 tools/ubench_fp6; cat $OUT/ubench_fp6.txt
+    TMO=900 run pytest_bytes python -m pytest -m gpu -x -q tests/test_gpu_i8.py tests/test_gpu_jobs.py tests/test_gpu_configs.py tests/test_gpu_certificate.py; tail -3 $OUT/pytest_bytes.txt
+    run fuzz_bytes python tools/fuzz_routes.py 811 250; tail -2 $OUT/fuzz_bytes.txt
+    run ab_u8 python tools/ab_multi.py --u8 --images 64 r04=$R04 tree; cat $OUT/ab_u8.txt
+    run ab_u8_p1 python tools/ab_multi.py --u8 --images 64 --p1 r04=$R04 tree; cat $OUT/ab_u8_p1.txt
+    ;;
+*) echo "unknown stage $STAGE"; exit 2;;
+esac
