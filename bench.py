@@ -258,6 +258,7 @@ def main():
         t_up = time.perf_counter()
         for i, im in enumerate(imgs):
             ctx.upload_image(i, im)   # resident in HBM before the timed region
+        ctx.finalize_store()          # (uploads only copy; the images are built -- classification, layout kernels -- here, inside the timer)
         upload_s = time.perf_counter() - t_up   # host buffers -> HBM (PCIe) + the on-device layout / fp16 / norm passes
         sm = ShardedMatcher(ctx=ctx, device=coll_dev, force_collectives=args.force_collectives, **match_kw)
 

@@ -143,7 +143,15 @@ int msfm_set_pipeline(msfm_ctx* ctx, int min_sub_batches);
 /* ---- descriptor store -------------------------------------------------------------------
  * Replaces the per-pair Database::ReadDescriptors calls of MatchImagePairs
  * (src/Feature/FeatureMatching.cpp:32-33, "TODO: cache"): every image is uploaded once and
- * stays resident in HBM.  ids are Database image ids, 0 <= id < MSFM_MAX_IMAGES. */
+ * stays resident in HBM.  ids are Database image ids, 0 <= id < MSFM_MAX_IMAGES.
+ * msfm_upload_image COPIES the rows (the caller's buffer is free when it returns) and returns without building anything: the
+ * images of all uploads since the last use are built together -- classification (byte store? values in [0, 1]?), ONE device
+ * allocation, table-driven layout kernels -- by the next call that needs them (any matching call, msfm_subset_image of a
+ * pending source) or by msfm_finalize_store.  A device error of that build (out of memory) is therefore reported by THAT call.
+ * Resident per row: 184 B for a byte image (the 176-byte operand row of the integer matrix cores + norms; the fp32 / fp16 forms
+ * are derived on the device the first time a route needs them: a pair with a float image, msfm_knn2_pair, ratio > 0.95,
+ * msfm_set_prefilter 0 / 2), 788 B for a float image (+ 184 B with a byte twin); + 512 B per row of 128-row panels for
+ * images that take the brute-force route.  csrc/msfm_store.hip.h has the table. */
 int msfm_upload_image(msfm_ctx* ctx, int image_id, const void* desc, int n, int dim, int dtype);
 /* A new store entry from rows of a resident one, entirely on the device: the sub-matrix
  * FeatureUtils::ExtractTopScaleDescriptors builds (src/Feature/FeatureUtils.cpp:84-95, rows picked by
@@ -153,6 +161,12 @@ int msfm_upload_image(msfm_ctx* ctx, int image_id, const void* desc, int n, int 
 int msfm_subset_image(msfm_ctx* ctx, int src_image_id, int dst_image_id, const int32_t* rows, int count);
 int msfm_image_rows(const msfm_ctx* ctx, int image_id, int* out_n);
 int msfm_clear_images(msfm_ctx* ctx);
+/* Build everything uploaded so far now (otherwise the first matching call does it): the end of a bulk load, e.g. of
+ * FeatureMatcher::PreloadAllImages' one SELECT sweep over the descriptors table (host/FeatureMatching.cpp). */
+int msfm_finalize_store(msfm_ctx* ctx);
+/* Device bytes the store holds (its chunks, incl. forms derived on demand and keypoints), descriptor rows resident, images still
+ * waiting for msfm_finalize_store.  Any pointer may be NULL. */
+int msfm_store_info(const msfm_ctx* ctx, int64_t* out_device_bytes, int64_t* out_rows, int64_t* out_pending_images);
 
 /* ---- one pair ---------------------------------------------------------------------------
  * Twin of FeatureUtils::ComputeCrossMatches / ComputeMatches (src/Feature/FeatureUtils.cpp:

@@ -25,7 +25,7 @@ EXPORTS = [
     "msfm_match_pair", "msfm_match_pairs", "msfm_fetch_matches", "msfm_knn2_pair",
     "msfm_topscale_select", "msfm_pair_id", "msfm_pair_from_id", "msfm_swap_image_pair",
     "msfm_version", "msfm_upload_keypoints", "msfm_match_pairs_verified", "msfm_subset_image", "msfm_view_matches", "msfm_set_limits", "msfm_fetch_matches_device",
-    "msfm_fetch_order_certificate", "msfm_set_pipeline", "msfm_device_count",
+    "msfm_fetch_order_certificate", "msfm_set_pipeline", "msfm_device_count", "msfm_finalize_store", "msfm_store_info",
 ]
 
 
@@ -87,6 +87,11 @@ def load():
     L.msfm_image_rows.argtypes = [vp, C.c_int, C.POINTER(C.c_int)]
     L.msfm_subset_image.argtypes = [vp, C.c_int, C.c_int, ip, C.c_int]
     L.msfm_clear_images.argtypes = [vp]
+    try:   # (the A/B tools also load older builds of the library: tools/ab_multi.py)
+        L.msfm_finalize_store.argtypes = [vp]
+        L.msfm_store_info.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    except AttributeError:
+        pass
     L.msfm_match_pair.argtypes = [vp, C.c_int, C.c_int, C.c_float, C.c_int, C.c_double, ip, fp, C.POINTER(C.c_int)]
     L.msfm_match_pairs.argtypes = [vp, ip, C.c_int, C.POINTER(MatchParams), C.POINTER(C.c_int64)]
     L.msfm_fetch_matches.argtypes = [vp, ip, fp]
@@ -211,6 +216,17 @@ class Context:
 
     def clear_images(self):
         self._chk(self._L.msfm_clear_images(self._h))
+
+    def finalize_store(self):
+        """Build everything uploaded so far now (otherwise the first matching call does it)."""
+        if hasattr(self._L, "msfm_finalize_store"):
+            self._chk(self._L.msfm_finalize_store(self._h))
+
+    def store_info(self):
+        """-> {device_bytes, rows, pending_images} of the descriptor store."""
+        b, r, p = C.c_int64(), C.c_int64(), C.c_int64()
+        self._chk(self._L.msfm_store_info(self._h, C.byref(b), C.byref(r), C.byref(p)))
+        return {"device_bytes": b.value, "rows": r.value, "pending_images": p.value}
 
     def match_pair(self, id1, id2, ratio=0.8, cross_check=True, max_distance=0.7):
         n1 = max(self.image_rows(id1), 1)

@@ -91,10 +91,9 @@ template <> struct OrderTraits<3> {
 struct PairDesc {
     const float* a_panel;  // image id1 (query), panel layout
     const float* b_panel;  // image id2 (train)
-    const float* a_raw;    // row-major copies (tie fix-up)
-    const float* b_raw;
-    const float* a_rawp;   // the same rows for the exact re-check: position 64 h + 4 L + c of a row holds its element 16 (4 h + c) + L
-    const float* b_rawp;   // (lane L of a 16-lane group needs the elements 16 j + L, j = 0..7, in every accumulation order: two 16-byte loads)
+    const float* a_rawp;   // the fp32 rows, PERMUTED for the exact re-check: position 64 h + 4 L + c of a row holds its element 16 (4 h + c) + L
+    const float* b_rawp;   // (lane L of a 16-lane group needs the elements 16 j + L, j = 0..7, in every accumulation order: two 16-byte loads);
+                           // the sqrt-space tie fix-up reads them through rawp_pos (msfm_store.hip.h).  Null for byte images on the integer route
     int n1, n2;
     int a_blocks, b_tiles;
     int n1pad, n2pad;
@@ -137,32 +136,6 @@ __device__ __forceinline__ void top2_merge(float& s0, int& i0, float& s1, float 
     s1 = fminf(fmaxf(s0, bs0), fminf(s1, bs1));
     i0 = take_b ? bi0 : i0;
     s0 = fminf(s0, bs0);
-}
-
-// ---------------------------------------------------------------------------------------
-// layout kernel: row-major [n][128] f32 (or u8) -> panels [blk][pos][row], pos = storage
-// position in accumulation ("chain") order, rows >= n zero-filled.
-// ---------------------------------------------------------------------------------------
-template <int ORDER, typename T>
-__global__ void layout_kernel(const T* __restrict__ src, float* __restrict__ raw, float* __restrict__ panel,
-                              int n, int nblk) {
-    const long long total = (long long)nblk * kPanelFloats;
-    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
-         e += (long long)gridDim.x * blockDim.x) {
-        const int row = (int)(e & (kBM - 1));
-        const int pos = (int)((e >> 7) & (kDim - 1));
-        const int blk = (int)(e >> 14);
-        const int r = blk * kBM + row;
-        float v = 0.0f;
-        if (r < n) v = (float)src[(size_t)r * kDim + OrderTraits<ORDER>::pos_to_k(pos)];
-        panel[e] = v;
-    }
-    if (raw) {
-        const long long nraw = (long long)n * kDim;
-        for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < nraw;
-             e += (long long)gridDim.x * blockDim.x)
-            raw[e] = (float)src[e];
-    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -543,7 +516,10 @@ __global__ void merge_knn_kernel(const PairDesc* __restrict__ pairs,
     }
 }
 
-// exact-order S for two row-major descriptors (used only on the rare tie path)
+// position of element k of a row in its permuted copy (PairDesc::a_rawp; msfm_store.hip.h has the same function for the build kernels)
+__device__ __forceinline__ int tie_rawp_pos(int k) { return 64 * (k >> 6) + 4 * (k & 15) + ((k >> 4) & 3); }
+
+// exact-order S for two descriptors given as permuted rows (used only on the rare tie path)
 template <int ORDER>
 __device__ float l2sqr_rowmajor(const float* __restrict__ a, const float* __restrict__ b) {
     using OT = OrderTraits<ORDER>;
@@ -553,7 +529,7 @@ __device__ float l2sqr_rowmajor(const float* __restrict__ a, const float* __rest
         for (int v = 0; v < 4; ++v) {
             float p = 0.f;
             for (int it = 0; it < OT::kIters; ++it) {
-                const int k = OT::pos_to_k(g * OT::kGroupPos + v * OT::kIters + it);
+                const int k = tie_rawp_pos(OT::pos_to_k(g * OT::kGroupPos + v * OT::kIters + it));
                 const float t = a[k] - b[k];
                 if (it == 0) p = t * t;
                 else if (OT::kFused) p = __builtin_fmaf(t, t, p);
@@ -579,8 +555,8 @@ __global__ void tie_fixup_kernel(const PairDesc* __restrict__ pairs, const int* 
         const int4 w = fix_list[f];
         const PairDesc pd = pairs[w.x];
         const bool fwd = (w.y == 0);
-        const float* me = (fwd ? pd.a_raw : pd.b_raw) + (size_t)w.z * kDim;
-        const float* other = fwd ? pd.b_raw : pd.a_raw;
+        const float* me = (fwd ? pd.a_rawp : pd.b_rawp) + (size_t)w.z * kDim;
+        const float* other = fwd ? pd.b_rawp : pd.a_rawp;
         const int n_other = fwd ? pd.n2 : pd.n1;
         const long long ko = (fwd ? pd.kf_off : pd.kr_off) + w.z;
         const float d0 = k_d0[ko];

@@ -101,67 +101,6 @@ struct PfPair {            // per-pair extras of the prefilter path (parallel to
     const int* b_n2;       //   candidate's accumulator into the exact S (pf_exact_candidates_kernel<4>)
 };
 
-// ---------------------------------------------------------------------------------------------
-// upload-time preparation: fp16 operand rows (272 B each, see kPfRowBytes), row norms, maxima
-// ---------------------------------------------------------------------------------------------
-__global__ void pf_prepare_kernel(const float* __restrict__ raw, _Float16* __restrict__ h, float* __restrict__ nrm,
-                                  unsigned* __restrict__ maxima /* [0]=nrm_max bits, [1]=abs_max bits,
-                                                                   [6]=1 if a value is not an integer in [0, 255] */,
-                                  int n, int npad) {
-    const long long total = (long long)npad * 16;
-    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
-         e += (long long)gridDim.x * blockDim.x) {
-        const int row = (int)(e >> 4), g = (int)(e & 15);
-        h8 v;
-        float amax = 0.f;
-        bool bytes = true;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const float x = row < n ? raw[(size_t)row * kDim + g * 8 + k] : 0.f;
-            v[k] = (_Float16)x;
-            amax = fmaxf(amax, fabsf(x));
-            if (!(fabsf(x) <= 3.0e38f)) amax = f_inf();  // NaN / inf
-            bytes = bytes && x >= 0.f && x <= 255.f && x == __builtin_rintf(x);
-        }
-        *reinterpret_cast<h8*>(h + (size_t)row * kPfRowHalfs + g * 8) = v;
-        if (amax > 0.f) atomicMax(&maxima[1], __float_as_uint(amax));
-        if (!bytes) maxima[6] = 1u;
-    }
-    for (int row = blockIdx.x * blockDim.x + threadIdx.x; row < npad; row += gridDim.x * blockDim.x) {
-        float s = f_inf();
-        if (row < n) {
-            s = 0.f;
-            for (int k = 0; k < kDim; ++k) {
-                const float x = raw[(size_t)row * kDim + k];
-                s = fmaf(x, x, s);
-            }
-            atomicMax(&maxima[0], __float_as_uint(s));  // s >= 0: uint order == float order; NaN bits sort high
-        }
-        nrm[row] = s;
-        // the quadruple granule: zero until pf_ext_kernel fills it (an image that is not fp16-safe never gets one)
-        h8 z;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) z[k] = (_Float16)0.f;
-        *reinterpret_cast<h8*>(h + (size_t)row * kPfRowHalfs + kDim) = z;
-    }
-}
-
-// norm quadruples [h_hi, h_lo, c, c, 0, 0, 0, 0], h = |row|^2 / 2 / c (padding rows: +inf -> never selected), into the
-// 17th granule of every operand row
-__global__ void pf_ext_kernel(const float* __restrict__ nrm, _Float16* __restrict__ h16, int npad, float c) {
-    const float inv_c = 1.f / c;  // power of two: exact
-    for (int row = blockIdx.x * blockDim.x + threadIdx.x; row < npad; row += gridDim.x * blockDim.x) {
-        const float h = 0.5f * nrm[row] * inv_c;
-        const _Float16 hi = (_Float16)h;
-        const float rest = h - (float)hi;
-        const _Float16 lo = (rest == rest && fabsf(rest) < 3.0e38f) ? (_Float16)rest : (_Float16)0.f;
-        h8 v;
-        v[0] = hi; v[1] = lo; v[2] = (_Float16)c; v[3] = (_Float16)c;
-        v[4] = v[5] = v[6] = v[7] = (_Float16)0.f;
-        *reinterpret_cast<h8*>(h16 + (size_t)row * kPfRowHalfs + kDim) = v;
-    }
-}
-
 __device__ __forceinline__ void glds_copy_bytes(const void* g, void* lds, int bytes, int tid, int nthreads) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const char* gp = reinterpret_cast<const char*>(g);
@@ -604,6 +543,7 @@ __global__ __launch_bounds__(kExSpan) void pf_exact_candidates_kernel(
 
 #include "msfm_plan.hip.h"
 #include "msfm_q8.hip.h"
+#include "msfm_store.hip.h"
 
 // finalize: the same outputs as merge_knn_kernel (idx0, d0, d1, tie queue)
 __global__ void pf_finalize_kernel(const PairDesc* __restrict__ pairs, const PfPair* __restrict__ pf,

@@ -47,37 +47,6 @@ constexpr float kQ8LevelStep = 1.f / 16.f;
 // (~4.5 per live row on RootSIFT-like data against 2.5 after an fp16 sweep 1'; 12 at m = 1): no sweep 1'
 constexpr float kQ8DirectMaxLevel = 0.625f;
 
-// byte twin of a float image: qf = rint(x * scale) as floats (the input format of pf_prepare_i8_kernel), err[row] >= |x - q inv|_2
-// flags[0] |= 1 when a value is outside [0, 1] or not finite: no twin.  maxima[0] = max err (float bits).
-__global__ void pf_quantise_q8_kernel(const float* __restrict__ raw, float* __restrict__ qf, float* __restrict__ err,
-                                      unsigned* __restrict__ flags, unsigned* __restrict__ err_max, int n, float scale, float inv) {
-    const int lane = threadIdx.x & 63;
-    for (int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; row < n; row += (gridDim.x * blockDim.x) >> 6) {
-        float s = 0.f;
-        bool bad = false;
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const float x = raw[(size_t)row * kDim + lane + 64 * k];
-            if (!(x >= 0.f && x <= 1.f)) bad = true;
-            const float q = fminf(fmaxf(rintf(x * scale), 0.f), 255.f);
-            qf[(size_t)row * kDim + lane + 64 * k] = q;
-            const float d = fmaf(-q, inv, x);   // x - q inv, rounded once
-            s = fmaf(d, d, s);
-        }
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
-        if (__ballot(bad) != 0ull) {
-            if (lane == 0) atomicOr(&flags[0], 1u);
-        }
-        if (lane == 0) {
-            // rounded up: the differences (one rounding each), 130 fp32 roundings of non-negative terms (< 1e-5 relative), the sqrt
-            const float e = sqrtf(s) * (1.f + 2e-5f) + 1e-7f;
-            err[row] = e;
-            atomicMax(err_max, __float_as_uint(e));
-        }
-    }
-}
-
 // live / dead from the integer sweep on the twins.  Rows: rp_s0 / rp_s1 hold S~min and an upper bound of the second
 // smallest S~ (floats holding integers); columns: per 512-row block the two largest accumulator maxima (-S~/2).
 // Live rows / columns get the marker +inf in tu / tv (dead: -inf), every live column carries ALL block bits.

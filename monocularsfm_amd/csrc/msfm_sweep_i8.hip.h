@@ -40,7 +40,7 @@
 
 constexpr int kI8RowBytes = 176;                        // 128 operand bytes + 16 digits of H0 - h + the 16 constants + 16 B padding
 constexpr int kI8TileBytes = kPfBT * kI8RowBytes;       // 11264 B = 11 DMA pieces
-constexpr int kI8DigitLo = -243968, kI8DigitHi = 245759;   // representable H0 - h (see pf_digits_i8_kernel)
+constexpr int kI8DigitLo = -243968, kI8DigitHi = 245759;   // representable H0 - h (see st_digits, msfm_store.hip.h)
 // SIXTEEN waves of 32 rows (four per SIMD): on the integer cores a tile's matrix phase is 16 x 34 cycles per SIMD, and one
 // wave issues a VALU instruction every 8 cycles at best -- with two 64-row waves per SIMD the ~130 VALU instructions per
 // tile and wave set the pace (profiles/r02_i8_sweep_ablation.txt); four 32-row waves give the epilogue twice the issue slots
@@ -70,70 +70,6 @@ __device__ __forceinline__ float2 i8_cp_unpack(int code) {   // -> the float pip
     const int hi = msfm_cp_hi(code);
     if (hi == kCpNone) return make_float2(-f_inf(), -f_inf());
     return make_float2((float)hi, msfm_cp_has_second(code) ? (float)(hi - msfm_cp_gap(code)) : -f_inf());
-}
-
-// upload-time preparation of a byte image: signed operand rows (digits zero until pf_digits_i8_kernel), the float "norms"
-// 2h (+inf on padding rows).  `raw` holds the bytes widened to float (the store's row-major copy).
-// maxima[2] = max 2h, maxima[3] = ~(min 2h) (float bits).
-__global__ void pf_prepare_i8_kernel(const float* __restrict__ raw, signed char* __restrict__ rows, float* __restrict__ nrm2h,
-                                     unsigned* __restrict__ maxima, int n, int npad, int* __restrict__ n2 /* nullable: |x - 128|^2 exactly */) {
-    const long long total = (long long)npad * 11;
-    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
-        const int row = (int)(e / 11), g = (int)(e - (long long)row * 11);
-        i4v v = {0, 0, 0, 0};
-        if (row < n && g < 8) {
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const int x = (int)raw[(size_t)row * kDim + g * 16 + k] - 128;
-                v[k >> 2] |= (x & 255) << (8 * (k & 3));
-            }
-        }
-        *reinterpret_cast<i4v*>(rows + (size_t)row * kI8RowBytes + g * 16) = v;
-    }
-    for (int row = blockIdx.x * blockDim.x + threadIdx.x; row < npad; row += gridDim.x * blockDim.x) {
-        float f = f_inf();
-        if (row < n) {
-            int s = 0;
-            for (int k = 0; k < kDim; ++k) {
-                const int x = (int)raw[(size_t)row * kDim + k] - 128;
-                s += x * x;
-            }
-            f = (float)(2 * (s >> 1));
-            atomicMax(&maxima[2], __float_as_uint(f));
-            atomicMax(&maxima[3], ~__float_as_uint(f));
-            if (n2) n2[row] = s;
-        } else if (n2) {
-            n2[row] = 0;
-        }
-        nrm2h[row] = f;
-    }
-}
-
-// the 16 digits of V = H0 - h behind every real row's operand bytes: V = d_0 - 128 (d_1 + ... + d_15), d_0 in [-128, -1],
-// the rest filled greedily (the host has checked that every row of the image is inside [kI8DigitLo, kI8DigitHi]); behind
-// them the 16 constants [1, -128 x 15] the OTHER side's digits are multiplied with
-__global__ void pf_digits_i8_kernel(const float* __restrict__ nrm2h, signed char* __restrict__ rows, int n, int h0) {
-    for (int row = blockIdx.x * blockDim.x + threadIdx.x; row < n; row += gridDim.x * blockDim.x) {
-        const int h = (int)(0.5f * nrm2h[row]);
-        const int V = h0 - h;
-        const int Wp = (V + 128) >> 7;          // floor((V + 128) / 128)
-        signed char d[16];
-        d[0] = (signed char)(V - (Wp << 7));    // [-128, -1]
-        int R = -Wp;                            // d_1 + ... + d_15
-#pragma unroll
-        for (int k = 1; k < 16; ++k) {
-            const int x = R < -128 ? -128 : (R > 127 ? 127 : R);
-            d[k] = (signed char)x;
-            R -= x;
-        }
-        i4v lo;
-#pragma unroll
-        for (int w = 0; w < 4; ++w)
-            lo[w] = (d[4 * w] & 255) | ((d[4 * w + 1] & 255) << 8) | ((d[4 * w + 2] & 255) << 16) | ((d[4 * w + 3] & 255) << 24);
-        const i4v hi = {(int)0x80808001u, (int)0x80808080u, (int)0x80808080u, (int)0x80808080u};
-        *reinterpret_cast<i4v*>(rows + (size_t)row * kI8RowBytes + kDim) = lo;
-        *reinterpret_cast<i4v*>(rows + (size_t)row * kI8RowBytes + kDim + 16) = hi;
-    }
 }
 
 template <int PASS>

@@ -46,7 +46,7 @@ def test_prefilter_equals_bruteforce_and_oracle(gpu_ctx, oracle, shape, order):
     try:
         out = knn_both_modes(gpu_ctx, imgs[0], imgs[1])
         pp, pe = assert_same(out)
-        assert pp["prefilter_pairs"] == 1 and pp["fallback_pairs"] == 0 and pp["dist_kernel_launches"] == 0
+        assert (pp["prefilter_pairs"], pp["fallback_pairs"], pp["dist_kernel_launches"]) == (1, 0, 0), pp
         assert pe["prefilter_pairs"] == 0 and pe["dist_kernel_launches"] == 1
         # a handful of candidates per row/column, not thousands
         assert pp["candidates"] <= 8 * (n1 + n2)

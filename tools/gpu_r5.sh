@@ -19,5 +19,20 @@ probe)   # what an upload can cost, the block-scaled fp6 instruction, parity of 
     run ab_u8 python tools/ab_multi.py --u8 --images 64 r04=$R04 tree; cat $OUT/ab_u8.txt
     run ab_u8_p1 python tools/ab_multi.py --u8 --images 64 --p1 r04=$R04 tree; cat $OUT/ab_u8_p1.txt
     ;;
+malloc)  # device / page-locked allocation cost by size
+    run ubench_malloc tools/ubench_malloc; cat $OUT/ubench_malloc.txt
+    ;;
+store)   # the rebuilt store: whole GPU suite, fuzz, the bench line's upload figure, the CLI end to end
+    TMO=1500 run pytest_gpu python -m pytest tests -m gpu -x -q; tail -5 $OUT/pytest_gpu.txt
+    run fuzz_routes python tools/fuzz_routes.py 821 400; tail -2 $OUT/fuzz_routes.txt
+    MSFM_Q8=2 run fuzz_routes_q8 python tools/fuzz_routes.py 822 300; tail -2 $OUT/fuzz_routes_q8.txt
+    run fuzz_jobs python tools/fuzz_jobs.py 823 150; tail -2 $OUT/fuzz_jobs.txt
+    run bench python bench.py --u8-images 0 --steps 10 --warmup 3 --sustained-steps 0; python - <<'PY'
+import json
+d=json.loads(open("gpurun_out/r5/store/bench.txt").read().strip().splitlines()[-1])
+print("ms_per_step", round(d["ms_per_step"],3), "upload_ms", round(d["pcie_inclusive"]["upload_ms"],2), "matches", d["config"]["matches_per_step"], "checksum", d["exchange_checksum"], "gpu/cpu", round(d.get("gpu_over_cpu",0)))
+PY
+    run cli_e2e python tools/cli_e2e_bench.py; tail -6 $OUT/cli_e2e.txt
+    ;;
 *) echo "unknown stage $STAGE"; exit 2;;
 esac
