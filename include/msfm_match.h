@@ -212,6 +212,37 @@ int msfm_view_matches(msfm_ctx* ctx, const int32_t** out_qt, const float** out_d
  * instead of staging them through the host.  Complete when the call returns. */
 int msfm_fetch_matches_device(msfm_ctx* ctx, int32_t* d_out_qt, float* d_out_dist);
 
+/* ---- batch of pairs, STREAMING form (bounded memory) ----------------------------------------
+ * msfm_match_pairs keeps the whole call's lists resident (12 bytes per match in HBM and the same page-locked): BASELINE's
+ * largest config produces 6.9e9 matches.  The reference streams by construction -- one transaction per <= 100 pairs,
+ * BruteFeatureMatcher::RunMatching (src/Feature/FeatureMatching.cpp:13, 70-72, 118-139).  Same here:
+ *   msfm_match_pairs_begin   takes the pair list (copied) and the parameters (geometric_verification != 0: the lists are verified
+ *                            on the device as in msfm_match_pairs_verified, `verify` NULL = the reference's constants);
+ *   msfm_match_pairs_next    completes ONE device sub-batch -- the next `n_pairs` pairs of the list, in order -- and hands out its
+ *                            lists: CSR offsets relative to the chunk, (q, t) rows and distances in page-locked host memory AND in
+ *                            device memory (for an RCCL send straight from HBM), the order-certificate counts.  The pointers are valid
+ *                            until the next msfm_match_pairs_next / any other matching call on the context.  n_pairs == 0: done.
+ * Between two calls the library keeps up to three sub-batches in flight exactly as msfm_match_pairs does; what is resident at any time
+ * is the scratch of those (msfm_set_limits) plus their lists.  msfm_get_profile accumulates over the series. */
+typedef struct msfm_chunk {
+    int first_pair;                 /* index into the pair list given to msfm_match_pairs_begin */
+    int n_pairs;                    /* 0: the series is complete */
+    int64_t count;                  /* matches of the chunk = offsets[n_pairs] */
+    const int64_t* offsets;         /* n_pairs + 1 */
+    const int32_t* qt;              /* host (page-locked): 2 * count */
+    const float* dist;              /* host: count */
+    const int32_t* d_qt;            /* device: 2 * count */
+    const float* d_dist;            /* device: count */
+    const int32_t* sensitive_rows;  /* n_pairs (msfm_fetch_order_certificate) */
+} msfm_chunk;
+struct msfm_verify_params;
+int msfm_match_pairs_begin(msfm_ctx* ctx, const int32_t* pairs, int n_pairs, const msfm_match_params* params,
+                           int geometric_verification, const struct msfm_verify_params* verify);
+int msfm_match_pairs_next(msfm_ctx* ctx, msfm_chunk* out);
+/* Plain device -> host copy through the library's own runtime (a caller without a HIP runtime of its own -- a ctypes binding --
+ * reading msfm_chunk::d_qt / d_dist or a buffer msfm_fetch_matches_device filled). */
+int msfm_read_device(msfm_ctx* ctx, void* host_dst, const void* device_src, int64_t bytes);
+
 /* ---- batch of pairs with the geometric verification hand-off -------------------------------
  * Lines 36-60 of FeatureMatching.cpp in one call: matching as above, then FeatureUtils::FilterMatches
  * (src/Feature/FeatureUtils.cpp:176-206: GetAlignedPointsFromMatches + cv::findFundamentalMat(FM_RANSAC,

@@ -26,6 +26,7 @@ EXPORTS = [
     "msfm_topscale_select", "msfm_pair_id", "msfm_pair_from_id", "msfm_swap_image_pair",
     "msfm_version", "msfm_upload_keypoints", "msfm_match_pairs_verified", "msfm_subset_image", "msfm_view_matches", "msfm_set_limits", "msfm_fetch_matches_device",
     "msfm_fetch_order_certificate", "msfm_set_pipeline", "msfm_device_count", "msfm_finalize_store", "msfm_store_info",
+    "msfm_match_pairs_begin", "msfm_match_pairs_next", "msfm_read_device",
 ]
 
 
@@ -50,6 +51,13 @@ class Profile(C.Structure):
                 ("sweep1_i8_launches", C.c_int), ("sweep1_q8_launches", C.c_int), ("sweep1b_launches", C.c_int),
                 ("sweep1b_ms", C.c_double), ("sweep1b_descriptor_pairs", C.c_int64), ("order_sensitive_rows", C.c_int64),
                 ("demoted_pairs", C.c_int), ("mixed_route_sub_batches", C.c_int)]
+
+
+class Chunk(C.Structure):
+    """msfm_chunk: one completed device sub-batch of a streaming series (msfm_match_pairs_begin / _next)."""
+    _fields_ = [("first_pair", C.c_int), ("n_pairs", C.c_int), ("count", C.c_int64), ("offsets", C.POINTER(C.c_int64)),
+                ("qt", C.POINTER(C.c_int32)), ("dist", C.POINTER(C.c_float)), ("d_qt", C.c_void_p), ("d_dist", C.c_void_p),
+                ("sensitive_rows", C.POINTER(C.c_int32))]
 
 
 class MsfmError(RuntimeError):
@@ -90,6 +98,9 @@ def load():
     try:   # (the A/B tools also load older builds of the library: tools/ab_multi.py)
         L.msfm_finalize_store.argtypes = [vp]
         L.msfm_store_info.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+        L.msfm_match_pairs_begin.argtypes = [vp, ip, C.c_int, C.POINTER(MatchParams), C.c_int, C.POINTER(VerifyParams)]
+        L.msfm_match_pairs_next.argtypes = [vp, C.POINTER(Chunk)]
+        L.msfm_read_device.argtypes = [vp, vp, vp, C.c_int64]
     except AttributeError:
         pass
     L.msfm_match_pair.argtypes = [vp, C.c_int, C.c_int, C.c_float, C.c_int, C.c_double, ip, fp, C.POINTER(C.c_int)]
@@ -266,6 +277,35 @@ class Context:
         d = np.empty(max(M, 1), np.float32)
         self._chk(self._L.msfm_fetch_matches(self._h, _ip(qt), _fp(d)))
         return offs, qt[:M], d[:M]
+
+    def match_pairs_stream(self, pairs, ratio=0.8, cross_check=True, max_distance=0.7, verified=False, copy=True):
+        """Generator over the device sub-batches of the job, in pair order (msfm_match_pairs_begin / _next): nothing accumulates in the
+        library.  Yields dicts {first, n_pairs, offsets[n+1] (relative to the chunk), qt[m, 2], dist[m], sensitive[n], d_qt, d_dist
+        (device pointers)}; with copy=False qt / dist / offsets are views, valid until the next item is requested."""
+        pairs = np.ascontiguousarray(np.asarray(pairs, dtype=np.int32).reshape(-1, 2))
+        prm = MatchParams(ratio, int(bool(cross_check)), max_distance)
+        self._chk(self._L.msfm_match_pairs_begin(self._h, _ip(pairs), pairs.shape[0], C.byref(prm), int(bool(verified)), None))
+        ch = Chunk()
+        while True:
+            self._chk(self._L.msfm_match_pairs_next(self._h, C.byref(ch)))
+            n = ch.n_pairs
+            if n == 0:
+                return
+            m = int(ch.count)
+            offs = np.ctypeslib.as_array(ch.offsets, shape=(n + 1,))
+            qt = np.ctypeslib.as_array(ch.qt, shape=(m, 2)) if m else np.zeros((0, 2), np.int32)
+            d = np.ctypeslib.as_array(ch.dist, shape=(m,)) if m else np.zeros(0, np.float32)
+            sens = np.ctypeslib.as_array(ch.sensitive_rows, shape=(n,))
+            if copy:
+                offs, qt, d, sens = offs.copy(), qt.copy(), d.copy(), sens.copy()
+            yield {"first": ch.first_pair, "n_pairs": n, "offsets": offs, "qt": qt, "dist": d, "sensitive": sens,
+                   "d_qt": ch.d_qt, "d_dist": ch.d_dist}
+
+    def read_device(self, dev_ptr, shape, dtype):
+        """A device buffer (raw pointer) as a new NumPy array, copied through the library's own runtime."""
+        out = np.empty(shape, dtype)
+        self._chk(self._L.msfm_read_device(self._h, out.ctypes.data_as(C.c_void_p), C.c_void_p(dev_ptr), out.nbytes))
+        return out
 
     def fetch_matches_device(self, qt_ptr, dist_ptr=None):
         """Copy the last call's lists into caller-owned DEVICE memory on this context's GPU (raw pointers, e.g.

@@ -113,6 +113,71 @@ struct FillSegs {
     int n;
 };
 
+// A second core for the host side of an upload: memcpy into page-locked memory runs at 32 GB/s on one core of this box and at 59 GB/s on
+// two (profiles/r05_ubench_upload.txt) -- and it, not the DMA behind it (38-46 GB/s), is what a bulk load waits for.  The helper takes the
+// upper half of every piece; between the uploads of a burst it spins (a wake-up through the condition variable costs more than the copy
+// of a whole image), after ~100 us without work it sleeps.
+struct CopyHelper {
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::atomic<unsigned> posted{0}, done{0};
+    std::atomic<bool> sleeping{false}, stop{false};
+    char* dst = nullptr;
+    const char* src = nullptr;
+    size_t bytes = 0;
+    void run() {
+        unsigned seen = 0;
+        for (;;) {
+            int spins = 0;
+            while (posted.load(std::memory_order_acquire) == seen && !stop.load(std::memory_order_relaxed)) {
+                if (++spins < 40000) {
+                    __builtin_ia32_pause();
+                    continue;
+                }
+                std::unique_lock<std::mutex> lk(mu);
+                sleeping.store(true);
+                cv.wait(lk, [&] { return posted.load() != seen || stop.load(); });
+                sleeping.store(false);
+                spins = 0;
+            }
+            if (stop.load()) return;
+            seen = posted.load(std::memory_order_acquire);
+            std::memcpy(dst, src, bytes);
+            done.store(seen, std::memory_order_release);
+        }
+    }
+    // dst[0 .. n) = src[0 .. n), the upper half on the helper's core
+    void copy(char* d, const char* s, size_t n) {
+        if (n < ((size_t)256 << 10)) {
+            std::memcpy(d, s, n);
+            return;
+        }
+        if (!th.joinable()) th = std::thread([this] { run(); });
+        const size_t half = (n / 2) & ~(size_t)4095;
+        dst = d + half;
+        src = s + half;
+        bytes = n - half;
+        const unsigned ticket = posted.fetch_add(1, std::memory_order_release) + 1;
+        if (sleeping.load()) {
+            std::lock_guard<std::mutex> lk(mu);
+            cv.notify_one();
+        }
+        std::memcpy(d, s, half);
+        while (done.load(std::memory_order_acquire) != ticket) __builtin_ia32_pause();
+    }
+    ~CopyHelper() {
+        if (th.joinable()) {
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                stop.store(true);
+                cv.notify_one();
+            }
+            th.join();
+        }
+    }
+};
+
 // One image of the descriptor store (msfm_store.hip.h says what is resident and what is derived on demand).
 struct Image {
     int n = -1;  // -1: not uploaded
@@ -172,10 +237,18 @@ struct StoreChunk {
 struct StoreArena {
     std::vector<StoreChunk> chunks;
     int cur = -1;
+    bool recycle = false;   // keep emptied chunks for the next taker instead of freeing them (the inbox: the same few chunks wave after wave)
     // room for `bytes` more in the current chunk, or a new current chunk of max(bytes, min_chunk)
     hipError_t reserve(size_t bytes, size_t min_chunk) {
         bytes += 256;
         if (cur >= 0 && chunks[(size_t)cur].base && chunks[(size_t)cur].used + bytes <= chunks[(size_t)cur].cap) return hipSuccess;
+        if (recycle)
+            for (size_t i = 0; i < chunks.size(); ++i)
+                if (chunks[i].base && chunks[i].live == 0 && chunks[i].cap >= bytes) {
+                    chunks[i].used = 0;
+                    cur = (int)i;
+                    return hipSuccess;
+                }
         if (cur >= 0 && chunks[(size_t)cur].live == 0) free_chunk(cur);   // (an empty current chunk that is too small)
         int slot = -1;
         for (size_t i = 0; i < chunks.size(); ++i)
@@ -217,7 +290,7 @@ struct StoreArena {
         if (chunk < 0) return;
         StoreChunk& c = chunks[(size_t)chunk];
         if (--c.live <= 0) {
-            if (chunk == cur) c.used = 0, c.live = 0;   // the current chunk is kept for the next taker
+            if (chunk == cur || recycle) c.used = 0, c.live = 0;   // the current chunk is kept for the next taker
             else free_chunk(chunk);
         }
         chunk = -1;
@@ -289,6 +362,7 @@ struct Scratch {
     DevBuf d_k_i0, d_k_d0, d_k_d1;
     DevBuf d_st_qt, d_st_d, d_counts, d_offsets, d_sens;
     DevBuf d_sub_qt, d_sub_d;         // the sub-batch's match lists, compact (CSR order), before they join the call's lists
+    PinnedBuf h_sub_qt, h_sub_d;      // streaming form: the same lists in page-locked host memory (msfm_match_pairs_next)
     DevBuf d_fix_count, d_fix_list;
     int fix_cap_eff = 0;              // capacity handed to the kernels of the current batch (0: ties need no fix-up)
     bool keys_epilogue = false;       // the epilogue reads the reduce slots of the exact re-check itself: no pf_finalize_kernel, no kNN arrays
@@ -329,10 +403,14 @@ struct Scratch {
     void release_all() {
         for_each_buf([](DevBuf& b, void*) { b.release(); }, nullptr);
         for (PinnedBuf& h : h_up) h.release();
+        h_sub_qt.release();
+        h_sub_d.release();
         h_summary.release();
         h_tail.release();
     }
 };
+
+struct MatchJob;   // msfm_job.hip.h
 
 struct msfm_ctx {
     int device = 0;
@@ -353,6 +431,8 @@ struct msfm_ctx {
     size_t inbox_waiting = 0;         // bytes of those uploads
     bool store_async = false;         // copies / kernels may be in flight on the store's stream (the other streams of a matching call do not wait for it)
     PinnedBuf up_ring;                // page-locked staging of the uploads: kUpSlots slots of kUpSlotBytes
+    CopyHelper copier;                // second core of the host copy (MSFM_UPLOAD_THREADS=1: off)
+    bool copy_helper = true;
     hipEvent_t up_ev[2] = {nullptr, nullptr};
     bool up_ev_recorded[2] = {false, false};
     unsigned up_seq = 0;
@@ -386,6 +466,7 @@ struct msfm_ctx {
 
     msfm_profile prof = {};
     std::vector<hipEvent_t> ev_pool;
+    MatchJob* job = nullptr;          // the matching call in progress (one at a time; the streaming form keeps it between calls)
 };
 
 #define SC (*ctx->cur)

@@ -211,6 +211,7 @@ inline size_t al256(size_t b) { return (b + 255) & ~(size_t)255; }
 // Everything uploaded since the last call becomes a built image: classification, decisions, ONE allocation, the build kernels.
 int finalize_store(msfm_ctx* ctx) {
     if (ctx->pending.empty()) return MSFM_OK;
+    HostClock hc;   // MSFM_DEBUG_TIMING=1
     HIPCHK(ctx, hipSetDevice(ctx->device));
     hipStream_t st = store_stream(ctx);
     std::vector<int> ids;
@@ -247,6 +248,7 @@ int finalize_store(msfm_ctx* ctx) {
     HIPCHK(ctx, hipGetLastError());
     rc = read_maxima(ctx, P);
     if (rc != MSFM_OK) return rc;
+    hc.lap("store: classify + read-back");
 
     // ---- decisions per image, sizes
     std::vector<char> want_float(P, 0), want_twin(P, 0);
@@ -288,6 +290,7 @@ int finalize_store(msfm_ctx* ctx) {
         if (want_twin[j]) total += al256(npad * kI8RowBytes) + al256(npad * 4) + al256(std::max<size_t>(n, 1) * 4);
     }
     HIPCHK(ctx, ctx->store.reserve(total, 0));
+    hc.lap("store: decisions + allocation");
     std::vector<int> twins;
     for (size_t j = 0; j < P; ++j) {
         Image& im = ctx->images[(size_t)ids[j]];
@@ -342,12 +345,14 @@ int finalize_store(msfm_ctx* ctx) {
     } else {
         HIPCHK(ctx, hipStreamSynchronize(st));   // (the inbox is handed back below; the job table's staging is rewritten by the next caller)
     }
+    hc.lap("store: build kernels + twins");
     for (size_t j = 0; j < P; ++j) {
         Image& im = ctx->images[(size_t)ids[j]];
         im.pending = false;
         im.inbox = nullptr;
         ctx->inbox.drop(im.inbox_chunk);
     }
+    hc.lap("store: inbox handed back");
     return MSFM_OK;
 }
 
@@ -476,8 +481,10 @@ int msfm_upload_image(msfm_ctx* ctx, int image_id, const void* desc, int n, int 
     int rc = begin_pending(ctx, image_id, n, kind, dtype == MSFM_DTYPE_U8, 0, &inbox);
     if (rc != MSFM_OK || n == 0) return rc;
     const char* src = static_cast<const char*>(desc);
-    return stage_h2d(ctx, inbox, (size_t)n * kDim * (kind == kSrcU8 ? 1 : 4),
-                     [src](char* dst, size_t off, size_t piece) { std::memcpy(dst, src + off, piece); });
+    return stage_h2d(ctx, inbox, (size_t)n * kDim * (kind == kSrcU8 ? 1 : 4), [src, ctx](char* dst, size_t off, size_t piece) {
+        if (ctx->copy_helper) ctx->copier.copy(dst, src + off, piece);
+        else std::memcpy(dst, src + off, piece);
+    });
 }
 
 int msfm_finalize_store(msfm_ctx* ctx) {

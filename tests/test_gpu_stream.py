@@ -1,0 +1,99 @@
+"""The streaming form of the C ABI (msfm_match_pairs_begin / _next): one device sub-batch per call, nothing accumulates in the
+library -- the reference streams by construction, one transaction per <= 100 pairs (src/Feature/FeatureMatching.cpp:13, 70-72,
+118-139).  The chunks, concatenated, must be the lists msfm_match_pairs returns, bit for bit, under every cut."""
+import numpy as np
+import pytest
+
+from monocularsfm_amd import _lib, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    a = np.asarray(a)
+    return a.view(np.int32) if a.dtype == np.float32 else a
+
+
+def collect(ctx, pairs, **kw):
+    offs = [np.zeros(1, np.int64)]
+    qt, d, sens = [], [], []
+    nxt = 0
+    chunks = 0
+    for ch in ctx.match_pairs_stream(pairs, **kw):
+        assert ch["first"] == nxt and ch["n_pairs"] > 0      # in pair order, contiguous
+        assert ch["offsets"][0] == 0 and len(ch["offsets"]) == ch["n_pairs"] + 1 and ch["offsets"][-1] == len(ch["qt"]) == len(ch["dist"])
+        offs.append(offs[-1][-1] + ch["offsets"][1:])
+        qt.append(ch["qt"])
+        d.append(ch["dist"])
+        sens.append(ch["sensitive"])
+        nxt += ch["n_pairs"]
+        chunks += 1
+    assert nxt == len(pairs)
+    return np.concatenate(offs), np.concatenate(qt) if qt else np.zeros((0, 2), np.int32), np.concatenate(d) if d else np.zeros(0, np.float32), \
+        np.concatenate(sens) if sens else np.zeros(0, np.int32), chunks
+
+
+@pytest.mark.parametrize("kind", ["rootsift", "u8"])
+def test_stream_equals_one_call_under_forced_cuts(kind):
+    n_img = 12
+    if kind == "rootsift":
+        imgs = synth.rootsift_images(n_img, [1500, 700, 2100, 64, 900, 1300, 0, 1800, 1000, 400, 1600, 1200], seed=77, n_proto=4000)
+        kw = {}
+    else:
+        imgs = synth.u8_images(n_img, [1500, 700, 2100, 64, 900, 1300, 1, 1800, 1000, 400, 1600, 1200], seed=78, dup_frac=0.2, as_float=False)
+        kw = {"max_distance": 1e9}
+    pairs = synth.all_pairs(n_img)
+    with _lib.Context(0) as ctx:
+        for i, im in enumerate(imgs):
+            ctx.upload_image(i, im)
+        ref = ctx.match_pairs(pairs, **kw)
+        cert = ctx.order_certificate(len(pairs))
+        for limit in (0, 7, 1):
+            ctx.set_limits(max_pairs_per_batch=limit)
+            offs, qt, d, sens, chunks = collect(ctx, pairs, **kw)
+            assert np.array_equal(offs, ref[0]) and np.array_equal(qt, ref[1]) and np.array_equal(bits(d), bits(ref[2]))
+            assert np.array_equal(sens, cert)
+            if limit:
+                assert chunks == -(-len(pairs) // limit)
+        ctx.set_limits()
+        # a series left open is abandoned by the next matching call
+        it = ctx.match_pairs_stream(pairs, **kw)
+        next(it)
+        again = ctx.match_pairs(pairs, **kw)
+        assert np.array_equal(again[0], ref[0]) and np.array_equal(again[1], ref[1])
+        with pytest.raises(_lib.MsfmError):
+            next(it)          # its series is gone (state error, not stale data)
+        # an empty pair list: no chunk
+        assert list(ctx.match_pairs_stream(np.zeros((0, 2), np.int32))) == []
+
+
+def test_stream_with_verification_equals_the_verified_call():
+    imgs = synth.rootsift_images(5, [1200, 1100, 900, 1000, 1300], seed=79, n_proto=2500)
+    pairs = synth.all_pairs(5)
+    with _lib.Context(0) as ctx:
+        for i, im in enumerate(imgs):
+            ctx.upload_image(i, im)
+            ctx.upload_keypoints(i, synth.keypoints(len(im), seed=100 + i))
+        ref = ctx.match_pairs_verified(pairs)
+        ctx.set_limits(max_pairs_per_batch=3)
+        offs, qt, d, _, chunks = collect(ctx, pairs, verified=True)
+        assert chunks == 4
+        assert np.array_equal(offs, ref[0]) and np.array_equal(qt, ref[1]) and np.array_equal(bits(d), bits(ref[2]))
+
+
+def test_stream_device_pointers_hold_the_same_lists():
+    imgs = synth.u8_images(4, [2000, 1500, 1800, 900], seed=80, dup_frac=0.3, as_float=False)
+    pairs = synth.all_pairs(4)
+    with _lib.Context(0) as ctx:
+        for i, im in enumerate(imgs):
+            ctx.upload_image(i, im)
+        ctx.set_limits(max_pairs_per_batch=2)
+        seen = 0
+        for ch in ctx.match_pairs_stream(pairs, max_distance=1e9, copy=False):
+            m = len(ch["qt"])
+            if m == 0:
+                continue
+            assert np.array_equal(ctx.read_device(ch["d_qt"], (m, 2), np.int32), ch["qt"])
+            assert np.array_equal(bits(ctx.read_device(ch["d_dist"], (m,), np.float32)), bits(ch["dist"]))
+            seen += m
+        assert seen > 100

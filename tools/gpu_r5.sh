@@ -34,5 +34,8 @@ print("ms_per_step", round(d["ms_per_step"],3), "upload_ms", round(d["pcie_inclu
 PY
     run cli_e2e python tools/cli_e2e_bench.py; tail -6 $OUT/cli_e2e.txt
     ;;
+newtests)   # the tests added in round 5
+    TMO=900 run pytest_new python -m pytest -m gpu -x -q tests/test_gpu_stream.py tests/test_gpu_store.py; tail -15 $OUT/pytest_new.txt
+    ;;
 *) echo "unknown stage $STAGE"; exit 2;;
 esac
