@@ -160,6 +160,61 @@ def cpu_baseline(imgs, pairs, budget_s=20.0, max_pairs=4096, seed=0):
     }
 
 
+def end_to_end(cpu_rate, cpu_single_rate, n_images=128, n_desc=5000):
+    """"wall-clock ... includes DB I/O for the ComputeMatches end-to-end figure; report both".  north_star states its
+    >= 10x target on the ComputeMatches wall clock.  Writes the South-Building-shaped SQLite database (outside every timed region), then
+    runs the drop-in executable `monocularsfm_amd/host/ComputeMatches <yaml>` ONCE, cold -- a fresh process: HIP start-up, context,
+    every allocation, the bulk load, pre-emptive filter, matching, geometric verification on the device, the rows written -- the way a
+    user runs it (reference: sfm/ComputeMatches.cpp:59-65 prints the same wall clock).  The CPU side is an ESTIMATE of the matching
+    alone (no DB I/O, no RANSAC) from this run's cpu_baseline rate: a lower bound of what the reference's CLI would take here."""
+    import re
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    from monocularsfm_amd import synth
+    exe = os.path.join(ROOT, "monocularsfm_amd", "host", "ComputeMatches")
+    if not os.path.exists(exe):
+        return {"error": "monocularsfm_amd/host/ComputeMatches is not built"}
+    tmp = tempfile.mkdtemp(prefix="msfm_bench_e2e_")
+    try:
+        db_path = os.path.join(tmp, "south-building-synth.db")
+        t0 = time.perf_counter()
+        descs, _ = synth.south_building_database(db_path, n_images, n_desc, seed=1234)
+        build_s = time.perf_counter() - t0
+        cfg = os.path.join(tmp, "cfg.yaml")
+        open(cfg, "w").write('%%YAML:1.0\ndatabase_path : "%s"\nSIFTmatch.match_type : 1\n' % db_path)
+        env = dict(os.environ, MSFM_CLI_TIMING="1")
+        t0 = time.perf_counter()
+        r = subprocess.run([exe, cfg], capture_output=True, text=True, env=env, timeout=600)
+        wall = time.perf_counter() - t0
+        if r.returncode != 0:
+            return {"error": "ComputeMatches exited with %d: %s" % (r.returncode, r.stderr[-300:])}
+        phases = {}
+        for name, val in re.findall(r"([a-zA-Z+\- ]+?) ([0-9.]+) s(?: \||$)", (r.stderr.strip().splitlines() or [""])[-1].replace("[msfm timing] ", "")):
+            phases[name.strip()] = float(val)
+        con = sqlite3.connect(db_path)
+        rows, matches = con.execute("SELECT COUNT(*), SUM(rows) FROM matches").fetchone()
+        con.close()
+        n_rows = np.array([len(d) for d in descs], np.int64)
+        pairs = n_images * (n_images - 1) // 2
+        total = int((n_rows.sum() ** 2 - (n_rows ** 2).sum()) // 2)
+        out = {"command": "monocularsfm_amd/host/ComputeMatches <yaml> (brute-force mode, pre-emptive filter and geometric verification on: the reference's defaults)",
+               "wall_s": wall, "cold": True, "phases_s": phases, "phases_sum_s": sum(phases.values()),
+               "db_bytes": os.path.getsize(db_path), "db_build_s_untimed": build_s, "images": n_images, "pairs": pairs,
+               "rows_written": int(rows), "matches_written": int(matches or 0), "descriptor_pairs": total,
+               "file_cache": "warm (the database was written just before the run)",
+               "last_stdout_line": (r.stdout.strip().splitlines() or [""])[-1]}
+        if cpu_rate:
+            out["cpu_port_matching_s_estimate"] = total / cpu_rate
+            out["cpu_port_single_thread_matching_s_estimate"] = total / cpu_single_rate if cpu_single_rate else None
+            out["ratio"] = out["cpu_port_matching_s_estimate"] / wall
+            out["ratio_vs_single_thread"] = (total / cpu_single_rate) / wall if cpu_single_rate else None
+        return out
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -187,6 +242,7 @@ def main():
     ap.add_argument("--sustained-steps", type=int, default=200,
                     help="extra untimed-for-`value` run of this many steps after the K timed ones -> sustained_ms_per_step "
                          "(the part's clock is set by a power budget: a 1 s burst and a 10 s run differ); 0 = skip")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the cold end-to-end run of the ComputeMatches executable (end_to_end)")
     ap.add_argument("--no-solo", action="store_true",
                     help="skip the 4 extra steps with the pipeline off that measure the sweeps alone (roofline.solo); for kernel traces")
     args = ap.parse_args()
@@ -244,6 +300,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    ranks_seen = None
+    if multi:   # every rank of the process group answers: an all_reduce of ones over the exchange backend (RCCL when --backend nccl)
+        one = torch.ones(1, dtype=torch.int32, device=coll_dev)
+        dist.all_reduce(one, op=dist.ReduceOp.SUM)
+        ranks_seen = int(one.cpu()[0])
     ctx = _lib.Context(local_rank, order=args.order)
     if args.no_prefilter:
         ctx.set_prefilter(False)
@@ -381,6 +442,9 @@ def main():
         # the step is cut into sub-batches (two equal ones for this job) launched on separate streams: the bandwidth-bound tail of
         # one runs beside the sweeps of the next (msfm_set_pipeline / MSFM_PIPELINE; 1 = one launch per sweep, no overlap)
         "pipeline_env": os.environ.get("MSFM_PIPELINE"),
+        # ranks that answered an all_reduce over the exchange backend before the job started (None at N = 1 without --force-collectives)
+        "rccl_ranks_seen" if args.backend == "nccl" else "gloo_ranks_seen": ranks_seen,
+        "exchange_backend": args.backend if multi else None,
     }
     pf_ms, pf_launches = acc["approx_kernel_ms"], acc["approx_kernel_launches"]
     if pf_launches > 0:
@@ -467,7 +531,23 @@ def main():
         full = args.u8_images >= 1329
         n_img = min(args.u8_images, 1329)
         t_gen = time.perf_counter()
-        u_imgs, u_pairs, u_name = synth.job("synthetic-u8", n_img, 8192, seed=1329)
+        if world > 1:
+            # N ranks: the set is generated ONCE (rank 0; 13 s for the full config, and the ranks share a 16-CPU cgroup) and reaches the
+            # others through a file under $TMPDIR, read back memory-mapped
+            import tempfile
+            cache = os.path.join(tempfile.gettempdir(), "msfm_u8_%dx8192_seed1329.npy" % n_img)
+            if rank == 0 and not os.path.exists(cache):
+                u_imgs, u_pairs, u_name = synth.job("synthetic-u8", n_img, 8192, seed=1329)
+                tmp_path = cache + ".%d.tmp.npy" % os.getpid()
+                np.save(tmp_path, np.stack(u_imgs))
+                os.replace(tmp_path, cache)
+            dist.barrier()
+            stack = np.load(cache, mmap_mode="r")
+            u_imgs = [stack[i] for i in range(n_img)]
+            u_pairs = synth.all_pairs(n_img)
+            u_name = "synthetic u8 descriptors: %d images x 8192 desc, brute-force all pairs" % n_img
+        else:
+            u_imgs, u_pairs, u_name = synth.job("synthetic-u8", n_img, 8192, seed=1329)
         gen_s = time.perf_counter() - t_gen
         u_acc = {"approx_kernel_ms": 0.0, "prefilter_descriptor_pairs": 0, "sweep1_i8_launches": 0, "sub_batches": 0,
                  "approx_kernel_launches": 0, "order_sensitive_rows": 0, "candidates": 0}
@@ -519,6 +599,13 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(imgs, pairs, budget_s=args.cpu_budget)
         out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+    if rank == 0 and world == 1 and not args.no_e2e and args.workload == "south-building":
+        ctx.clear_images()   # (the executable is a process of its own: this one's store is not in its way)
+        cb = out.get("cpu_baseline", {})
+        try:
+            out["end_to_end"] = end_to_end(cb.get("value"), cb.get("single_thread_value"), n_images=args.images or 128)
+        except Exception as e:  # noqa: BLE001  (a failure here must not take the headline line with it)
+            out["end_to_end"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if rank == 0:
         print(json.dumps(out), flush=True)
     ctx.close()

@@ -108,3 +108,27 @@ def job(workload="south-building", n_images=None, n_desc=None, seed=1234):
     else:
         raise ValueError("unknown workload " + workload)
     return imgs, all_pairs(n_images), name
+
+
+def south_building_database(path, n_images=128, n_desc=5000, seed=1234):
+    """A South-Building-shaped SQLite database as FeatureExtraction would leave it (BASELINE configs[1]; SURVEY.md 8(d): synthetic
+    when the dataset is unavailable): n_images x ~n_desc float32 RootSIFT-like descriptors + keypoints, written through the build's
+    Database twin.  A shared pool of "landmarks" carried by the largest keypoints makes the reference's pre-emptive test (top-100
+    scales, >= 4 cross-matches; src/Feature/FeatureMatching.cpp:148-179) keep the pairs, as it does on real overlapping photographs.
+    -> (descriptors, keypoints)"""
+    from . import database
+    rng = np.random.default_rng(seed)
+    counts = rng.integers(int(n_desc * 0.92), int(n_desc * 1.08) + 1, n_images)
+    descs = rootsift_images(n_images, counts.tolist(), seed=seed, n_proto=20000)
+    kps = [keypoints(len(d), seed=50 + i) for i, d in enumerate(descs)]
+    pool = descs[0][:120].copy()
+    for i in range(n_images):
+        k = min(80, len(descs[i]))
+        pick = rng.choice(120, k, replace=False)
+        rows = rng.choice(len(descs[i]), k, replace=False)
+        v = np.abs(pool[pick] * (1 + 0.03 * rng.standard_normal((k, 128)).astype(F32)))
+        descs[i][rows] = v / np.linalg.norm(v, axis=1, keepdims=True)
+        kps[i][rows, 2] = 100 + rng.uniform(0, 50, k).astype(F32)
+    database.write_synthetic_database(path, descs, kps)
+    return descs, kps
+

@@ -52,6 +52,15 @@ def test_bench_line_contract():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in cb, k
     assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0
+    # SURVEY 8(d) "report both": the cold end-to-end run of the drop-in executable next to the kernel figure
+    e2e = d["end_to_end"]
+    assert "error" not in e2e, e2e
+    for k in ("wall_s", "phases_s", "db_bytes", "pairs", "rows_written", "cold", "cpu_port_matching_s_estimate", "ratio"):
+        assert k in e2e, k
+    assert e2e["cold"] is True and e2e["pairs"] == 24 * 23 // 2 and 0 < e2e["rows_written"] <= e2e["pairs"]
+    assert e2e["wall_s"] > 0 and 0 < e2e["phases_sum_s"] <= e2e["wall_s"] and "device match + fetch" in e2e["phases_s"]
+    assert abs(e2e["ratio"] - e2e["cpu_port_matching_s_estimate"] / e2e["wall_s"]) < 1e-9
+    assert d["pcie_inclusive"]["upload_ms"] > 0
 
 
 def test_bench_two_ranks_sharing_the_gpu():

@@ -10,22 +10,11 @@ from monocularsfm_amd import database, synth
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 5000
 rng = np.random.default_rng(1234)
-counts = rng.integers(int(n * 0.92), int(n * 1.08) + 1, N)
 t0 = time.time()
-descs = synth.rootsift_images(N, counts.tolist(), seed=1234, n_proto=20000)
-kps = [synth.keypoints(len(d), seed=50 + i) for i, d in enumerate(descs)]
-# landmarks carried by the largest keypoints so that the reference's pre-emptive test (top-100 scales, >= 4
-# cross-matches) keeps the pairs, as it does on real overlapping photographs
-pool = descs[0][:120].copy()
-for i in range(N):
-    pick = rng.choice(120, 80, replace=False)
-    rows = rng.choice(len(descs[i]), 80, replace=False)
-    v = np.abs(pool[pick] * (1 + 0.03 * rng.standard_normal((80, 128)).astype(np.float32)))
-    descs[i][rows] = v / np.linalg.norm(v, axis=1, keepdims=True)
-    kps[i][rows, 2] = 100 + rng.uniform(0, 50, 80).astype(np.float32)
 tmp = tempfile.mkdtemp(prefix="msfm_e2e_")
 db_path = os.path.join(tmp, "south-building-synth.db")
-database.write_synthetic_database(db_path, descs, kps)
+descs, kps = synth.south_building_database(db_path, N, n, seed=1234)
+counts = np.array([len(d) for d in descs])
 cfg = os.path.join(tmp, "cfg.yaml")
 open(cfg, "w").write('%%YAML:1.0\ndatabase_path : "%s"\nSIFTmatch.match_type : 1\n' % db_path)
 print("dataset: %d images, %d descriptors, db %.0f MB, built in %.1f s" % (N, int(counts.sum()), os.path.getsize(db_path) / 1e6, time.time() - t0))

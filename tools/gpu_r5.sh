@@ -37,5 +37,8 @@ PY
 newtests)   # the tests added in round 5
     TMO=900 run pytest_new python -m pytest -m gpu -x -q tests/test_gpu_stream.py tests/test_gpu_store.py; tail -15 $OUT/pytest_new.txt
     ;;
+contract)   # bench.py's contract tests (end_to_end block included) + the two-rank flows
+    TMO=1500 run pytest_contract python -m pytest -m gpu -x -q tests/test_bench_contract.py tests/test_gpu_exchange.py; tail -15 $OUT/pytest_contract.txt
+    ;;
 *) echo "unknown stage $STAGE"; exit 2;;
 esac
