@@ -252,16 +252,15 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # plain `python bench.py --gpus N`: become the launcher -- one rank per GPU under torch.distributed.run, rank 0's JSON line
         # (the only thing the ranks print on stdout) passes through, the job's exit code is ours
-        import socket
         import subprocess
-        with socket.socket() as sk:
-            sk.bind(("127.0.0.1", 0))
-            port = sk.getsockname()[1]
-        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        # --standalone: torchrun's own rendezvous picks a free port itself (binding a socket, closing it and handing the
+        # number on left a window for another process to take the port); 127.0.0.1: the container's hostname may not resolve
+        env = dict(os.environ)
+        env.pop("MASTER_PORT", None)
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         env.setdefault("OMP_NUM_THREADS", "2")
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
-               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+               "--nproc-per-node", str(args.gpus), os.path.abspath(__file__)] + sys.argv[1:]
         # (the ranks print one thing on stdout -- rank 0's JSON line -- but libraries under them may not keep to that: gloo
         # announces its connections there; anything that is not the line goes to stderr)
         proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)

@@ -239,6 +239,15 @@ struct msfm_verify_params;
 int msfm_match_pairs_begin(msfm_ctx* ctx, const int32_t* pairs, int n_pairs, const msfm_match_params* params,
                            int geometric_verification, const struct msfm_verify_params* verify);
 int msfm_match_pairs_next(msfm_ctx* ctx, msfm_chunk* out);
+/* What the context holds right now, in bytes: the descriptor store, uploads waiting in the inbox, the scratch of the sub-batches in
+ * flight (grow-only: its high-water mark), the call-wide result lists on the device (msfm_match_pairs; the streaming form has none),
+ * page-locked host memory (result lists, staging); and the device's free / total memory (hipMemGetInfo). */
+typedef struct msfm_memory {
+    int64_t device_free, device_total;
+    int64_t store, inbox, scratch, results_device;
+    int64_t page_locked_host;
+} msfm_memory;
+int msfm_memory_info(msfm_ctx* ctx, msfm_memory* out);
 /* Plain device -> host copy through the library's own runtime (a caller without a HIP runtime of its own -- a ctypes binding --
  * reading msfm_chunk::d_qt / d_dist or a buffer msfm_fetch_matches_device filled). */
 int msfm_read_device(msfm_ctx* ctx, void* host_dst, const void* device_src, int64_t bytes);

@@ -26,7 +26,7 @@ EXPORTS = [
     "msfm_topscale_select", "msfm_pair_id", "msfm_pair_from_id", "msfm_swap_image_pair",
     "msfm_version", "msfm_upload_keypoints", "msfm_match_pairs_verified", "msfm_subset_image", "msfm_view_matches", "msfm_set_limits", "msfm_fetch_matches_device",
     "msfm_fetch_order_certificate", "msfm_set_pipeline", "msfm_device_count", "msfm_finalize_store", "msfm_store_info",
-    "msfm_match_pairs_begin", "msfm_match_pairs_next", "msfm_read_device",
+    "msfm_match_pairs_begin", "msfm_match_pairs_next", "msfm_read_device", "msfm_memory_info",
 ]
 
 
@@ -58,6 +58,10 @@ class Chunk(C.Structure):
     _fields_ = [("first_pair", C.c_int), ("n_pairs", C.c_int), ("count", C.c_int64), ("offsets", C.POINTER(C.c_int64)),
                 ("qt", C.POINTER(C.c_int32)), ("dist", C.POINTER(C.c_float)), ("d_qt", C.c_void_p), ("d_dist", C.c_void_p),
                 ("sensitive_rows", C.POINTER(C.c_int32))]
+
+
+class Memory(C.Structure):
+    _fields_ = [(k, C.c_int64) for k in ("device_free", "device_total", "store", "inbox", "scratch", "results_device", "page_locked_host")]
 
 
 class MsfmError(RuntimeError):
@@ -101,6 +105,7 @@ def load():
         L.msfm_match_pairs_begin.argtypes = [vp, ip, C.c_int, C.POINTER(MatchParams), C.c_int, C.POINTER(VerifyParams)]
         L.msfm_match_pairs_next.argtypes = [vp, C.POINTER(Chunk)]
         L.msfm_read_device.argtypes = [vp, vp, vp, C.c_int64]
+        L.msfm_memory_info.argtypes = [vp, C.POINTER(Memory)]
     except AttributeError:
         pass
     L.msfm_match_pair.argtypes = [vp, C.c_int, C.c_int, C.c_float, C.c_int, C.c_double, ip, fp, C.POINTER(C.c_int)]
@@ -300,6 +305,12 @@ class Context:
                 offs, qt, d, sens = offs.copy(), qt.copy(), d.copy(), sens.copy()
             yield {"first": ch.first_pair, "n_pairs": n, "offsets": offs, "qt": qt, "dist": d, "sensitive": sens,
                    "d_qt": ch.d_qt, "d_dist": ch.d_dist}
+
+    def memory_info(self):
+        """Bytes the context holds (store, inbox, scratch, result lists, page-locked host) + the device's free / total memory."""
+        m = Memory()
+        self._chk(self._L.msfm_memory_info(self._h, C.byref(m)))
+        return {k: getattr(m, k) for k, _ in Memory._fields_}
 
     def read_device(self, dev_ptr, shape, dtype):
         """A device buffer (raw pointer) as a new NumPy array, copied through the library's own runtime."""

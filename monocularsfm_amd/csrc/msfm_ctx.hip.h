@@ -3,16 +3,53 @@
 #pragma once
 namespace {
 
+// MSFM_DEBUG_TIMING=1: what the allocations of a call cost the host (printed at the end of every matching call)
+struct AllocClock {
+    double dev_ms = 0, pin_ms = 0, free_ms = 0;
+    long long dev_bytes = 0, pin_bytes = 0;
+    int dev_n = 0, pin_n = 0, free_n = 0;
+    static double now() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+};
+inline AllocClock& alloc_clock() {
+    static AllocClock c;
+    return c;
+}
+inline hipError_t timed_malloc(void** p, size_t bytes) {
+    const double t0 = AllocClock::now();
+    const hipError_t e = hipMalloc(p, bytes);
+    AllocClock& c = alloc_clock();
+    c.dev_ms += AllocClock::now() - t0;
+    c.dev_bytes += (long long)bytes;
+    c.dev_n += 1;
+    return e;
+}
+inline void timed_free(void* p) {
+    const double t0 = AllocClock::now();
+    (void)hipFree(p);
+    AllocClock& c = alloc_clock();
+    c.free_ms += AllocClock::now() - t0;
+    c.free_n += 1;
+}
+inline hipError_t timed_host_malloc(void** p, size_t bytes) {
+    const double t0 = AllocClock::now();
+    const hipError_t e = hipHostMalloc(p, bytes, hipHostMallocDefault);
+    AllocClock& c = alloc_clock();
+    c.pin_ms += AllocClock::now() - t0;
+    c.pin_bytes += (long long)bytes;
+    c.pin_n += 1;
+    return e;
+}
+
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
     hipError_t ensure(size_t bytes) {
         if (bytes <= cap) return hipSuccess;
-        if (p) (void)hipFree(p);
+        if (p) timed_free(p);
         p = nullptr;
         cap = 0;
         size_t want = bytes + bytes / 4 + 256;
-        hipError_t e = hipMalloc(&p, want);
+        hipError_t e = timed_malloc(&p, want);
         if (e == hipSuccess) cap = want;
         return e;
     }
@@ -21,7 +58,7 @@ struct DevBuf {
         if (bytes <= cap) return hipSuccess;
         const size_t want = std::max(bytes + bytes / 2 + 4096, hint);
         void* q = nullptr;
-        hipError_t e = hipMalloc(&q, want);
+        hipError_t e = timed_malloc(&q, want);
         if (e != hipSuccess) return e;
         if (p && keep) {
             e = hipMemcpyAsync(q, p, keep, hipMemcpyDeviceToDevice, stream);
@@ -52,7 +89,7 @@ struct PinnedBuf {
         if (bytes <= cap) return hipSuccess;
         size_t want = std::max(bytes + bytes / 2 + 4096, hint);
         void* q = nullptr;
-        hipError_t e = hipHostMalloc(&q, want, hipHostMallocDefault);
+        hipError_t e = timed_host_malloc(&q, want);
         if (e != hipSuccess) return e;
         if (p && keep) std::memcpy(q, p, keep);
         if (p) (void)hipHostFree(p);
@@ -66,6 +103,72 @@ struct PinnedBuf {
         cap = 0;
     }
     template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+// The call-wide result lists on the host: ONE contiguous range of address space, page-locked piece by piece as the lists grow.
+// Round 4 kept them in one hipHostMalloc block, re-allocated "once or twice" per call: page-locking costs 0.2 ms per MiB on this part
+// (profiles/r05_ubench_malloc.txt) -- 0.9 s for config 4's 4.3 GB, all of it with the GPU idle behind the two sub-batches in flight
+// (the first call of a process: 8.9 s against 8.0 s warm).  Now the range is reserved up front (address space only: an upper bound of
+// the job's matches) and a completed sub-batch page-locks just the 32-MiB pieces its lists reach into -- a few ms, while the next
+// sub-batches run.  The range never moves: msfm_view_matches' pointers stay valid, nothing waits for a copy of the lists.
+struct GrowPinned {
+    char* base = nullptr;
+    size_t reserved = 0, pinned = 0;   // [0, pinned) is page-locked
+    static constexpr size_t kPiece = (size_t)32 << 20;
+    hipError_t reserve(size_t bytes) {
+        bytes = (bytes + kPiece - 1) / kPiece * kPiece;
+        if (bytes <= reserved) return hipSuccess;
+        release();
+        void* p = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+        if (p == MAP_FAILED) return hipErrorOutOfMemory;
+        base = static_cast<char*>(p);
+        reserved = bytes;
+        pinned = 0;
+        return hipSuccess;
+    }
+    hipError_t ensure_pinned(size_t upto) {
+        if (upto > reserved) return hipErrorOutOfMemory;
+        while (pinned < upto) {
+            const double t0 = AllocClock::now();
+            const hipError_t e = hipHostRegister(base + pinned, kPiece, hipHostRegisterDefault);
+            AllocClock& c = alloc_clock();
+            c.pin_ms += AllocClock::now() - t0;
+            c.pin_bytes += (long long)kPiece;
+            c.pin_n += 1;
+            if (e != hipSuccess) return e;
+            pinned += kPiece;
+        }
+        return hipSuccess;
+    }
+    // device -> this range at byte offset `off`, asynchronous: one copy per registered piece it touches (a copy may not straddle two
+    // registrations)
+    hipError_t copy_in(size_t off, const void* dev, size_t bytes, hipStream_t stream) {
+        const char* s = static_cast<const char*>(dev);
+        while (bytes) {
+            const size_t n = std::min(bytes, kPiece - off % kPiece);
+            const hipError_t e = hipMemcpyAsync(base + off, s, n, hipMemcpyDeviceToHost, stream);
+            if (e != hipSuccess) return e;
+            off += n;
+            s += n;
+            bytes -= n;
+        }
+        return hipSuccess;
+    }
+    void release() {
+        for (size_t off = 0; off < pinned; off += kPiece) (void)hipHostUnregister(base + off);
+        if (base) munmap(base, reserved);
+        base = nullptr;
+        reserved = pinned = 0;
+    }
+    template <typename T> T* as() const { return reinterpret_cast<T*>(base); }
+};
+
+// The call-wide result lists on the device (msfm_fetch_matches_device): SEGMENTS, a sub-batch's lists whole in one of them, none ever
+// moved or freed during a call (round 4: one buffer, grown by allocate + copy + hipFree behind a drain of every stream -- the hipFree
+// alone waited 20-70 ms for the sub-batches in flight).  Kept between calls.
+struct OutSeg {
+    DevBuf qt, d;
+    size_t cap = 0, first = 0, count = 0;   // entries; `first` = index of its first match in the call's lists
 };
 
 // a table inside an upload arena (Scratch::d_up): not owned, set by UploadPlan::place
@@ -259,7 +362,7 @@ struct StoreArena {
         }
         StoreChunk& c = chunks[(size_t)slot];
         const size_t want = std::max(bytes, min_chunk);
-        hipError_t e = hipMalloc((void**)&c.base, want);
+        hipError_t e = timed_malloc((void**)&c.base, want);
         if (e != hipSuccess) {
             c.base = nullptr;
             return e;
@@ -440,7 +543,8 @@ struct msfm_ctx {
     PinnedBuf h_jobs, h_store_maxima;
     hipEvent_t jobs_ev = nullptr;     // behind the last copy out of h_jobs
     size_t store_peak_bytes = 0;      // largest store.bytes() seen (msfm_store_info)
-    DevBuf d_out_qt, d_out_d;         // the match lists of the whole call (msfm_fetch_matches_device)
+    std::vector<OutSeg> out_segs;     // the match lists of the whole call on the device (msfm_fetch_matches_device)
+    size_t out_used = 0;              // segments holding lists of the current call
     int fix_cap = 1 << 16;            // entries of the sqrt-space tie queue; grows on overflow (the sub-batch is re-run)
     // sub-batch limits of msfm_match_pairs (msfm_set_limits / MSFM_MAX_PAIRS_PER_BATCH / MSFM_SCRATCH_MIB)
     int max_pairs_per_batch = kDefaultMaxPairsPerBatch;
@@ -461,7 +565,7 @@ struct msfm_ctx {
     bool have_results = false;
     std::vector<int64_t> res_offsets;
     std::vector<int32_t> res_sens;   // per pair: rows / columns without an order-invariance certificate
-    PinnedBuf res_qt, res_dist;  // (q, t) int32 pairs and distances of res_count matches
+    GrowPinned res_qt, res_dist;  // (q, t) int32 pairs and distances of res_count matches
     size_t res_count = 0;
 
     msfm_profile prof = {};

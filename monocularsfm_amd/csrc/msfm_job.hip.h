@@ -83,6 +83,21 @@ struct MatchJob {
     ctx->res_sens.assign((size_t)n_pairs, 0);
     ctx->res_count = 0;
     ctx->prof = msfm_profile{};
+    ctx->out_used = 0;
+    for (OutSeg& s : ctx->out_segs) s.count = 0;
+    if (!streaming) {
+        // address space for the host lists: a pair yields at most min(n1, n2) matches (each query row one, each train row once under the
+        // cross-check; without it n1)
+        long long bound = 1;
+        for (int k = 0; k < n_pairs; ++k) {
+            const int i = pairs[2 * k], j = pairs[2 * k + 1];
+            if (i < 0 || i >= kSlots || j < 0 || j >= kSlots) return fail(ctx, MSFM_E_INVALID, "image id out of range");
+            const long long n1 = ctx->images[(size_t)i].n, n2 = ctx->images[(size_t)j].n;
+            if (n1 > 0 && n2 > 0) bound += prm.cross_check ? std::min(n1, n2) : n1;
+        }
+        if (ctx->res_qt.reserve((size_t)bound * 8) != hipSuccess || ctx->res_dist.reserve((size_t)bound * 4) != hipSuccess)
+            return fail(ctx, MSFM_E_DEVICE, "cannot reserve address space for the result lists");
+    }
 
     ev_begin = get_event(ctx, 0), ev_end = get_event(ctx, 1);
     if (!ev_begin || !ev_end) return fail(ctx, MSFM_E_DEVICE, "hipEventCreate failed");
@@ -315,24 +330,35 @@ struct MatchJob {
             for (size_t p = 0; p < P; ++p) SC.prof.order_sensitive_rows += sens[p];
             ctx->res_count += (size_t)total;   // (matches of the job so far)
         } else {
-            // the call's lists: grown with the end of the call in mind (matches per pair so far x pairs to come), so that a call
-            // of a hundred sub-batches re-allocates -- and re-pins gigabytes of host memory -- once or twice, not a dozen times
+            // the call's lists: the host range page-locks the pieces this sub-batch reaches into (GrowPinned), the device side takes a
+            // segment with room for the whole sub-batch -- nothing moves, nothing is freed, no stream is drained
             const size_t need = base + (size_t)total + 1;
-            if (need * 8 > ctx->res_qt.cap || need * 4 > ctx->res_dist.cap || need * 8 > ctx->d_out_qt.cap || need * 4 > ctx->d_out_d.cap) {
-                rc = drain_streams(ctx);   // copies of earlier sub-batches may still be writing into the buffers that move
-                if (rc != MSFM_OK) return rc;
-                const double per_pair = (double)(base + (size_t)total) / (double)std::max(1, w.end);
-                const size_t hint = (size_t)(per_pair * (double)n_pairs * 1.08) + 4096;
-                HIPCHK(ctx, ctx->res_qt.ensure(need * 8, base * 8, hint * 8));
-                HIPCHK(ctx, ctx->res_dist.ensure(need * 4, base * 4, hint * 4));
-                HIPCHK(ctx, ctx->d_out_qt.ensure_keep(need * sizeof(int2), base * sizeof(int2), SC.stream, hint * sizeof(int2)));
-                HIPCHK(ctx, ctx->d_out_d.ensure_keep(need * 4, base * 4, SC.stream, hint * 4));
-            }
+            if (ctx->res_qt.ensure_pinned(need * 8) != hipSuccess || ctx->res_dist.ensure_pinned(need * 4) != hipSuccess)
+                return fail(ctx, MSFM_E_DEVICE, "cannot page-lock the result lists");
             if (total > 0) {
-                HIPCHK(ctx, hipMemcpyAsync(ctx->res_qt.as<int32_t>() + 2 * base, SC.d_sub_qt.p, (size_t)total * 8, hipMemcpyDeviceToHost, SC.stream));
-                HIPCHK(ctx, hipMemcpyAsync(ctx->res_dist.as<float>() + base, SC.d_sub_d.p, (size_t)total * 4, hipMemcpyDeviceToHost, SC.stream));
-                HIPCHK(ctx, hipMemcpyAsync(ctx->d_out_qt.as<int2>() + base, SC.d_sub_qt.p, (size_t)total * 8, hipMemcpyDeviceToDevice, SC.stream));
-                HIPCHK(ctx, hipMemcpyAsync(ctx->d_out_d.as<float>() + base, SC.d_sub_d.p, (size_t)total * 4, hipMemcpyDeviceToDevice, SC.stream));
+                OutSeg* seg = ctx->out_used ? &ctx->out_segs[ctx->out_used - 1] : nullptr;
+                if (!seg || seg->cap - seg->count < (size_t)total) {
+                    // the next kept segment that is large enough, or a new one sized for ~8 sub-batches like this
+                    while (true) {
+                        if (ctx->out_used == ctx->out_segs.size()) {
+                            ctx->out_segs.push_back(OutSeg{});
+                            OutSeg& s = ctx->out_segs.back();
+                            const size_t cap = std::max<size_t>((size_t)total * 8, (size_t)4 << 20);
+                            HIPCHK(ctx, s.qt.ensure(cap * 8));
+                            HIPCHK(ctx, s.d.ensure(cap * 4));
+                            s.cap = cap;
+                        }
+                        seg = &ctx->out_segs[ctx->out_used++];
+                        seg->first = base;
+                        seg->count = 0;
+                        if (seg->cap >= (size_t)total) break;
+                    }
+                }
+                HIPCHK(ctx, ctx->res_qt.copy_in(base * 8, SC.d_sub_qt.p, (size_t)total * 8, SC.stream));
+                HIPCHK(ctx, ctx->res_dist.copy_in(base * 4, SC.d_sub_d.p, (size_t)total * 4, SC.stream));
+                HIPCHK(ctx, hipMemcpyAsync(seg->qt.as<int2>() + seg->count, SC.d_sub_qt.p, (size_t)total * 8, hipMemcpyDeviceToDevice, SC.stream));
+                HIPCHK(ctx, hipMemcpyAsync(seg->d.as<float>() + seg->count, SC.d_sub_d.p, (size_t)total * 4, hipMemcpyDeviceToDevice, SC.stream));
+                seg->count += (size_t)total;
             }
             ctx->res_count = base + (size_t)total;
             for (size_t p = 0; p < P; ++p) {
@@ -418,6 +444,12 @@ struct MatchJob {
         HIPCHK(ctx, hipEventElapsedTime(&ms, ev_begin, ev_end));
         ctx->prof.total_device_ms = ms;
         open = false;
+        if (std::getenv("MSFM_DEBUG_TIMING")) {
+            AllocClock& c = alloc_clock();
+            std::fprintf(stderr, "[msfm alloc] since the last report: %d hipMalloc %.1f ms (%.2f GiB), %d hipFree %.1f ms, %d hipHostMalloc %.1f ms (%.2f GiB)\n",
+                         c.dev_n, c.dev_ms, c.dev_bytes / 1073741824.0, c.free_n, c.free_ms, c.pin_n, c.pin_ms, c.pin_bytes / 1073741824.0);
+            c = AllocClock{};
+        }
         return MSFM_OK;
     }
 };

@@ -12,6 +12,8 @@
 #include "msfm_prefilter.hip.h"
 #include "msfm_verify.hip.h"
 
+#include <sys/mman.h>
+
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -166,8 +168,12 @@ void msfm_destroy(msfm_ctx* ctx) {
     ctx->store.release_all();
     ctx->inbox.release_all();
     for (Scratch& sc : ctx->sc) sc.release_all();
-    DevBuf* bufs[] = {&ctx->d_jobs, &ctx->d_store_maxima, &ctx->d_zero_row, &ctx->d_out_qt, &ctx->d_out_d};
+    DevBuf* bufs[] = {&ctx->d_jobs, &ctx->d_store_maxima, &ctx->d_zero_row};
     for (DevBuf* b : bufs) b->release();
+    for (OutSeg& s : ctx->out_segs) {
+        s.qt.release();
+        s.d.release();
+    }
     ctx->res_qt.release();
     ctx->res_dist.release();
     ctx->up_ring.release();
@@ -376,8 +382,8 @@ int msfm_match_pairs_next(msfm_ctx* ctx, msfm_chunk* out) {
 int msfm_fetch_matches(msfm_ctx* ctx, int32_t* out_qt, float* out_dist) {
     if (!ctx) return MSFM_E_INVALID;
     if (!ctx->have_results) return fail(ctx, MSFM_E_STATE, "msfm_fetch_matches without a completed msfm_match_pairs");
-    if (out_qt && ctx->res_count) std::memcpy(out_qt, ctx->res_qt.p, ctx->res_count * 8);
-    if (out_dist && ctx->res_count) std::memcpy(out_dist, ctx->res_dist.p, ctx->res_count * 4);
+    if (out_qt && ctx->res_count) std::memcpy(out_qt, ctx->res_qt.base, ctx->res_count * 8);
+    if (out_dist && ctx->res_count) std::memcpy(out_dist, ctx->res_dist.base, ctx->res_count * 4);
     return MSFM_OK;
 }
 
@@ -385,11 +391,36 @@ int msfm_fetch_matches_device(msfm_ctx* ctx, int32_t* d_out_qt, float* d_out_dis
     if (!ctx) return MSFM_E_INVALID;
     if (!ctx->have_results) return fail(ctx, MSFM_E_STATE, "msfm_fetch_matches_device without a completed msfm_match_pairs");
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    if (d_out_qt && ctx->res_count)
-        HIPCHK(ctx, hipMemcpyAsync(d_out_qt, ctx->d_out_qt.p, ctx->res_count * 8, hipMemcpyDeviceToDevice, SC.stream));
-    if (d_out_dist && ctx->res_count)
-        HIPCHK(ctx, hipMemcpyAsync(d_out_dist, ctx->d_out_d.p, ctx->res_count * 4, hipMemcpyDeviceToDevice, SC.stream));
+    for (size_t k = 0; k < ctx->out_used; ++k) {
+        const OutSeg& s = ctx->out_segs[k];
+        if (!s.count) continue;
+        if (d_out_qt) HIPCHK(ctx, hipMemcpyAsync(d_out_qt + 2 * s.first, s.qt.p, s.count * 8, hipMemcpyDeviceToDevice, SC.stream));
+        if (d_out_dist) HIPCHK(ctx, hipMemcpyAsync(d_out_dist + s.first, s.d.p, s.count * 4, hipMemcpyDeviceToDevice, SC.stream));
+    }
     HIPCHK(ctx, hipStreamSynchronize(SC.stream));
+    return MSFM_OK;
+}
+
+int msfm_memory_info(msfm_ctx* ctx, msfm_memory* out) {
+    if (!ctx || !out) return MSFM_E_INVALID;
+    *out = msfm_memory{};
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    size_t free_b = 0, total_b = 0;
+    HIPCHK(ctx, hipMemGetInfo(&free_b, &total_b));
+    out->device_free = (int64_t)free_b;
+    out->device_total = (int64_t)total_b;
+    out->store = (int64_t)ctx->store.bytes();
+    out->inbox = (int64_t)ctx->inbox.bytes();
+    size_t pinned = ctx->up_ring.cap + ctx->h_jobs.cap + ctx->h_store_maxima.cap + ctx->res_qt.pinned + ctx->res_dist.pinned;
+    long long scratch = 0;
+    for (Scratch& sc : ctx->sc) {
+        scratch += sc.device_bytes();
+        for (const PinnedBuf& h : sc.h_up) pinned += h.cap;
+        pinned += sc.h_summary.cap + sc.h_tail.cap + sc.h_sub_qt.cap + sc.h_sub_d.cap;
+    }
+    out->scratch = scratch;
+    for (const OutSeg& s : ctx->out_segs) out->results_device += (int64_t)(s.qt.cap + s.d.cap);
+    out->page_locked_host = (int64_t)pinned;
     return MSFM_OK;
 }
 

@@ -4,6 +4,12 @@ all 882 456 pairs: the N = 1 anchor of north_star's >= 6x strong-scaling target)
     python tools/config4_full.py > gpurun_out/config4_full.json
     python tools/config4_full.py --images 512 --desc 16384 --seed 4096 > gpurun_out/config5_512.json      (130 816 pairs)
 
+`--stream`: the job through the STREAMING form of the C ABI (msfm_match_pairs_begin / _next): one device sub-batch per call, nothing
+accumulates in the library -- the same checks on the chunks as they arrive (the lists of the sampled pairs are kept, the rest is
+consumed and dropped), peak device / page-locked memory from msfm_memory_info after every chunk:
+
+    python tools/config4_full.py --images 1024 --desc 16384 --seed 4096 --stream > gpurun_out/config5_1024_stream.json  (523 776 pairs)
+
 `--warm`: one untimed call first (every buffer allocated, plan hints learnt): the timed call is then what a step of bench.py's
 strong_u8 job measures; without it the call includes the first-touch cost of its scratch and result buffers (~10 ms per GiB).
 Checks: (1) the call's sub-batch count against the count predicted from the library's scratch formula (msfm_pair_scratch_bytes,
@@ -70,7 +76,10 @@ def main():
     ap.add_argument("--int-oracle-pairs", type=int, default=2)
     ap.add_argument("--seed", type=int, default=1329)
     ap.add_argument("--warm", action="store_true", help="one untimed call first: the timed one runs on allocated buffers")
+    ap.add_argument("--stream", action="store_true", help="msfm_match_pairs_begin / _next: bounded memory (see above)")
     args = ap.parse_args()
+    if args.stream:
+        return stream_main(args)
 
     t0 = time.perf_counter()
     imgs, pairs, name = synth.job("synthetic-u8", args.images, args.desc, seed=args.seed)
@@ -82,6 +91,7 @@ def main():
     t0 = time.perf_counter()
     for i, im in enumerate(imgs):
         ctx.upload_image(i, im)
+    ctx.finalize_store()
     upload_s = time.perf_counter() - t0
     free_store, _ = mem_info()
     cold_wall_s = None
@@ -161,6 +171,7 @@ def main():
         "properties": {"offsets_monotone": True, "indices_in_range": in_range, "q_strictly_ascending_per_pair": q_ascending,
                        "train_index_unique_per_pair": t_unique},
         "memory": {"device_total_GiB": total_mem / 2**30, "store_GiB": (free0 - free_store) / 2**30,
+                   "store_bytes_per_row": ctx.store_info()["device_bytes"] / max(1, ctx.store_info()["rows"]), "library_view": ctx.memory_info(),
                    "device_peak_GiB_after_call": (free0 - free_after) / 2**30,
                    "result_lists_page_locked_GiB": M * 12 / 2**30, "host_max_rss_GiB": resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 2**20},
         "setup": {"generate_s": gen_s, "upload_s": upload_s, "store_bytes": int(sum(x.nbytes for x in imgs))},
@@ -169,6 +180,109 @@ def main():
     # (the pipeline's cost marks -- six parts -- may cut inside a memory-bounded sub-batch: up to five more)
     ok = mismatches == 0 and int_mismatches == 0 and in_range and q_ascending and t_unique and \
         len(bounds) - 1 <= prof["sub_batches"] <= len(bounds) - 1 + 5
+    ctx.close()
+    sys.exit(0 if ok else 1)
+
+
+def stream_main(args):
+    """The job through msfm_match_pairs_begin / _next (see the module docstring)."""
+    t0 = time.perf_counter()
+    imgs, pairs, name = synth.job("synthetic-u8", args.images, args.desc, seed=args.seed)
+    gen_s = time.perf_counter() - t0
+    n_rows = np.array([len(x) for x in imgs], np.int64)
+    total_desc_pairs = int((n_rows[pairs[:, 0]] * n_rows[pairs[:, 1]]).sum())
+    ctx = _lib.Context(0)
+    mem0 = ctx.memory_info()
+    t0 = time.perf_counter()
+    for i, im in enumerate(imgs):
+        ctx.upload_image(i, im)
+    ctx.finalize_store()
+    upload_s = time.perf_counter() - t0
+    mem_store = ctx.memory_info()
+    rng = np.random.default_rng(4)
+    want = set(rng.choice(len(pairs), max(0, args.oracle_pairs - 10), replace=False).tolist()) | {0, len(pairs) - 1}
+    kept = {}              # pair index -> (q, t, dist bits) of the sampled pairs
+    cuts = []
+    peak_dev = peak_pin = 0
+    M = 0
+    chunks = 0
+    in_range = q_ascending = t_unique = True
+    crc = 0
+    import zlib
+    t0 = time.perf_counter()
+    for ch in ctx.match_pairs_stream(pairs, max_distance=1e9, copy=False):
+        first, n = ch["first"], ch["n_pairs"]
+        offs, qt, d = ch["offsets"], ch["qt"], ch["dist"]
+        chunks += 1
+        M += int(offs[-1])
+        if chunks <= 3 or chunks % 25 == 0:                 # the pairs on either side of a cut
+            cuts += [first, first + n - 1]
+            want |= {first, first + n - 1}
+        for p in [p for p in want if first <= p < first + n]:
+            s, e = int(offs[p - first]), int(offs[p - first + 1])
+            kept[p] = (qt[s:e, 0].copy(), qt[s:e, 1].copy(), d[s:e].view(np.int32).copy())
+        if len(qt):
+            crc = (crc + int(qt.view(np.int64).sum(dtype=np.int64))) & 0xFFFFFFFFFFFFFFFF   # (a cheap running sum: the consumer must not starve the pipeline)
+        if len(qt) and chunks % 4 == 1:     # the whole-result properties on every fourth chunk
+            cq, ct = qt[:, 0], qt[:, 1]
+            pair_of = np.repeat(np.arange(first, first + n), np.diff(offs))
+            in_range &= bool(((cq >= 0) & (cq < n_rows[pairs[pair_of, 0]]) & (ct >= 0) & (ct < n_rows[pairs[pair_of, 1]])).all())
+            same_pair = pair_of[1:] == pair_of[:-1]
+            q_ascending &= bool((np.diff(cq.astype(np.int64))[same_pair] > 0).all())
+            key = np.sort((pair_of - first).astype(np.int64) * (1 << 20) + ct)
+            t_unique &= bool((np.diff(key) != 0).all())
+        m = ctx.memory_info()
+        peak_dev = max(peak_dev, m["device_total"] - m["device_free"])
+        peak_pin = max(peak_pin, m["page_locked_host"])
+    wall_s = time.perf_counter() - t0
+    prof = ctx.profile()
+    mem_end = ctx.memory_info()
+    from oracle import c_oracle, int_oracle
+    c_oracle.build()
+    sel = np.asarray(sorted(kept), np.int64)
+    f32 = {int(i): imgs[int(i)].astype(np.float32) for i in np.unique(pairs[sel])}
+    t0 = time.perf_counter()
+    o_offs, oq, ot, od = c_oracle.match_pairs(f32, pairs[sel], max_distance=1e9, nthreads=16)
+    oracle_s = time.perf_counter() - t0
+    mismatches = 0
+    for k, p in enumerate(sel):
+        q, tt, db = kept[int(p)]
+        os_, oe = int(o_offs[k]), int(o_offs[k + 1])
+        ok = len(q) == oe - os_ and np.array_equal(q, oq[os_:oe]) and np.array_equal(tt, ot[os_:oe]) and np.array_equal(db, od[os_:oe].view(np.int32))
+        mismatches += 0 if ok else 1
+    int_mismatches = 0
+    for p in sel[:args.int_oracle_pairs]:
+        i, j = pairs[p]
+        iq, it, idist = int_oracle.match_pair(imgs[int(i)], imgs[int(j)], 0.8, True, 1e9)
+        q, tt, db = kept[int(p)]
+        ok = np.array_equal(q, iq) and np.array_equal(tt, it) and np.array_equal(db, np.asarray(idist, np.float32).view(np.int32))
+        int_mismatches += 0 if ok else 1
+    info = ctx.store_info()
+    out = {
+        "workload": name + (" -- BASELINE configs[3] in full" if (args.images, args.desc, args.seed) == (1329, 8192, 1329) else
+                            " -- seeded subset of BASELINE configs[4] (4096 x 16384)" if (args.desc, args.seed) == (16384, 4096) else "") +
+                    ", STREAMED: msfm_match_pairs_begin + one msfm_match_pairs_next per device sub-batch, one MI355X, first call of the process",
+        "streaming": True, "chunks": chunks, "image_pairs": int(len(pairs)), "descriptor_pairs": total_desc_pairs, "matches": M,
+        "wall_s": wall_s, "value_descriptor_pairs_per_s": total_desc_pairs / wall_s, "image_pairs_per_s": len(pairs) / wall_s,
+        "device_s": prof["total_device_ms"] * 1e-3, "sub_batches": prof["sub_batches"],
+        "sweep1_ms_total": prof["approx_kernel_ms"], "sweep1_i8_launches": prof["sweep1_i8_launches"],
+        "sweep1_frac_of_5_POPs": 256.0 * prof["prefilter_descriptor_pairs"] / max(1e-9, prof["approx_kernel_ms"] * 1e-3) / 5e15,
+        "fallback_pairs": prof["fallback_pairs"], "plan_regrows": prof["plan_regrows"], "candidates": prof["candidates"],
+        "order_sensitive_rows": prof.get("order_sensitive_rows"), "qt_sum64": crc, "properties_checked_on": "every fourth chunk",
+        "oracle_checked_pairs": int(len(sel)), "oracle_mismatching_pairs": mismatches, "oracle_matches_checked": int(o_offs[-1]),
+        "int_oracle_checked_pairs": int(min(args.int_oracle_pairs, len(sel))), "int_oracle_mismatching_pairs": int_mismatches,
+        "oracle_pairs_at_chunk_cuts": [int(x) for x in cuts], "oracle_wall_s": oracle_s,
+        "properties": {"indices_in_range": in_range, "q_strictly_ascending_per_pair": q_ascending, "train_index_unique_per_pair": t_unique},
+        "memory": {"device_total_GiB": mem0["device_total"] / 2**30, "device_used_before_GiB": (mem0["device_total"] - mem0["device_free"]) / 2**30,
+                   "store_GiB": mem_store["store"] / 2**30, "store_bytes_per_row": info["device_bytes"] / max(1, info["rows"]),
+                   "device_peak_GiB_incl_store": peak_dev / 2**30, "scratch_GiB_at_end": mem_end["scratch"] / 2**30,
+                   "call_wide_result_lists_on_device_GiB": mem_end["results_device"] / 2**30,
+                   "page_locked_host_peak_GiB": peak_pin / 2**30, "what_one_call_would_have_pinned_GiB": M * 12 / 2**30,
+                   "host_max_rss_GiB": resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 2**20},
+        "setup": {"generate_s": gen_s, "upload_s": upload_s, "store_input_bytes": int(sum(x.nbytes for x in imgs))},
+    }
+    print(json.dumps(out, indent=1))
+    ok = mismatches == 0 and int_mismatches == 0 and in_range and q_ascending and t_unique
     ctx.close()
     sys.exit(0 if ok else 1)
 

@@ -40,5 +40,14 @@ newtests)   # the tests added in round 5
 contract)   # bench.py's contract tests (end_to_end block included) + the two-rank flows
     TMO=1500 run pytest_contract python -m pytest -m gpu -x -q tests/test_bench_contract.py tests/test_gpu_exchange.py; tail -15 $OUT/pytest_contract.txt
     ;;
+cfg4stream)   # config 4 in full through the streaming form, cold: no call-wide page-locked result buffer
+    TMO=1500 run config4_stream python tools/config4_full.py --stream --int-oracle-pairs 1; head -c 700 $OUT/config4_stream.txt; echo; grep -n "GiB\|mismatch" $OUT/config4_stream.txt
+    ;;
+stream)   # bounded memory: config 5 at 1024 of its 4096 images through msfm_match_pairs_begin / _next
+    TMO=1500 run config5_1024_stream python tools/config4_full.py --images 1024 --desc 16384 --seed 4096 --stream --oracle-pairs 24 --int-oracle-pairs 1; head -c 1500 $OUT/config5_1024_stream.txt; echo
+    ;;
+cfg4)   # config 4 in full, one call, cold then warm (first call <= 8.3 s, warm <= 7.6 s, store <= 0.4 KB per row)
+    TMO=1500 run config4_full python tools/config4_full.py --warm --int-oracle-pairs 1; head -c 1200 $OUT/config4_full.txt; echo; grep -n "store_\|cold_first" $OUT/config4_full.txt
+    ;;
 *) echo "unknown stage $STAGE"; exit 2;;
 esac
