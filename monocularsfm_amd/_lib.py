@@ -146,6 +146,18 @@ class Context:
     """One matcher context bound to one GPU (msfm_ctx)."""
 
     def __init__(self, device=0, order=ORDER_SSE4X4):
+        # PyTorch-ROCm bundles a HIP runtime of its own (torch/lib/libamdhip64.so) next to the system one this library links: two
+        # runtimes in one process.  Measured on the GPU box: torch's cannot find a device any more once the system runtime has been
+        # initialised first ("No HIP GPUs are available"), the other order works.  So when torch is already imported and has not
+        # touched the GPU yet, let it do so before msfm_create (bench.py / sharding.py set their device before creating a context).
+        import sys
+        torch = sys.modules.get("torch")
+        if torch is not None:
+            try:
+                if torch.cuda.is_available() and not torch.cuda.is_initialized():
+                    torch.cuda.init()
+            except Exception:   # noqa: BLE001  (no GPU for torch: msfm_create below reports the real state)
+                pass
         self._L = load()
         h = C.c_void_p()
         rc = self._L.msfm_create(int(device), C.byref(h))

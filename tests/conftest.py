@@ -30,6 +30,20 @@ def built_lib():
     return _lib.load()
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _torch_runtime_first():
+    """Two HIP runtimes share the test process on the GPU box (PyTorch's bundled one, the system one behind libmsfm_match.so), and
+    torch's only comes up if it initialises FIRST (monocularsfm_amd/_lib.py, Context.__init__): the tests that use torch tensors
+    (tests/test_gpu_exchange.py) must not depend on which test created the first context."""
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except Exception:   # noqa: BLE001
+        pass
+    yield
+
+
 @pytest.fixture(scope="session")
 def gpu_ctx(built_lib):
     """One GPU context for the whole session; fails loudly (no skip, no fallback) without a GPU."""
