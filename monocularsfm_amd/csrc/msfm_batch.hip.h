@@ -565,8 +565,9 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
     const long long kn = std::max<long long>(1, b.kf_elems + b.kr_elems);
     HIPCHK(ctx, SC.d_rp_s0.ensure(std::max<long long>(1, b.rp_elems) * 4));
     HIPCHK(ctx, SC.d_rp_s1.ensure(std::max<long long>(1, b.rp_elems) * 4));
-    // column partials of sweep 1: one float2 (the two largest of four row-class maxima) per 512-row A block and column
-    HIPCHK(ctx, SC.d_cp_s0.ensure(std::max<long long>(1, b.cp_elems) * 8));
+    // column partials of sweep 1: one float2 (the two largest of four row-class maxima) per 512-row A block and column; the integer
+    // sweeps pack theirs into 4 bytes (msfm_cp_pack) -- a mixed sub-batch keeps the 8-byte stride for both
+    HIPCHK(ctx, SC.d_cp_s0.ensure(std::max<long long>(1, b.cp_elems) * ((i8 || (q8_direct && !q8_mixed)) ? 4 : 8)));   // (coarse twins: q8_scatter_kernel writes float2 entries)
     HIPCHK(ctx, SC.d_tu.ensure(kn * 4));
     HIPCHK(ctx, SC.d_colmask.ensure(kn * 4));
     HIPCHK(ctx, SC.d_best.ensure(kn * 8));
@@ -1035,9 +1036,6 @@ int run_knn(msfm_ctx* ctx, Batch& b, size_t ev_base, bool* exact_launched, Prune
     assign_common(b);
     SC.fix_cap_eff = need_fix ? ctx->fix_cap : 0;
     const long long kn = std::max<long long>(1, b.kf_elems + b.kr_elems);
-    HIPCHK(ctx, SC.d_k_i0.ensure(kn * 4));
-    HIPCHK(ctx, SC.d_k_d0.ensure(kn * 4));
-    HIPCHK(ctx, SC.d_k_d1.ensure(kn * 4));
     HIPCHK(ctx, SC.d_fix_count.ensure(4));
     HIPCHK(ctx, SC.d_fix_list.ensure((size_t)ctx->fix_cap * sizeof(int4)));
     HIPCHK(ctx, hipMemsetAsync(SC.d_fix_count.p, 0, 4, SC.stream));
@@ -1047,6 +1045,11 @@ int run_knn(msfm_ctx* ctx, Batch& b, size_t ev_base, bool* exact_launched, Prune
     // match lists of a batch that is on the matrix-core route throughout, no sqrt-space tie queue: the epilogue reads best / second
     // keys directly (KnnFromKeys); the knnMatch-level API and mixed batches keep the kNN arrays
     SC.keys_epilogue = lists_only && any_pf && !any_exact && SC.fix_cap_eff == 0;
+    if (!SC.keys_epilogue) {   // (the final kNN arrays: 12 bytes per padded row and column, only where something reads them)
+        HIPCHK(ctx, SC.d_k_i0.ensure(kn * 4));
+        HIPCHK(ctx, SC.d_k_d0.ensure(kn * 4));
+        HIPCHK(ctx, SC.d_k_d1.ensure(kn * 4));
+    }
     int rc;
     if (any_pf) {
         rc = run_prefilter(ctx, b, ev_base + 2, prune);  // events ev_base+2 .. ev_base+5

@@ -416,7 +416,7 @@ constexpr int kSlots = 2 * MSFM_MAX_IMAGES + 2;  // ids >= MSFM_MAX_IMAGES: auxi
 // device has free when the call starts (hipMemGetInfo + what the sets already hold) -- a 9-second job gains ~2.5 % from 7
 // instead of 19 sub-batches per 80 000 pairs, but every GiB of scratch costs ~10 ms the first time it is allocated
 // (profiles/r04_scratch_ab.txt).
-constexpr long long kDefaultScratchBytes = (long long)64 << 30;
+constexpr long long kDefaultScratchBytes = (long long)64 << 30;   // (round 5: a pair on the integer route is charged 0.7 of round 4's estimate; the sets hold ~50 GiB under this limit)
 constexpr int kDefaultMaxPairsPerBatch = 16384;
 constexpr int kMaxPairsPerBatchLimit = 65535;   // gridDim.y
 // A call large enough is cut into at least this many sub-batches so that the bandwidth-bound tail of one (thresholds, plan,

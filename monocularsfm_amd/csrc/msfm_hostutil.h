@@ -62,17 +62,22 @@ inline std::vector<long long> msfm_pipeline_marks(long long total, long long n_s
 //     sweep 2 and its candidate lists for ONE SIXTEENTH of the rows alive (measured: 1 - 3.3 %; buffers that turn out too small are
 //     re-grown and the sub-batch re-run, this is only the cut): 20 B + 8 candidates x 8 B per compacted row, a column once per
 //     512-row block group (at most 32);
+//   route 3, INTEGER matrix cores (both images byte stores, match lists with ratio <= 0.95): as route 1 with 4-byte column partials and
+//     without the final kNN arrays (the epilogue reads the reduce slots: 24 B per padded row and column), + 4 B per candidate and
+//     compacted row for the exact-S hand-over of sweep 2;
 //   route 2, matrix cores, dense sweep 2 (kNN-level API, ratio > 0.95): candidate lists of 16 entries per row and column instead;
 //   route 0, brute force: three 4-byte row partials per padded row, three per 128-row block and column.
+// (A mixed sub-batch -- byte pairs next to float pairs -- allocates by route 1's sizes for all of them: this is the cut, not a cap.)
 inline long long msfm_pair_scratch_bytes(int n1, int n2, int n1pad, int n2pad, int blocks128, int blocks512, int route) {
     if (n1 <= 0 || n2 <= 0) return 0;
-    const long long common = 36LL * ((long long)n1pad + n2pad) + 24LL * n1 + 1024;
+    const long long slots = (long long)n1pad + n2pad;
+    const long long common = (route == 3 ? 24LL : 36LL) * slots + 24LL * n1 + 1024;
     if (route == 0) return common + 12LL * n1pad + 12LL * (long long)blocks128 * n2pad;
-    const long long partials = 8LL * n1pad + 8LL * (long long)blocks512 * n2pad;
+    const long long partials = 8LL * n1pad + (route == 3 ? 4LL : 8LL) * (long long)blocks512 * n2pad;
     if (route == 2) return common + partials + 128LL * ((long long)n1 + n2) + 16384;
     const long long bits = blocks512 < 32 ? blocks512 : 32;
     const long long cmp_rows = ((long long)n1 + (long long)n2 * bits) / 16 + 1024;
-    return common + partials + 84LL * cmp_rows;
+    return common + partials + (route == 3 ? 120LL : 84LL) * cmp_rows;
 }
 
 // One key into a slot's (best, second) -- the reduction of the exact re-check (pf_exact_candidates_kernel).  best ends as the

@@ -117,7 +117,7 @@ struct MatchJob {
         }
     }
     kScratchBytes = std::max<long long>(1, budget / kSets);
-    // which buffers a pair needs (msfm_pair_scratch_bytes): 0 brute force, 1 matrix cores + compacted sweep 2, 2 + dense sweep 2
+    // which buffers a pair needs (msfm_pair_scratch_bytes): 0 brute force, 1 matrix cores + compacted sweep 2 (3: on the integer cores), 2 + dense sweep 2
     scratch_route = !ctx->prefilter ? 0 : ((prune.ratio > 0.f && prune.ratio <= 0.95f) ? 1 : 2);
     kMaxPairsPerBatch = ctx->max_pairs_per_batch;
     // cumulative-cost marks of the parts (empty: no cost cut): msfm_pipeline_marks (msfm_hostutil.h) -- shrinking parts
@@ -171,8 +171,9 @@ struct MatchJob {
                     return fail(ctx, MSFM_E_STATE, "geometric verification needs msfm_upload_keypoints for image " +
                                                        std::to_string(ia.nk < ia.n ? pairs[2 * end] : pairs[2 * end + 1]));
             }
+            const bool bytes_pair = ctx->prefilter == 1 && ctx->images[(size_t)pairs[2 * end]].is_u8 && ctx->images[(size_t)pairs[2 * end + 1]].is_u8;
             const long long need = pd.valid ? msfm_pair_scratch_bytes(pd.n1, pd.n2, pd.n1pad, pd.n2pad, pd.a_blocks, pd.a_blocks256,
-                                                                     pp.use ? scratch_route : 0) : 0;
+                                                                     !pp.use ? 0 : (scratch_route == 1 && bytes_pair ? 3 : scratch_route)) : 0;
             const long long c = pd.valid ? (long long)pd.n1 * pd.n2 : 0;
             if (end > begin && est + need > kScratchBytes) break;
             if (end > begin && !marks.empty() && cost_begin + cost + c / 2 > mark) break;

@@ -40,25 +40,26 @@ def mem_info():
     return free.value, total.value
 
 
-def pair_scratch_bytes(n1, n2):
-    """msfm_pair_scratch_bytes (csrc/msfm_hostutil.h), route 1: matrix cores + compacted sweep 2"""
+def pair_scratch_bytes(n1, n2, route=1):
+    """msfm_pair_scratch_bytes (csrc/msfm_hostutil.h): route 1 matrix cores + compacted sweep 2, route 3 the same on the integer cores
+    (byte stores: what this tool's jobs take)"""
     if n1 <= 0 or n2 <= 0:
         return 0
     n1pad, n2pad = (n1 + 511) // 512 * 512, (n2 + 511) // 512 * 512
     blocks512 = n1pad // 512
-    common = 36 * (n1pad + n2pad) + 24 * n1 + 1024
-    partials = 8 * n1pad + 8 * blocks512 * n2pad
+    common = (24 if route == 3 else 36) * (n1pad + n2pad) + 24 * n1 + 1024
+    partials = 8 * n1pad + (4 if route == 3 else 8) * blocks512 * n2pad
     cmp_rows = (n1 + n2 * min(blocks512, 32)) // 16 + 1024
-    return common + partials + 84 * cmp_rows
+    return common + partials + (120 if route == 3 else 84) * cmp_rows
 
 
 def predicted_sub_batches(n_rows, pairs, free_bytes, max_pairs=16384, sets=3):
-    """The memory / pair-count cut of match_pairs_impl (csrc/msfm_match.hip): budget = min(64 GiB, free / 4), a third per set."""
+    """The memory / pair-count cut of MatchJob::build (csrc/msfm_job.hip.h): budget = min(64 GiB, free / 4), a third per set."""
     per_set = min(64 << 30, free_bytes // 4) // sets
     bounds = [0]
     est, cnt = 0, 0
     for k, (i, j) in enumerate(pairs):
-        need = pair_scratch_bytes(int(n_rows[i]), int(n_rows[j]))
+        need = pair_scratch_bytes(int(n_rows[i]), int(n_rows[j]), 3)
         if cnt > 0 and (cnt >= max_pairs or est + need > per_set):
             bounds.append(k)
             est, cnt = 0, 0
