@@ -49,5 +49,15 @@ stream)   # bounded memory: config 5 at 1024 of its 4096 images through msfm_mat
 cfg4)   # config 4 in full, one call, cold then warm (first call <= 8.3 s, warm <= 7.6 s, store <= 0.4 KB per row)
     TMO=1500 run config4_full python tools/config4_full.py --warm --int-oracle-pairs 1; head -c 1200 $OUT/config4_full.txt; echo; grep -n "store_\|cold_first" $OUT/config4_full.txt
     ;;
+tail)   # the exact re-check at 64 VGPRs (co-resident with sweep 1) under 2 / 3 / 4 parts; against round 4's build
+    run ab_parts python tools/ab_envs.py --rounds 14 "" "MSFM_PIPELINE=3" "MSFM_PIPELINE=4" "MSFM_PIPELINE=3,MSFM_PIPELINE_TAPER=0.5" "MSFM_PIPELINE=1"; cat $OUT/ab_parts.txt
+    run ab_r04 python tools/ab_multi.py --rounds 14 r04=$R04 tree; cat $OUT/ab_r04.txt
+    BENCH="python $ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-e2e --sustained-steps 0 --u8-images 0 --no-solo"
+    cd /tmp; timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/prof_stats -- $BENCH > $OUT/prof_stats.log 2>&1; echo "stats rc=$?"; cd $ROOT
+    DB=$(ls -t $(find $OUT/prof_stats -name '*.db') | head -1)
+    python tools/rocprof_summary.py "$DB" "$BENCH" > $OUT/bench_kernel_stats.txt 2>&1; head -16 $OUT/bench_kernel_stats.txt | cut -c1-60,150-215
+    python tools/step_timeline.py "$DB" 2 > $OUT/step_timeline.txt 2>&1; tail -1 $OUT/step_timeline.txt | cut -c1-300
+    find $OUT -type f -size +8M -delete
+    ;;
 *) echo "unknown stage $STAGE"; exit 2;;
 esac
