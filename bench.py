@@ -242,6 +242,10 @@ def main():
     ap.add_argument("--sustained-steps", type=int, default=200,
                     help="extra untimed-for-`value` run of this many steps after the K timed ones -> sustained_ms_per_step "
                          "(the part's clock is set by a power budget: a 1 s burst and a 10 s run differ); 0 = skip")
+    ap.add_argument("--super-batch-pairs", type=int, default=0,
+                    help="bounded memory: the step's lists are produced and consumed chunk by chunk -- N = 1: the streaming form of the C ABI "
+                         "(msfm_match_pairs_begin / _next, one device sub-batch per chunk; the value only switches it on); N > 1: "
+                         "ShardedMatcher.match_to_writer_batches with super-batches of this many pairs.  0 = one call, lists resident")
     ap.add_argument("--no-e2e", action="store_true", help="skip the cold end-to-end run of the ComputeMatches executable (end_to_end)")
     ap.add_argument("--no-solo", action="store_true",
                     help="skip the 4 extra steps with the pipeline off that measure the sweeps alone (roofline.solo); for kernel traces")
@@ -322,7 +326,40 @@ def main():
         upload_s = time.perf_counter() - t_up   # host buffers -> HBM (PCIe) + the on-device layout / fp16 / norm passes
         sm = ShardedMatcher(ctx=ctx, device=coll_dev, force_collectives=args.force_collectives, **match_kw)
 
+        stream_stats = {"chunks": 0, "max_chunk_matches": 0, "page_locked_peak": 0, "device_peak": 0}
+
+        def step_streamed():
+            """The lists never exist as a whole: every chunk is consumed (a running sum over its rows: what a database writer or an
+            RCCL send would do with it) and dropped."""
+            counts = np.zeros(len(pairs), np.int64)
+            acc = [0]
+            t = time.perf_counter()
+            if not multi:
+                for ch in ctx.match_pairs_stream(pairs, copy=False, **match_kw):
+                    counts[ch["first"]:ch["first"] + ch["n_pairs"]] = np.diff(ch["offsets"])
+                    if len(ch["qt"]):
+                        acc[0] = (acc[0] + int(ch["qt"].view(np.int64).sum(dtype=np.int64))) & 0xFFFFFFFFFFFFFFFF
+                    stream_stats["chunks"] += 1
+                    stream_stats["max_chunk_matches"] = max(stream_stats["max_chunk_matches"], len(ch["qt"]))
+                sm.last = {"compute_ms": (time.perf_counter() - t) * 1e3, "exchange_ms": 0.0}
+            else:
+                def sink(b0, offs, qt, d):
+                    if len(qt):
+                        acc[0] = (acc[0] + int(np.ascontiguousarray(qt).view(np.int64).sum(dtype=np.int64))) & 0xFFFFFFFFFFFFFFFF
+                    stream_stats["chunks"] += 1
+                    stream_stats["max_chunk_matches"] = max(stream_stats["max_chunk_matches"], len(qt))
+                counts = sm.match_to_writer_batches(pairs, n_rows, batch_pairs=args.super_batch_pairs, dst=0, sink=sink)
+            m = ctx.memory_info()
+            stream_stats["page_locked_peak"] = max(stream_stats["page_locked_peak"], m["page_locked_host"])
+            stream_stats["device_peak"] = max(stream_stats["device_peak"], m["device_total"] - m["device_free"])
+            stream_stats["qt_sum64"] = acc[0]
+            offs = np.zeros(len(pairs) + 1, np.int64)
+            np.cumsum(counts, out=offs[1:])
+            return offs, None, None
+
         def step():
+            if args.super_batch_pairs > 0:
+                return step_streamed()
             if not multi:
                 # one rank: the step ends with the lists in the library's page-locked host buffers ("view": no second copy)
                 t = time.perf_counter()
@@ -364,6 +401,7 @@ def main():
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 sustained = float(t.cpu()[0])
         run_job.sustained = sustained
+        run_job.stream_stats = dict(stream_stats) if args.super_batch_pairs > 0 else None
         # after everything timed: the sweeps ALONE (one sub-batch per step, nothing in flight beside them) -- in the timed
         # region the other sub-batches' bandwidth-bound tails run beside a sweep and stretch its event span
         run_job.solo = None
@@ -402,6 +440,7 @@ def main():
     dt, result, upload_s, per_rank, n_rows = run_job(imgs, pairs, args.steps, args.warmup, collect, args.sustained_steps, **main_kw)
     sustained = run_job.sustained
     solo = run_job.solo
+    stream_main = run_job.stream_stats
     total_desc_pairs = int((n_rows[pairs[:, 0]] * n_rows[pairs[:, 1]]).sum())
     offs = result[0]
     n_matches = int(offs[-1])
@@ -444,6 +483,10 @@ def main():
         # ranks that answered an all_reduce over the exchange backend before the job started (None at N = 1 without --force-collectives)
         "rccl_ranks_seen" if args.backend == "nccl" else "gloo_ranks_seen": ranks_seen,
         "exchange_backend": args.backend if multi else None,
+        # --super-batch-pairs: the lists of a step were produced and consumed chunk by chunk (bounded memory)
+        "streamed": None if not stream_main else dict(stream_main, super_batch_pairs=args.super_batch_pairs,
+                                                     page_locked_peak_GiB=stream_main["page_locked_peak"] / 2**30,
+                                                     device_peak_GiB=stream_main["device_peak"] / 2**30),
     }
     pf_ms, pf_launches = acc["approx_kernel_ms"], acc["approx_kernel_launches"]
     if pf_launches > 0:

@@ -294,3 +294,31 @@ class ShardedMatcher:
         if with_dist:
             return goffs, allm[:, 0:2], allm[:, 2].view(np.float32)
         return goffs, allm, None
+
+    def match_to_writer_batches(self, pairs, n_rows, batch_pairs=65536, dst=0, sink=None, with_dist=False):
+        """The same flow in SUPER-BATCHES of at most `batch_pairs` pairs, for jobs whose lists do not fit memory (BASELINE's largest
+        config: 6.9e9 matches = 83 GB): every super-batch is partitioned over the ranks, matched, exchanged, handed to
+        `sink(first_pair, offsets, qt, dist)` on the writer rank -- offsets relative to the super-batch, the arrays views valid until
+        the next one -- and dropped.  What is resident at any time is one super-batch's lists: on a rank its share (in the library),
+        on the writer the whole super-batch.  The reference streams the same way, one transaction per <= 100 pairs
+        (/root/reference/src/Feature/FeatureMatching.cpp:13, 70-72, 118-139; the C++ drop-in: host/FeatureMatching.cpp's super-batches).
+        -> per-pair match counts int64[P] on every rank; self.last sums the phases over the super-batches."""
+        pairs = np.asarray(pairs, np.int32).reshape(-1, 2)
+        P = len(pairs)
+        counts = np.zeros(P, np.int64)
+        rank, _ = self._rank_world()
+        tot = {"compute_ms": 0.0, "exchange_ms": 0.0, "local_pairs": 0, "local_matches": 0, "super_batches": 0, "max_batch_matches": 0}
+        step = max(1, int(batch_pairs))
+        for b0 in range(0, P, step):
+            sub = pairs[b0:b0 + step]
+            offs, qt, d = self.match_to_writer(sub, n_rows, dst=dst, with_dist=with_dist)
+            counts[b0:b0 + len(sub)] = np.diff(offs)
+            for k in ("compute_ms", "exchange_ms", "local_pairs", "local_matches"):
+                tot[k] += self.last[k]
+            tot["super_batches"] += 1
+            tot["max_batch_matches"] = max(tot["max_batch_matches"], int(offs[-1]))
+            if sink is not None and rank == dst:
+                sink(b0, offs, qt, d)
+        self.last = tot
+        return counts
+

@@ -107,3 +107,27 @@ def test_bench_gpus_2_launches_itself():
     import torch
     if torch.cuda.device_count() < 2:
         assert bad.returncode != 0 and not [l for l in bad.stdout.splitlines() if l.startswith("{")]
+
+
+def test_bench_streamed_steps_give_the_same_job():
+    """--super-batch-pairs: the step's lists are produced and consumed chunk by chunk (N = 1: msfm_match_pairs_begin / _next; N = 2:
+    super-batches through the exchange) -- same number of matches as the one-call step, page-locked memory bounded by a chunk."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "synthetic-u8", "--images", "14", "--desc", "3000", "--steps", "2",
+            "--warmup", "1", "--u8-images", "0", "--no-cpu-baseline", "--no-e2e", "--sustained-steps", "0", "--no-solo"]
+    lines = {}
+    for name, extra in (("one_call", []), ("streamed", ["--super-batch-pairs", "20"]),
+                        ("two_ranks", ["--super-batch-pairs", "20", "--gpus", "2", "--backend", "gloo", "--share-gpu"])):
+        # (N = 1: a chunk is a device sub-batch -- cut at 20 pairs here; N = 2: a chunk is a super-batch of the exchange)
+        r = subprocess.run(base + extra, capture_output=True, text=True, timeout=900, cwd=ROOT, env=dict(env, MSFM_MAX_PAIRS_PER_BATCH="20"))
+        assert r.returncode == 0, (name, r.stderr[-2000:])
+        lines[name] = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    m = lines["one_call"]["config"]["matches_per_step"]
+    assert m > 100 and lines["one_call"]["streamed"] is None
+    for name in ("streamed", "two_ranks"):
+        d = lines[name]
+        assert d["config"]["matches_per_step"] == m and d["streamed"]["chunks"] >= 2 * 5, d["streamed"]
+        assert 0 < d["streamed"]["max_chunk_matches"] < m
+    assert lines["streamed"]["streamed"]["qt_sum64"] == lines["two_ranks"]["streamed"]["qt_sum64"]
+    assert lines["two_ranks"]["n_gpus"] == 2 and lines["two_ranks"]["gloo_ranks_seen"] == 2
+
