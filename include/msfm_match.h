@@ -126,7 +126,7 @@ int msfm_get_profile(const msfm_ctx* ctx, msfm_profile* out);
  * at most `scratch_bytes` of device scratch for ALL sub-batches in flight TOGETHER (three scratch sets share it, a third each;
  * what a pair needs: msfm_pair_scratch_bytes in csrc/msfm_hostutil.h -- on the matrix-core route ~2 MB per pair of 8192-row
  * images).  scratch_bytes <= 0 (default): 64 GiB, but never more than a quarter of what the device has free when the call starts
- * (hipMemGetInfo + what the sets already hold); an explicit value is honoured up to three quarters of that.  The call's result
+ * (hipMemGetInfo + what the sets already hold); an explicit value is honoured up to half of that (the per-pair figure is what a call is CUT by, not a cap: buffers that turn out too small are re-grown and the sub-batch re-run).  The device is asked once per state of the store, not per call.  The call's result
  * lists (12 bytes per match, device + page-locked host) and the descriptor store are NOT part of this budget.  Also
  * MSFM_MAX_PAIRS_PER_BATCH and MSFM_SCRATCH_MIB in the environment at msfm_create.  Results do not depend on the cut (tests force
  * small limits to cross it).  The reference's counterpart is the 100-pair flush of BruteFeatureMatcher::RunMatching

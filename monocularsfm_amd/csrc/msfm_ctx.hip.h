@@ -549,6 +549,9 @@ struct msfm_ctx {
     // sub-batch limits of msfm_match_pairs (msfm_set_limits / MSFM_MAX_PAIRS_PER_BATCH / MSFM_SCRATCH_MIB)
     int max_pairs_per_batch = kDefaultMaxPairsPerBatch;
     long long scratch_bytes = 0;      // msfm_set_limits / MSFM_SCRATCH_MIB: total for the scratch sets in flight; 0 = automatic (above)
+    long long budget_cached = 0;      // the automatic scratch budget, derived from hipMemGetInfo once per (store size, limit)
+    size_t budget_for_store = 0;
+    long long budget_for_limit = 0;
     long long issue_seq = 0;          // sub-batches issued so far
     double pipeline_taper = kDefaultTaper;   // size of a call's last part relative to the average part (MSFM_PIPELINE_TAPER; 1: equal parts)
     int in_flight = kInFlight;        // scratch sets used (MSFM_IN_FLIGHT=1 at msfm_create: no sub-batch overlap, for A/B measurements)

@@ -65,6 +65,7 @@ inline std::vector<long long> msfm_pipeline_marks(long long total, long long n_s
 //   route 3, INTEGER matrix cores (both images byte stores, match lists with ratio <= 0.95): as route 1 with 4-byte column partials and
 //     without the final kNN arrays (the epilogue reads the reduce slots: 24 B per padded row and column), + 4 B per candidate and
 //     compacted row for the exact-S hand-over of sweep 2;
+//   route 4, route 1 for float stores whose byte twins are coarse (values beyond 0.625): one EIGHTH of the rows instead of a sixteenth;
 //   route 2, matrix cores, dense sweep 2 (kNN-level API, ratio > 0.95): candidate lists of 16 entries per row and column instead;
 //   route 0, brute force: three 4-byte row partials per padded row, three per 128-row block and column.
 // (A mixed sub-batch -- byte pairs next to float pairs -- allocates by route 1's sizes for all of them: this is the cut, not a cap.)
@@ -76,7 +77,9 @@ inline long long msfm_pair_scratch_bytes(int n1, int n2, int n1pad, int n2pad, i
     const long long partials = 8LL * n1pad + (route == 3 ? 4LL : 8LL) * (long long)blocks512 * n2pad;
     if (route == 2) return common + partials + 128LL * ((long long)n1 + n2) + 16384;
     const long long bits = blocks512 < 32 ? blocks512 : 32;
-    const long long cmp_rows = ((long long)n1 + (long long)n2 * bits) / 16 + 1024;
+    // (route 4 = route 1 with COARSE byte twins, msfm_q8.hip.h: plan A holds every live column once per block group and the prune kernel
+    // only knows live / dead -- twice the compacted rows of the direct route)
+    const long long cmp_rows = ((long long)n1 + (long long)n2 * bits) / (route == 4 ? 8 : 16) + 1024;
     return common + partials + (route == 3 ? 120LL : 84LL) * cmp_rows;
 }
 

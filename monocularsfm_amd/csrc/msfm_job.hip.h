@@ -33,6 +33,7 @@ struct MatchJob {
     long long kScratchBytes = 1;
     int scratch_route = 1;
     int kMaxPairsPerBatch = kDefaultMaxPairsPerBatch;
+    bool coarse_twins = false;   // float stores whose twins need the fp16 sweep 1' (plan A: more compacted rows per pair)
     std::vector<long long> marks;
     long long cost_done = 0;   // cost of the sub-batches built so far (a re-built sub-batch starts from its own begin: see build)
     bool need_fix = false;
@@ -106,20 +107,32 @@ struct MatchJob {
     // ---- the cut: scratch memory per set, pair count, and a cost limit that gives a large call >= `pipeline` sub-batches
     kSets = ctx->in_flight;
     // the scratch sets in flight SHARE the budget (three sets at half of it each were 1.5 x the documented limit)
+    // (the automatic budget is derived from the device's free memory ONCE per state of the context -- the store's size and the limit
+    // set by the caller -- not per call: a hipMemGetInfo per call made the cut depend on what else was momentarily allocated on the GPU,
+    // and the pre-emptive filter's many small calls paid the driver query each time)
     long long budget = ctx->scratch_bytes > 0 ? ctx->scratch_bytes : kDefaultScratchBytes;
-    {
+    if (ctx->budget_cached > 0 && ctx->budget_for_store == ctx->store.bytes() && ctx->budget_for_limit == ctx->scratch_bytes) {
+        budget = ctx->budget_cached;
+    } else {
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
             long long held = 0;   // what the scratch sets hold already is theirs to use
             for (Scratch& sc : ctx->sc) held += sc.device_bytes();
             const long long avail = (long long)free_b + held;
-            budget = std::min(budget, ctx->scratch_bytes > 0 ? avail * 3 / 4 : avail / 4);
+            // (an explicit limit is honoured up to half of what is free: the estimate per pair is the cut, not a cap -- buffers that turn
+            // out too small are re-grown)
+            budget = std::min(budget, ctx->scratch_bytes > 0 ? avail / 2 : avail / 4);
         }
+        ctx->budget_cached = budget;
+        ctx->budget_for_store = ctx->store.bytes();
+        ctx->budget_for_limit = ctx->scratch_bytes;
     }
     kScratchBytes = std::max<long long>(1, budget / kSets);
     // which buffers a pair needs (msfm_pair_scratch_bytes): 0 brute force, 1 matrix cores + compacted sweep 2 (3: on the integer cores), 2 + dense sweep 2
     scratch_route = !ctx->prefilter ? 0 : ((prune.ratio > 0.f && prune.ratio <= 0.95f) ? 1 : 2);
     kMaxPairsPerBatch = ctx->max_pairs_per_batch;
+    coarse_twins = ctx->prefilter == 1 && ctx->q8_route && ctx->q8_level > 0.f &&
+                   !(ctx->q8_direct == 2 || (ctx->q8_direct == 1 && ctx->q8_level <= kQ8DirectMaxLevel));
     // cumulative-cost marks of the parts (empty: no cost cut): msfm_pipeline_marks (msfm_hostutil.h) -- shrinking parts
     marks.clear();
     if (ctx->pipeline > 1 && n_pairs > 1) {
@@ -173,7 +186,7 @@ struct MatchJob {
             }
             const bool bytes_pair = ctx->prefilter == 1 && ctx->images[(size_t)pairs[2 * end]].is_u8 && ctx->images[(size_t)pairs[2 * end + 1]].is_u8;
             const long long need = pd.valid ? msfm_pair_scratch_bytes(pd.n1, pd.n2, pd.n1pad, pd.n2pad, pd.a_blocks, pd.a_blocks256,
-                                                                     !pp.use ? 0 : (scratch_route == 1 && bytes_pair ? 3 : scratch_route)) : 0;
+                                                                     !pp.use ? 0 : (scratch_route == 1 && bytes_pair ? 3 : (scratch_route == 1 && coarse_twins ? 4 : scratch_route))) : 0;
             const long long c = pd.valid ? (long long)pd.n1 * pd.n2 : 0;
             if (end > begin && est + need > kScratchBytes) break;
             if (end > begin && !marks.empty() && cost_begin + cost + c / 2 > mark) break;

@@ -10,6 +10,8 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (gfx950); run with -m gpu on the GPU box")
+    config.addinivalue_line("markers", "slow: the BASELINE configs at full size on one MI355X (minutes); opt-in: -m slow on the GPU box "
+                                       "(not part of -m gpu; skipped without a GPU)")
 
 
 @pytest.fixture(scope="session")
