@@ -15,8 +15,8 @@ namespace {
 
 constexpr size_t kUpSlotBytes = (size_t)4 << 20;     // one ring slot: an image of up to 8192 float rows travels in one piece
 constexpr int kUpSlots = 2;                          // memcpy into one slot while the other one's DMA runs
-constexpr size_t kInboxWaveBytes = (size_t)128 << 20;   // uploads waiting beyond this are built before the next one is accepted
-constexpr size_t kInboxMinChunk = (size_t)32 << 20;
+constexpr size_t kInboxWaveBytes = (size_t)256 << 20;   // uploads waiting beyond this are built before the next one is accepted
+constexpr size_t kInboxMinChunk = (size_t)64 << 20;
 
 inline hipStream_t store_stream(msfm_ctx* ctx) { return ctx->sc[0].stream; }
 

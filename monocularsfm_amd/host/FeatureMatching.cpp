@@ -21,13 +21,14 @@ namespace MonocularSfM {
 namespace {
 // MSFM_CLI_TIMING=1: wall-clock per phase on stderr when the matcher closes
 struct PhaseClock {
-    double exist = 0, read_desc = 0, device = 0, read_kp = 0, verify = 0, emit = 0, preemptive = 0;
+    double exist = 0, read_desc = 0, device = 0, read_kp = 0, verify = 0, emit = 0, preemptive = 0, open_dev = 0, close_dev = 0;
     bool on = std::getenv("MSFM_CLI_TIMING") != nullptr;
     void Report() const {
         if (!on || exist + read_desc + device + emit == 0) return;
         std::fprintf(stderr, "[msfm timing] exist-check %.3f s | read descriptors + upload %.3f s | device match + fetch %.3f s | "
-                             "pre-emptive filter %.3f s | read keypoints %.3f s | verification %.3f s | stdout + WriteMatches %.3f s\n",
-                     exist, read_desc, device, preemptive, read_kp, verify, emit);
+                             "pre-emptive filter %.3f s | read keypoints %.3f s | verification %.3f s | stdout + WriteMatches %.3f s | "
+                             "open database + device %.3f s | close %.3f s\n",
+                     exist, read_desc, device, preemptive, read_kp, verify, emit, open_dev, close_dev);
     }
 } g_clock;
 struct Lap {
@@ -63,6 +64,7 @@ FeatureMatcher::FeatureMatcher(const std::string& database_path, const int& max_
 FeatureMatcher::~FeatureMatcher() { CloseDatabaseAndDevice(); }
 
 void FeatureMatcher::OpenDatabaseAndDevice() {
+    Lap lap_open(&g_clock.open_dev);
     database_ = new Database();
     database_->Open(database_path_);
     if (!ctx_) {
@@ -101,6 +103,8 @@ void FeatureMatcher::OpenDatabaseAndDevice() {
 }
 
 void FeatureMatcher::CloseDatabaseAndDevice() {
+    {
+    Lap lap_close(&g_clock.close_dev);
     if (database_) {
         database_->Close();
         delete database_;
@@ -116,6 +120,7 @@ void FeatureMatcher::CloseDatabaseAndDevice() {
     descriptor_cache_.clear();
     resident_.clear();
     keypoints_cache_.clear();
+    }
     g_clock.Report();
     g_clock = PhaseClock();
 }
@@ -201,6 +206,9 @@ void FeatureMatcher::PreloadAllImages() {
     database_->VisitAllDescriptors(visit, &sink);   // images the side table does not cover
     sink.keypoints = true;
     database_->VisitAllKeyPoints(visit, &sink);
+    // the uploads above only copied: build the store now (classification, one allocation, layout kernels), inside this phase's clock
+    MSFM_CALL(ctx_, msfm_finalize_store(ctx_));
+    for (msfm_ctx* c : extra_ctxs_) MSFM_CALL(c, msfm_finalize_store(c));
     bulk_loaded_ = true;
 }
 

@@ -93,15 +93,15 @@ def test_subset_of_a_pending_image_and_of_a_byte_image(oracle):
 
 
 def test_bulk_upload_is_built_in_waves():
-    # more than the inbox holds at once (128 MiB): the library builds what is waiting and carries on; results as for small stores
-    imgs = synth.rootsift_images(44, 8000, seed=96, n_proto=12000)     # 44 x 4.1 MB = 180 MB
+    # more than the inbox holds at once (256 MiB): the library builds what is waiting and carries on; results as for small stores
+    imgs = synth.rootsift_images(72, 8000, seed=96, n_proto=12000)     # 72 x 4.1 MB = 295 MB
     with _lib.Context(0) as ctx:
         for i, im in enumerate(imgs):
             ctx.upload_image(i, im)
-        assert 0 < ctx.store_info()["pending_images"] < 44
-        pairs = np.array([(43, 0), (1, 42), (20, 21)], np.int32)
+        assert 0 < ctx.store_info()["pending_images"] < 72
+        pairs = np.array([(71, 0), (1, 70), (20, 21)], np.int32)
         got = ctx.match_pairs(pairs)
         with _lib.Context(0) as ref:
-            for i in (0, 1, 20, 21, 42, 43):
+            for i in (0, 1, 20, 21, 70, 71):
                 ref.upload_image(i, imgs[i])
             assert same(got, ref.match_pairs(pairs))

@@ -59,5 +59,8 @@ tail)   # the exact re-check at 64 VGPRs (co-resident with s
     python tools/step_timeline.py "$DB" 2 > $OUT/step_timeline.txt 2>&1; tail -1 $OUT/step_timeline.txt | cut -c1-300
     find $OUT -type f -size +8M -delete
     ;;
+cli)   # where the CLI's wall clock goes
+    run cli_e2e python tools/cli_e2e_bench.py; head -3 $OUT/cli_e2e.txt
+    ;;
 *) echo "unknown stage $STAGE"; exit 2;;
 esac
