@@ -655,12 +655,27 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
         long long max_ranges = 1;
         for (const PlanGroup& g : cp.groups) max_ranges = std::max<long long>(max_ranges, g.ranges);
         const long long slack = (long long)kPfWgRows * (long long)G + kPfWgRows;
-        // (route Q: plan A holds every live column once per 512-row block group of the other image)
-        const long long rows_cap = std::max<long long>(ctx->cmp_rows_hint + ctx->cmp_rows_hint / 2, (q8_refine ? cp.rows_ub_all_bits / 8 : cp.rows_ub / 4)) + slack;
+        // Capacities.  A fresh buffer is sized generously (1.5 x what the previous sub-batch needed, or a quarter of all rows before anything
+        // is known; route Q's plan A holds every live column once per 512-row block group of the other image: an eighth of those).  A buffer
+        // that EXISTS is kept as long as it holds what the previous sub-batch needed + 1/8: growing means hipFree + hipMalloc, and the
+        // hipFree waits for everything in flight on the device (round 4's second call of a job re-grew six buffers per scratch set by 4 %
+        // -- 1.5 x the first call's need against the first call's a-priori size -- and stalled 36 ms doing it).
+        const long long prior = q8_refine ? cp.rows_ub_all_bits / 8 : cp.rows_ub / 4;
+        const long long rows_min = (ctx->cmp_rows_hint > 0 ? ctx->cmp_rows_hint + ctx->cmp_rows_hint / 8 : prior) + slack;
+        long long rows_have = (long long)std::min(std::min(SC.d_cmp_tu.cap / 4, SC.d_live_idx.cap / 4), std::min(SC.d_row_pair.cap / 4, SC.d_row_src.cap / 8));
+        if (i8) rows_have = std::min<long long>(rows_have, (long long)(SC.d_cmp_n2.cap / 4));
+        if (q8_refine) rows_have = std::min<long long>(rows_have, (long long)std::min(SC.d_cmp_s0.cap / 4, SC.d_cmp_s1.cap / 4));
+        const long long rows_cap = rows_have >= rows_min ? rows_have : std::max<long long>(ctx->cmp_rows_hint + ctx->cmp_rows_hint / 2, prior) + slack;
         // (per group: 8 entries per compacted row rounded up to 1024, + 1024 -- plan_group_cap_units)
-        const long long cand_cap = std::max<long long>(8 * rows_cap + 2048LL * (long long)G, ctx->cand_hint);
+        const long long cand_min = std::max<long long>(8 * rows_min + 2048LL * (long long)G, ctx->cand_hint);
+        long long cand_have = (long long)(SC.d_cand.cap / sizeof(int2));
+        if (i8) cand_have = std::min<long long>(cand_have, (long long)(SC.d_cand_val.cap / 4));
+        const long long cand_cap = cand_have >= cand_min ? cand_have : std::max<long long>(8 * rows_cap + 2048LL * (long long)G, ctx->cand_hint);
         // (the list holds 8 x the longest per-XCD sub-list: twice the balanced size leaves room for skew)
-        const long long items_cap = std::max<long long>(2 * ((rows_cap / kPfWgRows + (long long)G) * max_ranges + 64) / 8 * 8, (ctx->items_hint + 64) / 8 * 8);
+        const long long items_min = std::max<long long>(2 * ((rows_min / kPfWgRows + (long long)G) * max_ranges + 64) / 8 * 8, (ctx->items_hint + 64) / 8 * 8);
+        const long long items_have = (long long)(SC.d_vitems.cap / sizeof(WorkItem)) / 8 * 8;
+        const long long items_cap = items_have >= items_min ? items_have
+                                                            : std::max<long long>(2 * ((rows_cap / kPfWgRows + (long long)G) * max_ranges + 64) / 8 * 8, (ctx->items_hint + 64) / 8 * 8);
         HIPCHK(ctx, SC.d_gtot.ensure(std::max<size_t>(1, G) * 4));
         HIPCHK(ctx, SC.d_grow0.ensure((4 * std::max<size_t>(1, G) + 8) * 8));   // grow0 | gpos[3] | fwd_items_x[8]
         HIPCHK(ctx, SC.d_cnt.ensure(std::max<size_t>(1, M) * 4));

@@ -45,6 +45,7 @@ struct DevBuf {
     size_t cap = 0;
     hipError_t ensure(size_t bytes) {
         if (bytes <= cap) return hipSuccess;
+        if (p && std::getenv("MSFM_DEBUG_TIMING")) std::fprintf(stderr, "[msfm alloc] regrow %p: %zu -> %zu bytes\n", (void*)this, cap, bytes);
         if (p) timed_free(p);
         p = nullptr;
         cap = 0;

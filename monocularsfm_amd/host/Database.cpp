@@ -74,6 +74,13 @@ void Database::Open(const std::string& path) {
     Exec(database_, "PRAGMA journal_mode=WAL");
     Exec(database_, "PRAGMA temp_store=MEMORY");
     Exec(database_, "PRAGMA foreign_keys=ON");
+    // Connection-local read path, not part of the on-disk contract: SQLite maps the file instead of copying every page through its
+    // cache with pread (the bulk load reads the whole descriptors table once: 341 MB for the South-Building-shaped database).
+    // MSFM_SQLITE_MMAP=0: off.
+    {
+        const char* e = std::getenv("MSFM_SQLITE_MMAP");
+        if (!(e && e[0] == '0')) Exec(database_, "PRAGMA mmap_size=4294967296");
+    }
     CreateTables();
     UpdateSchema();
     PrepareSQLStatements();

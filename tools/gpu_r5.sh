@@ -62,5 +62,44 @@ tail)   # the exact re-check at 64 VGPRs (co-resident with s
 cli)   # where the CLI's wall clock goes
     run cli_e2e python tools/cli_e2e_bench.py; head -3 $OUT/cli_e2e.txt
     ;;
+evidence)   # the round's evidence in one call on one box (copy what is judged into profiles/ as r05_*)
+    TMO=1500 run pytest_gpu python -m pytest tests -m gpu -q; tail -2 $OUT/pytest_gpu.txt
+    TMO=900 run bench python bench.py; python - <<'PY'
+import json
+d=json.loads([l for l in open("gpurun_out/r5/evidence/bench.txt") if l.startswith("{")][-1]); r=d["roofline"]
+json.dump(d, open("gpurun_out/r5/evidence/bench.json","w"), indent=1)
+print("ms_per_step", round(d["ms_per_step"],3), "value %.4g" % d["value"], "sustained", d["sustained_ms_per_step"], "frac", round(r["frac"],4), "solo", round(r["solo"]["frac"],4), "upload_ms", round(d["pcie_inclusive"]["upload_ms"],2))
+print("strong_u8", {k: d["strong_u8"].get(k) for k in ("value","seconds_per_step","sub_batches_per_step_rank0","matches_per_step","error")})
+print("end_to_end", {k: d["end_to_end"].get(k) for k in ("wall_s","phases_s","rows_written","ratio","ratio_vs_single_thread","error")})
+PY
+    BENCH="python $ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-e2e --sustained-steps 0 --u8-images 0 --no-solo"
+    cd /tmp
+    timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/prof_stats -- $BENCH > $OUT/prof_stats.log 2>&1; echo "stats rc=$?"
+    MSFM_PIPELINE=1 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/prof_stats_p1 -- $BENCH > $OUT/prof_stats_p1.log 2>&1; echo "stats p1 rc=$?"
+    timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $BENCH > $OUT/pmc_fetch.log 2>&1; echo "fetch rc=$?"
+    timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $BENCH > $OUT/pmc_write.log 2>&1; echo "write rc=$?"
+    timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/prof_u8_p1 -- python $ROOT/tools/job_ab.py --images 64 --pipeline 1 --warm 2 > $OUT/prof_u8_p1.log 2>&1; echo "stats u8 p1 rc=$?"
+    cd $ROOT
+    DB=$(ls -t $(find $OUT/prof_stats -name '*.db') | head -1)
+    python tools/rocprof_summary.py "$DB" "$BENCH" > $OUT/bench_kernel_stats.txt 2>&1; head -8 $OUT/bench_kernel_stats.txt | cut -c1-60,150-215
+    python tools/step_timeline.py "$DB" 2 > $OUT/step_timeline.txt 2>&1; tail -1 $OUT/step_timeline.txt | cut -c1-300
+    DB1=$(ls -t $(find $OUT/prof_stats_p1 -name '*.db') | head -1)
+    python tools/rocprof_summary.py "$DB1" "MSFM_PIPELINE=1 $BENCH" > $OUT/bench_kernel_stats_pipeline1.txt 2>&1; head -12 $OUT/bench_kernel_stats_pipeline1.txt | cut -c1-60,150-215
+    DBU=$(ls -t $(find $OUT/prof_u8_p1 -name '*.db') | head -1)
+    python tools/rocprof_summary.py "$DBU" "tools/job_ab.py --images 64 --pipeline 1 (byte job, 2016 pairs of 8192-row images, one sub-batch)" > $OUT/u8_kernel_stats_pipeline1.txt 2>&1; head -14 $OUT/u8_kernel_stats_pipeline1.txt | cut -c1-60,150-215
+    KERN="sweep_i8_kernel<1>,sweep_kernel<3>,pf_prune_q8_kernel,pf_assign_kernel,pf_exact_candidates_kernel,epilogue_kernel,fill_segs_kernel,st_float_kernel,st_i8_kernel,st_classify_kernel"
+    PMC_STEPS=5 python tools/pmc_summary.py $OUT/pmc_traffic_approx.json "$KERN" $OUT/pmc_fetch $OUT/pmc_write > $OUT/pmc_traffic.txt 2>&1; python - <<'PY'
+import json
+d=json.load(open("gpurun_out/r5/evidence/pmc_traffic_approx.json"))
+for k,v in d.items():
+    if k.startswith("_"): continue
+    print(k, {c:(round(x.get("per_launch_KB_mean",0)*x["launches"]/5/1e6,3),"GB/step",x["launches"]) for c,x in v.items()})
+PY
+    find $OUT -type f -size +8M -delete
+    run cli_e2e python tools/cli_e2e_bench.py; head -3 $OUT/cli_e2e.txt
+    MSFM_Q8=2 run fuzz_q8 python tools/fuzz_routes.py 901 1200; tail -1 $OUT/fuzz_q8.txt
+    run fuzz_default python tools/fuzz_routes.py 904 1500; tail -1 $OUT/fuzz_default.txt
+    run fuzz_jobs python tools/fuzz_jobs.py 905 600; tail -1 $OUT/fuzz_jobs.txt
+    ;;
 *) echo "unknown stage $STAGE"; exit 2;;
 esac
