@@ -30,7 +30,7 @@ def main():
     rng = np.random.default_rng(seed)
     ctx = _lib.Context(0)
     bad = 0
-    n_sub = n_demoted = n_q8 = n_i8 = n_mixed = 0
+    n_sub = n_demoted = n_q8 = n_i8 = n_mixed = n_chunks = 0
     for case in range(cases):
         n_img = int(rng.integers(3, 20))
         big = rng.random() < 0.35
@@ -82,6 +82,29 @@ def main():
             if not same(ref, got):
                 bad += 1
                 print("MISMATCH cut", case, kind, sizes, "max_pairs", mp, "scratch", sb, "parts", parts, flush=True)
+            if rng.random() < 0.5:   # the same cut through the STREAMING form: the chunks, concatenated, are the call's lists
+                offs, qts, ds = [np.zeros(1, np.int64)], [], []
+                for ch in ctx.match_pairs_stream(pairs, ratio, cc, md):
+                    offs.append(offs[-1][-1] + ch["offsets"][1:])
+                    qts.append(ch["qt"])
+                    ds.append(ch["dist"])
+                    n_chunks += 1
+                st = (np.concatenate(offs), np.concatenate(qts) if qts else np.zeros((0, 2), np.int32), np.concatenate(ds) if ds else np.zeros(0, F32))
+                if not same(ref, st):
+                    bad += 1
+                    print("MISMATCH stream", case, kind, sizes, "max_pairs", mp, "scratch", sb, "parts", parts, flush=True)
+        # a store rebuilt in another order / with images re-uploaded gives the same lists (uploads only copy; finalize builds)
+        if rng.random() < 0.25:
+            ctx.clear_images()
+            for i in reversed(range(n_img)):
+                ctx.upload_image(i, imgs[i])
+                if rng.random() < 0.3:
+                    ctx.finalize_store()
+            ctx.set_limits(0, 0)
+            ctx.set_pipeline(0)
+            if not same(ref, ctx.match_pairs(pairs, ratio, cc, md)):
+                bad += 1
+                print("MISMATCH store order", case, kind, sizes, flush=True)
         # the oracle on the whole list (row products bounded: the C oracle does ~1e9 descriptor pairs a second and core)
         work = float(sum(sizes[i] * sizes[j] for i, j in pairs))
         if work < 6e8:
@@ -98,7 +121,8 @@ def main():
                 print("   profile of the default call:", {x: pr[x] for x in ("sub_batches", "sweep1_q8_launches", "sweep1_i8_launches", "mixed_route_sub_batches",
                                                                            "demoted_pairs", "fallback_pairs", "prefilter_pairs", "plan_regrows")}, flush=True)
     print("job cases done, mismatches:", bad, "| sub-batches under the random cuts:", n_sub, "| route Q / integer sweep-1 launches (defaults):", n_q8, "/", n_i8,
-          "| sub-batches with BOTH first sweeps (twins + fp16):", n_mixed, "| pairs demoted from the integer route in mixed sub-batches:", n_demoted)
+          "| sub-batches with BOTH first sweeps (twins + fp16):", n_mixed, "| pairs demoted from the integer route in mixed sub-batches:", n_demoted,
+          "| chunks of the streaming form compared:", n_chunks)
     return 1 if bad else 0
 
 

@@ -97,9 +97,20 @@ for k,v in d.items():
 PY
     find $OUT -type f -size +8M -delete
     run cli_e2e python tools/cli_e2e_bench.py; head -3 $OUT/cli_e2e.txt
+    run upload_timing python tools/upload_timing.py; cat $OUT/upload_timing.txt
+    MSFM_DEBUG_TIMING=1 run cold_call_u8 python tools/cold_call.py u8 400; grep "context\|alloc\]" $OUT/cold_call_u8.txt | head -12
+    MSFM_DEBUG_TIMING=1 run cold_call_sb python tools/cold_call.py south-building; grep "context\|alloc\]" $OUT/cold_call_sb.txt | head -12
+    run two_runtimes python tools/two_runtimes_probe.py monocularsfm_amd/csrc/libmsfm_match.so; tail -2 $OUT/two_runtimes.txt
     MSFM_Q8=2 run fuzz_q8 python tools/fuzz_routes.py 901 1200; tail -1 $OUT/fuzz_q8.txt
     run fuzz_default python tools/fuzz_routes.py 904 1500; tail -1 $OUT/fuzz_default.txt
     run fuzz_jobs python tools/fuzz_jobs.py 905 600; tail -1 $OUT/fuzz_jobs.txt
+    ;;
+fuzz)   # long seeded fuzz on the final build: routes, jobs (incl. the streaming form and store rebuilds), verification
+    TMO=900 run fuzz_jobs python tools/fuzz_jobs.py 951 2500; tail -1 $OUT/fuzz_jobs.txt
+    TMO=600 MSFM_Q8=2 run fuzz_q8 python tools/fuzz_routes.py 952 3000; tail -1 $OUT/fuzz_q8.txt
+    TMO=600 run fuzz_default python tools/fuzz_routes.py 953 3000; tail -1 $OUT/fuzz_default.txt
+    TMO=600 MSFM_Q8=2 MSFM_Q8_DIRECT=0 run fuzz_refine python tools/fuzz_routes.py 954 1000; tail -1 $OUT/fuzz_refine.txt
+    TMO=300 run fuzz_verify python tools/fuzz_verify.py 955 300; tail -1 $OUT/fuzz_verify.txt
     ;;
 *) echo "unknown stage $STAGE"; exit 2;;
 esac

@@ -1,3 +1,5 @@
+"""Two HIP runtimes in one process (PyTorch-ROCm bundles its own libamdhip64.so; libmsfm_match.so links the system one): which order of
+initialisation works?  python tools/two_runtimes_probe.py <libmsfm_match.so>   -> profiles/r05_two_hip_runtimes.txt"""
 import ctypes as C, sys
 path = sys.argv[1]
 L = C.CDLL(path)

@@ -1,3 +1,5 @@
+"""Wall clock of uploading the bench job's 128 images + msfm_finalize_store on fresh contexts, one / two cores for the host copy
+(MSFM_UPLOAD_THREADS): python tools/upload_timing.py   -> profiles/r05_upload_timing.txt"""
 import os, sys, time, numpy as np
 sys.path.insert(0, '.')
 from monocularsfm_amd import _lib, synth
