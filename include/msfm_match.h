@@ -223,7 +223,9 @@ int msfm_fetch_matches_device(msfm_ctx* ctx, int32_t* d_out_qt, float* d_out_dis
  *                            device memory (for an RCCL send straight from HBM), the order-certificate counts.  The pointers are valid
  *                            until the next msfm_match_pairs_next / any other matching call on the context.  n_pairs == 0: done.
  * Between two calls the library keeps up to three sub-batches in flight exactly as msfm_match_pairs does; what is resident at any time
- * is the scratch of those (msfm_set_limits) plus their lists.  msfm_get_profile accumulates over the series. */
+ * is the scratch of those (msfm_set_limits) plus their lists.  msfm_get_profile accumulates over the series.  While a series is open
+ * (until the call that returns n_pairs == 0) the store must not change: uploads, msfm_subset_image and msfm_clear_images return
+ * MSFM_E_STATE; another matching call abandons the series (what it has in flight is drained first). */
 typedef struct msfm_chunk {
     int first_pair;                 /* index into the pair list given to msfm_match_pairs_begin */
     int n_pairs;                    /* 0: the series is complete */

@@ -120,7 +120,13 @@ struct GrowPinned {
         bytes = (bytes + kPiece - 1) / kPiece * kPiece;
         if (bytes <= reserved) return hipSuccess;
         release();
-        void* p = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+        // (the bound can be far beyond what the job will produce -- min(n1, n2) per pair -- and beyond what the system lets one mapping
+        // be: take what it gives; a job that outgrows the range is told to use the streaming form)
+        void* p = MAP_FAILED;
+        for (; bytes >= kPiece; bytes = (bytes / 2 + kPiece - 1) / kPiece * kPiece) {
+            p = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+            if (p != MAP_FAILED || bytes == kPiece) break;
+        }
         if (p == MAP_FAILED) return hipErrorOutOfMemory;
         base = static_cast<char*>(p);
         reserved = bytes;
@@ -575,6 +581,7 @@ struct msfm_ctx {
     msfm_profile prof = {};
     std::vector<hipEvent_t> ev_pool;
     MatchJob* job = nullptr;          // the matching call in progress (one at a time; the streaming form keeps it between calls)
+    bool series_open = false;         // a streaming series (msfm_match_pairs_begin .. _next) has sub-batches in flight: the store must not change
 };
 
 #define SC (*ctx->cur)

@@ -150,6 +150,7 @@ struct MatchJob {
     need_fix = !(prm.ratio <= 1.f);
 
         open = true;
+        ctx->series_open = streaming;
         return MSFM_OK;
     }
 
@@ -348,7 +349,7 @@ struct MatchJob {
             // segment with room for the whole sub-batch -- nothing moves, nothing is freed, no stream is drained
             const size_t need = base + (size_t)total + 1;
             if (ctx->res_qt.ensure_pinned(need * 8) != hipSuccess || ctx->res_dist.ensure_pinned(need * 4) != hipSuccess)
-                return fail(ctx, MSFM_E_DEVICE, "cannot page-lock the result lists");
+                return fail(ctx, MSFM_E_DEVICE, "cannot page-lock the result lists (beyond the reserved range or the host's memory): use msfm_match_pairs_begin / _next");
             if (total > 0) {
                 OutSeg* seg = ctx->out_used ? &ctx->out_segs[ctx->out_used - 1] : nullptr;
                 if (!seg || seg->cap - seg->count < (size_t)total) {
@@ -458,6 +459,7 @@ struct MatchJob {
         HIPCHK(ctx, hipEventElapsedTime(&ms, ev_begin, ev_end));
         ctx->prof.total_device_ms = ms;
         open = false;
+        ctx->series_open = false;
         if (std::getenv("MSFM_DEBUG_TIMING")) {
             AllocClock& c = alloc_clock();
             std::fprintf(stderr, "[msfm alloc] since the last report: %d hipMalloc %.1f ms (%.2f GiB), %d hipFree %.1f ms, %d hipHostMalloc %.1f ms (%.2f GiB)\n",

@@ -228,6 +228,7 @@ int msfm_get_profile(const msfm_ctx* ctx, msfm_profile* out) {
 // that the caller can free or reuse its buffers and a following call starts from an idle stream.
 static int drained(msfm_ctx* ctx, int rc) {
     if (rc != MSFM_OK && ctx) {
+        ctx->series_open = false;
         for (Scratch& sc : ctx->sc)
             if (sc.stream) (void)hipStreamSynchronize(sc.stream);
         ctx->cur = &ctx->sc[0];
@@ -295,7 +296,12 @@ static int match_pairs_impl(msfm_ctx* ctx, const int32_t* pairs, int n_pairs, co
     if (!ctx) return MSFM_E_INVALID;
     if (n_pairs < 0 || (n_pairs > 0 && !pairs) || !out_offsets) return fail(ctx, MSFM_E_INVALID, "bad pair list");
     MatchJob& job = *ctx->job;
-    job.open = false;   // (a streaming series left open is abandoned)
+    if (ctx->series_open) {   // a streaming series left open is abandoned: what it has in flight is drained first
+        const int rc0 = drain_streams(ctx);
+        if (rc0 != MSFM_OK) return rc0;
+        ctx->series_open = false;
+    }
+    job.open = false;
     int rc = job.start(ctx, pairs, n_pairs, params, verify, false);
     if (rc != MSFM_OK) return rc;
     while (job.more()) {
@@ -337,6 +343,11 @@ static int begin_impl(msfm_ctx* ctx, const int32_t* pairs, int n_pairs, const ms
         (!(v.threshold >= 0.0) || !(v.confidence > 0.0) || !(v.confidence < 1.0) || v.max_iters < 1 || v.max_iters > (1 << 16)))
         return fail(ctx, MSFM_E_INVALID, "bad verification parameters");
     MatchJob& job = *ctx->job;
+    if (ctx->series_open) {
+        const int rc0 = drain_streams(ctx);
+        if (rc0 != MSFM_OK) return rc0;
+        ctx->series_open = false;
+    }
     job.open = false;
     job.pairs_own.assign(pairs, pairs + 2 * (size_t)n_pairs);
     return job.start(ctx, job.pairs_own.data(), n_pairs, params, geometric_verification ? &v : nullptr, true);

@@ -470,6 +470,7 @@ extern "C" {
 
 int msfm_upload_image(msfm_ctx* ctx, int image_id, const void* desc, int n, int dim, int dtype) {
     if (!ctx) return MSFM_E_INVALID;
+    if (ctx->series_open) return fail(ctx, MSFM_E_STATE, "the store cannot change while a streaming series (msfm_match_pairs_begin .. _next) is open");
     if (image_id < 0 || image_id >= kSlots) return fail(ctx, MSFM_E_INVALID, "image id out of range");
     if (n < 0 || dim != MSFM_DIM) return fail(ctx, MSFM_E_INVALID, "descriptors must be n x 128");
     if (n >= (1 << 18)) return fail(ctx, MSFM_E_INVALID, "more than 2^18 - 1 rows (BFMatcher packs the train index in 18 bits)");
@@ -507,6 +508,7 @@ int msfm_store_info(const msfm_ctx* ctx, int64_t* out_device_bytes, int64_t* out
 
 int msfm_subset_image(msfm_ctx* ctx, int src_image_id, int dst_image_id, const int32_t* rows, int count) {
     if (!ctx) return MSFM_E_INVALID;
+    if (ctx->series_open) return fail(ctx, MSFM_E_STATE, "the store cannot change while a streaming series (msfm_match_pairs_begin .. _next) is open");
     if (src_image_id < 0 || src_image_id >= kSlots || dst_image_id < 0 || dst_image_id >= kSlots || src_image_id == dst_image_id)
         return fail(ctx, MSFM_E_INVALID, "bad image ids for msfm_subset_image");
     if (count < 0 || (count > 0 && !rows)) return fail(ctx, MSFM_E_INVALID, "bad row list");
@@ -547,6 +549,7 @@ int msfm_image_rows(const msfm_ctx* ctx, int image_id, int* out_n) {
 
 int msfm_clear_images(msfm_ctx* ctx) {
     if (!ctx) return MSFM_E_INVALID;
+    if (ctx->series_open) return fail(ctx, MSFM_E_STATE, "the store cannot change while a streaming series (msfm_match_pairs_begin .. _next) is open");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     for (Scratch& sc : ctx->sc)
         if (sc.stream) HIPCHK(ctx, hipStreamSynchronize(sc.stream));
@@ -561,6 +564,7 @@ int msfm_clear_images(msfm_ctx* ctx) {
 
 int msfm_upload_keypoints(msfm_ctx* ctx, int image_id, const float* kpts, int n, int stride_floats) {
     if (!ctx) return MSFM_E_INVALID;
+    if (ctx->series_open) return fail(ctx, MSFM_E_STATE, "the store cannot change while a streaming series (msfm_match_pairs_begin .. _next) is open");
     if (image_id < 0 || image_id >= kSlots) return fail(ctx, MSFM_E_INVALID, "image id out of range");
     if (n < 0 || (n > 0 && !kpts) || stride_floats < 2) return fail(ctx, MSFM_E_INVALID, "bad keypoint array");
     Image& im = ctx->images[(size_t)image_id];

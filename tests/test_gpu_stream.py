@@ -56,9 +56,16 @@ def test_stream_equals_one_call_under_forced_cuts(kind):
             if limit:
                 assert chunks == -(-len(pairs) // limit)
         ctx.set_limits()
-        # a series left open is abandoned by the next matching call
+        # a series left open: the store must not change under it; the next matching call abandons it
+        ctx.set_limits(max_pairs_per_batch=7)
         it = ctx.match_pairs_stream(pairs, **kw)
         next(it)
+        with pytest.raises(_lib.MsfmError) as err:
+            ctx.upload_image(0, imgs[0])
+        assert err.value.code == _lib.E_STATE
+        with pytest.raises(_lib.MsfmError):
+            ctx.clear_images()
+        ctx.set_limits()
         again = ctx.match_pairs(pairs, **kw)
         assert np.array_equal(again[0], ref[0]) and np.array_equal(again[1], ref[1])
         with pytest.raises(_lib.MsfmError):
