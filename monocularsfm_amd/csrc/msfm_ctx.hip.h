@@ -446,7 +446,7 @@ constexpr long long kMinPipelineCost = 15000000000LL;
 // Everything ONE device sub-batch in flight owns: its stream, the partial / plan / candidate / result scratch, the upload arenas
 // with their page-locked staging, the page-locked words the host reads at the end of the sub-batch, its share of the profile.  A
 // context has kInFlight (three) of them: while the tail of sub-batch k (thresholds, plan, sweep 2, exact re-check, epilogue,
-// copy-out) runs on one stream, the sweeps of sub-batches k + 1 and k + 2 are already queued on the others (match_pairs_impl).
+// copy-out) runs on one stream, the sweeps of sub-batches k + 1 and k + 2 are already queued on the others (MatchJob, msfm_job.hip.h).
 // Buffers grow on demand (DevBuf::ensure = hipFree + hipMalloc, both of which synchronise the DEVICE: a growth inside issue()
 // serialises the pipeline once -- in the first call of a job shape, and whenever a later sub-batch is larger than any before --
 // and is also what makes re-using a buffer safe that kernels queued earlier still read; steady state allocates nothing).

@@ -52,7 +52,7 @@ inline std::vector<long long> msfm_pipeline_marks(long long total, long long n_s
     return marks;
 }
 
-// Device scratch ONE image pair adds to a sub-batch, in bytes -- what match_pairs_impl (msfm_match.hip) cuts a call by, and
+// Device scratch ONE image pair adds to a sub-batch, in bytes -- what MatchJob::build (msfm_job.hip.h) cuts a call by, and
 // what the buffers of a scratch set really hold (round 3 charged 2 x a_blocks128 x n2pad 4-byte units per pair whatever the
 // route: 2.6 - 3.4 x what the matrix-core route allocates, so a "48 GiB" budget produced 200 sub-batches of config 4 on a
 // 58 GiB footprint).  n1pad / n2pad: rows padded to 512; blocks128 / blocks512: 128- / 512-row blocks of image 1.

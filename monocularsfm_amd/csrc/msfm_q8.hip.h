@@ -40,7 +40,7 @@
 
 // The twins' scale.  A context quantises with ONE scale s = 255 / m, m = the largest value of its twinned images rounded up to
 // a multiple of 1/16 (RootSIFT values rarely exceed 0.45: s ~ 580, error norms ~0.0056 instead of 0.0128 at s = 255); a
-// twin built under a smaller m is rebuilt at the start of the next matching call (msfm_match.hip: the loop over the call's images at the top of match_pairs_impl, build_q8_twin).  The
+// twin built under a smaller m is rebuilt at the start of the next matching call (msfm_store_host.hip.h: rebuild_stale_twins -> build_twins, from the resident fp32 rows).  The
 // real number the bounds are stated with is the float `inv` ~ 1 / s itself: the twin is a^ = q * inv EXACTLY.
 constexpr float kQ8LevelStep = 1.f / 16.f;
 // with twins at least this fine the twins' sweep yields thresholds tight enough to collect candidates with directly

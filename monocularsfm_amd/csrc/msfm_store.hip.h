@@ -203,7 +203,8 @@ __global__ void st_float_kernel(const StoreJob* __restrict__ jobs) {
     }
 }
 
-// the 16 digits of V = H0 - h (msfm_sweep_i8.hip.h: pf_digits_i8_kernel) as four packed words
+// the 16 digits of V = H0 - h as four packed words: V = d_0 - 128 (d_1 + ... + d_15), d_0 in [-128, -1], the rest filled greedily
+// (msfm_sweep_i8.hip.h says what the fifth k-step does with them; the host has checked the image's range: digit_centre)
 __device__ __forceinline__ i4v st_digits(int h, int h0) {
     const int V = h0 - h;
     const int Wp = (V + 128) >> 7;
