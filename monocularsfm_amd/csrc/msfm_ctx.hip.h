@@ -46,7 +46,13 @@ struct DevBuf {
     hipError_t ensure(size_t bytes) {
         if (bytes <= cap) return hipSuccess;
         if (p && std::getenv("MSFM_DEBUG_TIMING")) std::fprintf(stderr, "[msfm alloc] regrow %p: %zu -> %zu bytes\n", (void*)this, cap, bytes);
-        if (p) timed_free(p);
+        if (p) {
+            // kernels queued earlier (this sub-batch's or, on another stream, a sub-batch still in flight) may read the old buffer: wait for
+            // the device EXPLICITLY (rounds 3 / 4 leaned on hipFree doing so implicitly).  Rare by construction: buffers are kept while they
+            // hold the previous need + 1/8 (msfm_batch.hip.h), the result lists never re-grow (GrowPinned, OutSeg).
+            (void)hipDeviceSynchronize();
+            timed_free(p);
+        }
         p = nullptr;
         cap = 0;
         size_t want = bytes + bytes / 4 + 256;
@@ -447,9 +453,10 @@ constexpr long long kMinPipelineCost = 15000000000LL;
 // with their page-locked staging, the page-locked words the host reads at the end of the sub-batch, its share of the profile.  A
 // context has kInFlight (three) of them: while the tail of sub-batch k (thresholds, plan, sweep 2, exact re-check, epilogue,
 // copy-out) runs on one stream, the sweeps of sub-batches k + 1 and k + 2 are already queued on the others (MatchJob, msfm_job.hip.h).
-// Buffers grow on demand (DevBuf::ensure = hipFree + hipMalloc, both of which synchronise the DEVICE: a growth inside issue()
-// serialises the pipeline once -- in the first call of a job shape, and whenever a later sub-batch is larger than any before --
-// and is also what makes re-using a buffer safe that kernels queued earlier still read; steady state allocates nothing).
+// Buffers grow on demand (DevBuf::ensure = an explicit hipDeviceSynchronize + hipFree + hipMalloc: a growth inside issue()
+// serialises the pipeline once -- in the first call of a job shape, and whenever a later sub-batch is more than 1/8 larger than
+// any before -- and the explicit wait is what makes replacing a buffer safe that kernels queued earlier still read; steady
+// state allocates nothing).
 struct PfPending {                // what the end-of-batch synchronisation has to look at
     bool active = false, compact = false, i8 = false, q8 = false;
     size_t n_lists = 0, P = 0;

@@ -4,7 +4,7 @@
 // image is uploaded once.  Rounds 1-4 built an image INSIDE msfm_upload_image -- up to 11 hipMalloc, 6-8 kernel launches and 3-4
 // hipStreamSynchronize per image, from pageable memory: 52 ms for the 128 images of the bench job, more than a whole matching step
 // (VERDICT r04).  Now an upload only copies the caller's rows into the context's INBOX (device memory) and returns; the images of all
-// uploads since the last use are built TOGETHER by finalize_store (msfm_match.hip) -- before the first matching call, or on
+// uploads since the last use are built TOGETHER by finalize_store (msfm_store_host.hip.h) -- before the first matching call, or on
 // msfm_finalize_store -- with kernels that walk a TABLE of jobs (one per image, blockIdx.y):
 //
 //   st_classify_kernel   per image: max |row|^2, max |value|, all values integers 0..255? all in [0, 1]? min / max of floor(|x-128|^2 / 2)
