@@ -200,6 +200,11 @@ def end_to_end(cpu_rate, cpu_single_rate, n_images=128, n_desc=5000):
         shutil.copyfile(db_path, db2)     # (a second, untouched copy: the first run leaves its rows behind)
         cfg2 = os.path.join(tmp, "cfg2.yaml")
         open(cfg2, "w").write('%%YAML:1.0\ndatabase_path : "%s"\nSIFTmatch.match_type : 1\n' % db2)
+        # Both runs start on a device that has been left alone for a second: a process that initialises the HIP runtime within ~0.1 s of
+        # another GPU process's exit waits for the driver to finish tearing that one down -- hipGetDeviceCount 170-240 ms instead of
+        # 52 ms, with this executable and with a one-line HIP program alike (profiles/r05_hip_init_settle.txt).
+        settle_s = 1.0
+        time.sleep(settle_s)
         t0 = time.perf_counter()
         r = subprocess.run([exe, cfg], capture_output=True, text=True, env=env, timeout=600)
         wall = time.perf_counter() - t0
@@ -207,6 +212,7 @@ def end_to_end(cpu_rate, cpu_single_rate, n_images=128, n_desc=5000):
             return {"error": "ComputeMatches exited with %d: %s" % (r.returncode, r.stderr[-300:])}
         # ... and once more in another fresh process: the first GPU process on a box that has just been handed over also pays the
         # device's own wake-up (0.60 s against 0.41 s on one box: twice the time in "open database + device" and in the first launches)
+        time.sleep(settle_s)
         t0 = time.perf_counter()
         r2 = subprocess.run([exe, cfg2], capture_output=True, text=True, env=env, timeout=600)
         wall2 = time.perf_counter() - t0 if r2.returncode == 0 else None
@@ -221,7 +227,7 @@ def end_to_end(cpu_rate, cpu_single_rate, n_images=128, n_desc=5000):
         total = int((n_rows.sum() ** 2 - (n_rows ** 2).sum()) // 2)
         out = {"command": "monocularsfm_amd/host/ComputeMatches <yaml> (brute-force mode, pre-emptive filter and geometric verification on: the reference's defaults)",
                "wall_s": wall, "cold": True, "phases_s": phases, "phases_sum_s": sum(phases.values()),
-               "second_process_wall_s": wall2,
+               "second_process_wall_s": wall2, "settle_s_before_each_process": settle_s,
                "db_bytes": os.path.getsize(db_path), "db_build_s_untimed": build_s, "images": n_images, "pairs": pairs,
                "rows_written": int(rows), "matches_written": int(matches or 0), "descriptor_pairs": total,
                "file_cache": "warm (the database was written just before the run)",

@@ -40,16 +40,40 @@ inline hipError_t timed_host_malloc(void** p, size_t bytes) {
     return e;
 }
 
+// Device buffers REPLACED by larger ones while a matching call has sub-batches in flight wait here for a moment at which the call has
+// drained its streams anyway (a re-run, the end of the call): hipFree waits for the whole device, and a sub-batch that replaces buffers
+// while its predecessor's sweep 1 is running -- the first call of a job in a process: the scratch set still has the sizes of the call
+// before -- stalled its own launches behind that sweep (11 ms of the ComputeMatches executable's matching call, profiles/r05_cli_cold_call.txt).
+// Kernels and copies queued earlier may still read the old buffer: it stays valid until the flush.
+struct DeferredFrees {
+    std::vector<void*> dead, dead_host;   // device memory; page-locked host memory (hipHostFree waits for the device as well)
+    bool empty() const { return dead.empty() && dead_host.empty(); }
+    void flush() {   // (the caller has synchronised every stream that could touch them)
+        for (void* q : dead) timed_free(q);
+        for (void* q : dead_host) (void)hipHostFree(q);
+        dead.clear();
+        dead_host.clear();
+    }
+};
+inline thread_local DeferredFrees* t_deferred_frees = nullptr;   // set by MatchJob while it launches (a context is driven by one thread at a time)
+struct DeferFreesScope {
+    DeferredFrees* prev;
+    explicit DeferFreesScope(DeferredFrees* d) : prev(t_deferred_frees) { static const bool off = std::getenv("MSFM_AB_NO_DEFER") != nullptr; t_deferred_frees = off ? nullptr : d; }
+    ~DeferFreesScope() { t_deferred_frees = prev; }
+};
+
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
     hipError_t ensure(size_t bytes) {
         if (bytes <= cap) return hipSuccess;
         if (p && std::getenv("MSFM_DEBUG_TIMING")) std::fprintf(stderr, "[msfm alloc] regrow %p: %zu -> %zu bytes\n", (void*)this, cap, bytes);
-        if (p) {
-            // kernels queued earlier (this sub-batch's or, on another stream, a sub-batch still in flight) may read the old buffer: wait for
-            // the device EXPLICITLY (rounds 3 / 4 leaned on hipFree doing so implicitly).  Rare by construction: buffers are kept while they
-            // hold the previous need + 1/8 (msfm_batch.hip.h), the result lists never re-grow (GrowPinned, OutSeg).
+        if (p && t_deferred_frees) {
+            t_deferred_frees->dead.push_back(p);
+        } else if (p) {
+            // kernels queued earlier may read the old buffer: wait for the device EXPLICITLY (rounds 3 / 4 leaned on hipFree doing so
+            // implicitly).  Rare by construction: buffers are kept while they hold the prediction + 1/8 (msfm_batch.hip.h), the
+            // result lists never re-grow (GrowPinned, OutSeg).
             (void)hipDeviceSynchronize();
             timed_free(p);
         }
@@ -88,26 +112,69 @@ struct DevBuf {
     template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
 };
 
+// Small page-locked buffers (the staging of a sub-batch's tables, the words read back at its end, the store's job tables) are pieces of
+// ONE block per context: hipHostMalloc costs ~1 ms per call whatever the size, and a fresh process's first job made fifteen of them
+// (12 - 17 ms of the ComputeMatches executable's 0.4 s; profiles/r05_cli_cold_call.txt).  A piece is never handed back (a buffer that
+// re-grows takes a new one); what does not fit gets its own allocation as before.
+struct PinnedPool {
+    char* base = nullptr;
+    size_t cap = 0, used = 0;
+    bool failed = false;
+    static constexpr size_t kBytes = (size_t)16 << 20, kLargestPiece = (size_t)4 << 20;
+    void* take(size_t bytes) {
+        bytes = (bytes + 255) & ~(size_t)255;
+        if (failed || bytes > kLargestPiece) return nullptr;
+        if (!base) {
+            void* q = nullptr;
+            if (timed_host_malloc(&q, kBytes) != hipSuccess) {
+                failed = true;
+                return nullptr;
+            }
+            base = static_cast<char*>(q);
+            cap = kBytes;
+        }
+        if (used + bytes > cap) return nullptr;
+        void* p = base + used;
+        used += bytes;
+        return p;
+    }
+    void release() {
+        if (base) (void)hipHostFree(base);
+        base = nullptr;
+        cap = used = 0;
+    }
+};
+
 // page-locked host memory, grow-only and content-preserving (result lists of a call accumulate over its sub-batches)
 struct PinnedBuf {
     void* p = nullptr;
     size_t cap = 0;
+    PinnedPool* pool = nullptr;   // set once by msfm_create for the small buffers
+    bool pooled = false;          // p is a piece of the pool: not freed on its own
     hipError_t ensure(size_t bytes, size_t keep, size_t hint = 0) {
         if (bytes <= cap) return hipSuccess;
         size_t want = std::max(bytes + bytes / 2 + 4096, hint);
-        void* q = nullptr;
-        hipError_t e = timed_host_malloc(&q, want);
-        if (e != hipSuccess) return e;
+        void* q = pool ? pool->take(want) : nullptr;
+        const bool from_pool = q != nullptr;
+        if (!q) {
+            const hipError_t e = timed_host_malloc(&q, want);
+            if (e != hipSuccess) return e;
+        }
         if (p && keep) std::memcpy(q, p, keep);
-        if (p) (void)hipHostFree(p);
+        if (p && !pooled) {
+            if (t_deferred_frees) t_deferred_frees->dead_host.push_back(p);
+            else (void)hipHostFree(p);
+        }
         p = q;
         cap = want;
+        pooled = from_pool;
         return hipSuccess;
     }
     void release() {
-        if (p) (void)hipHostFree(p);
+        if (p && !pooled) (void)hipHostFree(p);
         p = nullptr;
         cap = 0;
+        pooled = false;
     }
     template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
 };
@@ -122,6 +189,14 @@ struct GrowPinned {
     char* base = nullptr;
     size_t reserved = 0, pinned = 0;   // [0, pinned) is page-locked
     static constexpr size_t kPiece = (size_t)32 << 20;
+    // Where the piece that holds byte `off` ends.  The first 32 MiB are cut finer -- 1, 1, 2, 4, 8, 16 MiB --: page-locking costs 0.2 ms
+    // per MiB, and the lists of a small call (the pre-emptive filter's: a few KB) paid 2 x 6.4 ms for a 32-MiB piece each.
+    static size_t piece_end(size_t off) {
+        if (off >= kPiece) return (off / kPiece + 1) * kPiece;
+        size_t end = (size_t)1 << 20;
+        while (end <= off) end *= 2;
+        return end;
+    }
     hipError_t reserve(size_t bytes) {
         bytes = (bytes + kPiece - 1) / kPiece * kPiece;
         if (bytes <= reserved) return hipSuccess;
@@ -142,14 +217,15 @@ struct GrowPinned {
     hipError_t ensure_pinned(size_t upto) {
         if (upto > reserved) return hipErrorOutOfMemory;
         while (pinned < upto) {
+            const size_t piece = piece_end(pinned) - pinned;
             const double t0 = AllocClock::now();
-            const hipError_t e = hipHostRegister(base + pinned, kPiece, hipHostRegisterDefault);
+            const hipError_t e = hipHostRegister(base + pinned, piece, hipHostRegisterDefault);
             AllocClock& c = alloc_clock();
             c.pin_ms += AllocClock::now() - t0;
-            c.pin_bytes += (long long)kPiece;
+            c.pin_bytes += (long long)piece;
             c.pin_n += 1;
             if (e != hipSuccess) return e;
-            pinned += kPiece;
+            pinned += piece;
         }
         return hipSuccess;
     }
@@ -158,7 +234,7 @@ struct GrowPinned {
     hipError_t copy_in(size_t off, const void* dev, size_t bytes, hipStream_t stream) {
         const char* s = static_cast<const char*>(dev);
         while (bytes) {
-            const size_t n = std::min(bytes, kPiece - off % kPiece);
+            const size_t n = std::min(bytes, piece_end(off) - off);
             const hipError_t e = hipMemcpyAsync(base + off, s, n, hipMemcpyDeviceToHost, stream);
             if (e != hipSuccess) return e;
             off += n;
@@ -168,7 +244,7 @@ struct GrowPinned {
         return hipSuccess;
     }
     void release() {
-        for (size_t off = 0; off < pinned; off += kPiece) (void)hipHostUnregister(base + off);
+        for (size_t off = 0; off < pinned; off = piece_end(off)) (void)hipHostUnregister(base + off);
         if (base) munmap(base, reserved);
         base = nullptr;
         reserved = pinned = 0;
@@ -461,6 +537,7 @@ struct PfPending {                // what the end-of-batch synchronisation has t
     bool active = false, compact = false, i8 = false, q8 = false;
     size_t n_lists = 0, P = 0;
     long long rows_cap = 0, cand_cap = 0, items_cap = 0;
+    long long rows_ub = 0;            // the rows this sub-batch could compact at most: what its needs are relative to (the next prediction)
     int compact_pairs = 0;
     long long dense_swept = 0;
     size_t ev_base = 0;
@@ -555,6 +632,7 @@ struct msfm_ctx {
     unsigned up_seq = 0;
     DevBuf d_jobs, d_store_maxima;    // finalize_store's job table and its per-job maxima (two sets of 8 words per job)
     PinnedBuf h_jobs, h_store_maxima;
+    PinnedPool pinned_pool;           // the small page-locked buffers of the context and its scratch sets
     hipEvent_t jobs_ev = nullptr;     // behind the last copy out of h_jobs
     size_t store_peak_bytes = 0;      // largest store.bytes() seen (msfm_store_info)
     std::vector<OutSeg> out_segs;     // the match lists of the whole call on the device (msfm_fetch_matches_device)
@@ -575,7 +653,9 @@ struct msfm_ctx {
     float q8_level = 0.f;             // m: largest value of the twinned images so far, rounded up to a multiple of 1/16 (msfm_q8.hip.h)
     int q8_direct = 1;                // thresholds for sweep 2 straight from the twins' sweep when they are fine enough (MSFM_Q8_DIRECT=0: never, 2: always)
     int q8_route = 1;                 // float images in [0, 1] get byte twins and their first sweep on the integer cores (MSFM_Q8=0: off)
-    long long cmp_rows_hint = 0;      // compacted rows the previous batch needed (sizes the next batch's buffers)
+    DeferredFrees deferred;           // device buffers replaced while sub-batches were in flight: freed when the call has drained
+    long long cmp_rows_hint = 0;      // compacted rows the previous batch needed (sizes the next batch's buffers) ...
+    long long hint_rows_ub = 0;       // ... of the rows it could compact at most: the prediction scales with that, and is void beyond a factor 2
     long long items_hint = 0, cand_hint = 0;   // likewise: work items, candidate-list capacity
 
     // results of the last msfm_match_pairs call

@@ -72,6 +72,10 @@ struct MatchJob {
         s.sweep2_recorded = false;
     }
     ctx->last_sweep1 = nullptr;
+    if (!ctx->deferred.empty()) {   // (what the call before replaced: nothing is in flight now, and nobody waits for a result)
+        HIPCHK(ctx, hipDeviceSynchronize());
+        ctx->deferred.flush();
+    }
     // uploads since the last use are built now (msfm_store_host.hip.h); twins built before a later upload raised the context's level
     // (msfm_q8.hip.h) are rebuilt: nothing is in flight
     {
@@ -401,11 +405,14 @@ struct MatchJob {
     // launch ahead as many sub-batches as there are free scratch sets, wait for the oldest one (re-running it alone if a buffer was too
     // small): *slot_out = the scratch set whose sub-batch has just been completed
     int step(int* slot_out) {
+        const DeferFreesScope defer(&ctx->deferred);   // buffers replaced below are freed once the streams have been drained
         const std::vector<char> no_force;
         while (next_begin < n_pairs && issued - completed < kSets) {
             const int slot = (int)(issued % kSets);
+            int rc = ensure_scratch_set(ctx, slot);
+            if (rc != MSFM_OK) return rc;
             ctx->cur = &ctx->sc[slot];
-            int rc = build(sb[slot], next_begin, no_force);
+            rc = build(sb[slot], next_begin, no_force);
             if (rc != MSFM_OK) return rc;
             rc = issue(sb[slot], 2 + 12 * (size_t)slot);
             if (rc != MSFM_OK) return rc;
@@ -422,6 +429,7 @@ struct MatchJob {
             // drop what is in flight behind it, re-run this sub-batch alone until it fits, carry on from its end
             rc = drain_streams(ctx);
             if (rc != MSFM_OK) return rc;
+            ctx->deferred.flush();
             for (int k = 0; k < kSets; ++k)
                 if (k != slot) {
                     sb[k].active = false;
@@ -452,6 +460,7 @@ struct MatchJob {
     int finish() {
         int rc = drain_streams(ctx);
         if (rc != MSFM_OK) return rc;
+        // (ctx->deferred is flushed by the next call's start or msfm_destroy: a hipFree is ~0.1 ms, and the caller is waiting for its lists)
         ctx->cur = &ctx->sc[0];
         HIPCHK(ctx, hipEventRecord(ev_end, SC.stream));
         HIPCHK(ctx, hipEventSynchronize(ev_end));

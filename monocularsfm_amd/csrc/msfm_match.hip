@@ -58,15 +58,57 @@ static void destroy_streams(msfm_ctx* ctx);
 static MatchJob* new_match_job();
 static void delete_match_job(MatchJob* j);
 
+// The stream and the events of scratch set k exist.  A stream is a hardware queue: ~11 ms to create on this part -- msfm_create makes
+// the first, a call that puts a second / third sub-batch in flight the others, at a moment when the device is busy with the sub-batch before
+// and the host is ahead of it (the ComputeMatches executable on the South-Building job: one set for the pre-emptive filter, two for the
+// pairs: 22 ms less in front of the first upload, 11 of them never spent).
+int ensure_scratch_set(msfm_ctx* ctx, int k) {
+    Scratch& sc = ctx->sc[k];
+    if (sc.stream) return MSFM_OK;
+    hipError_t e = hipSuccess;
+    if ((e = hipStreamCreateWithFlags(&sc.stream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&sc.sweep1_done, hipEventDisableTiming)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&sc.sweep2_done, hipEventDisableTiming)) != hipSuccess)
+        return fail(ctx, MSFM_E_DEVICE, std::string("stream / events of a scratch set: ") + hipGetErrorString(e));
+    return MSFM_OK;
+}
+
+// msfm_create behind the device checks: streams and events of the scratch sets, the kernels' LDS attributes, the zero row
+static int create_rest(msfm_ctx* ctx) {
+    auto bad = [ctx](const char* what, hipError_t e) { return fail(ctx, MSFM_E_DEVICE, std::string("msfm_create: ") + what + ": " + hipGetErrorString(e)); };
+    hipError_t e = hipSuccess;
+    // (the first scratch set's stream -- uploads and the store build use it as well; the other sets get theirs when a call first has
+    // more than one sub-batch in flight: ensure_scratch_set)
+    if (ensure_scratch_set(ctx, 0) != MSFM_OK) return MSFM_E_DEVICE;
+    // dynamic LDS beyond 64 KiB: the brute-force kernel (108 KiB), the sweeps (94 / 124 KiB)
+    struct { const void* f; int bytes; } attrs[] = {
+        {reinterpret_cast<const void*>(dist_top2_kernel<0>), kLdsBytes},     {reinterpret_cast<const void*>(dist_top2_kernel<1>), kLdsBytes},
+        {reinterpret_cast<const void*>(dist_top2_kernel<3>), kLdsBytesIdxStash},
+        {reinterpret_cast<const void*>(sweep_kernel<1>), kPfLdsBytes},       {reinterpret_cast<const void*>(sweep_kernel<2>), kPfLdsBytes},
+        {reinterpret_cast<const void*>(sweep_kernel<3>), kPfLdsBytes},       {reinterpret_cast<const void*>(sweep_kernel<4>), kPfLdsBytes},
+        {reinterpret_cast<const void*>(sweep_i8_kernel<1>), kI8LdsBytes},    {reinterpret_cast<const void*>(sweep_i8_kernel<3>), kI8LdsBytes3},
+    };
+    for (const auto& a : attrs)
+        if ((e = hipFuncSetAttribute(a.f, hipFuncAttributeMaxDynamicSharedMemorySize, a.bytes)) != hipSuccess)
+            return bad("cannot reserve the kernels' LDS", e);
+    // the all-zero operand row the compacted sweep reads for rows without a source
+    if ((e = ctx->d_zero_row.ensure(kPfRowBytes)) != hipSuccess || (e = hipMemset(ctx->d_zero_row.p, 0, kPfRowBytes)) != hipSuccess)
+        return bad("the zero row", e);
+    return MSFM_OK;
+}
+
 int msfm_create(int device_ordinal, msfm_ctx** out_ctx) {
     if (!out_ctx) return MSFM_E_INVALID;
     *out_ctx = nullptr;
     int count = 0;
+    HostClock hc;   // MSFM_DEBUG_TIMING=1: where a context's creation goes (the runtime's own start-up is most of it)
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return MSFM_E_DEVICE;  // no GPU, no fallback
+    hc.lap("create: hipGetDeviceCount");
     if (device_ordinal < 0 || device_ordinal >= count) return MSFM_E_INVALID;
     if (hipSetDevice(device_ordinal) != hipSuccess) return MSFM_E_DEVICE;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_ordinal) != hipSuccess) return MSFM_E_DEVICE;
+    hc.lap("create: set device, properties");
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
         std::fprintf(stderr, "msfm_create: device %d is %s, this library is built for gfx950 only\n",
                      device_ordinal, prop.gcnArchName);
@@ -78,56 +120,26 @@ int msfm_create(int device_ordinal, msfm_ctx** out_ctx) {
     ctx->images.resize(kSlots);
     ctx->inbox.recycle = true;
     ctx->job = new_match_job();
+    for (Scratch& sc : ctx->sc) {
+        for (PinnedBuf& h : sc.h_up) h.pool = &ctx->pinned_pool;
+        sc.h_summary.pool = sc.h_tail.pool = &ctx->pinned_pool;
+    }
+    ctx->h_jobs.pool = ctx->h_store_maxima.pool = &ctx->pinned_pool;
     ctx->cu_count = prop.multiProcessorCount;
     ctx->clock_mhz = prop.clockRate / 1000;
     std::snprintf(ctx->dev_name, sizeof(ctx->dev_name), "%s (%s)", prop.name, prop.gcnArchName);
-    for (Scratch& sc : ctx->sc)
-        if (hipStreamCreateWithFlags(&sc.stream, hipStreamNonBlocking) != hipSuccess ||
-            hipEventCreateWithFlags(&sc.sweep1_done, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&sc.sweep2_done, hipEventDisableTiming) != hipSuccess) {
-            destroy_streams(ctx);
-            delete ctx;
-            return MSFM_E_DEVICE;
-        }
-    // the distance kernel needs 108 KiB of dynamic LDS
-    hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void*>(dist_top2_kernel<0>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
-    hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(dist_top2_kernel<1>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
-    if (e1 == hipSuccess)
-        e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(dist_top2_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytesIdxStash);
-    if (e0 != hipSuccess || e1 != hipSuccess) {
-        std::fprintf(stderr, "msfm_create: cannot reserve %d bytes of LDS: %s\n", kLdsBytes,
-                     hipGetErrorString(e0 != hipSuccess ? e0 : e1));
+    // (Round 5 tried the streams of the other scratch sets, the kernel attributes and the zero row on a helper thread, joined by the first
+    // matching call: 45 of msfm_create's 95 ms.  The runtime serialises them with the uploads the caller makes meanwhile -- the
+    // ComputeMatches executable's bulk load went from 48 to 72 ms --, so nothing was gained: profiles/r05_cli_cold_call.txt.)
+    if (create_rest(ctx) != MSFM_OK) {
+        std::fprintf(stderr, "%s\n", ctx->err.c_str());
         destroy_streams(ctx);
+        ctx->d_zero_row.release();
+        delete_match_job(ctx->job);
         delete ctx;
         return MSFM_E_DEVICE;
     }
-    hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(sweep_kernel<1>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, kPfLdsBytes);
-    hipError_t e3 = hipFuncSetAttribute(reinterpret_cast<const void*>(sweep_kernel<2>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, kPfLdsBytes);
-    hipError_t e4 = hipFuncSetAttribute(reinterpret_cast<const void*>(sweep_kernel<3>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, kPfLdsBytes);
-    if (e4 == hipSuccess)
-        e4 = hipFuncSetAttribute(reinterpret_cast<const void*>(sweep_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, kPfLdsBytes);
-    hipError_t e5 = hipFuncSetAttribute(reinterpret_cast<const void*>(sweep_i8_kernel<1>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, kI8LdsBytes);
-    hipError_t e6 = hipFuncSetAttribute(reinterpret_cast<const void*>(sweep_i8_kernel<3>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, kI8LdsBytes3);
-    if (e5 != hipSuccess || e6 != hipSuccess) e2 = e5 != hipSuccess ? e5 : e6;
-    if (e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess) {
-        std::fprintf(stderr, "msfm_create: cannot reserve %d bytes of LDS for the prefilter kernels\n", kPfLdsBytes);
-        destroy_streams(ctx);
-        delete ctx;
-        return MSFM_E_DEVICE;
-    }
-    // the all-zero operand row the compacted sweep reads for rows without a source
-    if (ctx->d_zero_row.ensure(kPfRowBytes) != hipSuccess || hipMemset(ctx->d_zero_row.p, 0, kPfRowBytes) != hipSuccess) {
-        destroy_streams(ctx);
-        delete ctx;
-        return MSFM_E_DEVICE;
-    }
+    hc.lap("create: streams, events, kernel attributes, zero row");
     if (const char* e = std::getenv("MSFM_PREFILTER")) ctx->prefilter = e[0] == '2' ? 2 : (e[0] != '0');
     if (const char* e = std::getenv("MSFM_MAX_PAIRS_PER_BATCH"))
         if (std::atoi(e) > 0) ctx->max_pairs_per_batch = std::min(std::atoi(e), kMaxPairsPerBatchLimit);
@@ -162,12 +174,16 @@ static void destroy_streams(msfm_ctx* ctx) {
 
 void msfm_destroy(msfm_ctx* ctx) {
     if (!ctx) return;
+    HostClock hc;   // MSFM_DEBUG_TIMING=1
     (void)hipSetDevice(ctx->device);
     for (Scratch& sc : ctx->sc)
         if (sc.stream) (void)hipStreamSynchronize(sc.stream);
+    ctx->deferred.flush();
     ctx->store.release_all();
     ctx->inbox.release_all();
+    hc.lap("destroy: store");
     for (Scratch& sc : ctx->sc) sc.release_all();
+    hc.lap("destroy: scratch sets");
     DevBuf* bufs[] = {&ctx->d_jobs, &ctx->d_store_maxima, &ctx->d_zero_row};
     for (DevBuf* b : bufs) b->release();
     for (OutSeg& s : ctx->out_segs) {
@@ -179,12 +195,15 @@ void msfm_destroy(msfm_ctx* ctx) {
     ctx->up_ring.release();
     ctx->h_jobs.release();
     ctx->h_store_maxima.release();
+    ctx->pinned_pool.release();   // (behind every buffer that holds a piece of it: the scratch sets' above)
+    hc.lap("destroy: result lists, page-locked memory");
     for (hipEvent_t e : ctx->up_ev)
         if (e) (void)hipEventDestroy(e);
     if (ctx->jobs_ev) (void)hipEventDestroy(ctx->jobs_ev);
     delete_match_job(ctx->job);
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
     destroy_streams(ctx);
+    hc.lap("destroy: events, streams");
     delete ctx;
 }
 
@@ -283,7 +302,8 @@ void add_profile(msfm_profile& to, const msfm_profile& d) {
 }
 
 int drain_streams(msfm_ctx* ctx) {
-    for (Scratch& s : ctx->sc) HIPCHK(ctx, hipStreamSynchronize(s.stream));
+    for (Scratch& s : ctx->sc)
+        if (s.stream) HIPCHK(ctx, hipStreamSynchronize(s.stream));
     return MSFM_OK;
 }
 
@@ -422,12 +442,14 @@ int msfm_memory_info(msfm_ctx* ctx, msfm_memory* out) {
     out->device_total = (int64_t)total_b;
     out->store = (int64_t)ctx->store.bytes();
     out->inbox = (int64_t)ctx->inbox.bytes();
-    size_t pinned = ctx->up_ring.cap + ctx->h_jobs.cap + ctx->h_store_maxima.cap + ctx->res_qt.pinned + ctx->res_dist.pinned;
+    // (buffers that are pieces of the context's pool count once, with the pool)
+    auto own = [](const PinnedBuf& h) { return h.pooled ? (size_t)0 : h.cap; };
+    size_t pinned = ctx->pinned_pool.cap + ctx->up_ring.cap + own(ctx->h_jobs) + own(ctx->h_store_maxima) + ctx->res_qt.pinned + ctx->res_dist.pinned;
     long long scratch = 0;
     for (Scratch& sc : ctx->sc) {
         scratch += sc.device_bytes();
-        for (const PinnedBuf& h : sc.h_up) pinned += h.cap;
-        pinned += sc.h_summary.cap + sc.h_tail.cap + sc.h_sub_qt.cap + sc.h_sub_d.cap;
+        for (const PinnedBuf& h : sc.h_up) pinned += own(h);
+        pinned += own(sc.h_summary) + own(sc.h_tail) + sc.h_sub_qt.cap + sc.h_sub_d.cap;
     }
     out->scratch = scratch;
     for (const OutSeg& s : ctx->out_segs) out->results_device += (int64_t)(s.qt.cap + s.d.cap);

@@ -360,7 +360,9 @@ void FeatureMatcher::MatchImagePairGroups(const std::vector<std::vector<std::pai
                 verified[(size_t)p].swap(prune_matches);
             verify_seconds[(size_t)p] = pair_timer.ElapsedSeconds();
         };
-        const int nthreads = std::max(1, std::min<int>(P / 4 + 1, (int)std::thread::hardware_concurrency()));
+        // (the host twin of FilterMatches runs RANSAC per pair: all cores; otherwise this loop only copies the lists -- starting a
+        // thread per core of a 256-core host cost 10 ms for 1 ms of copying)
+        const int nthreads = host_verify ? std::max(1, std::min<int>(P / 4 + 1, (int)std::thread::hardware_concurrency())) : 1;
         std::atomic<int> next(0);
         std::vector<std::thread> pool;
         for (int t = 1; t < nthreads; ++t)

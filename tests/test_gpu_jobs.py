@@ -334,17 +334,17 @@ def test_tie_queue_grows_instead_of_failing(built_lib, oracle):
 
 @pytest.mark.parametrize("twins", [True, False])
 def test_plan_regrow_with_sub_batches_in_flight(oracle, twins):
-    """A fresh context sizes the sweep-2 plan from a guess (a quarter of the rows).  Data on which most rows stay alive
-    (half of every image is a shared set of rows, ratio 0.95) outgrows it: the sub-batch is dropped while its successor is
+    """A fresh context sizes the sweep-2 plan from a guess (5/16 of the rows).  Data on which most rows stay alive
+    (1150 rows of every image are a shared set, ratio 0.95) outgrows it: the sub-batch is dropped while its successor is
     already in flight on the other stream, everything is drained, it is re-run alone and the loop carries on behind it.
     Same lists as the brute-force route; the profile counts the re-runs."""
     from monocularsfm_amd import _lib
     rng = np.random.default_rng(3)
     sizes = [1500, 1400, 1600, 1300, 1550, 1450]
     imgs = synth.rootsift_images(len(sizes), sizes, seed=91, n_proto=4000)
-    shared = imgs[0][:700].copy()
+    shared = imgs[0][:1150].copy()
     for k, im in enumerate(imgs):
-        rows = rng.choice(len(im), 700, replace=False)
+        rows = rng.choice(len(im), 1150, replace=False)
         v = np.abs(shared * (1 + 0.01 * rng.standard_normal(shared.shape).astype(F32)))
         im[rows] = (v / np.linalg.norm(v, axis=1, keepdims=True)).astype(F32)
         if not twins:
@@ -376,6 +376,35 @@ def test_plan_regrow_with_sub_batches_in_flight(oracle, twins):
             os.environ["MSFM_Q8"] = old
     assert got[0][-1] > 3000
     check_pairs_vs_oracle(oracle, imgs, pairs, np.arange(len(pairs)), *got, nthreads=8, **kw)
+
+
+@pytest.mark.gpu
+def test_a_small_call_before_a_large_one_does_not_cost_the_large_one_a_re_run(oracle):
+    """The ComputeMatches executable's order of calls in a fresh process: the pre-emptive filter (every pair on 100-row subsets:
+    FeatureMatching.cpp:148-203) and then the pairs on the full images.  What the small call needed says nothing about the large one:
+    the prediction of the sweep-2 plan's buffers is relative to the rows a sub-batch could compact at most and void beyond a factor
+    two (round 5: the buffers kept from the small call made the large call's first sub-batch overflow its plan -- two sub-batches
+    dropped and re-run, 45 ms of the executable's 0.41 s)."""
+    from monocularsfm_amd import _lib
+    n_img = 20
+    imgs = synth.rootsift_images(n_img, [2400 + 37 * k for k in range(n_img)], seed=77, n_proto=6000)
+    pairs = synth.all_pairs(n_img)
+    kw = {"ratio": 0.8, "cross_check": True, "max_distance": 0.7}
+    with _lib.Context(0) as ctx:
+        for i, im in enumerate(imgs):
+            ctx.upload_image(i, im)
+            ctx.subset_image(i, 100 + i, np.arange(0, 100, dtype=np.int32) * 7)
+        small = ctx.match_pairs(pairs + 100, **kw)
+        assert ctx.profile()["prefilter_pairs"] == len(pairs)
+        got = ctx.match_pairs(pairs, **kw)
+        p = ctx.profile()
+        assert p["prefilter_pairs"] == len(pairs) and p["plan_regrows"] == 0, p
+        again = ctx.match_pairs(pairs, **kw)
+        assert ctx.profile()["plan_regrows"] == 0 and same_result(got, again)
+        small2 = ctx.match_pairs(pairs + 100, **kw)     # ... and back: the large call's buffers hold the small one
+        assert ctx.profile()["plan_regrows"] == 0 and same_result(small, small2)
+    assert got[0][-1] > 1000
+    check_pairs_vs_oracle(oracle, imgs, pairs, np.arange(0, len(pairs), 9), *got, nthreads=8, **kw)
 
 
 @pytest.mark.gpu

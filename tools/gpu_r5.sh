@@ -112,5 +112,40 @@ fuzz)   # long seeded fuzz on the final build: routes, jobs (incl. the streaming
     TMO=600 MSFM_Q8=2 MSFM_Q8_DIRECT=0 run fuzz_refine python tools/fuzz_routes.py 954 1000; tail -1 $OUT/fuzz_refine.txt
     TMO=300 run fuzz_verify python tools/fuzz_verify.py 955 300; tail -1 $OUT/fuzz_verify.txt
     ;;
+final)   # the final tree once more: the GPU suite, the default bench line, the kernel statistics of the timed region
+    TMO=1500 run pytest_gpu python -m pytest tests -m gpu -q; tail -2 $OUT/pytest_gpu.txt
+    TMO=900 run bench python bench.py; python - <<'PY'
+import json
+d=json.loads([l for l in open("gpurun_out/r5/final/bench.txt") if l.startswith("{")][-1]); r=d["roofline"]
+json.dump(d, open("gpurun_out/r5/final/bench.json","w"), indent=1)
+print("ms_per_step", round(d["ms_per_step"],3), "value %.4g" % d["value"], "sustained", d["sustained_ms_per_step"], "frac", round(r["frac"],4), "solo", round(r["solo"]["frac"],4), "upload_ms", round(d["pcie_inclusive"]["upload_ms"],2), "traffic_source", r.get("traffic_source"))
+print("strong_u8", {k: d["strong_u8"].get(k) for k in ("value","seconds_per_step","matches_per_step","error")})
+print("end_to_end", {k: d["end_to_end"].get(k) for k in ("wall_s","second_process_wall_s","phases_s","rows_written","ratio","error")})
+PY
+    BENCH="python $ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-e2e --sustained-steps 0 --u8-images 0 --no-solo"
+    cd /tmp; timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/prof_stats -- $BENCH > $OUT/prof_stats.log 2>&1; echo "stats rc=$?"; cd $ROOT
+    DB=$(ls -t $(find $OUT/prof_stats -name '*.db') | head -1)
+    python tools/rocprof_summary.py "$DB" "$BENCH" > $OUT/bench_kernel_stats.txt 2>&1; head -8 $OUT/bench_kernel_stats.txt | cut -c1-60,150-215
+    find $OUT -type f -size +8M -delete
+    ;;
+clidbg)   # where a COLD process's matching call goes: the executable under MSFM_DEBUG_TIMING and under a kernel trace
+    python - <<'PY' > $OUT/setup.txt 2>&1
+import os, sys
+sys.path.insert(0, os.getcwd())
+from monocularsfm_amd import synth
+os.makedirs("/tmp/clidbg", exist_ok=True)
+synth.south_building_database("/tmp/clidbg/sb.db", 128, 5000, seed=1234)
+open("/tmp/clidbg/cfg.yaml", "w").write('%YAML:1.0\ndatabase_path : "/tmp/clidbg/sb.db"\nSIFTmatch.match_type : 1\n')
+PY
+    EXE=$ROOT/monocularsfm_amd/host/ComputeMatches
+    for k in 1 2; do cp /tmp/clidbg/sb.db /tmp/clidbg/run.db; sed 's/sb.db/run.db/' /tmp/clidbg/cfg.yaml > /tmp/clidbg/run.yaml
+        MSFM_CLI_TIMING=1 MSFM_DEBUG_TIMING=1 $EXE /tmp/clidbg/run.yaml > $OUT/cli_$k.out 2> $OUT/cli_$k.err; echo "cli $k rc=$?"; done
+    grep -v "^\[msfm alloc\] regrow" $OUT/cli_2.err | tail -60
+    cp /tmp/clidbg/sb.db /tmp/clidbg/run.db
+    cd /tmp; timeout 300 rocprofv3 --kernel-trace -d $OUT/prof -- $EXE /tmp/clidbg/run.yaml > $OUT/prof.log 2>&1; echo "trace rc=$?"; cd $ROOT
+    DB=$(ls -t $(find $OUT/prof -name '*.db') | head -1)
+    python tools/process_timeline.py "$DB" 150 > $OUT/cli_process_timeline.txt 2>&1; tail -70 $OUT/cli_process_timeline.txt | cut -c1-140
+    find $OUT -type f -size +8M -delete
+    ;;
 *) echo "unknown stage $STAGE"; exit 2;;
 esac
