@@ -4,6 +4,7 @@
 # Output: gpurun_out/r5/<stage>/ ; what is judged is copied to profiles/r05_* (index: profiles/r05_README.md).
 # tools/_ab/libmsfm_match_r04.so = the library of commit 73e894c (round 4's final build):
 #   git worktree add /tmp/w 73e894c && make -C /tmp/w/monocularsfm_amd/csrc && cp /tmp/w/monocularsfm_amd/csrc/libmsfm_match.so tools/_ab/libmsfm_match_r04.so
+# tools/_ab/libmsfm_match_head.so = likewise, commit c5c0334 (before the cold matching call was looked at: stage cliab)
 set -u
 STAGE=${1:-probe}
 ROOT=$(pwd); OUT=$ROOT/gpurun_out/r5/$STAGE; rm -rf $OUT; mkdir -p $OUT; export TMPDIR=/tmp
@@ -146,6 +147,28 @@ PY
     DB=$(ls -t $(find $OUT/prof -name '*.db') | head -1)
     python tools/process_timeline.py "$DB" 150 > $OUT/cli_process_timeline.txt 2>&1; tail -70 $OUT/cli_process_timeline.txt | cut -c1-140
     find $OUT -type f -size +8M -delete
+    ;;
+cliab)   # the executable, cold, this tree against the library of an earlier commit (tools/_ab/libmsfm_match_head.so: see the header), alternating
+    python - <<'PY' > $OUT/setup.txt 2>&1
+import os, sys
+sys.path.insert(0, os.getcwd())
+from monocularsfm_amd import synth
+os.makedirs("/tmp/clidbg", exist_ok=True)
+synth.south_building_database("/tmp/clidbg/sb.db", 128, 5000, seed=1234)
+open("/tmp/clidbg/run.yaml", "w").write('%YAML:1.0\ndatabase_path : "/tmp/clidbg/run.db"\nSIFTmatch.match_type : 1\n')
+PY
+    EXE=$ROOT/monocularsfm_amd/host/ComputeMatches
+    for round in 1 2 3 4 5 6; do for v in tree before; do
+        cp /tmp/clidbg/sb.db /tmp/clidbg/run.db; sleep 1
+        t0=$(date +%s.%N)
+        if [ $v = before ]; then LD_PRELOAD=$ROOT/tools/_ab/libmsfm_match_head.so MSFM_CLI_TIMING=1 $EXE /tmp/clidbg/run.yaml > /dev/null 2> /tmp/clidbg/err.txt
+        else MSFM_CLI_TIMING=1 $EXE /tmp/clidbg/run.yaml > /dev/null 2> /tmp/clidbg/err.txt; fi
+        t1=$(date +%s.%N)
+        echo "$v wall $(python -c "print('%.3f' % ($t1 - $t0))") $(grep 'msfm timing' /tmp/clidbg/err.txt | sed 's/\[msfm timing\] //')"
+    done; done | tee $OUT/cli_ab.txt
+    ;;
+settle)   # HIP start-up against the time since the previous GPU process exited
+    run hip_init_settle bash tools/hip_init_settle.sh; cat $OUT/hip_init_settle.txt
     ;;
 *) echo "unknown stage $STAGE"; exit 2;;
 esac
