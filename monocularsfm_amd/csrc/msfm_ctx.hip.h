@@ -58,7 +58,7 @@ struct DeferredFrees {
 inline thread_local DeferredFrees* t_deferred_frees = nullptr;   // set by MatchJob while it launches (a context is driven by one thread at a time)
 struct DeferFreesScope {
     DeferredFrees* prev;
-    explicit DeferFreesScope(DeferredFrees* d) : prev(t_deferred_frees) { static const bool off = std::getenv("MSFM_AB_NO_DEFER") != nullptr; t_deferred_frees = off ? nullptr : d; }
+    explicit DeferFreesScope(DeferredFrees* d) : prev(t_deferred_frees) { t_deferred_frees = d; }
     ~DeferFreesScope() { t_deferred_frees = prev; }
 };
 

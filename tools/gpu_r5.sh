@@ -121,7 +121,7 @@ d=json.loads([l for l in open("gpurun_out/r5/final/bench.txt") if l.startswith("
 json.dump(d, open("gpurun_out/r5/final/bench.json","w"), indent=1)
 print("ms_per_step", round(d["ms_per_step"],3), "value %.4g" % d["value"], "sustained", d["sustained_ms_per_step"], "frac", round(r["frac"],4), "solo", round(r["solo"]["frac"],4), "upload_ms", round(d["pcie_inclusive"]["upload_ms"],2), "traffic_source", r.get("traffic_source"))
 print("strong_u8", {k: d["strong_u8"].get(k) for k in ("value","seconds_per_step","matches_per_step","error")})
-print("end_to_end", {k: d["end_to_end"].get(k) for k in ("wall_s","second_process_wall_s","phases_s","rows_written","ratio","error")})
+print("end_to_end", {k: d["end_to_end"].get(k) for k in ("wall_s","walls_s","phases_s","rows_written","ratio","error")})
 PY
     BENCH="python $ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-e2e --sustained-steps 0 --u8-images 0 --no-solo"
     cd /tmp; timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/prof_stats -- $BENCH > $OUT/prof_stats.log 2>&1; echo "stats rc=$?"; cd $ROOT
