@@ -7,6 +7,8 @@
 // constructor defaults (0.7 / 0.8 / true) are what run.  MSFM_HONOUR_YAML_MATCH_PARAMS=1 opts
 // into using the YAML values instead.
 #include <cassert>
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <iostream>
 #include <memory>
@@ -18,7 +20,18 @@
 
 using namespace MonocularSfM;
 
+namespace {
+// MSFM_CLI_TIMING=1: the wall clock (seconds since the epoch) at which main() was entered and left, on stderr -- against the caller's own
+// clock around the process they bound what the loader (before) and the runtimes' exit handlers (after) take
+void StampWallClock(const char* what) {
+    if (!std::getenv("MSFM_CLI_TIMING")) return;
+    const double now = std::chrono::duration<double>(std::chrono::system_clock::now().time_since_epoch()).count();
+    std::fprintf(stderr, "[msfm timing] %s at %.6f\n", what, now);
+}
+}  // namespace
+
 int main(int argc, char** argv) {
+    StampWallClock("main entered");
     if (argc != 2) {
         std::cout << "You need specify the YAML file path!" << std::endl;
         exit(-1);
@@ -67,5 +80,7 @@ int main(int argc, char** argv) {
     timer.Start();
     matcher->RunMatching();
     timer.PrintMinutes();
+    matcher.reset();
+    StampWallClock("main left");
     return 0;
 }

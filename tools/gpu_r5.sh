@@ -134,7 +134,9 @@ clidbg)   # where a COLD process's matching call goes: the executable under MSFM
 import os, sys
 sys.path.insert(0, os.getcwd())
 from monocularsfm_amd import synth
-os.makedirs("/tmp/clidbg", exist_ok=True)
+import shutil
+shutil.rmtree("/tmp/clidbg", ignore_errors=True)
+os.makedirs("/tmp/clidbg")
 synth.south_building_database("/tmp/clidbg/sb.db", 128, 5000, seed=1234)
 open("/tmp/clidbg/cfg.yaml", "w").write('%YAML:1.0\ndatabase_path : "/tmp/clidbg/sb.db"\nSIFTmatch.match_type : 1\n')
 PY
@@ -153,7 +155,9 @@ cliab)   # the executable, cold, this tree against the library of an earlier com
 import os, sys
 sys.path.insert(0, os.getcwd())
 from monocularsfm_amd import synth
-os.makedirs("/tmp/clidbg", exist_ok=True)
+import shutil
+shutil.rmtree("/tmp/clidbg", ignore_errors=True)
+os.makedirs("/tmp/clidbg")
 synth.south_building_database("/tmp/clidbg/sb.db", 128, 5000, seed=1234)
 open("/tmp/clidbg/run.yaml", "w").write('%YAML:1.0\ndatabase_path : "/tmp/clidbg/run.db"\nSIFTmatch.match_type : 1\n')
 PY
