@@ -223,7 +223,7 @@ def end_to_end(cpu_rate, cpu_single_rate, n_images=128, n_desc=5000):
         walls = [w for w, _, _ in runs]
         wall, r, db_used = sorted(runs, key=lambda x: x[0])[1]
         phases = {}
-        for name, val in re.findall(r"([a-zA-Z+\- ]+?) ([0-9.]+) s(?: \||$)", (r.stderr.strip().splitlines() or [""])[-1].replace("[msfm timing] ", "")):
+        for name, val in re.findall(r"([a-zA-Z+\- ]+?) ([0-9.]+) s(?: \||$)", ([l for l in r.stderr.splitlines() if "exist-check" in l] or [""])[-1].replace("[msfm timing] ", "")):
             phases[name.strip()] = float(val)
         con = sqlite3.connect(db_used)
         rows, matches = con.execute("SELECT COUNT(*), SUM(rows) FROM matches").fetchone()

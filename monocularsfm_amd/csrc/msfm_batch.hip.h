@@ -654,40 +654,18 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
         n_lists = G;
         long long max_ranges = 1;
         for (const PlanGroup& g : cp.groups) max_ranges = std::max<long long>(max_ranges, g.ranges);
-        const long long slack = (long long)kPfWgRows * (long long)G + kPfWgRows;
-        // Capacities.  What the previous sub-batch needed (compacted rows, candidate entries, work items) is the prediction for this one --
-        // RELATIVE to the rows the two sub-batches could compact at most (the parts of one call, and the calls of a repeated job, are alike;
-        // a call of another kind -- the pre-emptive filter's 100-row subsets before the full images -- is not: its needs say nothing, and
-        // measured in round 5 a buffer kept from it made the first sub-batch of the ComputeMatches executable's main call overflow its plan,
-        // which dropped and re-ran two sub-batches: 45 ms of a 0.41 s process).  Without a usable prediction: 5/16 of all rows (all of them
-        // for a small sub-batch) (route Q
-        // direct keeps ~20 % alive on SIFT-like data, each group padded to 512; plan A of the refining route holds every live column once
-        // per 512-row block group of the other image: 5/32 of those).  A buffer that EXISTS is kept as long as it holds the prediction
-        // + 1/8; a fresh one gets 1.5 x: growing means a device synchronisation + hipFree + hipMalloc (round 4's second call of a job
-        // re-grew six buffers per scratch set by 4 % and stalled 36 ms doing it).
+        // Capacities: msfm_plan_room (msfm_hostutil.h) -- a prediction relative to the rows this sub-batch could compact at most; existing
+        // buffers are kept while they hold it.
         const long long ub = q8_refine ? cp.rows_ub_all_bits : cp.rows_ub;
-        const bool hinted = ctx->cmp_rows_hint > 0 && ctx->hint_rows_ub > 0 && ub <= 2 * ctx->hint_rows_ub && 2 * ub >= ctx->hint_rows_ub;
-        const double hscale = hinted ? (double)ub / (double)ctx->hint_rows_ub : 0.0;
-        const long long rows_hint = (long long)((double)ctx->cmp_rows_hint * hscale), items_hint = (long long)((double)ctx->items_hint * hscale),
-                        cand_hint = (long long)((double)ctx->cand_hint * hscale);
-        // (a small sub-batch -- up to 2 M rows: 0.25 GB of plan buffers -- gets room for every row: on the pre-emptive filter's 100-row
-        // subsets more than half of the rows stay alive)
-        const long long prior = std::max<long long>(q8_refine ? cp.rows_ub_all_bits * 5 / 32 : cp.rows_ub * 5 / 16, std::min<long long>(ub, 1LL << 21));
-        const long long rows_min = (hinted ? rows_hint + rows_hint / 8 : prior) + slack;
         long long rows_have = (long long)std::min(std::min(SC.d_cmp_tu.cap / 4, SC.d_live_idx.cap / 4), std::min(SC.d_row_pair.cap / 4, SC.d_row_src.cap / 8));
         if (i8) rows_have = std::min<long long>(rows_have, (long long)(SC.d_cmp_n2.cap / 4));
         if (q8_refine) rows_have = std::min<long long>(rows_have, (long long)std::min(SC.d_cmp_s0.cap / 4, SC.d_cmp_s1.cap / 4));
-        const long long rows_cap = rows_have >= rows_min ? rows_have : std::max<long long>(rows_hint + rows_hint / 2, prior) + slack;
-        // (per group: 8 entries per compacted row rounded up to 1024, + 1024 -- plan_group_cap_units)
-        const long long cand_min = std::max<long long>(8 * rows_min + 2048LL * (long long)G, cand_hint);
         long long cand_have = (long long)(SC.d_cand.cap / sizeof(int2));
         if (i8) cand_have = std::min<long long>(cand_have, (long long)(SC.d_cand_val.cap / 4));
-        const long long cand_cap = cand_have >= cand_min ? cand_have : std::max<long long>(8 * rows_cap + 2048LL * (long long)G, cand_hint);
-        // (the list holds 8 x the longest per-XCD sub-list: twice the balanced size leaves room for skew)
-        const long long items_min = std::max<long long>(2 * ((rows_min / kPfWgRows + (long long)G) * max_ranges + 64) / 8 * 8, (items_hint + 64) / 8 * 8);
         const long long items_have = (long long)(SC.d_vitems.cap / sizeof(WorkItem)) / 8 * 8;
-        const long long items_cap = items_have >= items_min ? items_have
-                                                            : std::max<long long>(2 * ((rows_cap / kPfWgRows + (long long)G) * max_ranges + 64) / 8 * 8, (items_hint + 64) / 8 * 8);
+        const MsfmPlanRoom room = msfm_plan_room(ub, q8_refine ? cp.rows_ub_all_bits * 5 / 32 : cp.rows_ub * 5 / 16, (long long)G, max_ranges, kPfWgRows,
+                                                 ctx->hint_rows_ub, ctx->cmp_rows_hint, ctx->cand_hint, ctx->items_hint, rows_have, cand_have, items_have);
+        const long long rows_cap = room.rows, cand_cap = room.cand, items_cap = room.items;
         SC.pf_pending.rows_ub = ub;
         HIPCHK(ctx, SC.d_gtot.ensure(std::max<size_t>(1, G) * 4));
         HIPCHK(ctx, SC.d_grow0.ensure((4 * std::max<size_t>(1, G) + 8) * 8));   // grow0 | gpos[3] | fwd_items_x[8]

@@ -189,14 +189,9 @@ struct GrowPinned {
     char* base = nullptr;
     size_t reserved = 0, pinned = 0;   // [0, pinned) is page-locked
     static constexpr size_t kPiece = (size_t)32 << 20;
-    // Where the piece that holds byte `off` ends.  The first 32 MiB are cut finer -- 1, 1, 2, 4, 8, 16 MiB --: page-locking costs 0.2 ms
-    // per MiB, and the lists of a small call (the pre-emptive filter's: a few KB) paid 2 x 6.4 ms for a 32-MiB piece each.
-    static size_t piece_end(size_t off) {
-        if (off >= kPiece) return (off / kPiece + 1) * kPiece;
-        size_t end = (size_t)1 << 20;
-        while (end <= off) end *= 2;
-        return end;
-    }
+    // (pieces of 1, 1, 2, 4, 8, 16, 32, 32, ... MiB: msfm_pinned_piece_end, msfm_hostutil.h -- the lists of a small call, the pre-emptive
+    // filter's few KB, paid 2 x 6.4 ms for a 32-MiB piece each)
+    static size_t piece_end(size_t off) { return (size_t)msfm_pinned_piece_end(off); }
     hipError_t reserve(size_t bytes) {
         bytes = (bytes + kPiece - 1) / kPiece * kPiece;
         if (bytes <= reserved) return hipSuccess;

@@ -83,6 +83,48 @@ inline long long msfm_pair_scratch_bytes(int n1, int n2, int n1pad, int n2pad, i
     return common + partials + (route == 3 ? 120LL : 84LL) * cmp_rows;
 }
 
+// Room for the device-side plan of sweep 2 (compacted rows, candidate entries, work items) of a sub-batch that could compact `ub` rows at
+// most, in `groups` groups of at most `max_ranges` ranges -- MatchJob sizes the buffers BEFORE the plan exists.  The prediction is what
+// the previous sub-batch needed (hint_*), scaled by the ratio of the two upper bounds and void beyond a factor two: the parts of a call and
+// the calls of a repeated job are alike, a call of another kind (the pre-emptive filter's 100-row subsets before the full images) says
+// nothing.  Without one: `prior_16ths` / 16 of the rows (5 on the direct routes, 2.5 -> the caller passes rows_ub_all_bits * 5 / 32 as
+// `ub_prior`), and all rows for a small sub-batch (up to 2 M rows = 0.25 GB of plan buffers: on 100-row subsets more than half stay alive).
+// A buffer that EXISTS (have_*) is kept as long as it holds the prediction + 1/8, a fresh one gets 1.5 x the prediction: growing means
+// replacing the buffer.  (Round 5, first half: absolute hints -- the buffers kept from the small call counted as large enough for the
+// large call's first sub-batch, whose plan then overflowed: profiles/r05_cli_cold_call.txt.)
+struct MsfmPlanRoom { long long rows, cand, items; bool hinted; };
+inline MsfmPlanRoom msfm_plan_room(long long ub, long long ub_prior, long long groups, long long max_ranges, int wg_rows,
+                                   long long hint_ub, long long hint_rows, long long hint_cand, long long hint_items,
+                                   long long have_rows, long long have_cand, long long have_items) {
+    auto mx = [](long long a, long long b) { return a > b ? a : b; };
+    const long long slack = (long long)wg_rows * groups + wg_rows;
+    const bool hinted = hint_rows > 0 && hint_ub > 0 && ub <= 2 * hint_ub && 2 * ub >= hint_ub;
+    const double s = hinted ? (double)ub / (double)hint_ub : 0.0;
+    const long long h_rows = (long long)((double)hint_rows * s), h_cand = (long long)((double)hint_cand * s), h_items = (long long)((double)hint_items * s);
+    const long long prior = mx(ub_prior, ub < (1LL << 21) ? ub : (1LL << 21));
+    const long long rows_min = (hinted ? h_rows + h_rows / 8 : prior) + slack;
+    MsfmPlanRoom r;
+    r.hinted = hinted;
+    r.rows = have_rows >= rows_min ? have_rows : mx(h_rows + h_rows / 2, prior) + slack;
+    // (per group: 8 entries per compacted row rounded up to 1024, + 1024 -- plan_group_cap_units)
+    const long long cand_min = mx(8 * rows_min + 2048 * groups, h_cand);
+    r.cand = have_cand >= cand_min ? have_cand : mx(8 * r.rows + 2048 * groups, h_cand);
+    // (the list holds 8 x the longest per-XCD sub-list: twice the balanced size leaves room for skew)
+    const long long items_min = mx(2 * ((rows_min / wg_rows + groups) * max_ranges + 64) / 8 * 8, (h_items + 64) / 8 * 8);
+    r.items = have_items >= items_min ? have_items : mx(2 * ((r.rows / wg_rows + groups) * max_ranges + 64) / 8 * 8, (h_items + 64) / 8 * 8);
+    return r;
+}
+
+// Where the page-locked piece of a call's result lists that holds byte `off` ends (GrowPinned, msfm_ctx.hip.h): the first 32 MiB are cut
+// 1, 1, 2, 4, 8, 16 MiB, then 32-MiB pieces -- page-locking costs 0.2 ms per MiB, and a small call's lists should cost a small piece.
+inline unsigned long long msfm_pinned_piece_end(unsigned long long off) {
+    const unsigned long long piece = 32ull << 20;
+    if (off >= piece) return (off / piece + 1) * piece;
+    unsigned long long end = 1ull << 20;
+    while (end <= off) end *= 2;
+    return end;
+}
+
 // One key into a slot's (best, second) -- the reduction of the exact re-check (pf_exact_candidates_kernel).  best ends as the
 // smallest key the slot ever saw, second as the second smallest DISTINCT key: every key but the final minimum loses exactly once
 // against `best` (when it arrives, or when a smaller one displaces it) and is then offered to `second`; a key arriving twice meets

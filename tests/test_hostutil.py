@@ -7,7 +7,9 @@
     end, the last one `taper` of the average;
   * the device scratch one image pair adds to a sub-batch (what a call is cut by), and its Python twin in tools/config4_full.py;
   * the fold of a candidate's key into a slot's (best, second) in the exact re-check -- the device kernel calls this very function
-    with atomicMin: 200 000 random arrival sequences with repeated keys, every arrival acting on a STALE look at the slot.
+    with atomicMin: 200 000 random arrival sequences with repeated keys, every arrival acting on a STALE look at the slot;
+  * the room a sub-batch's sweep-2 plan gets before the plan exists (msfm_plan_room): the executable's order of calls -- the pre-emptive
+    filter's subsets, then the full images -- with the numbers measured on the South-Building job; the page-locked pieces of the lists.
 The reference's counterpart of the second is the fixed 100-pair flush of BruteFeatureMatcher::RunMatching
 (/root/reference/src/Feature/FeatureMatching.cpp:118-139)."""
 import os
@@ -102,6 +104,49 @@ int main() {
             for (int i = 0; i < n; ++i) if (keys[i] < m0) m0 = keys[i];
             for (int i = 0; i < n; ++i) if (keys[i] != m0 && keys[i] < m1) m1 = keys[i];
             if (best != m0 || second != m1) { std::printf("fold: best %llx second %llx, want %llx %llx (n = %d)\n", best, second, m0, m1, n); return 1; }
+        }
+    }
+    // room for the sweep-2 plan: the ComputeMatches executable's order of calls (all pairs on 100-row subsets, then on the full images)
+    {
+        const int W = 512;
+        // the small call, nothing known: every row fits (its sub-batch is below 2 M rows)
+        const long long ub_s = 1625600, g_s = 255;
+        MsfmPlanRoom a = msfm_plan_room(ub_s, ub_s * 5 / 16, g_s, 1, W, 0, 0, 0, 0, 0, 0, 0);
+        if (a.hinted || a.rows < ub_s || a.cand < 8 * a.rows || a.items < 2 * (a.rows / W + g_s)) { std::printf("plan room: small call\n"); return 1; }
+        // the large call's first sub-batch, the small call's needs as the hint and its buffers in place: the hint is void (factor 25),
+        // the buffers are too small for 5/16 of the rows, fresh ones hold what the job really needs (measured: 10 457 600 rows)
+        const long long ub_l = 40875057, g_l = 8128;
+        MsfmPlanRoom b = msfm_plan_room(ub_l, ub_l * 5 / 16, g_l, 2, W, ub_s, 932352, 7335936, 1920, a.rows, a.cand, a.items);
+        if (b.hinted || b.rows < 10457600 + 10457600 / 8 || b.rows <= a.rows || b.cand < 83105792 || b.items < 20960) { std::printf("plan room: large call after small\n"); return 1; }
+        // (round 5's first half kept a.rows here: the absolute hint + 1/8 + slack was below them)
+        // its second sub-batch: alike -> hinted, the buffers are kept
+        MsfmPlanRoom c = msfm_plan_room(41025592, 41025592LL * 5 / 16, g_l, 2, W, ub_l, 10457600, 83105792, 20960, b.rows, b.cand, b.items);
+        if (!c.hinted || c.rows != b.rows || c.cand != b.cand || c.items != b.items) { std::printf("plan room: alike sub-batch re-sized\n"); return 1; }
+        // a sub-batch of the same kind, 1.8 x the size: the prediction scales with it
+        MsfmPlanRoom d = msfm_plan_room(ub_l * 9 / 5, ub_l * 9 / 5 * 5 / 16, g_l * 2, 2, W, ub_l, 10457600, 83105792, 20960, b.rows, b.cand, b.items);
+        if (!d.hinted || d.rows < 10457600LL * 9 / 5 * 9 / 8 || d.cand < 83105792LL * 9 / 5 || d.items < 20960LL * 9 / 5) { std::printf("plan room: scaled hint\n"); return 1; }
+        // back to the small call: the large call's buffers hold it, nothing is replaced
+        MsfmPlanRoom e = msfm_plan_room(ub_s, ub_s * 5 / 16, g_s, 1, W, 41025592, 10250240, 81693696, 42448, d.rows, d.cand, d.items);
+        if (e.hinted || e.rows != d.rows || e.cand != d.cand || e.items != d.items) { std::printf("plan room: small call after large\n"); return 1; }
+        // monotone: more rows never get less room (fresh buffers)
+        long long prev = 0;
+        for (long long ub = 1000; ub < 400000000LL; ub = ub * 3 / 2) {
+            const MsfmPlanRoom r = msfm_plan_room(ub, ub * 5 / 16, 64, 1, W, 0, 0, 0, 0, 0, 0, 0);
+            if (r.rows < prev || r.cand < 8 * r.rows) { std::printf("plan room: not monotone at %lld\n", ub); return 1; }
+            prev = r.rows;
+        }
+    }
+    // page-locked pieces of the result lists: they tile the range, 1 MiB first, 32 MiB from 32 MiB on, every end 4-KiB aligned
+    {
+        unsigned long long off = 0, n = 0;
+        const unsigned long long MiB = 1ull << 20, want[] = {1, 2, 4, 8, 16, 32, 64, 96};
+        while (off < 96 * MiB) {
+            const unsigned long long end = msfm_pinned_piece_end(off);
+            if (end != want[n] * MiB) { std::printf("pieces: %llu -> %llu\n", off, end); return 1; }
+            for (unsigned long long inside : {off, off + 1, (off + end) / 2, end - 1})
+                if (msfm_pinned_piece_end(inside) != end) { std::printf("pieces: inside %llu\n", inside); return 1; }
+            off = end;
+            ++n;
         }
     }
     std::printf("ok %lld\n", checked);

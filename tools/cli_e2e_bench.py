@@ -32,7 +32,7 @@ for label, env in (("geometric verification on the device (reference default flo
     r = subprocess.run([exe, c2], capture_output=True, text=True, env=e)
     dt = time.time() - t0
     assert r.returncode == 0, r.stderr[-500:]
-    print("   ", r.stderr.strip().splitlines()[-1] if r.stderr.strip() else "")
+    print("   ", ([l for l in r.stderr.splitlines() if "exist-check" in l] or [""])[-1])
     db = database.Database(db2)
     rows = db.db.execute("SELECT COUNT(*), SUM(rows) FROM matches").fetchone()
     db.Close()
