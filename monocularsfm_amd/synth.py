@@ -83,7 +83,8 @@ def keypoints(n, seed=0, width=3072, height=2304):
 
 def all_pairs(n_images):
     """BruteFeatureMatcher::RunMatching's enumeration (FeatureMatching.cpp:110-139): (i, j), j < i, i-major."""
-    return np.array([(i, j) for i in range(n_images) for j in range(i)], np.int32).reshape(-1, 2)
+    i, j = np.tril_indices(int(n_images), -1)      # row-major over the lower triangle = i-major, j ascending
+    return np.ascontiguousarray(np.stack([i, j], 1).astype(np.int32)).reshape(-1, 2)
 
 
 def job(workload="south-building", n_images=None, n_desc=None, seed=1234):

@@ -78,6 +78,7 @@ def main():
     ap.add_argument("--seed", type=int, default=1329)
     ap.add_argument("--warm", action="store_true", help="one untimed call first: the timed one runs on allocated buffers")
     ap.add_argument("--stream", action="store_true", help="msfm_match_pairs_begin / _next: bounded memory (see above)")
+    ap.add_argument("--cut-every", type=int, default=25, help="--stream: the pairs on either side of every N-th chunk cut go to the oracle")
     args = ap.parse_args()
     if args.stream:
         return stream_main(args)
@@ -216,7 +217,7 @@ def stream_main(args):
         offs, qt, d = ch["offsets"], ch["qt"], ch["dist"]
         chunks += 1
         M += int(offs[-1])
-        if chunks <= 3 or chunks % 25 == 0:                 # the pairs on either side of a cut
+        if chunks <= 3 or chunks % args.cut_every == 0:                 # the pairs on either side of a cut
             cuts += [first, first + n - 1]
             want |= {first, first + n - 1}
         for p in [p for p in want if first <= p < first + n]:
@@ -261,6 +262,7 @@ def stream_main(args):
     info = ctx.store_info()
     out = {
         "workload": name + (" -- BASELINE configs[3] in full" if (args.images, args.desc, args.seed) == (1329, 8192, 1329) else
+                            " -- BASELINE configs[4] IN FULL (4096 x 16384)" if (args.images, args.desc, args.seed) == (4096, 16384, 4096) else
                             " -- seeded subset of BASELINE configs[4] (4096 x 16384)" if (args.desc, args.seed) == (16384, 4096) else "") +
                     ", STREAMED: msfm_match_pairs_begin + one msfm_match_pairs_next per device sub-batch, one MI355X, first call of the process",
         "streaming": True, "chunks": chunks, "image_pairs": int(len(pairs)), "descriptor_pairs": total_desc_pairs, "matches": M,

@@ -1,0 +1,26 @@
+#!/bin/bash
+# Round 6: the GPU calls of the round, one stage per `gpurun` call (each box is fresh; comparisons happen inside one stage).
+#   /usr/local/graft/bin/gpurun --timeout 1500 -- 'bash tools/gpu_r6.sh <stage>'
+# Output: gpurun_out/r6/<stage>/ ; what is judged is copied to profiles/r06_* (index: profiles/r06_README.md).
+set -u
+STAGE=${1:-toggle}
+ROOT=$(pwd); OUT=$ROOT/gpurun_out/r6/$STAGE; rm -rf $OUT; mkdir -p $OUT; export TMPDIR=/tmp
+run() { local name=$1; shift; local t0=$(date +%s); timeout ${TMO:-600} "$@" > $OUT/$name.txt 2>$OUT/$name.err; echo "$name rc=$? ($(( $(date +%s) - t0 )) s)"; }
+
+case $STAGE in
+toggle)   # what the operand encoding costs the power-limited sweep 1
+    run operand_toggle python tools/operand_toggle.py; cat $OUT/operand_toggle.txt; tail -3 $OUT/operand_toggle.err
+    ;;
+cfg5full)   # BASELINE configs[4] IN FULL, streamed, one GPU
+    free -g | head -2
+    TMO=1700 run config5_full_stream python tools/config4_full.py --stream --images 4096 --desc 16384 --seed 4096 --oracle-pairs 24 --int-oracle-pairs 1 --cut-every 100
+    head -c 1800 $OUT/config5_full_stream.txt; echo; grep -n "GiB\|mismatch" $OUT/config5_full_stream.txt; tail -5 $OUT/config5_full_stream.err
+    ;;
+first)   # both of the above in one call
+    bash tools/gpu_r6.sh toggle
+    bash tools/gpu_r6.sh cfg5full
+    ;;
+*)
+    echo "unknown stage $STAGE"; exit 2
+    ;;
+esac
