@@ -8,7 +8,9 @@
  * src/Feature/FeatureMatching.cpp:36-49 and :163-170, and the Database blobs on either side.
  *
  * Conventions
- *   - plain C types only; every call returns an int status (MSFM_OK == 0), never throws,
+ *   - plain C types only; every call returns an int status (MSFM_OK == 0), never throws
+ *     (every entry point runs behind one exception barrier, csrc/msfm_guard.h: an allocation
+ *     failure inside the library comes back as MSFM_E_DEVICE, the context stays usable),
  *     never exits.  msfm_last_error() gives the text of the last failure on a context.
  *   - the caller owns all host buffers; the library owns all device memory.
  *   - descriptors are row-major, contiguous, 128 columns (cv::Mat CV_32F n x 128 as read by
@@ -245,6 +247,10 @@ struct msfm_verify_params;
 int msfm_match_pairs_begin(msfm_ctx* ctx, const int32_t* pairs, int n_pairs, const msfm_match_params* params,
                            int geometric_verification, const struct msfm_verify_params* verify);
 int msfm_match_pairs_next(msfm_ctx* ctx, msfm_chunk* out);
+/* Ends a series before its last chunk (a consumer that stops early, an error in the consumer's own loop): drains what the series has
+ * in flight, unlocks the store; a following msfm_match_pairs_next returns MSFM_E_STATE.  No series open: MSFM_OK, nothing happens.
+ * (The reference's counterpart is leaving the pair loop of FeatureMatcher::MatchImagePairs, src/Feature/FeatureMatching.cpp:14-72.) */
+int msfm_match_pairs_end(msfm_ctx* ctx);
 /* What the context holds right now, in bytes: the descriptor store, uploads waiting in the inbox, the scratch of the sub-batches in
  * flight (grow-only: its high-water mark), the call-wide result lists on the device (msfm_match_pairs; the streaming form has none),
  * page-locked host memory (result lists, staging); and the device's free / total memory (hipMemGetInfo). */

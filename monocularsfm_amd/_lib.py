@@ -26,7 +26,7 @@ EXPORTS = [
     "msfm_topscale_select", "msfm_pair_id", "msfm_pair_from_id", "msfm_swap_image_pair",
     "msfm_version", "msfm_upload_keypoints", "msfm_match_pairs_verified", "msfm_subset_image", "msfm_view_matches", "msfm_set_limits", "msfm_fetch_matches_device",
     "msfm_fetch_order_certificate", "msfm_set_pipeline", "msfm_device_count", "msfm_finalize_store", "msfm_store_info",
-    "msfm_match_pairs_begin", "msfm_match_pairs_next", "msfm_read_device", "msfm_memory_info",
+    "msfm_match_pairs_begin", "msfm_match_pairs_next", "msfm_read_device", "msfm_memory_info", "msfm_match_pairs_end",
 ]
 
 
@@ -106,6 +106,7 @@ def load():
         L.msfm_match_pairs_next.argtypes = [vp, C.POINTER(Chunk)]
         L.msfm_read_device.argtypes = [vp, vp, vp, C.c_int64]
         L.msfm_memory_info.argtypes = [vp, C.POINTER(Memory)]
+        L.msfm_match_pairs_end.argtypes = [vp]
     except AttributeError:
         pass
     L.msfm_match_pair.argtypes = [vp, C.c_int, C.c_int, C.c_float, C.c_int, C.c_double, ip, fp, C.POINTER(C.c_int)]
@@ -303,20 +304,28 @@ class Context:
         prm = MatchParams(ratio, int(bool(cross_check)), max_distance)
         self._chk(self._L.msfm_match_pairs_begin(self._h, _ip(pairs), pairs.shape[0], C.byref(prm), int(bool(verified)), None))
         ch = Chunk()
-        while True:
-            self._chk(self._L.msfm_match_pairs_next(self._h, C.byref(ch)))
-            n = ch.n_pairs
-            if n == 0:
-                return
-            m = int(ch.count)
-            offs = np.ctypeslib.as_array(ch.offsets, shape=(n + 1,))
-            qt = np.ctypeslib.as_array(ch.qt, shape=(m, 2)) if m else np.zeros((0, 2), np.int32)
-            d = np.ctypeslib.as_array(ch.dist, shape=(m,)) if m else np.zeros(0, np.float32)
-            sens = np.ctypeslib.as_array(ch.sensitive_rows, shape=(n,))
-            if copy:
-                offs, qt, d, sens = offs.copy(), qt.copy(), d.copy(), sens.copy()
-            yield {"first": ch.first_pair, "n_pairs": n, "offsets": offs, "qt": qt, "dist": d, "sensitive": sens,
-                   "d_qt": ch.d_qt, "d_dist": ch.d_dist}
+        done = False
+        try:
+            while True:
+                self._chk(self._L.msfm_match_pairs_next(self._h, C.byref(ch)))
+                n = ch.n_pairs
+                if n == 0:
+                    done = True
+                    return
+                m = int(ch.count)
+                offs = np.ctypeslib.as_array(ch.offsets, shape=(n + 1,))
+                qt = np.ctypeslib.as_array(ch.qt, shape=(m, 2)) if m else np.zeros((0, 2), np.int32)
+                d = np.ctypeslib.as_array(ch.dist, shape=(m,)) if m else np.zeros(0, np.float32)
+                sens = np.ctypeslib.as_array(ch.sensitive_rows, shape=(n,))
+                if copy:
+                    offs, qt, d, sens = offs.copy(), qt.copy(), d.copy(), sens.copy()
+                yield {"first": ch.first_pair, "n_pairs": n, "offsets": offs, "qt": qt, "dist": d, "sensitive": sens,
+                       "d_qt": ch.d_qt, "d_dist": ch.d_dist}
+        finally:
+            # a consumer that breaks out of the loop (GeneratorExit) or whose body raises must not leave the series open: the store
+            # would stay locked for uploads until the next matching call
+            if not done and getattr(self, "_h", None):
+                self._L.msfm_match_pairs_end(self._h)
 
     def memory_info(self):
         """Bytes the context holds (store, inbox, scratch, result lists, page-locked host) + the device's free / total memory."""

@@ -10,8 +10,10 @@ struct AllocClock {
     int dev_n = 0, pin_n = 0, free_n = 0;
     static double now() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 };
+// (per THREAD: a context is driven by one thread at a time and host/FeatureMatching.cpp runs one thread per context -- a process-wide
+// clock was a data race between them and mixed their figures)
 inline AllocClock& alloc_clock() {
-    static AllocClock c;
+    static thread_local AllocClock c;
     return c;
 }
 inline hipError_t timed_malloc(void** p, size_t bytes) {
@@ -436,6 +438,14 @@ struct StoreArena {
                     cur = (int)i;
                     return hipSuccess;
                 }
+        // a chunk with enough room behind what it holds becomes the current one again: an incremental caller (upload, keypoints, match,
+        // image after image) alternates exact-size image chunks with small keypoint requests -- without this every cycle abandoned a
+        // partly used 1-MiB keypoint chunk for a fresh one
+        for (size_t i = 0; i < chunks.size(); ++i)
+            if (chunks[i].base && chunks[i].used + bytes <= chunks[i].cap) {
+                cur = (int)i;
+                return hipSuccess;
+            }
         if (cur >= 0 && chunks[(size_t)cur].live == 0) free_chunk(cur);   // (an empty current chunk that is too small)
         int slot = -1;
         for (size_t i = 0; i < chunks.size(); ++i)
@@ -674,6 +684,14 @@ int fail(msfm_ctx* ctx, int code, const std::string& msg) {
     if (ctx) ctx->err = msg;
     return code;
 }
+
+// The exception barrier of the C ABI (msfm_guard.h): every `extern "C"` entry point runs its body between these two.  An exception leaves
+// the context usable: after_api_exception (msfm_match.hip) records the text, drains the streams and closes an open series.
+void after_api_exception(msfm_ctx* ctx, const char* text) noexcept;
+#define MSFM_API_BEGIN(ctxp) \
+    return msfm_guard([&](int, const char* t__) noexcept { after_api_exception(ctxp, t__); }, [&]() -> int {
+#define MSFM_API_END \
+    });
 
 #define HIPCHK(ctx, call)                                                                     \
     do {                                                                                      \

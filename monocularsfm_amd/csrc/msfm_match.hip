@@ -8,6 +8,7 @@
 // when there is none.
 #include "msfm_match.h"
 #include "msfm_hostutil.h"
+#include "msfm_guard.h"
 #include "msfm_kernels.hip.h"
 #include "msfm_prefilter.hip.h"
 #include "msfm_verify.hip.h"
@@ -43,6 +44,7 @@ extern "C" {
 const char* msfm_version(void) { return "msfm-match 0.1 (gfx950)"; }
 
 int msfm_device_count(void) {
+    MSFM_API_BEGIN(nullptr)
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return 0;
     int usable = 0;
@@ -52,6 +54,7 @@ int msfm_device_count(void) {
         ++usable;   // (ordinals are contiguous: the count of leading gfx950 devices)
     }
     return usable;
+    MSFM_API_END
 }
 
 static void destroy_streams(msfm_ctx* ctx);
@@ -98,6 +101,7 @@ static int create_rest(msfm_ctx* ctx) {
 }
 
 int msfm_create(int device_ordinal, msfm_ctx** out_ctx) {
+    MSFM_API_BEGIN(nullptr)
     if (!out_ctx) return MSFM_E_INVALID;
     *out_ctx = nullptr;
     int count = 0;
@@ -159,6 +163,7 @@ int msfm_create(int device_ordinal, msfm_ctx** out_ctx) {
         if (std::atoll(e) > 0) ctx->scratch_bytes = std::atoll(e) * (1LL << 20);
     *out_ctx = ctx;
     return MSFM_OK;
+    MSFM_API_END
 }
 
 static void destroy_streams(msfm_ctx* ctx) {
@@ -174,6 +179,7 @@ static void destroy_streams(msfm_ctx* ctx) {
 
 void msfm_destroy(msfm_ctx* ctx) {
     if (!ctx) return;
+    try {
     HostClock hc;   // MSFM_DEBUG_TIMING=1
     (void)hipSetDevice(ctx->device);
     for (Scratch& sc : ctx->sc)
@@ -205,42 +211,54 @@ void msfm_destroy(msfm_ctx* ctx) {
     destroy_streams(ctx);
     hc.lap("destroy: events, streams");
     delete ctx;
+    } catch (...) {   // (the C ABI never throws; nothing above is expected to)
+    }
 }
 
 const char* msfm_last_error(const msfm_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
 int msfm_device_info(const msfm_ctx* ctx, char* name, int name_cap, int* cu_count, int* clock_mhz) {
+    MSFM_API_BEGIN(nullptr)
     if (!ctx) return MSFM_E_INVALID;
     if (name && name_cap > 0) std::snprintf(name, (size_t)name_cap, "%s", ctx->dev_name);
     if (cu_count) *cu_count = ctx->cu_count;
     if (clock_mhz) *clock_mhz = ctx->clock_mhz;
     return MSFM_OK;
+    MSFM_API_END
 }
 
 int msfm_set_prefilter(msfm_ctx* ctx, int enable) {
+    MSFM_API_BEGIN(ctx)
     if (!ctx) return MSFM_E_INVALID;
     ctx->prefilter = enable == 2 ? 2 : (enable ? 1 : 0);
     return MSFM_OK;
+    MSFM_API_END
 }
 
 int msfm_set_limits(msfm_ctx* ctx, int max_pairs_per_batch, int64_t scratch_bytes) {
+    MSFM_API_BEGIN(ctx)
     if (!ctx) return MSFM_E_INVALID;
     // (the pair index of a sub-batch is gridDim.y of several kernels: at most 65535)
     ctx->max_pairs_per_batch = max_pairs_per_batch > 0 ? std::min(max_pairs_per_batch, kMaxPairsPerBatchLimit) : kDefaultMaxPairsPerBatch;
     ctx->scratch_bytes = scratch_bytes > 0 ? scratch_bytes : 0;
     return MSFM_OK;
+    MSFM_API_END
 }
 
 int msfm_set_pipeline(msfm_ctx* ctx, int min_sub_batches) {
+    MSFM_API_BEGIN(ctx)
     if (!ctx) return MSFM_E_INVALID;
     ctx->pipeline = min_sub_batches > 0 ? std::min(min_sub_batches, 64) : kDefaultPipeline;
     return MSFM_OK;
+    MSFM_API_END
 }
 
 int msfm_get_profile(const msfm_ctx* ctx, msfm_profile* out) {
+    MSFM_API_BEGIN(nullptr)
     if (!ctx || !out) return MSFM_E_INVALID;
     *out = ctx->prof;
     return MSFM_OK;
+    MSFM_API_END
 }
 
 // An error return may leave launches of the failed batch in flight: drain the stream before handing control back, so
@@ -311,17 +329,45 @@ int drain_streams(msfm_ctx* ctx) {
 
 #include "msfm_job.hip.h"
 
+namespace {
+// behind an exception caught at the C ABI (msfm_guard.h): the text for msfm_last_error, nothing left in flight, no series left open
+void after_api_exception(msfm_ctx* ctx, const char* text) noexcept {
+    if (!ctx) return;
+    try {
+        ctx->err = text ? text : "C++ exception";
+    } catch (...) {
+    }
+    ctx->series_open = false;
+    ctx->have_results = false;
+    if (ctx->job) ctx->job->open = false;
+    for (Scratch& sc : ctx->sc)
+        if (sc.stream) (void)hipStreamSynchronize(sc.stream);
+    ctx->cur = &ctx->sc[0];
+}
+}  // namespace
+
+// Any matching call ends a streaming series that was left open (msfm_match_pairs_begin without the msfm_match_pairs_next that returns
+// n_pairs == 0): its sub-batches in flight are drained, the store is unlocked, a later msfm_match_pairs_next returns MSFM_E_STATE.
+static int abandon_series(msfm_ctx* ctx) {
+    MatchJob& job = *ctx->job;
+    if (ctx->series_open || (job.open && job.streaming)) {
+        const int rc = drain_streams(ctx);
+        ctx->series_open = false;
+        job.open = false;
+        if (rc != MSFM_OK) return rc;
+        for (SubBatch& w : job.sb) w.active = false;
+    }
+    job.open = false;
+    return MSFM_OK;
+}
+
 static int match_pairs_impl(msfm_ctx* ctx, const int32_t* pairs, int n_pairs, const msfm_match_params* params,
                             const msfm_verify_params* verify, int64_t* out_offsets) {
     if (!ctx) return MSFM_E_INVALID;
     if (n_pairs < 0 || (n_pairs > 0 && !pairs) || !out_offsets) return fail(ctx, MSFM_E_INVALID, "bad pair list");
     MatchJob& job = *ctx->job;
-    if (ctx->series_open) {   // a streaming series left open is abandoned: what it has in flight is drained first
-        const int rc0 = drain_streams(ctx);
-        if (rc0 != MSFM_OK) return rc0;
-        ctx->series_open = false;
-    }
-    job.open = false;
+    const int rc0 = abandon_series(ctx);   // a streaming series left open is abandoned: what it has in flight is drained first
+    if (rc0 != MSFM_OK) return rc0;
     int rc = job.start(ctx, pairs, n_pairs, params, verify, false);
     if (rc != MSFM_OK) return rc;
     while (job.more()) {
@@ -338,16 +384,20 @@ static int match_pairs_impl(msfm_ctx* ctx, const int32_t* pairs, int n_pairs, co
 
 int msfm_match_pairs(msfm_ctx* ctx, const int32_t* pairs, int n_pairs, const msfm_match_params* params,
                      int64_t* out_offsets) {
+    MSFM_API_BEGIN(ctx)
     return drained(ctx, match_pairs_impl(ctx, pairs, n_pairs, params, nullptr, out_offsets));
+    MSFM_API_END
 }
 
 int msfm_match_pairs_verified(msfm_ctx* ctx, const int32_t* pairs, int n_pairs, const msfm_match_params* params,
                               const msfm_verify_params* verify, int64_t* out_offsets) {
+    MSFM_API_BEGIN(ctx)
     msfm_verify_params v = {3.0, 0.99, 1000, 0x5eed5eedULL};  // FeatureUtils.cpp:196: FM_RANSAC, 3.0, 0.99; OpenCV's maxIters
     if (verify) v = *verify;
     if (!(v.threshold >= 0.0) || !(v.confidence > 0.0) || !(v.confidence < 1.0) || v.max_iters < 1 || v.max_iters > (1 << 16))
         return fail(ctx, MSFM_E_INVALID, "bad verification parameters");
     return drained(ctx, match_pairs_impl(ctx, pairs, n_pairs, params, &v, out_offsets));
+    MSFM_API_END
 }
 
 static MatchJob* new_match_job() { return new (std::nothrow) MatchJob(); }
@@ -363,22 +413,20 @@ static int begin_impl(msfm_ctx* ctx, const int32_t* pairs, int n_pairs, const ms
         (!(v.threshold >= 0.0) || !(v.confidence > 0.0) || !(v.confidence < 1.0) || v.max_iters < 1 || v.max_iters > (1 << 16)))
         return fail(ctx, MSFM_E_INVALID, "bad verification parameters");
     MatchJob& job = *ctx->job;
-    if (ctx->series_open) {
-        const int rc0 = drain_streams(ctx);
-        if (rc0 != MSFM_OK) return rc0;
-        ctx->series_open = false;
-    }
-    job.open = false;
+    const int rc0 = abandon_series(ctx);
+    if (rc0 != MSFM_OK) return rc0;
     job.pairs_own.assign(pairs, pairs + 2 * (size_t)n_pairs);
     return job.start(ctx, job.pairs_own.data(), n_pairs, params, geometric_verification ? &v : nullptr, true);
 }
 
 int msfm_match_pairs_begin(msfm_ctx* ctx, const int32_t* pairs, int n_pairs, const msfm_match_params* params, int geometric_verification,
                            const msfm_verify_params* verify) {
+    MSFM_API_BEGIN(ctx)
     if (!ctx) return MSFM_E_INVALID;
     const int rc = drained(ctx, begin_impl(ctx, pairs, n_pairs, params, geometric_verification, verify));
     if (rc != MSFM_OK) ctx->job->open = false;
     return rc;
+    MSFM_API_END
 }
 
 static int next_impl(msfm_ctx* ctx, msfm_chunk* out) {
@@ -404,21 +452,34 @@ static int next_impl(msfm_ctx* ctx, msfm_chunk* out) {
 }
 
 int msfm_match_pairs_next(msfm_ctx* ctx, msfm_chunk* out) {
+    MSFM_API_BEGIN(ctx)
     if (!ctx || !out) return MSFM_E_INVALID;
     const int rc = drained(ctx, next_impl(ctx, out));
     if (rc != MSFM_OK) ctx->job->open = false;
     return rc;
+    MSFM_API_END
+}
+
+int msfm_match_pairs_end(msfm_ctx* ctx) {
+    MSFM_API_BEGIN(ctx)
+    if (!ctx) return MSFM_E_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    return abandon_series(ctx);
+    MSFM_API_END
 }
 
 int msfm_fetch_matches(msfm_ctx* ctx, int32_t* out_qt, float* out_dist) {
+    MSFM_API_BEGIN(ctx)
     if (!ctx) return MSFM_E_INVALID;
     if (!ctx->have_results) return fail(ctx, MSFM_E_STATE, "msfm_fetch_matches without a completed msfm_match_pairs");
     if (out_qt && ctx->res_count) std::memcpy(out_qt, ctx->res_qt.base, ctx->res_count * 8);
     if (out_dist && ctx->res_count) std::memcpy(out_dist, ctx->res_dist.base, ctx->res_count * 4);
     return MSFM_OK;
+    MSFM_API_END
 }
 
 int msfm_fetch_matches_device(msfm_ctx* ctx, int32_t* d_out_qt, float* d_out_dist) {
+    MSFM_API_BEGIN(ctx)
     if (!ctx) return MSFM_E_INVALID;
     if (!ctx->have_results) return fail(ctx, MSFM_E_STATE, "msfm_fetch_matches_device without a completed msfm_match_pairs");
     HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -430,9 +491,11 @@ int msfm_fetch_matches_device(msfm_ctx* ctx, int32_t* d_out_qt, float* d_out_dis
     }
     HIPCHK(ctx, hipStreamSynchronize(SC.stream));
     return MSFM_OK;
+    MSFM_API_END
 }
 
 int msfm_memory_info(msfm_ctx* ctx, msfm_memory* out) {
+    MSFM_API_BEGIN(ctx)
     if (!ctx || !out) return MSFM_E_INVALID;
     *out = msfm_memory{};
     HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -455,34 +518,42 @@ int msfm_memory_info(msfm_ctx* ctx, msfm_memory* out) {
     for (const OutSeg& s : ctx->out_segs) out->results_device += (int64_t)(s.qt.cap + s.d.cap);
     out->page_locked_host = (int64_t)pinned;
     return MSFM_OK;
+    MSFM_API_END
 }
 
 int msfm_read_device(msfm_ctx* ctx, void* host_dst, const void* device_src, int64_t bytes) {
+    MSFM_API_BEGIN(ctx)
     if (!ctx || bytes < 0 || (bytes > 0 && (!host_dst || !device_src))) return MSFM_E_INVALID;
     if (bytes == 0) return MSFM_OK;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipMemcpy(host_dst, device_src, (size_t)bytes, hipMemcpyDeviceToHost));
     return MSFM_OK;
+    MSFM_API_END
 }
 
 int msfm_fetch_order_certificate(msfm_ctx* ctx, int32_t* out_sensitive_rows) {
+    MSFM_API_BEGIN(ctx)
     if (!ctx) return MSFM_E_INVALID;
     if (!ctx->have_results) return fail(ctx, MSFM_E_STATE, "msfm_fetch_order_certificate without a completed msfm_match_pairs");
     if (out_sensitive_rows && !ctx->res_sens.empty()) std::memcpy(out_sensitive_rows, ctx->res_sens.data(), ctx->res_sens.size() * 4);
     return MSFM_OK;
+    MSFM_API_END
 }
 
 int msfm_view_matches(msfm_ctx* ctx, const int32_t** out_qt, const float** out_dist, int64_t* out_count) {
+    MSFM_API_BEGIN(ctx)
     if (!ctx) return MSFM_E_INVALID;
     if (!ctx->have_results) return fail(ctx, MSFM_E_STATE, "msfm_view_matches without a completed msfm_match_pairs");
     if (out_qt) *out_qt = ctx->res_qt.as<int32_t>();
     if (out_dist) *out_dist = ctx->res_dist.as<float>();
     if (out_count) *out_count = (int64_t)ctx->res_count;
     return MSFM_OK;
+    MSFM_API_END
 }
 
 int msfm_match_pair(msfm_ctx* ctx, int id1, int id2, float ratio, int cross_check, double max_distance,
                     int32_t* out_qt, float* out_dist, int* out_count) {
+    MSFM_API_BEGIN(ctx)
     if (!ctx || !out_count) return MSFM_E_INVALID;
     const int32_t pr[2] = {id1, id2};
     msfm_match_params prm = {ratio, cross_check, max_distance};
@@ -491,6 +562,7 @@ int msfm_match_pair(msfm_ctx* ctx, int id1, int id2, float ratio, int cross_chec
     if (rc != MSFM_OK) return rc;
     *out_count = (int)offs[1];
     return msfm_fetch_matches(ctx, out_qt, out_dist);
+    MSFM_API_END
 }
 
 static int knn2_pair_impl(msfm_ctx* ctx, int id1, int id2, int32_t* fwd_idx0, float* fwd_d0, float* fwd_d1,
@@ -498,8 +570,16 @@ static int knn2_pair_impl(msfm_ctx* ctx, int id1, int id2, int32_t* fwd_idx0, fl
 
 int msfm_knn2_pair(msfm_ctx* ctx, int id1, int id2, int32_t* fwd_idx0, float* fwd_d0, float* fwd_d1,
                    int32_t* rev_idx0, float* rev_d0, float* rev_d1) {
+    MSFM_API_BEGIN(ctx)
     if (!ctx) return MSFM_E_INVALID;
-    return drained(ctx, knn2_pair_impl(ctx, id1, id2, fwd_idx0, fwd_d0, fwd_d1, rev_idx0, rev_d0, rev_d1));
+    // a streaming series left open is abandoned (include/msfm_match.h): what it has in flight is drained first -- this call runs on
+    // scratch set 0 and would otherwise overwrite the tail words of a sub-batch the series still has to complete
+    const int rc0 = abandon_series(ctx);
+    if (rc0 != MSFM_OK) return rc0;
+    const int rc = drained(ctx, knn2_pair_impl(ctx, id1, id2, fwd_idx0, fwd_d0, fwd_d1, rev_idx0, rev_d0, rev_d1));
+    if (rc != MSFM_OK) ctx->job->open = false;
+    return rc;
+    MSFM_API_END
 }
 
 static int knn2_pair_impl(msfm_ctx* ctx, int id1, int id2, int32_t* fwd_idx0, float* fwd_d0, float* fwd_d1,
@@ -590,6 +670,7 @@ static int knn2_pair_impl(msfm_ctx* ctx, int id1, int id2, int32_t* fwd_idx0, fl
 // ---- host-only helpers --------------------------------------------------------------------
 
 int msfm_topscale_select(const float* kpts, int n, int k, int32_t* out_idx, int* out_count) {
+    MSFM_API_BEGIN(nullptr)
     if (n < 0 || k < 0 || !out_idx || !out_count || (n > 0 && !kpts)) return MSFM_E_INVALID;
     if (k > n) {  // "if(num_features > kpts.size()) top_scale_descriptors = descriptors"
         for (int i = 0; i < n; ++i) out_idx[i] = i;
@@ -608,21 +689,26 @@ int msfm_topscale_select(const float* kpts, int n, int k, int32_t* out_idx, int*
     for (int i = 0; i < k; ++i) out_idx[i] = order[(size_t)i];
     *out_count = k;
     return MSFM_OK;
+    MSFM_API_END
 }
 
 int msfm_swap_image_pair(int id1, int id2) { return id1 > id2 ? 1 : 0; }
 
 int msfm_pair_id(int id1, int id2, int32_t* out_pair_id) {
+    MSFM_API_BEGIN(nullptr)
     if (!out_pair_id || id1 < 0 || id2 < 0 || id1 >= MSFM_MAX_IMAGES || id2 >= MSFM_MAX_IMAGES) return MSFM_E_INVALID;
     *out_pair_id = msfm_swap_image_pair(id1, id2) ? MSFM_MAX_IMAGES * id2 + id1 : MSFM_MAX_IMAGES * id1 + id2;
     return MSFM_OK;
+    MSFM_API_END
 }
 
 int msfm_pair_from_id(int32_t pair_id, int* out_id1, int* out_id2) {
+    MSFM_API_BEGIN(nullptr)
     if (!out_id1 || !out_id2 || pair_id < 0) return MSFM_E_INVALID;
     *out_id2 = pair_id % MSFM_MAX_IMAGES;
     *out_id1 = (pair_id - *out_id2) / MSFM_MAX_IMAGES;
     return MSFM_OK;
+    MSFM_API_END
 }
 
 }  // extern "C"

@@ -222,9 +222,27 @@ int finalize_store(msfm_ctx* ctx) {
         for (int id : p)
             if (ctx->images[(size_t)id].pending) ids.push_back(id);
     }
+    // The images leave the pending list only when the build has succeeded: a build that fails (out of device memory in store.reserve,
+    // reported by THIS call) leaves them pending with their inbox rows, so a retry -- after the caller freed memory -- builds them
+    // instead of returning MSFM_OK with nothing built.
+    struct RestorePending {
+        msfm_ctx* ctx;
+        const std::vector<int>* ids;
+        size_t waiting;
+        bool done = false;
+        ~RestorePending() {
+            if (done) return;
+            for (int id : *ids)
+                if (ctx->images[(size_t)id].pending) ctx->pending.push_back(id);
+            ctx->inbox_waiting += waiting;
+        }
+    } restore{ctx, &ids, ctx->inbox_waiting};
     ctx->pending.clear();
     ctx->inbox_waiting = 0;
-    if (ids.empty()) return MSFM_OK;
+    if (ids.empty()) {
+        restore.done = true;
+        return MSFM_OK;
+    }
     const size_t P = ids.size();
     HIPCHK(ctx, ctx->d_store_maxima.ensure(P * 64));
     HIPCHK(ctx, hipMemsetAsync(ctx->d_store_maxima.p, 0, P * 64, st));
@@ -353,6 +371,7 @@ int finalize_store(msfm_ctx* ctx) {
         ctx->inbox.drop(im.inbox_chunk);
     }
     hc.lap("store: inbox handed back");
+    restore.done = true;
     return MSFM_OK;
 }
 
@@ -469,6 +488,7 @@ int ensure_forms(msfm_ctx* ctx, const std::vector<int>& wide_ids, const std::vec
 extern "C" {
 
 int msfm_upload_image(msfm_ctx* ctx, int image_id, const void* desc, int n, int dim, int dtype) {
+    MSFM_API_BEGIN(ctx)
     if (!ctx) return MSFM_E_INVALID;
     if (ctx->series_open) return fail(ctx, MSFM_E_STATE, "the store cannot change while a streaming series (msfm_match_pairs_begin .. _next) is open");
     if (image_id < 0 || image_id >= kSlots) return fail(ctx, MSFM_E_INVALID, "image id out of range");
@@ -486,14 +506,18 @@ int msfm_upload_image(msfm_ctx* ctx, int image_id, const void* desc, int n, int 
         if (ctx->copy_helper) ctx->copier.copy(dst, src + off, piece);
         else std::memcpy(dst, src + off, piece);
     });
+    MSFM_API_END
 }
 
 int msfm_finalize_store(msfm_ctx* ctx) {
+    MSFM_API_BEGIN(ctx)
     if (!ctx) return MSFM_E_INVALID;
     return finalize_store(ctx);
+    MSFM_API_END
 }
 
 int msfm_store_info(const msfm_ctx* ctx, int64_t* out_device_bytes, int64_t* out_rows, int64_t* out_pending_images) {
+    MSFM_API_BEGIN(nullptr)
     if (!ctx) return MSFM_E_INVALID;
     long long rows = 0, pend = 0;
     for (const Image& im : ctx->images) {
@@ -504,9 +528,11 @@ int msfm_store_info(const msfm_ctx* ctx, int64_t* out_device_bytes, int64_t* out
     if (out_rows) *out_rows = rows;
     if (out_pending_images) *out_pending_images = pend;
     return MSFM_OK;
+    MSFM_API_END
 }
 
 int msfm_subset_image(msfm_ctx* ctx, int src_image_id, int dst_image_id, const int32_t* rows, int count) {
+    MSFM_API_BEGIN(ctx)
     if (!ctx) return MSFM_E_INVALID;
     if (ctx->series_open) return fail(ctx, MSFM_E_STATE, "the store cannot change while a streaming series (msfm_match_pairs_begin .. _next) is open");
     if (src_image_id < 0 || src_image_id >= kSlots || dst_image_id < 0 || dst_image_id >= kSlots || src_image_id == dst_image_id)
@@ -537,17 +563,21 @@ int msfm_subset_image(msfm_ctx* ctx, int src_image_id, int dst_image_id, const i
                        (const int*)d_idx, inbox, count, as_u8 ? 1 : 0);
     HIPCHK(ctx, hipGetLastError());
     return MSFM_OK;
+    MSFM_API_END
 }
 
 int msfm_image_rows(const msfm_ctx* ctx, int image_id, int* out_n) {
+    MSFM_API_BEGIN(nullptr)
     if (!ctx || !out_n) return MSFM_E_INVALID;
     if (image_id < 0 || image_id >= kSlots) return MSFM_E_INVALID;
     if (ctx->images[(size_t)image_id].n < 0) return MSFM_E_NOIMAGE;
     *out_n = ctx->images[(size_t)image_id].n;
     return MSFM_OK;
+    MSFM_API_END
 }
 
 int msfm_clear_images(msfm_ctx* ctx) {
+    MSFM_API_BEGIN(ctx)
     if (!ctx) return MSFM_E_INVALID;
     if (ctx->series_open) return fail(ctx, MSFM_E_STATE, "the store cannot change while a streaming series (msfm_match_pairs_begin .. _next) is open");
     HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -560,9 +590,11 @@ int msfm_clear_images(msfm_ctx* ctx) {
     ctx->inbox.release_all();
     ctx->q8_level = 0.f;
     return MSFM_OK;
+    MSFM_API_END
 }
 
 int msfm_upload_keypoints(msfm_ctx* ctx, int image_id, const float* kpts, int n, int stride_floats) {
+    MSFM_API_BEGIN(ctx)
     if (!ctx) return MSFM_E_INVALID;
     if (ctx->series_open) return fail(ctx, MSFM_E_STATE, "the store cannot change while a streaming series (msfm_match_pairs_begin .. _next) is open");
     if (image_id < 0 || image_id >= kSlots) return fail(ctx, MSFM_E_INVALID, "image id out of range");
@@ -586,9 +618,11 @@ int msfm_upload_keypoints(msfm_ctx* ctx, int image_id, const float* kpts, int n,
     if (rc != MSFM_OK) return rc;
     im.nk = n;
     return MSFM_OK;
+    MSFM_API_END
 }
 
 int msfm_set_accum_order(msfm_ctx* ctx, int order) {
+    MSFM_API_BEGIN(ctx)
     if (!ctx) return MSFM_E_INVALID;
     if (order != MSFM_ORDER_SSE4X4 && order != MSFM_ORDER_AVX2_FMA && order != MSFM_ORDER_AVX512_FMA)
         return fail(ctx, MSFM_E_INVALID, "unknown accumulation order");
@@ -596,6 +630,7 @@ int msfm_set_accum_order(msfm_ctx* ctx, int order) {
     // asks for them -- ensure_forms; nothing else in the store depends on the order)
     ctx->order = order;
     return MSFM_OK;
+    MSFM_API_END
 }
 
 }  // extern "C"

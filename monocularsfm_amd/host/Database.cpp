@@ -289,6 +289,22 @@ void Database::WriteMatches(const image_t image_id1, const image_t image_id2, co
     SQL_CALL(Sqlite().reset(sql_stmt_add_matches_));
 }
 
+void Database::WriteMatchesStored(const image_t image_id1, const image_t image_id2, const point2D_t* stored_rows, size_t count) const {
+    SQL_CALL(Sqlite().bind_int64(sql_stmt_add_matches_, 1, ImagePairToPairId(image_id1, image_id2)));
+    WriteBlob<point2D_t>(sql_stmt_add_matches_, stored_rows, count, 2, 2);   // bound SQLITE_STATIC: the caller's rows must outlive the step below
+    SQL_CALL(Sqlite().step(sql_stmt_add_matches_));
+    SQL_CALL(Sqlite().reset(sql_stmt_add_matches_));
+}
+
+std::vector<image_pair_t> Database::ReadAllMatchPairIds() const {
+    std::vector<image_pair_t> ids;
+    sqlite3_stmt* stmt = nullptr;
+    SQL_CALL(Sqlite().prepare_v2(database_, "SELECT pair_id FROM matches ORDER BY pair_id;", -1, &stmt, nullptr));
+    while (SQL_CALL(Sqlite().step(stmt)) == msfm_host::SQLITE_ROW_) ids.push_back((image_pair_t)Sqlite().column_int64(stmt, 0));
+    SQL_CALL(Sqlite().finalize(stmt));
+    return ids;
+}
+
 image_pair_t Database::ImagePairToPairId(const image_t image_id1, const image_t image_id2) {
     assert(image_id1 >= 0 && image_id2 >= 0);
     assert((size_t)image_id1 < kMaxNumImages && (size_t)image_id2 < kMaxNumImages);

@@ -63,6 +63,13 @@ public:
     void WriteKeyPoints(const image_t image_id, const std::vector<KeyPoint>& keypoints) const;
     void WriteDescriptors(const image_t image_id, const Descriptors& descriptors) const;
     void WriteMatches(const image_t image_id1, const image_t image_id2, const std::vector<DMatch>& matches) const;
+    // The same row from a list that already has the STORED layout (count x 2, column 0 = the index in the image with the smaller id,
+    // Database.cpp:633-640): what WriteMatches builds from the DMatch vector, without the vector -- the matcher's device threads lay the
+    // rows out while the SQLite thread writes the previous ones (host/FeatureMatching.cpp).
+    void WriteMatchesStored(const image_t image_id1, const image_t image_id2, const point2D_t* stored_rows, size_t count) const;
+    // Every pair_id that has a `matches` row, ascending: one index sweep instead of one ExistMatches SELECT per pair of a large job
+    // (FeatureMatcher::MatchImagePairs asks per pair, src/Feature/FeatureMatching.cpp:21-25).
+    std::vector<image_pair_t> ReadAllMatchPairIds() const;
 
     static image_pair_t ImagePairToPairId(const image_t image_id1, const image_t image_id2);
     static void PairIdToImagePair(const image_pair_t pair_id, image_t* image_id1, image_t* image_id2);

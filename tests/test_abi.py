@@ -100,3 +100,100 @@ def test_diagnostic_probes_are_compiled_out_of_the_shipped_code_object(built_lib
                          capture_output=True, text=True).stdout
     assert "v_mfma_i32_32x32x32_i8" in asm and "v_mfma_f32_32x32x16_f16" in asm      # (the disassembly is the real thing)
     assert "s_memtime" not in asm and "s_memrealtime" not in asm
+
+
+GUARD_DRIVER = r"""
+#include "msfm_guard.h"
+#include <cstdio>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+int main() {
+    std::string text;
+    int code_seen = -1;
+    auto set = [&](int code, const char* t) noexcept { code_seen = code; text = t; };
+    // (1) the plain return value passes through, the error callback is not called
+    if (msfm_guard(set, []() -> int { return 7; }) != 7 || code_seen != -1) return 1;
+    // (2) a real allocation failure: a vector nobody can allocate -> MSFM_E_DEVICE (2), not std::terminate
+    int rc = msfm_guard(set, []() -> int { std::vector<long long> v; v.resize(v.max_size() / 2); return (int)v.size(); });
+    if (rc != 2 || code_seen != 2 || text.find("bad_alloc") == std::string::npos) { std::printf("bad_alloc: rc %d '%s'\n", rc, text.c_str()); return 2; }
+    // (3) any std::exception -> MSFM_E_INVALID (1) with its what()
+    rc = msfm_guard(set, []() -> int { throw std::out_of_range("pair table index"); });
+    if (rc != 1 || text != "pair table index") { std::printf("exception: rc %d '%s'\n", rc, text.c_str()); return 3; }
+    rc = msfm_guard(set, []() -> int { std::vector<int> v(3); return v.at(10); });
+    if (rc != 1 || text.empty()) return 4;
+    // (4) anything else -> MSFM_E_DEVICE
+    rc = msfm_guard(set, []() -> int { throw 42; });
+    if (rc != 2 || text.find("unknown") == std::string::npos) return 5;
+    std::printf("guard ok\n");
+    return 0;
+}
+"""
+
+
+def test_exception_barrier_turns_exceptions_into_statuses(tmp_path):
+    """include/msfm_match.h: "never throws".  csrc/msfm_guard.h is the barrier every entry point runs behind: built here with g++,
+    a std::bad_alloc from a real failed allocation, a std::exception and a foreign throw come back as status codes."""
+    import subprocess
+    src = tmp_path / "guard_driver.cpp"
+    src.write_text(GUARD_DRIVER)
+    exe = tmp_path / "guard_driver"
+    subprocess.run(["g++", "-O1", "-std=c++17", "-I", os.path.join(ROOT, "monocularsfm_amd", "csrc"), "-o", str(exe), str(src)], check=True)
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0 and "guard ok" in r.stdout, (r.returncode, r.stdout, r.stderr)
+
+
+def test_every_entry_point_runs_behind_the_exception_barrier():
+    """No `extern "C"` function of the library may be left outside msfm_guard: every int-returning definition in the two files that
+    hold the C ABI opens with MSFM_API_BEGIN (one-line helpers that cannot throw -- msfm_swap_image_pair -- and the three
+    non-int entry points are listed by name)."""
+    csrc = os.path.join(ROOT, "monocularsfm_amd", "csrc")
+    plain = {"msfm_swap_image_pair", "msfm_version", "msfm_last_error", "msfm_destroy"}
+    defined = set()
+    for f in ("msfm_match.hip", "msfm_store_host.hip.h"):
+        lines = open(os.path.join(csrc, f)).read().split("\n")
+        in_c = False
+        for i, l in enumerate(lines):
+            if l.startswith('extern "C" {'):
+                in_c = True
+            elif l.startswith('}  // extern "C"'):
+                in_c = False
+            m = re.match(r"^(?:int|void|const char\*) (msfm_\w+)\(", l) if in_c else None
+            if not m:
+                continue
+            j = i
+            while not lines[j].rstrip().endswith(("{", ";", "}")):
+                j += 1
+            if lines[j].rstrip().endswith(";"):
+                continue                                  # a declaration
+            name = m.group(1)
+            defined.add(name)
+            if name in plain:
+                continue
+            assert lines[j + 1].strip().startswith("MSFM_API_BEGIN("), "%s:%d %s is outside the exception barrier" % (f, i + 1, name)
+    assert defined == set(declared_functions()), sorted(defined ^ set(declared_functions()))
+    src = open(os.path.join(csrc, "msfm_match.hip")).read()
+    body = src[src.index("void msfm_destroy("):]
+    assert "try {" in body[:200] and "catch (...)" in body[:body.index("\n}\n") + 3]
+
+
+def test_null_context_is_a_status_everywhere(built_lib):
+    """A NULL context returns MSFM_E_INVALID from every entry point that takes one (no GPU needed)."""
+    L = built_lib
+    i64 = C.c_int64()
+    n = C.c_int()
+    pr = (C.c_int32 * 2)(0, 1)
+    assert L.msfm_match_pairs(None, pr, 1, None, C.byref(i64)) == 1
+    assert L.msfm_match_pairs_begin(None, pr, 1, None, 0, None) == 1
+    assert L.msfm_match_pairs_next(None, None) == 1
+    assert L.msfm_match_pairs_end(None) == 1
+    assert L.msfm_upload_image(None, 0, None, 0, 128, 0) == 1
+    assert L.msfm_finalize_store(None) == 1
+    assert L.msfm_clear_images(None) == 1
+    assert L.msfm_image_rows(None, 0, C.byref(n)) == 1
+    assert L.msfm_knn2_pair(None, 0, 1, None, None, None, None, None, None) == 1
+    assert L.msfm_fetch_matches(None, None, None) == 1
+    assert L.msfm_set_limits(None, 0, 0) == 1
+    L.msfm_destroy(None)
+    assert L.msfm_last_error(None) is not None

@@ -104,3 +104,47 @@ def test_stream_device_pointers_hold_the_same_lists():
             assert np.array_equal(bits(ctx.read_device(ch["d_dist"], (m,), np.float32)), bits(ch["dist"]))
             seen += m
         assert seen > 100
+
+
+def test_knn2_pair_and_an_early_exit_both_end_an_open_series():
+    """(1) msfm_knn2_pair in the middle of a series abandons it like any other matching call (it ran on scratch set 0 with the
+    series' sub-batches in flight and the next _next handed out foreign offsets): the following _next is a state error, the kNN lists are
+    the ones a fresh context gives.  (2) A consumer that breaks out of the generator leaves no series open: msfm_match_pairs_end
+    unlocks the store, uploads work again, and a later series still equals the one-call result."""
+    imgs = synth.u8_images(8, [900, 1400, 700, 1100, 1300, 600, 1000, 1200], seed=81, dup_frac=0.2, as_float=False)
+    pairs = synth.all_pairs(8)
+    kw = {"max_distance": 1e9}
+    with _lib.Context(0) as ref_ctx:
+        for i, im in enumerate(imgs):
+            ref_ctx.upload_image(i, im)
+        knn_ref = ref_ctx.knn2_pair(3, 1)
+        ref = ref_ctx.match_pairs(pairs, **kw)
+    with _lib.Context(0) as ctx:
+        for i, im in enumerate(imgs):
+            ctx.upload_image(i, im)
+        ctx.set_limits(max_pairs_per_batch=3)
+        it = ctx.match_pairs_stream(pairs, **kw)
+        first = next(it)
+        assert first["n_pairs"] == 3
+        knn = ctx.knn2_pair(3, 1)                       # sub-batches 2 and 3 of the series are in flight here
+        for a, b in zip(knn, knn_ref):
+            assert np.array_equal(bits(a), bits(b))
+        with pytest.raises(_lib.MsfmError) as err:
+            next(it)
+        assert err.value.code == _lib.E_STATE
+        ctx.upload_image(0, imgs[0])                    # the store is unlocked
+        # (2) early exit
+        for k, ch in enumerate(ctx.match_pairs_stream(pairs, **kw)):
+            if k == 1:
+                break
+        ctx.upload_image(1, imgs[1])                    # no E_STATE: the generator's finally ended the series
+        assert ctx._L.msfm_match_pairs_end(ctx._h) == 0   # nothing open: a no-op
+        it = ctx.match_pairs_stream(pairs, **kw)
+        next(it)
+        it.close()                                      # GeneratorExit takes the same path
+        ctx.clear_images()
+        for i, im in enumerate(imgs):
+            ctx.upload_image(i, im)
+        offs, qt, d, _, chunks = collect(ctx, pairs, **kw)
+        assert chunks == -(-len(pairs) // 3)
+        assert np.array_equal(offs, ref[0]) and np.array_equal(qt, ref[1]) and np.array_equal(bits(d), bits(ref[2]))
