@@ -1,14 +1,31 @@
-// FeatureMatching.cpp -- see FeatureMatching.h.  Control flow follows the reference's
-// src/Feature/FeatureMatching.cpp (pair order, batch boundaries, transactions, resume-by-row,
-// stdout lines); the per-pair arithmetic runs on the GPU through include/msfm_match.h.
+// FeatureMatching.cpp -- see FeatureMatching.h.  Pair order, batch boundaries, transactions, resume-by-row and stdout lines follow the
+// reference's src/Feature/FeatureMatching.cpp; the per-pair arithmetic runs on the GPU through include/msfm_match.h.
+//
+// Shape of a run (round 6: the executable scales with the device count instead of adding its SQLite time to the GPU time):
+//
+//   calling thread (owns the SQLite handle)         device threads, one per GPU
+//   ------------------------------------------      ---------------------------------------------------------------
+//   bulk load, exist-check of every pair
+//   [pre-emptive filter of every pair: device threads, streaming series on the 100-row subsets]
+//   deal the pairs to do into blocks, round-robin    msfm_match_pairs_begin(all pairs of this device)
+//   for every reference group, in order:             loop: msfm_match_pairs_next -> lay the chunk's lists out as stored rows
+//       wait for the results of its pairs   <------        (column swap, [host RANSAC], emission options) -> bounded queue
+//       BEGIN; stdout lines; WriteMatches; END        (two more sub-batches stay in flight on the GPU meanwhile)
+//
+// The reference emits inside its pair loop too (FeatureMatching.cpp:13, 63-72); what is printed and written, and in which
+// transactions, is unchanged -- tests/test_cli_gpu.py compares stdout, rows and the transaction trace.
 #include "FeatureMatching.h"
 
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <iostream>
+#include <memory>
+#include <mutex>
 #include <string>
 #include <thread>
 
@@ -19,16 +36,24 @@
 namespace MonocularSfM {
 
 namespace {
-// MSFM_CLI_TIMING=1: wall-clock per phase on stderr when the matcher closes
+// MSFM_CLI_TIMING=1: wall-clock per phase on stderr when the matcher closes.  `device` and `layout` are summed over the device
+// threads and run BESIDE the calling thread's phases: the calling thread's own time is exist + read + preemptive + wait + emit.
 struct PhaseClock {
-    double exist = 0, read_desc = 0, device = 0, read_kp = 0, verify = 0, emit = 0, preemptive = 0, open_dev = 0, close_dev = 0;
+    double exist = 0, read_desc = 0, device = 0, layout = 0, read_kp = 0, emit = 0, wait = 0, preemptive = 0, open_dev = 0, close_dev = 0, run = 0;
+    long long pairs = 0, matches = 0;
+    int devices = 1;
     bool on = std::getenv("MSFM_CLI_TIMING") != nullptr;
     void Report() const {
         if (!on || exist + read_desc + device + emit == 0) return;
         std::fprintf(stderr, "[msfm timing] exist-check %.3f s | read descriptors + upload %.3f s | device match + fetch %.3f s | "
                              "pre-emptive filter %.3f s | read keypoints %.3f s | verification %.3f s | stdout + WriteMatches %.3f s | "
                              "open database + device %.3f s | close %.3f s\n",
-                     exist, read_desc, device, preemptive, read_kp, verify, emit, open_dev, close_dev);
+                     exist, read_desc, device / devices, preemptive, read_kp, layout / devices, emit, open_dev, close_dev);
+        // the pipeline's own figures: what bounds the run is the larger of the device threads' time and the calling thread's
+        std::fprintf(stderr, "[msfm pipeline] devices %d | pairs matched %lld | matches written %lld | matching phase wall %.3f s | device threads: in "
+                             "msfm_match_pairs_next %.3f s + row layout %.3f s (mean per device) | calling thread: waiting for results %.3f s, "
+                             "stdout + WriteMatches %.3f s -> bound by %s\n",
+                     devices, pairs, matches, run, device / devices, layout / devices, wait, emit, wait > emit ? "the devices" : "emission");
     }
 } g_clock;
 struct Lap {
@@ -46,6 +71,88 @@ struct Lap {
         const int rc__ = (expr);                   \
         if (rc__ != MSFM_OK) Die(ctx, #expr, rc__); \
     } while (0)
+
+// Pairs per block of the round-robin deal (cost-balanced: a block ends at the pair nearest to its share of sum n1 * n2).  Small blocks
+// keep the devices in step with the emitter -- the series of a device runs across its blocks without a gap, so the block size does not
+// cost device efficiency.  MSFM_SUPER_BATCH_PAIRS (the name of round 5's knob) overrides it; tests cross the boundaries with tiny values.
+size_t BlockPairs() {
+    static const size_t v = [] {
+        const char* e = std::getenv("MSFM_SUPER_BATCH_PAIRS");
+        const long long x = e ? std::atoll(e) : 0;
+        return x > 0 ? (size_t)x : (size_t)1024;
+    }();
+    return v;
+}
+
+// What a device thread hands to the emitter: the lists of `n` consecutive pairs of ITS pair list, already in the stored layout
+// (count x 2 int32, column 0 = the index in the image with the smaller id, Database.cpp:633-640).
+struct ResultChunk {
+    size_t first = 0, n = 0;             // local pair indices [first, first + n)
+    std::vector<int64_t> offsets;        // n + 1
+    std::vector<point2D_t> rows;         // 2 * offsets[n]
+    double seconds_per_pair = 0;         // wall clock of the chunk on the device thread / n (the "Elapsed time" line of a pair)
+    size_t Bytes() const { return rows.size() * sizeof(point2D_t) + offsets.size() * 8 + sizeof(*this); }
+};
+
+// Bounded single-producer / single-consumer queue: the producer blocks while more than `cap` bytes wait (emission is the slower side
+// then, and the device idles rather than the host buffering the whole job); one chunk always fits.
+class ChunkQueue {
+public:
+    explicit ChunkQueue(size_t cap_bytes) : cap_(cap_bytes) {}
+    // false: the consumer has given up (error elsewhere): stop producing
+    bool Push(std::unique_ptr<ResultChunk> c) {
+        std::unique_lock<std::mutex> l(mu_);
+        not_full_.wait(l, [&] { return aborted_ || q_.empty() || bytes_ <= cap_; });
+        if (aborted_) return false;
+        bytes_ += c->Bytes();
+        q_.push_back(std::move(c));
+        not_empty_.notify_one();
+        return true;
+    }
+    // nullptr: the producer has finished (or failed) and nothing is left
+    std::unique_ptr<ResultChunk> Pop() {
+        std::unique_lock<std::mutex> l(mu_);
+        not_empty_.wait(l, [&] { return closed_ || !q_.empty(); });
+        if (q_.empty()) return nullptr;
+        std::unique_ptr<ResultChunk> c = std::move(q_.front());
+        q_.pop_front();
+        bytes_ -= c->Bytes();
+        not_full_.notify_one();
+        return c;
+    }
+    void Close() {
+        std::lock_guard<std::mutex> l(mu_);
+        closed_ = true;
+        not_empty_.notify_all();
+    }
+    void Abort() {
+        std::lock_guard<std::mutex> l(mu_);
+        aborted_ = true;
+        not_full_.notify_all();
+    }
+
+private:
+    std::mutex mu_;
+    std::condition_variable not_empty_, not_full_;
+    std::deque<std::unique_ptr<ResultChunk>> q_;
+    size_t bytes_ = 0, cap_;
+    bool closed_ = false, aborted_ = false;
+};
+
+// One device's share of a run and the thread that works it off.
+struct DeviceRun {
+    msfm_ctx* ctx = nullptr;
+    std::vector<int32_t> pairs;          // 2 * n: (id1, id2) in the order this device computes them
+    std::unique_ptr<ChunkQueue> queue;
+    std::thread thread;
+    int status = MSFM_OK;
+    std::string error;
+    double in_next = 0, in_layout = 0;   // seconds inside msfm_match_pairs_next / laying the rows out
+    // emitter side
+    std::unique_ptr<ResultChunk> cur;
+    size_t consumed = 0;
+};
+
 }  // namespace
 
 FeatureMatcher::FeatureMatcher(const std::string& database_path, const int& max_num_matches,
@@ -67,7 +174,7 @@ void FeatureMatcher::OpenDatabaseAndDevice() {
     Lap lap_open(&g_clock.open_dev);
     database_ = new Database();
     database_->Open(database_path_);
-    if (!ctx_) {
+    if (devices_.empty()) {
         std::vector<int> devs;
         const char* list = std::getenv("MSFM_DEVICES");
         if (list && std::string(list) == "all") {   // every gfx950 device of the node: one context and one host thread each
@@ -87,18 +194,26 @@ void FeatureMatcher::OpenDatabaseAndDevice() {
             if (const char* d = std::getenv("MSFM_DEVICE")) dev = std::atoi(d);
             devs.push_back(dev);
         }
-        for (size_t g = 0; g < devs.size(); ++g) {
+        // (contexts of different GPUs come up in parallel: the first stream + first allocation of a device cost ~30 ms each)
+        devices_.assign(devs.size(), Device());
+        std::vector<int> status(devs.size(), MSFM_OK);
+        std::vector<std::thread> starters;
+        auto create = [&](size_t g) {
             msfm_ctx* c = nullptr;
-            const int rc = msfm_create(devs[g], &c);
-            if (rc != MSFM_OK) {
-                std::fprintf(stderr, "ComputeMatches: no usable gfx950 GPU at ordinal %d (msfm_create status %d); there is no CPU fallback\n", devs[g], rc);
+            status[g] = msfm_create(devs[g], &c);
+            if (status[g] == MSFM_OK)
+                if (const char* o = std::getenv("MSFM_ACCUM_ORDER")) status[g] = msfm_set_accum_order(c, std::atoi(o));
+            devices_[g].ctx = c;
+        };
+        create(0);   // (the runtime's own start-up happens once, on this thread)
+        for (size_t g = 1; g < devs.size(); ++g) starters.emplace_back(create, g);
+        for (auto& t : starters) t.join();
+        for (size_t g = 0; g < devs.size(); ++g)
+            if (status[g] != MSFM_OK || !devices_[g].ctx) {
+                std::fprintf(stderr, "ComputeMatches: no usable gfx950 GPU at ordinal %d (msfm_create status %d); there is no CPU fallback\n", devs[g], status[g]);
                 std::exit(EXIT_FAILURE);
             }
-            if (const char* o = std::getenv("MSFM_ACCUM_ORDER")) MSFM_CALL(c, msfm_set_accum_order(c, std::atoi(o)));
-            if (g == 0) ctx_ = c;
-            else extra_ctxs_.push_back(c);
-        }
-        extra_resident_.assign(extra_ctxs_.size(), std::set<image_t>());
+        ctx_ = devices_[0].ctx;
     }
 }
 
@@ -110,15 +225,14 @@ void FeatureMatcher::CloseDatabaseAndDevice() {
         delete database_;
         database_ = nullptr;
     }
-    if (ctx_) {
-        msfm_destroy(ctx_);
-        ctx_ = nullptr;
-    }
-    for (msfm_ctx* c : extra_ctxs_) msfm_destroy(c);
-    extra_ctxs_.clear();
-    extra_resident_.clear();
+    // (the contexts of different GPUs go down in parallel: ~30 ms each, ~150 hipFree)
+    std::vector<std::thread> closers;
+    for (size_t g = 1; g < devices_.size(); ++g) closers.emplace_back([c = devices_[g].ctx] { msfm_destroy(c); });
+    if (!devices_.empty()) msfm_destroy(devices_[0].ctx);
+    for (auto& t : closers) t.join();
+    devices_.clear();
+    ctx_ = nullptr;
     descriptor_cache_.clear();
-    resident_.clear();
     keypoints_cache_.clear();
     }
     g_clock.Report();
@@ -131,32 +245,31 @@ const std::vector<KeyPoint>& FeatureMatcher::KeyPointsOf(image_t image_id) {
     return it->second;
 }
 
-void FeatureMatcher::EnsureResidentOn(size_t extra_index, image_t image_id) {
-    std::set<image_t>& have = extra_resident_[extra_index];
-    if (have.count(image_id)) return;
-    EnsureResident(image_id);  // fills the host cache
-    msfm_ctx* c = extra_ctxs_[extra_index];
-    const Descriptors& d = descriptor_cache_.at(image_id);
-    MSFM_CALL(c, msfm_upload_image(c, image_id, d.data.data(), d.rows, d.rows ? d.cols : MSFM_DIM, MSFM_DTYPE_F32));
-    if (geometric_verification_ && !verification_on_host_) {
-        const std::vector<KeyPoint>& kpts = KeyPointsOf(image_id);
-        MSFM_CALL(c, msfm_upload_keypoints(c, image_id, reinterpret_cast<const float*>(kpts.data()), (int)kpts.size(), 4));
+// Descriptors (and, for the device's verification, keypoints) of one image on one device; calling thread only (SQLite)
+void FeatureMatcher::EnsureResidentOn(size_t g, image_t image_id) {
+    Device& dev = devices_[g];
+    if (dev.resident.count(image_id)) return;
+    const Descriptors* d = nullptr;
+    Descriptors read;
+    auto cached = descriptor_cache_.find(image_id);
+    if (cached != descriptor_cache_.end()) {
+        d = &cached->second;
+    } else {
+        read = database_->ReadDescriptors(image_id);
+        d = devices_.size() > 1 ? &(descriptor_cache_[image_id] = std::move(read)) : &read;
     }
-    have.insert(image_id);
-}
-
-void FeatureMatcher::EnsureResident(image_t image_id) {
-    if (resident_.count(image_id)) return;
-    Descriptors read = database_->ReadDescriptors(image_id);
-    const Descriptors& d = extra_ctxs_.empty() ? read : (descriptor_cache_[image_id] = std::move(read));
-    MSFM_CALL(ctx_, msfm_upload_image(ctx_, image_id, d.data.data(), d.rows, d.rows ? d.cols : MSFM_DIM, MSFM_DTYPE_F32));
+    MSFM_CALL(dev.ctx, msfm_upload_image(dev.ctx, image_id, d->data.data(), d->rows, d->rows ? d->cols : MSFM_DIM, MSFM_DTYPE_F32));
     if (geometric_verification_ && !verification_on_host_) {
         // the device verifies: it needs the keypoint coordinates next to the descriptors
         const std::vector<KeyPoint>& kpts = KeyPointsOf(image_id);
         static_assert(sizeof(KeyPoint) == 16, "KeyPoint must be 4 packed floats");
-        MSFM_CALL(ctx_, msfm_upload_keypoints(ctx_, image_id, reinterpret_cast<const float*>(kpts.data()), (int)kpts.size(), 4));
+        MSFM_CALL(dev.ctx, msfm_upload_keypoints(dev.ctx, image_id, reinterpret_cast<const float*>(kpts.data()), (int)kpts.size(), 4));
     }
-    resident_.insert(image_id);
+    dev.resident.insert(image_id);
+}
+
+void FeatureMatcher::EnsureResident(image_t image_id) {
+    for (size_t g = 0; g < devices_.size(); ++g) EnsureResidentOn(g, image_id);
 }
 
 void FeatureMatcher::PreloadAllImages() {
@@ -172,14 +285,12 @@ void FeatureMatcher::PreloadAllImages() {
         Sink* s = static_cast<Sink*>(user);
         FeatureMatcher* m = s->self;
         if (id < 0 || id >= MSFM_MAX_IMAGES) return;
-        std::vector<msfm_ctx*> ctxs(1, m->ctx_);
-        ctxs.insert(ctxs.end(), m->extra_ctxs_.begin(), m->extra_ctxs_.end());
         if (!s->keypoints) {
-            if (m->resident_.count(id)) return;
-            for (msfm_ctx* c : ctxs)
-                MSFM_CALL(c, msfm_upload_image(c, id, data, (int)rows, rows ? (int)cols : MSFM_DIM, elem == 1 ? MSFM_DTYPE_U8 : MSFM_DTYPE_F32));
-            m->resident_.insert(id);
-            for (auto& have : m->extra_resident_) have.insert(id);
+            if (m->devices_[0].resident.count(id)) return;
+            for (Device& dev : m->devices_) {
+                MSFM_CALL(dev.ctx, msfm_upload_image(dev.ctx, id, data, (int)rows, rows ? (int)cols : MSFM_DIM, elem == 1 ? MSFM_DTYPE_U8 : MSFM_DTYPE_F32));
+                dev.resident.insert(id);
+            }
         } else {
             // Database::ReadKeyPoints asserts cols == 4 (x, y, size, angle); a narrower blob would be over-read below
             if (rows > 0 && cols != 4) {
@@ -189,9 +300,9 @@ void FeatureMatcher::PreloadAllImages() {
             std::vector<KeyPoint>& kps = m->keypoints_cache_[id];
             kps.resize(rows);
             if (rows) std::memcpy(kps.data(), data, rows * sizeof(KeyPoint));
-            if (m->geometric_verification_ && !m->verification_on_host_ && m->resident_.count(id))
-                for (msfm_ctx* c : ctxs)
-                    MSFM_CALL(c, msfm_upload_keypoints(c, id, static_cast<const float*>(data), (int)rows, 4));
+            if (m->geometric_verification_ && !m->verification_on_host_ && m->devices_[0].resident.count(id))
+                for (Device& dev : m->devices_)
+                    MSFM_CALL(dev.ctx, msfm_upload_keypoints(dev.ctx, id, static_cast<const float*>(data), (int)rows, 4));
         }
     };
     static_assert(sizeof(KeyPoint) == 16, "KeyPoint must be 4 packed floats");
@@ -206,9 +317,15 @@ void FeatureMatcher::PreloadAllImages() {
     database_->VisitAllDescriptors(visit, &sink);   // images the side table does not cover
     sink.keypoints = true;
     database_->VisitAllKeyPoints(visit, &sink);
-    // the uploads above only copied: build the store now (classification, one allocation, layout kernels), inside this phase's clock
-    MSFM_CALL(ctx_, msfm_finalize_store(ctx_));
-    for (msfm_ctx* c : extra_ctxs_) MSFM_CALL(c, msfm_finalize_store(c));
+    // the uploads above only copied: build the stores now (classification, one allocation, layout kernels), inside this phase's clock --
+    // every device builds its own copy, all at once
+    std::vector<int> status(devices_.size(), MSFM_OK);
+    std::vector<std::thread> builders;
+    for (size_t g = 1; g < devices_.size(); ++g) builders.emplace_back([&, g] { status[g] = msfm_finalize_store(devices_[g].ctx); });
+    status[0] = msfm_finalize_store(devices_[0].ctx);
+    for (auto& t : builders) t.join();
+    for (size_t g = 0; g < devices_.size(); ++g)
+        if (status[g] != MSFM_OK) Die(devices_[g].ctx, "msfm_finalize_store", status[g]);
     bulk_loaded_ = true;
 }
 
@@ -216,165 +333,202 @@ void FeatureMatcher::MatchImagePairs(const std::vector<std::pair<image_t, image_
     MatchImagePairGroups({image_pairs});
 }
 
-// The reference calls MatchImagePairs once per group of <= 100 pairs: one transaction, and per pair either
-// the "Existing, Continue!" line or match -> filter -> verify -> stdout -> WriteMatches
-// (src/Feature/FeatureMatching.cpp:10-73).  Here several groups are computed together -- one batched GPU
-// call, one parallel verification pass -- and then EMITTED group by group, pair by pair, in the reference's
-// order, so stdout, the rows and the transaction boundaries are the same while the device sees thousands
-// of pairs per launch instead of 100.
+// The reference calls MatchImagePairs once per group of <= 100 pairs: one transaction, and per pair either the
+// "Existing, Continue!" line or match -> filter -> verify -> stdout -> WriteMatches (src/Feature/FeatureMatching.cpp:10-73).
+// Here the pairs of ALL groups that still need a row are dealt to the devices up front; the groups are then EMITTED one by one,
+// pair by pair, in the reference's order, each as soon as the devices have delivered its pairs -- stdout, the rows and the
+// transaction boundaries are the reference's, while each device sees one uninterrupted series instead of 100 pairs at a time.
 void FeatureMatcher::MatchImagePairGroups(const std::vector<std::vector<std::pair<image_t, image_t>>>& groups) {
-    struct Slot { int todo_index; };  // -1: a row exists (or an earlier group of this call writes it)
-    std::vector<std::vector<Slot>> slots(groups.size());
+    // ---- which pairs have a row already (the reference asks per pair, FeatureMatching.cpp:21-25)
+    std::vector<std::vector<int>> slot(groups.size());   // index into `todo`, or -1: a row exists (or an earlier pair of this call writes it)
     std::vector<int32_t> todo;
-    std::set<std::pair<image_t, image_t>> scheduled;
     {
-    Lap lap(&g_clock.exist);
-    for (size_t g = 0; g < groups.size(); ++g) {
-        slots[g].resize(groups[g].size());
-        for (size_t k = 0; k < groups[g].size(); ++k) {
-            const image_t image_id1 = groups[g][k].first, image_id2 = groups[g][k].second;
-            const std::pair<image_t, image_t> key(std::min(image_id1, image_id2), std::max(image_id1, image_id2));
-            if (scheduled.count(key) || database_->ExistMatches(image_id1, image_id2)) {
-                slots[g][k].todo_index = -1;
-                continue;
+        Lap lap(&g_clock.exist);
+        size_t total = 0;
+        for (const auto& g : groups) total += g.size();
+        // a large job reads the index of the matches table once instead of asking for every pair (2.3 us each, one by one)
+        const bool sweep = total >= 2048;
+        std::vector<image_pair_t> have;
+        if (sweep) have = database_->ReadAllMatchPairIds();
+        std::set<std::pair<image_t, image_t>> scheduled;
+        for (size_t g = 0; g < groups.size(); ++g) {
+            slot[g].resize(groups[g].size());
+            for (size_t k = 0; k < groups[g].size(); ++k) {
+                const image_t image_id1 = groups[g][k].first, image_id2 = groups[g][k].second;
+                const std::pair<image_t, image_t> key(std::min(image_id1, image_id2), std::max(image_id1, image_id2));
+                const bool exists = sweep ? std::binary_search(have.begin(), have.end(), Database::ImagePairToPairId(image_id1, image_id2))
+                                          : database_->ExistMatches(image_id1, image_id2);
+                if (exists || !scheduled.insert(key).second) {
+                    slot[g][k] = -1;
+                    continue;
+                }
+                slot[g][k] = (int)(todo.size() / 2);
+                todo.push_back(image_id1);
+                todo.push_back(image_id2);
             }
-            scheduled.insert(key);
-            slots[g][k].todo_index = (int)(todo.size() / 2);
-            todo.push_back(image_id1);
-            todo.push_back(image_id2);
         }
     }
-    }
-    const int P = (int)(todo.size() / 2);
-    std::vector<std::vector<DMatch>> verified((size_t)P);
-    std::vector<double> verify_seconds((size_t)P, 0.0);
-    double gpu_seconds_per_pair = 0.0;
+    const size_t P = todo.size() / 2;
+    const size_t G = devices_.size();
+    const bool verify_on_device = geometric_verification_ && !verification_on_host_;
+    const bool host_verify = geometric_verification_ && verification_on_host_;
+    static const EmissionOptions emission = EmissionOptions::FromEnvironment();
+
+    // ---- everything the device threads will touch is made resident / read now, on this thread (SQLite)
     if (P > 0) {
-        Timer timer;
-        timer.Start();
+        std::vector<int32_t> ids(todo);
+        std::sort(ids.begin(), ids.end());
+        ids.erase(std::unique(ids.begin(), ids.end()), ids.end());
         {
             Lap l(&g_clock.read_desc);
-            for (int32_t id : todo) EnsureResident(id);
+            for (int32_t id : ids) EnsureResident(id);
         }
-        msfm_match_params prm;
-        prm.ratio = (float)distance_ratio_;  // ComputeCrossMatches takes `const float distance_ratio`
-        prm.cross_check = cross_check_ ? 1 : 0;
-        prm.max_distance = max_distance_;
-        std::vector<int64_t> offs((size_t)P + 1);
-        const int32_t* qt = nullptr;   // the library's page-locked result buffers: valid until the next matching call
-        const float* dist = nullptr;
-        std::vector<int32_t> qt_merged;   // several devices: their lists concatenated in pair order
-        std::vector<float> dist_merged;
-        const bool verify_on_device = geometric_verification_ && !verification_on_host_;
-        // returns the status: device worker threads must not exit() the process while their siblings run
-        auto run_on = [&](msfm_ctx* c, const int32_t* pairs, int n, int64_t* out_offs) -> int {
-            if (verify_on_device) return msfm_match_pairs_verified(c, pairs, n, &prm, nullptr, out_offs);  // FilterMatches' constants
-            return msfm_match_pairs(c, pairs, n, &prm, out_offs);
-        };
-        if (extra_ctxs_.empty()) {
-            Lap l(&g_clock.device);
-            MSFM_CALL(ctx_, run_on(ctx_, todo.data(), P, offs.data()));
-            MSFM_CALL(ctx_, msfm_view_matches(ctx_, &qt, &dist, nullptr));
-        } else {
-            // contiguous ranges of equal cost sum n1 * n2, one per device; every device needs the images of its range
-            const size_t G = 1 + extra_ctxs_.size();
-            std::vector<double> cum((size_t)P + 1, 0.0);
-            for (int p = 0; p < P; ++p) {
-                int n1 = 0, n2 = 0;
-                (void)msfm_image_rows(ctx_, todo[2 * (size_t)p], &n1);
-                (void)msfm_image_rows(ctx_, todo[2 * (size_t)p + 1], &n2);
-                cum[(size_t)p + 1] = cum[(size_t)p] + (double)n1 * n2 + 1.0;
-            }
-            std::vector<int> cut(G + 1, P);
-            cut[0] = 0;
-            for (size_t g = 1; g < G; ++g)
-                cut[g] = (int)(std::lower_bound(cum.begin(), cum.end(), cum[(size_t)P] * (double)g / (double)G) - cum.begin());
-            for (size_t g = 1; g <= G; ++g) cut[g] = std::max(cut[g], cut[g - 1]);
-            {
-                Lap l(&g_clock.read_desc);
-                for (size_t g = 1; g < G; ++g)
-                    for (int p = cut[g]; p < cut[g + 1]; ++p) {
-                        EnsureResidentOn(g - 1, todo[2 * (size_t)p]);
-                        EnsureResidentOn(g - 1, todo[2 * (size_t)p + 1]);
-                    }
-            }
-            Lap l(&g_clock.device);
-            std::vector<std::vector<int64_t>> part_offs(G);
-            std::vector<std::thread> workers;
-            std::vector<int> status(G, MSFM_OK);
-            for (size_t g = 0; g < G; ++g) {
-                part_offs[g].assign((size_t)(cut[g + 1] - cut[g]) + 1, 0);
-                msfm_ctx* c = g == 0 ? ctx_ : extra_ctxs_[g - 1];
-                workers.emplace_back([&, g, c] { status[g] = run_on(c, todo.data() + 2 * (size_t)cut[g], cut[g + 1] - cut[g], part_offs[g].data()); });
-            }
-            for (auto& w : workers) w.join();
-            for (size_t g = 0; g < G; ++g)
-                if (status[g] != MSFM_OK) Die(g == 0 ? ctx_ : extra_ctxs_[g - 1], "msfm_match_pairs (device worker)", status[g]);
-            int64_t total = 0;
-            for (size_t g = 0; g < G; ++g) {
-                for (int p = cut[g]; p < cut[g + 1]; ++p) offs[(size_t)p + 1] = total + part_offs[g][(size_t)(p - cut[g]) + 1];
-                total += part_offs[g].back();
-            }
-            qt_merged.resize((size_t)total * 2 + 2);
-            dist_merged.resize((size_t)total + 1);
-            for (size_t g = 0; g < G; ++g) {
-                msfm_ctx* c = g == 0 ? ctx_ : extra_ctxs_[g - 1];
-                const int32_t* q = nullptr;
-                const float* dd = nullptr;
-                int64_t cnt = 0;
-                MSFM_CALL(c, msfm_view_matches(c, &q, &dd, &cnt));
-                const size_t at = (size_t)offs[(size_t)cut[g]];
-                if (cnt > 0) {
-                    std::memcpy(qt_merged.data() + 2 * at, q, (size_t)cnt * 8);
-                    std::memcpy(dist_merged.data() + at, dd, (size_t)cnt * 4);
-                }
-            }
-            qt = qt_merged.data();
-            dist = dist_merged.data();
-        }
-        gpu_seconds_per_pair = timer.ElapsedSeconds() / P;
-
-        // Geometric verification (FeatureUtils::FilterMatches) already happened on the device, unless the host
-        // twin was asked for: then keypoints are read once per image (SQLite handle: this thread only) and
-        // the pairs are verified on all host cores.
-        const bool host_verify = geometric_verification_ && verification_on_host_;
         if (host_verify) {
             Lap l(&g_clock.read_kp);
-            for (int32_t id : todo) (void)KeyPointsOf(id);
+            for (int32_t id : ids) (void)KeyPointsOf(id);
         }
-        Lap lv(&g_clock.verify);
-        auto verify_pair = [&](int p) {
-            Timer pair_timer;
-            pair_timer.Start();
-            const image_t image_id1 = todo[2 * (size_t)p], image_id2 = todo[2 * (size_t)p + 1];
-            std::vector<DMatch> prune_matches((size_t)(offs[(size_t)p + 1] - offs[(size_t)p]));
-            for (size_t i = 0; i < prune_matches.size(); ++i) {
-                const size_t k = (size_t)offs[(size_t)p] + i;
-                prune_matches[i].queryIdx = qt[2 * k];
-                prune_matches[i].trainIdx = qt[2 * k + 1];
-                prune_matches[i].distance = dist[k];
-            }
-            if (host_verify)
-                FilterMatches(keypoints_cache_.at(image_id1), keypoints_cache_.at(image_id2), prune_matches, &verified[(size_t)p]);
-            else
-                verified[(size_t)p].swap(prune_matches);
-            verify_seconds[(size_t)p] = pair_timer.ElapsedSeconds();
-        };
-        // (the host twin of FilterMatches runs RANSAC per pair: all cores; otherwise this loop only copies the lists -- starting a
-        // thread per core of a 256-core host cost 10 ms for 1 ms of copying)
-        const int nthreads = host_verify ? std::max(1, std::min<int>(P / 4 + 1, (int)std::thread::hardware_concurrency())) : 1;
-        std::atomic<int> next(0);
-        std::vector<std::thread> pool;
-        for (int t = 1; t < nthreads; ++t)
-            pool.emplace_back([&] { for (int p; (p = next.fetch_add(1)) < P;) verify_pair(p); });
-        for (int p; (p = next.fetch_add(1)) < P;) verify_pair(p);
-        for (auto& th : pool) th.join();
     }
-    // emission: the reference's order, one transaction per group
-    Lap le(&g_clock.emit);
-    static const EmissionOptions emission = EmissionOptions::FromEnvironment();
+
+    // ---- the deal: blocks of ~BlockPairs() pairs and equal cost sum n1 * n2, block b to device b mod G
+    std::vector<DeviceRun> runs(G);
+    std::vector<uint8_t> dev_of(P, 0);
+    if (P > 0) {
+        std::vector<double> cum(P + 1, 0.0);
+        for (size_t p = 0; p < P; ++p) {
+            int n1 = 0, n2 = 0;
+            (void)msfm_image_rows(ctx_, todo[2 * p], &n1);
+            (void)msfm_image_rows(ctx_, todo[2 * p + 1], &n2);
+            cum[p + 1] = cum[p] + (double)n1 * n2 + 1.0;
+        }
+        // (a small job still gives every device something: at least four blocks per device where the pairs allow it)
+        const size_t per_block = std::max<size_t>(1, std::min(BlockPairs(), (P + 4 * G - 1) / (4 * G)));
+        const size_t n_blocks = (P + per_block - 1) / per_block;
+        size_t begin = 0;
+        for (size_t b = 0; b < n_blocks; ++b) {
+            size_t end = b + 1 == n_blocks ? P
+                                           : (size_t)(std::lower_bound(cum.begin(), cum.end(), cum[P] * (double)(b + 1) / (double)n_blocks) - cum.begin());
+            end = std::min(P, std::max(end, begin));
+            DeviceRun& r = runs[b % G];
+            for (size_t p = begin; p < end; ++p) {
+                dev_of[p] = (uint8_t)(b % G);
+                r.pairs.push_back(todo[2 * p]);
+                r.pairs.push_back(todo[2 * p + 1]);
+            }
+            begin = end;
+        }
+    }
+    if (G > 255) Die(nullptr, "more than 255 devices", MSFM_E_INVALID);
+
+    // ---- device threads
+    msfm_match_params prm;
+    prm.ratio = (float)distance_ratio_;  // ComputeCrossMatches takes `const float distance_ratio`
+    prm.cross_check = cross_check_ ? 1 : 0;
+    prm.max_distance = max_distance_;
+    std::atomic<bool> give_up(false);
+    Timer run_timer;
+    run_timer.Start();
+    // what waits between a device and the emitter: 1 GiB over all devices (emission slower than the GPUs: they wait; never the whole job in memory)
+    const size_t queue_cap = ((size_t)1 << 30) / std::max<size_t>(1, G);
+    auto work = [&](DeviceRun& r) {
+        const size_t n = r.pairs.size() / 2;
+        auto fail = [&](const char* what, int rc) {
+            r.status = rc;
+            r.error = std::string(what) + ": " + msfm_last_error(r.ctx);
+        };
+        int rc = msfm_match_pairs_begin(r.ctx, r.pairs.data(), (int)n, &prm, verify_on_device ? 1 : 0, nullptr);  // NULL: FilterMatches' constants
+        if (rc != MSFM_OK) {
+            fail("msfm_match_pairs_begin", rc);
+            r.queue->Close();
+            return;
+        }
+        Timer chunk_timer;
+        chunk_timer.Start();
+        while (!give_up.load(std::memory_order_relaxed)) {
+            msfm_chunk ch;
+            Timer t;
+            t.Start();
+            rc = msfm_match_pairs_next(r.ctx, &ch);
+            r.in_next += t.ElapsedSeconds();
+            if (rc != MSFM_OK) {
+                fail("msfm_match_pairs_next", rc);
+                break;
+            }
+            if (ch.n_pairs == 0) break;
+            t.Restart();
+            std::unique_ptr<ResultChunk> out(new ResultChunk());
+            out->first = (size_t)ch.first_pair;
+            out->n = (size_t)ch.n_pairs;
+            out->offsets.resize(out->n + 1);
+            out->rows.resize((size_t)ch.count * 2);
+            int64_t at = 0;
+            std::vector<DMatch> list, kept;
+            for (size_t p = 0; p < out->n; ++p) {
+                const image_t id1 = r.pairs[2 * (out->first + p)], id2 = r.pairs[2 * (out->first + p) + 1];
+                const int32_t* qt = ch.qt + 2 * ch.offsets[p];
+                size_t m = (size_t)(ch.offsets[p + 1] - ch.offsets[p]);
+                out->offsets[p] = at;
+                const bool swap = Database::SwapImagePair(id1, id2);
+                point2D_t* dst = out->rows.data() + 2 * at;
+                if (!host_verify && !emission.scene_graph_order && emission.min_num_matches <= 0) {
+                    // the stored row straight from the device's list: column 0 = the smaller image id's index
+                    if (swap)
+                        for (size_t i = 0; i < m; ++i) {
+                            dst[2 * i] = qt[2 * i + 1];
+                            dst[2 * i + 1] = qt[2 * i];
+                        }
+                    else if (m)
+                        std::memcpy(dst, qt, m * 8);
+                } else {
+                    // FeatureUtils::FilterMatches by the host twin and / or the emission options: through the DMatch form
+                    list.resize(m);
+                    for (size_t i = 0; i < m; ++i) {
+                        list[i].queryIdx = qt[2 * i];
+                        list[i].trainIdx = qt[2 * i + 1];
+                        list[i].distance = ch.dist[(size_t)ch.offsets[p] + i];
+                    }
+                    if (host_verify) {
+                        FilterMatches(keypoints_cache_.at(id1), keypoints_cache_.at(id2), list, &kept);
+                        list.swap(kept);
+                    }
+                    ApplyEmissionOptions(emission, id1, id2, &list);
+                    m = list.size();
+                    for (size_t i = 0; i < m; ++i) {
+                        dst[2 * i + (swap ? 1 : 0)] = list[i].queryIdx;
+                        dst[2 * i + (swap ? 0 : 1)] = list[i].trainIdx;
+                    }
+                }
+                at += (int64_t)m;
+            }
+            out->offsets[out->n] = at;
+            out->rows.resize((size_t)at * 2);
+            out->seconds_per_pair = chunk_timer.ElapsedSeconds() / (double)out->n;
+            chunk_timer.Restart();
+            r.in_layout += t.ElapsedSeconds();
+            if (!r.queue->Push(std::move(out))) break;
+        }
+        if (r.status != MSFM_OK || give_up.load()) (void)msfm_match_pairs_end(r.ctx);
+        r.queue->Close();
+    };
+    for (size_t g = 0; g < G; ++g) {
+        runs[g].ctx = devices_[g].ctx;
+        runs[g].queue.reset(new ChunkQueue(queue_cap));
+        if (!runs[g].pairs.empty()) runs[g].thread = std::thread(work, std::ref(runs[g]));
+        else runs[g].queue->Close();
+    }
+    auto stop_all = [&]() {
+        give_up.store(true);
+        for (DeviceRun& r : runs) r.queue->Abort();
+        for (DeviceRun& r : runs)
+            if (r.thread.joinable()) r.thread.join();
+    };
+
+    // ---- emission: the reference's order, one transaction per group
+    double waited = 0;
+    Timer emit_timer;
+    emit_timer.Start();
     std::string out;
     char buf[160];
+    long long matches_written = 0;
     static const bool trace_txn = std::getenv("MSFM_TRACE_TRANSACTIONS") != nullptr;  // tests: one line per transaction
     for (size_t g = 0; g < groups.size(); ++g) {
         database_->BeginTransaction();
@@ -382,37 +536,58 @@ void FeatureMatcher::MatchImagePairGroups(const std::vector<std::vector<std::pai
         out.clear();
         for (size_t k = 0; k < groups[g].size(); ++k) {
             const image_t image_id1 = groups[g][k].first, image_id2 = groups[g][k].second;
-            const int p = slots[g][k].todo_index;
+            const int p = slot[g][k];
             if (p < 0) {
                 std::snprintf(buf, sizeof(buf), "Compute Matches %d - %d Existing, Continue!\n", image_id1, image_id2);
                 out += buf;
                 continue;
             }
-            ApplyEmissionOptions(emission, image_id1, image_id2, &verified[(size_t)p]);
-            std::snprintf(buf, sizeof(buf), "Compute Matches %d - %d ... \n\t matches num : %zu\n\t ", image_id1, image_id2,
-                          verified[(size_t)p].size());
+            // the pair's lists: the next one of its device (a device's pairs are consumed in the order it computes them)
+            DeviceRun& r = runs[dev_of[(size_t)p]];
+            while (!r.cur || r.consumed >= r.cur->first + r.cur->n) {
+                Timer w;
+                w.Start();
+                r.cur = r.queue->Pop();
+                waited += w.ElapsedSeconds();
+                if (!r.cur) {
+                    stop_all();
+                    for (DeviceRun& x : runs)
+                        if (x.status != MSFM_OK) {
+                            std::fprintf(stderr, "ComputeMatches: %s (status %d)\n", x.error.c_str(), x.status);
+                            std::exit(EXIT_FAILURE);
+                        }
+                    Die(r.ctx, "device thread ended before its last pair", MSFM_E_STATE);
+                }
+            }
+            const size_t li = r.consumed - r.cur->first;
+            const int64_t m = r.cur->offsets[li + 1] - r.cur->offsets[li];
+            std::snprintf(buf, sizeof(buf), "Compute Matches %d - %d ... \n\t matches num : %zu\n\t ", image_id1, image_id2, (size_t)m);
             out += buf;
-            out += Timer::Format(gpu_seconds_per_pair + verify_seconds[(size_t)p], "seconds");
+            out += Timer::Format(r.cur->seconds_per_pair, "seconds");
             out += "\n";
-            database_->WriteMatches(image_id1, image_id2, verified[(size_t)p]);
+            database_->WriteMatchesStored(image_id1, image_id2, r.cur->rows.data() + 2 * r.cur->offsets[li], (size_t)m);
+            matches_written += m;
+            ++r.consumed;
         }
         std::cout << out << std::flush;
         database_->EndTransaction();
     }
-}
-
-namespace {
-// Pairs computed per device call (the reference's groups are <= 100 pairs; they are emitted unchanged afterwards).
-// Finished groups reach the database once per super-batch, so this is also what an interrupted run can lose:
-// MSFM_SUPER_BATCH_PAIRS lowers it (tests cross the boundary with tiny values).
-size_t SuperBatchPairs() {
-    static const size_t v = [] {
-        const char* e = std::getenv("MSFM_SUPER_BATCH_PAIRS");
-        const long long x = e ? std::atoll(e) : 0;
-        return x > 0 ? (size_t)x : (size_t)16384;
-    }();
-    return v;
-}
+    for (DeviceRun& r : runs)
+        if (r.thread.joinable()) r.thread.join();
+    for (DeviceRun& r : runs) {
+        if (r.status != MSFM_OK) {
+            std::fprintf(stderr, "ComputeMatches: %s (status %d)\n", r.error.c_str(), r.status);
+            std::exit(EXIT_FAILURE);
+        }
+        g_clock.device += r.in_next;
+        g_clock.layout += r.in_layout;
+    }
+    g_clock.devices = (int)G;
+    g_clock.wait += waited;
+    g_clock.emit += emit_timer.ElapsedSeconds() - waited;
+    g_clock.run += run_timer.ElapsedSeconds();
+    g_clock.pairs += (long long)P;
+    g_clock.matches += matches_written;
 }
 
 void SequentialFeatureMatcher::RunMatching() {
@@ -420,7 +595,6 @@ void SequentialFeatureMatcher::RunMatching() {
     PreloadAllImages();
     const std::vector<Database::Image> images = database_->ReadAllImages();
     std::vector<std::vector<std::pair<image_t, image_t>>> groups;
-    size_t pending = 0;
     for (size_t i = 1; i < images.size(); ++i) {
         std::vector<std::pair<image_t, image_t>> image_pairs;
         for (int k = 1; k <= overlap_; ++k) {
@@ -428,13 +602,7 @@ void SequentialFeatureMatcher::RunMatching() {
             if (j < 0) break;
             image_pairs.emplace_back((image_t)i, (image_t)j);
         }
-        pending += image_pairs.size();
         groups.push_back(std::move(image_pairs));
-        if (pending >= SuperBatchPairs()) {
-            MatchImagePairGroups(groups);
-            groups.clear();
-            pending = 0;
-        }
     }
     if (!groups.empty()) MatchImagePairGroups(groups);
     CloseDatabaseAndDevice();
@@ -446,14 +614,6 @@ void BruteFeatureMatcher::RunMatching() {
     const std::vector<Database::Image> images = database_->ReadAllImages();
     // the reference's groups: a flush every max_pairs_size_ pairs and at the end of every row i
     std::vector<std::vector<std::pair<image_t, image_t>>> groups;
-    size_t pending = 0;
-    auto flush = [&]() {
-        if (groups.empty()) return;
-        if (is_preemtive_) PreemptivelyFilterGroups(&groups);
-        MatchImagePairGroups(groups);
-        groups.clear();
-        pending = 0;
-    };
     for (size_t i = 0; i < images.size(); ++i) {
         std::vector<std::pair<image_t, image_t>> image_pairs;
         int cur_pairs_size = 0;
@@ -461,24 +621,21 @@ void BruteFeatureMatcher::RunMatching() {
             image_pairs.emplace_back((image_t)i, (image_t)j);
             cur_pairs_size += 1;
             if (cur_pairs_size == max_pairs_size_) {
-                pending += image_pairs.size();
                 groups.push_back(image_pairs);
                 image_pairs.clear();
                 cur_pairs_size = 0;
             }
         }
-        if (cur_pairs_size != 0) {
-            pending += image_pairs.size();
-            groups.push_back(image_pairs);
-        }
-        if (pending >= SuperBatchPairs()) flush();
+        if (cur_pairs_size != 0) groups.push_back(image_pairs);
     }
-    flush();
+    if (!groups.empty()) {
+        if (is_preemtive_) PreemptivelyFilterGroups(&groups);
+        MatchImagePairGroups(groups);
+    }
     CloseDatabaseAndDevice();
 }
 
-// PreemptivelyFilterImagePairs (src/Feature/FeatureMatching.cpp:148-179) for every group of a super-batch in
-// one device call
+// PreemptivelyFilterImagePairs (src/Feature/FeatureMatching.cpp:148-179) for every group of the run at once
 void BruteFeatureMatcher::PreemptivelyFilterGroups(std::vector<std::vector<std::pair<image_t, image_t>>>* groups) {
     std::vector<std::pair<image_t, image_t>> all;
     for (const auto& g : *groups) all.insert(all.end(), g.begin(), g.end());
@@ -496,24 +653,85 @@ void BruteFeatureMatcher::PreemptivelyFilterGroups(std::vector<std::vector<std::
     }
 }
 
+// ComputeCrossMatches / ComputeMatches on the two 100-row top-scale subsets, no distance filter (FeatureMatching.cpp:163-172), keep the
+// pair iff it yields >= preemtive_min_num_matches_ matches.  Every device takes a contiguous share of the pairs: its own subsets
+// (device-side gathers of the resident rows), one streaming series, only the counts come back.
 std::vector<char> BruteFeatureMatcher::PreemptiveKeepFlags(const std::vector<std::pair<image_t, image_t>>& image_pairs) {
     std::vector<char> keep(image_pairs.size(), 0);
     if (image_pairs.empty()) return keep;
-    std::vector<int32_t> slots;
-    for (const auto& image_pair : image_pairs) {
-        slots.push_back(GetTopScaleDescriptors(image_pair.first));
-        slots.push_back(GetTopScaleDescriptors(image_pair.second));
+    const size_t P = image_pairs.size(), G = devices_.size();
+    // calling thread (SQLite): the images resident, their keypoints read, the rows of every subset chosen
+    std::vector<image_t> ids;
+    for (const auto& pr : image_pairs) {
+        ids.push_back(pr.first);
+        ids.push_back(pr.second);
     }
-    // ComputeCrossMatches / ComputeMatches on the two 100-row subsets, no distance filter here
-    // (src/Feature/FeatureMatching.cpp:163-172)
+    std::sort(ids.begin(), ids.end());
+    ids.erase(std::unique(ids.begin(), ids.end()), ids.end());
+    std::map<image_t, std::vector<int32_t>> rows_of;
+    for (image_t id : ids) {
+        bool need = false;
+        for (const Device& dev : devices_) need |= dev.top_scale.count(id) == 0;
+        if (!need) continue;
+        // the reference re-reads the descriptors here (FeatureMatching.cpp:181-196); they are resident on the
+        // device already (or become so now), so only the keypoint scales are needed on the host
+        EnsureResident(id);
+        const std::vector<KeyPoint>& kpts = KeyPointsOf(id);
+        static_assert(sizeof(KeyPoint) == 16, "KeyPoint must be 4 packed floats");
+        std::vector<int32_t> idx(kpts.size() + 1);
+        int count = 0;
+        const int rc = msfm_topscale_select(reinterpret_cast<const float*>(kpts.data()), (int)kpts.size(), preemtive_num_features_, idx.data(), &count);
+        if (rc != MSFM_OK) Die(ctx_, "msfm_topscale_select", rc);
+        idx.resize((size_t)count);
+        rows_of[id] = std::move(idx);
+    }
     msfm_match_params prm;
     prm.ratio = (float)distance_ratio_;
     prm.cross_check = cross_check_ ? 1 : 0;
     prm.max_distance = __builtin_huge_val();
-    const int P = (int)image_pairs.size();
-    std::vector<int64_t> offs((size_t)P + 1);
-    MSFM_CALL(ctx_, msfm_match_pairs(ctx_, slots.data(), P, &prm, offs.data()));
-    for (int p = 0; p < P; ++p) keep[(size_t)p] = (offs[(size_t)p + 1] - offs[(size_t)p] >= preemtive_min_num_matches_) ? 1 : 0;
+    std::vector<int> status(G, MSFM_OK);
+    std::vector<std::string> what(G);
+    auto share = [&](size_t g) {
+        Device& dev = devices_[g];
+        const size_t begin = P * g / G, end = P * (g + 1) / G;
+        if (begin == end) return;
+        auto fail = [&](const char* w, int rc) {
+            status[g] = rc;
+            what[g] = std::string(w) + ": " + msfm_last_error(dev.ctx);
+        };
+        std::vector<int32_t> slots;
+        slots.reserve(2 * (end - begin));
+        for (size_t p = begin; p < end; ++p)
+            for (image_t id : {image_pairs[p].first, image_pairs[p].second}) {
+                const int slot = MSFM_MAX_IMAGES + id;   // auxiliary store slot of this image's subset
+                if (!dev.top_scale.count(id)) {
+                    const std::vector<int32_t>& rows = rows_of.at(id);
+                    const int rc = msfm_subset_image(dev.ctx, id, slot, rows.data(), (int)rows.size());
+                    if (rc != MSFM_OK) return fail("msfm_subset_image", rc);
+                    dev.top_scale.insert(id);
+                }
+                slots.push_back(slot);
+            }
+        int rc = msfm_match_pairs_begin(dev.ctx, slots.data(), (int)(end - begin), &prm, 0, nullptr);
+        if (rc != MSFM_OK) return fail("msfm_match_pairs_begin (pre-emptive filter)", rc);
+        while (true) {
+            msfm_chunk ch;
+            rc = msfm_match_pairs_next(dev.ctx, &ch);
+            if (rc != MSFM_OK) return fail("msfm_match_pairs_next (pre-emptive filter)", rc);
+            if (ch.n_pairs == 0) break;
+            for (int p = 0; p < ch.n_pairs; ++p)
+                keep[begin + (size_t)ch.first_pair + (size_t)p] = (ch.offsets[p + 1] - ch.offsets[p] >= preemtive_min_num_matches_) ? 1 : 0;
+        }
+    };
+    std::vector<std::thread> threads;
+    for (size_t g = 1; g < G; ++g) threads.emplace_back(share, g);
+    share(0);
+    for (auto& t : threads) t.join();
+    for (size_t g = 0; g < G; ++g)
+        if (status[g] != MSFM_OK) {
+            std::fprintf(stderr, "ComputeMatches: %s (status %d)\n", what[g].c_str(), status[g]);
+            std::exit(EXIT_FAILURE);
+        }
     return keep;
 }
 
@@ -529,23 +747,20 @@ std::vector<std::pair<image_t, image_t>> BruteFeatureMatcher::PreemptivelyFilter
 int BruteFeatureMatcher::GetTopScaleDescriptors(const image_t& image_id) {
     const int slot = MSFM_MAX_IMAGES + image_id;  // auxiliary store slot of this image's subset
     if (HasTopScaleDescriptorsCache(image_id)) return slot;
-    // the reference re-reads the descriptors here (FeatureMatching.cpp:181-196); they are resident on the
-    // device already (or become so now), so only the keypoint scales are needed on the host
     EnsureResident(image_id);
     const std::vector<KeyPoint>& kpts = KeyPointsOf(image_id);
-    static_assert(sizeof(KeyPoint) == 16, "KeyPoint must be 4 packed floats");
     std::vector<int32_t> idx(kpts.size() + 1);
     int count = 0;
     const int rc = msfm_topscale_select(reinterpret_cast<const float*>(kpts.data()), (int)kpts.size(),
                                         preemtive_num_features_, idx.data(), &count);
     if (rc != MSFM_OK) Die(ctx_, "msfm_topscale_select", rc);
     MSFM_CALL(ctx_, msfm_subset_image(ctx_, image_id, slot, idx.data(), count));
-    top_scale_descriptors_cache_.insert(image_id);
+    devices_[0].top_scale.insert(image_id);
     return slot;
 }
 
 bool BruteFeatureMatcher::HasTopScaleDescriptorsCache(const image_t& image_id) {
-    return top_scale_descriptors_cache_.count(image_id) > 0;
+    return !devices_.empty() && devices_[0].top_scale.count(image_id) > 0;
 }
 
 }  // namespace MonocularSfM

@@ -3,7 +3,9 @@
 // (include/msfm_match.h).  Differences from the reference, all behind the same interface:
 //   * descriptors are uploaded to the GPU once per image instead of being re-read from SQLite
 //     for every pair (the "TODO: cache" at src/Feature/FeatureMatching.cpp:31);
-//   * the pairs of one MatchImagePairs call are matched as one batched launch sequence.
+//   * the pairs of a whole run are matched as ONE streaming series per GPU (msfm_match_pairs_begin / _next) on device threads,
+//     while the calling thread -- the only one that touches SQLite -- writes the rows of the pairs already finished, in the
+//     reference's order, groups and transactions (FeatureMatching.cpp:13, 63-72: the reference emits inside its pair loop too).
 #pragma once
 #include <map>
 #include <set>
@@ -27,8 +29,8 @@ public:
     // FeatureMatching.cpp:10-73: skip pairs that already have a row, match, distance filter,
     // geometric verification, one matches row per pair (rows may be 0), all in one transaction.
     void MatchImagePairs(const std::vector<std::pair<image_t, image_t>>& image_pairs);
-    // Several such calls at once: computed together (one device batch, one parallel verification pass),
-    // emitted group by group exactly as consecutive MatchImagePairs calls would.
+    // Any number of such calls at once: what consecutive MatchImagePairs calls would print and write, group by group (one
+    // transaction each), while the GPUs are already working on the pairs of the later groups (see FeatureMatching.cpp).
     void MatchImagePairGroups(const std::vector<std::vector<std::pair<image_t, image_t>>>& groups);
     virtual void RunMatching() = 0;
 
@@ -55,16 +57,20 @@ protected:
     bool geometric_verification_ = true;
     bool verification_on_host_ = false;  // MSFM_GEOMETRIC_VERIFICATION=host
     Database* database_ = nullptr;
-    msfm_ctx* ctx_ = nullptr;             // primary device (MSFM_DEVICE, or the first entry of MSFM_DEVICES)
-    std::set<image_t> resident_;
+    // One context per GPU: MSFM_DEVICE (default 0), MSFM_DEVICES="0,1,..." or "all".  The whole descriptor store is replicated on
+    // each; the pairs of a run are dealt to the devices in small cost-balanced blocks, round-robin, so that every device's results
+    // arrive at the pace the emitter consumes them (SQLite stays on the calling thread).
+    struct Device {
+        msfm_ctx* ctx = nullptr;
+        std::set<image_t> resident;
+        std::set<image_t> top_scale;   // images whose top-scale subset lives in the auxiliary slot MSFM_MAX_IMAGES + id
+    };
+    std::vector<Device> devices_;
+    msfm_ctx* ctx_ = nullptr;             // = devices_[0].ctx
     bool bulk_loaded_ = false;
-    // MSFM_DEVICES="0,1,...": the pairs of a super-batch are split over these GPUs (one context and one host
-    // thread per device, the whole descriptor store replicated on each; SQLite stays on the calling thread)
-    std::vector<msfm_ctx*> extra_ctxs_;                 // devices 1..G-1
-    std::vector<std::set<image_t>> extra_resident_;
-    std::map<image_t, Descriptors> descriptor_cache_;   // host copies, kept only when there are extra devices
-    void EnsureResidentOn(size_t extra_index, image_t image_id);
-    std::map<image_t, std::vector<KeyPoint>> keypoints_cache_;  // read once per image (verification)
+    std::map<image_t, Descriptors> descriptor_cache_;   // host copies, kept only with several devices and without the bulk load
+    void EnsureResidentOn(size_t device_index, image_t image_id);
+    std::map<image_t, std::vector<KeyPoint>> keypoints_cache_;  // read once per image (verification, pre-emptive filter)
 };
 
 class SequentialFeatureMatcher : public FeatureMatcher {
@@ -100,14 +106,13 @@ private:
         std::vector<std::pair<image_t, image_t>> image_pairs);
     void PreemptivelyFilterGroups(std::vector<std::vector<std::pair<image_t, image_t>>>* groups);
     std::vector<char> PreemptiveKeepFlags(const std::vector<std::pair<image_t, image_t>>& image_pairs);
-    int GetTopScaleDescriptors(const image_t& image_id);  // returns the auxiliary store slot
+    int GetTopScaleDescriptors(const image_t& image_id);  // returns the auxiliary store slot (on the first device)
     bool HasTopScaleDescriptorsCache(const image_t& image_id);
 
     int max_pairs_size_;
     bool is_preemtive_;
     int preemtive_num_features_;
     int preemtive_min_num_matches_;
-    std::set<image_t> top_scale_descriptors_cache_;
 };
 
 }  // namespace MonocularSfM

@@ -16,6 +16,19 @@ cfg5full)   # BASELINE configs[4] IN FULL, streamed, one GP
     TMO=1700 run config5_full_stream python tools/config4_full.py --stream --images 4096 --desc 16384 --seed 4096 --oracle-pairs 24 --int-oracle-pairs 1 --cut-every 100
     head -c 1800 $OUT/config5_full_stream.txt; echo; grep -n "GiB\|mismatch" $OUT/config5_full_stream.txt; tail -5 $OUT/config5_full_stream.err
     ;;
+cli)   # the pipelined executable: its tests, the small end-to-end job, then the config-4-shaped database
+    TMO=900 run pytest_cli python -m pytest -m gpu -x -q tests/test_cli_gpu.py tests/test_gpu_stream.py tests/test_abi.py; tail -4 $OUT/pytest_cli.txt
+    run cli_e2e python tools/cli_e2e_bench.py; tail -8 $OUT/cli_e2e.txt
+    TMO=1500 run cli_config4 python tools/cli_e2e_bench.py --config4 --tables ${TABLES:-u8,f32} --json $OUT/cli_config4.json; cat $OUT/cli_config4.txt; tail -5 $OUT/cli_config4.err
+    ;;
+suite)   # the whole GPU suite
+    TMO=1800 run pytest_gpu python -m pytest tests -m gpu -x -q; tail -5 $OUT/pytest_gpu.txt
+    ;;
+second)
+    bash tools/gpu_r6.sh suite
+    bash tools/gpu_r6.sh cli
+    bash tools/gpu_r6.sh toggle
+    ;;
 first)   # both of the above in one call
     bash tools/gpu_r6.sh toggle
     bash tools/gpu_r6.sh cfg5full

@@ -7,12 +7,13 @@ The integer route feeds the matrix cores `x' = x - 128` (csrc/msfm_store.hip.h):
 
     sift          |N(0, 48)| clipped to 0..255         -> x' = -128 .. -80      (today's encoding on SIFT-like data)
     recentred     the same rows + (128 - median)       -> x' centred on 0       (what a per-store offset c = median would feed)
-    zeros         every value 128                      -> x' = 0                (the guide's zero-filled case: the size of the prize)
-    const_m128    every value 0                        -> x' = -128, constant   (large magnitude, nothing toggles between operands)
+    positive      the same rows + 128 (clipped)        -> x' = x: 0 .. 127      (small POSITIVE operands: what c = 0 would feed)
+    sparse_0      128 except 4 random entries per row  -> x' = 0 in 97 %        (the guide's zero-filled case: the size of the prize)
+    sparse_m128   0 except 4 random entries per row    -> x' = -128 in 97 %     (large magnitude, nothing toggles between operands)
     uniform       uniform 0..255                       -> x' uniform            (the high-toggle end)
 
-Every call runs with max_distance = -1 (no row can pass the distance cut: all rows are provably dead after sweep 1, so the tail
-is empty and the call is sweep 1 + thresholds) and pipeline 1 (one launch per call).  Sweep 1's control flow does not depend on
+Every call runs with max_distance = 0.001 (no pair of distinct integer rows can pass the distance cut: all rows are provably dead
+after sweep 1, so the tail is empty and the call is sweep 1 + thresholds; a NEGATIVE max_distance switches the pruning off instead) and pipeline 1 (one launch per call).  Sweep 1's control flow does not depend on
 the data (every descriptor pair is multiplied, the epilogue is v_max3): the launch does the same work in every variant.
 Beside every variant: tools/power_sampler (socket power, shader clocks, PPT residency at 20 Hz).
 
@@ -28,6 +29,7 @@ import time
 
 import numpy as np
 
+MAXD = 1e-3   # below every distance of distinct integer rows (>= 1): every row is provably dead after sweep 1
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from monocularsfm_amd import _lib, synth  # noqa: E402
@@ -37,11 +39,24 @@ def variants(n_images, n_desc, seed):
     base = synth.u8_images(n_images, n_desc, seed=seed, as_float=False)
     med = int(np.median(np.concatenate([b[:256].ravel() for b in base])))
     rng = np.random.default_rng(seed + 1)
+
+    def sparse(fill):
+        """every row `fill` except four random positions with random values: 97 % of the operand bytes constant, rows still distinct
+        (an all-equal image has every distance 0: every row keeps all its candidates and the pairs fall back to brute force)"""
+        out = []
+        for b in base:
+            a = np.full_like(b, fill)
+            cols = rng.integers(0, 128, (len(b), 4))
+            a[np.arange(len(b))[:, None], cols] = rng.integers(0, 256, (len(b), 4), dtype=np.uint8)
+            out.append(a)
+        return out
     yield "sift", base, "x' = x - 128 on |N(0,48)|: median x' %d" % (med - 128)
     yield "recentred", [np.clip(b.astype(np.int32) + (128 - med), 0, 255).astype(np.uint8) for b in base], \
         "the same rows + %d: median x' 0 (values beyond 255 clipped: timing probe)" % (128 - med)
-    yield "zeros", [np.full_like(b, 128) for b in base], "x' = 0 everywhere"
-    yield "const_m128", [np.zeros_like(b) for b in base], "x' = -128 everywhere"
+    yield "positive", [np.clip(b.astype(np.int32) + 128, 0, 255).astype(np.uint8) for b in base], \
+        "the same rows + 128: x' = x, small POSITIVE operands, median x' +%d (clipped at 127)" % med
+    yield "sparse_0", sparse(128), "x' = 0 in 124 of 128 positions (the guide's zero-filled case, rows kept distinct)"
+    yield "sparse_m128", sparse(0), "x' = -128 in 124 of 128 positions (large magnitude, nothing toggles)"
     yield "uniform", [rng.integers(0, 256, b.shape, dtype=np.uint8) for b in base], "x' uniform -128 .. 127"
 
 
@@ -94,7 +109,7 @@ def main():
     dp = float(len(pairs)) * args.desc * args.desc
     print("# operand-toggle probe of sweep_i8_kernel<1>: %d images x %d byte descriptors, %d pairs, %.3e descriptor pairs per call" % (
         args.images, args.desc, len(pairs), dp))
-    print("# max_distance = -1 (every row dead after sweep 1: empty tail), pipeline 1 (one launch per call), %.0f s per variant and round" % args.seconds)
+    print("# max_distance = 0.001 (every row dead after sweep 1: empty tail), pipeline 1 (one launch per call), %.0f s per variant and round" % args.seconds)
     ctxs = {}
     notes = {}
     order = []
@@ -104,7 +119,7 @@ def main():
         for i, im in enumerate(imgs):
             c.upload_image(i, im)
         c.finalize_store()
-        c.match_pairs(pairs, max_distance=-1.0, fetch=False)     # warm: buffers, plan hints
+        c.match_pairs(pairs, max_distance=MAXD, fetch=False)     # warm: buffers, plan hints
         ctxs[name], notes[name] = c, note
         order.append(name)
     print("# device: %s" % ctxs[order[0]].device_info())
@@ -121,7 +136,7 @@ def main():
             cand = fb = 0
             t0 = time.perf_counter()
             while time.perf_counter() - t0 < args.seconds:
-                c.match_pairs(pairs, max_distance=-1.0, fetch=False)
+                c.match_pairs(pairs, max_distance=MAXD, fetch=False)
                 p = c.profile()
                 s1_ms += p["approx_kernel_ms"]
                 s1_n += p["approx_kernel_launches"]
