@@ -439,6 +439,15 @@ def main():
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 sustained = float(t.cpu()[0])
         run_job.sustained = sustained
+        # the last step's exchange as this rank saw it: the library's device-to-device copy into the (torch-allocated) send tensor and its
+        # rate -- the cross-runtime pointer of monocularsfm_amd/_lib.py -- and, for streamed steps, how much of the exchange the matching
+        # thread actually waited for (sharding.match_to_writer_batches pipelines it under the next super-batch)
+        last = dict(sm.last)
+        run_job.exchange_detail = None if not multi else {
+            "fetch_device_ms": last.get("fetch_device_ms"), "fetch_device_bytes": last.get("fetch_device_bytes"),
+            "fetch_device_GBps": (last["fetch_device_bytes"] / 1e9 / (last["fetch_device_ms"] * 1e-3)) if last.get("fetch_device_ms") else None,
+            "exchange_ms": last.get("exchange_ms"), "exchange_wait_ms": last.get("exchange_wait_ms"), "pipelined": last.get("pipelined"),
+            "local_matches": last.get("local_matches"), "super_batches": last.get("super_batches")}
         run_job.stream_stats = dict(stream_stats) if args.super_batch_pairs > 0 else None
         # after everything timed: the sweeps ALONE (one sub-batch per step, nothing in flight beside them) -- in the timed
         # region the other sub-batches' bandwidth-bound tails run beside a sweep and stretch its event span
@@ -479,6 +488,7 @@ def main():
     sustained = run_job.sustained
     solo = run_job.solo
     stream_main = run_job.stream_stats
+    main_exchange_detail = run_job.exchange_detail
     total_desc_pairs = int((n_rows[pairs[:, 0]] * n_rows[pairs[:, 1]]).sum())
     offs = result[0]
     n_matches = int(offs[-1])
@@ -504,6 +514,7 @@ def main():
                                   "to the writer rank" % world},
         # this rank's view per step (ms): matcher call (sweeps + epilogue + copy into the send buffer) vs exchange
         "per_rank_ms": [{"compute": c, "exchange": e} for c, e in per_rank],
+        "exchange_detail_rank0": main_exchange_detail,
         "device_ms_per_step_rank0": acc["total_device_ms"] / args.steps,
         # the same step repeated --sustained-steps times right after the timed region (power / thermal steady state)
         "sustained_ms_per_step": None if sustained is None else sustained * 1e3,
@@ -656,6 +667,7 @@ def main():
             "steps": args.u8_steps, "warmup": 1, "image_pairs": int(len(u_pairs)), "descriptor_pairs_per_step": u_total,
             "matches_per_step": int(u_res[0][-1]), "n_gpus": world, "scaling": "strong",
             "per_rank_ms": [{"compute": c, "exchange": e} for c, e in u_per_rank],
+            "exchange_detail_rank0": run_job.exchange_detail,
             "sub_batches_per_step_rank0": u_acc["sub_batches"] // max(1, args.u8_steps),
             "order_sensitive_rows_rank0": int(u_acc["order_sensitive_rows"]) // max(1, args.u8_steps),
             "sweep1": {"instruction": "v_mfma_i32_32x32x32_i8" if i8 else "v_mfma_f32_32x32x16_f16", "achieved": u_ach,

@@ -81,6 +81,18 @@ void Database::Open(const std::string& path) {
         const char* e = std::getenv("MSFM_SQLITE_MMAP");
         if (!(e && e[0] == '0')) Exec(database_, "PRAGMA mmap_size=4294967296");
     }
+    // MSFM_SQLITE_PRAGMAS="name=value;name=value": further connection-local pragmas (experiments with the write path: cache_size,
+    // wal_autocheckpoint, locking_mode -- tools/emit_bench.cpp); applied after the reference's four, before the tables are touched
+    if (const char* extra = std::getenv("MSFM_SQLITE_PRAGMAS")) {
+        std::string all(extra);
+        size_t at = 0;
+        while (at < all.size()) {
+            size_t end = all.find(';', at);
+            if (end == std::string::npos) end = all.size();
+            if (end > at) Exec(database_, ("PRAGMA " + all.substr(at, end - at)).c_str());
+            at = end + 1;
+        }
+    }
     CreateTables();
     UpdateSchema();
     PrepareSQLStatements();

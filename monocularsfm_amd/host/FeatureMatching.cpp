@@ -390,15 +390,32 @@ void FeatureMatcher::MatchImagePairGroups(const std::vector<std::vector<std::pai
     }
 
     // ---- the deal: blocks of ~BlockPairs() pairs and equal cost sum n1 * n2, block b to device b mod G
+    // The order the pairs are COMPUTED and their rows WRITTEN in: the reference's (default), or -- MSFM_EMIT_ORDER=pair_id -- ascending
+    // pair_id.  The matchers enumerate (i, j < i) with i outermost while the row key is kMaxNumImages * j + i (Database.cpp:656-667):
+    // the reference's order inserts into a different one of ~N key bands every time, each insert lands between two full leaves
+    // (a 3-KB row fills a 4-KB page) and SQLite rebalances three sibling pages for it -- 16 us per row on the GPU box, 3.4 x the cost
+    // of the same rows in key order, which SQLite appends (tools/emit_bench.cpp, profiles/r06_emission_study.txt).  In key order the
+    // stdout lines are still the reference's, in the reference's order, but printed when the rows are in; transactions hold 100 rows.
+    static const bool key_order = [] {
+        const char* e = std::getenv("MSFM_EMIT_ORDER");
+        return e && std::string(e) == "pair_id";
+    }();
+    std::vector<int> work_order(P);
+    for (size_t p = 0; p < P; ++p) work_order[p] = (int)p;
+    if (key_order)
+        std::sort(work_order.begin(), work_order.end(), [&](int a, int b) {
+            return Database::ImagePairToPairId(todo[2 * (size_t)a], todo[2 * (size_t)a + 1]) < Database::ImagePairToPairId(todo[2 * (size_t)b], todo[2 * (size_t)b + 1]);
+        });
     std::vector<DeviceRun> runs(G);
-    std::vector<uint8_t> dev_of(P, 0);
+    std::vector<uint8_t> dev_of(P, 0);   // by position in work_order
     if (P > 0) {
         std::vector<double> cum(P + 1, 0.0);
-        for (size_t p = 0; p < P; ++p) {
+        for (size_t w = 0; w < P; ++w) {
+            const size_t p = (size_t)work_order[w];
             int n1 = 0, n2 = 0;
             (void)msfm_image_rows(ctx_, todo[2 * p], &n1);
             (void)msfm_image_rows(ctx_, todo[2 * p + 1], &n2);
-            cum[p + 1] = cum[p] + (double)n1 * n2 + 1.0;
+            cum[w + 1] = cum[w] + (double)n1 * n2 + 1.0;
         }
         // (a small job still gives every device something: at least four blocks per device where the pairs allow it)
         const size_t per_block = std::max<size_t>(1, std::min(BlockPairs(), (P + 4 * G - 1) / (4 * G)));
@@ -409,8 +426,9 @@ void FeatureMatcher::MatchImagePairGroups(const std::vector<std::vector<std::pai
                                            : (size_t)(std::lower_bound(cum.begin(), cum.end(), cum[P] * (double)(b + 1) / (double)n_blocks) - cum.begin());
             end = std::min(P, std::max(end, begin));
             DeviceRun& r = runs[b % G];
-            for (size_t p = begin; p < end; ++p) {
-                dev_of[p] = (uint8_t)(b % G);
+            for (size_t w = begin; w < end; ++w) {
+                const size_t p = (size_t)work_order[w];
+                dev_of[w] = (uint8_t)(b % G);
                 r.pairs.push_back(todo[2 * p]);
                 r.pairs.push_back(todo[2 * p + 1]);
             }
@@ -487,6 +505,7 @@ void FeatureMatcher::MatchImagePairGroups(const std::vector<std::vector<std::pai
                         list[i].distance = ch.dist[(size_t)ch.offsets[p] + i];
                     }
                     if (host_verify) {
+                        kept.clear();   // (FilterMatches appends, and returns without touching the list for an empty input)
                         FilterMatches(keypoints_cache_.at(id1), keypoints_cache_.at(id2), list, &kept);
                         list.swap(kept);
                     }
@@ -522,7 +541,7 @@ void FeatureMatcher::MatchImagePairGroups(const std::vector<std::vector<std::pai
             if (r.thread.joinable()) r.thread.join();
     };
 
-    // ---- emission: the reference's order, one transaction per group
+    // ---- emission
     double waited = 0;
     Timer emit_timer;
     emit_timer.Start();
@@ -530,9 +549,61 @@ void FeatureMatcher::MatchImagePairGroups(const std::vector<std::vector<std::pai
     char buf[160];
     long long matches_written = 0;
     static const bool trace_txn = std::getenv("MSFM_TRACE_TRANSACTIONS") != nullptr;  // tests: one line per transaction
+    // the lists of the pair at position w of the work order: the next one of its device (a device's pairs are consumed in the order it
+    // computes them)
+    struct Fetched {
+        const point2D_t* rows;
+        size_t m;
+        double seconds;
+    };
+    auto fetch = [&](size_t w) -> Fetched {
+        DeviceRun& r = runs[dev_of[w]];
+        while (!r.cur || r.consumed >= r.cur->first + r.cur->n) {
+            Timer wt;
+            wt.Start();
+            r.cur = r.queue->Pop();
+            waited += wt.ElapsedSeconds();
+            if (!r.cur) {
+                stop_all();
+                for (DeviceRun& x : runs)
+                    if (x.status != MSFM_OK) {
+                        std::fprintf(stderr, "ComputeMatches: %s (status %d)\n", x.error.c_str(), x.status);
+                        std::exit(EXIT_FAILURE);
+                    }
+                Die(r.ctx, "device thread ended before its last pair", MSFM_E_STATE);
+            }
+        }
+        const size_t li = r.consumed - r.cur->first;
+        ++r.consumed;
+        return Fetched{r.cur->rows.data() + 2 * r.cur->offsets[li], (size_t)(r.cur->offsets[li + 1] - r.cur->offsets[li]), r.cur->seconds_per_pair};
+    };
+    std::vector<uint32_t> count_of;    // key order: what the stdout lines need, by todo index
+    std::vector<float> seconds_of;
+    if (key_order) {
+        // rows first, in ascending pair_id, 100 per transaction
+        count_of.resize(P);
+        seconds_of.resize(P);
+        for (size_t w0 = 0; w0 < P; w0 += 100) {
+            const size_t w1 = std::min(P, w0 + 100);
+            database_->BeginTransaction();
+            if (trace_txn) std::fprintf(stderr, "[msfm txn] %zu\n", w1 - w0);
+            for (size_t w = w0; w < w1; ++w) {
+                const size_t p = (size_t)work_order[w];
+                const Fetched f = fetch(w);
+                database_->WriteMatchesStored(todo[2 * p], todo[2 * p + 1], f.rows, f.m);
+                count_of[p] = (uint32_t)f.m;
+                seconds_of[p] = (float)f.seconds;
+                matches_written += (long long)f.m;
+            }
+            database_->EndTransaction();
+        }
+    }
+    // the reference's order: one transaction per group (key order: the lines only -- the rows are in)
     for (size_t g = 0; g < groups.size(); ++g) {
-        database_->BeginTransaction();
-        if (trace_txn) std::fprintf(stderr, "[msfm txn] %zu\n", groups[g].size());
+        if (!key_order) {
+            database_->BeginTransaction();
+            if (trace_txn) std::fprintf(stderr, "[msfm txn] %zu\n", groups[g].size());
+        }
         out.clear();
         for (size_t k = 0; k < groups[g].size(); ++k) {
             const image_t image_id1 = groups[g][k].first, image_id2 = groups[g][k].second;
@@ -542,35 +613,25 @@ void FeatureMatcher::MatchImagePairGroups(const std::vector<std::vector<std::pai
                 out += buf;
                 continue;
             }
-            // the pair's lists: the next one of its device (a device's pairs are consumed in the order it computes them)
-            DeviceRun& r = runs[dev_of[(size_t)p]];
-            while (!r.cur || r.consumed >= r.cur->first + r.cur->n) {
-                Timer w;
-                w.Start();
-                r.cur = r.queue->Pop();
-                waited += w.ElapsedSeconds();
-                if (!r.cur) {
-                    stop_all();
-                    for (DeviceRun& x : runs)
-                        if (x.status != MSFM_OK) {
-                            std::fprintf(stderr, "ComputeMatches: %s (status %d)\n", x.error.c_str(), x.status);
-                            std::exit(EXIT_FAILURE);
-                        }
-                    Die(r.ctx, "device thread ended before its last pair", MSFM_E_STATE);
-                }
+            size_t m;
+            double seconds;
+            if (key_order) {
+                m = count_of[(size_t)p];
+                seconds = seconds_of[(size_t)p];
+            } else {
+                const Fetched f = fetch((size_t)p);
+                database_->WriteMatchesStored(image_id1, image_id2, f.rows, f.m);
+                m = f.m;
+                seconds = f.seconds;
+                matches_written += (long long)m;
             }
-            const size_t li = r.consumed - r.cur->first;
-            const int64_t m = r.cur->offsets[li + 1] - r.cur->offsets[li];
-            std::snprintf(buf, sizeof(buf), "Compute Matches %d - %d ... \n\t matches num : %zu\n\t ", image_id1, image_id2, (size_t)m);
+            std::snprintf(buf, sizeof(buf), "Compute Matches %d - %d ... \n\t matches num : %zu\n\t ", image_id1, image_id2, m);
             out += buf;
-            out += Timer::Format(r.cur->seconds_per_pair, "seconds");
+            out += Timer::Format(seconds, "seconds");
             out += "\n";
-            database_->WriteMatchesStored(image_id1, image_id2, r.cur->rows.data() + 2 * r.cur->offsets[li], (size_t)m);
-            matches_written += m;
-            ++r.consumed;
         }
         std::cout << out << std::flush;
-        database_->EndTransaction();
+        if (!key_order) database_->EndTransaction();
     }
     for (DeviceRun& r : runs)
         if (r.thread.joinable()) r.thread.join();

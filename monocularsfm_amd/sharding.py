@@ -146,7 +146,7 @@ def range_bounds(parts, n_pairs):
     return b
 
 
-def gather_to_writer(bounds, local_offs, local_payload, dst=0, group=None, device=None, force_collectives=False):
+def gather_to_writer(bounds, local_offs, local_payload, dst=0, group=None, device=None, force_collectives=False, slot=""):
     """The exchange step of the CLI flow: only the rank that owns the SQLite handle needs the lists.
 
     bounds        : range_bounds(...) -- the same on every rank, no exchange needed (an empty range in the middle,
@@ -156,7 +156,8 @@ def gather_to_writer(bounds, local_offs, local_payload, dst=0, group=None, devic
                     stores, Database.cpp:631-654; cols = 3 adds the distance bits).  With RCCL it is the device tensor
                     the library filled (msfm_fetch_matches_device): the lists never visit the host on the sender.
     -> (global offsets int64[P+1] on every rank, payload int32[M, cols] as a NumPy view of a reused page-locked
-        host buffer on rank `dst` -- valid until the next call -- and None elsewhere).
+        host buffer on rank `dst` -- valid until the next call WITH THE SAME `slot` (the pipelined super-batches alternate two) --
+        and None elsewhere).
 
     One all_reduce(SUM) of the per-pair counts (disjoint supports: a concatenation), then every non-writer rank with
     matches SENDS its block and the writer RECEIVES each block at its final position of one [M, cols] buffer: no rank
@@ -187,7 +188,7 @@ def gather_to_writer(bounds, local_offs, local_payload, dst=0, group=None, devic
     # P2POp's peer is a GLOBAL rank; r / dst are ranks of `group`
     peer = (lambda r: dist.get_global_rank(group, r)) if (multi and group is not None) else (lambda r: r)
     if rank == dst:
-        out = _device_buffer(M, cols, dev, "recv") if pin else _host_buffer(M, cols, False, "recv")
+        out = _device_buffer(M, cols, dev, "recv" + slot) if pin else _host_buffer(M, cols, False, "recv" + slot)
         ops = [dist.P2POp(dist.irecv, out[int(blk[r]):int(blk[r + 1])], peer(r), group)
                for r in range(world) if r != dst and blk[r + 1] > blk[r]]
         if ops:
@@ -198,7 +199,7 @@ def gather_to_writer(bounds, local_offs, local_payload, dst=0, group=None, devic
             for q in reqs:
                 q.wait()
         if pin:
-            host = _host_buffer(M, cols, True, "host")
+            host = _host_buffer(M, cols, True, "host" + slot)
             host.copy_(out, non_blocking=True)
             torch.cuda.synchronize(dev)
             return offs, host.numpy()
@@ -248,33 +249,37 @@ class ShardedMatcher:
         mine, offs, qt, d = self.match_local(pairs, n_rows)
         return gather_matches(mine, offs, qt, d, len(pairs), group=self.group, device=self.device)
 
-    def match_to_writer(self, pairs, n_rows, dst=0, with_dist=False):
-        """The CLI flow: global offsets everywhere, the match lists only on rank `dst` (the SQLite writer).
-        -> (offsets, qt int32[M, 2] or None, dist float32[M] or None); qt / dist are views of a reused host buffer."""
+    def _compute_local(self, pairs, n_rows, with_dist, slot=""):
+        """This rank's share of `pairs` through the matcher, its lists as the send tensor of the exchange.
+        -> (bounds, local offsets, payload int32[m, cols] on the exchange device, timing dict)"""
         import time
         import torch
         rank, world = self._rank_world()
-        pairs = np.asarray(pairs, np.int32).reshape(-1, 2)
         parts = partition_pairs(pairs, n_rows, world)
         bounds = range_bounds(parts, len(pairs))
         mine = parts[rank]
         dev = self.device if self.device is not None else torch.device("cpu")
         cols = 3 if with_dist else 2
         t0 = time.perf_counter()
+        fetch_ms = 0.0
         if self._own_fn and dev.type == "cuda":
             # lists stay in HBM: the library copies them device-to-device into the send tensor
             kw = dict(self.match_kw)
             kw.pop("fetch", None)
             offs, _, _ = self.ctx.match_pairs(pairs[mine], fetch=False, **kw)
             m = int(offs[-1])
+            tf = time.perf_counter()
             if with_dist:
-                qt_t = _device_buffer(m, 2, dev, "send_qt")
-                d_t = _device_buffer(m, 1, dev, "send_d")
+                qt_t = _device_buffer(m, 2, dev, "send_qt" + slot)
+                d_t = _device_buffer(m, 1, dev, "send_d" + slot)
                 self.ctx.fetch_matches_device(qt_t.data_ptr() if m else 0, d_t.data_ptr() if m else 0)
                 payload = torch.cat([qt_t, d_t], dim=1)
             else:
-                payload = _device_buffer(m, 2, dev, "send_qt")
+                payload = _device_buffer(m, 2, dev, "send_qt" + slot)
                 self.ctx.fetch_matches_device(payload.data_ptr() if m else 0, 0)
+            # (the send tensor is torch's allocation, filled by the library through the system HIP runtime: the copy's rate is
+            # recorded -- msfm_fetch_matches_device returns when it has completed -- so that a slow cross-runtime path shows up)
+            fetch_ms = (time.perf_counter() - tf) * 1e3
         else:
             offs, qt, d = self.match_fn(pairs[mine])
             m = int(offs[-1])
@@ -284,41 +289,101 @@ class ShardedMatcher:
                 host[:, 2] = np.ascontiguousarray(d, dtype=np.float32).view(np.int32)
             payload = torch.from_numpy(host).to(dev)
         t1 = time.perf_counter()
+        info = {"compute_ms": (t1 - t0) * 1e3, "local_pairs": int(len(mine)), "local_matches": m,
+                "fetch_device_ms": fetch_ms, "fetch_device_bytes": m * 4 * cols if fetch_ms else 0}
+        return bounds, offs, payload, info
+
+    def match_to_writer(self, pairs, n_rows, dst=0, with_dist=False):
+        """The CLI flow: global offsets everywhere, the match lists only on rank `dst` (the SQLite writer).
+        -> (offsets, qt int32[M, 2] or None, dist float32[M] or None); qt / dist are views of a reused host buffer."""
+        import time
+        import torch
+        pairs = np.asarray(pairs, np.int32).reshape(-1, 2)
+        dev = self.device if self.device is not None else torch.device("cpu")
+        bounds, offs, payload, info = self._compute_local(pairs, n_rows, with_dist)
+        t1 = time.perf_counter()
         goffs, allm = gather_to_writer(bounds, offs, payload, dst=dst, group=self.group, device=dev,
                                        force_collectives=self.force_collectives)
-        t2 = time.perf_counter()
-        self.last = {"compute_ms": (t1 - t0) * 1e3, "exchange_ms": (t2 - t1) * 1e3, "local_pairs": int(len(mine)),
-                     "local_matches": m}
+        info["exchange_ms"] = (time.perf_counter() - t1) * 1e3
+        self.last = info
         if allm is None:
             return goffs, None, None
         if with_dist:
             return goffs, allm[:, 0:2], allm[:, 2].view(np.float32)
         return goffs, allm, None
 
-    def match_to_writer_batches(self, pairs, n_rows, batch_pairs=65536, dst=0, sink=None, with_dist=False):
+    def match_to_writer_batches(self, pairs, n_rows, batch_pairs=65536, dst=0, sink=None, with_dist=False, pipelined=True):
         """The same flow in SUPER-BATCHES of at most `batch_pairs` pairs, for jobs whose lists do not fit memory (BASELINE's largest
         config: 6.9e9 matches = 83 GB): every super-batch is partitioned over the ranks, matched, exchanged, handed to
         `sink(first_pair, offsets, qt, dist)` on the writer rank -- offsets relative to the super-batch, the arrays views valid until
-        the next one -- and dropped.  What is resident at any time is one super-batch's lists: on a rank its share (in the library),
-        on the writer the whole super-batch.  The reference streams the same way, one transaction per <= 100 pairs
-        (/root/reference/src/Feature/FeatureMatching.cpp:13, 70-72, 118-139; the C++ drop-in: host/FeatureMatching.cpp's super-batches).
-        -> per-pair match counts int64[P] on every rank; self.last sums the phases over the super-batches."""
+        the super-batch after the next -- and dropped.  What is resident at any time is two super-batches' lists: on a rank its
+        share (in the library + one send tensor), on the writer the whole super-batch.  The reference streams the same way, one
+        transaction per <= 100 pairs (/root/reference/src/Feature/FeatureMatching.cpp:13, 70-72, 118-139; the C++ drop-in:
+        host/FeatureMatching.cpp).
+        `pipelined` (default): the exchange of super-batch k -- all_reduce of the counts, sends to the writer, the writer's copy to
+        the host -- runs on a second thread WHILE super-batch k + 1 is being matched (two sets of send / receive buffers, taken in
+        turn); every rank issues its exchanges in the same order on that thread, so the collectives pair up as before.  The wall
+        clock of a step is then ~ sum(compute) + the last exchange instead of sum(compute + exchange).
+        -> per-pair match counts int64[P] on every rank; self.last sums the phases over the super-batches (`exchange_ms`: time
+        the exchanges took on their thread; `exchange_wait_ms`: what of it the matching thread actually waited for)."""
+        import time
+        import torch
+        from concurrent.futures import ThreadPoolExecutor
         pairs = np.asarray(pairs, np.int32).reshape(-1, 2)
         P = len(pairs)
         counts = np.zeros(P, np.int64)
         rank, _ = self._rank_world()
-        tot = {"compute_ms": 0.0, "exchange_ms": 0.0, "local_pairs": 0, "local_matches": 0, "super_batches": 0, "max_batch_matches": 0}
+        dev = self.device if self.device is not None else torch.device("cpu")
+        tot = {"compute_ms": 0.0, "exchange_ms": 0.0, "exchange_wait_ms": 0.0, "local_pairs": 0, "local_matches": 0, "super_batches": 0,
+               "max_batch_matches": 0, "fetch_device_ms": 0.0, "fetch_device_bytes": 0, "pipelined": bool(pipelined)}
         step = max(1, int(batch_pairs))
-        for b0 in range(0, P, step):
-            sub = pairs[b0:b0 + step]
-            offs, qt, d = self.match_to_writer(sub, n_rows, dst=dst, with_dist=with_dist)
-            counts[b0:b0 + len(sub)] = np.diff(offs)
-            for k in ("compute_ms", "exchange_ms", "local_pairs", "local_matches"):
-                tot[k] += self.last[k]
-            tot["super_batches"] += 1
-            tot["max_batch_matches"] = max(tot["max_batch_matches"], int(offs[-1]))
+
+        def exchange(k, bounds, offs, payload):
+            if dev.type == "cuda":
+                torch.cuda.set_device(dev)   # (the exchange thread's own current device)
+            t = time.perf_counter()
+            goffs, allm = gather_to_writer(bounds, offs, payload, dst=dst, group=self.group, device=dev,
+                                           force_collectives=self.force_collectives, slot=str(k & 1))
+            return goffs, allm, (time.perf_counter() - t) * 1e3
+
+        def deliver(b0, n_sub, res):
+            goffs, allm, ms = res
+            counts[b0:b0 + n_sub] = np.diff(goffs)
+            tot["exchange_ms"] += ms
+            tot["max_batch_matches"] = max(tot["max_batch_matches"], int(goffs[-1]))
             if sink is not None and rank == dst:
-                sink(b0, offs, qt, d)
+                if with_dist:
+                    sink(b0, goffs, allm[:, 0:2], allm[:, 2].view(np.float32))
+                else:
+                    sink(b0, goffs, allm, None)
+
+        pool = ThreadPoolExecutor(1) if pipelined else None
+        pending = None   # (first pair, pairs, future) of the exchange in flight
+        try:
+            for k, b0 in enumerate(range(0, P, step)):
+                sub = pairs[b0:b0 + step]
+                bounds, offs, payload, info = self._compute_local(sub, n_rows, with_dist, slot=str(k & 1))
+                for key in ("compute_ms", "local_pairs", "local_matches", "fetch_device_ms", "fetch_device_bytes"):
+                    tot[key] += info[key]
+                tot["super_batches"] += 1
+                if pool is None:
+                    res = exchange(k, bounds, offs, payload)
+                    tot["exchange_wait_ms"] += res[2]
+                    deliver(b0, len(sub), res)
+                    continue
+                if pending is not None:
+                    t = time.perf_counter()
+                    res = pending[2].result()
+                    tot["exchange_wait_ms"] += (time.perf_counter() - t) * 1e3
+                    deliver(pending[0], pending[1], res)
+                pending = (b0, len(sub), pool.submit(exchange, k, bounds, offs, payload))
+            if pending is not None:
+                t = time.perf_counter()
+                res = pending[2].result()
+                tot["exchange_wait_ms"] += (time.perf_counter() - t) * 1e3
+                deliver(pending[0], pending[1], res)
+        finally:
+            if pool is not None:
+                pool.shutdown(wait=True)
         self.last = tot
         return counts
-

@@ -18,6 +18,10 @@
 #if defined(__SSE2__)
 #include <emmintrin.h>
 #endif
+#if defined(__x86_64__)
+#include <immintrin.h>
+#define ORC_X86_SIMD 1
+#endif
 
 /* ------------------------------------------------------------------------- */
 /* S(a,b): restatement of cv::hal::normL2Sqr_(const float*, const float*, n)  */
@@ -69,7 +73,7 @@ static float l2sqr_sse4x4(const float* a, const float* b)
 #define l2sqr_sse4x4 l2sqr_sse4x4_scalar
 #endif
 
-static float l2sqr_avx2_fma(const float* a, const float* b)
+static float l2sqr_avx2_fma_plainc(const float* a, const float* b)
 {
     float p[32];
     for (int L = 0; L < 32; ++L) p[L] = 0.0f;
@@ -90,7 +94,7 @@ static float l2sqr_avx2_fma(const float* a, const float* b)
  * the SSE order:  y_l = (s_l + s_{l+8}) + (s_{l+4} + s_{l+12}),  result = (y0 + y2) + (y1 + y3).
  * A THIRD named order: its purpose is the cross-check of the order-invariance certificate (include/msfm_match.h), not a
  * claim about a particular OpenCV binary. */
-static float l2sqr_avx512_fma(const float* a, const float* b)
+static float l2sqr_avx512_fma_plainc(const float* a, const float* b)
 {
     float p[64];
     for (int L = 0; L < 64; ++L) p[L] = 0.0f;
@@ -105,6 +109,84 @@ static float l2sqr_avx512_fma(const float* a, const float* b)
     for (int l = 0; l < 4; ++l)
         y[l] = (s[l] + s[8 + l]) + (s[4 + l] + s[12 + l]);
     return (y[0] + y[2]) + (y[1] + y[3]);
+}
+
+/* The fused orders with REAL intrinsics (round 6: the CPU baseline is bounded from the fast side too -- a real OpenCV on an AVX2 /
+ * AVX-512 host dispatches these loops, not the SSE one): the same lane partials, the same reduction trees as the plain-C
+ * restatements above, bit for bit (tests/test_oracle_kat.py compares them on random and adversarial rows).  Compiled with
+ * per-function target attributes and chosen at run time (__builtin_cpu_supports): the library still loads on a host without them. */
+#if defined(ORC_X86_SIMD)
+__attribute__((target("avx2,fma"))) static inline float l2sqr_avx2_fma_simd(const float* a, const float* b)
+{
+    __m256 d0 = _mm256_setzero_ps(), d1 = _mm256_setzero_ps(), d2 = _mm256_setzero_ps(), d3 = _mm256_setzero_ps();
+    for (int j = 0; j < 128; j += 32) {
+        __m256 t0 = _mm256_sub_ps(_mm256_loadu_ps(a + j), _mm256_loadu_ps(b + j));
+        __m256 t1 = _mm256_sub_ps(_mm256_loadu_ps(a + j + 8), _mm256_loadu_ps(b + j + 8));
+        __m256 t2 = _mm256_sub_ps(_mm256_loadu_ps(a + j + 16), _mm256_loadu_ps(b + j + 16));
+        __m256 t3 = _mm256_sub_ps(_mm256_loadu_ps(a + j + 24), _mm256_loadu_ps(b + j + 24));
+        d0 = _mm256_fmadd_ps(t0, t0, d0);
+        d1 = _mm256_fmadd_ps(t1, t1, d1);
+        d2 = _mm256_fmadd_ps(t2, t2, d2);
+        d3 = _mm256_fmadd_ps(t3, t3, d3);
+    }
+    __m256 v = _mm256_add_ps(_mm256_add_ps(_mm256_add_ps(d0, d1), d2), d3);   /* s[l] = ((p0 + p1) + p2) + p3 per lane */
+    /* v_reduce_sum(v_float32x8): two horizontal adds inside the 128-bit halves, then low + high */
+    v = _mm256_hadd_ps(v, v);      /* (s0+s1, s2+s3, ..) | (s4+s5, s6+s7, ..) */
+    v = _mm256_hadd_ps(v, v);      /* ((s0+s1)+(s2+s3), ..) | ((s4+s5)+(s6+s7), ..) */
+    return _mm_cvtss_f32(_mm_add_ss(_mm256_castps256_ps128(v), _mm256_extractf128_ps(v, 1)));
+}
+__attribute__((target("avx512f"))) static inline float l2sqr_avx512_fma_simd(const float* a, const float* b)
+{
+    __m512 d0 = _mm512_setzero_ps(), d1 = _mm512_setzero_ps(), d2 = _mm512_setzero_ps(), d3 = _mm512_setzero_ps();
+    for (int j = 0; j < 128; j += 64) {
+        __m512 t0 = _mm512_sub_ps(_mm512_loadu_ps(a + j), _mm512_loadu_ps(b + j));
+        __m512 t1 = _mm512_sub_ps(_mm512_loadu_ps(a + j + 16), _mm512_loadu_ps(b + j + 16));
+        __m512 t2 = _mm512_sub_ps(_mm512_loadu_ps(a + j + 32), _mm512_loadu_ps(b + j + 32));
+        __m512 t3 = _mm512_sub_ps(_mm512_loadu_ps(a + j + 48), _mm512_loadu_ps(b + j + 48));
+        d0 = _mm512_fmadd_ps(t0, t0, d0);
+        d1 = _mm512_fmadd_ps(t1, t1, d1);
+        d2 = _mm512_fmadd_ps(t2, t2, d2);
+        d3 = _mm512_fmadd_ps(t3, t3, d3);
+    }
+    __m512 v = _mm512_add_ps(_mm512_add_ps(_mm512_add_ps(d0, d1), d2), d3);
+    /* low + high 256-bit halves, low + high 128-bit halves, then the four-lane sum of the SSE order */
+    __m256 h = _mm256_add_ps(_mm512_castps512_ps256(v), _mm256_castpd_ps(_mm512_extractf64x4_pd(_mm512_castps_pd(v), 1)));
+    __m128 y = _mm_add_ps(_mm256_castps256_ps128(h), _mm256_extractf128_ps(h, 1));
+    y = _mm_add_ps(y, _mm_movehl_ps(y, y));
+    y = _mm_add_ss(y, _mm_shuffle_ps(y, y, _MM_SHUFFLE(0, 0, 0, 1)));
+    return _mm_cvtss_f32(y);
+}
+#endif
+
+/* bit 0: the AVX2 + FMA3 intrinsics are in use, bit 1: the AVX-512F ones (0: the plain-C restatements run instead) */
+int orc_simd_level(void)
+{
+#if defined(ORC_X86_SIMD)
+    static int level = -1;
+    if (level < 0) {
+        __builtin_cpu_init();
+        level = ((__builtin_cpu_supports("avx2") && __builtin_cpu_supports("fma")) ? 1 : 0) | (__builtin_cpu_supports("avx512f") ? 2 : 0);
+    }
+    return level;
+#else
+    return 0;
+#endif
+}
+
+static float l2sqr_avx2_fma(const float* a, const float* b)
+{
+#if defined(ORC_X86_SIMD)
+    if (orc_simd_level() & 1) return l2sqr_avx2_fma_simd(a, b);
+#endif
+    return l2sqr_avx2_fma_plainc(a, b);
+}
+
+static float l2sqr_avx512_fma(const float* a, const float* b)
+{
+#if defined(ORC_X86_SIMD)
+    if (orc_simd_level() & 2) return l2sqr_avx512_fma_simd(a, b);
+#endif
+    return l2sqr_avx512_fma_plainc(a, b);
 }
 
 static float l2sqr_scalar(const float* a, const float* b)
@@ -126,6 +208,8 @@ float orc_l2sqr(const float* a, const float* b, int order)
     case MSFM_ORC_ORDER_SCALAR: return l2sqr_scalar(a, b);
     case MSFM_ORC_ORDER_AVX512_FMA: return l2sqr_avx512_fma(a, b);
     case 100: return l2sqr_sse4x4_scalar(a, b); /* test hook: plain-C SSE order */
+    case 101: return l2sqr_avx2_fma_plainc(a, b);   /* test hooks: the plain-C statements of the fused orders */
+    case 103: return l2sqr_avx512_fma_plainc(a, b);
     default: return NAN;
     }
 }
@@ -199,48 +283,61 @@ static void knn2_rows(const float* q, int q_begin, int q_end, const float* t, in
  * 2.5 MB per query row would measure the DRAM, not the cores. */
 #define ORC_QB 32
 #define ORC_TT 128
+#define ORC_DEFINE_BLOCKED(NAME, ATTR, L2)                                                                             \
+    ATTR static void NAME(const float* q, int q_begin, int q_end, const float* t, int nt, int order,                    \
+                          int32_t* idx0, float* d0, int32_t* idx1, float* d1)                                          \
+    {                                                                                                                  \
+        (void)order;                                                                                                   \
+        const int K = nt < 2 ? nt : 2;                                                                                 \
+        int32_t dist[ORC_QB][2], nidx[ORC_QB][2];                                                                      \
+        for (int b0 = q_begin; b0 < q_end; b0 += ORC_QB) {                                                             \
+            const int nb = (q_end - b0 < ORC_QB) ? q_end - b0 : ORC_QB;                                                \
+            for (int r = 0; r < nb; ++r) {                                                                             \
+                dist[r][0] = dist[r][1] = f2i(FLT_MAX);                                                                \
+                nidx[r][0] = nidx[r][1] = -1;                                                                          \
+            }                                                                                                          \
+            for (int j0 = 0; j0 < nt && K > 0; j0 += ORC_TT) {                                                         \
+                const int j1 = (nt - j0 < ORC_TT) ? nt : j0 + ORC_TT;                                                  \
+                for (int r = 0; r < nb; ++r) {                                                                         \
+                    const float* qi = q + (size_t)(b0 + r) * 128;                                                      \
+                    for (int j = j0; j < j1; ++j) {                                                                    \
+                        const float s = L2;                                                                            \
+                        const int32_t d = f2i(sqrtf(s));                                                               \
+                        if (d < dist[r][K - 1]) {                                                                      \
+                            int k;                                                                                     \
+                            for (k = K - 2; k >= 0 && dist[r][k] > d; --k) {                                           \
+                                nidx[r][k + 1] = nidx[r][k];                                                           \
+                                dist[r][k + 1] = dist[r][k];                                                           \
+                            }                                                                                          \
+                            nidx[r][k + 1] = j;                                                                        \
+                            dist[r][k + 1] = d;                                                                        \
+                        }                                                                                              \
+                    }                                                                                                  \
+                }                                                                                                      \
+            }                                                                                                          \
+            for (int r = 0; r < nb; ++r) {                                                                             \
+                idx0[b0 + r] = nidx[r][0];                                                                             \
+                d0[b0 + r] = i2f(dist[r][0]);                                                                          \
+                idx1[b0 + r] = nidx[r][1];                                                                             \
+                d1[b0 + r] = i2f(dist[r][1]);                                                                          \
+            }                                                                                                          \
+        }                                                                                                              \
+    }
+ORC_DEFINE_BLOCKED(knn2_rows_blocked_sse, , l2sqr_sse4x4(qi, t + (size_t)j * 128))
+ORC_DEFINE_BLOCKED(knn2_rows_blocked_any, , orc_l2sqr(qi, t + (size_t)j * 128, order))
+#if defined(ORC_X86_SIMD)
+ORC_DEFINE_BLOCKED(knn2_rows_blocked_avx2, __attribute__((target("avx2,fma"))), l2sqr_avx2_fma_simd(qi, t + (size_t)j * 128))
+ORC_DEFINE_BLOCKED(knn2_rows_blocked_avx512, __attribute__((target("avx512f"))), l2sqr_avx512_fma_simd(qi, t + (size_t)j * 128))
+#endif
 static void knn2_rows_blocked(const float* q, int q_begin, int q_end, const float* t, int nt, int order,
                               int32_t* idx0, float* d0, int32_t* idx1, float* d1)
 {
-    const int K = nt < 2 ? nt : 2;
-    int32_t dist[ORC_QB][2], nidx[ORC_QB][2];
-    for (int b0 = q_begin; b0 < q_end; b0 += ORC_QB) {
-        const int nb = (q_end - b0 < ORC_QB) ? q_end - b0 : ORC_QB;
-        for (int r = 0; r < nb; ++r) {
-            dist[r][0] = dist[r][1] = f2i(FLT_MAX);
-            nidx[r][0] = nidx[r][1] = -1;
-        }
-        for (int j0 = 0; j0 < nt && K > 0; j0 += ORC_TT) {
-            const int j1 = (nt - j0 < ORC_TT) ? nt : j0 + ORC_TT;
-            for (int r = 0; r < nb; ++r) {
-                const float* qi = q + (size_t)(b0 + r) * 128;
-                for (int j = j0; j < j1; ++j) {
-                    float s;
-                    switch (order) {
-                    case MSFM_ORC_ORDER_SSE4X4: s = l2sqr_sse4x4(qi, t + (size_t)j * 128); break;
-                    case MSFM_ORC_ORDER_AVX2_FMA: s = l2sqr_avx2_fma(qi, t + (size_t)j * 128); break;
-                    default: s = orc_l2sqr(qi, t + (size_t)j * 128, order);
-                    }
-                    const int32_t d = f2i(sqrtf(s));
-                    if (d < dist[r][K - 1]) {
-                        int k;
-                        for (k = K - 2; k >= 0 && dist[r][k] > d; --k) {
-                            nidx[r][k + 1] = nidx[r][k];
-                            dist[r][k + 1] = dist[r][k];
-                        }
-                        nidx[r][k + 1] = j;
-                        dist[r][k + 1] = d;
-                    }
-                }
-            }
-        }
-        for (int r = 0; r < nb; ++r) {
-            idx0[b0 + r] = nidx[r][0];
-            d0[b0 + r] = i2f(dist[r][0]);
-            idx1[b0 + r] = nidx[r][1];
-            d1[b0 + r] = i2f(dist[r][1]);
-        }
-    }
+    if (order == MSFM_ORC_ORDER_SSE4X4) return knn2_rows_blocked_sse(q, q_begin, q_end, t, nt, order, idx0, d0, idx1, d1);
+#if defined(ORC_X86_SIMD)
+    if (order == MSFM_ORC_ORDER_AVX2_FMA && (orc_simd_level() & 1)) return knn2_rows_blocked_avx2(q, q_begin, q_end, t, nt, order, idx0, d0, idx1, d1);
+    if (order == MSFM_ORC_ORDER_AVX512_FMA && (orc_simd_level() & 2)) return knn2_rows_blocked_avx512(q, q_begin, q_end, t, nt, order, idx0, d0, idx1, d1);
+#endif
+    knn2_rows_blocked_any(q, q_begin, q_end, t, nt, order, idx0, d0, idx1, d1);
 }
 
 static __thread int g_use_blocked = 0;   /* set by the pair-parallel workers */

@@ -51,6 +51,9 @@ enum {
 
 /* S(a,b) in the given order (never sqrt'ed). */
 float orc_l2sqr(const float* a, const float* b, int order);
+/* bit 0: the AVX2+FMA3 order runs on real intrinsics on this host, bit 1: the AVX-512F one (else their plain-C statements);
+ * orders 101 / 103 of orc_l2sqr are those plain-C statements (test hooks, like 100 for the SSE order) */
+int orc_simd_level(void);
 
 /*
  * knnMatch(query, train, k=2) of cv::BFMatcher(NORM_L2):

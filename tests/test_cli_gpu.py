@@ -427,3 +427,53 @@ def test_bulk_load_u8_side_table_and_scene_graph_order(exe, oracle, tmp_path):
         mb = np.frombuffer(b_[3], np.int32).reshape(-1, 2)
         assert {tuple(x) for x in ma} == {tuple(x) for x in mb}
         assert (np.diff(mb[:, 0]) > 0).all()
+
+
+@pytest.mark.parametrize("devices", ["", "0,0"])
+def test_key_order_emission_writes_the_same_rows_and_prints_the_same_lines(exe, dataset, tmp_path, devices):
+    """MSFM_EMIT_ORDER=pair_id (opt-in): the pairs are computed and their rows written in ascending pair_id -- SQLite appends instead of
+    rebalancing between two full leaves for every row of the reference's interleaved order (host/FeatureMatching.cpp) -- in
+    transactions of 100 rows; the stdout lines are the reference's, in the reference's order.  Same table, same text (also on a
+    partially filled database: the "Existing, Continue!" lines keep their places)."""
+    descs, kps = dataset
+    a, b = str(tmp_path / "ref_order.db"), str(tmp_path / "key_order.db")
+    database.write_synthetic_database(a, descs, kps)
+    shutil.copy(a, b)
+    strip = lambda s: re.sub(r"Elapsed time: [0-9.]+", "Elapsed time: X", s)
+    base = {"MSFM_GEOMETRIC_VERIFICATION": "0", "MSFM_TRACE_TRANSACTIONS": "1"}
+    if devices:
+        base["MSFM_DEVICES"] = devices
+    outs, txns = [], []
+    for path, env in ((a, {}), (b, {"MSFM_EMIT_ORDER": "pair_id"})):
+        cfg = tmp_path / (os.path.basename(path) + ".yaml")
+        cfg.write_text(YAML.format(db=path, mt=1))
+        e = dict(os.environ)
+        e.update(base)
+        e.update(env)
+        r = subprocess.run([exe, str(cfg)], capture_output=True, text=True, env=e, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(r.stdout)
+        txns.append([int(x) for x in re.findall(r"\[msfm txn\] (\d+)", r.stderr)])
+    da, dbb = database.Database(a), database.Database(b)
+    ra = da.db.execute("SELECT pair_id, rows, cols, data FROM matches ORDER BY pair_id").fetchall()
+    rb = dbb.db.execute("SELECT pair_id, rows, cols, data FROM matches ORDER BY pair_id").fetchall()
+    assert len(ra) > 5 and ra == rb
+    assert strip(outs[0]) == strip(outs[1])
+    assert sum(txns[1]) == len(rb) and all(t == 100 for t in txns[1][:-1])      # key order: 100 rows per transaction
+    # resume: drop a third of the rows of both, run again -- only those are recomputed, the lines say which
+    for d in (da, dbb):
+        d.db.execute("DELETE FROM matches WHERE pair_id % 3 = 1")
+        d.db.commit()
+    da.Close()
+    dbb.Close()
+    outs2 = []
+    for path, env in ((a, {}), (b, {"MSFM_EMIT_ORDER": "pair_id"})):
+        cfg = tmp_path / (os.path.basename(path) + ".yaml")
+        outs2.append(run_cli(exe, cfg, dict(base, **env)))
+    assert "Existing, Continue!" in outs2[0] and strip(outs2[0]) == strip(outs2[1])
+    da, dbb = database.Database(a), database.Database(b)
+    ra2 = da.db.execute("SELECT pair_id, rows, cols, data FROM matches ORDER BY pair_id").fetchall()
+    rb2 = dbb.db.execute("SELECT pair_id, rows, cols, data FROM matches ORDER BY pair_id").fetchall()
+    da.Close()
+    dbb.Close()
+    assert ra2 == rb2 == ra

@@ -233,3 +233,74 @@ def test_super_batches_and_the_host_cost_of_an_exchange_at_config4_scale(tmp_pat
     assert ms < (100.0 if world <= 2 else 200.0), ms
     print("host side of one exchange at config-4 scale, world %d: %.1f ms" % (world, ms))
 
+
+
+def _pipelined_worker(rank, world, port, out_dir):
+    """match_to_writer_batches(pipelined=True): the exchange of super-batch k runs while super-batch k + 1 is matched.  The matcher
+    sleeps 25 ms per super-batch (the GPU's time), the exchange is slowed by 25 ms (a slow link): serial = B x 50 ms, pipelined =
+    B x 25 ms + one exchange -- and the writer's bytes are the same either way."""
+    sys.path.insert(0, ROOT)
+    import time
+    import torch
+    torch.set_num_threads(1)
+    import torch.distributed as dist
+    from monocularsfm_amd import sharding
+    from monocularsfm_amd.sharding import ShardedMatcher
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n_img = 30
+    n_rows = np.arange(50, 50 + n_img)
+    pairs = np.array([(i, j) for i in range(n_img) for j in range(i)], np.int32)
+
+    def match_fn(sub):
+        time.sleep(0.025)
+        offs, rows = [0], []
+        for i, j in sub:
+            m = int((5 * i + 3 * j) % 11)
+            rows.append(np.stack([np.arange(m) + 7 * i, np.arange(m) + 7 * j], 1).astype(np.int32).reshape(-1, 2))
+            offs.append(offs[-1] + m)
+        return np.asarray(offs, np.int64), (np.concatenate(rows) if rows else np.zeros((0, 2), np.int32)), np.arange(offs[-1], dtype=np.float32)
+
+    real = sharding.gather_to_writer
+
+    def slow_link(*a, **kw):
+        time.sleep(0.025)
+        return real(*a, **kw)
+    sharding.gather_to_writer = slow_link
+    sm = ShardedMatcher(match_fn=match_fn)
+    batch = 40
+    B = -(-len(pairs) // batch)
+    out = {}
+    for mode in (False, True):
+        got = []
+        dist.barrier()
+        t0 = time.perf_counter()
+        counts = sm.match_to_writer_batches(pairs, n_rows, batch_pairs=batch, dst=0, with_dist=True, pipelined=mode,
+                                            sink=lambda b0, offs, qt, d: got.append((b0, np.array(offs), np.array(qt), np.array(d))))
+        dist.barrier()
+        out[mode] = (time.perf_counter() - t0, counts, got, dict(sm.last))
+    sharding.gather_to_writer = real
+    serial, piped = out[False], out[True]
+    assert np.array_equal(serial[1], piped[1])
+    assert len(serial[2]) == len(piped[2]) == (B if rank == 0 else 0)
+    for a, b in zip(serial[2], piped[2]):     # the writer's bytes: the same super-batches, the same rows, the same order
+        assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and np.array_equal(a[3].view(np.int32), b[3].view(np.int32))
+    assert piped[3]["pipelined"] and piped[3]["super_batches"] == B
+    # serial: every exchange is waited for in full; pipelined: the matching thread waits for a fraction of it
+    assert serial[3]["exchange_wait_ms"] >= 0.9 * B * 25.0
+    if rank == 0:
+        np.save(os.path.join(out_dir, "walls.npy"), np.array([serial[0], piped[0], piped[3]["exchange_wait_ms"], piped[3]["exchange_ms"], B]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_pipelined_exchange_hides_behind_the_next_super_batch(tmp_path, world):
+    mp.spawn(_pipelined_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    serial, piped, wait_ms, exch_ms, B = np.load(os.path.join(str(tmp_path), "walls.npy"))
+    # B super-batches of 25 ms matching + 25 ms exchange: serial >= B x 50 ms; pipelined ~ B x 25 ms + the last exchange
+    assert serial >= B * 0.050 * 0.95, (serial, B)
+    assert piped <= serial * 0.75, (serial, piped)
+    assert wait_ms <= 0.5 * exch_ms, (wait_ms, exch_ms)   # most of the exchange time ran beside the matching
+    print("world %d, %d super-batches: serial %.3f s, pipelined %.3f s (exchange %.0f ms on its thread, %.0f ms waited for)" % (world, int(B), serial, piped, exch_ms, wait_ms))

@@ -44,6 +44,7 @@ def config4_main(argv):
     ap.add_argument("--tables", default="u8,f32", help="which descriptor tables to run from: u8 (side table, MSFM_USE_DESCRIPTORS_U8=1), f32")
     ap.add_argument("--modes", default="off,device", help="geometric verification modes: off, device, host")
     ap.add_argument("--devices", default="", help="MSFM_DEVICES for the runs (e.g. 0,0 : two contexts on one GPU)")
+    ap.add_argument("--orders", default="reference,pair_id", help="emission orders: reference (default behaviour), pair_id (MSFM_EMIT_ORDER=pair_id)")
     ap.add_argument("--json", default="")
     ap.add_argument("--tmp", default=None)
     args = ap.parse_args(argv)
@@ -58,13 +59,13 @@ def config4_main(argv):
             gen_s = time.time() - t0
             base_mb = os.path.getsize(base) / 1e6
             print("database (%s table): %d images x %d descriptors, %.0f MB, built in %.1f s" % (table, args.images, args.desc, base_mb, gen_s), flush=True)
-            for mode in args.modes.split(","):
-                db2 = base + "." + mode
+            for mode, order in [(m, o) for m in args.modes.split(",") for o in args.orders.split(",")]:
+                db2 = base + "." + mode + "." + order
                 shutil.copyfile(base, db2)
                 for ext in ("-wal", "-shm"):
                     if os.path.exists(base + ext):
                         shutil.copyfile(base + ext, db2 + ext)
-                cfg = os.path.join(tmp, "cfg_%s_%s.yaml" % (table, mode))
+                cfg = os.path.join(tmp, "cfg_%s_%s_%s.yaml" % (table, mode, order))
                 # raw byte descriptors: distances are in byte units (hundreds), the reference's default max_distance 0.7 is for RootSIFT
                 open(cfg, "w").write('%%YAML:1.0\ndatabase_path : "%s"\nSIFTmatch.match_type : 1\nSIFTmatch.max_distance : 1000000000.0\n' % db2)
                 env = {"MSFM_HONOUR_YAML_MATCH_PARAMS": "1", "MSFM_GEOMETRIC_VERIFICATION": {"off": "0", "device": "1", "host": "host"}[mode]}
@@ -72,7 +73,9 @@ def config4_main(argv):
                     env["MSFM_USE_DESCRIPTORS_U8"] = "1"
                 if args.devices:
                     env["MSFM_DEVICES"] = args.devices
-                out_path = os.path.join(tmp, "stdout_%s_%s.txt" % (table, mode))
+                if order == "pair_id":
+                    env["MSFM_EMIT_ORDER"] = "pair_id"
+                out_path = os.path.join(tmp, "stdout_%s_%s_%s.txt" % (table, mode, order))
                 wall, phases, pipe, stamps, t_start = run_exe(cfg, env, out_path)
                 lines = sum(1 for _ in open(out_path, "rb"))
                 last = subprocess.run(["tail", "-1", out_path], capture_output=True, text=True).stdout.strip()
@@ -82,7 +85,7 @@ def config4_main(argv):
                 size_after = sum(os.path.getsize(db2 + e) for e in ("", "-wal") if os.path.exists(db2 + e)) / 1e6
                 gpu = phases.get("device match + fetch", 0.0)
                 emit = phases.get("stdout + WriteMatches", 0.0)
-                rec = {"table": table, "verification": mode, "devices": args.devices or "0", "wall_s": wall, "phases_s": phases, "pipeline_line": pipe,
+                rec = {"table": table, "verification": mode, "emit_order": order, "devices": args.devices or "0", "wall_s": wall, "phases_s": phases, "pipeline_line": pipe,
                        "main_entered_after_s": (stamps[0] - t_start) if len(stamps) == 2 else None,
                        "behind_main_s": (t_start + wall - stamps[1]) if len(stamps) == 2 else None,
                        "image_pairs": n_pairs, "rows_written": rows, "matches_written": int(matches or 0), "match_blob_bytes": int(blob or 0),
@@ -90,8 +93,8 @@ def config4_main(argv):
                        "wall_over_max_of_device_and_emission": wall / max(1e-9, max(gpu, emit)),
                        "database_build_s": gen_s}
                 records.append(rec)
-                print("ComputeMatches, %s table, verification %s: wall %.2f s | rows %d of %d pairs, %d matches (%.2f GB of BLOBs), %d stdout lines | %s" % (
-                    table, mode, wall, rows, n_pairs, int(matches or 0), (blob or 0) / 1e9, lines, last), flush=True)
+                print("ComputeMatches, %s table, verification %s, rows in %s order: wall %.2f s | rows %d of %d pairs, %d matches (%.2f GB of BLOBs), %d stdout lines | %s" % (
+                    table, mode, order, wall, rows, n_pairs, int(matches or 0), (blob or 0) / 1e9, lines, last), flush=True)
                 print("    " + ([l for l in [pipe] if l] or ["(no pipeline line)"])[0], flush=True)
                 print("    phases: " + " | ".join("%s %.2f" % kv for kv in phases.items()), flush=True)
                 for f in (db2, db2 + "-wal", db2 + "-shm", out_path):
