@@ -59,6 +59,40 @@ def test_sse_intrinsics_equal_plain_c_statement(oracle):
     assert np.array_equal(bits(x), bits(y))
 
 
+def test_fused_order_intrinsics_equal_their_plain_c_statements(oracle):
+    """Round 6: the AVX2+FMA3 and AVX-512 orders run on real intrinsics where the host has them (the CPU baseline's fast side); orders
+    101 / 103 are their plain-C statements.  Same lane partials, same reduction trees: the same bits -- on random rows, on rows of very
+    different magnitude (cancellation in the trees), on byte-valued rows -- and through the cache-blocked kNN loop that the pair-parallel
+    baseline times."""
+    import ctypes as C
+    L = oracle.lib()
+    L.orc_simd_level.restype = C.c_int
+    level = L.orc_simd_level()
+    assert level in (0, 1, 3)            # AVX-512F hosts have AVX2 + FMA3
+    rng = np.random.default_rng(66)
+    A = rng.normal(size=(400, 128)).astype(F32) * rng.choice([1e-3, 1.0, 255.0], size=(400, 1)).astype(F32)
+    B = rng.normal(size=(400, 128)).astype(F32) * rng.choice([1e-3, 1.0, 255.0], size=(400, 1)).astype(F32)
+    A[:50] = rng.integers(0, 256, (50, 128)).astype(F32)
+    B[:50] = rng.integers(0, 256, (50, 128)).astype(F32)
+    for order, plain in ((1, 101), (3, 103)):
+        x = np.array([oracle.l2sqr(a, b, order) for a, b in zip(A, B)], F32)
+        y = np.array([oracle.l2sqr(a, b, plain) for a, b in zip(A, B)], F32)
+        assert np.array_equal(bits(x), bits(y)), order
+    from oracle import np_oracle
+    q, t = np.abs(A[:130]) / 300, np.abs(B[:257]) / 300
+    for order in (1, 3):
+        got = oracle.knn2_blocked(q, t, order)
+        ref = oracle.knn2(q, t, order)
+        for g, r in zip(got, ref):
+            assert np.array_equal(g.view(np.int32), r.view(np.int32))
+    if level & 1:
+        # and the NumPy restatement of the AVX2 order (an independent statement) agrees with the intrinsics
+        s_np = np_oracle.l2sqr_matrix(q[:20], t[:30], order=1) if hasattr(np_oracle, "l2sqr_matrix") else None
+        if s_np is not None:
+            s_c = np.array([[oracle.l2sqr(a, b, 1) for b in t[:30]] for a in q[:20]], F32)
+            assert np.array_equal(bits(s_np.astype(F32)), bits(s_c))
+
+
 def test_sse_order_is_not_fused(oracle):
     # t*t is rounded before the add: pick t^2 with low bits that an FMA would keep.
     a = np.zeros(128, F32)

@@ -24,6 +24,28 @@ cli)   # the pipelined executable: its tests, the small end-to-end job, then the
 suite)   # the whole GPU suite
     TMO=1800 run pytest_gpu python -m pytest tests -m gpu -x -q; tail -5 $OUT/pytest_gpu.txt
     ;;
+nccl1)   # the exchange path on ONE rank over RCCL, config 4 in full -- the library's copy into the torch-allocated
+         # send tensor (the cross-runtime pointer) timed, and the streamed form with the exchange pipelined under the next super-batch
+    TMO=900 run bench_nccl1 python bench.py --backend nccl --force-collectives --steps 5 --warmup 2 --no-cpu-baseline --no-e2e --sustained-steps 0 --no-solo
+    python - <<'PY'
+import json
+d=json.loads([l for l in open("gpurun_out/r6/nccl1/bench_nccl1.txt") if l.startswith("{")][-1])
+print("config 2:", round(d["ms_per_step"],2), "ms/step", d["per_rank_ms"], d.get("exchange_detail_rank0"))
+u=d.get("strong_u8",{}); print("config 4:", u.get("seconds_per_step"), "s/step", u.get("per_rank_ms"), u.get("exchange_detail_rank0"))
+PY
+    TMO=900 run bench_nccl1_stream python bench.py --backend nccl --force-collectives --steps 3 --warmup 1 --no-cpu-baseline --no-e2e --sustained-steps 0 --no-solo --super-batch-pairs 65536
+    python - <<'PY'
+import json
+d=json.loads([l for l in open("gpurun_out/r6/nccl1/bench_nccl1_stream.txt") if l.startswith("{")][-1])
+print("config 2 streamed:", round(d["ms_per_step"],2), "ms/step", d["per_rank_ms"], d.get("exchange_detail_rank0"))
+u=d.get("strong_u8",{}); print("config 4 streamed:", u.get("seconds_per_step"), "s/step", u.get("per_rank_ms"), u.get("exchange_detail_rank0"))
+PY
+    ;;
+third)
+    bash tools/gpu_r6.sh suite
+    bash tools/gpu_r6.sh cli
+    bash tools/gpu_r6.sh nccl1
+    ;;
 second)
     bash tools/gpu_r6.sh suite
     bash tools/gpu_r6.sh cli
