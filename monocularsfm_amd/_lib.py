@@ -99,7 +99,7 @@ def load():
     L.msfm_image_rows.argtypes = [vp, C.c_int, C.POINTER(C.c_int)]
     L.msfm_subset_image.argtypes = [vp, C.c_int, C.c_int, ip, C.c_int]
     L.msfm_clear_images.argtypes = [vp]
-    try:   # (the A/B tools also load older builds of the library: tools/ab_multi.py)
+    try:   # (the A/B tools also load older builds of the library: tools/ab.py)
         L.msfm_finalize_store.argtypes = [vp]
         L.msfm_store_info.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         L.msfm_match_pairs_begin.argtypes = [vp, ip, C.c_int, C.POINTER(MatchParams), C.c_int, C.POINTER(VerifyParams)]
@@ -124,7 +124,7 @@ def load():
     L.msfm_pair_from_id.argtypes = [C.c_int32, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.msfm_swap_image_pair.argtypes = [C.c_int, C.c_int]
     L.msfm_version.restype = C.c_char_p
-    try:   # (the A/B tools also load older builds of the library: tools/ab_multi.py)
+    try:   # (the A/B tools also load older builds of the library: tools/ab.py)
         L.msfm_device_count.argtypes = []
         L.msfm_device_count.restype = C.c_int
     except AttributeError:

@@ -424,68 +424,107 @@ constexpr size_t kHsTotals = 2 * sizeof(PlanSummary), kHsOverflow = kHsTotals + 
 //   sweep 2: match lists: only the rows / columns pruning left alive, compacted and grouped per streamed image
 //            (sweep_kernel<3>, plan built on the device); kNN-level API: everything again (sweep_kernel<2>)
 //   exact pinned-order S of the candidates, 64-bit atomicMin reduce, finalize
-int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
-    const size_t P = b.pairs.size();
+// The launch sequence of one sub-batch on the prefilter path, stage by stage (VERDICT r05 hygiene: it was one 490-line function).
+// Everything the stages share lives in the struct; each stage only LAUNCHES -- nothing waits for the device.
+struct PrefilterLaunch {
+    msfm_ctx* ctx;
+    Batch& b;
+    size_t ev_base;
+    PruneParams prune;
+    size_t P = 0;
     HostClock hc;
-    SC.pf_pending = PfPending{};
-    assign_partials(b, 1, 4 * ctx->cu_count);
-    // Sweep 2 on the compacted live rows, or on everything again?  Decided per batch, before any result exists: the Lowe
-    // test is what kills rows (~94 % at ratio 0.8 on SIFT-like data); with a ratio near or above 1 almost every row stays
-    // alive and the compacted sweep (both directions separately) would multiply up to twice what the dense one does.
-    const bool compact = prune.prune != 0 && prune.ratio > 0.f && prune.ratio <= 0.95f;
-    // Byte stores: both sweeps on the integer matrix cores (msfm_sweep_i8.hip.h) when every prefiltered pair of the batch
-    // joins two byte images (a store is bytes throughout or not at all; a mixed batch takes the fp16 kernels)
-    const bool i8 = compact && b.route_i8;   // (prepare_batch_images: the images' float forms may not even exist on this route)
-    if (i8)
-        for (size_t p = 0; p < P; ++p) {
-            if (!b.pairs[p].valid || !b.pf[p].use) continue;
-            const Image& ia = ctx->images[b.id1[p]];
-            const Image& ib = ctx->images[b.id2[p]];
-            PfPair& pp = b.pf[p];
-            pp.i8 = 1;
-            pp.a_h = reinterpret_cast<const _Float16*>(ia.i8);   // 176-byte rows behind the same pointers
-            pp.b_h = reinterpret_cast<const _Float16*>(ib.i8);
-            pp.a_nrm = ia.nrm_i8;
-            pp.b_nrm = ib.nrm_i8;
-            pp.a_nrm_max = ia.nrm_i8_max;
-            pp.b_nrm_max = ib.nrm_i8_max;
-            pp.a_c = pp.b_c = 0.f;
-            pp.a_h0 = ia.h0_i8;
-            pp.b_h0 = ib.h0_i8;
-            pp.a_n2 = ia.n2_i8;
-            pp.b_n2 = ib.n2_i8;
-        }
-    SC.pf_pending.i8 = i8;
-    // Route Q (msfm_q8.hip.h): float images with byte twins -- sweep 1 on the twins (integer matrix cores); coarse twins: an fp16
-    // sweep 1' on the rows that survive.  A pair takes it when both its images have twins; a sub-batch in which only SOME pairs do runs
-    // two first sweeps (fine twins: q8_mixed below) or keeps the fp16 route for all of them (coarse twins).
-    bool q8 = compact && !i8 && ctx->prefilter == 1 && ctx->q8_route;
-    long long q8_rows = 0, q8_pairs = 0, twin_pairs = 0, twin_rows = 0;
+    // routes of the sub-batch (choose_routes)
+    bool compact = false, i8 = false, q8 = false, q8_mixed = false, fine_twins = false, q8_direct = false, q8_refine = false;
     std::vector<char> twin;
-    if (q8) {
-        twin.assign(P, 0);
-        for (size_t p = 0; p < P; ++p)
-            if (b.pairs[p].valid && b.pf[p].use) {
-                q8_rows += b.pairs[p].n1 + b.pairs[p].n2;
-                q8_pairs += 1;
-                if (ctx->images[b.id1[p]].q8 != nullptr && ctx->images[b.id2[p]].q8 != nullptr) {
-                    twin[p] = 1;
-                    twin_pairs += 1;
-                    twin_rows += b.pairs[p].n1 + b.pairs[p].n2;
-                }
+    std::vector<PfPair> pfq, pf16;
+    long long dense_cand = 0;
+    // work items and buffers (build_and_upload)
+    std::vector<int> item_base16;
+    size_t per16 = 0;
+    long long kn = 1;
+    // launch state (launch_sweep1 onwards)
+    hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr, e3 = nullptr;
+    dim3 block, mgrid;
+    unsigned sweep_grid = 8;
+    const PairDesc* dp = nullptr;
+    const PfPair* dpf = nullptr;
+    float* tuv = nullptr;
+    unsigned* colmask = nullptr;
+    size_t n_lists = 0;
+    const CandList* dl = nullptr;
+    // the device-side plan of the compacted sweep 2 (plan_buffers)
+    CompactPlan cp;
+    size_t G = 0, M = 0;
+    long long rows_cap = 0, cand_cap = 0, items_cap = 0;
+    const PlanPair* dpp = nullptr;
+    PlanCounts pc = {};
+    PlanOut po = {};
+
+    PrefilterLaunch(msfm_ctx* c, Batch& batch, size_t ev, PruneParams pr) : ctx(c), b(batch), ev_base(ev), prune(pr) {}
+
+    // ---- stage 1: which matrix cores sweep what (byte stores, route Q, mixed sub-batches), the pairs' tables of each sweep
+    int choose_routes() {
+        P = b.pairs.size();
+        hc = HostClock();
+        SC.pf_pending = PfPending{};
+        assign_partials(b, 1, 4 * ctx->cu_count);
+        // Sweep 2 on the compacted live rows, or on everything again?  Decided per batch, before any result exists: the Lowe
+        // test is what kills rows (~94 % at ratio 0.8 on SIFT-like data); with a ratio near or above 1 almost every row stays
+        // alive and the compacted sweep (both directions separately) would multiply up to twice what the dense one does.
+        compact = prune.prune != 0 && prune.ratio > 0.f && prune.ratio <= 0.95f;
+        // Byte stores: both sweeps on the integer matrix cores (msfm_sweep_i8.hip.h) when every prefiltered pair of the batch
+        // joins two byte images (a store is bytes throughout or not at all; a mixed batch takes the fp16 kernels)
+        i8 = compact && b.route_i8;   // (prepare_batch_images: the images' float forms may not even exist on this route)
+        if (i8)
+            for (size_t p = 0; p < P; ++p) {
+                if (!b.pairs[p].valid || !b.pf[p].use) continue;
+                const Image& ia = ctx->images[b.id1[p]];
+                const Image& ib = ctx->images[b.id2[p]];
+                PfPair& pp = b.pf[p];
+                pp.i8 = 1;
+                pp.a_h = reinterpret_cast<const _Float16*>(ia.i8);   // 176-byte rows behind the same pointers
+                pp.b_h = reinterpret_cast<const _Float16*>(ib.i8);
+                pp.a_nrm = ia.nrm_i8;
+                pp.b_nrm = ib.nrm_i8;
+                pp.a_nrm_max = ia.nrm_i8_max;
+                pp.b_nrm_max = ib.nrm_i8_max;
+                pp.a_c = pp.b_c = 0.f;
+                pp.a_h0 = ia.h0_i8;
+                pp.b_h0 = ib.h0_i8;
+                pp.a_n2 = ia.n2_i8;
+                pp.b_n2 = ib.n2_i8;
             }
+        SC.pf_pending.i8 = i8;
+        // Route Q (msfm_q8.hip.h): float images with byte twins -- sweep 1 on the twins (integer matrix cores); coarse twins: an fp16
+        // sweep 1' on the rows that survive.  A pair takes it when both its images have twins; a sub-batch in which only SOME pairs do runs
+        // two first sweeps (fine twins: q8_mixed below) or keeps the fp16 route for all of them (coarse twins).
+        q8 = compact && !i8 && ctx->prefilter == 1 && ctx->q8_route;
+        long long q8_rows = 0, q8_pairs = 0, twin_pairs = 0, twin_rows = 0;
+        twin.clear();
+        if (q8) {
+            twin.assign(P, 0);
+            for (size_t p = 0; p < P; ++p)
+                if (b.pairs[p].valid && b.pf[p].use) {
+                    q8_rows += b.pairs[p].n1 + b.pairs[p].n2;
+                    q8_pairs += 1;
+                    if (ctx->images[b.id1[p]].q8 != nullptr && ctx->images[b.id2[p]].q8 != nullptr) {
+                        twin[p] = 1;
+                        twin_pairs += 1;
+                        twin_rows += b.pairs[p].n1 + b.pairs[p].n2;
+                    }
+                }
     }
     // (two plans and three sweeps only pay on real images: batches of small ones -- the pre-emptive filter's 100-row
     // subsets -- keep the fp16 route; MSFM_Q8=2 lifts the limit, for the tests)
-    const bool fine_twins = ctx->q8_direct == 2 || (ctx->q8_direct == 1 && ctx->q8_level <= kQ8DirectMaxLevel);
-    bool q8_mixed = false;   // some pairs join images without twins: THEIR sweep 1 runs on the fp16 cores, the twins' on the integer cores
+    fine_twins = ctx->q8_direct == 2 || (ctx->q8_direct == 1 && ctx->q8_level <= kQ8DirectMaxLevel);
+    q8_mixed = false;   // some pairs join images without twins: THEIR sweep 1 runs on the fp16 cores, the twins' on the integer cores
     if (q8 && twin_pairs < q8_pairs) {
         // (fine twins only: the coarse route's plan A / sweep 1' cover whole sub-batches; and only when a quarter of the work or more has twins)
         q8_mixed = fine_twins && twin_pairs > 0 && 4 * twin_rows >= q8_rows;
         if (!q8_mixed) q8 = false;
     }
     if (q8 && ctx->q8_route < 2 && (twin_pairs == 0 || twin_rows < 2 * 1024 * twin_pairs)) q8 = q8_mixed = false;
-    std::vector<PfPair> pfq, pf16;
+    pfq.clear(), pf16.clear();
     if (q8) {
         pfq = b.pf;
         for (size_t p = 0; p < P; ++p) {
@@ -522,10 +561,10 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
         }
     // fine twins: their sweep's bounds are the thresholds of sweep 2; coarse ones (a store with values near 1): an fp16 sweep 1'
     // of the live rows refines them first
-    const bool q8_direct = q8 && fine_twins;
-    const bool q8_refine = q8 && !q8_direct;
+    q8_direct = q8 && fine_twins;
+    q8_refine = q8 && !q8_direct;
     SC.pf_pending.q8 = q8_refine;   // (a plan A and a sweep 1' to account for at the end of the batch)
-    long long dense_cand = 0;
+    dense_cand = 0;
     for (size_t p = 0; p < P; ++p) {
         b.pf[p].tu_off = b.pairs[p].kf_off;
         b.pf[p].tv_off = b.pairs[p].kr_off;  // same combined index space as the kNN arrays
@@ -553,16 +592,21 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
         for (size_t p = 0; p < P; ++p)
             if (twin[p]) b.pairs[p].cp_off *= 2;
     }
-    std::vector<int> item_base16;
-    size_t per16 = 0;
-    build_items(b, 1);
-    if (b.n_items == 0) return MSFM_OK;
-    if (q8_mixed) {   // the fp16 first sweep's own item list: the pairs without twins
-        std::vector<char> only(P, 0);
-        for (size_t p = 0; p < P; ++p) only[p] = (b.pairs[p].valid && b.pf[p].use && !twin[p]) ? 1 : 0;
-        build_items(b, 1, &only, &item_base16, &per16);
+    return MSFM_OK;
     }
-    const long long kn = std::max<long long>(1, b.kf_elems + b.kr_elems);
+
+    // ---- stage 2: work items, the buffers of sweep 1 and of the reduce, every clear in one launch, the tables in one copy
+    int build_and_upload() {
+        item_base16.clear();
+        per16 = 0;
+        build_items(b, 1);
+        if (b.n_items == 0) return MSFM_OK;   // (nothing on this path: run() stops here)
+        if (q8_mixed) {   // the fp16 first sweep's own item list: the pairs without twins
+            std::vector<char> only(P, 0);
+            for (size_t p = 0; p < P; ++p) only[p] = (b.pairs[p].valid && b.pf[p].use && !twin[p]) ? 1 : 0;
+            build_items(b, 1, &only, &item_base16, &per16);
+    }
+    kn = std::max<long long>(1, b.kf_elems + b.kr_elems);
     HIPCHK(ctx, SC.d_rp_s0.ensure(std::max<long long>(1, b.rp_elems) * 4));
     HIPCHK(ctx, SC.d_rp_s1.ensure(std::max<long long>(1, b.rp_elems) * 4));
     // column partials of sweep 1: one float2 (the two largest of four row-class maxima) per 512-row A block and column; the integer
@@ -583,49 +627,53 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
     }
     fills.add(SC.d_totals.p, 128, 0);
     fills.add(SC.d_overflow.p, P, 0);   // (which pairs own an overflowed list: pf_overflow_kernel at the end of the chain)
-    int rc = upload_pair_tables(ctx, b, 1, q8 ? &pfq : nullptr, fills, q8_mixed ? &pf16 : nullptr, q8_mixed ? &item_base16 : nullptr, per16);
+    const int rc = upload_pair_tables(ctx, b, 1, q8 ? &pfq : nullptr, fills, q8_mixed ? &pf16 : nullptr, q8_mixed ? &item_base16 : nullptr, per16);
     if (rc != MSFM_OK) return rc;
+    return MSFM_OK;
+    }
 
-    hipEvent_t e0 = get_event(ctx, ev_base), e1 = get_event(ctx, ev_base + 1);
-    hipEvent_t e2 = get_event(ctx, ev_base + 2), e3 = get_event(ctx, ev_base + 3);
-    if (!e0 || !e1 || !e2 || !e3) return fail(ctx, MSFM_E_DEVICE, "hipEventCreate failed");
-    const dim3 block(kPfThreads);
-    const unsigned sweep_grid = (unsigned)std::max(8, (ctx->cu_count / 8) * 8);   // one persistent workgroup per CU, a multiple of the 8 XCDs
-    const PairDesc* dp = SC.d_pairs.as<PairDesc>();
-    const PfPair* dpf = SC.d_pf.as<PfPair>();
-    float* tuv = SC.d_tu.as<float>();  // rows at kf offsets, columns at kr offsets (one buffer)
-    unsigned* colmask = SC.d_colmask.as<unsigned>();
-    hc.lap("sweep-1 setup + uploads");
-    // Sweeps 1 of consecutive sub-batches are persistent one-workgroup-per-CU kernels: two of them cannot share the chip, and
-    // a launch that merely queues behind the other stream's sweep would be timed (events) with its wait.  So this one
-    // starts when the other stream's sweep 1 is done; what DOES overlap with it is that stream's tail.
-    if (ctx->last_sweep1 && ctx->last_sweep1 != ctx->cur)
-        HIPCHK(ctx, hipStreamWaitEvent(SC.stream, ctx->last_sweep1->sweep1_done, 0));
-    // ... and, with three sub-batches in flight, behind sweep 2 of the one before that: the matrix pipes see
-    // S1(k+1) S2(k) S1(k+2) S2(k+1) ..., every bandwidth-bound tail runs beside a sweep, and two persistent kernels never split the CUs
-    for (Scratch& other : ctx->sc)
-        if (&other != ctx->cur && other.sweep2_recorded && other.seq + 2 <= SC.seq)
-            HIPCHK(ctx, hipStreamWaitEvent(SC.stream, other.sweep2_done, 0));
-    HIPCHK(ctx, hipEventRecord(e0, SC.stream));
-    if (i8 || q8)
-        hipLaunchKernelGGL(sweep_i8_kernel<1>, dim3(std::min<unsigned>(sweep_grid, (unsigned)b.n_items)), dim3(kI8Threads), kI8LdsBytes, SC.stream, dp,
-                           q8 ? (const PfPair*)SC.d_pfq.as<PfPair>() : dpf,
-                           SC.d_items.as<WorkItem>(), SC.d_rp_s0.as<float>(), SC.d_rp_s1.as<float>(), SC.d_cp_s0.as<float>(),
-                           (const float*)nullptr, (int2*)nullptr, (unsigned long long*)nullptr, (const int*)nullptr, (int)b.n_items, (int*)nullptr,
-                           (int*)nullptr);
-    else
-        hipLaunchKernelGGL(sweep_kernel<1>, dim3(std::min<unsigned>(sweep_grid, (unsigned)b.n_items)), block, kPfLdsBytes, SC.stream, dp, dpf,
-                           SC.d_items.as<WorkItem>(), SC.d_rp_s0.as<float>(), SC.d_rp_s1.as<float>(),
-                           SC.d_cp_s0.as<float>(), (float*)nullptr, (const float*)nullptr, (const float*)nullptr,
-                           (int2*)nullptr, (unsigned long long*)nullptr, (const int*)nullptr, (int)b.n_items, (int*)nullptr);
-    HIPCHK(ctx, hipGetLastError());
-    if (q8_mixed && per16) {   // the pairs without twins: their own item list (the twins' sweep skipped them: not in use in ITS table)
-        hipLaunchKernelGGL(sweep_kernel<1>, dim3(std::min<unsigned>(sweep_grid, (unsigned)(per16 * 8))), block, kPfLdsBytes, SC.stream, dp,
-                           (const PfPair*)SC.d_pf16.as<PfPair>(), SC.d_items16.as<WorkItem>(), SC.d_rp_s0.as<float>(), SC.d_rp_s1.as<float>(),
-                           SC.d_cp_s0.as<float>(), (float*)nullptr, (const float*)nullptr, (const float*)nullptr,
-                           (int2*)nullptr, (unsigned long long*)nullptr, (const int*)nullptr, (int)(per16 * 8), (int*)nullptr);
+    // ---- stage 3: sweep 1 (ordered behind the other streams' sweeps), for the dense second sweep also the thresholds
+    int launch_sweep1() {
+        e0 = get_event(ctx, ev_base), e1 = get_event(ctx, ev_base + 1);
+        e2 = get_event(ctx, ev_base + 2), e3 = get_event(ctx, ev_base + 3);
+        if (!e0 || !e1 || !e2 || !e3) return fail(ctx, MSFM_E_DEVICE, "hipEventCreate failed");
+        block = dim3(kPfThreads);
+        sweep_grid = (unsigned)std::max(8, (ctx->cu_count / 8) * 8);   // one persistent workgroup per CU, a multiple of the 8 XCDs
+        dp = SC.d_pairs.as<PairDesc>();
+        dpf = SC.d_pf.as<PfPair>();
+        tuv = SC.d_tu.as<float>();  // rows at kf offsets, columns at kr offsets (one buffer)
+        colmask = SC.d_colmask.as<unsigned>();
+        hc.lap("sweep-1 setup + uploads");
+        // Sweeps 1 of consecutive sub-batches are persistent one-workgroup-per-CU kernels: two of them cannot share the chip, and
+        // a launch that merely queues behind the other stream's sweep would be timed (events) with its wait.  So this one
+        // starts when the other stream's sweep 1 is done; what DOES overlap with it is that stream's tail.
+        if (ctx->last_sweep1 && ctx->last_sweep1 != ctx->cur)
+            HIPCHK(ctx, hipStreamWaitEvent(SC.stream, ctx->last_sweep1->sweep1_done, 0));
+        // ... and, with three sub-batches in flight, behind sweep 2 of the one before that: the matrix pipes see
+        // S1(k+1) S2(k) S1(k+2) S2(k+1) ..., every bandwidth-bound tail runs beside a sweep, and two persistent kernels never split the CUs
+        for (Scratch& other : ctx->sc)
+            if (&other != ctx->cur && other.sweep2_recorded && other.seq + 2 <= SC.seq)
+                HIPCHK(ctx, hipStreamWaitEvent(SC.stream, other.sweep2_done, 0));
+        HIPCHK(ctx, hipEventRecord(e0, SC.stream));
+        if (i8 || q8)
+            hipLaunchKernelGGL(sweep_i8_kernel<1>, dim3(std::min<unsigned>(sweep_grid, (unsigned)b.n_items)), dim3(kI8Threads), kI8LdsBytes, SC.stream, dp,
+                               q8 ? (const PfPair*)SC.d_pfq.as<PfPair>() : dpf,
+                               SC.d_items.as<WorkItem>(), SC.d_rp_s0.as<float>(), SC.d_rp_s1.as<float>(), SC.d_cp_s0.as<float>(),
+                               (const float*)nullptr, (int2*)nullptr, (unsigned long long*)nullptr, (const int*)nullptr, (int)b.n_items, (int*)nullptr,
+                               (int*)nullptr);
+        else
+            hipLaunchKernelGGL(sweep_kernel<1>, dim3(std::min<unsigned>(sweep_grid, (unsigned)b.n_items)), block, kPfLdsBytes, SC.stream, dp, dpf,
+                               SC.d_items.as<WorkItem>(), SC.d_rp_s0.as<float>(), SC.d_rp_s1.as<float>(),
+                               SC.d_cp_s0.as<float>(), (float*)nullptr, (const float*)nullptr, (const float*)nullptr,
+                               (int2*)nullptr, (unsigned long long*)nullptr, (const int*)nullptr, (int)b.n_items, (int*)nullptr);
         HIPCHK(ctx, hipGetLastError());
-        SC.prof.mixed_route_sub_batches += 1;
+        if (q8_mixed && per16) {   // the pairs without twins: their own item list (the twins' sweep skipped them: not in use in ITS table)
+            hipLaunchKernelGGL(sweep_kernel<1>, dim3(std::min<unsigned>(sweep_grid, (unsigned)(per16 * 8))), block, kPfLdsBytes, SC.stream, dp,
+                               (const PfPair*)SC.d_pf16.as<PfPair>(), SC.d_items16.as<WorkItem>(), SC.d_rp_s0.as<float>(), SC.d_rp_s1.as<float>(),
+                               SC.d_cp_s0.as<float>(), (float*)nullptr, (const float*)nullptr, (const float*)nullptr,
+                               (int2*)nullptr, (unsigned long long*)nullptr, (const int*)nullptr, (int)(per16 * 8), (int*)nullptr);
+            HIPCHK(ctx, hipGetLastError());
+            SC.prof.mixed_route_sub_batches += 1;
     }
     DBGSYNC(ctx, "sweep_kernel<1>");
     HIPCHK(ctx, hipEventRecord(e1, SC.stream));
@@ -635,7 +683,7 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
     SC.prof.approx_kernel_launches += 1;
     if (i8 || q8) SC.prof.sweep1_i8_launches += 1;
     if (q8) SC.prof.sweep1_q8_launches += 1;
-    const dim3 mgrid((unsigned)((b.max_npad + 255) / 256), (unsigned)P);
+    mgrid = dim3((unsigned)((b.max_npad + 255) / 256), (unsigned)P);
     if (!compact) {
         hipLaunchKernelGGL(pf_thresholds_kernel, mgrid, dim3(256), 0, SC.stream, dp, dpf, SC.d_rp_s0.as<float>(),
                            SC.d_rp_s1.as<float>(), SC.d_cp_s0.as<float>(), (unsigned*)nullptr, tuv, tuv, prune, PlanCounts{}, 0);
@@ -643,14 +691,16 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
         DBGSYNC(ctx, "pf_thresholds_kernel");
     }
     hc.lap("launch sweep 1 (+ thresholds)");
+    return MSFM_OK;
+    }
 
-    size_t n_lists = 0;
-    const CandList* dl = nullptr;
-    if (compact) {
+    // ---- stage 4a (match lists): the static tables of the device-side plan of sweep 2 (the GPU is busy with sweep 1 meanwhile), its
+    // buffers from the prediction, everything it clears in one launch
+    int plan_buffers() {
         // ---- static plan tables (the GPU is busy with sweep 1 meanwhile), buffers from the prediction ----------
-        CompactPlan cp;
+        cp = CompactPlan{};
         build_compact_plan(ctx, b, cp, q8_refine);
-        const size_t G = cp.groups.size(), M = cp.member_pair.size();
+        G = cp.groups.size(), M = cp.member_pair.size();
         n_lists = G;
         long long max_ranges = 1;
         for (const PlanGroup& g : cp.groups) max_ranges = std::max<long long>(max_ranges, g.ranges);
@@ -665,7 +715,7 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
         const long long items_have = (long long)(SC.d_vitems.cap / sizeof(WorkItem)) / 8 * 8;
         const MsfmPlanRoom room = msfm_plan_room(ub, q8_refine ? cp.rows_ub_all_bits * 5 / 32 : cp.rows_ub * 5 / 16, (long long)G, max_ranges, kPfWgRows,
                                                  ctx->hint_rows_ub, ctx->cmp_rows_hint, ctx->cand_hint, ctx->items_hint, rows_have, cand_have, items_have);
-        const long long rows_cap = room.rows, cand_cap = room.cand, items_cap = room.items;
+        rows_cap = room.rows, cand_cap = room.cand, items_cap = room.items;
         SC.pf_pending.rows_ub = ub;
         HIPCHK(ctx, SC.d_gtot.ensure(std::max<size_t>(1, G) * 4));
         HIPCHK(ctx, SC.d_grow0.ensure((4 * std::max<size_t>(1, G) + 8) * 8));   // grow0 | gpos[3] | fwd_items_x[8]
@@ -708,10 +758,10 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
             HIPCHK(ctx, fb.launch(SC.stream));
         }
         hc.lap("plan tables + uploads");
-        const PlanPair* dpp = SC.d_ppair.as<PlanPair>();
-        PlanCounts pc = {dpp, (const int*)SC.d_member_group.as<int>(), SC.d_cnt.as<int>(), SC.d_gtot.as<int>()};
+        dpp = SC.d_ppair.as<PlanPair>();
+        pc = PlanCounts{dpp, (const int*)SC.d_member_group.as<int>(), SC.d_cnt.as<int>(), SC.d_gtot.as<int>()};
         HIPCHK(ctx, SC.d_summary_a.ensure(sizeof(PlanSummary)));
-        PlanOut po = {};
+        po = PlanOut{};
         po.vpairs = SC.d_vpairs.as<PairDesc>();
         po.vpf = SC.d_vpf.as<PfPair>();
         po.lists = SC.d_lists.as<CandList>();
@@ -729,35 +779,41 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
         po.items_cap = items_cap;
         po.cmp_tu = SC.d_cmp_tu.as<float>();
         po.cmp_n2 = i8 ? SC.d_cmp_n2.as<int>() : nullptr;
-        // the plan from the live counts in d_cnt / d_gtot: scan, descriptors + work items, member rows, slot assignment
-        auto launch_plan = [&](PlanSummary* summary, int norms_only) -> int {
-            po.summary = summary;
-            hipLaunchKernelGGL(pf_plan_scan_kernel, dim3(1), dim3(64), 0, SC.stream, SC.d_groups.as<PlanGroup>(), (int)G,
+        return MSFM_OK;
+    }
+
+    // the plan from the live counts in d_cnt / d_gtot: scan, descriptors + work items, member rows, slot assignment
+    int launch_plan(PlanSummary* summary, int norms_only) {
+        po.summary = summary;
+        hipLaunchKernelGGL(pf_plan_scan_kernel, dim3(1), dim3(64), 0, SC.stream, SC.d_groups.as<PlanGroup>(), (int)G,
+                           (const int*)SC.d_gtot.as<int>(), po);
+        HIPCHK(ctx, hipGetLastError());
+        DBGSYNC(ctx, "pf_plan_scan_kernel");
+        if (G > 0)
+            hipLaunchKernelGGL(pf_plan_write_kernel, dim3((unsigned)((G + 63) / 64)), dim3(64), 0, SC.stream, SC.d_groups.as<PlanGroup>(), (int)G,
                                (const int*)SC.d_gtot.as<int>(), po);
-            HIPCHK(ctx, hipGetLastError());
-            DBGSYNC(ctx, "pf_plan_scan_kernel");
-            if (G > 0)
-                hipLaunchKernelGGL(pf_plan_write_kernel, dim3((unsigned)((G + 63) / 64)), dim3(64), 0, SC.stream, SC.d_groups.as<PlanGroup>(), (int)G,
-                                   (const int*)SC.d_gtot.as<int>(), po);
-            HIPCHK(ctx, hipGetLastError());
-            DBGSYNC(ctx, "pf_plan_write_kernel");
-            if (G > 0)
-                hipLaunchKernelGGL(pf_member_rows_kernel, dim3((unsigned)((G + 3) / 4)), dim3(256), 0, SC.stream, SC.d_groups.as<PlanGroup>(), (int)G,
-                                   (const int*)SC.d_gmembers.as<int>(), (const int*)SC.d_cnt.as<int>(),
-                                   (const long long*)SC.d_grow0.as<long long>(), SC.d_mrow.as<long long>());
-            HIPCHK(ctx, hipGetLastError());
-            DBGSYNC(ctx, "pf_member_rows_kernel");
-            hipLaunchKernelGGL(pf_assign_kernel, dim3((unsigned)(2 * P), (unsigned)((b.max_npad + kAssignChunk - 1) / kAssignChunk)), dim3(256), 0,
-                               SC.stream, dp, dpf, dpp, (const float*)tuv,
-                               (const unsigned*)colmask, (const long long*)SC.d_mrow.as<long long>(), SC.d_cnt.as<int>(),
-                               SC.d_live_idx.as<int>(), SC.d_row_pair.as<int>(), SC.d_cmp_tu.as<float>(),
-                               SC.d_row_src.as<const _Float16*>(), i8 ? kI8RowBytes / 2 : kPfRowHalfs,
-                               SC.d_best.as<unsigned long long>(), SC.d_second.as<unsigned long long>(), norms_only,
-                               i8 ? SC.d_cmp_n2.as<int>() : (int*)nullptr);
-            HIPCHK(ctx, hipGetLastError());
-            DBGSYNC(ctx, "pf_assign_kernel");
-            return MSFM_OK;
-        };
+        HIPCHK(ctx, hipGetLastError());
+        DBGSYNC(ctx, "pf_plan_write_kernel");
+        if (G > 0)
+            hipLaunchKernelGGL(pf_member_rows_kernel, dim3((unsigned)((G + 3) / 4)), dim3(256), 0, SC.stream, SC.d_groups.as<PlanGroup>(), (int)G,
+                               (const int*)SC.d_gmembers.as<int>(), (const int*)SC.d_cnt.as<int>(),
+                               (const long long*)SC.d_grow0.as<long long>(), SC.d_mrow.as<long long>());
+        HIPCHK(ctx, hipGetLastError());
+        DBGSYNC(ctx, "pf_member_rows_kernel");
+        hipLaunchKernelGGL(pf_assign_kernel, dim3((unsigned)(2 * P), (unsigned)((b.max_npad + kAssignChunk - 1) / kAssignChunk)), dim3(256), 0,
+                           SC.stream, dp, dpf, dpp, (const float*)tuv,
+                           (const unsigned*)colmask, (const long long*)SC.d_mrow.as<long long>(), SC.d_cnt.as<int>(),
+                           SC.d_live_idx.as<int>(), SC.d_row_pair.as<int>(), SC.d_cmp_tu.as<float>(),
+                           SC.d_row_src.as<const _Float16*>(), i8 ? kI8RowBytes / 2 : kPfRowHalfs,
+                           SC.d_best.as<unsigned long long>(), SC.d_second.as<unsigned long long>(), norms_only,
+                           i8 ? SC.d_cmp_n2.as<int>() : (int*)nullptr);
+        HIPCHK(ctx, hipGetLastError());
+        DBGSYNC(ctx, "pf_assign_kernel");
+        return MSFM_OK;
+    }
+
+    // ---- stage 4b (route Q): live / dead from the twins' sweep; coarse twins: plan A, the fp16 sweep 1' of the live rows, scatter
+    int launch_route_q() {
         if (q8) {
             // ---- route Q: live / dead (fine twins: and the thresholds, the block masks, the counts of the plan) from the twins' sweep
             hipLaunchKernelGGL(pf_prune_q8_kernel, mgrid, dim3(256), 0, SC.stream, dp, dpf, (const PfPair*)SC.d_pfq.as<PfPair>(),
@@ -769,7 +825,7 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
         if (q8_refine) {
             // ---- coarse twins: plan A, fp16 sweep 1' on the live rows, scatter ------------------------------------------------
             HIPCHK(ctx, hipMemsetAsync(SC.d_summary_a.p, 0, sizeof(PlanSummary), SC.stream));
-            rc = launch_plan(SC.d_summary_a.as<PlanSummary>(), 1);
+            int rc = launch_plan(SC.d_summary_a.as<PlanSummary>(), 1);
             if (rc != MSFM_OK) return rc;
             HIPCHK(ctx, SC.d_cmp_s0.ensure((size_t)rows_cap * 4));
             HIPCHK(ctx, SC.d_cmp_s1.ensure((size_t)rows_cap * 4));
@@ -806,6 +862,11 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
             fb.add(SC.d_totals.p, 64, 0);
             HIPCHK(ctx, fb.launch(SC.stream));
         }
+        return MSFM_OK;
+    }
+
+    // ---- stage 4c: thresholds + live counts, the plan, the compacted sweep 2
+    int launch_compact_sweep2() {
         // thresholds + live counts per member / group (the plan tables above are uploaded by now; sweep 1 is still running)
         if (!q8_direct)
             hipLaunchKernelGGL(pf_thresholds_kernel, mgrid, dim3(256), 0, SC.stream, dp, dpf, SC.d_rp_s0.as<float>(),
@@ -815,7 +876,7 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
                                SC.d_rp_s1.as<float>(), SC.d_cp_s0.as<float>(), colmask, tuv, tuv, prune, pc, 0);
         HIPCHK(ctx, hipGetLastError());
         DBGSYNC(ctx, "pf_thresholds_kernel");
-        rc = launch_plan(SC.d_summary.as<PlanSummary>(), 0);
+        const int rc = launch_plan(SC.d_summary.as<PlanSummary>(), 0);
         if (rc != MSFM_OK) return rc;
         HIPCHK(ctx, hipEventRecord(e2, SC.stream));
         if (i8)
@@ -844,7 +905,11 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
         SC.pf_pending.cand_cap = cand_cap;
         SC.pf_pending.items_cap = items_cap;
         SC.pf_pending.compact_pairs = cp.pairs;
-    } else {
+        return MSFM_OK;
+    }
+
+    // ---- stage 4d: kNN-level API / ratio near 1 -- dense sweep 2: the pairs' own lists, the sweep-1 items again
+    int launch_dense_sweep2() {
         // ---- dense sweep 2: the pairs' own lists, the sweep-1 items again ----------------------------------------
         n_lists = P;
         std::vector<CandList>& lists = b.dense_lists;   // (lives as long as the sub-batch: the copy below may still be in flight)
@@ -868,26 +933,29 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
         HIPCHK(ctx, hipEventRecord(SC.sweep2_done, SC.stream));
         SC.sweep2_recorded = true;
         dl = SC.d_lists.as<CandList>();
+        return MSFM_OK;
     }
 
-    if (n_lists > 0) {
-        // list l on XCD l mod 8, its spans of 256 candidates handed out by a per-XCD cursor to that XCD's persistent workgroups
-        // (see the kernel): 8 workgroups of 4 waves per CU when it has the chip to itself, one per CU fits next to a sweep workgroup
-        const int wgs_per_xcd = std::max(1, ctx->cu_count / 8) * 8;
-        const dim3 cgrid((unsigned)(8 * wgs_per_xcd));
-        const unsigned long long* dcount = SC.d_cand_count.as<unsigned long long>();
+    // ---- stage 5: exact S of the candidates, [finalize], overflow bookkeeping; what finish_prefilter reads at the end of the batch
+    int launch_exact_and_finalize() {
+        if (n_lists > 0) {
+            // list l on XCD l mod 8, its spans of 256 candidates handed out by a per-XCD cursor to that XCD's persistent workgroups
+            // (see the kernel): 8 workgroups of 4 waves per CU when it has the chip to itself, one per CU fits next to a sweep workgroup
+            const int wgs_per_xcd = std::max(1, ctx->cu_count / 8) * 8;
+            const dim3 cgrid((unsigned)(8 * wgs_per_xcd));
+            const unsigned long long* dcount = SC.d_cand_count.as<unsigned long long>();
 #define MSFM_LAUNCH_EXACT(O)                                                                                             \
-    hipLaunchKernelGGL(pf_exact_candidates_kernel<O>, cgrid, dim3(kExSpan), 0, SC.stream, dp, dl, dcount,                  \
-                       (const int2*)SC.d_cand.as<int2>(), SC.d_best.as<unsigned long long>(), SC.d_second.as<unsigned long long>(), \
-                       (int)n_lists, SC.d_totals.as<int>() + 16, (const int*)SC.d_cand_val.as<int>(), 0)
-        // byte pairs on the integer route: the sweep handed over exact integers -- no rows are read, the named order does not matter
-        if (i8 && compact) MSFM_LAUNCH_EXACT(4);
-        else if (ctx->order == MSFM_ORDER_SSE4X4) MSFM_LAUNCH_EXACT(0);
-        else if (ctx->order == MSFM_ORDER_AVX2_FMA) MSFM_LAUNCH_EXACT(1);
-        else MSFM_LAUNCH_EXACT(3);
+        hipLaunchKernelGGL(pf_exact_candidates_kernel<O>, cgrid, dim3(kExSpan), 0, SC.stream, dp, dl, dcount,                  \
+                           (const int2*)SC.d_cand.as<int2>(), SC.d_best.as<unsigned long long>(), SC.d_second.as<unsigned long long>(), \
+                           (int)n_lists, SC.d_totals.as<int>() + 16, (const int*)SC.d_cand_val.as<int>(), 0)
+            // byte pairs on the integer route: the sweep handed over exact integers -- no rows are read, the named order does not matter
+            if (i8 && compact) MSFM_LAUNCH_EXACT(4);
+            else if (ctx->order == MSFM_ORDER_SSE4X4) MSFM_LAUNCH_EXACT(0);
+            else if (ctx->order == MSFM_ORDER_AVX2_FMA) MSFM_LAUNCH_EXACT(1);
+            else MSFM_LAUNCH_EXACT(3);
 #undef MSFM_LAUNCH_EXACT
-        HIPCHK(ctx, hipGetLastError());
-        DBGSYNC(ctx, "pf_exact_candidates_kernel");
+            HIPCHK(ctx, hipGetLastError());
+            DBGSYNC(ctx, "pf_exact_candidates_kernel");
     }
     if (!SC.keys_epilogue) {
         hipLaunchKernelGGL(pf_finalize_kernel, mgrid, dim3(256), 0, SC.stream, dp, dpf, (const float*)tuv, SC.d_best.as<unsigned long long>(),
@@ -911,6 +979,30 @@ int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
     SC.pf_pending.ev_base = ev_base;
     hc.lap("launch sweep 2 .. finalize");
     return MSFM_OK;
+    }
+
+    int run() {
+        int rc = choose_routes();
+        if (rc != MSFM_OK) return rc;
+        rc = build_and_upload();
+        if (rc != MSFM_OK || b.n_items == 0) return rc;
+        rc = launch_sweep1();
+        if (rc != MSFM_OK) return rc;
+        if (compact) {
+            rc = plan_buffers();
+            if (rc == MSFM_OK && q8) rc = launch_route_q();
+            if (rc == MSFM_OK) rc = launch_compact_sweep2();
+        } else {
+            rc = launch_dense_sweep2();
+        }
+        if (rc != MSFM_OK) return rc;
+        return launch_exact_and_finalize();
+    }
+};
+
+int run_prefilter(msfm_ctx* ctx, Batch& b, size_t ev_base, PruneParams prune) {
+    PrefilterLaunch launch(ctx, b, ev_base, prune);
+    return launch.run();
 }
 
 // After the batch's stream synchronisation: did the prefilter path complete?  *retry: run the batch again (buffers

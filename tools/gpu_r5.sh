@@ -17,8 +17,8 @@ probe)   # what an upload can cost, the block-scaled fp6 instruction, parity of 
     run ubench_fp6 tools/ubench_fp6; cat $OUT/ubench_fp6.txt
     TMO=900 run pytest_bytes python -m pytest -m gpu -x -q tests/test_gpu_i8.py tests/test_gpu_jobs.py tests/test_gpu_configs.py tests/test_gpu_certificate.py; tail -3 $OUT/pytest_bytes.txt
     run fuzz_bytes python tools/fuzz_routes.py 811 250; tail -2 $OUT/fuzz_bytes.txt
-    run ab_u8 python tools/ab_multi.py --u8 --images 64 r04=$R04 tree; cat $OUT/ab_u8.txt
-    run ab_u8_p1 python tools/ab_multi.py --u8 --images 64 --p1 r04=$R04 tree; cat $OUT/ab_u8_p1.txt
+    run ab_u8 python tools/ab.py --u8 --images 64 r04=$R04 tree; cat $OUT/ab_u8.txt
+    run ab_u8_p1 python tools/ab.py --u8 --images 64 --p1 r04=$R04 tree; cat $OUT/ab_u8_p1.txt
     ;;
 malloc)  # device / page-locked allocation cost by size
     run ubench_malloc tools/ubench_malloc; cat $OUT/ubench_malloc.txt
@@ -51,8 +51,8 @@ cfg4)   # config 4 in full, one call, cold then warm (first call <=
     TMO=1500 run config4_full python tools/config4_full.py --warm --int-oracle-pairs 1; head -c 1200 $OUT/config4_full.txt; echo; grep -n "store_\|cold_first" $OUT/config4_full.txt
     ;;
 tail)   # the exact re-check at 64 VGPRs (co-resident with sweep 1) under 2 / 3 / 4 parts; against round 4's build
-    run ab_parts python tools/ab_envs.py --rounds 14 "" "MSFM_PIPELINE=3" "MSFM_PIPELINE=4" "MSFM_PIPELINE=3,MSFM_PIPELINE_TAPER=0.5" "MSFM_PIPELINE=1"; cat $OUT/ab_parts.txt
-    run ab_r04 python tools/ab_multi.py --rounds 14 r04=$R04 tree; cat $OUT/ab_r04.txt
+    run ab_parts python tools/ab.py --rounds 14 tree "@MSFM_PIPELINE=3" "@MSFM_PIPELINE=4" "@MSFM_PIPELINE=3,MSFM_PIPELINE_TAPER=0.5" "@MSFM_PIPELINE=1"; cat $OUT/ab_parts.txt
+    run ab_r04 python tools/ab.py --rounds 14 r04=$R04 tree; cat $OUT/ab_r04.txt
     BENCH="python $ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-e2e --sustained-steps 0 --u8-images 0 --no-solo"
     cd /tmp; timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/prof_stats -- $BENCH > $OUT/prof_stats.log 2>&1; echo "stats rc=$?"; cd $ROOT
     DB=$(ls -t $(find $OUT/prof_stats -name '*.db') | head -1)
