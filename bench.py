@@ -244,6 +244,26 @@ def end_to_end(cpu_rate, cpu_single_rate, n_images=128, n_desc=5000):
             runs.append((wall_k, r, db_k))
         walls = [w for w, _, _ in runs]
         wall, r, db_used = sorted(runs, key=lambda x: x[0])[1]
+        # a fourth process with the geometric verification OFF: what the matcher hands to FeatureUtils::FilterMatches
+        # (src/Feature/FeatureUtils.cpp:176-206) -- the synthetic keypoints observe shared scene points (synth.scene_keypoints), so the
+        # verification keeps the true matches as it does on overlapping photographs, and the write phase is a representative one
+        noverify = None
+        try:
+            db_n = db_path + ".noverify"
+            shutil.copyfile(db_path + ".pristine", db_n)
+            cfg_n = os.path.join(tmp, "cfg_noverify.yaml")
+            open(cfg_n, "w").write('%%YAML:1.0\ndatabase_path : "%s"\nSIFTmatch.match_type : 1\n' % db_n)
+            time.sleep(settle_s)
+            t0 = time.perf_counter()
+            rn = subprocess.run([exe, cfg_n], capture_output=True, text=True, env=dict(env, MSFM_GEOMETRIC_VERIFICATION="0"), timeout=600)
+            wall_n = time.perf_counter() - t0
+            if rn.returncode == 0:
+                con = sqlite3.connect(db_n)
+                rows_n, matches_n = con.execute("SELECT COUNT(*), SUM(rows) FROM matches").fetchone()
+                con.close()
+                noverify = {"wall_s": wall_n, "rows_written": int(rows_n), "matches_written": int(matches_n or 0)}
+        except Exception as e:  # noqa: BLE001
+            noverify = {"error": "%s: %s" % (type(e).__name__, e)}
         phases = {}
         for name, val in re.findall(r"([a-zA-Z+\- ]+?) ([0-9.]+) s(?: \||$)", ([l for l in r.stderr.splitlines() if "exist-check" in l] or [""])[-1].replace("[msfm timing] ", "")):
             phases[name.strip()] = float(val)
@@ -258,6 +278,9 @@ def end_to_end(cpu_rate, cpu_single_rate, n_images=128, n_desc=5000):
                "phases_s": phases, "phases_sum_s": sum(phases.values()), "settle_s_before_each_process": settle_s,
                "db_bytes": os.path.getsize(db_path), "db_build_s_untimed": build_s, "images": n_images, "pairs": pairs,
                "rows_written": int(rows), "matches_written": int(matches or 0), "descriptor_pairs": total,
+               "verification_off": noverify,
+               "matches_kept_by_verification": (int(matches or 0) / noverify["matches_written"]) if noverify and noverify.get("matches_written") else None,
+               "matches_written_per_pair": int(matches or 0) / max(1, int(rows)),
                "file_cache": "warm (the database was written just before the run)",
                "last_stdout_line": (r.stdout.strip().splitlines() or [""])[-1]}
         return end_to_end_ratios(out, cpu_rate, cpu_single_rate)

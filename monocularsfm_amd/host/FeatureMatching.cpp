@@ -23,6 +23,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <functional>
 #include <iostream>
 #include <memory>
 #include <mutex>
@@ -137,6 +138,69 @@ private:
     std::deque<std::unique_ptr<ResultChunk>> q_;
     size_t bytes_ = 0, cap_;
     bool closed_ = false, aborted_ = false;
+};
+
+// fn(g) for every device g at once: g = 0 on the calling thread, the others on persistent helper threads (a thread spawn per image and
+// device of the bulk load would cost more than the uploads).  A context is only ever driven by the thread that runs ITS g.
+class DeviceCrew {
+public:
+    explicit DeviceCrew(size_t n) : n_(n) {
+        for (size_t g = 1; g < n_; ++g) helpers_.emplace_back([this, g] { Loop(g); });
+    }
+    ~DeviceCrew() {
+        {
+            std::lock_guard<std::mutex> l(mu_);
+            quit_ = true;
+            ++generation_;
+        }
+        start_.notify_all();
+        for (auto& t : helpers_) t.join();
+    }
+    template <class F>
+    void Run(F&& fn) {
+        if (n_ <= 1) {
+            fn((size_t)0);
+            return;
+        }
+        {
+            std::lock_guard<std::mutex> l(mu_);
+            fn_ = [&fn](size_t g) { fn(g); };
+            pending_ = n_ - 1;
+            ++generation_;
+        }
+        start_.notify_all();
+        fn((size_t)0);
+        std::unique_lock<std::mutex> l(mu_);
+        done_.wait(l, [&] { return pending_ == 0; });
+    }
+
+private:
+    void Loop(size_t g) {
+        unsigned long long seen = 0;
+        while (true) {
+            std::function<void(size_t)> fn;
+            {
+                std::unique_lock<std::mutex> l(mu_);
+                start_.wait(l, [&] { return generation_ != seen; });
+                seen = generation_;
+                if (quit_) return;
+                fn = fn_;
+            }
+            fn(g);
+            {
+                std::lock_guard<std::mutex> l(mu_);
+                if (--pending_ == 0) done_.notify_one();
+            }
+        }
+    }
+    size_t n_;
+    std::vector<std::thread> helpers_;
+    std::mutex mu_;
+    std::condition_variable start_, done_;
+    std::function<void(size_t)> fn_;
+    size_t pending_ = 0;
+    unsigned long long generation_ = 0;
+    bool quit_ = false;
 };
 
 // One device's share of a run and the thread that works it off.
@@ -276,10 +340,14 @@ void FeatureMatcher::PreloadAllImages() {
     if (const char* e = std::getenv("MSFM_BULK_LOAD"))
         if (e[0] == '0') return;
     Lap l(&g_clock.read_desc);
+    // (several devices: the copies of a row into the devices' page-locked rings run side by side -- one after the other they were
+    // G x the load time of one device, as much as the matching itself takes on 8 GPUs)
+    DeviceCrew crew(devices_.size());
     struct Sink {
         FeatureMatcher* self;
         bool keypoints;
-    } sink{this, false};
+        DeviceCrew* crew;
+    } sink{this, false, &crew};
     // visitors run on this thread while SQLite holds the row: upload from its buffer, keep nothing
     auto visit = [](void* user, image_t id, const void* data, size_t rows, size_t cols, size_t elem) {
         Sink* s = static_cast<Sink*>(user);
@@ -287,10 +355,14 @@ void FeatureMatcher::PreloadAllImages() {
         if (id < 0 || id >= MSFM_MAX_IMAGES) return;
         if (!s->keypoints) {
             if (m->devices_[0].resident.count(id)) return;
-            for (Device& dev : m->devices_) {
-                MSFM_CALL(dev.ctx, msfm_upload_image(dev.ctx, id, data, (int)rows, rows ? (int)cols : MSFM_DIM, elem == 1 ? MSFM_DTYPE_U8 : MSFM_DTYPE_F32));
-                dev.resident.insert(id);
-            }
+            std::vector<int> status(m->devices_.size(), MSFM_OK);
+            s->crew->Run([&](size_t g) {
+                Device& dev = m->devices_[g];
+                status[g] = msfm_upload_image(dev.ctx, id, data, (int)rows, rows ? (int)cols : MSFM_DIM, elem == 1 ? MSFM_DTYPE_U8 : MSFM_DTYPE_F32);
+                if (status[g] == MSFM_OK) dev.resident.insert(id);
+            });
+            for (size_t g = 0; g < status.size(); ++g)
+                if (status[g] != MSFM_OK) Die(m->devices_[g].ctx, "msfm_upload_image (bulk load)", status[g]);
         } else {
             // Database::ReadKeyPoints asserts cols == 4 (x, y, size, angle); a narrower blob would be over-read below
             if (rows > 0 && cols != 4) {
@@ -300,9 +372,12 @@ void FeatureMatcher::PreloadAllImages() {
             std::vector<KeyPoint>& kps = m->keypoints_cache_[id];
             kps.resize(rows);
             if (rows) std::memcpy(kps.data(), data, rows * sizeof(KeyPoint));
-            if (m->geometric_verification_ && !m->verification_on_host_ && m->devices_[0].resident.count(id))
-                for (Device& dev : m->devices_)
-                    MSFM_CALL(dev.ctx, msfm_upload_keypoints(dev.ctx, id, static_cast<const float*>(data), (int)rows, 4));
+            if (m->geometric_verification_ && !m->verification_on_host_ && m->devices_[0].resident.count(id)) {
+                std::vector<int> status(m->devices_.size(), MSFM_OK);
+                s->crew->Run([&](size_t g) { status[g] = msfm_upload_keypoints(m->devices_[g].ctx, id, static_cast<const float*>(data), (int)rows, 4); });
+                for (size_t g = 0; g < status.size(); ++g)
+                    if (status[g] != MSFM_OK) Die(m->devices_[g].ctx, "msfm_upload_keypoints (bulk load)", status[g]);
+            }
         }
     };
     static_assert(sizeof(KeyPoint) == 16, "KeyPoint must be 4 packed floats");
@@ -320,10 +395,7 @@ void FeatureMatcher::PreloadAllImages() {
     // the uploads above only copied: build the stores now (classification, one allocation, layout kernels), inside this phase's clock --
     // every device builds its own copy, all at once
     std::vector<int> status(devices_.size(), MSFM_OK);
-    std::vector<std::thread> builders;
-    for (size_t g = 1; g < devices_.size(); ++g) builders.emplace_back([&, g] { status[g] = msfm_finalize_store(devices_[g].ctx); });
-    status[0] = msfm_finalize_store(devices_[0].ctx);
-    for (auto& t : builders) t.join();
+    crew.Run([&](size_t g) { status[g] = msfm_finalize_store(devices_[g].ctx); });
     for (size_t g = 0; g < devices_.size(); ++g)
         if (status[g] != MSFM_OK) Die(devices_[g].ctx, "msfm_finalize_store", status[g]);
     bulk_loaded_ = true;

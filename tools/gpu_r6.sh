@@ -41,6 +41,45 @@ print("config 2 streamed:", round(d["ms_per_step"],2), "ms/step", d["per_rank_ms
 u=d.get("strong_u8",{}); print("config 4 streamed:", u.get("seconds_per_step"), "s/step", u.get("per_rank_ms"), u.get("exchange_detail_rank0"))
 PY
     ;;
+multi)   # the executable's device fan-out at config-4 scale with SEVERAL CONTEXTS ON THE ONE GPU (MSFM_DEVICES=0,0 / 0,0,0,0): same rows,
+         # and what the phases that do not shrink with the device count cost (bulk load into G stores, contexts, pre-emptive filter)
+    TMO=900 run cli_config4_2ctx python tools/cli_e2e_bench.py --config4 --tables u8 --modes off --devices 0,0 --json $OUT/cli_config4_2ctx.json; cat $OUT/cli_config4_2ctx.txt; tail -3 $OUT/cli_config4_2ctx.err
+    TMO=900 run cli_config4_4ctx python tools/cli_e2e_bench.py --config4 --tables u8 --modes off --orders pair_id --devices 0,0,0,0 --json $OUT/cli_config4_4ctx.json; cat $OUT/cli_config4_4ctx.txt; tail -3 $OUT/cli_config4_4ctx.err
+    ;;
+evidence)   # the round's evidence in one call on one box (copy what is judged into profiles/ as r06_*)
+    TMO=1500 run pytest_gpu python -m pytest tests -m gpu -q; tail -2 $OUT/pytest_gpu.txt
+    TMO=900 run bench python bench.py; python - <<'PY'
+import json
+d=json.loads([l for l in open("gpurun_out/r6/evidence/bench.txt") if l.startswith("{")][-1]); r=d["roofline"]
+json.dump(d, open("gpurun_out/r6/evidence/bench.json","w"), indent=1)
+print("ms_per_step", round(d["ms_per_step"],3), "value %.4g" % d["value"], "sustained", d["sustained_ms_per_step"], "frac", round(r["frac"],4), "solo", round(r["solo"]["frac"],4), "upload_ms", round(d["pcie_inclusive"]["upload_ms"],2), "traffic_source", r.get("traffic_source"))
+print("strong_u8", {k: d["strong_u8"].get(k) for k in ("value","seconds_per_step","sub_batches_per_step_rank0","matches_per_step","error")})
+print("end_to_end", {k: d["end_to_end"].get(k) for k in ("wall_s","walls_s","phases_s","rows_written","matches_written","matches_kept_by_verification","verification_off","ratio","ratio_vs_single_thread","error")})
+print("cpu_baseline", {k: d["cpu_baseline"].get(k) for k in ("value","fast_order_value","fast_order","cores","single_thread_value")}, "gpu_over_cpu", d.get("gpu_over_cpu"), d.get("gpu_over_cpu_fast_order"))
+PY
+    BENCH="python $ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-e2e --sustained-steps 0 --u8-images 0 --no-solo"
+    cd /tmp
+    timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/prof_stats -- $BENCH > $OUT/prof_stats.log 2>&1; echo "stats rc=$?"
+    MSFM_PIPELINE=1 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/prof_stats_p1 -- $BENCH > $OUT/prof_stats_p1.log 2>&1; echo "stats p1 rc=$?"
+    timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $BENCH > $OUT/pmc_fetch.log 2>&1; echo "fetch rc=$?"
+    timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $BENCH > $OUT/pmc_write.log 2>&1; echo "write rc=$?"
+    cd $ROOT
+    DB=$(ls -t $(find $OUT/prof_stats -name '*.db') | head -1)
+    python tools/rocprof_summary.py "$DB" "$BENCH" > $OUT/bench_kernel_stats.txt 2>&1; head -8 $OUT/bench_kernel_stats.txt | cut -c1-60,150-215
+    python tools/step_timeline.py "$DB" 2 > $OUT/step_timeline.txt 2>&1; tail -1 $OUT/step_timeline.txt | cut -c1-300
+    DB1=$(ls -t $(find $OUT/prof_stats_p1 -name '*.db') | head -1)
+    python tools/rocprof_summary.py "$DB1" "MSFM_PIPELINE=1 $BENCH" > $OUT/bench_kernel_stats_pipeline1.txt 2>&1; head -12 $OUT/bench_kernel_stats_pipeline1.txt | cut -c1-60,150-215
+    KERN="sweep_i8_kernel<1>,sweep_kernel<3>,pf_prune_q8_kernel,pf_assign_kernel,pf_exact_candidates_kernel,epilogue_kernel,fill_segs_kernel,st_float_kernel,st_i8_kernel,st_classify_kernel"
+    PMC_STEPS=5 python tools/pmc_summary.py $OUT/pmc_traffic_approx.json "$KERN" $OUT/pmc_fetch $OUT/pmc_write > $OUT/pmc_traffic.txt 2>&1; tail -3 $OUT/pmc_traffic.txt
+    find $OUT -type f -size +8M -delete
+    MSFM_Q8=2 run fuzz_q8 python tools/fuzz_routes.py 961 1200; tail -1 $OUT/fuzz_q8.txt
+    run fuzz_default python tools/fuzz_routes.py 964 1500; tail -1 $OUT/fuzz_default.txt
+    run fuzz_jobs python tools/fuzz_jobs.py 965 600; tail -1 $OUT/fuzz_jobs.txt
+    ;;
+fourth)
+    bash tools/gpu_r6.sh suite
+    bash tools/gpu_r6.sh multi
+    ;;
 third)
     bash tools/gpu_r6.sh suite
     bash tools/gpu_r6.sh cli
