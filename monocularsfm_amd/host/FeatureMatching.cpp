@@ -267,6 +267,13 @@ void FeatureMatcher::OpenDatabaseAndDevice() {
             status[g] = msfm_create(devs[g], &c);
             if (status[g] == MSFM_OK)
                 if (const char* o = std::getenv("MSFM_ACCUM_ORDER")) status[g] = msfm_set_accum_order(c, std::atoi(o));
+            // An ordinal listed k times (the tests' way to run the fan-out on a one-GPU box): every context would size its scratch
+            // for a quarter of the device's free memory on its own -- four of them on one MI355X ran out of memory at config-4 scale.
+            // They share the default budget instead (MSFM_SCRATCH_MIB still overrides: it is read at msfm_create, this only applies without it).
+            const long long sharing = (long long)std::count(devs.begin(), devs.end(), devs[g]);
+            if (status[g] == MSFM_OK && sharing > 1 && !std::getenv("MSFM_SCRATCH_MIB"))
+                status[g] = msfm_set_limits(c, std::getenv("MSFM_MAX_PAIRS_PER_BATCH") ? std::atoi(std::getenv("MSFM_MAX_PAIRS_PER_BATCH")) : 0,
+                                            ((int64_t)48 << 30) / sharing);
             devices_[g].ctx = c;
         };
         create(0);   // (the runtime's own start-up happens once, on this thread)
