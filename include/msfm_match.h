@@ -105,6 +105,10 @@ typedef struct msfm_profile {
     int mixed_route_sub_batches;  /* sub-batches that ran TWO first sweeps: the integer one on the pairs whose images both have fine byte
                                      twins, the fp16 one on the rest (an image with a value beyond [0, 1] among twinned ones) -- the twins'
                                      pairs are not demoted then.  Byte stores and coarse twins still choose one route per sub-batch */
+    int memory_shrinks;           /* times the call found the device OUT OF MEMORY while sizing a sub-batch's scratch (another tenant of the GPU,
+                                     several contexts on one device: the budget of msfm_set_limits is derived from the free memory once per
+                                     state of the store), gave every idle buffer back, halved the scratch share of a sub-batch and cut again from
+                                     the same pair.  Same results, more sub-batches; 0 normally.  After four of them the call fails with MSFM_E_DEVICE */
 } msfm_profile;
 
 /* ---- context ------------------------------------------------------------------------- */

@@ -50,7 +50,7 @@ class Profile(C.Structure):
                 ("sub_batches", C.c_int), ("tie_queue_regrows", C.c_int), ("plan_regrows", C.c_int),
                 ("sweep1_i8_launches", C.c_int), ("sweep1_q8_launches", C.c_int), ("sweep1b_launches", C.c_int),
                 ("sweep1b_ms", C.c_double), ("sweep1b_descriptor_pairs", C.c_int64), ("order_sensitive_rows", C.c_int64),
-                ("demoted_pairs", C.c_int), ("mixed_route_sub_batches", C.c_int)]
+                ("demoted_pairs", C.c_int), ("mixed_route_sub_batches", C.c_int), ("memory_shrinks", C.c_int)]
 
 
 class Chunk(C.Structure):

@@ -599,6 +599,7 @@ struct Scratch {
         for_each_buf([](DevBuf& b, void* a) { *static_cast<long long*>(a) += (long long)b.cap; }, &sum);
         return sum;
     }
+    void release_device() { for_each_buf([](DevBuf& b, void*) { b.release(); }, nullptr); }   // (the page-locked host side stays)
     void release_all() {
         for_each_buf([](DevBuf& b, void*) { b.release(); }, nullptr);
         for (PinnedBuf& h : h_up) h.release();
@@ -646,6 +647,7 @@ struct msfm_ctx {
     // sub-batch limits of msfm_match_pairs (msfm_set_limits / MSFM_MAX_PAIRS_PER_BATCH / MSFM_SCRATCH_MIB)
     int max_pairs_per_batch = kDefaultMaxPairsPerBatch;
     long long scratch_bytes = 0;      // msfm_set_limits / MSFM_SCRATCH_MIB: total for the scratch sets in flight; 0 = automatic (above)
+    int last_hip_error = 0;           // hipError_t of the last failed HIPCHK (0: none since the matching call began)
     long long budget_cached = 0;      // the automatic scratch budget, derived from hipMemGetInfo once per (store size, limit)
     size_t budget_for_store = 0;
     long long budget_for_limit = 0;
@@ -684,6 +686,12 @@ int fail(msfm_ctx* ctx, int code, const std::string& msg) {
     if (ctx) ctx->err = msg;
     return code;
 }
+// which HIP error the last failed HIPCHK saw: a matching call looks at it to tell "the device is out of memory" (it shrinks its
+// sub-batches and tries again, msfm_job.hip.h) from every other device error
+inline void note_hip_error(msfm_ctx* ctx, hipError_t e) {
+    if (ctx) ctx->last_hip_error = (int)e;
+}
+inline void note_hip_error(const msfm_ctx*, hipError_t) {}
 
 // The exception barrier of the C ABI (msfm_guard.h): every `extern "C"` entry point runs its body between these two.  An exception leaves
 // the context usable: after_api_exception (msfm_match.hip) records the text, drains the streams and closes an open series.
@@ -696,9 +704,11 @@ void after_api_exception(msfm_ctx* ctx, const char* text) noexcept;
 #define HIPCHK(ctx, call)                                                                     \
     do {                                                                                      \
         hipError_t e__ = (call);                                                              \
-        if (e__ != hipSuccess)                                                                \
+        if (e__ != hipSuccess) {                                                              \
+            note_hip_error(ctx, e__);                                                         \
             return fail(ctx, MSFM_E_DEVICE,                                                   \
                         std::string(#call) + ": " + hipGetErrorString(e__));                  \
+        }                                                                                     \
     } while (0)
 
 

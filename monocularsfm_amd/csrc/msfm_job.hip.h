@@ -41,6 +41,8 @@ struct MatchJob {
     int next_begin = 0;
     long long issued = 0, completed = 0;   // sub-batch k lives in slot k % kSets
     bool open = false;
+    bool memory_wait = false;   // a sub-batch did not fit the device's memory: nothing new is issued until what is in flight has been completed
+    int memory_shrinks = 0;
 
     // everything before the first launch
     int start(msfm_ctx* c, const int32_t* pairs_in, int n, const msfm_match_params* params, const msfm_verify_params* vp, bool stream_mode) {
@@ -56,6 +58,9 @@ struct MatchJob {
         for (SubBatch& w : sb) w = SubBatch{};
         next_begin = 0;
         issued = completed = 0;
+        memory_wait = false;
+        memory_shrinks = 0;
+        ctx->last_hip_error = 0;
     prm = msfm_match_params{0.8f, 1, 0.7};
     if (params) prm = *params;
     // rows / columns that provably fail the ratio test or the distance cut need no exact neighbours
@@ -400,25 +405,73 @@ struct MatchJob {
         return MSFM_OK;
     }
 
-    bool more() const { return completed < issued || next_begin < n_pairs; }
+    bool more() const { return completed < issued || next_begin < n_pairs; }   // (a sub-batch waiting for memory has not advanced next_begin)
 
     // launch ahead as many sub-batches as there are free scratch sets, wait for the oldest one (re-running it alone if a buffer was too
     // small): *slot_out = the scratch set whose sub-batch has just been completed
+    // The device ran out of memory while a sub-batch was being sized or launched (another tenant of the GPU; several contexts on one
+    // device -- the budget is derived from the free memory ONCE per state of the store, msfm_set_limits): not an error yet.  What the
+    // failed attempt launched is drained and dropped; nothing new is issued until the sub-batches in flight have been completed (their
+    // buffers are theirs); then every scratch buffer goes back to the device, the share of a sub-batch is halved -- and never more
+    // than a sixth of what is free now -- and the call cuts again from the same pair.  Results do not depend on the cut.
+    bool out_of_memory(int rc) const { return rc == MSFM_E_DEVICE && ctx->last_hip_error == (int)hipErrorOutOfMemory && memory_shrinks < 4; }
+    void drop_attempt(int slot) {
+        Scratch& sc = ctx->sc[slot];
+        if (sc.stream) (void)hipStreamSynchronize(sc.stream);
+        (void)hipGetLastError();   // (the runtime keeps the allocation's error for the next hipGetLastError: a launch check would see it)
+        sb[slot].active = false;
+        sc.pf_pending = PfPending{};
+        sc.sweep1_recorded = false;
+        sc.sweep2_recorded = false;
+        if (ctx->last_sweep1 == &sc) ctx->last_sweep1 = nullptr;
+        ctx->last_hip_error = 0;
+        memory_wait = true;
+    }
+    int shrink_memory() {
+        int rc = drain_streams(ctx);
+        if (rc != MSFM_OK) return rc;
+        ctx->deferred.flush();
+        for (Scratch& sc : ctx->sc) sc.release_device();   // (streams, events and the page-locked host side stay)
+        size_t free_b = 0, total_b = 0;
+        long long share = kScratchBytes / 2;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) share = std::min<long long>(share, (long long)(free_b / (2 * (size_t)kSets)));   // all sets together: half of what is free
+        kScratchBytes = std::max<long long>(1, share);
+        ctx->budget_cached = kScratchBytes * kSets;   // (later calls on this state of the store start from what worked)
+        ctx->hint_rows_ub = 0;                        // (the plan's prediction was relative to buffers that are gone)
+        memory_wait = false;
+        memory_shrinks += 1;
+        ctx->prof.memory_shrinks += 1;
+        if (std::getenv("MSFM_DEBUG_TIMING"))
+            std::fprintf(stderr, "[msfm alloc] out of device memory: scratch given back, %.2f GiB per sub-batch from pair %d on (%zu MiB free)\n",
+                         kScratchBytes / 1073741824.0, next_begin, free_b >> 20);
+        return MSFM_OK;
+    }
+
     int step(int* slot_out) {
         const DeferFreesScope defer(&ctx->deferred);   // buffers replaced below are freed once the streams have been drained
         const std::vector<char> no_force;
-        while (next_begin < n_pairs && issued - completed < kSets) {
-            const int slot = (int)(issued % kSets);
-            int rc = ensure_scratch_set(ctx, slot);
+        while (true) {
+            while (!memory_wait && next_begin < n_pairs && issued - completed < kSets) {
+                const int slot = (int)(issued % kSets);
+                int rc = ensure_scratch_set(ctx, slot);
+                if (rc != MSFM_OK) return rc;
+                ctx->cur = &ctx->sc[slot];
+                rc = build(sb[slot], next_begin, no_force);
+                if (rc == MSFM_OK) rc = issue(sb[slot], 2 + 12 * (size_t)slot);
+                if (out_of_memory(rc)) {
+                    drop_attempt(slot);
+                    break;
+                }
+                if (rc != MSFM_OK) return rc;
+                next_begin = sb[slot].end;
+                ++issued;
+            }
+            if (issued > completed) break;          // something is in flight: complete the oldest below
+            if (!memory_wait) break;                // (nothing left to do: the caller checks more())
+            const int rc = shrink_memory();          // nothing in flight and the next sub-batch did not fit: smaller ones
             if (rc != MSFM_OK) return rc;
-            ctx->cur = &ctx->sc[slot];
-            rc = build(sb[slot], next_begin, no_force);
-            if (rc != MSFM_OK) return rc;
-            rc = issue(sb[slot], 2 + 12 * (size_t)slot);
-            if (rc != MSFM_OK) return rc;
-            next_begin = sb[slot].end;
-            ++issued;
         }
+        if (issued == completed) return fail(ctx, MSFM_E_STATE, "step() without work");
         const int slot = (int)(completed % kSets);
         ctx->cur = &ctx->sc[slot];
         std::vector<char> force_exact;

@@ -317,6 +317,7 @@ void add_profile(msfm_profile& to, const msfm_profile& d) {
     to.sweep1b_descriptor_pairs += d.sweep1b_descriptor_pairs;
     to.demoted_pairs += d.demoted_pairs;
     to.mixed_route_sub_batches += d.mixed_route_sub_batches;
+    to.memory_shrinks += d.memory_shrinks;
 }
 
 int drain_streams(msfm_ctx* ctx) {

@@ -420,3 +420,66 @@ def test_job_fuzz_random_stores_under_random_cuts(built_lib, q8):
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_jobs.py"), "5", "30"], cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "mismatches: 0" in r.stdout
+
+
+@pytest.mark.parametrize("form", ["one_call", "stream"])
+def test_out_of_device_memory_shrinks_the_sub_batches_and_carries_on(form):
+    """The scratch budget of a call is derived from the device's free memory ONCE per state of the store (msfm_set_limits).  When another
+    tenant of the GPU takes the memory afterwards -- here: a torch tensor that leaves ~0.7 GB -- a sub-batch no longer fits: the call
+    gives its scratch back, halves the share of a sub-batch (at most a sixth of what is free) and cuts again from the same pair
+    (msfm_profile.memory_shrinks), instead of failing with MSFM_E_DEVICE.  Same lists as on an empty device, from more sub-batches."""
+    torch = pytest.importorskip("torch")
+    from monocularsfm_amd import _lib
+    imgs = synth.u8_images(40, 8192, seed=77, dup_frac=0.05, as_float=False)
+    pairs = synth.all_pairs(40)                       # 780 pairs x ~1.9 MB of scratch
+    small = synth.all_pairs(12)
+    kw = {"max_distance": 1e9}
+    with _lib.Context(0) as ref_ctx:
+        for i, im in enumerate(imgs):
+            ref_ctx.upload_image(i, im)
+        ref = tuple(np.array(x) for x in ref_ctx.match_pairs(pairs, **kw))
+        ref_batches = ref_ctx.profile()["sub_batches"]
+    hog = None
+    try:
+        with _lib.Context(0) as ctx:
+            for i, im in enumerate(imgs):
+                ctx.upload_image(i, im)
+            ctx.match_pairs(small, **kw)              # the budget of this store state is cached now: 64 GiB
+            free = ctx.memory_info()["device_free"]
+            hog = torch.empty(int(free - (700 << 20)), dtype=torch.uint8, device="cuda:0")
+            torch.cuda.synchronize()
+            assert ctx.memory_info()["device_free"] < (1 << 30)
+            if form == "one_call":
+                got = ctx.match_pairs(pairs, **kw)
+            else:
+                offs, qt, d = [np.zeros(1, np.int64)], [], []
+                for ch in ctx.match_pairs_stream(pairs, **kw):
+                    offs.append(offs[-1][-1] + ch["offsets"][1:])
+                    qt.append(ch["qt"])
+                    d.append(ch["dist"])
+                got = (np.concatenate(offs), np.concatenate(qt), np.concatenate(d))
+            prof = ctx.profile()
+            assert prof["memory_shrinks"] >= 1 and prof["sub_batches"] > ref_batches, prof
+            assert same_result(got, ref)
+            # the context remembers what worked: the next call on this store state starts from the smaller share
+            again = ctx.match_pairs(pairs, **kw)
+            assert same_result(again, ref) and ctx.profile()["memory_shrinks"] == 0
+            # a job that cannot fit at all still fails with a status, not a crash: one pair needs more than is left
+            del hog
+            hog = None
+            torch.cuda.empty_cache()
+            free = ctx.memory_info()["device_free"]
+            hog = torch.empty(int(free - (24 << 20)), dtype=torch.uint8, device="cuda:0")
+            torch.cuda.synchronize()
+            ctx.set_limits()                          # (forget the remembered share: the budget is derived afresh)
+            with pytest.raises(_lib.MsfmError) as err:
+                ctx.match_pairs(pairs, **kw)
+            assert err.value.code == _lib.E_DEVICE and "memory" in str(err.value).lower()
+            del hog
+            hog = None
+            torch.cuda.empty_cache()
+            ok = ctx.match_pairs(small, **kw)         # and the context is usable afterwards
+            assert len(ok[0]) == len(small) + 1
+    finally:
+        del hog
+        torch.cuda.empty_cache()
