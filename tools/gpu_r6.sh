@@ -76,6 +76,10 @@ PY
     run fuzz_default python tools/fuzz_routes.py 964 1500; tail -1 $OUT/fuzz_default.txt
     run fuzz_jobs python tools/fuzz_jobs.py 965 600; tail -1 $OUT/fuzz_jobs.txt
     ;;
+oom)   # the out-of-memory shrink (tests/test_gpu_jobs.py) + the job-level suite around it, then four contexts on the one GPU at config-4 scale
+    TMO=900 MSFM_DEBUG_TIMING= run pytest_oom python -m pytest -m gpu -x -q tests/test_gpu_jobs.py tests/test_gpu_stream.py tests/test_gpu_configs.py; tail -6 $OUT/pytest_oom.txt
+    TMO=900 run cli_config4_4ctx python tools/cli_e2e_bench.py --config4 --tables u8 --modes off --orders pair_id --devices 0,0,0,0 --json $OUT/cli_config4_4ctx.json; cat $OUT/cli_config4_4ctx.txt; tail -3 $OUT/cli_config4_4ctx.err
+    ;;
 fourth)
     bash tools/gpu_r6.sh suite
     bash tools/gpu_r6.sh multi
