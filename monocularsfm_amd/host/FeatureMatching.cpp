@@ -305,7 +305,12 @@ void FeatureMatcher::MatchImagePairGroups(const std::vector<std::vector<std::pai
         size_t total = 0;
         for (const auto& g : groups) total += g.size();
         // a large job reads the index of the matches table once instead of asking for every pair (2.3 us each, one by one)
-        const bool sweep = total >= 2048;
+        // (MSFM_EXIST_SWEEP_MIN: the pair count from which the sweep is used -- the tests set 0 / a huge value to run both ways)
+        static const size_t sweep_min = [] {
+            const char* e = std::getenv("MSFM_EXIST_SWEEP_MIN");
+            return e ? (size_t)std::atoll(e) : (size_t)2048;
+        }();
+        const bool sweep = total >= sweep_min;
         std::vector<image_pair_t> have;
         if (sweep) have = database_->ReadAllMatchPairIds();
         std::set<std::pair<image_t, image_t>> scheduled;
@@ -353,7 +358,8 @@ void FeatureMatcher::MatchImagePairGroups(const std::vector<std::vector<std::pai
     // the reference's order inserts into a different one of ~N key bands every time, each insert lands between two full leaves
     // (a 3-KB row fills a 4-KB page) and SQLite rebalances three sibling pages for it -- 16 us per row on the GPU box, 3.4 x the cost
     // of the same rows in key order, which SQLite appends (tools/emit_bench.cpp, profiles/r06_emission_study.txt).  In key order the
-    // stdout lines are still the reference's, in the reference's order, but printed when the rows are in; transactions hold 100 rows.
+    // stdout lines are still the reference's, in the reference's order, a group's as soon as its rows and those of every group before
+    // it are in; transactions hold 100 rows.
     static const bool key_order = [] {
         const char* e = std::getenv("MSFM_EMIT_ORDER");
         return e && std::string(e) == "pair_id";
@@ -530,33 +536,10 @@ void FeatureMatcher::MatchImagePairGroups(const std::vector<std::vector<std::pai
         ++r.consumed;
         return Fetched{r.cur->rows.data() + 2 * r.cur->offsets[li], (size_t)(r.cur->offsets[li + 1] - r.cur->offsets[li]), r.cur->seconds_per_pair};
     };
+    // one group's stdout lines (and, in the reference's order, its rows): "Existing, Continue!" or the pair's three lines
     std::vector<uint32_t> count_of;    // key order: what the stdout lines need, by todo index
     std::vector<float> seconds_of;
-    if (key_order) {
-        // rows first, in ascending pair_id, 100 per transaction
-        count_of.resize(P);
-        seconds_of.resize(P);
-        for (size_t w0 = 0; w0 < P; w0 += 100) {
-            const size_t w1 = std::min(P, w0 + 100);
-            database_->BeginTransaction();
-            if (trace_txn) std::fprintf(stderr, "[msfm txn] %zu\n", w1 - w0);
-            for (size_t w = w0; w < w1; ++w) {
-                const size_t p = (size_t)work_order[w];
-                const Fetched f = fetch(w);
-                database_->WriteMatchesStored(todo[2 * p], todo[2 * p + 1], f.rows, f.m);
-                count_of[p] = (uint32_t)f.m;
-                seconds_of[p] = (float)f.seconds;
-                matches_written += (long long)f.m;
-            }
-            database_->EndTransaction();
-        }
-    }
-    // the reference's order: one transaction per group (key order: the lines only -- the rows are in)
-    for (size_t g = 0; g < groups.size(); ++g) {
-        if (!key_order) {
-            database_->BeginTransaction();
-            if (trace_txn) std::fprintf(stderr, "[msfm txn] %zu\n", groups[g].size());
-        }
+    auto emit_group = [&](size_t g, bool write_rows) {
         out.clear();
         for (size_t k = 0; k < groups[g].size(); ++k) {
             const image_t image_id1 = groups[g][k].first, image_id2 = groups[g][k].second;
@@ -568,15 +551,15 @@ void FeatureMatcher::MatchImagePairGroups(const std::vector<std::vector<std::pai
             }
             size_t m;
             double seconds;
-            if (key_order) {
-                m = count_of[(size_t)p];
-                seconds = seconds_of[(size_t)p];
-            } else {
+            if (write_rows) {
                 const Fetched f = fetch((size_t)p);
                 database_->WriteMatchesStored(image_id1, image_id2, f.rows, f.m);
                 m = f.m;
                 seconds = f.seconds;
                 matches_written += (long long)m;
+            } else {
+                m = count_of[(size_t)p];
+                seconds = seconds_of[(size_t)p];
             }
             std::snprintf(buf, sizeof(buf), "Compute Matches %d - %d ... \n\t matches num : %zu\n\t ", image_id1, image_id2, m);
             out += buf;
@@ -584,7 +567,50 @@ void FeatureMatcher::MatchImagePairGroups(const std::vector<std::vector<std::pai
             out += "\n";
         }
         std::cout << out << std::flush;
-        if (!key_order) database_->EndTransaction();
+    };
+    if (key_order) {
+        // rows in ascending pair_id, 100 per transaction; a group's lines are printed -- in the reference's order -- as soon as its rows and
+        // those of every group before it are in (brute-force enumeration: row i of the images after key band i - 1)
+        count_of.resize(P);
+        seconds_of.resize(P);
+        std::vector<uint32_t> remaining(groups.size(), 0);
+        std::vector<uint32_t> group_of(P, 0);
+        for (size_t g = 0; g < groups.size(); ++g)
+            for (size_t k = 0; k < groups[g].size(); ++k)
+                if (slot[g][k] >= 0) {
+                    remaining[g] += 1;
+                    group_of[(size_t)slot[g][k]] = (uint32_t)g;
+                }
+        size_t cursor = 0;
+        auto print_ready = [&]() {
+            while (cursor < groups.size() && remaining[cursor] == 0) emit_group(cursor++, false);
+        };
+        print_ready();
+        for (size_t w0 = 0; w0 < P; w0 += 100) {
+            const size_t w1 = std::min(P, w0 + 100);
+            database_->BeginTransaction();
+            if (trace_txn) std::fprintf(stderr, "[msfm txn] %zu\n", w1 - w0);
+            for (size_t w = w0; w < w1; ++w) {
+                const size_t p = (size_t)work_order[w];
+                const Fetched f = fetch(w);
+                database_->WriteMatchesStored(todo[2 * p], todo[2 * p + 1], f.rows, f.m);
+                count_of[p] = (uint32_t)f.m;
+                seconds_of[p] = (float)f.seconds;
+                matches_written += (long long)f.m;
+                remaining[group_of[p]] -= 1;
+            }
+            database_->EndTransaction();
+            print_ready();
+        }
+        print_ready();
+    } else {
+        // the reference's order: one transaction per group
+        for (size_t g = 0; g < groups.size(); ++g) {
+            database_->BeginTransaction();
+            if (trace_txn) std::fprintf(stderr, "[msfm txn] %zu\n", groups[g].size());
+            emit_group(g, true);
+            database_->EndTransaction();
+        }
     }
     for (DeviceRun& r : runs)
         if (r.thread.joinable()) r.thread.join();

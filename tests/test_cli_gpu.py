@@ -275,22 +275,25 @@ def test_images_without_descriptors_and_tiny_images(exe, tmp_path, mt):
                 assert r == 0, (pid, r)
 
 
-def test_partial_resume_recomputes_only_missing_rows(exe, dataset, tmp_path):
+@pytest.mark.parametrize("exist_check", ["per_pair", "index_sweep"])
+def test_partial_resume_recomputes_only_missing_rows(exe, dataset, tmp_path, exist_check):
     """Rows are the checkpoint (FeatureMatching.cpp:23-27): after deleting a few rows a rerun recomputes exactly
-    those, in place, with the same bytes, and reports every other pair as existing."""
+    those, in place, with the same bytes, and reports every other pair as existing.  Both forms of the exist-check: one
+    ExistMatches SELECT per pair (the reference's, used for small jobs) and the one sweep over the table's keys a large job takes."""
     descs, kps = dataset
+    sweep_env = {"MSFM_EXIST_SWEEP_MIN": "0" if exist_check == "index_sweep" else "1000000000"}
     db_path = str(tmp_path / "resume.db")
     database.write_synthetic_database(db_path, descs, kps)
     cfg = tmp_path / "resume.yaml"
     cfg.write_text(YAML.format(db=db_path, mt=1))
-    run_cli(exe, cfg, {})
+    run_cli(exe, cfg, sweep_env)
     db = database.Database(db_path)
     before = db.db.execute("SELECT pair_id, rows, cols, data FROM matches ORDER BY pair_id").fetchall()
     victims = [before[1][0], before[len(before) // 2][0], before[-1][0]]
     db.db.execute("DELETE FROM matches WHERE pair_id IN (%s)" % ",".join(str(v) for v in victims))
     db.db.commit()
     db.Close()
-    out = run_cli(exe, cfg, {})
+    out = run_cli(exe, cfg, sweep_env)
     db = database.Database(db_path)
     after = db.db.execute("SELECT pair_id, rows, cols, data FROM matches ORDER BY pair_id").fetchall()
     db.Close()
