@@ -80,6 +80,11 @@ oom)   # the out-of-memory shrink (tests/test_gpu_jobs.py) + the job-level suite
     TMO=900 MSFM_DEBUG_TIMING= run pytest_oom python -m pytest -m gpu -x -q tests/test_gpu_jobs.py tests/test_gpu_stream.py tests/test_gpu_configs.py; tail -6 $OUT/pytest_oom.txt
     TMO=900 run cli_config4_4ctx python tools/cli_e2e_bench.py --config4 --tables u8 --modes off --orders pair_id --devices 0,0,0,0 --json $OUT/cli_config4_4ctx.json; cat $OUT/cli_config4_4ctx.txt; tail -3 $OUT/cli_config4_4ctx.err
     ;;
+check)   # the tree once more: the GPU suite, smoke(), the executable at config-4 scale in both row orders
+    TMO=1800 run pytest_gpu python -m pytest tests -m gpu -q; tail -4 $OUT/pytest_gpu.txt
+    run smoke python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')"; tail -2 $OUT/smoke.txt
+    TMO=900 run cli_config4 python tools/cli_e2e_bench.py --config4 --tables u8 --modes off --json $OUT/cli_config4.json; cat $OUT/cli_config4.txt; tail -3 $OUT/cli_config4.err
+    ;;
 fourth)
     bash tools/gpu_r6.sh suite
     bash tools/gpu_r6.sh multi
