@@ -85,6 +85,13 @@ check)   # the tree once more: the GPU suite, smoke(), the executable at config-
     run smoke python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')"; tail -2 $OUT/smoke.txt
     TMO=900 run cli_config4 python tools/cli_e2e_bench.py --config4 --tables u8 --modes off --json $OUT/cli_config4.json; cat $OUT/cli_config4.txt; tail -3 $OUT/cli_config4.err
     ;;
+fuzz)   # long seeded fuzz on the final build: routes, whole jobs (incl. the streaming form and store rebuilds), verification
+    TMO=900 run fuzz_jobs python tools/fuzz_jobs.py 971 2500; tail -1 $OUT/fuzz_jobs.txt
+    TMO=600 MSFM_Q8=2 run fuzz_q8 python tools/fuzz_routes.py 972 3000; tail -1 $OUT/fuzz_q8.txt
+    TMO=600 run fuzz_default python tools/fuzz_routes.py 973 3000; tail -1 $OUT/fuzz_default.txt
+    TMO=600 MSFM_Q8=2 MSFM_Q8_DIRECT=0 run fuzz_refine python tools/fuzz_routes.py 974 1000; tail -1 $OUT/fuzz_refine.txt
+    TMO=300 run fuzz_verify python tools/fuzz_verify.py 975 300; tail -1 $OUT/fuzz_verify.txt
+    ;;
 fourth)
     bash tools/gpu_r6.sh suite
     bash tools/gpu_r6.sh multi
