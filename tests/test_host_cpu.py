@@ -152,6 +152,40 @@ def test_fundamental_ransac_recovers_the_epipolar_inliers(host):
     assert mask[:7].all()
 
 
+def test_synthetic_scene_keypoints_have_the_geometry_the_verification_keeps(host):
+    """synth.scene_cameras / scene_keypoints (round 6: the bench's end_to_end database): rows that observe the same scene point in two
+    images are a true epipolar correspondence (+ 0.7 px noise) -- FeatureUtils::FilterMatches' twin keeps them and drops the rows that
+    observe nothing (random positions), which is what makes the write phase of the end-to-end figure a representative one."""
+    from monocularsfm_amd import synth
+    rng = np.random.default_rng(12)
+    n_points, n = 400, 900
+    ids = []
+    for _ in range(2):
+        a = np.full(n, -1, np.int64)
+        a[rng.choice(n, 300, replace=False)] = rng.choice(n_points, 300, replace=False)
+        ids.append(a)
+    cams = synth.scene_cameras(2, seed=5)
+    kps = synth.scene_keypoints(ids, cams, n_points, seed=6)
+    assert all(k.shape == (n, 4) and k.dtype == np.float32 for k in kps)
+    # the "matches": every scene point seen by both images (true), plus as many pairs of rows that observe nothing (false)
+    both = np.intersect1d(ids[0][ids[0] >= 0], ids[1][ids[1] >= 0])
+    assert len(both) >= 150
+    r0 = {int(v): i for i, v in enumerate(ids[0]) if v >= 0}
+    r1 = {int(v): i for i, v in enumerate(ids[1]) if v >= 0}
+    true_q, true_t = [r0[int(v)] for v in both], [r1[int(v)] for v in both]
+    free0, free1 = np.nonzero(ids[0] < 0)[0][:len(both)], np.nonzero(ids[1] < 0)[0][:len(both)]
+    p1 = np.r_[kps[0][true_q, :2], kps[0][free0, :2]].astype(np.float32)
+    p2 = np.r_[kps[1][true_t, :2], kps[1][free1, :2]].astype(np.float32)
+    truth = np.r_[np.ones(len(both), bool), np.zeros(len(both), bool)]
+    mask = np.zeros(len(p1), np.uint8)
+    fp = C.POINTER(C.c_float)
+    p1, p2 = np.ascontiguousarray(p1), np.ascontiguousarray(p2)
+    assert host.host_fundamental_ransac(p1.ctypes.data_as(fp), p2.ctypes.data_as(fp), len(p1), mask.ctypes.data_as(C.POINTER(C.c_ubyte))) == len(p1)
+    got = mask.astype(bool)
+    assert (got & truth).sum() >= 0.9 * truth.sum(), (got & truth).sum()
+    assert (got & ~truth).sum() <= 0.15 * (~truth).sum()
+
+
 def test_fundamental_ransac_runs_its_iterations_on_unrelated_points(host):
     """A consensus of ~8 of 358 makes 1 - w^8 round to 1.0: the adaptive bound must then stay at the cap instead
     of collapsing (log(1) = 0 in the denominator).  With all 1000 hypotheses tried, some 8-point model always
