@@ -480,3 +480,53 @@ def test_key_order_emission_writes_the_same_rows_and_prints_the_same_lines(exe, 
     da.Close()
     dbb.Close()
     assert ra2 == rb2 == ra
+
+
+@pytest.mark.parametrize("order", ["reference", "pair_id"])
+def test_killed_run_leaves_whole_rows_and_the_rerun_completes_the_table(exe, tmp_path, order):
+    """Rows are the checkpoint of an interrupted run (FeatureMatching.cpp:23-27, 63-72).  The emitter writes a group per transaction
+    while the device threads are ahead of it: a process killed (SIGKILL) in the middle leaves a database that opens, holds only whole
+    rows -- each byte-identical to the uninterrupted run's -- and the rerun skips those and writes the rest: the same table in the end."""
+    import signal
+    n_img = 48
+    clean, cut = str(tmp_path / "clean.db"), str(tmp_path / "cut.db")
+    synth.south_building_database(clean, n_img, 500, seed=77)
+    shutil.copy(clean, cut)
+    for ext in ("-wal", "-shm"):
+        if os.path.exists(clean + ext):
+            shutil.copy(clean + ext, cut + ext)
+    env = dict(os.environ, MSFM_GEOMETRIC_VERIFICATION="0")
+    if order == "pair_id":
+        env["MSFM_EMIT_ORDER"] = "pair_id"
+    cfg_clean, cfg_cut = tmp_path / "clean.yaml", tmp_path / "cut.yaml"
+    cfg_clean.write_text(YAML.format(db=clean, mt=1))
+    cfg_cut.write_text(YAML.format(db=cut, mt=1))
+    r = subprocess.run([exe, str(cfg_clean)], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = database.Database(clean)
+    want = dict((row[0], row[1:]) for row in d.db.execute("SELECT pair_id, rows, cols, data FROM matches"))
+    d.Close()
+    assert len(want) > 600
+    # the interrupted run: killed once a third of the pairs have been announced on stdout
+    p = subprocess.Popen([exe, str(cfg_cut)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, env=env)
+    seen = 0
+    for line in p.stdout:
+        if line.startswith("Compute Matches"):
+            seen += 1
+            if seen >= len(want) // 3:
+                break
+    p.send_signal(signal.SIGKILL)
+    p.stdout.close()
+    p.wait()
+    d = database.Database(cut)
+    part = dict((row[0], row[1:]) for row in d.db.execute("SELECT pair_id, rows, cols, data FROM matches"))
+    d.Close()
+    assert 0 < len(part) < len(want), (len(part), len(want))
+    for k, v in part.items():
+        assert want[k] == v
+    out = run_cli(exe, cfg_cut, {"MSFM_GEOMETRIC_VERIFICATION": "0", **({"MSFM_EMIT_ORDER": "pair_id"} if order == "pair_id" else {})})
+    assert out.count("Existing, Continue!") == len(part)
+    d = database.Database(cut)
+    full = dict((row[0], row[1:]) for row in d.db.execute("SELECT pair_id, rows, cols, data FROM matches"))
+    d.Close()
+    assert full == want
