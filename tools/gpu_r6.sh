@@ -92,6 +92,21 @@ fuzz)   # long seeded fuzz on the final build: routes, whole jobs (incl. the str
     TMO=600 MSFM_Q8=2 MSFM_Q8_DIRECT=0 run fuzz_refine python tools/fuzz_routes.py 974 1000; tail -1 $OUT/fuzz_refine.txt
     TMO=300 run fuzz_verify python tools/fuzz_verify.py 975 300; tail -1 $OUT/fuzz_verify.txt
     ;;
+small)   # the small-job regime: what one rank of an N = 8 run of config 2 sees (1/8 of the pairs: 46 images -> 1035 pairs)
+    for n in 46 64 91; do
+      run bench_$n python bench.py --images $n --steps 30 --warmup 5 --no-cpu-baseline --no-e2e --u8-images 0 --sustained-steps 0 --no-solo
+      python - <<PY
+import json
+d=json.loads([l for l in open("gpurun_out/r6/small/bench_$n.txt") if l.startswith("{")][-1]); r=d["roofline"]
+print("images $n: pairs", d["config"]["image_pairs"], "ms_per_step %.3f" % d["ms_per_step"], "sweep1 ms/step %.3f" % r["sweep1_ms_per_step"], "step/sweep1 %.2f" % r["step_over_sweep1"], "device_ms %.3f" % d["device_ms_per_step_rank0"], "sub-batches", d["sub_batches_per_step"])
+PY
+    done
+    BENCH="python $ROOT/bench.py --images 46 --steps 3 --warmup 2 --no-cpu-baseline --no-e2e --sustained-steps 0 --u8-images 0 --no-solo"
+    cd /tmp; timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/prof_stats -- $BENCH > $OUT/prof_stats.log 2>&1; echo "stats rc=$?"; cd $ROOT
+    DB=$(ls -t $(find $OUT/prof_stats -name '*.db') | head -1)
+    python tools/step_timeline.py "$DB" 2 > $OUT/step_timeline_46.txt 2>&1; tail -60 $OUT/step_timeline_46.txt | cut -c1-150
+    find $OUT -type f -size +8M -delete
+    ;;
 fourth)
     bash tools/gpu_r6.sh suite
     bash tools/gpu_r6.sh multi
