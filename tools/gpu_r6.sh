@@ -107,6 +107,15 @@ PY
     python tools/step_timeline.py "$DB" 2 > $OUT/step_timeline_46.txt 2>&1; tail -60 $OUT/step_timeline_46.txt | cut -c1-150
     find $OUT -type f -size +8M -delete
     ;;
+prefetch3)   # EXPERIMENT: sweep 1 with three k-steps of B fragments in registers (119 VGPRs instead of 111); tools/_ab/libmsfm_prefetch3.so =
+             # hipcc ... -DMSFM_I8_PREFETCH3 (built in the container, travels with the snapshot)
+    V=tools/_ab/libmsfm_prefetch3.so
+    run ab_f32_p1 python tools/ab.py --p1 --rounds 14 tree pre3=$V; cat $OUT/ab_f32_p1.txt
+    run ab_f32 python tools/ab.py --rounds 14 tree pre3=$V; cat $OUT/ab_f32.txt
+    run ab_u8_p1 python tools/ab.py --u8 --images 64 --p1 --rounds 12 tree pre3=$V; cat $OUT/ab_u8_p1.txt
+    run ab_u8 python tools/ab.py --u8 --images 64 --rounds 12 tree pre3=$V; cat $OUT/ab_u8.txt
+    run ab_u8_big python tools/ab.py --u8 --images 160 --rounds 6 tree pre3=$V; cat $OUT/ab_u8_big.txt
+    ;;
 fourth)
     bash tools/gpu_r6.sh suite
     bash tools/gpu_r6.sh multi
