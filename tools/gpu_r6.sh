@@ -116,6 +116,18 @@ prefetch3)   # EXPERIMENT: sweep 1 with three k-steps of B fragments in register
     run ab_u8 python tools/ab.py --u8 --images 64 --rounds 12 tree pre3=$V; cat $OUT/ab_u8.txt
     run ab_u8_big python tools/ab.py --u8 --images 160 --rounds 6 tree pre3=$V; cat $OUT/ab_u8_big.txt
     ;;
+sq)   # SQ counters of the sweeps for the bench command (two --pmc passes of their own: never together with a trace)
+    BENCH="python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-e2e --sustained-steps 0 --u8-images 0 --no-solo"
+    cd /tmp
+    rocprofv3 --list-avail 2>/dev/null | grep -o "SQ_[A-Z0-9_]*" | sort -u | grep -E "MFMA|LDS|BARRIER|WAIT|BUSY|VALU|ACTIVE_INST|WAVE_CYCLES|IFETCH|INST_LEVEL" | tr '\n' ' ' > $OUT/sq_counters_available.txt; wc -w $OUT/sq_counters_available.txt
+    timeout 400 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU --output-format csv -d $OUT/pmc_sq -- $BENCH > $OUT/pmc_sq.log 2>&1; echo "sq rc=$?"
+    timeout 400 rocprofv3 --pmc SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_MFMA SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_VMEM --output-format csv -d $OUT/pmc_sq2 -- $BENCH > $OUT/pmc_sq2.log 2>&1; echo "sq2 rc=$?"
+    cd $ROOT
+    python tools/pmc_summary.py $OUT/pmc_sq.json "sweep_kernel<3>,sweep_i8_kernel<1>" $OUT/pmc_sq | tail -45
+    python tools/pmc_summary.py $OUT/pmc_sq2.json "sweep_kernel<3>,sweep_i8_kernel<1>" $OUT/pmc_sq2 | tail -45
+    tail -3 $OUT/pmc_sq2.log
+    find $OUT -type f -size +8M -delete
+    ;;
 fourth)
     bash tools/gpu_r6.sh suite
     bash tools/gpu_r6.sh multi
